@@ -1,0 +1,319 @@
+"""ctypes binding of the CPU oracle (oracle/libsgz_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package `signalizer_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsgz_oracle.so")
+
+NUM_SPEC_COLOURS = 5
+NUM_GRAPHS = 2
+
+CH_LEFT, CH_RIGHT, CH_MERGE, CH_SIDE, CH_PHASE, CH_SEPARATE, CH_MIDSIDE, CH_COMPLEX = range(8)
+INTERP_NONE, INTERP_LINEAR, INTERP_LANCZOS = range(3)
+VIEW_LINEAR, VIEW_LOG = range(2)
+(WIN_RECT, WIN_HANN, WIN_HAMMING, WIN_FLATTOP, WIN_BLACKMAN, WIN_EXACT_BLACKMAN, WIN_NUTTALL,
+ WIN_BLACKMAN_NUTTALL, WIN_BLACKMAN_HARRIS, WIN_TRIANGULAR, WIN_WELCH, WIN_GAUSSIAN, WIN_KAISER) = range(13)
+WIN_SYMMETRIC, WIN_PERIODIC = range(2)
+
+
+class SpectrumParams(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_float),
+        ("window_size", C.c_uint32),
+        ("hop", C.c_uint32),
+        ("axis_points", C.c_uint32),
+        ("channel_mode", C.c_uint32),
+        ("bin_interp", C.c_uint32),
+        ("view_scaling", C.c_uint32),
+        ("window_type", C.c_uint32),
+        ("window_symmetry", C.c_uint32),
+        ("num_pairs", C.c_uint32),
+        ("window_alpha", C.c_double),
+        ("window_beta", C.c_double),
+        ("view_left", C.c_double),
+        ("view_right", C.c_double),
+        ("min_log_freq", C.c_double),
+        ("low_db", C.c_double),
+        ("high_db", C.c_double),
+        ("clip_db", C.c_double),
+        ("slope_a", C.c_double),
+        ("slope_b", C.c_double),
+        ("pole", C.c_float * NUM_GRAPHS),
+        ("colours", (C.c_uint8 * 3) * (NUM_SPEC_COLOURS + 1)),
+        ("_pad", C.c_uint8 * 2),
+        ("ratios", C.c_double * NUM_SPEC_COLOURS),
+    ]
+
+
+class ZeroCrossingState(C.Structure):
+    _fields_ = [("state", C.c_double), ("threshold", C.c_double), ("steady_clock", C.c_uint64),
+                ("cross_origin", C.c_uint64), ("count", C.c_uint64), ("armed", C.c_int)]
+
+
+class ScopeView(C.Structure):
+    _fields_ = [("window_size", C.c_double), ("left", C.c_double), ("right", C.c_double),
+                ("rendering_scale", C.c_double), ("width", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class VectorFilters(C.Structure):
+    _fields_ = [("env", C.c_float * 2), ("balance", (C.c_float * 2) * 2), ("phase", C.c_float * 2)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
+    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "sgz_oracle.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsgz_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        vp = C.c_void_p
+        L.sgzo_window.restype = C.c_double
+        L.sgzo_window.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_uint32, vp]
+        L.sgzo_transform_size.restype = C.c_uint32
+        L.sgzo_transform_size.argtypes = [C.c_uint32]
+        L.sgzo_fft_forward.argtypes = [vp, C.c_uint32]
+        L.sgzo_fft_forward_f64.argtypes = [vp, C.c_uint32]
+        L.sgzo_separate_transforms_ipl.argtypes = [vp, C.c_uint32]
+        L.sgzo_lanczos_kernel.restype = C.c_double
+        L.sgzo_lanczos_kernel.argtypes = [C.c_double, C.c_int]
+        L.sgzo_lanczos_filter_f64.restype = C.c_double
+        L.sgzo_lanczos_filter_f64.argtypes = [vp, C.c_size_t, C.c_double, C.c_int]
+        L.sgzo_remap_frequencies.argtypes = [C.POINTER(SpectrumParams), vp]
+        L.sgzo_slope_map.argtypes = [C.POINTER(SpectrumParams), vp, vp]
+        L.sgzo_colour_ratios.argtypes = [vp, vp]
+        L.sgzo_rotate_hue_rgb8.argtypes = [vp, C.c_float, vp]
+        L.sgzo_colour_table.argtypes = [C.POINTER(SpectrumParams), C.c_uint32, vp]
+        L.sgzo_prepare_transform.argtypes = [C.c_uint32, vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+        L.sgzo_map_to_linear_space.restype = C.c_int
+        L.sgzo_map_to_linear_space.argtypes = [C.POINTER(SpectrumParams), vp, C.c_double, vp, C.c_uint32, vp]
+        L.sgzo_map_and_transform_filters.argtypes = [C.POINTER(SpectrumParams), vp, vp, vp, vp]
+        L.sgzo_blend_column.argtypes = [C.POINTER(SpectrumParams), vp, vp, C.c_uint32, vp]
+        L.sgzo_spectrogram.restype = C.c_long
+        L.sgzo_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
+        L.sgzo_spectrogram_range.restype = C.c_long
+        L.sgzo_spectrogram_range.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, C.c_long, C.c_long, vp]
+        L.sgzo_num_frames.restype = C.c_long
+        L.sgzo_num_frames.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32]
+        L.sgzo_zero_crossing_process.restype = C.c_size_t
+        L.sgzo_zero_crossing_process.argtypes = [C.POINTER(ZeroCrossingState), C.c_uint32, vp, vp, C.c_size_t, vp, C.c_size_t]
+        L.sgzo_scope_lanczos.restype = C.c_size_t
+        L.sgzo_scope_lanczos.argtypes = [C.POINTER(ScopeView), vp, C.c_size_t, vp, vp, C.c_size_t]
+        L.sgzo_scope_num_points.restype = C.c_size_t
+        L.sgzo_scope_num_points.argtypes = [C.POINTER(ScopeView)]
+        L.sgzo_peak_filter.restype = C.c_double
+        L.sgzo_peak_filter.argtypes = [vp, C.c_uint32, C.c_size_t, C.c_uint32, C.c_double, vp]
+        L.sgzo_vector_polar.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+        L.sgzo_vector_audio_processing.argtypes = [C.POINTER(VectorFilters), vp, vp, C.c_size_t, C.c_uint32,
+                                                   C.c_float, C.c_float, C.c_float, C.c_int, vp]
+        _lib = L
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params_from_dict(d: dict) -> SpectrumParams:
+    """Fill a SpectrumParams from the plain dict produced by signalizer_amd.config.spectrum_config()."""
+    p = SpectrumParams()
+    for k, v in d.items():
+        if k == "pole":
+            for i in range(NUM_GRAPHS):
+                p.pole[i] = v[i]
+        elif k == "colours":
+            for i in range(NUM_SPEC_COLOURS + 1):
+                for c in range(3):
+                    p.colours[i][c] = int(v[i][c])
+        elif k == "ratios":
+            for i in range(NUM_SPEC_COLOURS):
+                p.ratios[i] = float(v[i])
+        else:
+            setattr(p, k, v)
+    return p
+
+
+# ----------------------------------------------------------------------------- convenience wrappers
+def window(type_: int, symmetry: int, W: int, alpha: float = 0.0, beta: float = 0.0):
+    out = np.zeros(W, np.float32)
+    scale = lib().sgzo_window(type_, symmetry, alpha, beta, W, _ptr(out))
+    return out, scale
+
+
+def fft32(x: np.ndarray) -> np.ndarray:
+    buf = np.ascontiguousarray(x, dtype=np.complex64).copy()
+    lib().sgzo_fft_forward(_ptr(buf), buf.size)
+    return buf
+
+
+def fft64(x: np.ndarray) -> np.ndarray:
+    buf = np.ascontiguousarray(x, dtype=np.complex128).copy()
+    lib().sgzo_fft_forward_f64(_ptr(buf), buf.size)
+    return buf
+
+
+def remap_frequencies(p: SpectrumParams) -> np.ndarray:
+    out = np.zeros(p.axis_points, np.float32)
+    lib().sgzo_remap_frequencies(C.byref(p), _ptr(out))
+    return out
+
+
+def slope_map(p: SpectrumParams, mapped: np.ndarray) -> np.ndarray:
+    out = np.zeros(p.axis_points, np.float32)
+    lib().sgzo_slope_map(C.byref(p), _ptr(mapped), _ptr(out))
+    return out
+
+
+def colour_ratios(ratios) -> np.ndarray:
+    r = np.asarray(ratios, np.float64)
+    out = np.zeros(NUM_SPEC_COLOURS + 1, np.float32)
+    lib().sgzo_colour_ratios(_ptr(r), _ptr(out))
+    return out
+
+
+def colour_table(p: SpectrumParams, pair: int) -> np.ndarray:
+    out = np.zeros((NUM_SPEC_COLOURS + 1, 3), np.float32)
+    lib().sgzo_colour_table(C.byref(p), pair, _ptr(out))
+    return out
+
+
+def rotate_hue(rgb, amount: float) -> np.ndarray:
+    a = np.asarray(rgb, np.uint8)
+    out = np.zeros(3, np.uint8)
+    lib().sgzo_rotate_hue_rgb8(_ptr(a), C.c_float(amount), _ptr(out))
+    return out
+
+
+def frame_bins(p: SpectrumParams, L: np.ndarray, R: np.ndarray):
+    """window x frame -> FFT -> (split, |.|): returns (csf_after_map [N+1] complex64, csp [2P] complex64)."""
+    W = p.window_size
+    N = lib().sgzo_transform_size(W)
+    win = np.zeros(N, np.float32)
+    scale = lib().sgzo_window(p.window_type, p.window_symmetry, p.window_alpha, p.window_beta, W, _ptr(win))
+    csf = np.zeros(N + 1, np.complex64)
+    Lc = np.ascontiguousarray(L[:W], np.float32)
+    Rc = np.ascontiguousarray(R[:W], np.float32)
+    lib().sgzo_prepare_transform(p.channel_mode, _ptr(Lc), _ptr(Rc), _ptr(win), W, N, _ptr(csf))
+    lib().sgzo_fft_forward(_ptr(csf), N)
+    raw = csf.copy()
+    mapped = remap_frequencies(p)
+    csp = np.zeros(2 * p.axis_points, np.complex64)
+    lib().sgzo_map_to_linear_space(C.byref(p), _ptr(mapped), scale, _ptr(csf), N, _ptr(csp))
+    return raw, csf, csp
+
+
+def map_to_linear_space(p: SpectrumParams, csf_raw: np.ndarray, scale: float):
+    N = csf_raw.size - 1
+    csf = np.ascontiguousarray(csf_raw, np.complex64).copy()
+    mapped = remap_frequencies(p)
+    csp = np.zeros(2 * p.axis_points, np.complex64)
+    rc = lib().sgzo_map_to_linear_space(C.byref(p), _ptr(mapped), scale, _ptr(csf), N, _ptr(csp))
+    return rc, csf, csp
+
+
+def filters(p: SpectrumParams, csp: np.ndarray, states: np.ndarray):
+    """states: [graphs][P] complex64 in/out. returns results [graphs][P] complex64."""
+    mapped = remap_frequencies(p)
+    slope = slope_map(p, mapped)
+    results = np.zeros((NUM_GRAPHS, p.axis_points), np.complex64)
+    cspc = np.ascontiguousarray(csp, np.complex64)
+    lib().sgzo_map_and_transform_filters(C.byref(p), _ptr(slope), _ptr(cspc), _ptr(states), _ptr(results))
+    return results
+
+
+def blend_column(p: SpectrumParams, frames: np.ndarray) -> np.ndarray:
+    """frames: [pairs][P] complex64 (magnitude in .real). returns RGBA8 [P][4]."""
+    fr = np.ascontiguousarray(frames, np.complex64)
+    ratios = colour_ratios([p.ratios[i] for i in range(NUM_SPEC_COLOURS)])
+    out = np.zeros((p.axis_points, 4), np.uint8)
+    lib().sgzo_blend_column(C.byref(p), _ptr(ratios), _ptr(fr), fr.shape[0], _ptr(out))
+    return out
+
+
+def spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False, want_mapped: bool = False):
+    """planar: [2*pairs][S] float32. returns dict(rgba [F][P][4], lines [F][C][G][P] c64, mapped [F][C][2P] c64)."""
+    planar = np.ascontiguousarray(planar, np.float32)
+    nch, S = planar.shape
+    assert nch == 2 * p.num_pairs
+    F = lib().sgzo_num_frames(S, p.window_size, p.hop)
+    P = p.axis_points
+    rgba = np.zeros((F, P, 4), np.uint8)
+    lines = np.zeros((F, p.num_pairs, NUM_GRAPHS, P), np.complex64) if want_lines else None
+    mapped = np.zeros((F, p.num_pairs, 2 * P), np.complex64) if want_mapped else None
+    ptrs = (C.c_void_p * nch)(*[planar[c].ctypes.data for c in range(nch)])
+    n = lib().sgzo_spectrogram(C.byref(p), ptrs, S, _ptr(rgba),
+                               _ptr(lines) if want_lines else None, _ptr(mapped) if want_mapped else None)
+    assert n == F, (n, F)
+    return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F}
+
+
+def spectrogram_range(p: SpectrumParams, planar: np.ndarray, f0: int, f1: int) -> np.ndarray:
+    planar = np.ascontiguousarray(planar, np.float32)
+    nch, S = planar.shape
+    rgba = np.zeros((f1 - f0, p.axis_points, 4), np.uint8)
+    ptrs = (C.c_void_p * nch)(*[planar[c].ctypes.data for c in range(nch)])
+    lib().sgzo_spectrogram_range(C.byref(p), ptrs, S, f0, f1, _ptr(rgba))
+    return rgba
+
+
+def zero_crossing(st: ZeroCrossingState, mode: int, a: np.ndarray, b: np.ndarray | None = None, max_out: int = 1 << 20):
+    a = np.ascontiguousarray(a, np.float32)
+    b = a if b is None else np.ascontiguousarray(b, np.float32)
+    out = np.zeros(max_out, np.uint64)
+    n = lib().sgzo_zero_crossing_process(C.byref(st), mode, _ptr(a), _ptr(b), a.size, _ptr(out), max_out)
+    return out[:min(n, max_out)].copy()
+
+
+def scope_lanczos(view: ScopeView, ring: np.ndarray):
+    ring = np.ascontiguousarray(ring, np.float32)
+    n = lib().sgzo_scope_num_points(C.byref(view))
+    x = np.zeros(n, np.float32)
+    y = np.zeros(n, np.float32)
+    m = lib().sgzo_scope_lanczos(C.byref(view), _ptr(ring), ring.size, _ptr(x), _ptr(y), n)
+    assert m == n
+    return x, y
+
+
+def peak_filter(channels: np.ndarray, coeff_pow: float, env: np.ndarray, lanes: int = 8) -> float:
+    ch = np.ascontiguousarray(channels, np.float32)
+    ptrs = (C.c_void_p * ch.shape[0])(*[ch[c].ctypes.data for c in range(ch.shape[0])])
+    return lib().sgzo_peak_filter(ptrs, ch.shape[0], ch.shape[1], lanes, coeff_pow, _ptr(env))
+
+
+def vector_polar(L: np.ndarray, R: np.ndarray) -> np.ndarray:
+    L = np.ascontiguousarray(L, np.float32)
+    R = np.ascontiguousarray(R, np.float32)
+    out = np.zeros((L.size, 3), np.float32)
+    lib().sgzo_vector_polar(_ptr(L), _ptr(R), L.size, 0, _ptr(out))
+    return out
+
+
+def vector_audio_processing(f: VectorFilters, L, R, envelope_coeff, stereo_coeff, second_speed=0.25,
+                            env_mode=1, lanes=8):
+    L = np.ascontiguousarray(L, np.float32)
+    R = np.ascontiguousarray(R, np.float32)
+    gain = C.c_float(float("nan"))
+    lib().sgzo_vector_audio_processing(C.byref(f), _ptr(L), _ptr(R), L.size, lanes, envelope_coeff,
+                                       stereo_coeff, second_speed, env_mode, C.byref(gain))
+    return gain.value

@@ -1,0 +1,221 @@
+/*
+ * scope_vector.c -- CPU restatement of the Oscilloscope and Vectorscope arithmetic on the hot path.
+ * TEST INFRASTRUCTURE (see sgz_oracle.h).  Follows:
+ *   Source/Oscilloscope/StreamPreprocessing.h:315-349   ZeroCrossingProcessor::process
+ *   Source/Oscilloscope/OscilloscopeDSP.inl:311-385     executeSamplingWindows (trigger channel mix)
+ *   Source/Oscilloscope/OscilloscopeDSP.inl:231-240     calculateTriggeringOffset (ZeroCrossing)
+ *   Source/Oscilloscope/OscilloscopeRendering.cpp:551-649,:790-891  drawWavePlot, Lanczos branch
+ *   Source/Oscilloscope/OscilloscopeDSP.inl:713-886 / Source/Vectorscope/VectorscopeRendering.cpp:826-889 runPeakFilter
+ *   Source/Vectorscope/VectorscopeRendering.cpp:500-746 drawPolarPlot
+ *   Source/Vectorscope/Vectorscope.cpp:268-377          Processor::audioProcessing
+ * cpl::simd::{atan,sincos,cos} are restated with libm (UNVERIFIED vs cpl: cpl uses SIMD polynomial
+ * approximations; parity on these outputs is a stated fp32 tolerance, never bit-exactness).
+ */
+#include "sgz_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* OscChannels, Source/Common/CommonSignalizer.h:458-493 */
+enum { OSC_LEFT = 0, OSC_RIGHT = 1, OSC_MID = 2, OSC_SIDE = 3, OSC_SEPARATE = 4, OSC_MIDSIDE = 5 };
+
+/* ZeroCrossingProcessor::process over one block of the trigger channel.
+ * a,b = the trigger pair's two channels (b unused for Left/Right/Separate: pass the chosen channel as a). */
+size_t sgzo_zero_crossing_process(sgzo_zero_crossing_state *st, uint32_t osc_mode, const float *a,
+                                  const float *b, size_t n, uint64_t *out, size_t max_out)
+{
+    size_t produced = 0;
+    for (size_t i = 0; i < n; ++i) {
+        double sample;
+        switch (osc_mode) {
+        case OSC_MID: case OSC_MIDSIDE: sample = (double)(0.5f * (a[i] + b[i])); break;   /* :371-376, MidSide -> Mid :342-352 */
+        case OSC_SIDE: sample = (double)(0.5f * (a[i] - b[i])); break;                    /* :377-382 */
+        default: sample = (double)a[i]; break;
+        }
+        if (sample > 0 && st->state < 0) {                 /* StreamPreprocessing.h:333-337 */
+            st->armed = 1;
+            st->cross_origin = st->steady_clock + st->count;
+        }
+        if (st->armed && sample > st->threshold) {         /* :339-343 */
+            st->armed = 0;
+            if (produced < max_out) out[produced] = st->cross_origin;
+            produced++;
+        }
+        st->state = sample;
+        st->count++;
+    }
+    return produced;
+}
+
+/* Scalars of drawWavePlot for TriggeringMode::ZeroCrossing (OscilloscopeRendering.cpp:551-600, :790-826) */
+typedef struct { double samplePos0, inc, samplesPerPixel, unit0, right; } scope_scalars;
+
+static scope_scalars scope_derive(const sgzo_scope_view *v)
+{
+    scope_scalars s;
+    const double horizontalDelta = v->right - v->left;
+    const double sizeMinusOne = fmax(1.0, v->window_size - 1);
+    const double pixelsPerSample = v->rendering_scale * fabs(((double)v->width - 1) / (sizeMinusOne * horizontalDelta));
+    /* calculateTriggeringOffset, OscilloscopeDSP.inl:238 */
+    const double sampleOffset = (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5;
+    s.inc = horizontalDelta / (v->rendering_scale * ((double)v->width - 1));
+    s.samplesPerPixel = 1.0 / pixelsPerSample;
+    s.unit0 = v->left;
+    s.right = v->right;
+    s.samplePos0 = sampleOffset + (-s.unit0 / s.inc * s.samplesPerPixel);   /* :802-826 */
+    return s;
+}
+
+size_t sgzo_scope_num_points(const sgzo_scope_view *v)
+{
+    const scope_scalars s = scope_derive(v);
+    size_t n = 0;
+    double unitSpacePos = s.unit0;
+    do { unitSpacePos += s.inc; ++n; } while (unitSpacePos < (s.right + s.inc));
+    return n;
+}
+
+/* Lanczos branch of drawWavePlot, OscilloscopeRendering.cpp:790-891.
+ * `ring` is the channel's front buffer in time order with ring[0] at the stream cursor (the oldest
+ * sample; CLIFOStream proxy view, begin()+cursorPosition()).  DynamicChannelEvaluator::startFrom
+ * (SampleColourEvaluators.h:75-95) positions the read pointer at cursor + offset and wraps it
+ * circularly over the view, inc() wraps likewise; offset = -floor(samplePos) - KernelSize (:829).
+ * UNVERIFIED vs cpl: CLIFOStream::createProxyView()/cursorPosition() semantics. */
+size_t sgzo_scope_lanczos(const sgzo_scope_view *v, const float *ring, size_t len,
+                          float *out_x, float *out_y, size_t max_points)
+{
+    enum { KernelSize = 10, KernelBufferSize = 21 };
+    if (len == 0) return 0;
+    const scope_scalars s = scope_derive(v);
+    double samplePos = s.samplePos0;
+    double currentSample = floor(samplePos);
+    double unitSpacePos = s.unit0;
+    long cursor = (-(long)floor(samplePos) - KernelSize) % (long)len;
+    if (cursor < 0) cursor += (long)len;
+    float kernel[KernelBufferSize];
+    for (int i = 0; i < KernelBufferSize; ++i) {
+        kernel[i] = ring[cursor];
+        if (++cursor == (long)len) cursor = 0;
+    }
+    size_t n = 0;
+    do {
+        double delta = currentSample - samplePos;
+        while (delta > 1) {
+            samplePos += 1;
+            delta -= 1;
+            memmove(kernel, kernel + 1, sizeof(float) * (KernelBufferSize - 1));     /* std::rotate + overwrite */
+            kernel[KernelBufferSize - 1] = ring[cursor];
+            if (++cursor == (long)len) cursor = 0;
+        }
+        const double y = sgzo_lanczos_filter_f64(kernel, KernelBufferSize, (double)KernelSize + delta, KernelSize);
+        if (n < max_points) { out_x[n] = (float)unitSpacePos; out_y[n] = (float)y; }
+        ++n;
+        currentSample += s.samplesPerPixel;
+        unitSpacePos += s.inc;
+    } while (unitSpacePos < (s.right + s.inc));
+    return n;
+}
+
+/* runPeakFilter: max|x| over the window with the SIMD tail dropped, then
+ * env = max(env*coeff, peak^2), gain = 1/max_c sqrt(env_c).  `coeff_pow` is the already exponentiated
+ * per-frame coefficient (VectorscopeRendering.cpp:838-842 / OscilloscopeDSP.inl:745-747). */
+double sgzo_peak_filter(const float *const *ch, uint32_t nch, size_t n, uint32_t lanes,
+                        double coeff_pow, double *env)
+{
+    const size_t stop = n - (n & (size_t)(lanes - 1));
+    double start = 0;
+    for (uint32_t c = 0; c < nch; ++c) {
+        float peak = 0.0f;
+        for (size_t i = 0; i < stop; ++i) { const float a = fabsf(ch[c][i]); if (a > peak) peak = a; }
+        const double highest = (double)peak;
+        /* filters.envelope[] is float storage (relaxed_atomic<AFloat>) */
+        const float e = (float)fmax((double)(float)env[c] * coeff_pow, highest * highest);
+        env[c] = (double)e;
+        start = fmax(start, sqrt((double)e));
+    }
+    return 1.0 / start;
+}
+
+/* drawPolarPlot, one contiguous section, lanes = 8 (AVX fp32).  xyz = (X*len, Y*len, fade-1). */
+void sgzo_vector_polar(const float *L, const float *R, size_t n, int fade, float *xyz)
+{
+    (void)fade;
+    const float cosineRotation = -0.70710678118654752440f;   /* consts::sqrt_half_two_minus */
+    const float sineRotation = 0.70710678118654752440f;      /* consts::sqrt_half_two */
+    const long V = 8;
+    const float fadePerSample = 1.0f / (float)n;
+    const float incremental = fadePerSample * (float)V;
+    float sampleFade[8], outFade[8];
+    for (int l = 0; l < V; ++l) { sampleFade[l] = fadePerSample * (float)l; outFade[l] = fadePerSample * (float)l; }
+    long i = 0;
+    const long sectionSamples = (long)n;
+    for (; i < sectionSamples - V; i += V) {
+        for (int l = 0; l < V; ++l) {
+            const float vl = L[i + l], vr = R[i + l];
+            const float length = fmaxf(fabsf(vl), fabsf(vr));
+            const float vY = vl * cosineRotation - vr * sineRotation;
+            const float vX = vl * sineRotation + vr * cosineRotation;
+            float angle = atanf(vX / vY);
+            if (vl == 0.0f && vr == 0.0f) angle = 0.0f;
+            const float sx = sinf(angle), cy = cosf(angle);
+            outFade[l] = sampleFade[l] - 1.0f;
+            xyz[(i + l) * 3 + 0] = sx * length;
+            xyz[(i + l) * 3 + 1] = cy * length;
+            xyz[(i + l) * 3 + 2] = outFade[l];
+            sampleFade[l] += incremental;
+        }
+    }
+    long remaining = 0;
+    const float currentSampleFade = outFade[V - 1];
+    for (; i < sectionSamples; ++i, ++remaining) {
+        const float vl = L[i], vr = R[i];
+        const float length = fmaxf(fabsf(vl), fabsf(vr));
+        const float vY = vl * cosineRotation - vr * sineRotation;
+        const float vX = vl * sineRotation + vr * cosineRotation;
+        float angle = atanf(vX / vY);
+        if (vl == 0.0f && vr == 0.0f) angle = 0.0f;
+        xyz[i * 3 + 0] = sinf(angle) * length;
+        xyz[i * 3 + 1] = cosf(angle) * length;
+        xyz[i * 3 + 2] = currentSampleFade - (float)remaining * fadePerSample;
+    }
+}
+
+/* VectorScope::Processor::audioProcessing, Vectorscope.cpp:268-377 (channels 0,1 only; tail dropped). */
+void sgzo_vector_audio_processing(sgzo_vector_filters *f, const float *L, const float *R, size_t n,
+                                  uint32_t lanes, float envelope_coeff, float stereo_coeff,
+                                  float second_speed, int env_mode, float *gain_out)
+{
+    float filterEnv[2] = { f->env[0], f->env[1] };
+    float balance[2][2] = { { f->balance[0][0], f->balance[0][1] }, { f->balance[1][0], f->balance[1][1] } };
+    float phase[2] = { f->phase[0], f->phase[1] };
+    const float stereoPoles[2] = { stereo_coeff, powf(stereo_coeff, second_speed) };
+    const float envelope = envelope_coeff;
+    const float mReal = -0.70710678118654752440f, mImag = 0.70710678118654752440f;
+    n -= n & (size_t)(lanes - 1);
+    for (size_t z = 0; z < n; ++z) {
+        const float l = L[z], r = R[z];
+        const float vX = l * mReal - r * mImag;
+        const float vY = r * mImag + l * mReal;
+        const float radians = atanf(vY / vX);
+        const float angle = (vX == 0.0f && vY == 0.0f) ? 0.78539816339744830962f : radians;
+        const float outPhase = cosf(angle * 2.0f);
+        const float lSquared = l * l, rSquared = r * r;
+        filterEnv[0] = lSquared + envelope * (filterEnv[0] - lSquared);
+        filterEnv[1] = rSquared + envelope * (filterEnv[1] - rSquared);
+        balance[0][0] = lSquared + stereoPoles[0] * (balance[0][0] - lSquared);
+        balance[0][1] = rSquared + stereoPoles[0] * (balance[0][1] - rSquared);
+        balance[1][0] = lSquared + stereoPoles[1] * (balance[1][0] - lSquared);
+        balance[1][1] = rSquared + stereoPoles[1] * (balance[1][1] - rSquared);
+        phase[0] = outPhase + stereoPoles[0] * (phase[0] - outPhase);
+        phase[1] = outPhase + stereoPoles[1] * (phase[1] - outPhase);
+    }
+    if (env_mode == 1) {
+        const double currentEnvelope = 1.0 / fmax(sqrt((double)filterEnv[0]), sqrt((double)filterEnv[1]));
+        f->env[0] = filterEnv[0]; f->env[1] = filterEnv[1];
+        if (isnormal(currentEnvelope) && gain_out) *gain_out = (float)currentEnvelope;
+    }
+    for (int i = 0; i < 2; ++i) {
+        f->phase[i] = phase[i];
+        for (int j = 0; j < 2; ++j) f->balance[i][j] = balance[i][j];
+    }
+}

@@ -1,0 +1,164 @@
+/*
+ * sgz_oracle.h -- CPU restatement ("oracle") of Signalizer's visualiser DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / the reported CPU baseline.  The product (signalizer_amd/, libsgz.so) never
+ * links, imports or falls back to it.
+ *
+ * PARITY UNPINNED.  The reference (jthorborg/signalizer v0.4.3) ships no tests, golden vectors
+ * or fixtures, and every arithmetic primitive on the path lives in the un-vendored submodule
+ * `cpl` (https://bitbucket.org/Mayae/cpl, pinned commit unrecoverable: /root/reference/External/cpl
+ * is empty, .gitmodules:1-3).  The reference cannot be compiled here.  This oracle therefore
+ * restates (a) the Signalizer-owned code in /root/reference/Source line by line (file:line cited
+ * at each function) and (b) the cpl primitives from their published definitions, each such
+ * primitive tagged "UNVERIFIED vs cpl".  It is pinned only against independent mathematics
+ * (numpy fp64 FFT, scipy windows, closed-form known answers; see tests/test_oracle_*.py).
+ *
+ * Build: strict IEEE fp32/fp64, no contraction (-ffp-contract=off), see oracle/Makefile.
+ */
+#ifndef SGZ_ORACLE_H
+#define SGZ_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } sgzo_cf;
+typedef struct { double re, im; } sgzo_cd;
+
+/* Source/Common/CommonSignalizer.h:495-539 (SpectrumChannels) */
+enum {
+    SGZO_CH_LEFT = 0, SGZO_CH_RIGHT = 1, SGZO_CH_MERGE = 2, SGZO_CH_SIDE = 3,
+    SGZO_CH_PHASE = 4, SGZO_CH_SEPARATE = 5, SGZO_CH_MIDSIDE = 6, SGZO_CH_COMPLEX = 7
+};
+/* SpectrumContent::BinInterpolation (Source/Spectrum/SpectrumParameters.h) */
+enum { SGZO_INTERP_NONE = 0, SGZO_INTERP_LINEAR = 1, SGZO_INTERP_LANCZOS = 2 };
+/* SpectrumContent::ViewScaling */
+enum { SGZO_VIEW_LINEAR = 0, SGZO_VIEW_LOG = 1 };
+/* window shapes (cpl::dsp::WindowTypes is in the missing submodule; this is the build's own list) */
+enum {
+    SGZO_WIN_RECT = 0, SGZO_WIN_HANN = 1, SGZO_WIN_HAMMING = 2, SGZO_WIN_FLATTOP = 3,
+    SGZO_WIN_BLACKMAN = 4, SGZO_WIN_EXACT_BLACKMAN = 5, SGZO_WIN_NUTTALL = 6,
+    SGZO_WIN_BLACKMAN_NUTTALL = 7, SGZO_WIN_BLACKMAN_HARRIS = 8, SGZO_WIN_TRIANGULAR = 9,
+    SGZO_WIN_WELCH = 10, SGZO_WIN_GAUSSIAN = 11, SGZO_WIN_KAISER = 12, SGZO_WIN_END = 13
+};
+enum { SGZO_WIN_SYMMETRIC = 0, SGZO_WIN_PERIODIC = 1 };
+
+#define SGZO_NUM_SPEC_COLOURS 5
+#define SGZO_NUM_GRAPHS 2
+
+/* POD mirror of Signalizer::TransformConstant<float> (Source/Spectrum/TransformConstant.h:48-241)
+ * plus the parameters Spectrum::handleFlagUpdates derives it from (Source/Spectrum/Spectrum.cpp:351-616). */
+typedef struct sgzo_spectrum_params {
+    float    sample_rate;        /* TransformConstant::sampleRate (T = float)                 */
+    uint32_t window_size;        /* W, TransformConstant::windowSize                          */
+    uint32_t hop;                /* sampleBufferSize (SpectrumDSP.cpp:51-54)                  */
+    uint32_t axis_points;        /* P                                                         */
+    uint32_t channel_mode;       /* SGZO_CH_*                                                 */
+    uint32_t bin_interp;         /* SGZO_INTERP_*                                             */
+    uint32_t view_scaling;       /* SGZO_VIEW_*                                               */
+    uint32_t window_type;        /* SGZO_WIN_*                                                */
+    uint32_t window_symmetry;    /* SGZO_WIN_SYMMETRIC / PERIODIC                             */
+    uint32_t num_pairs;          /* stereo pairs blended into one column                      */
+    double   window_alpha, window_beta;
+    double   view_left, view_right;   /* state.viewRect                                       */
+    double   min_log_freq;            /* state.minLogFreq (10 Hz, Spectrum.cpp:83)            */
+    double   low_db, high_db, clip_db;/* TransformConstant::lowDBs/highDBs/clipDB             */
+    double   slope_a, slope_b;        /* PowerSlopeValue::PowerFunction                       */
+    float    pole[SGZO_NUM_GRAPHS];   /* TransformConstant::filter[k].pole                    */
+    uint8_t  colours[SGZO_NUM_SPEC_COLOURS + 1][3]; /* [0]=background, 1..5 gradient, RGB8    */
+    uint8_t  _pad[2];
+    double   ratios[SGZO_NUM_SPEC_COLOURS];         /* content->specRatios normalised values  */
+} sgzo_spectrum_params;
+
+/* ---------------- primitives (cpl restatements, UNVERIFIED vs cpl) ---------------- */
+double   sgzo_window(uint32_t type, uint32_t symmetry, double alpha, double beta,
+                     uint32_t W, float *out);            /* returns windowKernelScale */
+uint32_t sgzo_transform_size(uint32_t W);               /* TransformConstant.h:84 */
+void     sgzo_fft_forward(sgzo_cf *buf, uint32_t N);    /* fp32, unnormalised, natural order */
+void     sgzo_fft_forward_f64(sgzo_cd *buf, uint32_t N);
+void     sgzo_separate_transforms_ipl(sgzo_cf *csf, uint32_t N);
+sgzo_cf  sgzo_lanczos_filter_wrap(const sgzo_cf *v, size_t size, float x, int a);
+sgzo_cf  sgzo_linear_filter(const sgzo_cf *v, size_t size, float x);
+double   sgzo_lanczos_filter_f64(const float *v, size_t size, double x, int a);
+double   sgzo_lanczos_kernel(double d, int a);
+
+/* ---------------- TransformConstant (a8) ---------------- */
+void sgzo_remap_frequencies(const sgzo_spectrum_params *p, float *mapped /*P*/);
+void sgzo_slope_map(const sgzo_spectrum_params *p, const float *mapped, float *slope /*P*/);
+void sgzo_colour_ratios(const double ratios[SGZO_NUM_SPEC_COLOURS], float out[SGZO_NUM_SPEC_COLOURS + 1]);
+void sgzo_rotate_hue_rgb8(const uint8_t rgb[3], float amount, uint8_t out[3]);
+void sgzo_colour_table(const sgzo_spectrum_params *p, uint32_t pair, float sca[SGZO_NUM_SPEC_COLOURS + 1][3]);
+
+/* ---------------- per-frame chain (a2..a7) ---------------- */
+/* a2: Source/Spectrum/TransformDSP.inl:39-231; L,R: the W newest samples in time order */
+void sgzo_prepare_transform(uint32_t mode, const float *L, const float *R, const float *window,
+                            uint32_t W, uint32_t N, sgzo_cf *buf /*N+1*/);
+/* a4: TransformDSP.inl:506-1102; csf is N+1 long and is modified in place; csp is 2*P complex */
+int  sgzo_map_to_linear_space(const sgzo_spectrum_params *p, const float *mapped, double window_scale,
+                              sgzo_cf *csf, uint32_t N, sgzo_cf *csp);
+/* a5: TransformDSP.inl:1299-1435; states/results: [graph][P] of (float,float) */
+void sgzo_map_and_transform_filters(const sgzo_spectrum_params *p, const float *slope,
+                                    const sgzo_cf *csp, sgzo_cf *states, sgzo_cf *results);
+/* a7: SpectrumDSP.cpp:111-206; frames: [pair][P] (magnitude,phase); out RGBA8 [P][4] */
+void sgzo_blend_column(const sgzo_spectrum_params *p, const float *norm_ratios,
+                       const sgzo_cf *frames, uint32_t num_pairs, uint8_t *rgba);
+
+/* ---------------- whole offline job (ideal STFT framing) ---------------- */
+/* planar: [2*num_pairs][nsamples]; rgba_out: [F][P][4]; line_out (optional): [F][pair][graph][P] complex;
+ * mapped_out (optional): [F][pair][2*P] complex (csp) ; returns number of frames F (or <0 on error). */
+long sgzo_spectrogram(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                      uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out);
+/* same but only the FFT-heavy part of frames [f0,f1) - used by bench.py's bounded cpu_baseline sample */
+long sgzo_spectrogram_range(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                            long f0, long f1, uint8_t *rgba_out);
+long sgzo_num_frames(size_t nsamples, uint32_t W, uint32_t hop);
+
+/* ---------------- Oscilloscope (a10..a12) ---------------- */
+typedef struct sgzo_zero_crossing_state {   /* Source/Oscilloscope/StreamPreprocessing.h:315-349 */
+    double   state;
+    double   threshold;
+    uint64_t steady_clock;
+    uint64_t cross_origin;
+    uint64_t count;
+    int      armed;                          /* isPeakHolding */
+} sgzo_zero_crossing_state;
+/* returns number of triggers written (at most max_out); indices are absolute sample positions */
+size_t sgzo_zero_crossing_process(sgzo_zero_crossing_state *st, uint32_t osc_mode, const float *a,
+                                  const float *b, size_t n, uint64_t *out, size_t max_out);
+
+typedef struct sgzo_scope_view {            /* the scalars drawWavePlot derives, OscilloscopeRendering.cpp:551-649 */
+    double window_size;      /* state.effectiveWindowSize (samples)       */
+    double left, right;      /* state.viewOffsets[Left/Right]             */
+    double rendering_scale;  /* oglc->getRenderingScale()                 */
+    uint32_t width;          /* getWidth() pixels                         */
+    uint32_t _pad;
+} sgzo_scope_view;
+/* ring: history with newest sample at ring[len-1]; out_xy: (x,y) float pairs; returns point count */
+size_t sgzo_scope_lanczos(const sgzo_scope_view *v, const float *ring, size_t len,
+                          float *out_x, float *out_y, size_t max_points);
+size_t sgzo_scope_num_points(const sgzo_scope_view *v);
+
+/* a12: peak envelope, OscilloscopeDSP.inl:713-886 / VectorscopeRendering.cpp:826-889 */
+double sgzo_peak_filter(const float *const *ch, uint32_t nch, size_t n, uint32_t lanes,
+                        double coeff_pow, double *env /*nch, in/out*/);
+
+/* ---------------- Vectorscope (a13, a14) ---------------- */
+void sgzo_vector_polar(const float *L, const float *R, size_t n, int fade, float *xyz /*n*3*/);
+typedef struct sgzo_vector_filters {          /* Source/Vectorscope/Vectorscope.h filters */
+    float env[2];
+    float balance[2][2];
+    float phase[2];
+} sgzo_vector_filters;
+void sgzo_vector_audio_processing(sgzo_vector_filters *f, const float *L, const float *R, size_t n,
+                                  uint32_t lanes, float envelope_coeff, float stereo_coeff,
+                                  float second_speed, int env_mode /*0 none,1 rms*/, float *gain_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
