@@ -1,0 +1,226 @@
+/*
+ * sgz.h -- C ABI of libsgz.so, the MI355X (gfx950) DSP back end for Signalizer's visualiser hot path.
+ *
+ * Drop-in boundary.  Every entry point names the reference interface it
+ * replaces (paths relative to jthorborg/signalizer v0.4.3).  Plain pointers and sizes only: no C++
+ * types, no torch types, no exceptions cross this boundary.  All functions return an sgz_status;
+ * sgz_last_error() gives the text of the last failure on the calling thread.
+ *
+ * Pointer spaces: parameters named `d_*` are DEVICE (HBM) pointers, everything else is host memory.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef SGZ_H
+#define SGZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGZ_ABI_VERSION 1
+
+typedef enum sgz_status {
+    SGZ_OK = 0,
+    SGZ_EMPTY = 1,          /* nothing to pop (frameQueue empty)                              */
+    SGZ_SKIPPED_FRAME = 2,  /* prepareTransform returned false, TransformDSP.inl:45-46          */
+    SGZ_EINVAL = -1,
+    SGZ_EHIP = -2,          /* a HIP runtime call failed / no gfx950 device                     */
+    SGZ_ENOMEM = -3,
+    SGZ_EUNSUPPORTED = -4   /* e.g. SpectrumChannels::Phase (not built yet)                     */
+} sgz_status;
+
+/* SpectrumChannels, Source/Common/CommonSignalizer.h:495-539 */
+enum { SGZ_CH_LEFT = 0, SGZ_CH_RIGHT, SGZ_CH_MERGE, SGZ_CH_SIDE, SGZ_CH_PHASE, SGZ_CH_SEPARATE,
+       SGZ_CH_MIDSIDE, SGZ_CH_COMPLEX };
+/* SpectrumContent::BinInterpolation */
+enum { SGZ_INTERP_NONE = 0, SGZ_INTERP_LINEAR, SGZ_INTERP_LANCZOS };
+/* SpectrumContent::ViewScaling */
+enum { SGZ_VIEW_LINEAR = 0, SGZ_VIEW_LOG };
+/* window shapes / symmetry (stand-in for cpl::dsp::WindowTypes, which lives in the missing cpl) */
+enum { SGZ_WIN_RECT = 0, SGZ_WIN_HANN, SGZ_WIN_HAMMING, SGZ_WIN_FLATTOP, SGZ_WIN_BLACKMAN,
+       SGZ_WIN_EXACT_BLACKMAN, SGZ_WIN_NUTTALL, SGZ_WIN_BLACKMAN_NUTTALL, SGZ_WIN_BLACKMAN_HARRIS,
+       SGZ_WIN_TRIANGULAR, SGZ_WIN_WELCH, SGZ_WIN_GAUSSIAN, SGZ_WIN_KAISER, SGZ_WIN_END };
+enum { SGZ_WIN_SYMMETRIC = 0, SGZ_WIN_PERIODIC };
+/* OscChannels, Source/Common/CommonSignalizer.h:458-493 */
+enum { SGZ_OSC_LEFT = 0, SGZ_OSC_RIGHT, SGZ_OSC_MID, SGZ_OSC_SIDE, SGZ_OSC_SEPARATE, SGZ_OSC_MIDSIDE };
+
+#define SGZ_NUM_SPEC_COLOURS 5   /* SpectrumContent::numSpectrumColours */
+#define SGZ_NUM_GRAPHS 2         /* SpectrumContent::LineGraphs::LineEnd (LineMain, LineSecond) */
+
+/* POD mirror of Signalizer::TransformConstant<float> inputs
+ * (Source/Spectrum/TransformConstant.h:190-239, filled by Spectrum::handleFlagUpdates,
+ *  Source/Spectrum/Spectrum.cpp:351-616). */
+typedef struct sgz_spectrum_config {
+    float    sample_rate;
+    uint32_t window_size;        /* W; transform size N = max(32, nextPow2(W)), TransformConstant.h:84 */
+    uint32_t hop;                /* sampleBufferSize, SpectrumDSP.cpp:51-54                           */
+    uint32_t axis_points;        /* P, Spectrum.cpp:445                                               */
+    uint32_t channel_mode;       /* SGZ_CH_*                                                          */
+    uint32_t bin_interp;         /* SGZ_INTERP_*                                                      */
+    uint32_t view_scaling;       /* SGZ_VIEW_*                                                        */
+    uint32_t window_type;        /* SGZ_WIN_*                                                         */
+    uint32_t window_symmetry;
+    uint32_t num_pairs;          /* stereo pairs (numChannels/2), SpectrumDSP.cpp:65-72               */
+    double   window_alpha, window_beta;
+    double   view_left, view_right;
+    double   min_log_freq;
+    double   low_db, high_db, clip_db;
+    double   slope_a, slope_b;
+    float    pole[SGZ_NUM_GRAPHS];                    /* constant.filter[k].pole                      */
+    uint8_t  colours[SGZ_NUM_SPEC_COLOURS + 1][3];    /* [0] background, [1..5] gradient stops (RGB8) */
+    uint8_t  _pad[2];
+    double   ratios[SGZ_NUM_SPEC_COLOURS];            /* content->specRatios (normalised values)      */
+} sgz_spectrum_config;
+
+typedef struct sgz_timing {         /* filled by the batch entry points when non-NULL */
+    double h2d_ms, kernel_ms, d2h_ms;
+    uint64_t frames;
+} sgz_timing;
+
+const char *sgz_last_error(void);
+int         sgz_abi_version(void);
+/* number of visible gfx950 devices (0 when no GPU: every compute entry point then fails with SGZ_EHIP;
+ * there is NO CPU fallback in this library). */
+int         sgz_device_count(void);
+sgz_status  sgz_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectrum "constant block": replaces TransformConstant<float> + its (re)build in
+ * Spectrum::handleFlagUpdates (Spectrum.cpp:489 setStorage, :573 remapFrequencies,
+ * :580 generateSlopeMap, :586 regenerateWindowKernel, :226-246 colour ratios).
+ * Host-side tables are built on the CPU in fp64 with the reference's expression order and uploaded
+ * once; the query functions below expose them for parity tests (they need no GPU).
+ */
+typedef struct sgz_plan sgz_plan;
+sgz_status sgz_plan_create(const sgz_spectrum_config *cfg, sgz_plan **out);   /* host tables only, no GPU needed */
+void       sgz_plan_destroy(sgz_plan *plan);
+sgz_status sgz_plan_upload(sgz_plan *plan);                                   /* device tables; needs a GPU */
+uint32_t   sgz_plan_transform_size(const sgz_plan *plan);
+double     sgz_plan_window_scale(const sgz_plan *plan);                        /* windowKernelScale */
+uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /* first max-of-bins pixel */
+sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out /*N*/);
+sgz_status sgz_plan_get_mapped_frequencies(const sgz_plan *plan, float *out /*P*/);
+sgz_status sgz_plan_get_slope_map(const sgz_plan *plan, float *out /*P*/);
+sgz_status sgz_plan_get_colour_ratios(const sgz_plan *plan, float *out /*6*/);
+sgz_status sgz_plan_get_colour_table(const sgz_plan *plan, uint32_t pair, float *out /*6*3*/);
+/* juce::Colour::withRotatedHue restated (juce_Colour.cpp:33-107,:331-336) */
+void       sgz_rotate_hue_rgb8(const uint8_t rgb[3], float amount, uint8_t out[3]);
+long       sgz_num_frames(size_t nsamples, uint32_t window_size, uint32_t hop);
+
+/* ------------------------------------------------------------------------------------------------
+ * Offline / batch spectrogram: TransformPair::audioEntryPoint (TransformDSP.inl:1165-1211) +
+ * AudioDispatcher::blendAndDispatchSpectrums (SpectrumDSP.cpp:111-206) over a whole buffer with ideal
+ * STFT framing (frame f = samples [f*hop, f*hop+W)).
+ *
+ * d_planar:   DEVICE fp32, channel c at d_planar + c*channel_stride, 2*num_pairs channels, nsamples each.
+ * d_rgba:     DEVICE RGBA8 [frames][P][4]        (the columns oglImage.updateSingleColumn receives)
+ * d_lines:    optional DEVICE float2 [frames][pairs][graphs][P] (lineGraphs[k].results, TransformPair.h:63-94)
+ * d_state:    optional DEVICE float2 [pairs][graphs][P] peak-decay state, read as carry-in and
+ *             updated to the state after the last frame (lineGraphs[k].states); NULL = start from zero.
+ * Asynchronous on `stream`; the caller synchronises.
+ */
+sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, size_t channel_stride,
+                                         size_t nsamples, uint8_t *d_rgba, float *d_lines,
+                                         float *d_state, void *stream);
+/* Host-buffer convenience wrapper (H2D, render, D2H); `planar` are the reference's planar channel
+ * pointers (AudioStream::Listener::onStreamAudio's float** buffer, Spectrum.h:370). */
+sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *const *planar,
+                                  uint32_t num_channels, size_t nsamples, uint8_t *rgba_out,
+                                  float *lines_out, sgz_timing *timing);
+
+/* Stage entry points (parity tests call these through the ABI; all DEVICE pointers, async on stream):
+ *  bins:   per (frame,pair) the post-split magnitude array csf[0..N] of mapToLinearSpace
+ *          (TransformDSP.inl:858-869 for Separate/MidSide; :553-560 mono modes) as float [N+1];
+ *  mapped: csp magnitudes after pixel mapping (TransformDSP.inl:871-985), float [frames][pairs][2][P];
+ *  decay+colour from given mapped magnitudes (TransformDSP.inl:1299-1435 + SpectrumDSP.cpp:111-206). */
+sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                          float *d_bins /*[frames][pairs][N+1]*/, void *stream);
+sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                            float *d_mapped /*[frames][pairs][2][P]*/, void *stream);
+sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t frames,
+                                   float *d_mapped, void *stream);
+sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,
+                                  uint8_t *d_rgba, float *d_lines, float *d_state, void *stream);
+
+/* Multi-GPU time-chunk sharding (collective A2).  Rank q renders its frames with a zero
+ * carry-in and publishes its end state A_q (the d_state output above).  Because fl(x*pole) is monotone,
+ * the true state entering rank r is  fold_{q<r} carry = max(A_q, decay^{frames_q}(carry))  evaluated with
+ * sequential fp32 multiplies -- bit-identical to the reference's sequential recurrence
+ * (TransformDSP.inl:1336-1341) run over the whole stream on one device.
+ * d_aggs: DEVICE float [world][pairs][graphs][P][2] (an all-gather of every rank's end state);
+ * frames_per_rank: HOST int64 [world]; d_carry: DEVICE float [pairs][graphs][P][2] (out). */
+sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64_t *frames_per_rank,
+                                uint32_t world, uint32_t rank, float *d_carry, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Real-time per-block path: replaces Spectrum::ProcessorShell::onStreamAudio (SpectrumDSP.cpp:210-216)
+ * -> AudioDispatcher::dispatch (:63-108) and the consumer side Spectrum::renderColourSpectrum's
+ * frameQueue.popElement (SpectrumRendering.cpp:696-721).  One producer thread (push) and one consumer
+ * thread (pop) may run concurrently.  push never blocks on the GPU.
+ */
+typedef struct sgz_spectrum sgz_spectrum;
+sgz_status sgz_spectrum_create(const sgz_spectrum_config *cfg, sgz_spectrum **out);
+void       sgz_spectrum_destroy(sgz_spectrum *s);
+sgz_status sgz_spectrum_configure(sgz_spectrum *s, const sgz_spectrum_config *cfg);   /* handleFlagUpdates */
+/* onStreamAudio(ctx, float** buffer, numChannels, numSamples) */
+sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
+/* frameQueue.popElement -> RGBA8 column of P pixels; SGZ_EMPTY when none is ready */
+sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint32_t *axis_points);
+/* lineGraphs[graph].getResults(P) for pair `pair`: float2 [P] (TransformPair.h:72-76) */
+sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t graph, float *out /*2*P*/);
+sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                                   /* clearAudioState, TransformPair.h:177-184 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Oscilloscope: Lanczos-10 per-point resampler (drawWavePlot, OscilloscopeRendering.cpp:790-891),
+ * zero-crossing trigger (ZeroCrossingProcessor::process, StreamPreprocessing.h:315-349) and the peak
+ * envelope (runPeakFilter, OscilloscopeDSP.inl:713-886).
+ */
+typedef struct sgz_scope_view {
+    double   window_size;       /* state.effectiveWindowSize, samples      */
+    double   left, right;       /* state.viewOffsets[Left], [Right]        */
+    double   rendering_scale;   /* oglc->getRenderingScale()               */
+    uint32_t width;             /* getWidth(), pixels                      */
+    uint32_t _pad;
+} sgz_scope_view;
+size_t     sgz_scope_num_points(const sgz_scope_view *view);
+/* d_ring: DEVICE fp32 front buffer in time order (index 0 at the stream cursor), len samples, `channels`
+ * buffers at d_ring + c*stride.  d_xy: DEVICE float2 [channels][points] = the (x, y) of addVertex(x, y, 0). */
+sgz_status sgz_scope_lanczos_device(const sgz_scope_view *view, const float *d_ring, size_t len,
+                                    size_t stride, uint32_t channels, float *d_xy, void *stream);
+typedef struct sgz_zero_crossing_state {
+    double   state;
+    double   threshold;
+    uint64_t steady_clock;
+    uint64_t cross_origin;
+    uint64_t count;
+    int32_t  armed;
+    int32_t  _pad;
+} sgz_zero_crossing_state;
+/* d_a/d_b: DEVICE trigger-pair channels for this block; d_triggers: DEVICE uint64 [max_triggers] absolute
+ * sample indices (the values peaks.push receives); *num_triggers and *st are updated on the host
+ * (this call synchronises the stream: the trigger list is consumed by host logic). */
+sgz_status sgz_scope_zero_crossing_device(sgz_zero_crossing_state *st, uint32_t osc_mode, const float *d_a,
+                                          const float *d_b, size_t n, uint64_t *d_triggers,
+                                          size_t max_triggers, size_t *num_triggers, void *stream);
+/* peak envelope over `channels` windows of n samples; env (host, in/out, [channels]); returns gain */
+sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t channels, size_t n,
+                                  uint32_t lanes, double coeff_pow, double *env, double *gain, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vectorscope: polar transform (drawPolarPlot, VectorscopeRendering.cpp:500-746) and the audio-thread
+ * one-pole filters (Processor::audioProcessing, Vectorscope.cpp:268-377).
+ */
+/* d_xyz: DEVICE float3 [pairs][n]; pair p uses channels 2p, 2p+1 of d_planar */
+sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_t pairs, size_t n,
+                                   uint32_t lanes, float *d_xyz, void *stream);
+typedef struct sgz_vector_filters { float env[2]; float balance[2][2]; float phase[2]; } sgz_vector_filters;
+sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float *d_left, const float *d_right,
+                                              size_t n, uint32_t lanes, float envelope_coeff, float stereo_coeff,
+                                              float second_speed, int env_mode, float *gain_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGZ_H */

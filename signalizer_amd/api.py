@@ -1,0 +1,325 @@
+"""Host-side binding of libsgz.so (include/sgz.h) for Python callers, tests and bench.py.
+
+Mirrors the reference's operator surface for the path: a `SpectrumProcessor` with `on_stream_audio`
+(AudioStream::Listener::onStreamAudio, Source/Spectrum/Spectrum.h:370) / `pop_column`
+(frameQueue.popElement, SpectrumRendering.cpp:696-721) and the batch `render_spectrogram`.
+PyTorch is used only as the device allocator / stream provider.  No CPU fallback: if libsgz.so is
+missing or no GPU is visible, compute calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NUM_SPEC_COLOURS = 5
+NUM_GRAPHS = 2
+
+SGZ_OK, SGZ_EMPTY, SGZ_SKIPPED_FRAME = 0, 1, 2
+SGZ_EINVAL, SGZ_EHIP, SGZ_ENOMEM, SGZ_EUNSUPPORTED = -1, -2, -3, -4
+
+
+class SgzError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"sgz status {status}: {msg}")
+        self.status = status
+
+
+class SpectrumConfig(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_float), ("window_size", C.c_uint32), ("hop", C.c_uint32), ("axis_points", C.c_uint32),
+        ("channel_mode", C.c_uint32), ("bin_interp", C.c_uint32), ("view_scaling", C.c_uint32),
+        ("window_type", C.c_uint32), ("window_symmetry", C.c_uint32), ("num_pairs", C.c_uint32),
+        ("window_alpha", C.c_double), ("window_beta", C.c_double), ("view_left", C.c_double),
+        ("view_right", C.c_double), ("min_log_freq", C.c_double), ("low_db", C.c_double), ("high_db", C.c_double),
+        ("clip_db", C.c_double), ("slope_a", C.c_double), ("slope_b", C.c_double),
+        ("pole", C.c_float * NUM_GRAPHS), ("colours", (C.c_uint8 * 3) * (NUM_SPEC_COLOURS + 1)),
+        ("_pad", C.c_uint8 * 2), ("ratios", C.c_double * NUM_SPEC_COLOURS),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("frames", C.c_uint64)]
+
+
+class ScopeView(C.Structure):
+    _fields_ = [("window_size", C.c_double), ("left", C.c_double), ("right", C.c_double),
+                ("rendering_scale", C.c_double), ("width", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class ZeroCrossingState(C.Structure):
+    _fields_ = [("state", C.c_double), ("threshold", C.c_double), ("steady_clock", C.c_uint64),
+                ("cross_origin", C.c_uint64), ("count", C.c_uint64), ("armed", C.c_int32), ("_pad", C.c_int32)]
+
+
+class VectorFilters(C.Structure):
+    _fields_ = [("env", C.c_float * 2), ("balance", (C.c_float * 2) * 2), ("phase", C.c_float * 2)]
+
+
+def config_from_dict(d: dict) -> SpectrumConfig:
+    c = SpectrumConfig()
+    for k, v in d.items():
+        if k == "pole":
+            for i in range(NUM_GRAPHS):
+                c.pole[i] = v[i]
+        elif k == "colours":
+            for i in range(NUM_SPEC_COLOURS + 1):
+                for j in range(3):
+                    c.colours[i][j] = int(v[i][j])
+        elif k == "ratios":
+            for i in range(NUM_SPEC_COLOURS):
+                c.ratios[i] = float(v[i])
+        else:
+            setattr(c, k, v)
+    return c
+
+
+_lib = None
+LIB_PATH = _build.LIB
+
+# every symbol include/sgz.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "sgz_last_error", "sgz_abi_version", "sgz_device_count", "sgz_set_device",
+    "sgz_plan_create", "sgz_plan_destroy", "sgz_plan_upload", "sgz_plan_transform_size",
+    "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_get_window",
+    "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
+    "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
+    "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped",
+    "sgz_stage_map_from_bins", "sgz_stage_decay_colour", "sgz_decay_fold_carry",
+    "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
+    "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state",
+    "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
+    "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
+]
+
+
+def lib() -> C.CDLL:
+    """Load libsgz.so (building it with hipcc if the in-tree .so is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = LIB_PATH
+    if not os.path.exists(path):
+        _build.build()
+    L = C.CDLL(path)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    L.sgz_last_error.restype = C.c_char_p
+    L.sgz_plan_create.argtypes = [C.POINTER(SpectrumConfig), C.POINTER(vp)]
+    L.sgz_plan_destroy.argtypes = [vp]
+    L.sgz_plan_destroy.restype = None
+    L.sgz_plan_upload.argtypes = [vp]
+    L.sgz_plan_transform_size.argtypes = [vp]
+    L.sgz_plan_transform_size.restype = u32
+    L.sgz_plan_window_scale.argtypes = [vp]
+    L.sgz_plan_window_scale.restype = C.c_double
+    L.sgz_plan_break_pixel.argtypes = [vp]
+    L.sgz_plan_break_pixel.restype = u32
+    for f in ("sgz_plan_get_window", "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map",
+              "sgz_plan_get_colour_ratios"):
+        getattr(L, f).argtypes = [vp, vp]
+    L.sgz_plan_get_colour_table.argtypes = [vp, u32, vp]
+    L.sgz_rotate_hue_rgb8.argtypes = [vp, C.c_float, vp]
+    L.sgz_rotate_hue_rgb8.restype = None
+    L.sgz_num_frames.argtypes = [sz, u32, u32]
+    L.sgz_num_frames.restype = C.c_long
+    L.sgz_spectrogram_render_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
+    L.sgz_spectrogram_render.argtypes = [C.POINTER(SpectrumConfig), vp, u32, sz, vp, vp, C.POINTER(Timing)]
+    L.sgz_stage_bins.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgz_stage_mapped.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgz_stage_map_from_bins.argtypes = [vp, vp, sz, vp, vp]
+    L.sgz_stage_decay_colour.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    L.sgz_decay_fold_carry.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.sgz_spectrum_create.argtypes = [C.POINTER(SpectrumConfig), C.POINTER(vp)]
+    L.sgz_spectrum_destroy.argtypes = [vp]
+    L.sgz_spectrum_destroy.restype = None
+    L.sgz_spectrum_configure.argtypes = [vp, C.POINTER(SpectrumConfig)]
+    L.sgz_spectrum_push.argtypes = [vp, vp, u32, u32]
+    L.sgz_spectrum_pop_column.argtypes = [vp, vp, C.POINTER(u32)]
+    L.sgz_spectrum_line_results.argtypes = [vp, u32, u32, vp]
+    L.sgz_spectrum_clear_state.argtypes = [vp]
+    L.sgz_scope_num_points.argtypes = [C.POINTER(ScopeView)]
+    L.sgz_scope_num_points.restype = sz
+    L.sgz_scope_lanczos_device.argtypes = [C.POINTER(ScopeView), vp, sz, sz, u32, vp, vp]
+    L.sgz_scope_zero_crossing_device.argtypes = [C.POINTER(ZeroCrossingState), u32, vp, vp, sz, vp, sz,
+                                                 C.POINTER(sz), vp]
+    L.sgz_peak_filter_device.argtypes = [vp, sz, u32, sz, u32, C.c_double, vp, C.POINTER(C.c_double), vp]
+    L.sgz_vector_polar_device.argtypes = [vp, sz, u32, sz, u32, vp, vp]
+    L.sgz_vector_audio_processing_device.argtypes = [C.POINTER(VectorFilters), vp, vp, sz, u32, C.c_float,
+                                                     C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float), vp]
+    _lib = L
+    return L
+
+
+def check(status: int) -> int:
+    if status < 0:
+        raise SgzError(status, (lib().sgz_last_error() or b"").decode(errors="replace"))
+    return status
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Plan:
+    """The Spectrum constant block (TransformConstant mirror). Host tables need no GPU."""
+
+    def __init__(self, cfg: dict | SpectrumConfig):
+        self.cfg = cfg if isinstance(cfg, SpectrumConfig) else config_from_dict(cfg)
+        h = C.c_void_p()
+        check(lib().sgz_plan_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sgz_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self):
+        check(lib().sgz_plan_upload(self.h))
+        return self
+
+    @property
+    def N(self) -> int:
+        return lib().sgz_plan_transform_size(self.h)
+
+    @property
+    def P(self) -> int:
+        return self.cfg.axis_points
+
+    @property
+    def C(self) -> int:
+        return self.cfg.num_pairs
+
+    @property
+    def sides(self) -> int:
+        return 2 if self.cfg.channel_mode in (5, 6) else 1
+
+    @property
+    def window_scale(self) -> float:
+        return lib().sgz_plan_window_scale(self.h)
+
+    @property
+    def break_pixel(self) -> int:
+        return lib().sgz_plan_break_pixel(self.h)
+
+    def window(self) -> np.ndarray:
+        out = np.zeros(self.N, np.float32)
+        check(lib().sgz_plan_get_window(self.h, _np_ptr(out)))
+        return out
+
+    def mapped_frequencies(self) -> np.ndarray:
+        out = np.zeros(self.P, np.float32)
+        check(lib().sgz_plan_get_mapped_frequencies(self.h, _np_ptr(out)))
+        return out
+
+    def slope_map(self) -> np.ndarray:
+        out = np.zeros(self.P, np.float32)
+        check(lib().sgz_plan_get_slope_map(self.h, _np_ptr(out)))
+        return out
+
+    def colour_ratios(self) -> np.ndarray:
+        out = np.zeros(NUM_SPEC_COLOURS + 1, np.float32)
+        check(lib().sgz_plan_get_colour_ratios(self.h, _np_ptr(out)))
+        return out
+
+    def colour_table(self, pair: int) -> np.ndarray:
+        out = np.zeros((NUM_SPEC_COLOURS + 1, 3), np.float32)
+        check(lib().sgz_plan_get_colour_table(self.h, pair, _np_ptr(out)))
+        return out
+
+    def num_frames(self, nsamples: int) -> int:
+        return lib().sgz_num_frames(nsamples, self.cfg.window_size, self.cfg.hop)
+
+    # ---- device entry points (torch tensors on the GPU) -------------------------------------------
+    def render(self, planar, rgba=None, lines=None, state=None, stream=None):
+        """planar: torch.float32 [2*C, S] (cuda, contiguous rows). Returns rgba uint8 [F, P, 4]."""
+        import torch
+        assert planar.is_cuda and planar.dtype == torch.float32 and planar.stride(1) == 1
+        S = planar.shape[1]
+        F = self.num_frames(S)
+        if rgba is None:
+            rgba = torch.empty((F, self.P, 4), dtype=torch.uint8, device=planar.device)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(lib().sgz_spectrogram_render_device(
+            self.h, planar.data_ptr(), planar.stride(0), S, rgba.data_ptr(),
+            lines.data_ptr() if lines is not None else None,
+            state.data_ptr() if state is not None else None, s))
+        return rgba
+
+    def stage_bins(self, planar):
+        import torch
+        S = planar.shape[1]
+        F = self.num_frames(S)
+        out = torch.empty((F, self.C, self.N + 1), dtype=torch.float32, device=planar.device)
+        check(lib().sgz_stage_bins(self.h, planar.data_ptr(), planar.stride(0), S, out.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def stage_mapped(self, planar):
+        import torch
+        S = planar.shape[1]
+        F = self.num_frames(S)
+        out = torch.empty((F, self.C, self.sides, self.P), dtype=torch.float32, device=planar.device)
+        check(lib().sgz_stage_mapped(self.h, planar.data_ptr(), planar.stride(0), S, out.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def stage_map_from_bins(self, bins):
+        import torch
+        F = bins.shape[0]
+        out = torch.empty((F, self.C, self.sides, self.P), dtype=torch.float32, device=bins.device)
+        check(lib().sgz_stage_map_from_bins(self.h, bins.data_ptr(), F, out.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream))
+        return out
+
+    def stage_decay_colour(self, mapped, want_lines=False, state=None):
+        import torch
+        F = mapped.shape[0]
+        rgba = torch.empty((F, self.P, 4), dtype=torch.uint8, device=mapped.device)
+        lines = torch.empty((F, self.C, NUM_GRAPHS, self.P, 2), dtype=torch.float32, device=mapped.device) if want_lines else None
+        check(lib().sgz_stage_decay_colour(self.h, mapped.data_ptr(), F, rgba.data_ptr(),
+                                           lines.data_ptr() if want_lines else None,
+                                           state.data_ptr() if state is not None else None,
+                                           torch.cuda.current_stream().cuda_stream))
+        return rgba, lines
+
+
+    def fold_carry(self, aggs, frames_per_rank, rank: int, carry):
+        """aggs: cuda float32 [world, C, G, P, 2]; carry: cuda float32 [C, G, P, 2] (out)."""
+        import torch
+        world = aggs.shape[0]
+        fr = (C.c_int64 * world)(*[int(f) for f in frames_per_rank])
+        check(lib().sgz_decay_fold_carry(self.h, aggs.data_ptr(), fr, world, rank, carry.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream))
+        return carry
+
+
+def render_spectrogram(cfg: dict, planar: np.ndarray, want_lines: bool = False):
+    """Host-buffer batch render (sgz_spectrogram_render). planar: float32 [2*C, S]."""
+    c = config_from_dict(cfg)
+    planar = np.ascontiguousarray(planar, np.float32)
+    nch, S = planar.shape
+    F = lib().sgz_num_frames(S, c.window_size, c.hop)
+    rgba = np.zeros((F, c.axis_points, 4), np.uint8)
+    lines = np.zeros((F, c.num_pairs, NUM_GRAPHS, c.axis_points, 2), np.float32) if want_lines else None
+    ptrs = (C.c_void_p * nch)(*[planar[i].ctypes.data for i in range(nch)])
+    t = Timing()
+    check(lib().sgz_spectrogram_render(C.byref(c), ptrs, nch, S, _np_ptr(rgba),
+                                       _np_ptr(lines) if want_lines else None, C.byref(t)))
+    return rgba, lines, {"h2d_ms": t.h2d_ms, "kernel_ms": t.kernel_ms, "d2h_ms": t.d2h_ms, "frames": t.frames}
+
+
+def rotate_hue(rgb, amount: float) -> np.ndarray:
+    a = np.asarray(rgb, np.uint8)
+    out = np.zeros(3, np.uint8)
+    lib().sgz_rotate_hue_rgb8(_np_ptr(a), C.c_float(amount), _np_ptr(out))
+    return out

@@ -1,0 +1,368 @@
+// api.hip -- the extern "C" shim of libsgz.so (include/sgz.h): plan lifetime, the offline/batch spectrogram
+// entry points, the per-stage hooks the parity tests call, and the real-time push/pop handle.
+// There is NO CPU fallback: without a gfx950 device every compute entry point fails with SGZ_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace sgz {
+
+thread_local std::string g_lastError;
+
+sgz_status fail(sgz_status st, const std::string &msg)
+{
+    g_lastError = msg;
+    return st;
+}
+sgz_status hipFail(hipError_t e, const char *what)
+{
+    g_lastError = std::string(what) + ": " + hipGetErrorString(e);
+    return SGZ_EHIP;
+}
+
+Plan::~Plan()
+{
+    // best effort; ignore errors on teardown
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_recs, d_mapped, d_agg, d_scratch, d_stateCopy};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+template <typename T>
+static sgz_status uploadVec(const std::vector<T> &v, T **dst)
+{
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    if (v.empty()) return SGZ_OK;
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T)));
+    SGZ_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SGZ_OK;
+}
+
+sgz_status uploadPlan(Plan &p, std::string &err)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        err = "no HIP device visible (libsgz has no CPU fallback)";
+        return SGZ_EHIP;
+    }
+    if (p.tw1.empty()) {
+        err = "transform size " + std::to_string(p.N) + " has no gfx950 kernel yet (built: 4096, 32768)";
+        return SGZ_EUNSUPPORTED;
+    }
+    sgz_status st;
+    if ((st = uploadVec(p.window, &p.d_window)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.slope, &p.d_slope)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.colourTables, &p.d_colourTables)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.weights, &p.d_weights)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
+    (void)hipGetDevice(&p.device);
+    p.uploaded = true;
+    return SGZ_OK;
+}
+
+sgz_status ensureCap(float **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SGZ_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(buf), need * sizeof(float)));
+    *cap = need;
+    return SGZ_OK;
+}
+
+int numCUs()
+{
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// K_A launch over `frames` frames of `planar`; writes mapped/bins as requested.
+sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
+                          float *d_binsOut, const float *d_binsIn, hipStream_t stream)
+{
+    StftParams prm{};
+    prm.planar = d_planar;
+    prm.chStride = chStride;
+    prm.frames = frames;
+    prm.hop = p.cfg.hop; prm.W = p.W; prm.P = p.P; prm.C = p.C;
+    prm.sides = uint32_t(p.sides); prm.mode = p.cfg.channel_mode;
+    prm.window = p.d_window;
+    prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
+    prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
+    prm.recs = p.d_recs; prm.weights = p.d_weights;
+    prm.invSize = p.scalars.invSize;
+    prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn;
+    const long tasks = frames * long(p.C);
+    const int perCU = (p.N >= 32768) ? 1 : 8;
+    const int grid = int(std::min<long>(tasks, long(numCUs()) * perCU));
+    if (grid <= 0) return SGZ_OK;
+    SGZ_HIP(launchStftMap(prm, p.N, grid, stream));
+    return SGZ_OK;
+}
+
+sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
+                                 float *d_state, hipStream_t stream)
+{
+    if (frames <= 0) return SGZ_OK;
+    DecayParams prm{};
+    prm.mapped = d_mapped;
+    prm.frames = frames;
+    prm.P = p.P; prm.C = p.C; prm.sides = uint32_t(p.sides);
+    prm.chunk = 8;
+    prm.numChunks = uint32_t((frames + prm.chunk - 1) / prm.chunk);
+    prm.slope = p.d_slope;
+    prm.colourTables = p.d_colourTables;
+    prm.sc = p.scalars;
+    prm.state = d_state; prm.stateIn = d_state; prm.rgba = d_rgba; prm.lines = d_lines;
+    if (prm.numChunks > 1) {
+        if (d_state) {      // chunk 0 reads the carry-in while the last chunk writes the new state: snapshot it
+            const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+            sgz_status st0 = ensureCap(&p.d_stateCopy, &p.stateCopyCap, stateN);
+            if (st0 != SGZ_OK) return st0;
+            SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            prm.stateIn = p.d_stateCopy;
+        }
+        const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
+        sgz_status st = ensureCap(&p.d_agg, &p.aggCap, need);
+        if (st != SGZ_OK) return st;
+        prm.agg = p.d_agg;
+        SGZ_HIP(launchDecayLocal(prm, stream));
+    }
+    SGZ_HIP(launchDecayEmit(prm, stream));
+    return SGZ_OK;
+}
+
+}  // namespace sgz
+
+using namespace sgz;
+
+struct sgz_plan { Plan impl; };
+
+extern "C" {
+
+const char *sgz_last_error(void) { return g_lastError.c_str(); }
+int sgz_abi_version(void) { return SGZ_ABI_VERSION; }
+
+int sgz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+sgz_status sgz_set_device(int device)
+{
+    SGZ_HIP(hipSetDevice(device));
+    return SGZ_OK;
+}
+
+sgz_status sgz_plan_create(const sgz_spectrum_config *cfg, sgz_plan **out)
+{
+    if (!cfg || !out) return fail(SGZ_EINVAL, "null argument");
+    sgz_plan *pl = new (std::nothrow) sgz_plan();
+    if (!pl) return fail(SGZ_ENOMEM, "out of memory");
+    std::string err;
+    sgz_status st = buildPlan(*cfg, pl->impl, err);
+    if (st != SGZ_OK) { delete pl; return fail(st, err); }
+    *out = pl;
+    return SGZ_OK;
+}
+
+void sgz_plan_destroy(sgz_plan *plan) { delete plan; }
+
+sgz_status sgz_plan_upload(sgz_plan *plan)
+{
+    if (!plan) return fail(SGZ_EINVAL, "null plan");
+    std::string err;
+    sgz_status st = uploadPlan(plan->impl, err);
+    if (st != SGZ_OK && !err.empty()) g_lastError = err;
+    return st;
+}
+
+uint32_t sgz_plan_transform_size(const sgz_plan *plan) { return plan ? plan->impl.N : 0; }
+double sgz_plan_window_scale(const sgz_plan *plan) { return plan ? plan->impl.windowScale : 0.0; }
+uint32_t sgz_plan_break_pixel(const sgz_plan *plan) { return plan ? plan->impl.breakPixel : 0; }
+
+sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out)
+{
+    if (!plan || !out) return fail(SGZ_EINVAL, "null argument");
+    std::memcpy(out, plan->impl.window.data(), plan->impl.window.size() * sizeof(float));
+    return SGZ_OK;
+}
+sgz_status sgz_plan_get_mapped_frequencies(const sgz_plan *plan, float *out)
+{
+    if (!plan || !out) return fail(SGZ_EINVAL, "null argument");
+    std::memcpy(out, plan->impl.mapped.data(), plan->impl.mapped.size() * sizeof(float));
+    return SGZ_OK;
+}
+sgz_status sgz_plan_get_slope_map(const sgz_plan *plan, float *out)
+{
+    if (!plan || !out) return fail(SGZ_EINVAL, "null argument");
+    std::memcpy(out, plan->impl.slope.data(), plan->impl.slope.size() * sizeof(float));
+    return SGZ_OK;
+}
+sgz_status sgz_plan_get_colour_ratios(const sgz_plan *plan, float *out)
+{
+    if (!plan || !out) return fail(SGZ_EINVAL, "null argument");
+    std::memcpy(out, plan->impl.scalars.ratios, sizeof(plan->impl.scalars.ratios));
+    return SGZ_OK;
+}
+sgz_status sgz_plan_get_colour_table(const sgz_plan *plan, uint32_t pair, float *out)
+{
+    if (!plan || !out || pair >= plan->impl.C) return fail(SGZ_EINVAL, "bad argument");
+    const size_t n = (SGZ_NUM_SPEC_COLOURS + 1) * 3;
+    std::memcpy(out, plan->impl.colourTables.data() + size_t(pair) * n, n * sizeof(float));
+    return SGZ_OK;
+}
+void sgz_rotate_hue_rgb8(const uint8_t rgb[3], float amount, uint8_t out[3]) { rotateHueRgb8(rgb, amount, out); }
+
+long sgz_num_frames(size_t nsamples, uint32_t window_size, uint32_t hop)
+{
+    if (nsamples < window_size || hop == 0) return 0;
+    return long((nsamples - window_size) / hop) + 1;
+}
+
+static sgz_status checkReady(sgz_plan *plan)
+{
+    if (!plan) return fail(SGZ_EINVAL, "null plan");
+    if (!plan->impl.uploaded) {
+        std::string err;
+        sgz_status st = uploadPlan(plan->impl, err);
+        if (st != SGZ_OK) return fail(st, err);
+    }
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, size_t channel_stride,
+                                         size_t nsamples, uint8_t *d_rgba, float *d_lines, float *d_state,
+                                         void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    if (!d_planar || (!d_rgba && !d_lines)) return fail(SGZ_EINVAL, "null buffer");
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    if (frames <= 0) return SGZ_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P);
+    if (st != SGZ_OK) return st;
+    if ((st = runStft(p, d_planar, channel_stride, frames, p.d_mapped, nullptr, nullptr, s)) != SGZ_OK) return st;
+    return runDecayColour(p, p.d_mapped, frames, d_rgba, d_lines, d_state, s);
+}
+
+sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *const *planar, uint32_t num_channels,
+                                  size_t nsamples, uint8_t *rgba_out, float *lines_out, sgz_timing *timing)
+{
+    if (!cfg || !planar || !rgba_out) return fail(SGZ_EINVAL, "null argument");
+    if (num_channels != 2 * cfg->num_pairs) return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72)");
+    sgz_plan *plan = nullptr;
+    sgz_status st = sgz_plan_create(cfg, &plan);
+    if (st != SGZ_OK) return st;
+    st = sgz_plan_upload(plan);
+    if (st != SGZ_OK) { sgz_plan_destroy(plan); return st; }
+    Plan &p = plan->impl;
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    float *d_audio = nullptr, *d_lines = nullptr;
+    uint8_t *d_rgba = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    auto cleanup = [&]() {
+        if (d_audio) (void)hipFree(d_audio);
+        if (d_lines) (void)hipFree(d_lines);
+        if (d_rgba) (void)hipFree(d_rgba);
+        for (hipEvent_t e : {e0, e1, e2, e3}) if (e) (void)hipEventDestroy(e);
+        sgz_plan_destroy(plan);
+    };
+    if (frames <= 0) { cleanup(); if (timing) *timing = sgz_timing{}; return SGZ_OK; }
+#define SGZ_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hipFail(_e, #call); } } while (0)
+    SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_audio), size_t(num_channels) * nsamples * sizeof(float)));
+    SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_rgba), size_t(frames) * p.P * 4));
+    if (lines_out) SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_lines), size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float)));
+    SGZ_HIP_C(hipEventCreate(&e0)); SGZ_HIP_C(hipEventCreate(&e1)); SGZ_HIP_C(hipEventCreate(&e2)); SGZ_HIP_C(hipEventCreate(&e3));
+    SGZ_HIP_C(hipEventRecord(e0, nullptr));
+    for (uint32_t c = 0; c < num_channels; ++c)
+        SGZ_HIP_C(hipMemcpyAsync(d_audio + size_t(c) * nsamples, planar[c], nsamples * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    SGZ_HIP_C(hipEventRecord(e1, nullptr));
+    st = sgz_spectrogram_render_device(plan, d_audio, nsamples, nsamples, d_rgba, d_lines, nullptr, nullptr);
+    if (st != SGZ_OK) { cleanup(); return st; }
+    SGZ_HIP_C(hipEventRecord(e2, nullptr));
+    SGZ_HIP_C(hipMemcpyAsync(rgba_out, d_rgba, size_t(frames) * p.P * 4, hipMemcpyDeviceToHost, nullptr));
+    if (lines_out)
+        SGZ_HIP_C(hipMemcpyAsync(lines_out, d_lines, size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    SGZ_HIP_C(hipEventRecord(e3, nullptr));
+    SGZ_HIP_C(hipStreamSynchronize(nullptr));
+    if (timing) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2); (void)hipEventElapsedTime(&c, e2, e3);
+        timing->h2d_ms = a; timing->kernel_ms = b; timing->d2h_ms = c; timing->frames = uint64_t(frames);
+    }
+#undef SGZ_HIP_C
+    cleanup();
+    return SGZ_OK;
+}
+
+sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                          float *d_bins, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    return runStft(p, d_planar, channel_stride, frames, nullptr, d_bins, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                            float *d_mapped, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t frames, float *d_mapped, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    return runStft(plan->impl, nullptr, 0, long(frames), d_mapped, nullptr, d_bins, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames, uint8_t *d_rgba,
+                                  float *d_lines, float *d_state, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    return runDecayColour(plan->impl, d_mapped, long(frames), d_rgba, d_lines, d_state, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64_t *frames_per_rank, uint32_t world,
+                                uint32_t rank, float *d_carry, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    if (!d_aggs || !frames_per_rank || !d_carry || rank >= world || world > 64) return fail(SGZ_EINVAL, "bad argument");
+    Plan &p = plan->impl;
+    long long fr[64];
+    for (uint32_t q = 0; q < world; ++q) fr[q] = frames_per_rank[q];
+    const size_t perRank = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+    SGZ_HIP(launchDecayFold(d_aggs, fr, world, rank, perRank, p.P, p.scalars, d_carry, reinterpret_cast<hipStream_t>(stream)));
+    return SGZ_OK;
+}
+
+}  // extern "C"

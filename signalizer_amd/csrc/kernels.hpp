@@ -1,0 +1,48 @@
+// kernels.hpp -- launch interfaces between the C-ABI glue (api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.hpp"
+
+namespace sgz {
+
+struct StftParams {
+    const float *planar;      // device, channel c at planar + c*chStride
+    size_t chStride;
+    long frames;
+    uint32_t hop, W, P, C;
+    uint32_t sides, mode;
+    const float *window;      // [N]
+    const float2 *tw1;        // [R][T]
+    const float2 *tw2;        // [R][R]
+    const PixelRec *recs;     // [sides][P]
+    const float *weights;
+    float invSize;
+    float *mapped;            // [frames][C][sides][P] or null
+    float *binsOut;           // [frames][C][N+1] or null (test hook)
+    const float *binsIn;      // test hook: skip the FFT, map from these bins
+};
+hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+
+struct DecayParams {
+    const float *mapped;      // [frames][C][sides][P]
+    long frames;
+    uint32_t P, C, sides;
+    uint32_t chunk;           // frames per time chunk
+    uint32_t numChunks;
+    const float *slope;       // [P]
+    const float *colourTables;// [C][6][3]
+    DeviceScalars sc;
+    float *agg;               // [numChunks][C][sides][G][P] chunk-end aggregates (zero carry-in, chunk 0 uses state)
+    const float *stateIn;     // [C][G][P][2] carry-in (a private copy when numChunks > 1), may be null
+    float *state;             // [C][G][P][2] (float2: left/right) out: state after the last frame, may be null
+    uint8_t *rgba;            // [frames][P][4] or null
+    float *lines;             // [frames][C][G][P][2] or null
+};
+hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
+hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
+hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
+                           uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
+
+}  // namespace sgz

@@ -1,0 +1,384 @@
+// plan.cpp -- host construction of the Spectrum constant block (no GPU needed).
+// Mirrors, in the product's own code, what Spectrum::handleFlagUpdates rebuilds
+// (Source/Spectrum/Spectrum.cpp:351-616): setStorage (TransformConstant.h:81-92), remapFrequencies
+// (:125-180), generateSlopeMap (:109-118), regenerateWindowKernel (:104-107), colour ratios
+// (Spectrum.cpp:226-246), colour rotation (TransformConstant.h:55-65), and it pre-resolves the
+// pixel->bin mapping decisions of mapToLinearSpace (TransformDSP.inl:565-639, :871-985, :995-1096)
+// into per-pixel records so the device does no fp64 index math ("hard parts").
+#include "plan.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace sgz {
+
+uint32_t transformSizeFor(uint32_t W)
+{
+    uint32_t n = 1;
+    while (n < W) n <<= 1;
+    return n < 32 ? 32u : n;           // max(32, nextPow2Inc(W)), TransformConstant.h:84
+}
+
+// ---- window design (stand-in for cpl's windowDesigner.generateWindow; scale = W / sum(w)) ----------
+static double besselI0(double x)
+{
+    double sum = 1.0, term = 1.0;
+    const double q = x * x * 0.25;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / (double(k) * double(k));
+        sum += term;
+        if (term < sum * 1e-17) break;
+    }
+    return sum;
+}
+
+double designWindow(uint32_t type, uint32_t symmetry, double alpha, double beta, uint32_t W, float *out)
+{
+    if (W == 0) return 1.0;
+    const double kPi = 3.14159265358979323846;
+    const double D = (symmetry == SGZ_WIN_PERIODIC) ? double(W) : (W > 1 ? double(W - 1) : 1.0);
+    static const double cosCoeffs[][5] = {
+        /* HANN */              {0.5, 0.5, 0, 0, 0},
+        /* HAMMING */           {0.54, 0.46, 0, 0, 0},
+        /* FLATTOP */           {0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368},
+        /* BLACKMAN */          {0.42, 0.5, 0.08, 0, 0},
+        /* EXACT_BLACKMAN */    {7938.0 / 18608.0, 9240.0 / 18608.0, 1430.0 / 18608.0, 0, 0},
+        /* NUTTALL */           {0.355768, 0.487396, 0.144232, 0.012604, 0},
+        /* BLACKMAN_NUTTALL */  {0.3635819, 0.4891775, 0.1365995, 0.0106411, 0},
+        /* BLACKMAN_HARRIS */   {0.35875, 0.48829, 0.14128, 0.01168, 0},
+    };
+    double sum = 0.0;
+    for (uint32_t n = 0; n < W; ++n) {
+        const double x = double(n) / D;
+        const double t = 2.0 * kPi * x;
+        double w = 1.0;
+        if (type >= SGZ_WIN_HANN && type <= SGZ_WIN_BLACKMAN_HARRIS) {
+            const double *c = cosCoeffs[type - SGZ_WIN_HANN];
+            // a0 - a1 cos t + a2 cos 2t - a3 cos 3t + a4 cos 4t, evaluated left to right
+            switch (type) {
+            case SGZ_WIN_HANN: case SGZ_WIN_HAMMING: w = c[0] - c[1] * std::cos(t); break;
+            case SGZ_WIN_BLACKMAN: case SGZ_WIN_EXACT_BLACKMAN:
+                w = c[0] - c[1] * std::cos(t) + c[2] * std::cos(2 * t); break;
+            case SGZ_WIN_FLATTOP:
+                w = c[0] - c[1] * std::cos(t) + c[2] * std::cos(2 * t) - c[3] * std::cos(3 * t) + c[4] * std::cos(4 * t); break;
+            default:
+                w = c[0] - c[1] * std::cos(t) + c[2] * std::cos(2 * t) - c[3] * std::cos(3 * t); break;
+            }
+        } else if (type == SGZ_WIN_TRIANGULAR) {
+            w = 1.0 - std::fabs(2.0 * x - 1.0);
+        } else if (type == SGZ_WIN_WELCH) {
+            const double u = 2.0 * x - 1.0; w = 1.0 - u * u;
+        } else if (type == SGZ_WIN_GAUSSIAN) {
+            const double s = alpha > 0 ? alpha : 0.4;
+            const double u = (2.0 * x - 1.0) / s;
+            w = std::exp(-0.5 * u * u);
+        } else if (type == SGZ_WIN_KAISER) {
+            const double u = 2.0 * x - 1.0;
+            const double r = 1.0 - u * u;
+            w = besselI0(beta * std::sqrt(r > 0 ? r : 0)) / besselI0(beta);
+        }
+        out[n] = float(w);
+        sum += double(out[n]);
+    }
+    return sum > 0 ? double(W) / sum : 1.0;
+}
+
+double lanczosKernel(double d, int a)
+{
+    const double kPi = 3.14159265358979323846;
+    if (d == 0.0) return 1.0;
+    if (d <= -double(a) || d >= double(a)) return 0.0;
+    const double pd = kPi * d;
+    return double(a) * std::sin(pd) * std::sin(pd / double(a)) / (pd * pd);
+}
+
+// juce::Colour::withRotatedHue through ColourHelpers::HSB (juce_Colour.cpp:33-107, :331-336); SURVEY Q12.
+static inline int roundToInt(float v) { return int(std::lrint(double(v))); }
+void rotateHueRgb8(const uint8_t rgb[3], float amount, uint8_t out[3])
+{
+    const int r = rgb[0], g = rgb[1], b = rgb[2];
+    const int hi = std::max(r, std::max(g, b)), lo = std::min(r, std::min(g, b));
+    float hue = 0, sat = 0;
+    if (hi != 0) {
+        sat = float(hi - lo) / float(hi);
+        if (sat > 0) {
+            const float invDiff = 1.0f / float(hi - lo);
+            const float red = float(hi - r) * invDiff, green = float(hi - g) * invDiff, blue = float(hi - b) * invDiff;
+            if (r == hi) hue = blue - green;
+            else if (g == hi) hue = 2.0f + red - blue;
+            else hue = 4.0f + green - red;
+            hue *= 1.0f / 6.0f;
+            if (hue < 0) ++hue;
+        }
+    }
+    const float brightness = float(hi) / 255.0f;
+    float h = hue + amount, s = sat, v = brightness * 255.0f;
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    const uint8_t intV = uint8_t(roundToInt(v));
+    if (s <= 0) { out[0] = out[1] = out[2] = intV; return; }
+    s = std::min(1.0f, s);
+    h = (h - std::floor(h)) * 6.0f + 0.00001f;
+    const float f = h - std::floor(h);
+    const uint8_t x = uint8_t(roundToInt(v * (1.0f - s)));
+    const uint8_t up = uint8_t(roundToInt(v * (1.0f - (s * (1.0f - f)))));
+    const uint8_t dn = uint8_t(roundToInt(v * (1.0f - s * f)));
+    if (h < 1.0f)      { out[0] = intV; out[1] = up;   out[2] = x; }
+    else if (h < 2.0f) { out[0] = dn;   out[1] = intV; out[2] = x; }
+    else if (h < 3.0f) { out[0] = x;    out[1] = intV; out[2] = up; }
+    else if (h < 4.0f) { out[0] = x;    out[1] = dn;   out[2] = intV; }
+    else if (h < 5.0f) { out[0] = up;   out[1] = x;    out[2] = intV; }
+    else               { out[0] = intV; out[1] = x;    out[2] = dn; }
+}
+
+// ---- pixel records ------------------------------------------------------------------------------------
+namespace {
+
+struct RecBuilder {
+    Plan &p;
+    long N;
+    size_t csfSize;
+    explicit RecBuilder(Plan &pl) : p(pl), N(long(pl.N)), csfSize(size_t(pl.N) + 1) {}
+
+    int32_t wrap(long i) const { long m = i % long(csfSize); if (m < 0) m += long(csfSize); return int32_t(m); }
+
+    PixelRec interp(float pos, size_t clampHi) {
+        PixelRec r{};
+        r.kind = 0;
+        r.c = int32_t(p.weights.size());
+        const double xd = double(pos);
+        switch (p.cfg.bin_interp) {
+        case SGZ_INTERP_LINEAR: {
+            const long fl = long(std::floor(xd));
+            const float frac = float(xd - double(fl));
+            r.a = wrap(fl); r.b = 2;
+            p.weights.push_back(1.0f - frac);
+            p.weights.push_back(frac);
+            break;
+        }
+        case SGZ_INTERP_LANCZOS: {
+            const int a = 5;
+            const long fl = long(std::floor(xd));
+            r.a = wrap(fl - a + 1); r.b = 2 * a;
+            for (long i = fl - a + 1; i <= fl + a; ++i) p.weights.push_back(float(lanczosKernel(xd - double(i), a)));
+            break;
+        }
+        default: {   // None: +0.5 to centre bins, TransformDSP.inl:577
+            size_t idx = size_t(xd + 0.5);
+            idx = idx > clampHi ? clampHi : idx;
+            r.a = int32_t(idx); r.b = 1;
+            p.weights.push_back(1.0f);
+            break;
+        }
+        }
+        return r;
+    }
+};
+
+}  // namespace
+
+static void buildPixelRecords(Plan &p)
+{
+    const long N = long(p.N), P = long(p.P);
+    const size_t numBins = size_t(N >> 1);
+    const float *mf = p.mapped.data();
+    const float topFrequency = p.cfg.sample_rate / 2;                  // TransformDSP.inl:523
+    const float freqToBin = float(float(numBins) / topFrequency);      // :524
+    RecBuilder rb(p);
+    p.recs.assign(size_t(p.sides) * size_t(P), PixelRec{});
+    p.weights.clear();
+    PixelRec *left = p.recs.data();
+    PixelRec *right = p.sides == 2 ? p.recs.data() + P : nullptr;
+    long x = 0, oldBin = 0;
+
+    auto maxRec = [&](long xx) {
+        const long bin = long(size_t(mf[xx] * freqToBin));              // :612 / :948
+        long diff = bin - oldBin;
+        long counter = diff ? 1 : 0;
+        long first = oldBin + counter, cnt = 0;
+        do { ++cnt; ++counter; --diff; } while (diff > 0);
+        PixelRec r{}; r.kind = 1; r.a = int32_t(first); r.b = int32_t(cnt); r.c = int32_t(bin);
+        oldBin = bin;
+        return r;
+    };
+
+    const uint32_t mode = p.cfg.channel_mode;
+    if (mode == SGZ_CH_COMPLEX) {                                      // TransformDSP.inl:987-1097
+        const double fftBandwidth = 1.0 / double(numBins * 2);
+        p.breakPixel = uint32_t(P);
+        bool firstBreak = true;
+        while (x < P) {
+            for (; x < P; ++x) {
+                if (x != P - 1) {
+                    const double bw = double((mf[x + 1] - mf[x]) / topFrequency);
+                    if (bw > fftBandwidth) break;
+                }
+                left[x] = rb.interp(mf[x] * freqToBin, size_t(N));
+            }
+            if (firstBreak) { p.breakPixel = uint32_t(x); firstBreak = false; }
+            if (x != P) oldBin = long(mf[x] * freqToBin);
+            for (; x < P; ++x) {
+                if (x != P - 1) {
+                    const double bw = double((mf[x + 1] - mf[x]) / topFrequency);
+                    if (bw < fftBandwidth) break;
+                }
+                left[x] = maxRec(x);
+            }
+        }
+        return;
+    }
+
+    const double fftBandwidth = 1.0 / double(numBins);
+    for (x = 0; x < P - 1; ++x) {                                       // :568-601 / :878-936
+        const double bw = double((mf[x + 1] - mf[x]) / topFrequency);
+        if (bw > fftBandwidth) break;
+        const float pos = mf[x] * freqToBin;
+        left[x] = rb.interp(pos, numBins);
+        if (right) {
+            if (p.cfg.bin_interp == SGZ_INTERP_NONE) {
+                PixelRec r = left[x];
+                r.a = int32_t(N - long(left[x].a));                       // csf[N - index], :933
+                r.c = int32_t(p.weights.size());
+                p.weights.push_back(1.0f);
+                right[x] = r;
+            } else {
+                right[x] = rb.interp(float(N) - pos, numBins);            // N - (float), :893,:912
+            }
+        }
+    }
+    p.breakPixel = uint32_t(x);
+    oldBin = long(mf[x] * freqToBin);                                    // :606 / :942
+    for (; x < P; ++x) {
+        left[x] = maxRec(x);
+        if (right) {                                                     // offsets mirrored: csf[N - offset], :963
+            PixelRec r = left[x];
+            right[x] = r;                                                // device applies N - offset for side 1
+        }
+    }
+}
+
+static void buildTwiddles(Plan &p)
+{
+    // N = R^3 fast path (R = 16 or 32): tw1[q][t] = W_N^{t q}, t < R^2 ; tw2[q2][t2] = W_{R^2}^{t2 q2}
+    const double kTwoPi = 6.28318530717958647692;
+    int R = 0;
+    if (p.N == 32768) R = 32; else if (p.N == 4096) R = 16;
+    if (!R) return;
+    const uint32_t T = uint32_t(R * R);
+    p.tw1.resize(size_t(R) * T * 2);
+    for (int q = 0; q < R; ++q)
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint64_t m = (uint64_t(t) * uint64_t(q)) % p.N;
+            const double ang = -kTwoPi * double(m) / double(p.N);
+            p.tw1[(size_t(q) * T + t) * 2 + 0] = float(std::cos(ang));
+            p.tw1[(size_t(q) * T + t) * 2 + 1] = float(std::sin(ang));
+        }
+    p.tw2.resize(size_t(R) * R * 2);
+    for (int q2 = 0; q2 < R; ++q2)
+        for (int t2 = 0; t2 < R; ++t2) {
+            const uint32_t m = uint32_t(t2 * q2) % T;
+            const double ang = -kTwoPi * double(m) / double(T);
+            p.tw2[(size_t(q2) * R + t2) * 2 + 0] = float(std::cos(ang));
+            p.tw2[(size_t(q2) * R + t2) * 2 + 1] = float(std::sin(ang));
+        }
+}
+
+sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
+{
+    if (cfg.window_size < 1 || cfg.axis_points < 2 || cfg.num_pairs < 1 || cfg.hop < 1 || !(cfg.sample_rate >= 1)) {
+        err = "invalid spectrum config (window_size>=1, axis_points>=2 (TransformConstant.h:127), num_pairs>=1, hop>=1, sample_rate>=1)";
+        return SGZ_EINVAL;
+    }
+    if (cfg.channel_mode > SGZ_CH_COMPLEX || cfg.bin_interp > SGZ_INTERP_LANCZOS || cfg.view_scaling > SGZ_VIEW_LOG ||
+        cfg.window_type >= SGZ_WIN_END) {
+        err = "invalid enum value in spectrum config";
+        return SGZ_EINVAL;
+    }
+    if (cfg.channel_mode == SGZ_CH_PHASE) {
+        err = "SpectrumChannels::Phase is not built yet";
+        return SGZ_EUNSUPPORTED;
+    }
+    p.cfg = cfg;
+    p.W = cfg.window_size;
+    p.N = transformSizeFor(p.W);
+    p.log2N = 0; while ((1u << p.log2N) < p.N) ++p.log2N;
+    p.P = cfg.axis_points;
+    p.C = cfg.num_pairs;
+    p.sides = (cfg.channel_mode == SGZ_CH_SEPARATE || cfg.channel_mode == SGZ_CH_MIDSIDE) ? 2 : 1;
+    p.stateChannels = cfg.channel_mode > SGZ_CH_SIDE ? 2 : 1;
+
+    // windowKernel (N entries; [W,N) stay zero = the zero padding of prepareTransform :220-223)
+    p.window.assign(p.N, 0.0f);
+    p.windowScale = designWindow(cfg.window_type, cfg.window_symmetry, cfg.window_alpha, cfg.window_beta, p.W, p.window.data());
+
+    // mappedFrequencies, TransformConstant.h:125-180
+    p.mapped.resize(p.P);
+    {
+        const double viewSize = cfg.view_right - cfg.view_left;
+        const double sampleRate = double(cfg.sample_rate);
+        if (cfg.view_scaling == SGZ_VIEW_LINEAR) {
+            const double halfSampleRate = sampleRate * 0.5;
+            const double complexFactor = cfg.channel_mode == SGZ_CH_COMPLEX ? 2.0 : 1.0;
+            const double freqPerPixel = halfSampleRate / double(p.P - 1);
+            for (uint32_t i = 0; i < p.P; ++i)
+                p.mapped[i] = float(complexFactor * cfg.view_left * halfSampleRate + complexFactor * viewSize * double(i) * freqPerPixel);
+        } else {
+            const double sampleSize = double(p.P - 1);
+            const double minFreq = cfg.min_log_freq;
+            const double end = double(cfg.sample_rate / 2);
+            for (uint32_t i = 0; i < p.P; ++i) {
+                if (cfg.channel_mode != SGZ_CH_COMPLEX) {
+                    p.mapped[i] = float(minFreq * std::pow(end / minFreq, cfg.view_left + viewSize * (double(i) / sampleSize)));
+                } else {
+                    double arg = cfg.view_left + viewSize * double(i) / sampleSize;
+                    if (arg < 0.5) p.mapped[i] = float(minFreq * std::pow(end / minFreq, arg * 2));
+                    else {
+                        arg -= 0.5;
+                        const double power = minFreq * std::pow(end / minFreq, 1.0 - arg * 2);
+                        p.mapped[i] = float(end + (end - power));
+                    }
+                }
+            }
+        }
+    }
+    // slopeMap, TransformConstant.h:109-118
+    p.slope.resize(p.P);
+    {
+        const float a = float(cfg.slope_a), b = float(cfg.slope_b);
+        for (uint32_t i = 0; i < p.P; ++i) p.slope[i] = b * float(std::pow(double(p.mapped[i]), double(a)));
+    }
+    // scalars
+    DeviceScalars &s = p.scalars;
+    s.invSize = float(p.windowScale / (double(p.W) * 0.5));
+    for (int k = 0; k < SGZ_NUM_GRAPHS; ++k) s.pole[k] = cfg.pole[k];
+    {
+        const double lowerFraction = std::pow(10.0, cfg.low_db / 20.0);
+        const double upperFraction = std::pow(10.0, cfg.high_db / 20.0);
+        s.deltaYRecip = float(1.0 / std::log(upperFraction / lowerFraction));
+        s.minFracRecip = float(1.0 / lowerFraction);
+        s.lowerClip = float(cfg.clip_db);
+    }
+    {   // Spectrum::calculateSpectrumColourRatios, Spectrum.cpp:226-246
+        double acc = 0.0, vals[SGZ_NUM_SPEC_COLOURS];
+        for (int i = 0; i < SGZ_NUM_SPEC_COLOURS; ++i) { vals[i] = std::max(0.0001, cfg.ratios[i]); acc += vals[i]; }
+        acc += double(FLT_EPSILON);
+        s.ratios[0] = 0;
+        for (int i = 0; i < SGZ_NUM_SPEC_COLOURS; ++i) s.ratios[i + 1] = float(vals[i] / acc);
+    }
+    // colour stops per pair: generateSpectrogramColourRotation (TransformConstant.h:55-65) through
+    // ColourRotation::operator[] (CommonSignalizer.h:931-937) and FloatColour (:1139-1163)
+    p.colourTables.resize(size_t(p.C) * (SGZ_NUM_SPEC_COLOURS + 1) * 3);
+    for (uint32_t pair = 0; pair < p.C; ++pair)
+        for (int i = 0; i <= SGZ_NUM_SPEC_COLOURS; ++i) {
+            const uint32_t rotation = i == 0 ? 0u : pair;
+            uint8_t rgb[3];
+            rotateHueRgb8(cfg.colours[i], float(rotation) / float(p.C), rgb);
+            for (int c = 0; c < 3; ++c)
+                p.colourTables[(size_t(pair) * (SGZ_NUM_SPEC_COLOURS + 1) + i) * 3 + c] = float(rgb[c]) / 255.0f;
+        }
+    buildPixelRecords(p);
+    buildTwiddles(p);
+    return SGZ_OK;
+}
+
+}  // namespace sgz

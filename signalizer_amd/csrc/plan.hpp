@@ -1,0 +1,77 @@
+// plan.hpp -- host-side "constant block" of the Spectrum path (the MI355X counterpart of
+// Signalizer::TransformConstant<float>, Source/Spectrum/TransformConstant.h:48-241) and the device
+// tables derived from it.  Built on the CPU in fp64 with the reference's expression order, uploaded once.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sgz.h"
+
+namespace sgz {
+
+constexpr int kMaxTaps = 10;   // Lanczos a=5 => 10 taps (TransformDSP.inl:514, lanczosFilterSize = 5)
+
+// One record per (side, pixel): how mapToLinearSpace produces csp[x] (TransformDSP.inl:565-639, :878-984).
+struct PixelRec {
+    int32_t kind;    // 0 = interpolate (None/Linear/Lanczos taps), 1 = arg-max of |X|^2 over a bin run
+    int32_t a;       // interp: first tap index into csf (already wrapped into [0,N]); max: first offset
+    int32_t b;       // interp: number of taps;                                           max: run length (>=1)
+    int32_t c;       // interp: offset of this pixel's weights in the weight table;         max: fallback bin
+};
+
+// Scalars the kernels need (all derived on the host exactly as the reference derives them).
+struct DeviceScalars {
+    float invSize;        // windowKernelScale / (W/2), TransformDSP.inl:540
+    float pole[SGZ_NUM_GRAPHS];
+    float deltaYRecip;    // 1 / ln(upper/lower), TransformDSP.inl:1311
+    float minFracRecip;   // 1 / lower,           :1312
+    float lowerClip;      // (float)clipDB,       :1314
+    float ratios[SGZ_NUM_SPEC_COLOURS + 1];   // normalizedSpecRatios, Spectrum.cpp:226-246
+};
+
+struct Plan {
+    sgz_spectrum_config cfg{};
+    uint32_t N = 0, W = 0, P = 0, C = 0;
+    int log2N = 0;
+    int sides = 1;              // 2 for Separate/MidSide (left at csp[0,P), right at csp[P,2P))
+    int stateChannels = 1;      // TransformConstant::getStateConfigurationChannels, TransformConstant.h:183-186
+    double windowScale = 1.0;   // windowKernelScale
+    uint32_t breakPixel = 0;
+
+    // host tables
+    std::vector<float> window;          // N entries, [W,N) zero   (windowKernel)
+    std::vector<float> mapped;          // P   (mappedFrequencies)
+    std::vector<float> slope;           // P   (slopeMap)
+    std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
+    std::vector<PixelRec> recs;         // sides * P
+    std::vector<float> weights;         // packed tap weights
+    std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels
+    DeviceScalars scalars{};
+
+    // device mirrors (owned)
+    bool uploaded = false;
+    float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
+    float *d_tw1 = nullptr, *d_tw2 = nullptr;
+    PixelRec *d_recs = nullptr;
+    // work buffers (grown on demand)
+    float *d_mapped = nullptr; size_t mappedCap = 0;      // [frames][pairs][2][P]
+    float *d_agg = nullptr; size_t aggCap = 0;            // decay chunk aggregates
+    float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
+    float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
+    int device = 0;
+
+    ~Plan();
+};
+
+// Builds every host table; returns SGZ_OK or an error (message in `err`).
+sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &plan, std::string &err);
+sgz_status uploadPlan(Plan &plan, std::string &err);
+
+void rotateHueRgb8(const uint8_t rgb[3], float amount, uint8_t out[3]);
+double designWindow(uint32_t type, uint32_t symmetry, double alpha, double beta, uint32_t W, float *out);
+uint32_t transformSizeFor(uint32_t W);
+double lanczosKernel(double d, int a);
+
+}  // namespace sgz

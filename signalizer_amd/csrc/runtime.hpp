@@ -1,0 +1,28 @@
+// runtime.hpp -- internal helpers shared by api.hip and realtime.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace sgz {
+extern thread_local std::string g_lastError;
+sgz_status fail(sgz_status st, const std::string &msg);
+sgz_status hipFail(hipError_t e, const char *what);
+#define SGZ_HIP(call)                                        \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return ::sgz::hipFail(_e, #call); \
+    } while (0)
+
+sgz_status ensureCap(float **buf, size_t *cap, size_t need);
+int numCUs();
+// K_A over `frames` frames (ideal STFT framing from d_planar); any of mapped/binsOut may be null
+sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
+                   float *d_binsOut, const float *d_binsIn, hipStream_t stream);
+// K_B: decay recurrence + dB map + colour blend
+sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
+                          float *d_state, hipStream_t stream);
+}  // namespace sgz

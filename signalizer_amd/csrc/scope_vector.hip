@@ -1,0 +1,438 @@
+// scope_vector.hip -- Oscilloscope and Vectorscope kernels + their C-ABI entry points.  gfx950 only.
+//
+//  K9  sgz_scope_lanczos_device        drawWavePlot, Lanczos branch  (Source/Oscilloscope/OscilloscopeRendering.cpp:790-891)
+//  K10 sgz_scope_zero_crossing_device  ZeroCrossingProcessor::process (Source/Oscilloscope/StreamPreprocessing.h:315-349)
+//  K11 sgz_peak_filter_device          runPeakFilter (OscilloscopeDSP.inl:713-886, VectorscopeRendering.cpp:826-889)
+//  K12 sgz_vector_polar_device         drawPolarPlot (Source/Vectorscope/VectorscopeRendering.cpp:500-746)
+//  K13 sgz_vector_audio_processing_device  Processor::audioProcessing (Source/Vectorscope/Vectorscope.cpp:268-377)
+// All are HBM-bound elementwise / scan work: coalesced loads, wave shuffles, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "runtime.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace sgz;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- K9
+struct ScopeScalars { double samplePos0, inc, samplesPerPixel, unit0, right; long cursor0; size_t points; };
+
+ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len)
+{
+    ScopeScalars s{};
+    const double horizontalDelta = v.right - v.left;
+    const double sizeMinusOne = std::max(1.0, v.window_size - 1);                            // :568
+    const double pixelsPerSample = v.rendering_scale * std::fabs((double(v.width) - 1) / (sizeMinusOne * horizontalDelta));   // :572
+    const double sampleOffset = (v.window_size * 0.5 - double(int(v.window_size * 0.5))) - 1.5;   // OscilloscopeDSP.inl:238
+    s.inc = horizontalDelta / (v.rendering_scale * (double(v.width) - 1));                   // :822
+    s.samplesPerPixel = 1.0 / pixelsPerSample;                                               // :824
+    s.unit0 = v.left;
+    s.right = v.right;
+    s.samplePos0 = sampleOffset + (-s.unit0 / s.inc * s.samplesPerPixel);                    // :826
+    size_t n = 0;
+    double unitSpacePos = s.unit0;
+    do { unitSpacePos += s.inc; ++n; } while (unitSpacePos < (s.right + s.inc));             // :883-889
+    s.points = n;
+    if (len) {
+        long c = (-long(std::floor(s.samplePos0)) - 10) % long(len);                         // :829, KernelSize = 10
+        if (c < 0) c += long(len);
+        s.cursor0 = c;
+    }
+    return s;
+}
+
+__constant__ double kCosPiI10[21];
+__constant__ double kSinPiI10[21];
+
+// one thread per output point.  y = sum_i ring[cursor + i] * L(10 + delta - i), L = Lanczos a = 10, fp64.
+__global__ void __launch_bounds__(256)
+scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channels, size_t points,
+                   double samplePos0, double spp, double unit0, double inc, long cursor0, float2 *xy)
+{
+    const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= points) return;
+    // closed form of the reference's running sums (currentSample += spp; samplePos += 1 while delta > 1)
+    const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
+    const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
+    const double delta = D - shifts;
+    const double x = 10.0 + delta;
+    const long fl = long(floor(x));
+    long cur = (cursor0 + long(shifts)) % long(len);
+    const double kPi = 3.14159265358979323846;
+    // sin(pi (x - i)) = (-1)^i sin(pi x);  sin(pi (x - i)/10) = s10 cos(pi i/10) - c10 sin(pi i/10)
+    const double sPi = sin(kPi * x);
+    double s10, c10;
+    sincos(kPi * x / 10.0, &s10, &c10);
+    const float ux = float(unit0 + double(p) * inc);
+    for (uint32_t c = 0; c < channels; ++c) {
+        const float *r = ring + size_t(c) * stride;
+        double acc = 0.0;
+        for (long i = fl - 9; i <= fl + 10; ++i) {
+            if (i < 0 || i >= 21) continue;
+            long idx = cur + i; if (idx >= long(len)) idx -= long(len);
+            const double d = x - double(i);
+            double w;
+            if (d == 0.0) w = 1.0;
+            else {
+                const double pd = kPi * d;
+                const double sa = (i & 1) ? -sPi : sPi;
+                const double sb = s10 * kCosPiI10[i] - c10 * kSinPiI10[i];
+                w = 10.0 * sa * sb / (pd * pd);
+            }
+            acc += double(r[idx]) * w;
+        }
+        xy[size_t(c) * points + p] = make_float2(ux, float(acc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K10
+// One workgroup scans the whole block: each thread owns a contiguous segment.
+struct ZcResult { unsigned long long lastArm; unsigned long long count; int armed; int anyArm; double lastSample; };
+
+__device__ __forceinline__ double zcSample(uint32_t mode, const float *a, const float *b, size_t i)
+{
+    switch (mode) {
+    case SGZ_OSC_MID: case SGZ_OSC_MIDSIDE: return double(0.5f * (a[i] + b[i]));   // OscilloscopeDSP.inl:371-376
+    case SGZ_OSC_SIDE: return double(0.5f * (a[i] - b[i]));                         // :377-382
+    default: return double(a[i]);
+    }
+}
+
+// Sequential automaton (StreamPreprocessing.h:331-347):  arm_i = (s_i > 0 && s_{i-1} < 0) sets armed and
+// crossOrigin = clock + i;  then if (armed && s_i > threshold) { armed = false; push(crossOrigin); }.
+// Closed form: with lastArm(i) = max{j <= i : arm_j} and lastThr(i) = max{k <= i : s_k > threshold},
+//   fire_i  <=>  s_i > threshold  &&  lastArm(i) > lastThr(i-1),   value = clock + lastArm(i)
+// (virtual indices: an arm inherited from the previous block sits at -1, "none" at -3, no threshold yet -2).
+// So the trigger list is two prefix-max scans + an ordered compaction.
+__global__ void __launch_bounds__(1024)
+zeroCrossingKernel(uint32_t mode, const float *a, const float *b, size_t n, double prevState, double threshold,
+                   int armedIn, unsigned long long originIn, unsigned long long clockPlusCount,
+                   unsigned long long *out, size_t maxOut, ZcResult *res)
+{
+    __shared__ long long sArm[1024], sThr[1024];
+    __shared__ unsigned int sCnt[1024];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const size_t seg = (n + T - 1) / T;
+    const size_t i0 = min(n, size_t(tid) * seg), i1 = min(n, i0 + seg);
+    long long segArm = -4, segThr = -4;                 // -4: no event in this segment
+    for (size_t i = i0; i < i1; ++i) {
+        const double s = zcSample(mode, a, b, i);
+        const double prev = i ? zcSample(mode, a, b, i - 1) : prevState;
+        if (s > 0 && prev < 0) segArm = (long long)i;
+        if (s > threshold) segThr = (long long)i;
+    }
+    sArm[tid] = segArm; sThr[tid] = segThr;
+    __syncthreads();
+    if (tid == 0) {                                     // exclusive prefix-max over the 1024 segments
+        long long ca = armedIn ? -1 : -3, ct = -2;
+        for (int t = 0; t < T; ++t) {
+            const long long la = sArm[t], lt = sThr[t];
+            sArm[t] = ca; sThr[t] = ct;
+            if (la > -4) ca = la;
+            if (lt > -4) ct = lt;
+        }
+    }
+    __syncthreads();
+    const long long inArm = sArm[tid], inThr = sThr[tid];
+    long long la = inArm, lt = inThr;
+    unsigned int fires = 0;
+    for (size_t i = i0; i < i1; ++i) {                  // count
+        const double s = zcSample(mode, a, b, i);
+        const double prev = i ? zcSample(mode, a, b, i - 1) : prevState;
+        if (s > 0 && prev < 0) la = (long long)i;
+        if (s > threshold) { if (la > lt) ++fires; lt = (long long)i; }
+    }
+    sCnt[tid] = fires;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int acc = 0;
+        for (int t = 0; t < T; ++t) { const unsigned int c = sCnt[t]; sCnt[t] = acc; acc += c; }
+        res->count = acc;
+    }
+    __syncthreads();
+    size_t pos = sCnt[tid];
+    la = inArm; lt = inThr;
+    for (size_t i = i0; i < i1; ++i) {                  // ordered write
+        const double s = zcSample(mode, a, b, i);
+        const double prev = i ? zcSample(mode, a, b, i - 1) : prevState;
+        if (s > 0 && prev < 0) la = (long long)i;
+        if (s > threshold) {
+            if (la > lt) {
+                if (pos < maxOut) out[pos] = (la == -1) ? originIn : clockPlusCount + (unsigned long long)la;
+                ++pos;
+            }
+            lt = (long long)i;
+        }
+    }
+    if (tid == T - 1) {                                 // state after the whole block
+        res->armed = (la > lt) ? 1 : 0;
+        res->anyArm = la >= 0 ? 1 : 0;
+        res->lastArm = la >= 0 ? (unsigned long long)la : 0ull;
+        res->lastSample = n ? zcSample(mode, a, b, n - 1) : prevState;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K11
+__global__ void __launch_bounds__(1024)
+peakKernel(const float *ch, size_t stride, size_t stop, float *peaks)
+{
+    __shared__ float sm[16];
+    const float *x = ch + size_t(blockIdx.x) * stride;
+    float m = 0.f;
+    for (size_t i = threadIdx.x; i < stop; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) r = fmaxf(r, sm[w]);
+        peaks[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K12
+__global__ void __launch_bounds__(256)
+vectorPolarKernel(const float *planar, size_t stride, uint32_t pairs, size_t n, uint32_t lanes, float3 *xyz)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t pair = blockIdx.y;
+    if (i >= n) return;
+    const float l = planar[size_t(2 * pair) * stride + i];
+    const float r = planar[size_t(2 * pair + 1) * stride + i];
+    const float cosineRotation = -0.70710678118654752440f, sineRotation = 0.70710678118654752440f;   // :521-524
+    const float length = fmaxf(fabsf(l), fabsf(r));                                                 // :563
+    const float vY = l * cosineRotation - r * sineRotation;                                          // :566
+    const float vX = l * sineRotation + r * cosineRotation;                                          // :567
+    float angle = atanf(vX / vY);                                                                    // :576
+    if (l == 0.f && r == 0.f) angle = 0.f;                                                           // :578
+    float sx, cy;
+    sincosf(angle, &sx, &cy);
+    // fade ramp: SIMD body for i < mainEnd (vSampleFade lane ramp), scalar tail afterwards (:528-543,:592,:600-634)
+    const float fadePerSample = 1.0f / float(n);
+    const long V = long(lanes);
+    const long iters = (long(n) > V) ? (long(n) - 1) / V : 0;
+    const long mainEnd = iters * V;
+    float fade;
+    if (long(i) < mainEnd) {
+        const long k = long(i) / V, lane = long(i) % V;
+        // vSampleFade[lane] = fl(fadePerSample*lane) (+)= fl(fadePerSample*V), k times
+        float f = fadePerSample * float(lane);
+        const float incr = fadePerSample * float(V);
+        for (long t = 0; t < k; ++t) f += incr;
+        fade = f - 1.0f;
+    } else {
+        float base;
+        if (iters > 0) {
+            float f = fadePerSample * float(V - 1);
+            const float incr = fadePerSample * float(V);
+            for (long t = 0; t < iters - 1; ++t) f += incr;
+            base = f - 1.0f;                                  // outFade[vectorLength-1] of the last SIMD iteration
+        } else base = fadePerSample * float(V - 1);           // never written: initial ramp value (:535-538)
+        fade = base - float(long(i) - mainEnd) * fadePerSample;
+    }
+    xyz[size_t(pair) * n + i] = make_float3(sx * length, cy * length, fade);
+}
+
+// ------------------------------------------------------------------------------------------- K13
+struct VecState { float env[2]; float bal[2][2]; float phase[2]; };
+
+__global__ void __launch_bounds__(64)
+vectorAudioKernel(const float *L, const float *R, size_t n, float envelope, float pole0, float pole1, VecState *st)
+{
+    __shared__ float sL[64], sR[64], sP[64];
+    const int lane = threadIdx.x;
+    // lane k < 8 owns one recurrence: 0,1 env L/R; 2,3 slow balance L/R; 4,5 fast balance L/R; 6 slow phase; 7 fast phase
+    float y = 0.f, a = 0.f;
+    if (lane < 8) {
+        const float *s = reinterpret_cast<const float *>(st);
+        y = s[lane];
+        a = lane < 2 ? envelope : ((lane == 2 || lane == 3 || lane == 6) ? pole0 : pole1);
+    }
+    const int sel = (lane == 0 || lane == 2 || lane == 4) ? 0 : ((lane == 1 || lane == 3 || lane == 5) ? 1 : 2);
+    for (size_t base = 0; base < n; base += 64) {
+        const size_t i = base + lane;
+        if (i < n) {
+            const float l = L[i], r = R[i];
+            const float mReal = -0.70710678118654752440f, mImag = 0.70710678118654752440f;
+            const float vX = l * mReal - r * mImag;                        // Vectorscope.cpp:303
+            const float vY = r * mImag + l * mReal;                        // :304
+            const float radians = atanf(vY / vX);                          // :310
+            const float ang = (vX == 0.f && vY == 0.f) ? 0.78539816339744830962f : radians;   // :311
+            sP[lane] = cosf(ang * 2.0f);                                   // :316
+            sL[lane] = l * l; sR[lane] = r * r;                            // :323-324
+        }
+        __syncthreads();
+        if (lane < 8) {
+            const float *src = sel == 0 ? sL : (sel == 1 ? sR : sP);
+            const int m = int(min(size_t(64), n - base));
+            for (int k = 0; k < m; ++k) { const float x = src[k]; y = x + a * (y - x); }   // :327-342
+        }
+        __syncthreads();
+    }
+    if (lane < 8) reinterpret_cast<float *>(st)[lane] = y;
+}
+
+float *g_scratch = nullptr;
+size_t g_scratchBytes = 0;
+sgz_status scratch(size_t bytes, void **out)
+{
+    if (g_scratchBytes < bytes) {
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr; g_scratchBytes = 0;
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&g_scratch), bytes));
+        g_scratchBytes = bytes;
+    }
+    *out = g_scratch;
+    return SGZ_OK;
+}
+
+bool g_constInit = false;
+sgz_status initConst()
+{
+    if (g_constInit) return SGZ_OK;
+    double c[21], s[21];
+    const double kPi = 3.14159265358979323846;
+    for (int i = 0; i < 21; ++i) { c[i] = std::cos(kPi * i / 10.0); s[i] = std::sin(kPi * i / 10.0); }
+    SGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kCosPiI10), c, sizeof(c)));
+    SGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kSinPiI10), s, sizeof(s)));
+    g_constInit = true;
+    return SGZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sgz_scope_num_points(const sgz_scope_view *view)
+{
+    if (!view || view->width < 2 || !(view->right > view->left)) return 0;
+    return scopeDerive(*view, 0).points;
+}
+
+sgz_status sgz_scope_lanczos_device(const sgz_scope_view *view, const float *d_ring, size_t len, size_t stride,
+                                    uint32_t channels, float *d_xy, void *stream)
+{
+    if (!view || !d_ring || !d_xy || len == 0 || view->width < 2 || !(view->right > view->left))
+        return fail(SGZ_EINVAL, "bad scope arguments");
+    sgz_status st = initConst();
+    if (st != SGZ_OK) return st;
+    const ScopeScalars s = scopeDerive(*view, len);
+    const int block = 256;
+    const unsigned grid = unsigned((s.points + block - 1) / block);
+    hipLaunchKernelGGL(scopeLanczosKernel, dim3(grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream), d_ring, len,
+                       stride, channels, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0,
+                       reinterpret_cast<float2 *>(d_xy));
+    SGZ_HIP(hipGetLastError());
+    return SGZ_OK;
+}
+
+sgz_status sgz_scope_zero_crossing_device(sgz_zero_crossing_state *zs, uint32_t osc_mode, const float *d_a, const float *d_b,
+                                          size_t n, uint64_t *d_triggers, size_t max_triggers, size_t *num_triggers,
+                                          void *stream)
+{
+    if (!zs || !d_a || !d_triggers || !num_triggers) return fail(SGZ_EINVAL, "null argument");
+    if (!d_b) d_b = d_a;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    void *scr = nullptr;
+    sgz_status st = scratch(sizeof(ZcResult), &scr);
+    if (st != SGZ_OK) return st;
+    ZcResult *d_res = reinterpret_cast<ZcResult *>(scr);
+    if (n == 0) { *num_triggers = 0; return SGZ_OK; }
+    hipLaunchKernelGGL(zeroCrossingKernel, dim3(1), dim3(1024), 0, s, osc_mode, d_a, d_b, n, zs->state, zs->threshold,
+                       int(zs->armed), (unsigned long long)zs->cross_origin,
+                       (unsigned long long)(zs->steady_clock + zs->count), reinterpret_cast<unsigned long long *>(d_triggers),
+                       max_triggers, d_res);
+    SGZ_HIP(hipGetLastError());
+    ZcResult h{};
+    SGZ_HIP(hipMemcpyAsync(&h, d_res, sizeof(h), hipMemcpyDeviceToHost, s));
+    SGZ_HIP(hipStreamSynchronize(s));
+    *num_triggers = size_t(h.count);
+    if (h.anyArm) zs->cross_origin = zs->steady_clock + zs->count + h.lastArm;
+    zs->armed = h.armed;
+    zs->state = h.lastSample;
+    zs->count += n;
+    return SGZ_OK;
+}
+
+sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t channels, size_t n, uint32_t lanes,
+                                  double coeff_pow, double *env, double *gain, void *stream)
+{
+    if (!d_ch || !env || !gain || channels == 0 || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    void *scr = nullptr;
+    sgz_status st = scratch(sizeof(float) * channels + 64, &scr);
+    if (st != SGZ_OK) return st;
+    float *d_peaks = reinterpret_cast<float *>(scr);
+    const size_t stop = n - (n & size_t(lanes - 1));          // SIMD tail dropped, :740 / :860
+    hipLaunchKernelGGL(peakKernel, dim3(channels), dim3(1024), 0, s, d_ch, stride, stop, d_peaks);
+    SGZ_HIP(hipGetLastError());
+    std::vector<float> peaks(channels);
+    SGZ_HIP(hipMemcpyAsync(peaks.data(), d_peaks, sizeof(float) * channels, hipMemcpyDeviceToHost, s));
+    SGZ_HIP(hipStreamSynchronize(s));
+    double start = 0;
+    for (uint32_t c = 0; c < channels; ++c) {                  // VectorscopeRendering.cpp:873-879
+        const double highest = double(peaks[c]);
+        const float e = float(std::max(double(float(env[c])) * coeff_pow, highest * highest));
+        env[c] = double(e);
+        start = std::max(start, std::sqrt(double(e)));
+    }
+    *gain = 1.0 / start;
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_t pairs, size_t n, uint32_t lanes,
+                                   float *d_xyz, void *stream)
+{
+    if (!d_planar || !d_xyz || pairs == 0 || lanes == 0) return fail(SGZ_EINVAL, "bad argument");
+    if (n == 0) return SGZ_OK;
+    const int block = 256;
+    dim3 grid(unsigned((n + block - 1) / block), pairs);
+    hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, reinterpret_cast<hipStream_t>(stream), d_planar, stride,
+                       pairs, n, lanes, reinterpret_cast<float3 *>(d_xyz));
+    SGZ_HIP(hipGetLastError());
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float *d_left, const float *d_right, size_t n,
+                                              uint32_t lanes, float envelope_coeff, float stereo_coeff, float second_speed,
+                                              int env_mode, float *gain_out, void *stream)
+{
+    if (!f || !d_left || !d_right || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    void *scr = nullptr;
+    sgz_status st = scratch(sizeof(VecState), &scr);
+    if (st != SGZ_OK) return st;
+    VecState h{};
+    h.env[0] = f->env[0]; h.env[1] = f->env[1];
+    // lane order of the kernel: env L,R ; slow bal L,R ; fast bal L,R ; slow phase ; fast phase
+    h.bal[0][0] = f->balance[0][0]; h.bal[0][1] = f->balance[0][1];
+    h.bal[1][0] = f->balance[1][0]; h.bal[1][1] = f->balance[1][1];
+    h.phase[0] = f->phase[0]; h.phase[1] = f->phase[1];
+    SGZ_HIP(hipMemcpyAsync(scr, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    n -= n & size_t(lanes - 1);                                               // Vectorscope.cpp:292
+    const float pole1 = std::pow(stereo_coeff, second_speed);                 // :281
+    if (n) {
+        hipLaunchKernelGGL(vectorAudioKernel, dim3(1), dim3(64), 0, s, d_left, d_right, n, envelope_coeff, stereo_coeff, pole1,
+                           reinterpret_cast<VecState *>(scr));
+        SGZ_HIP(hipGetLastError());
+    }
+    SGZ_HIP(hipMemcpyAsync(&h, scr, sizeof(h), hipMemcpyDeviceToHost, s));
+    SGZ_HIP(hipStreamSynchronize(s));
+    if (env_mode == 1) {                                                      // :346-363
+        const double currentEnvelope = 1.0 / std::max(std::sqrt(double(h.env[0])), std::sqrt(double(h.env[1])));
+        f->env[0] = h.env[0]; f->env[1] = h.env[1];
+        if (std::isnormal(currentEnvelope) && gain_out) *gain_out = float(currentEnvelope);
+    }
+    f->balance[0][0] = h.bal[0][0]; f->balance[0][1] = h.bal[0][1];
+    f->balance[1][0] = h.bal[1][0]; f->balance[1][1] = h.bal[1][1];
+    f->phase[0] = h.phase[0]; f->phase[1] = h.phase[1];
+    return SGZ_OK;
+}
+
+}  // extern "C"

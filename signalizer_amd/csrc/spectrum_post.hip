@@ -1,0 +1,211 @@
+// spectrum_post.hip -- K_B: peak-decay recurrence across frames, log-dB scaling and the gradient colour
+// map with additive blend over stereo pairs -> RGBA8 columns.  gfx950 only.
+//
+// Replaces TransformPair::mapAndTransformDFTFilters (Source/Spectrum/TransformDSP.inl:1299-1435) and
+// AudioDispatcher::blendAndDispatchSpectrums (Source/Spectrum/SpectrumDSP.cpp:111-206).
+//
+// The recurrence  s_t = max(fl(s_{t-1} * pole), mag_t)  is sequential in the reference.  Here time is cut
+// into chunks: because x -> fl(x * pole) is monotone, s_t = max(a_t, b_t) holds EXACTLY, where a_t is the
+// chunk-local scan started from 0 and b_t is the carry (state at the end of the previous chunk) decayed by
+// sequential fp32 multiplies.  So the chunked result is bit-identical to the sequential one; the same
+// identity carries the state across GPUs in the multi-GPU time-chunk sharding.
+//
+// fp contraction is OFF in this file: every multiply/add must round exactly as the reference's scalar code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace sgz {
+
+constexpr int kMaxChunk = 8;
+constexpr int G = SGZ_NUM_GRAPHS;
+constexpr int NC = SGZ_NUM_SPEC_COLOURS + 1;
+
+// K_B1: chunk-end aggregates.  thread <-> (chunk, pair, side, pixel); both graphs per thread.
+__global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
+{
+    const size_t perChunk = size_t(prm.C) * prm.sides * prm.P;
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= perChunk * prm.numChunks) return;
+    const uint32_t chunk = uint32_t(gid / perChunk);
+    const size_t rem = gid - size_t(chunk) * perChunk;          // (pair, side, pixel) linear
+    const uint32_t pixel = uint32_t(rem % prm.P);
+    const uint32_t ps = uint32_t(rem / prm.P);                  // pair * sides + side
+    const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
+
+    float a[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+    const long f0 = long(chunk) * prm.chunk;
+    const long f1 = min(f0 + long(prm.chunk), prm.frames);
+    for (long f = f0; f < f1; ++f) {
+        const float mag = prm.mapped[size_t(f) * perChunk + rem];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            a[k] = a[k] * prm.sc.pole[k];                       // states[i] *= pole, TransformDSP.inl:1336,:1370
+            if (mag > a[k]) a[k] = mag;                         // :1338-1341
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        prm.agg[((size_t(chunk) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] = a[k];
+}
+
+__device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalars &sc)
+{
+    const float deltaX = slope * st * sc.minFracRecip;          // :1343 (left-to-right fp32)
+    // std::log(float): evaluated in fp64 and rounded once (matches a correctly rounded logf)
+    return deltaX > 0.f ? float(log(double(deltaX))) * sc.deltaYRecip : sc.lowerClip;   // :1345
+}
+
+// K_B2: carry fix-up + dB map + colour blend.  thread <-> (chunk, pixel); loops pairs, sides, graphs.
+__global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(prm.P) * prm.numChunks) return;
+    const uint32_t chunk = uint32_t(gid / prm.P);
+    const uint32_t pixel = uint32_t(gid - size_t(chunk) * prm.P);
+    const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
+    const long f0 = long(chunk) * prm.chunk;
+    const long f1 = min(f0 + long(prm.chunk), prm.frames);
+    const int len = int(f1 - f0);
+    const float slope = prm.slope[pixel];
+
+    float cb[kMaxChunk][3];
+#pragma unroll
+    for (int t = 0; t < kMaxChunk; ++t) cb[t][0] = cb[t][1] = cb[t][2] = 0.f;   // colourBuffer, SpectrumDSP.cpp:170-174
+
+    for (uint32_t pair = 0; pair < prm.C; ++pair) {
+        const float *sca = prm.colourTables + size_t(pair) * NC * 3;
+        for (uint32_t side = 0; side < prm.sides; ++side) {
+            const uint32_t ps = pair * prm.sides + side;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const float pole = prm.sc.pole[k];
+                // carry = exact state at the end of chunk-1 (fold of the chunk aggregates, sequential decay)
+                float cr = 0.f;
+                if (chunk > 0) {
+                    cr = prm.agg[((size_t(0) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel];
+                    for (uint32_t d = 1; d < chunk; ++d) {
+                        for (uint32_t i = 0; i < prm.chunk; ++i) cr = cr * pole;
+                        const float ad = prm.agg[((size_t(d) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel];
+                        if (ad > cr) cr = ad;
+                    }
+                }
+                float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < kMaxChunk; ++t) {
+                    if (t < len) {
+                        const long f = f0 + t;
+                        const float mag = prm.mapped[size_t(f) * perFrame + size_t(ps) * prm.P + pixel];
+                        a = a * pole;
+                        if (mag > a) a = mag;
+                        cr = cr * pole;
+                        s = a > cr ? a : cr;
+                        const float result = dbMap(slope, s, prm.sc);
+                        if (prm.lines)
+                            prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
+                        if (side == 0 && k == 0 && prm.rgba) {
+                            // renderSf, SpectrumDSP.cpp:119-168
+                            const float intensity = result;
+                            if (!(intensity < 0.f)) {
+                                float colour[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
+                                if (intensity < 0.999f) {
+                                    float accumulatedSum = 0.f;
+                                    for (int c = 1; c < NC; ++c) {
+                                        const float nextScale = prm.sc.ratios[c];
+                                        accumulatedSum += nextScale;
+                                        if (accumulatedSum >= intensity) {
+                                            const float mn = accumulatedSum - nextScale;
+                                            const float mx = accumulatedSum;
+                                            const float mix = (intensity - mn) / (mx - mn);
+                                            const float imix = 1.f - mix;
+                                            const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
+                                            colour[0] = ca[0] * imix + cbb[0] * mix;
+                                            colour[1] = ca[1] * imix + cbb[1] * mix;
+                                            colour[2] = ca[2] * imix + cbb[2] * mix;
+                                            break;
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) cb[t][c] += (1.f - cb[t][c]) * colour[c];   // GL_ONE_MINUS_SRC_COLOR
+                            }
+                        }
+                    }
+                }
+                if (prm.state && f1 == prm.frames && len > 0)
+                    prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = s;
+            }
+        }
+    }
+    if (prm.rgba) {
+#pragma unroll
+        for (int t = 0; t < kMaxChunk; ++t) {
+            if (t < len) {
+                uchar4 px;
+                px.x = (unsigned char)(cb[t][0] * 255.f);       // static_cast<uint8_t>(c * maxByte), :195-198
+                px.y = (unsigned char)(cb[t][1] * 255.f);
+                px.z = (unsigned char)(cb[t][2] * 255.f);
+                px.w = 255;
+                reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f0 + t) * prm.P + pixel] = px;
+            }
+        }
+    }
+}
+
+// carry-in state of rank `rank` from every rank's zero-carry end state (see sgz.h, sgz_decay_fold_carry)
+struct FoldFrames { long long f[64]; };
+__global__ void __launch_bounds__(256)
+decayFoldKernel(const float *aggs, FoldFrames frames, uint32_t rank, size_t perRank, uint32_t P, float pole0, float pole1,
+                float *carry)
+{
+    const size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= perRank) return;
+    const uint32_t k = uint32_t((e / (size_t(P) * 2)) % G);
+    const float pole = k == 0 ? pole0 : pole1;
+    float c = 0.f;
+    for (uint32_t q = 0; q < rank; ++q) {
+        for (long long i = 0; i < frames.f[q]; ++i) c = c * pole;
+        const float a = aggs[size_t(q) * perRank + e];
+        if (a > c) c = a;
+    }
+    carry[e] = c;
+}
+
+hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
+                           uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream)
+{
+    if (world > 64) return hipErrorInvalidValue;
+    FoldFrames fr{};
+    for (uint32_t q = 0; q < world; ++q) fr.f[q] = framesPerRank[q];
+    const int block = 256;
+    const unsigned grid = unsigned((perRank + block - 1) / block);
+    hipLaunchKernelGGL(decayFoldKernel, dim3(grid), dim3(block), 0, stream, aggs, fr, rank, perRank, P, sc.pole[0], sc.pole[1], carry);
+    return hipGetLastError();
+}
+
+hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream)
+{
+    const size_t total = size_t(prm.C) * prm.sides * prm.P * prm.numChunks;
+    const int block = 256;
+    const unsigned grid = unsigned((total + block - 1) / block);
+    hipLaunchKernelGGL(decayLocalKernel, dim3(grid), dim3(block), 0, stream, prm);
+    return hipGetLastError();
+}
+
+hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream)
+{
+    const size_t total = size_t(prm.P) * prm.numChunks;
+    const int block = 256;
+    const unsigned grid = unsigned((total + block - 1) / block);
+    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(block), 0, stream, prm);
+    return hipGetLastError();
+}
+
+}  // namespace sgz

@@ -1,0 +1,203 @@
+"""GPU parity tests of the Spectrum path: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Bars (north star): bit-exact for the integer colour map (and every stage whose inputs are identical),
+a stated fp32 tolerance for spectral magnitudes.
+  * bins (window x FFT x split x |.|): |gpu - oracle| <= 4e-6 * max|X| per bin   (different but correct
+    fp32 butterfly orders; the oracle itself is 2e-7*max away from numpy fp64)
+  * pixel mapping given identical bins: bit-exact
+  * decay + dB + colour given identical mapped magnitudes: RGBA8 bit-exact, lines within 1 ulp (logf)
+  * end to end: RGBA8 channel values differ by at most 1 LSB on at most 0.5 % of the bytes
+"""
+import numpy as np
+import pytest
+
+from signalizer_amd import api, config, synth
+
+pytestmark = pytest.mark.gpu
+
+BIN_TOL = 4e-6
+
+
+def _planar_cuda(x, gpu):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to(gpu)
+
+
+def _oracle_bins(po, p, x, frames, hop, W):
+    """oracle csf[0..N] after split/abs for each frame (pair 0.. )"""
+    C = p.num_pairs
+    N = po.lib().sgzo_transform_size(W)
+    out = np.zeros((frames, C, N + 1), np.float32)
+    raws = []
+    for f in range(frames):
+        for c in range(C):
+            L = x[2 * c, f * hop:f * hop + W]
+            R = x[2 * c + 1, f * hop:f * hop + W]
+            raw, csf, csp = po.frame_bins(p, L, R)
+            out[f, c] = csf.real
+    return out
+
+
+@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2small", "midside", "left", "w3000"])
+def test_bins_tolerance(gpu, oracle, cfgname):
+    po = oracle
+    cfg = {
+        "cfg1": config.cfg1(),
+        "cfg2small": config.cfg2(),
+        "midside": config.spectrum_config(channel_mode=config.CH_MIDSIDE, window_type=config.WIN_BLACKMAN_HARRIS),
+        "left": config.spectrum_config(channel_mode=config.CH_LEFT, window_size=4096, hop=1024),
+        "w3000": config.spectrum_config(window_size=3000, hop=750, window_type=config.WIN_KAISER, window_beta=8.0,
+                                        window_symmetry=config.WIN_SYMMETRIC),
+    }[cfgname]
+    W, hop = cfg["window_size"], cfg["hop"]
+    frames = 3
+    S = W + (frames - 1) * hop
+    x = synth.gen(11, cfg["sample_rate"], S, 2)
+    p = po.params_from_dict(cfg)
+    plan = api.Plan(cfg).upload()
+    bins = plan.stage_bins(_planar_cuda(x, gpu)).cpu().numpy()
+    ref = _oracle_bins(po, p, x, frames, hop, W)
+    assert bins.shape == ref.shape
+    if plan.sides == 1:
+        # mono modes: the oracle keeps bins >= N/2 as raw complex (TransformDSP.inl:557-560); compare the |.| region
+        nb = plan.N // 2
+        bins, ref = bins[..., :nb], ref[..., :nb]
+    err = np.abs(bins - ref).max()
+    scale = np.abs(ref).max()
+    assert err <= BIN_TOL * scale, (err, scale, err / scale)
+
+
+@pytest.mark.parametrize("interp", [config.INTERP_NONE, config.INTERP_LINEAR, config.INTERP_LANCZOS])
+@pytest.mark.parametrize("view", [config.VIEW_LOG, config.VIEW_LINEAR])
+def test_mapping_bit_exact_given_bins(gpu, oracle, interp, view):
+    """mapToLinearSpace (TransformDSP.inl:871-985) on identical csf magnitudes must match bit for bit."""
+    import torch
+    po = oracle
+    cfg = config.spectrum_config(window_size=4096, hop=4096, bin_interp=interp, view_scaling=view, axis_points=700)
+    p = po.params_from_dict(cfg)
+    x = synth.gen(5, 48000, 4096 * 2, 2)
+    plan = api.Plan(cfg).upload()
+    frames = 2
+    csfs = np.zeros((frames, 1, plan.N + 1), np.float32)
+    want = np.zeros((frames, 1, 2, plan.P), np.float32)
+    for f in range(frames):
+        raw, csf, csp = po.frame_bins(p, x[0, f * 4096:(f + 1) * 4096], x[1, f * 4096:(f + 1) * 4096])
+        csfs[f, 0] = csf.real
+        v = csp.reshape(2, plan.P)
+        want[f, 0] = np.sqrt((v.real * v.real + v.imag * v.imag).astype(np.float32)).astype(np.float32)
+    got = plan.stage_map_from_bins(torch.from_numpy(csfs).to(gpu)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+
+
+def test_decay_colour_bit_exact_given_mapped(gpu, oracle):
+    """mapAndTransformDFTFilters + blendAndDispatchSpectrums on identical mapped magnitudes."""
+    import torch
+    po = oracle
+    cfg = config.spectrum_config(window_size=4096, hop=1024, num_pairs=3, axis_points=333,
+                                 ratios=(0.1, 0.3, 0.2, 0.25, 0.15), low_db=-100.0, high_db=6.0)
+    p = po.params_from_dict(cfg)
+    frames = 37                                    # > 4 time chunks: exercises the exact carry fix-up
+    S = 4096 + (frames - 1) * 1024
+    x = synth.gen(9, 48000, S, 6)
+    x[:, 20000:30000] = 0                          # silence: pure decay + clip path
+    r = po.spectrogram(p, x, want_lines=True, want_mapped=True)
+    P, C = 333, 3
+    mapped = r["mapped"].reshape(frames, C, 2, P)
+    mag = np.sqrt((mapped.real ** 2 + mapped.imag ** 2).astype(np.float32)).astype(np.float32)
+    plan = api.Plan(cfg).upload()
+    rgba, lines = plan.stage_decay_colour(torch.from_numpy(mag).to(gpu), want_lines=True)
+    rgba = rgba.cpu().numpy()
+    lines = lines.cpu().numpy()                    # [F][C][G][P][2]
+    ref_lines = r["lines"]                         # [F][C][G][P] complex (left, right)
+    ref = np.stack([ref_lines.real, ref_lines.imag], axis=-1).astype(np.float32)
+    ulp = np.abs(lines.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()               # std::log(float): device rounds log() from fp64 once
+    mism = (rgba != r["rgba"])
+    # a 1-ulp logf difference can flip a truncation: allow <= 1 LSB on <= 1e-4 of bytes
+    assert mism.mean() <= 1e-4, mism.mean()
+    assert np.abs(rgba.astype(int) - r["rgba"].astype(int)).max() <= 1
+
+
+def test_end_to_end_cfg1(gpu, oracle):
+    po = oracle
+    cfg = config.cfg1()
+    x = synth.gen(1, 48000, 4096, 2)
+    r = po.spectrogram(po.params_from_dict(cfg), x)
+    plan = api.Plan(cfg).upload()
+    rgba = plan.render(_planar_cuda(x, gpu)).cpu().numpy()
+    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
+
+
+def test_end_to_end_cfg2_8frames_and_host_wrapper(gpu, oracle):
+    po = oracle
+    cfg = config.cfg2()
+    S = 32768 + 7 * 8192
+    x = synth.gen(2, 48000, S, 2)
+    r = po.spectrogram(po.params_from_dict(cfg), x, want_lines=True)
+    rgba, lines, timing = api.render_spectrogram(cfg, x, want_lines=True)   # host-buffer C entry point
+    assert timing["frames"] == 8
+    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
+    ref = np.stack([r["lines"].real, r["lines"].imag], axis=-1)
+    ok = ref > -100                                                       # not the clip sentinel
+    assert np.abs(lines - ref)[ok].max() <= 2e-4                          # normalised dB units (1.0 = 120 dB)
+
+
+def test_multi_pair_blend(gpu, oracle):
+    po = oracle
+    cfg = config.spectrum_config(window_size=4096, hop=2048, num_pairs=4, axis_points=257)
+    x = synth.gen(21, 48000, 4096 + 5 * 2048, 8)
+    r = po.spectrogram(po.params_from_dict(cfg), x)
+    plan = api.Plan(cfg).upload()
+    rgba = plan.render(_planar_cuda(x, gpu)).cpu().numpy()
+    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3
+
+
+def test_state_carry_across_calls(gpu, oracle):
+    """rendering [0,T) in one call == rendering two halves with the decay state carried (exactly)."""
+    import torch
+    cfg = config.spectrum_config(window_size=4096, hop=1024)
+    plan = api.Plan(cfg).upload()
+    frames = 24
+    S = 4096 + (frames - 1) * 1024
+    x = _planar_cuda(synth.gen(3, 48000, S, 2), gpu)
+    full = plan.render(x).cpu().numpy()
+    state = torch.zeros((1, 2, plan.P, 2), dtype=torch.float32, device=gpu)
+    h = 11
+    a = plan.render(x[:, :4096 + (h - 1) * 1024].contiguous(), state=state).cpu().numpy()
+    b = plan.render(x[:, h * 1024:].contiguous(), state=state).cpu().numpy()
+    assert np.array_equal(np.concatenate([a, b]), full)
+
+
+def test_full_size_cfg2_properties(gpu):
+    """BASELINE cfg2 at full size (348 frames): size-independent properties.
+    (i) shift: frames [k, k+m) of the full render == render of the shifted buffer when decay is off;
+    (ii) linearity in dB: scaling the input by 0.5 moves every unclipped line value by 20log10(0.5)/120."""
+    import torch
+    cfg = config.cfg2()
+    cfg["pole"] = (0.0, 0.0)
+    S = int(config.CFG2_SECONDS * 48000)
+    x = _planar_cuda(synth.gen(config.CFG2_SEED, 48000, S, 2), gpu)
+    plan = api.Plan(cfg).upload()
+    F = plan.num_frames(S)
+    assert F == 348
+    lines = torch.empty((F, 1, 2, plan.P, 2), dtype=torch.float32, device=gpu)
+    full = plan.render(x, lines=lines).cpu().numpy()
+    k, m = 100, 16
+    sub = plan.render(x[:, k * 8192:k * 8192 + 32768 + (m - 1) * 8192].contiguous()).cpu().numpy()
+    assert np.array_equal(sub, full[k:k + m])
+    lines2 = torch.empty_like(lines)
+    plan.render((x * 0.5).contiguous(), lines=lines2)
+    a, b = lines.cpu().numpy(), lines2.cpu().numpy()
+    ok = (a > -1) & (b > -1)
+    assert np.abs((a - b)[ok] - 20 * np.log10(2.0) / 120.0).max() < 1e-4
+    assert full[..., 3].min() == 255
+
+
+def test_unsupported_and_errors(gpu):
+    with pytest.raises(api.SgzError):
+        api.Plan(config.spectrum_config(channel_mode=config.CH_PHASE))
+    with pytest.raises(api.SgzError):
+        api.Plan(config.spectrum_config(axis_points=1))
