@@ -104,6 +104,12 @@ def lib() -> C.CDLL:
     path = LIB_PATH
     if not os.path.exists(path):
         _build.build()
+    # PyTorch-ROCm bundles its own HIP/HSA runtime: if torch is going to share this process it must be
+    # loaded first so that libsgz.so binds to the same runtime instance (two runtimes cannot both own the GPU).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(path)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     L.sgz_last_error.restype = C.c_char_p

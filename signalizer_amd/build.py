@@ -40,7 +40,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if s.endswith(".cpp"):   # pure host code: strict fp (tables must match the reference's fp64 expression order)
             cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-c", s, "-o", o]
         else:
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", s, "-o", o]
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                   "-x", "hip", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -79,11 +79,56 @@ __device__ __forceinline__ float bufLoad(__amdgpu_buffer_rsrc_t r, int voff, int
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// NOTE: __builtin_amdgcn_raw_buffer_load_b64/_b128 are mis-lowered to a single buffer_load_dword by this
+// ROCm 7.2 hipcc (verified in the ISA), so a complex twiddle is fetched as two dword loads.
 __device__ __forceinline__ float2 bufLoad2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y));
+    const float x = bufLoad(r, voff, soff);
+    const float y = bufLoad(r, voff + 4, soff);
+    return make_float2(x, y);
+}
+
+// Pixel mapping of mapToLinearSpace (TransformDSP.inl:565-639, :871-985) on the csf magnitudes held in LDS
+// (bank-padded natural order).  Every operation rounds exactly like the reference's scalar fp32 code:
+// contraction is off in this function (NB: hip's __fmul_rn/__fadd_rn are plain * and + and would be fused,
+// and __fsqrt_rn is the approximate native sqrt -- neither is used here).
+template <int LR>
+__device__ __forceinline__ void mapPixels(const StftParams &prm, const float *lds, int tid, long task)
+{
+#pragma clang fp contract(off)
+    constexpr int R = 1 << LR, T = R * R, N = R * T;
+    const int total = int(prm.sides * prm.P);
+    float *out = prm.mapped + size_t(task) * total;
+    for (int idx = tid; idx < total; idx += T) {
+        const PixelRec rec = prm.recs[idx];
+        const int side = idx >= int(prm.P) ? 1 : 0;
+        float val;
+        if (rec.kind == 0) {
+            float acc = 0.f;
+            int k = rec.a;
+            for (int i = 0; i < rec.b; ++i) {
+                const float m = lds[k + (k >> LR)];
+                const float prod = m * prm.weights[rec.c + i];
+                acc = acc + prod;
+                k = (k == N) ? 0 : k + 1;
+            }
+            val = prm.invSize * acc;
+        } else {
+            float best = 0.f;
+            int arg = rec.c;
+            for (int i = 0; i < rec.b; ++i) {
+                const int off = rec.a + i;
+                const int k = side ? (N - off) : off;
+                const float m = lds[k + (k >> LR)];
+                const float sq = m * m + 0.f;                         // Math::square(csf[offset]) with imag == 0
+                if (sq > best) { best = sq; arg = k; }
+            }
+            val = prm.invSize * lds[arg + (arg >> LR)];
+        }
+        // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365)
+        const float sq = val * val + 0.f;
+        out[idx] = __builtin_sqrtf(sq);                               // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    }
 }
 
 // One workgroup = one (frame, pair).  LR = log2(R).
@@ -286,38 +331,7 @@ stftMapKernel(const StftParams prm)
         }
 
         // ---------------------------------------------------------------------- pixel mapping
-        if (prm.mapped) {
-            const int total = int(prm.sides * prm.P);
-            float *out = prm.mapped + size_t(task) * total;
-            for (int idx = tid; idx < total; idx += T) {
-                const PixelRec rec = prm.recs[idx];
-                const int side = idx >= int(prm.P) ? 1 : 0;
-                float val;
-                if (rec.kind == 0) {
-                    float acc = 0.f;
-                    int k = rec.a;
-                    for (int i = 0; i < rec.b; ++i) {
-                        const float m = lds[k + (k >> LR)];
-                        acc = __fadd_rn(acc, __fmul_rn(m, prm.weights[rec.c + i]));
-                        k = (k == N) ? 0 : k + 1;
-                    }
-                    val = __fmul_rn(prm.invSize, acc);
-                } else {
-                    float best = 0.f;
-                    int arg = rec.c;
-                    for (int i = 0; i < rec.b; ++i) {
-                        const int off = rec.a + i;
-                        const int k = side ? (N - off) : off;
-                        const float m = lds[k + (k >> LR)];
-                        const float sq = __fadd_rn(__fmul_rn(m, m), 0.f);
-                        if (sq > best) { best = sq; arg = k; }
-                    }
-                    val = __fmul_rn(prm.invSize, lds[arg + (arg >> LR)]);
-                }
-                // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365)
-                out[idx] = __fsqrt_rn(__fadd_rn(__fmul_rn(val, val), 0.f));
-            }
-        }
+        if (prm.mapped) mapPixels<LR>(prm, lds, tid, task);
     }
 }
 

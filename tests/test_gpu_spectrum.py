@@ -5,7 +5,8 @@ a stated fp32 tolerance for spectral magnitudes.
   * bins (window x FFT x split x |.|): |gpu - oracle| <= 4e-6 * max|X| per bin   (different but correct
     fp32 butterfly orders; the oracle itself is 2e-7*max away from numpy fp64)
   * pixel mapping given identical bins: bit-exact
-  * decay + dB + colour given identical mapped magnitudes: RGBA8 bit-exact, lines within 1 ulp (logf)
+  * decay + dB + colour given identical mapped magnitudes: lines within 2 ulp (std::log(float) is not
+    correctly rounded in any libm), RGBA8 identical except where that ulp flips a truncation (<= 1e-4 of bytes)
   * end to end: RGBA8 channel values differ by at most 1 LSB on at most 0.5 % of the bytes
 """
 import numpy as np
@@ -111,7 +112,9 @@ def test_decay_colour_bit_exact_given_mapped(gpu, oracle):
     ref_lines = r["lines"]                         # [F][C][G][P] complex (left, right)
     ref = np.stack([ref_lines.real, ref_lines.imag], axis=-1).astype(np.float32)
     ulp = np.abs(lines.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 1, ulp.max()               # std::log(float): device rounds log() from fp64 once
+    # std::log(float): the device rounds an fp64 log() once, glibc logf is within 0.82 ulp: <= 1 ulp apart,
+    # then one more rounding in `* deltaYRecip`
+    assert ulp.max() <= 2, ulp.max()
     mism = (rgba != r["rgba"])
     # a 1-ulp logf difference can flip a truncation: allow <= 1 LSB on <= 1e-4 of bytes
     assert mism.mean() <= 1e-4, mism.mean()
