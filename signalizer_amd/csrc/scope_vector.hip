@@ -65,10 +65,16 @@ scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channe
     const long fl = long(floor(x));
     long cur = (cursor0 + long(shifts)) % long(len);
     const double kPi = 3.14159265358979323846;
-    // sin(pi (x - i)) = (-1)^i sin(pi x);  sin(pi (x - i)/10) = s10 cos(pi i/10) - c10 sin(pi i/10)
-    const double sPi = sin(kPi * x);
+    // d_i = x - i = m + e with m = round(x) - i (integer) and e = x - round(x) in [-1/2, 1/2] (exact):
+    //   sin(pi d)    = (-1)^m sin(pi e)
+    //   sin(pi d/10) = sin(pi m/10) cos(pi e/10) + cos(pi m/10) sin(pi e/10)
+    // Only the m = 0 tap has |d| < 1/2 and it is evaluated directly, so no tap suffers cancellation
+    // (a plain angle addition around floor(x) loses ~1 % on the nearest tap when x is within 1e-13 of an integer).
+    const long rn = long(rint(x));
+    const double e = x - double(rn);
+    const double sPi = sin(kPi * e);
     double s10, c10;
-    sincos(kPi * x / 10.0, &s10, &c10);
+    sincos(kPi * e / 10.0, &s10, &c10);
     const float ux = float(unit0 + double(p) * inc);
     for (uint32_t c = 0; c < channels; ++c) {
         const float *r = ring + size_t(c) * stride;
@@ -77,12 +83,15 @@ scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channe
             if (i < 0 || i >= 21) continue;
             long idx = cur + i; if (idx >= long(len)) idx -= long(len);
             const double d = x - double(i);
+            const long m = rn - i;                     // in [-10, 10]
             double w;
             if (d == 0.0) w = 1.0;
             else {
                 const double pd = kPi * d;
-                const double sa = (i & 1) ? -sPi : sPi;
-                const double sb = s10 * kCosPiI10[i] - c10 * kSinPiI10[i];
+                const double sa = (m & 1) ? -sPi : sPi;
+                const long am = m < 0 ? -m : m;
+                const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
+                const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
                 w = 10.0 * sa * sb / (pd * pd);
             }
             acc += double(r[idx]) * w;
