@@ -58,11 +58,38 @@ class ShardPlan:
         return 0 if self.local_frames == 0 else (self.local_frames - 1) * self.hop + self.window
 
 
+class GpuBackend:
+    """the product path: stages run as HIP kernels through the C ABI (libsgz.so)"""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def render(self, x, rgba, state):
+        self.plan.render(x, rgba=rgba, state=state)
+
+    def stage_mapped(self, x, mapped):
+        from . import api
+        api.check(api.lib().sgz_stage_mapped(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1], mapped.data_ptr(), self._stream()))
+
+    def stage_decay_colour(self, mapped, frames, rgba, state):
+        from . import api
+        api.check(api.lib().sgz_stage_decay_colour(self.plan.h, mapped.data_ptr(), frames, rgba.data_ptr(), None,
+                                                   state.data_ptr(), self._stream()))
+
+    def fold_carry(self, aggs, frames_per_rank, rank, carry):
+        self.plan.fold_carry(aggs, frames_per_rank, rank, carry)
+
+
 class TimeChunkRenderer:
-    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1):
+    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1, backend=None):
         import torch
         self.torch = torch
         self.plan = plan
+        self.backend = backend if backend is not None else GpuBackend(plan)
         self.rank, self.world = rank, world
         self.nch, S = chunk_audio.shape
         W, hop = plan.cfg.window_size, plan.cfg.hop
@@ -94,30 +121,24 @@ class TimeChunkRenderer:
         torch = self.torch
         if self.world == 1:
             self.state.zero_()
-            self.plan.render(self._view(), rgba=self.rgba, state=self.state)
+            self.backend.render(self._view(), self.rgba, self.state)
             return self.rgba
         import torch.distributed as dist
         # A1: halo = everybody's leading W samples
         self.halo_send.copy_(self.buf[:, :self.W])
-        dist.all_gather_into_tensor(self.halo_all, self.halo_send)
+        dist.all_gather_into_tensor(self.halo_all.view(-1), self.halo_send.view(-1))
         if self.rank + 1 < self.world:
             self.buf[:, self.S:] = self.halo_all[self.rank + 1]
         x = self._view()
         # K_A once, K_B twice (zero carry -> aggregate; folded carry -> final)
-        from . import api
-        api.check(api.lib().sgz_stage_mapped(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1], self.mapped.data_ptr(),
-                                             torch.cuda.current_stream().cuda_stream))
+        self.backend.stage_mapped(x, self.mapped)
         self.state.zero_()
-        api.check(api.lib().sgz_stage_decay_colour(self.plan.h, self.mapped.data_ptr(), self.local_frames,
-                                                   self.rgba.data_ptr(), None, self.state.data_ptr(),
-                                                   torch.cuda.current_stream().cuda_stream))
+        self.backend.stage_decay_colour(self.mapped, self.local_frames, self.rgba, self.state)
         # A2: decay carry
-        dist.all_gather_into_tensor(self.agg_all, self.state)
+        dist.all_gather_into_tensor(self.agg_all.view(-1), self.state.view(-1))
         if self.rank > 0:
-            self.plan.fold_carry(self.agg_all, self.frames_per_rank, self.rank, self.carry)
-            api.check(api.lib().sgz_stage_decay_colour(self.plan.h, self.mapped.data_ptr(), self.local_frames,
-                                                       self.rgba.data_ptr(), None, self.carry.data_ptr(),
-                                                       torch.cuda.current_stream().cuda_stream))
+            self.backend.fold_carry(self.agg_all, self.frames_per_rank, self.rank, self.carry)
+            self.backend.stage_decay_colour(self.mapped, self.local_frames, self.rgba, self.carry)
         return self.rgba
 
     def time_stft_kernel(self, iters: int = 50) -> float:

@@ -1,0 +1,110 @@
+"""CPU tests of the product's host logic and of the C-ABI surface (no compute calls: no GPU here).
+The host tables of libsgz.so (window, mapped frequencies, slope map, colour ratios/tables) are built by the
+product's own C++ (signalizer_amd/csrc/plan.cpp) and must equal the oracle's bit for bit."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from signalizer_amd import api, config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cases():
+    yield "cfg1", config.cfg1()
+    yield "cfg2", config.cfg2()
+    yield "cfg5", config.cfg5()
+    yield "linear_kaiser", config.spectrum_config(view_scaling=config.VIEW_LINEAR, window_type=config.WIN_KAISER,
+                                                  window_beta=9.5, window_symmetry=config.WIN_SYMMETRIC, window_size=3000,
+                                                  hop=700, num_pairs=3, channel_mode=config.CH_LEFT, bin_interp=config.INTERP_LINEAR)
+    yield "complex_log", config.spectrum_config(channel_mode=config.CH_COMPLEX, axis_points=999, window_type=config.WIN_FLATTOP)
+    yield "complex_lin", config.spectrum_config(channel_mode=config.CH_COMPLEX, view_scaling=config.VIEW_LINEAR, axis_points=512,
+                                                window_size=1024, hop=256)
+    yield "zoom_slope", config.spectrum_config(view_left=0.3, view_right=0.65, slope_a=0.5, slope_b=0.01, axis_points=777,
+                                               window_type=config.WIN_GAUSSIAN, window_alpha=0.3, num_pairs=5,
+                                               colours=[(12, 34, 56), (200, 10, 90), (1, 2, 3), (255, 255, 255), (90, 180, 45), (250, 128, 7)],
+                                               ratios=(0.0, 1.0, 0.5, 0.00001, 0.3))
+    for w in range(13):
+        yield f"win{w}", config.spectrum_config(window_type=w, window_size=500, hop=100, window_alpha=0.35, window_beta=6.0,
+                                                window_symmetry=w % 2)
+
+
+@pytest.mark.parametrize("name,cfg", list(_cases()))
+def test_plan_tables_equal_oracle(oracle, name, cfg):
+    po = oracle
+    plan = api.Plan(cfg)
+    p = po.params_from_dict(cfg)
+    w, scale = po.window(p.window_type, p.window_symmetry, p.window_size, p.window_alpha, p.window_beta)
+    assert plan.N == po.lib().sgzo_transform_size(p.window_size)
+    win = plan.window()
+    assert np.array_equal(win[:p.window_size].view(np.uint32), w.view(np.uint32)) and (win[p.window_size:] == 0).all()
+    assert plan.window_scale == scale
+    mf = po.remap_frequencies(p)
+    assert np.array_equal(plan.mapped_frequencies().view(np.uint32), mf.view(np.uint32))
+    assert np.array_equal(plan.slope_map().view(np.uint32), po.slope_map(p, mf).view(np.uint32))
+    assert np.array_equal(plan.colour_ratios().view(np.uint32), po.colour_ratios(cfg["ratios"]).view(np.uint32))
+    for pair in range(p.num_pairs):
+        assert np.array_equal(plan.colour_table(pair), po.colour_table(p, pair))
+    plan.close()
+
+
+def test_frame_count_matches_reference_cadence():
+    assert api.lib().sgz_num_frames(2880000, 32768, 8192) == 348
+    assert api.lib().sgz_num_frames(5760000, 65536, 16384) == 348
+    assert api.lib().sgz_num_frames(4095, 4096, 1) == 0
+
+
+def test_break_pixel_is_where_pixel_bandwidth_exceeds_bin_bandwidth():
+    plan = api.Plan(config.cfg2())
+    mf = plan.mapped_frequencies()
+    b = plan.break_pixel
+    bw = (mf[1:] - mf[:-1]) / np.float32(24000.0)
+    assert 0 < b < plan.P - 1
+    assert bw[b].astype(np.float64) > 1.0 / 16384 and (bw[:b].astype(np.float64) <= 1.0 / 16384).all()
+
+
+def test_config_validation_mirrors_reference_assertions():
+    for bad in (dict(axis_points=1), dict(window_size=0), dict(num_pairs=0), dict(hop=0), dict(sample_rate=0.5),
+                dict(channel_mode=9), dict(window_type=99), dict(bin_interp=3)):
+        with pytest.raises(api.SgzError) as e:
+            api.Plan(config.spectrum_config(**bad))
+        assert e.value.status == api.SGZ_EINVAL
+    with pytest.raises(api.SgzError) as e:
+        api.Plan(config.spectrum_config(channel_mode=config.CH_PHASE))
+    assert e.value.status == api.SGZ_EUNSUPPORTED
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    hdr = open(os.path.join(ROOT, "include", "sgz.h")).read()
+    declared = sorted(set(re.findall(r"\b(sgz_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = api.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(api.EXPORTS) == declared
+    assert L.sgz_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors must have the C layout (the parity tests pass these structs across the ABI)"""
+    assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4   # incl. tail/align padding
+    assert api.SpectrumConfig.ratios.offset % 8 == 0 and api.SpectrumConfig.window_alpha.offset == 40
+    assert C.sizeof(api.ScopeView) == 40 and C.sizeof(api.ZeroCrossingState) == 48 and C.sizeof(api.VectorFilters) == 32
+
+
+@pytest.mark.skipif(api.lib().sgz_device_count() > 0, reason="only meaningful without a GPU")
+def test_no_cpu_fallback_compute_fails_loudly_without_gpu():
+    plan = api.Plan(config.cfg1())
+    with pytest.raises(api.SgzError) as e:
+        plan.upload()
+    assert e.value.status == api.SGZ_EHIP
+    x = np.zeros((2, 8192), np.float32)
+    with pytest.raises(api.SgzError) as e:
+        api.render_spectrogram(config.cfg1(), x)
+    assert e.value.status == api.SGZ_EHIP
+    h = C.c_void_p()
+    c = api.config_from_dict(config.cfg1())
+    assert api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)) == api.SGZ_EHIP

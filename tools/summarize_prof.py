@@ -1,0 +1,36 @@
+"""Condense rocprofv3 output (kernel stats + PMC FETCH_SIZE/WRITE_SIZE) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
+
+
+for f in find("*kernel_stats.csv"):
+    print("== kernel stats:", os.path.relpath(f, out))
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    for r in rows[:12]:
+        print("  {Name:60.60s} calls={Calls:>6s} total_ns={TotalDurationNs:>12s} avg_ns={AverageNs:>12s} pct={Percentage:>6s}".format(**r))
+
+for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for f in find("*counter_collection.csv"):
+        if tag not in f:
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = r.get("Kernel_Name", "?")
+                acc[k][0] += float(r.get("Counter_Value", 0))
+                acc[k][1] += 1
+        print(f"== {counter} (raw counter units per dispatch; FETCH/WRITE_SIZE are in KiB-like units, see MI355X_MICROARCH.md HBM):", os.path.relpath(f, out))
+        for k, (v, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:8]:
+            print(f"  {k[:60]:60s} dispatches={n:6d} avg={v / max(n, 1):14.1f}")
