@@ -16,6 +16,7 @@
 namespace sgz {
 
 thread_local std::string g_lastError;
+uint32_t g_ablate = 0;
 
 sgz_status fail(sgz_status st, const std::string &msg)
 {
@@ -31,7 +32,7 @@ sgz_status hipFail(hipError_t e, const char *what)
 Plan::~Plan()
 {
     // best effort; ignore errors on teardown
-    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_recs, d_mapped, d_agg, d_scratch, d_stateCopy};
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_recs, d_items, d_mapped, d_agg, d_scratch, d_stateCopy};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -65,6 +66,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
     (void)hipGetDevice(&p.device);
     p.uploaded = true;
     return SGZ_OK;
@@ -94,7 +96,7 @@ int numCUs()
 
 // K_A launch over `frames` frames of `planar`; writes mapped/bins as requested.
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
-                          float *d_binsOut, const float *d_binsIn, hipStream_t stream)
+                          float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock)
 {
     StftParams prm{};
     prm.planar = d_planar;
@@ -106,8 +108,9 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.recs = p.d_recs; prm.weights = p.d_weights;
+    prm.items = p.d_items; prm.nItems = uint32_t(p.items.size());
     prm.invSize = p.scalars.invSize;
-    prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn;
+    prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
     const long tasks = frames * long(p.C);
     const int perCU = (p.N >= 32768) ? 1 : 8;
     const int grid = int(std::min<long>(tasks, long(numCUs()) * perCU));
@@ -349,6 +352,19 @@ sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     return runDecayColour(plan->impl, d_mapped, long(frames), d_rgba, d_lines, d_state, reinterpret_cast<hipStream_t>(stream));
+}
+
+void sgz_debug_set_ablate(uint32_t bits) { g_ablate = bits; }
+
+/* debug hook (not in sgz.h): per-phase shader clocks of workgroup 0 of K_A; d_clocks: DEVICE uint64[16] */
+sgz_status sgz_debug_phase_clocks(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                                  float *d_mapped, unsigned long long *d_clocks, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), d_clocks);
 }
 
 sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64_t *frames_per_rank, uint32_t world,

@@ -18,10 +18,14 @@ struct StftParams {
     const float2 *tw2;        // [R][R]
     const PixelRec *recs;     // [sides][P]
     const float *weights;
+    const MaxItem *items;     // balanced arg-max work list (null: serial per-pixel scan)
+    uint32_t nItems;
     float invSize;
     float *mapped;            // [frames][C][sides][P] or null
     float *binsOut;           // [frames][C][N+1] or null (test hook)
     const float *binsIn;      // test hook: skip the FFT, map from these bins
+    uint32_t ablate;          // debug: bit0 skip DIFs, bit1 skip exchange 1, bit2 skip exchange 2, bit3 skip mirror/M, bit4 skip map, bit5 skip twiddles
+    unsigned long long *phaseClock;   // debug hook: workgroup 0 stores s_memtime at phase boundaries (16 slots) or null
 };
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
 

@@ -7,6 +7,7 @@
 // into per-pixel records so the device does no fp64 index math ("hard parts").
 #include "plan.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -259,27 +260,31 @@ static void buildPixelRecords(Plan &p)
 
 static void buildTwiddles(Plan &p)
 {
-    // N = R^3 fast path (R = 16 or 32): tw1[q][t] = W_N^{t q}, t < R^2 ; tw2[q2][t2] = W_{R^2}^{t2 q2}
+    // N = R^3 fast path (R = 16 or 32).  Factorised tables (see TwFactors in spectrum_fft.hip):
+    //   tw1 rows [W_N^{t b}] b = 1..3, then [W_N^{t 4a}] a = 1..R/4-1, t < R^2
+    //   tw2 rows [W_T^{t2 b}], [W_T^{t2 4a}], t2 < R, T = R^2
     const double kTwoPi = 6.28318530717958647692;
     int R = 0;
     if (p.N == 32768) R = 32; else if (p.N == 4096) R = 16;
     if (!R) return;
     const uint32_t T = uint32_t(R * R);
-    p.tw1.resize(size_t(R) * T * 2);
-    for (int q = 0; q < R; ++q)
+    const int rows = 3 + R / 4 - 1;
+    auto mult = [&](int row) { return row < 3 ? row + 1 : 4 * (row - 3 + 1); };
+    p.tw1.resize(size_t(rows) * T * 2);
+    for (int row = 0; row < rows; ++row)
         for (uint32_t t = 0; t < T; ++t) {
-            const uint64_t m = (uint64_t(t) * uint64_t(q)) % p.N;
+            const uint64_t m = (uint64_t(t) * uint64_t(mult(row))) % p.N;
             const double ang = -kTwoPi * double(m) / double(p.N);
-            p.tw1[(size_t(q) * T + t) * 2 + 0] = float(std::cos(ang));
-            p.tw1[(size_t(q) * T + t) * 2 + 1] = float(std::sin(ang));
+            p.tw1[(size_t(row) * T + t) * 2 + 0] = float(std::cos(ang));
+            p.tw1[(size_t(row) * T + t) * 2 + 1] = float(std::sin(ang));
         }
-    p.tw2.resize(size_t(R) * R * 2);
-    for (int q2 = 0; q2 < R; ++q2)
+    p.tw2.resize(size_t(rows) * R * 2);
+    for (int row = 0; row < rows; ++row)
         for (int t2 = 0; t2 < R; ++t2) {
-            const uint32_t m = uint32_t(t2 * q2) % T;
+            const uint32_t m = uint32_t(t2 * mult(row)) % T;
             const double ang = -kTwoPi * double(m) / double(T);
-            p.tw2[(size_t(q2) * R + t2) * 2 + 0] = float(std::cos(ang));
-            p.tw2[(size_t(q2) * R + t2) * 2 + 1] = float(std::sin(ang));
+            p.tw2[(size_t(row) * R + t2) * 2 + 0] = float(std::cos(ang));
+            p.tw2[(size_t(row) * R + t2) * 2 + 1] = float(std::sin(ang));
         }
 }
 
@@ -377,6 +382,18 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                 p.colourTables[(size_t(pair) * (SGZ_NUM_SPEC_COLOURS + 1) + i) * 3 + c] = float(rgb[c]) / 255.0f;
         }
     buildPixelRecords(p);
+    // balanced arg-max work list: every kind-1 record cut into pieces of <= 16 offsets
+    p.items.clear();
+    for (size_t r = 0; r < p.recs.size(); ++r) {
+        const PixelRec &rec = p.recs[r];
+        if (rec.kind != 1) continue;
+        for (int32_t o = 0; o < rec.b; o += 16) {
+            MaxItem it;
+            it.slot = uint32_t(r);
+            it.off0cnt = uint32_t(rec.a + o) | (uint32_t(std::min<int32_t>(16, rec.b - o)) << 24);
+            p.items.push_back(it);
+        }
+    }
     buildTwiddles(p);
     return SGZ_OK;
 }

@@ -21,6 +21,12 @@ struct PixelRec {
     int32_t c;       // interp: offset of this pixel's weights in the weight table;         max: fallback bin
 };
 
+// Work item of the balanced arg-max: scan `cnt` (<= 16) consecutive offsets starting at off0 for record `slot`.
+struct MaxItem {
+    uint32_t slot;      // side * P + pixel
+    uint32_t off0cnt;   // off0 | cnt << 24
+};
+
 // Scalars the kernels need (all derived on the host exactly as the reference derives them).
 struct DeviceScalars {
     float invSize;        // windowKernelScale / (W/2), TransformDSP.inl:540
@@ -47,6 +53,7 @@ struct Plan {
     std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
+    std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces
     std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels
     DeviceScalars scalars{};
 
@@ -55,6 +62,7 @@ struct Plan {
     float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
     float *d_tw1 = nullptr, *d_tw2 = nullptr;
     PixelRec *d_recs = nullptr;
+    MaxItem *d_items = nullptr;
     // work buffers (grown on demand)
     float *d_mapped = nullptr; size_t mappedCap = 0;      // [frames][pairs][2][P]
     float *d_agg = nullptr; size_t aggCap = 0;            // decay chunk aggregates

@@ -21,7 +21,8 @@ sgz_status ensureCap(float **buf, size_t *cap, size_t need);
 int numCUs();
 // K_A over `frames` frames (ideal STFT framing from d_planar); any of mapped/binsOut may be null
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
-                   float *d_binsOut, const float *d_binsIn, hipStream_t stream);
+                   float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock = nullptr);
+extern uint32_t g_ablate;   // debug only (tools/ablate.py)
 // K_B: decay recurrence + dB map + colour blend
 sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
                           float *d_state, hipStream_t stream);
