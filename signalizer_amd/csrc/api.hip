@@ -112,9 +112,9 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     prm.invSize = p.scalars.invSize;
     prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
     const long tasks = frames * long(p.C);
-    const int perCU = (p.N >= 32768) ? 1 : 8;
-    const int grid = int(std::min<long>(tasks, long(numCUs()) * perCU));
-    if (grid <= 0) return SGZ_OK;
+    if (tasks <= 0) return SGZ_OK;
+    if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
+    const int grid = int(tasks);                 // one workgroup per (frame, pair); the dispatcher refills CUs
     SGZ_HIP(launchStftMap(prm, p.N, grid, stream));
     return SGZ_OK;
 }
@@ -146,6 +146,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         if (st != SGZ_OK) return st;
         prm.agg = p.d_agg;
         SGZ_HIP(launchDecayLocal(prm, stream));
+        SGZ_HIP(launchDecayCarry(prm, stream));
     }
     SGZ_HIP(launchDecayEmit(prm, stream));
     return SGZ_OK;

@@ -45,6 +45,7 @@ struct DecayParams {
     float *lines;             // [frames][C][G][P][2] or null
 };
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
+hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);

@@ -382,6 +382,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                 p.colourTables[(size_t(pair) * (SGZ_NUM_SPEC_COLOURS + 1) + i) * 3 + c] = float(rgb[c]) / 255.0f;
         }
     buildPixelRecords(p);
+    p.weights.insert(p.weights.end(), size_t(kMaxTaps), 0.0f);    // padding: the kernel reads kMaxTaps weights unconditionally
     // balanced arg-max work list: every kind-1 record cut into pieces of <= 16 offsets
     p.items.clear();
     for (size_t r = 0; r < p.recs.size(); ++r) {

@@ -4,7 +4,8 @@
 // Replaces, per frame: TransformPair::prepareTransform (Source/Spectrum/TransformDSP.inl:39-231),
 // doTransform (:487-502, cpl::dsp::UniFFT forward), and mapToLinearSpace (:506-1102) up to csp[].
 //
-// Structure (N = R^3, R = 32 for N = 32768, R = 16 for N = 4096; T = R^2 threads, R points per thread,
+// Structure (N = R^3, R = 32 for N = 32768, R = 16 for N = 4096; T = R^2 virtual threads of R points, two per
+// real thread (see stftMapKernel),
 // all butterflies in VGPRs, LDS only for the two digit transposes and the k <-> N-k mirror):
 //   pass 1  thread t        : R-point DIF over x[t + T j]  (coalesced strided HBM/L2 loads, window fused),
 //                             times W_N^{t q}            -> exchange 1 (workgroup-wide, re then im)
@@ -88,6 +89,12 @@ __device__ __forceinline__ float2 bufLoad2(__amdgpu_buffer_rsrc_t r, int voff, i
     return make_float2(x, y);
 }
 
+#define SGZ_CLK(slot)                                                                                   \
+    do {                                                                                                \
+        if (prm.phaseClock && tid == 0 && task == 0)                   \
+            prm.phaseClock[slot] = __builtin_readcyclecounter();                                         \
+    } while (0)
+
 // Pixel mapping of mapToLinearSpace (TransformDSP.inl:565-639, :871-985) on the csf magnitudes held in LDS
 // (bank-padded natural order).  Every operation rounds exactly like the reference's scalar fp32 code:
 // contraction is off in these functions (NB: hip's __fmul_rn/__fadd_rn are plain * and + and would be fused,
@@ -107,11 +114,11 @@ __device__ __forceinline__ float finishPixel(float val)
     return __builtin_sqrtf(sq);                                        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
 }
 
-template <int LR>
+template <int LR, int NT>
 __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const float *lds, int tid, long task)
 {
 #pragma clang fp contract(off)
-    constexpr int R = 1 << LR, T = R * R, N = R * T;
+    constexpr int R = 1 << LR, T = NT, N = R * R * R;
     const int total = int(prm.sides * prm.P);
     float *out = prm.mapped + size_t(task) * total;
     for (int idx = tid; idx < total; idx += T) {
@@ -145,65 +152,110 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
 }
 
 // balanced version; `slots` = sides*P zero-initialised 64-bit keys in LDS.  Contains one workgroup barrier.
-template <int LR>
+// Table reads (items, records, tap weights) are issued in batches of independent loads: a thread's work list is
+// tiny, so what matters is the number of dependent global-load round trips (2-3 per phase), not the byte count.
+template <int LR, int NT>
 __device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const float *lds, unsigned long long *slots,
                                                   int tid, long task)
 {
 #pragma clang fp contract(off)
-    constexpr int R = 1 << LR, T = R * R, N = R * T;
+    constexpr int R = 1 << LR, N = R * R * R;
+    constexpr int IB = 8;                                                // items per thread per batch
+    constexpr int RB = 4;                                                // records per thread per batch
     const int total = int(prm.sides * prm.P);
     float *out = prm.mapped + size_t(task) * total;
     // (a) arg-max pieces
-    for (uint32_t it = tid; it < prm.nItems; it += T) {
-        const MaxItem item = prm.items[it];
-        const int off0 = int(item.off0cnt & 0xFFFFFFu), cnt = int(item.off0cnt >> 24);
-        const bool right = item.slot >= prm.P;
-        float best = 0.f;
-        uint32_t bestOff = 0;
+    for (uint32_t base = 0; base < prm.nItems; base += NT * IB) {
+        MaxItem item[IB];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < cnt) {
-                const int off = off0 + i;
+        for (int b = 0; b < IB; ++b) {
+            const uint32_t it = base + b * NT + tid;
+            item[b] = it < prm.nItems ? prm.items[it] : MaxItem{0u, 0u};
+        }
+#pragma unroll
+        for (int b = 0; b < IB; ++b) {
+            const int off0 = int(item[b].off0cnt & 0xFFFFFFu), cnt = int(item[b].off0cnt >> 24);
+            const bool right = item[b].slot >= prm.P;
+            float best = 0.f;
+            uint32_t bestOff = 0;
+            float mv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                           // 16 independent LDS reads (index clamped, not branched)
+                const int off = off0 + (i < cnt ? i : 0);
                 const int k = right ? (N - off) : off;
-                const float m = lds[k + (k >> LR)];
-                const float sq = m * m + 0.f;                         // Math::square(csf[offset]) with imag == 0
-                if (sq > best) { best = sq; bestOff = uint32_t(off); }
+                mv[i] = lds[k + (k >> LR)];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float sq = mv[i] * mv[i] + 0.f;                 // Math::square(csf[offset]) with imag == 0
+                const bool take = (i < cnt) & (sq > best);            // first strictly greater wins (TransformDSP.inl:965)
+                best = take ? sq : best;
+                bestOff = take ? uint32_t(off0 + i) : bestOff;
+            }
+            if (best > 0.f) {
+                const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(best)) << 32) | (0xFFFFFFFFu - bestOff);
+                atomicMax(&slots[item[b].slot], key);
             }
         }
-        if (best > 0.f) {
-            const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(best)) << 32) | (0xFFFFFFFFu - bestOff);
-            atomicMax(&slots[item.slot], key);
-        }
     }
-    // (b) interpolated pixels (<= 10 taps, accumulated in tap order)
-    for (int idx = tid; idx < total; idx += T) {
-        const PixelRec rec = prm.recs[idx];
-        if (rec.kind != 0) continue;
-        float acc = 0.f;
-        int k = rec.a;
+    SGZ_CLK(10);
+    // (b) interpolated pixels (<= 10 taps, accumulated in tap order); (c) after the barrier: resolve the arg-max pixels
+    const bool oneBatch = total <= NT * RB;                              // then the records stay in registers across the barrier
+    PixelRec rec[RB];
+    for (int base = 0; base < total; base += NT * RB) {
 #pragma unroll
-        for (int i = 0; i < kMaxTaps; ++i) {
-            if (i < rec.b) {
-                const float m = lds[k + (k >> LR)];
-                const float prod = m * prm.weights[rec.c + i];
-                acc = acc + prod;
+        for (int b = 0; b < RB; ++b) {
+            const int idx = base + b * NT + tid;
+            rec[b] = idx < total ? prm.recs[idx] : PixelRec{2, 0, 0, 0};
+        }
+        // tap weights and magnitudes: unconditional, independent loads (the weight table is padded by kMaxTaps zeros)
+        float w[RB][kMaxTaps], mv[RB][kMaxTaps];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int wbase = rec[b].kind == 0 ? rec[b].c : 0;
+            int k = rec[b].kind == 0 ? rec[b].a : 0;
+#pragma unroll
+            for (int i = 0; i < kMaxTaps; ++i) {
+                w[b][i] = prm.weights[wbase + i];
+                mv[b][i] = lds[k + (k >> LR)];
                 k = (k == N) ? 0 : k + 1;
             }
         }
-        out[idx] = finishPixel<LR>(prm.invSize * acc);
-    }
-    __syncthreads();
-    // (c) resolve the arg-max pixels
-    for (int idx = tid; idx < total; idx += T) {
-        const PixelRec rec = prm.recs[idx];
-        if (rec.kind != 1) continue;
-        const unsigned long long key = slots[idx];
-        int k = rec.c;                                                   // maxLBin = maxRBin = bin (TransformDSP.inl:953)
-        if ((key >> 32) != 0) {
-            const int off = int(0xFFFFFFFFu - uint32_t(key));
-            k = (idx >= int(prm.P)) ? (N - off) : off;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int idx = base + b * NT + tid;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < kMaxTaps; ++i) {
+                const float prod = mv[b][i] * w[b][i];
+                acc = (i < rec[b].b) ? acc + prod : acc;               // taps accumulate in order (lanczosFilter restatement)
+            }
+            if (rec[b].kind == 0) out[idx] = finishPixel<LR>(prm.invSize * acc);
         }
-        out[idx] = finishPixel<LR>(prm.invSize * lds[k + (k >> LR)]);
+    }
+    SGZ_CLK(11);
+    __syncthreads();
+    SGZ_CLK(12);
+    for (int base = 0; base < total; base += NT * RB) {
+        if (!oneBatch) {
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int idx = base + b * NT + tid;
+                rec[b] = idx < total ? prm.recs[idx] : PixelRec{2, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            if (rec[b].kind != 1) continue;
+            const int idx = base + b * NT + tid;
+            const unsigned long long key = slots[idx];
+            int k = rec[b].c;                                            // maxLBin = maxRBin = bin (TransformDSP.inl:953)
+            if ((key >> 32) != 0) {
+                const int off = int(0xFFFFFFFFu - uint32_t(key));
+                k = (idx >= int(prm.P)) ? (N - off) : off;
+            }
+            out[idx] = finishPixel<LR>(prm.invSize * lds[k + (k >> LR)]);
+        }
     }
 }
 
@@ -215,11 +267,6 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
-#define SGZ_CLK(slot)                                                                                   \
-    do {                                                                                                \
-        if (prm.phaseClock && tid == 0 && blockIdx.x == 0 && task == 0)                   \
-            prm.phaseClock[slot] = __builtin_readcyclecounter();                                         \
-    } while (0)
 
 // Factorised twiddles: W^{x q} for q = 4a + b is B_a * A_b with A_b = W^{x b} (b = 1..3) and B_a = W^{x 4a}
 // (a = 1..R/4-1), so a thread fetches 3 + R/4 - 1 complex values instead of R - 1 (10 instead of 31 at R = 32)
@@ -258,33 +305,35 @@ struct TwFactors {
     }
 };
 
-// One workgroup = one (frame, pair) at a time.  LR = log2(R).
+// One workgroup = one (frame, pair) at a time.  LR = log2(R), N = R^3, T = R^2 "virtual threads" of R points.
 //
-// Thread roles.  pass 1: t = tid.  passes 2/3: group gi = tid / R owns q = qOf(gi), lane l = tid % R is t2 (pass 2)
-// then q2 (pass 3).  q's are paired {p, R-p} (and {0, R/2}) on sibling groups of ONE wave, so the k <-> N-k mirror
-// of the two-for-one split is a lane permutation inside the wave (ds_bpermute), not a workgroup exchange.
+// A REAL thread owns TWO virtual threads (sets A and B): TR = T/2 real threads, 2R complex points = 4R data VGPRs,
+// 8 waves per workgroup at R = 32 -> a 256-VGPR budget per thread, i.e. no spills and room to keep the next
+// frame's samples in flight.  Roles:
+//   pass 1    : columns tA = tid, tB = tid + TR                       (x[t + T j], j < R)
+//   passes 2/3: group p = tid / R, lane l = tid % R.   A = (q = p,           t2|q2 = l)
+//                                                      B = (q = R-p (R/2 if p = 0), t2|q2 = R-1-l)
+// A and B of one thread are mirror partners: bin k = q + R q2 + T m3 of A pairs with N-k = B's bin R-1-m3, so the
+// two-for-one split (TransformDSP.inl:858) is pure register arithmetic.  Only group p = 0 (q = 0 and q = R/2, which
+// mirror onto themselves) needs a lane permutation (ds_bpermute inside its half-wave).
 template <int LR>
-__global__ void __launch_bounds__(1 << (2 * LR))
+__global__ void __launch_bounds__((1 << (2 * LR)) / 2)
 stftMapKernel(const StftParams prm)
 {
     constexpr int R = 1 << LR;
     constexpr int T = R * R;
+    constexpr int TR = T / 2;
     constexpr int N = R * T;
     constexpr int PADSTRIDE = T + (T >> LR);          // padded distance between k and k + T
-    constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of thread 0's 2R-float scratch
+    constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of column 0's 2R-float scratch
     constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max slots (sides*P u64)
+    constexpr int TILE = R * (R + 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const long tasks = prm.frames * long(prm.C);
-    const int voff4 = tid * 4, voff8 = tid * 8;
-    const int gi = tid >> LR, l = tid & (R - 1);
-    const int pairIdx = gi >> 1;
-    const int q = (gi & 1) ? (pairIdx == 0 ? R / 2 : R - pairIdx) : pairIdx;
-    // mirror partner thread (same wave): (q', q2') with q' = (R - q) % R
-    const int pg = gi < 2 ? gi : (gi ^ 1);
-    const int pl = gi == 0 ? ((R - l) & (R - 1)) : (R - 1 - l);
-    const int partnerLaneBytes = (((pg << LR) + pl) & 63) << 2;
+    const int p = tid >> LR, l = tid & (R - 1), lb = R - 1 - l;
+    const int qA = p, qB = (p == 0) ? R / 2 : R - p;
     const bool split = (prm.sides == 2);
     const int mode = prm.mode;
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(lds + SLOTS);
@@ -297,187 +346,192 @@ stftMapKernel(const StftParams prm)
     else if (mode == SGZ_CH_SIDE) { mixRR = -1.f; mixIR = 0.f; mixS = 0.5f; }
     else if (mode == SGZ_CH_MIDSIDE) { mixRR = 1.f; mixIL = 1.f; mixIR = -1.f; mixS = 0.5f; }
 
-    float re[R], im[R];
-    // audio of a task goes in flight early (before the previous frame's mapping phase), the window after it:
-    // at most 2R + O(20) registers are live across the mapping loop, 3R only once its registers are dead.
+    float reA[R], imA[R], reB[R], imB[R];
+
+    // raw samples of one column: L -> re, R -> im (strided dword buffer loads; reads past W return 0 = zero padding)
     auto issueAudio = [&](long task) {
         const long frame = task / prm.C;
         const int pair = int(task - frame * prm.C);
         const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
         const __amdgpu_buffer_rsrc_t rsL = makeRsrc(L, prm.W * 4u);
         const __amdgpu_buffer_rsrc_t rsR = makeRsrc(L + prm.chStride, prm.W * 4u);
-        if (prm.ablate & 64) {     // EXPERIMENT (timing only, wrong layout): same bytes through 16 B/lane loads
-#pragma unroll
-            for (int j = 0; j < R; j += 4) {
-                const float4 a = *reinterpret_cast<const float4 *>(L + (j / 4) * (T * 4) + tid * 4);
-                const float4 b = *reinterpret_cast<const float4 *>(L + prm.chStride + (j / 4) * (T * 4) + tid * 4);
-                re[j] = a.x; re[j + 1] = a.y; re[j + 2] = a.z; re[j + 3] = a.w;
-                im[j] = b.x; im[j + 1] = b.y; im[j + 2] = b.z; im[j + 3] = b.w;
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            re[j] = bufLoad(rsL, voff4, j * (T * 4));
-            im[j] = bufLoad(rsR, voff4, j * (T * 4));
+            reA[j] = bufLoad(rsL, tid * 4, j * (T * 4));
+            imA[j] = bufLoad(rsR, tid * 4, j * (T * 4));
+            reB[j] = bufLoad(rsL, (tid + TR) * 4, j * (T * 4));
+            imB[j] = bufLoad(rsR, (tid + TR) * 4, j * (T * 4));
         }
     };
-    // window the prefetched samples (prepareTransform, TransformDSP.inl:59-216); the window itself is L2 resident
+    // window the samples (prepareTransform); the window table is L2 resident
     auto applyWindow = [&]() {
         const __amdgpu_buffer_rsrc_t rsW = makeRsrc(prm.window, prm.W * 4u);
+        constexpr int WB = R;                                          // all window loads in flight together
 #pragma unroll
-        for (int jb = 0; jb < R; jb += 16) {
-            float wv[16];
-            if (prm.ablate & 64) {
+        for (int jb = 0; jb < R; jb += WB) {
+            float wa[WB], wb[WB];
 #pragma unroll
-                for (int j = 0; j < 16; j += 4) {
-                    const float4 a = *reinterpret_cast<const float4 *>(prm.window + ((jb + j) / 4) * (T * 4) + tid * 4);
-                    wv[j] = a.x; wv[j + 1] = a.y; wv[j + 2] = a.z; wv[j + 3] = a.w;
-                }
-            } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) wv[j] = bufLoad(rsW, voff4, (jb + j) * (T * 4));
+            for (int j = 0; j < WB; ++j) {
+                wa[j] = bufLoad(rsW, tid * 4, (jb + j) * (T * 4));
+                wb[j] = bufLoad(rsW, (tid + TR) * 4, (jb + j) * (T * 4));
             }
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
+            for (int jj = 0; jj < WB; ++jj) {
                 const int j = jb + jj;
-                const float lft = re[j], rgt = im[j], w = (prm.ablate & 128) ? 1.0f : wv[jj];
                 // branch-free channel mix: (a*l + b*r) * w * s with a, b in {0, +-1}, s in {1, 0.5} rounds exactly
                 // like the reference's `(l +- r) * w * 0.5f` / `l * w` (adding a signed zero is exact)
-                const float xr = (mixRL * lft + mixRR * rgt) * w * mixS;
-                const float xi = (mixIL * lft + mixIR * rgt) * w * mixS;
-                re[j] = xr; im[j] = xi;
+                const float la = reA[j], ra = imA[j], lb_ = reB[j], rb = imB[j];
+                reA[j] = (mixRL * la + mixRR * ra) * wa[jj] * mixS;
+                imA[j] = (mixIL * la + mixIR * ra) * wa[jj] * mixS;
+                reB[j] = (mixRL * lb_ + mixRR * rb) * wb[jj] * mixS;
+                imB[j] = (mixIL * lb_ + mixIR * rb) * wb[jj] * mixS;
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    // One workgroup per task, no persistent frame loop: with a loop, LLVM hoists dozens of loop-invariant LDS/global
+    // address computations out of it and immediately spills them (measured: 33 prologue spills, ~50 reloads on the
+    // critical path of every frame).  Straight-line code has no such hoisting, and the dispatcher refills CUs anyway.
+    //
     // XCD-aware task order.  Workgroup b is observed to run on XCD b % 8 (a speed assumption only, never a
-    // correctness one): give every XCD one contiguous eighth of the frames, so that the 32 workgroups sharing an
-    // L2 walk 32 consecutive (75 %-overlapping) frames together and each sample is fetched from HBM once per XCD.
-    const bool xcdOrder = (gridDim.x % 8 == 0) && tasks >= 16;
-    const long perXcd = xcdOrder ? (tasks + 7) / 8 : tasks;
-    const long stride = xcdOrder ? gridDim.x / 8 : gridDim.x;
-    const long xcdBase = xcdOrder ? long(blockIdx.x % 8) * perXcd : 0;
-    long local = xcdOrder ? long(blockIdx.x / 8) : long(blockIdx.x);
-    auto taskAt = [&](long loc) { return (loc < perXcd && xcdBase + loc < tasks) ? xcdBase + loc : -1L; };
-    long task = taskAt(local);
-    if (task >= 0 && prm.binsIn == nullptr) { issueAudio(task); applyWindow(); }
-
-    for (; task >= 0; local += stride, task = taskAt(local)) {
-        const long nextTask = taskAt(local + stride);
+    // correctness one): XCD x gets the contiguous task range [base(x), base(x+1)), so that the workgroups sharing an
+    // L2 walk consecutive (75 %-overlapping) frames together and each sample is fetched from HBM once per XCD.
+    long task = blockIdx.x;
+    if (gridDim.x % 8 == 0 || tasks >= 64) {
+        const long nb = gridDim.x, x = blockIdx.x % 8, i = blockIdx.x / 8;
+        const long per = nb / 8, extra = nb % 8;                   // XCD x owns per + (x < extra) workgroups
+        task = x * per + (x < extra ? x : extra) + i;
+    }
+    {
         SGZ_CLK(0);
         if (prm.binsIn == nullptr) {
+            issueAudio(task);
+            applyWindow();
             // ------------------------------------------------------------------ pass 1: DIF (samples already windowed)
-            SGZ_CLK(1);
             {
-                if (!(prm.ablate & 1)) dif<R, R, 0>(re, im);
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(prm.ablate & 1)) { dif<R, R, 0>(reA, imA); dif<R, R, 0>(reB, imB); }
                 if (!(prm.ablate & 32)) {
-                TwFactors<LR> tw;
-                tw.load(makeRsrc(prm.tw1, uint32_t(3 + R / 4 - 1) * T * 8u), voff8, T * 8);
-                tw.apply(re, im);                                      // times W_N^{t q}
+                    const __amdgpu_buffer_rsrc_t rs = makeRsrc(prm.tw1, uint32_t(3 + R / 4 - 1) * T * 8u);
+                    TwFactors<LR> ta, tb;
+                    ta.load(rs, tid * 8, T * 8);
+                    tb.load(rs, (tid + TR) * 8, T * 8);
+                    ta.apply(reA, imA);                                // times W_N^{t q}
+                    tb.apply(reB, imB);
                 }
             }
-            SGZ_CLK(2);
+            SGZ_CLK(1);
             // ---------------------------------------------------------- exchange 1 (workgroup-wide; re then im)
             __syncthreads();                                           // previous frame's mapping reads are done
             if (!(prm.ablate & 2)) {
-            const int tw_ = opaque(tid);                               // write index
-            const int rd_ = opaque(q * T + l);                         // read base
+                const int rdA = qA * T + l, rdB = qB * T + lb;
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tw_] = re[brev(qq, LR)];
-            __syncthreads();
+                for (int qq = 0; qq < R; ++qq) { lds[qq * T + tid] = reA[brev(qq, LR)]; lds[qq * T + tid + TR] = reB[brev(qq, LR)]; }
+                __syncthreads();
 #pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) re[j2] = lds[rd_ + R * j2];
-            __syncthreads();
+                for (int j2 = 0; j2 < R; ++j2) { reA[j2] = lds[rdA + R * j2]; reB[j2] = lds[rdB + R * j2]; }
+                __syncthreads();
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tw_] = im[brev(qq, LR)];
-            __syncthreads();
+                for (int qq = 0; qq < R; ++qq) { lds[qq * T + tid] = imA[brev(qq, LR)]; lds[qq * T + tid + TR] = imB[brev(qq, LR)]; }
+                __syncthreads();
 #pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) im[j2] = lds[rd_ + R * j2];
+                for (int j2 = 0; j2 < R; ++j2) { imA[j2] = lds[rdA + R * j2]; imB[j2] = lds[rdB + R * j2]; }
+            }
+            SGZ_CLK(2);
+            // ------------------------------------------------------------------ pass 2 (A: t2 = l, B: t2 = R-1-l)
+            {
+                if (!(prm.ablate & 1)) { dif<R, R, 0>(reA, imA); dif<R, R, 0>(reB, imB); }
+                if (!(prm.ablate & 32)) {
+                    const __amdgpu_buffer_rsrc_t rs = makeRsrc(prm.tw2, uint32_t(3 + R / 4 - 1) * R * 8u);
+                    TwFactors<LR> ta, tb;
+                    ta.load(rs, l * 8, R * 8);
+                    tb.load(rs, lb * 8, R * 8);
+                    ta.apply(reA, imA);                                // times W_T^{t2 q2}
+                    tb.apply(reB, imB);
+                }
             }
             SGZ_CLK(3);
-            // ------------------------------------------------------------------ pass 2 (thread (q, t2 = l))
-            {
-                if (!(prm.ablate & 1)) dif<R, R, 0>(re, im);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(prm.ablate & 32)) {
-                TwFactors<LR> tw;
-                tw.load(makeRsrc(prm.tw2, uint32_t(3 + R / 4 - 1) * R * 8u), l * 8, R * 8);
-                tw.apply(re, im);                                      // times W_T^{t2 q2}
-                }
-            }
-            SGZ_CLK(4);
-            // ------------------------------- exchange 2: R x R transpose inside each R-lane group (wave-local)
-            const int l2_ = opaque(l);
-            const int base = opaque(gi) * (R * (R + 1));
+            // ------------------------------- exchange 2: R x R transposes inside each R-lane group (wave-local tiles)
             __syncthreads();                                           // every wave has finished reading exchange 1
             if (!(prm.ablate & 4)) {
+                const int tA = p * TILE, tB = (R / 2 + p) * TILE;
 #pragma unroll
-            for (int q2 = 0; q2 < R; ++q2) lds[base + q2 * (R + 1) + l2_] = re[brev(q2, LR)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int q2 = 0; q2 < R; ++q2) { lds[tA + q2 * (R + 1) + l] = reA[brev(q2, LR)]; lds[tB + q2 * (R + 1) + lb] = reB[brev(q2, LR)]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-            for (int j = 0; j < R; ++j) re[j] = lds[base + l2_ * (R + 1) + j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < R; ++j) { reA[j] = lds[tA + l * (R + 1) + j]; reB[j] = lds[tB + lb * (R + 1) + j]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int q2 = 0; q2 < R; ++q2) lds[base + q2 * (R + 1) + l2_] = im[brev(q2, LR)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int q2 = 0; q2 < R; ++q2) { lds[tA + q2 * (R + 1) + l] = imA[brev(q2, LR)]; lds[tB + q2 * (R + 1) + lb] = imB[brev(q2, LR)]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-            for (int j = 0; j < R; ++j) im[j] = lds[base + l2_ * (R + 1) + j];
+                for (int j = 0; j < R; ++j) { imA[j] = lds[tA + l * (R + 1) + j]; imB[j] = lds[tB + lb * (R + 1) + j]; }
             }
+            SGZ_CLK(4);
+            // ------------------------------------------------------------------ pass 3 (A: q2 = l, B: q2 = R-1-l)
+            if (!(prm.ablate & 1)) { dif<R, R, 0>(reA, imA); dif<R, R, 0>(reB, imB); }
             SGZ_CLK(5);
-            // ------------------------------------------------------------------ pass 3 (thread (q, q2 = l))
-            if (!(prm.ablate & 1)) dif<R, R, 0>(re, im);
-            SGZ_CLK(6);
-            // X[c + T m3] at index brev(m3), c = q + R q2
-            const int c = opaque(q + R * l);
-            const int ownBase = c + (c >> LR);                         // padded address of k = c
-            const int tid3 = opaque(tid);
-            const int plb = opaque(partnerLaneBytes);
+            // X[c + T m3] at register brev(m3);  cA = qA + R l,  cB = qB + R (R-1-l)
+            const int cA = qA + R * l, cB = qB + R * lb;
+            const int baseA = cA + (cA >> LR), baseB = cB + (cB >> LR);    // padded LDS address of k = c
             if (split && !(prm.ablate & 8)) {
-                if (tid == 0) {                                        // column c = 0 mirrors onto itself: redo it below
+                if (tid == 0) {                                        // column 0 (q = 0, q2 = 0) mirrors onto itself: redone below
 #pragma unroll
                     for (int m3 = 0; m3 < R; ++m3) {
-                        lds[SCRATCH + 2 * m3] = re[brev(m3, LR)];
-                        lds[SCRATCH + 2 * m3 + 1] = im[brev(m3, LR)];
+                        lds[SCRATCH + 2 * m3] = reA[brev(m3, LR)];
+                        lds[SCRATCH + 2 * m3 + 1] = imA[brev(m3, LR)];
                     }
                 }
-                // k = c + T m3 pairs with N - k = (T - c) + T (R-1-m3): partner thread, register R-1-m3
+                // mirror lanes for group p = 0 (inside lanes 0..R-1 of wave 0): A (q = 0): q2' = R - q2 ; B (q = R/2): lane R-1-l
+                const int laneA0 = (((R - l) & (R - 1))) << 2, laneB0 = (R - 1 - l) << 2;
 #pragma unroll
                 for (int m3 = 0; m3 < R / 2; ++m3) {
-                    const int ia = brev(m3, LR), ib = brev(R - 1 - m3, LR);
-                    const float mra = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plb, __builtin_bit_cast(int, re[ib])));
-                    const float mrb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plb, __builtin_bit_cast(int, re[ia])));
-                    const float mia = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plb, __builtin_bit_cast(int, im[ib])));
-                    const float mib = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plb, __builtin_bit_cast(int, im[ia])));
-                    // k < N/2: X1 = (Z[k] + conj Z[N-k])/2 ; k > N/2: X2 = (Z[N-k'] - conj Z[k'])/(2i) (see oracle)
-                    const float ua = re[ia] + mra, va = im[ia] - mia;
-                    const float ub = re[ib] - mrb, vb = im[ib] + mib;
-                    re[ia] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
-                    re[ib] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
+                    const int ia = brev(m3, LR), ib = brev(R - 1 - m3, LR);      // k < N/2 at ia, k > N/2 at ib
+                    // mirror values: Z[N - k] for the four bins (A,ia) (A,ib) (B,ia) (B,ib)
+                    float mAa_r = reB[ib], mAa_i = imB[ib], mAb_r = reB[ia], mAb_i = imB[ia];
+                    float mBa_r = reA[ib], mBa_i = imA[ib], mBb_r = reA[ia], mBb_i = imA[ia];
+                    if (p == 0) {
+                        mAa_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneA0, __builtin_bit_cast(int, reA[ib])));
+                        mAa_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneA0, __builtin_bit_cast(int, imA[ib])));
+                        mAb_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneA0, __builtin_bit_cast(int, reA[ia])));
+                        mAb_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneA0, __builtin_bit_cast(int, imA[ia])));
+                        mBa_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneB0, __builtin_bit_cast(int, reB[ib])));
+                        mBa_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneB0, __builtin_bit_cast(int, imB[ib])));
+                        mBb_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneB0, __builtin_bit_cast(int, reB[ia])));
+                        mBb_i = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(laneB0, __builtin_bit_cast(int, imB[ia])));
+                    }
+                    // k < N/2: X1 = (Z[k] + conj Z[N-k])/2 ; k > N/2: X2 = (Z[N-k] - conj Z[k])/(2i)  (magnitudes only)
+                    const float uAa = reA[ia] + mAa_r, vAa = imA[ia] - mAa_i, uAb = reA[ib] - mAb_r, vAb = imA[ib] + mAb_i;
+                    const float uBa = reB[ia] + mBa_r, vBa = imB[ia] - mBa_i, uBb = reB[ib] - mBb_r, vBb = imB[ib] + mBb_i;
+                    reA[ia] = 0.5f * __builtin_amdgcn_sqrtf(uAa * uAa + vAa * vAa);
+                    reA[ib] = 0.5f * __builtin_amdgcn_sqrtf(uAb * uAb + vAb * vAb);
+                    reB[ia] = 0.5f * __builtin_amdgcn_sqrtf(uBa * uBa + vBa * vBa);
+                    reB[ib] = 0.5f * __builtin_amdgcn_sqrtf(uBb * uBb + vBb * vBb);
                 }
             } else {
-                if (tid == 0) { lds[SCRATCH] = re[0]; lds[SCRATCH + 1] = im[0];
-                                lds[SCRATCH + R] = re[brev(R / 2, LR)]; lds[SCRATCH + R + 1] = im[brev(R / 2, LR)]; }
+                if (tid == 0) { lds[SCRATCH] = reA[0]; lds[SCRATCH + 1] = imA[0];
+                                lds[SCRATCH + R] = reA[brev(R / 2, LR)]; lds[SCRATCH + R + 1] = imA[brev(R / 2, LR)]; }
 #pragma unroll
                 for (int m3 = 0; m3 < R; ++m3) {                       // csf[k] = |Z[k]| (TransformDSP.inl:553-560, :993-1002)
                     const int i = brev(m3, LR);
-                    re[i] = __builtin_amdgcn_sqrtf(re[i] * re[i] + im[i] * im[i]);
+                    reA[i] = __builtin_amdgcn_sqrtf(reA[i] * reA[i] + imA[i] * imA[i]);
+                    reB[i] = __builtin_amdgcn_sqrtf(reB[i] * reB[i] + imB[i] * imB[i]);
                 }
             }
-            SGZ_CLK(7);
+            SGZ_CLK(6);
             __syncthreads();                                           // exchange-2 tiles are dead: M may overwrite them
 #pragma unroll
-            for (int m3 = 0; m3 < R; ++m3) lds[ownBase + m3 * PADSTRIDE] = re[brev(m3, LR)];
-            __syncthreads();
+            for (int m3 = 0; m3 < R; ++m3) {
+                lds[baseA + m3 * PADSTRIDE] = reA[brev(m3, LR)];
+                lds[baseB + m3 * PADSTRIDE] = reB[brev(m3, LR)];
+            }
             if (balanced)
-                for (int i = tid; i < int(prm.sides * prm.P); i += T) slots[i] = 0ull;
+                for (int i = tid; i < int(prm.sides * prm.P); i += TR) slots[i] = 0ull;
+            __syncthreads();
             if (split && tid >= 1 && tid < R / 2) {
                 // column 0: k = T m3 pairs with T (R - m3); both were held by thread 0 -> lanes 1..R/2-1 redo them
                 const int m3 = tid;
@@ -501,8 +555,8 @@ stftMapKernel(const StftParams prm)
                         lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
                 }
             }
-            if (split && tid == T - 1) {
-                const int kq = N / 2 - 1;                            // held by thread (q2 = R-1, q = R-1)... any thread may scale it
+            if (split && tid == R) {
+                const int kq = N / 2 - 1;
                 lds[kq + (kq >> LR)] *= 0.5f;                        // csf[N/2-1] *= 0.5 (quirk Q3, :864)
             }
             __syncthreads();
@@ -510,29 +564,24 @@ stftMapKernel(const StftParams prm)
             // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM
             const float *src = prm.binsIn + size_t(task) * (N + 1);
             __syncthreads();
-            for (int k = tid; k <= N; k += T) lds[k + (k >> LR)] = src[k];
+            for (int k = tid; k <= N; k += TR) lds[k + (k >> LR)] = src[k];
             if (balanced)
-                for (int i = tid; i < int(prm.sides * prm.P); i += T) slots[i] = 0ull;
+                for (int i = tid; i < int(prm.sides * prm.P); i += TR) slots[i] = 0ull;
             __syncthreads();
         }
-        SGZ_CLK(8);
+        SGZ_CLK(7);
 
         if (prm.binsOut) {
             float *dst = prm.binsOut + size_t(task) * (N + 1);
-            for (int k = tid; k <= N; k += T) dst[k] = lds[k + (k >> LR)];
+            for (int k = tid; k <= N; k += TR) dst[k] = lds[k + (k >> LR)];
         }
-        // next frame's audio goes in flight now and lands during the mapping phase
-        const bool more = nextTask >= 0 && prm.binsIn == nullptr;
-        if (more) issueAudio(nextTask);
-        SGZ_CLK(9);
+        SGZ_CLK(8);
         // ---------------------------------------------------------------------- pixel mapping
         if (prm.mapped && !(prm.ablate & 16)) {
-            if (balanced) mapPixelsBalanced<LR>(prm, lds, slots, tid, task);
-            else mapPixelsSerial<LR>(prm, lds, tid, task);
+            if (balanced) mapPixelsBalanced<LR, TR>(prm, lds, slots, tid, task);
+            else mapPixelsSerial<LR, TR>(prm, lds, tid, task);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) applyWindow();
-        SGZ_CLK(10);
+        SGZ_CLK(9);
     }
 }
 
@@ -553,7 +602,7 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
         if (e != hipSuccess) return e;
         attrBytes = ldsBytes;
     }
-    hipLaunchKernelGGL(stftMapKernel<LR>, dim3(grid), dim3(T), ldsBytes, stream, p2);
+    hipLaunchKernelGGL(stftMapKernel<LR>, dim3(grid), dim3(T / 2), ldsBytes, stream, p2);
     return hipGetLastError();
 }
 

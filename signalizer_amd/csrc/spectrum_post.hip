@@ -40,19 +40,51 @@ __global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
 #pragma unroll
     for (int k = 0; k < G; ++k)
         a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
-    const long f0 = long(chunk) * prm.chunk;
-    const long f1 = min(f0 + long(prm.chunk), prm.frames);
-    for (long f = f0; f < f1; ++f) {
-        const float mag = prm.mapped[size_t(f) * perChunk + rem];
+    const long f0 = long(chunk) * kMaxChunk;
+    const int len = int(min(long(kMaxChunk), prm.frames - f0));
+    float mag[kMaxChunk];
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            a[k] = a[k] * prm.sc.pole[k];                       // states[i] *= pole, TransformDSP.inl:1336,:1370
-            if (mag > a[k]) a[k] = mag;                         // :1338-1341
+    for (int t = 0; t < kMaxChunk; ++t)                         // independent loads first
+        mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem];
+#pragma unroll
+    for (int t = 0; t < kMaxChunk; ++t) {
+        if (t < len) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                a[k] = a[k] * prm.sc.pole[k];                   // states[i] *= pole, TransformDSP.inl:1336,:1370
+                if (mag[t] > a[k]) a[k] = mag[t];               // :1338-1341
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < G; ++k)
         prm.agg[((size_t(chunk) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] = a[k];
+}
+
+// K_B1b: exact state at the END of every chunk, in place: agg[c] <- max(agg[c], decay^chunkLen(agg[c-1])) with the
+// decay done by sequential fp32 multiplies.  thread <-> (pair, side, graph, pixel); sequential over chunks (tiny).
+__global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
+{
+    const size_t per = size_t(prm.C) * prm.sides * G * prm.P;
+    const size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= per) return;
+    const uint32_t k = uint32_t((e / prm.P) % G);
+    const float pole = prm.sc.pole[k];
+    float c = prm.agg[e];
+    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 8) {
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (d0 + j < prm.numChunks) ? prm.agg[size_t(d0 + j) * per + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (d0 + j < prm.numChunks) {
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;      // every chunk before the last is full
+                if (a[j] > c) c = a[j];
+                prm.agg[size_t(d0 + j) * per + e] = c;
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalars &sc)
@@ -63,6 +95,7 @@ __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalar
 }
 
 // K_B2: carry fix-up + dB map + colour blend.  thread <-> (chunk, pixel); loops pairs, sides, graphs.
+// agg[c] holds the exact end state of chunk c (K_B1b) when numChunks > 1.
 __global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -70,10 +103,11 @@ __global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
     const uint32_t chunk = uint32_t(gid / prm.P);
     const uint32_t pixel = uint32_t(gid - size_t(chunk) * prm.P);
     const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
-    const long f0 = long(chunk) * prm.chunk;
-    const long f1 = min(f0 + long(prm.chunk), prm.frames);
+    const long f0 = long(chunk) * kMaxChunk;
+    const long f1 = min(f0 + long(kMaxChunk), prm.frames);
     const int len = int(f1 - f0);
     const float slope = prm.slope[pixel];
+    const bool last = (f1 == prm.frames);
 
     float cb[kMaxChunk][3];
 #pragma unroll
@@ -83,63 +117,63 @@ __global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
         const float *sca = prm.colourTables + size_t(pair) * NC * 3;
         for (uint32_t side = 0; side < prm.sides; ++side) {
             const uint32_t ps = pair * prm.sides + side;
+            float mag[kMaxChunk];
+#pragma unroll
+            for (int t = 0; t < kMaxChunk; ++t)                 // independent loads first
+                mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perFrame + size_t(ps) * prm.P + pixel];
 #pragma unroll
             for (int k = 0; k < G; ++k) {
+                // what the colour column needs is (side 0, graph 0); everything else only matters for line output
+                // and for the state after the last frame
+                const bool colour = (side == 0 && k == 0 && prm.rgba);
+                if (!colour && !prm.lines && !(last && prm.state)) continue;
                 const float pole = prm.sc.pole[k];
-                // carry = exact state at the end of chunk-1 (fold of the chunk aggregates, sequential decay)
-                float cr = 0.f;
-                if (chunk > 0) {
-                    cr = prm.agg[((size_t(0) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel];
-                    for (uint32_t d = 1; d < chunk; ++d) {
-                        for (uint32_t i = 0; i < prm.chunk; ++i) cr = cr * pole;
-                        const float ad = prm.agg[((size_t(d) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel];
-                        if (ad > cr) cr = ad;
-                    }
-                }
+                float cr = chunk > 0 ? prm.agg[((size_t(chunk - 1) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] : 0.f;
                 float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
                 float s = 0.f;
 #pragma unroll
                 for (int t = 0; t < kMaxChunk; ++t) {
                     if (t < len) {
                         const long f = f0 + t;
-                        const float mag = prm.mapped[size_t(f) * perFrame + size_t(ps) * prm.P + pixel];
                         a = a * pole;
-                        if (mag > a) a = mag;
+                        if (mag[t] > a) a = mag[t];
                         cr = cr * pole;
                         s = a > cr ? a : cr;
-                        const float result = dbMap(slope, s, prm.sc);
-                        if (prm.lines)
-                            prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
-                        if (side == 0 && k == 0 && prm.rgba) {
-                            // renderSf, SpectrumDSP.cpp:119-168
-                            const float intensity = result;
-                            if (!(intensity < 0.f)) {
-                                float colour[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
-                                if (intensity < 0.999f) {
-                                    float accumulatedSum = 0.f;
-                                    for (int c = 1; c < NC; ++c) {
-                                        const float nextScale = prm.sc.ratios[c];
-                                        accumulatedSum += nextScale;
-                                        if (accumulatedSum >= intensity) {
-                                            const float mn = accumulatedSum - nextScale;
-                                            const float mx = accumulatedSum;
-                                            const float mix = (intensity - mn) / (mx - mn);
-                                            const float imix = 1.f - mix;
-                                            const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
-                                            colour[0] = ca[0] * imix + cbb[0] * mix;
-                                            colour[1] = ca[1] * imix + cbb[1] * mix;
-                                            colour[2] = ca[2] * imix + cbb[2] * mix;
-                                            break;
+                        if (colour || prm.lines) {
+                            const float result = dbMap(slope, s, prm.sc);
+                            if (prm.lines)
+                                prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
+                            if (colour) {
+                                // renderSf, SpectrumDSP.cpp:119-168
+                                const float intensity = result;
+                                if (!(intensity < 0.f)) {
+                                    float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
+                                    if (intensity < 0.999f) {
+                                        float accumulatedSum = 0.f;
+                                        for (int c = 1; c < NC; ++c) {
+                                            const float nextScale = prm.sc.ratios[c];
+                                            accumulatedSum += nextScale;
+                                            if (accumulatedSum >= intensity) {
+                                                const float mn = accumulatedSum - nextScale;
+                                                const float mx = accumulatedSum;
+                                                const float mix = (intensity - mn) / (mx - mn);
+                                                const float imix = 1.f - mix;
+                                                const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
+                                                colourv[0] = ca[0] * imix + cbb[0] * mix;
+                                                colourv[1] = ca[1] * imix + cbb[1] * mix;
+                                                colourv[2] = ca[2] * imix + cbb[2] * mix;
+                                                break;
+                                            }
                                         }
                                     }
-                                }
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) cb[t][c] += (1.f - cb[t][c]) * colour[c];   // GL_ONE_MINUS_SRC_COLOR
+                                    for (int c = 0; c < 3; ++c) cb[t][c] += (1.f - cb[t][c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
+                                }
                             }
                         }
                     }
                 }
-                if (prm.state && f1 == prm.frames && len > 0)
+                if (prm.state && last && len > 0)
                     prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = s;
             }
         }
@@ -196,6 +230,15 @@ hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream)
     const int block = 256;
     const unsigned grid = unsigned((total + block - 1) / block);
     hipLaunchKernelGGL(decayLocalKernel, dim3(grid), dim3(block), 0, stream, prm);
+    return hipGetLastError();
+}
+
+hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
+{
+    const size_t total = size_t(prm.C) * prm.sides * G * prm.P;
+    const int block = 256;
+    const unsigned grid = unsigned((total + block - 1) / block);
+    hipLaunchKernelGGL(decayCarryKernel, dim3(grid), dim3(block), 0, stream, prm);
     return hipGetLastError();
 }
 

@@ -17,5 +17,6 @@ for rep in range(3):
     api.check(L.sgz_debug_phase_clocks(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), clk.data_ptr(), None))
     torch.cuda.synchronize()
     c = clk.cpu().numpy()
-    d = np.diff(c[:11])
-    print("rep", rep, "total cycles", c[10] - c[0], " ".join(f"{n}={int(v)}" for n, v in zip(names, d)))
+    d = np.diff(c[:10])
+    print('   map detail: items', c[10]-c[8], 'interp', c[11]-c[10], 'barrier', c[12]-c[11], 'resolve', c[9]-c[12])
+    print("rep", rep, "total cycles", c[9] - c[0], " ".join(f"{n}={int(v)}" for n, v in zip(names, d)))
