@@ -32,7 +32,8 @@ sgz_status hipFail(hipError_t e, const char *what)
 Plan::~Plan()
 {
     // best effort; ignore errors on teardown
-    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_recs, d_items, d_mapped, d_agg, d_scratch, d_stateCopy};
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_recs, d_items, d_mapped, d_agg, d_scratch,
+                    d_stateCopy, d_work0, d_work1, d_binsWork};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -54,10 +55,6 @@ sgz_status uploadPlan(Plan &p, std::string &err)
         err = "no HIP device visible (libsgz has no CPU fallback)";
         return SGZ_EHIP;
     }
-    if (p.tw1.empty()) {
-        err = "transform size " + std::to_string(p.N) + " has no gfx950 kernel yet (built: 4096, 32768)";
-        return SGZ_EUNSUPPORTED;
-    }
     sgz_status st;
     if ((st = uploadVec(p.window, &p.d_window)) != SGZ_OK) return st;
     if ((st = uploadVec(p.slope, &p.d_slope)) != SGZ_OK) return st;
@@ -65,6 +62,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.weights, &p.d_weights)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
     (void)hipGetDevice(&p.device);
@@ -114,6 +112,22 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
+    if (!p.fused) {
+        // generic multi-kernel path (any power-of-two N): work buffers for a slab of tasks, <= 256 MiB each
+        const size_t perTask = size_t(p.N) * 2;                                  // floats of one complex buffer
+        long slab = long(std::max<size_t>(1, (size_t(64) << 20) / perTask));      // 64 Mi floats = 256 MiB
+        slab = std::min<long>(slab, tasks);
+        if (p.workSlab < size_t(slab)) {
+            for (float **b : {&p.d_work0, &p.d_work1, &p.d_binsWork}) if (*b) { (void)hipFree(*b); *b = nullptr; }
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_work0), size_t(slab) * perTask * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_work1), size_t(slab) * perTask * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_binsWork), size_t(slab) * (size_t(p.N) + 1) * sizeof(float)));
+            p.workSlab = size_t(slab);
+        }
+        SGZ_HIP(launchGeneric(prm, p.N, reinterpret_cast<const float2 *>(p.d_twN), reinterpret_cast<float2 *>(p.d_work0),
+                              reinterpret_cast<float2 *>(p.d_work1), p.d_binsWork, long(p.workSlab), stream));
+        return SGZ_OK;
+    }
     const int grid = int(tasks);                 // one workgroup per (frame, pair); the dispatcher refills CUs
     SGZ_HIP(launchStftMap(prm, p.N, grid, stream));
     return SGZ_OK;

@@ -28,6 +28,8 @@ struct StftParams {
     unsigned long long *phaseClock;   // debug hook: workgroup 0 stores s_memtime at phase boundaries (16 slots) or null
 };
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
+                         long slab, hipStream_t stream);
 
 struct DecayParams {
     const float *mapped;      // [frames][C][sides][P]

@@ -266,7 +266,16 @@ static void buildTwiddles(Plan &p)
     const double kTwoPi = 6.28318530717958647692;
     int R = 0;
     if (p.N == 32768) R = 32; else if (p.N == 4096) R = 16;
-    if (!R) return;
+    p.fused = R != 0;
+    if (!R) {   // generic radix-2 Stockham path: one table W_N^i, i < N/2
+        p.twN.resize(size_t(p.N / 2) * 2);
+        for (uint32_t i = 0; i < p.N / 2; ++i) {
+            const double ang = -kTwoPi * double(i) / double(p.N);
+            p.twN[size_t(i) * 2 + 0] = float(std::cos(ang));
+            p.twN[size_t(i) * 2 + 1] = float(std::sin(ang));
+        }
+        return;
+    }
     const uint32_t T = uint32_t(R * R);
     const int rows = 3 + R / 4 - 1;
     auto mult = [&](int row) { return row < 3 ? row + 1 : 4 * (row - 3 + 1); };

@@ -54,13 +54,16 @@ struct Plan {
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
     std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces
-    std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels
+    std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels (fused N = R^3 path)
+    std::vector<float> twN;             // generic path: W_N^i, i < N/2
+    bool fused = false;                 // N in {4096, 32768}: spectrum_fft.hip; otherwise spectrum_generic.hip
     DeviceScalars scalars{};
 
     // device mirrors (owned)
     bool uploaded = false;
     float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
-    float *d_tw1 = nullptr, *d_tw2 = nullptr;
+    float *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twN = nullptr;
+    float *d_work0 = nullptr, *d_work1 = nullptr, *d_binsWork = nullptr; size_t workSlab = 0;   // generic path buffers
     PixelRec *d_recs = nullptr;
     MaxItem *d_items = nullptr;
     // work buffers (grown on demand)

@@ -1,0 +1,177 @@
+// spectrum_generic.hip -- K_A for ANY power-of-two transform size (32 <= N, not only the fused 4096 / 32768
+// kernel of spectrum_fft.hip): the same stages as separate HBM-resident kernels.  gfx950 only.
+//
+//   genericPrepare : prepareTransform (Source/Spectrum/TransformDSP.inl:39-231)   audio x window -> complex [tasks][N]
+//   genericStage   : one radix-2 Stockham (autosort) pass of the forward DFT; log2 N launches, ping-pong in HBM
+//                    (doTransform, :487-502 -- natural order, unnormalised)
+//   genericBins    : two-for-one split + DC/Nyquist fix-ups + |.|  (:858-869 ; mono :553-560)  -> csf magnitudes [N+1]
+//   genericMap     : pixel mapping from HBM-resident csf (:565-639, :871-985), same PixelRec table as the fused kernel
+//
+// This path moves ~(2 log2 N + 6) * N * 8 bytes per frame-pair through HBM/L2 instead of the fused kernel's
+// 2*W*4: it exists for completeness (every window size the reference accepts works, e.g. BASELINE cfg5's
+// N = 65536), not for speed; fusing N = 2 R^3 is listed under "next" in DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace sgz {
+
+__global__ void __launch_bounds__(256)
+genericPrepare(const float *planar, size_t chStride, uint32_t hop, uint32_t W, uint32_t N, uint32_t C, uint32_t mode,
+               const float *window, long task0, long ntasks, float2 *out)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * N) return;
+    const long t = long(gid / N);
+    const uint32_t n = uint32_t(gid - size_t(t) * N);
+    const long task = task0 + t;
+    const long frame = task / C;
+    const uint32_t pair = uint32_t(task - frame * C);
+    float xr = 0.f, xi = 0.f;
+    if (n < W) {
+        const float *L = planar + size_t(2 * pair) * chStride + size_t(frame) * hop;
+        const float l = L[n], r = L[chStride + n], w = window[n];
+        switch (mode) {                                           // TransformDSP.inl:59-216
+        case SGZ_CH_LEFT: xr = l * w; break;
+        case SGZ_CH_RIGHT: xr = r * w; break;
+        case SGZ_CH_MERGE: xr = (l + r) * w * 0.5f; break;
+        case SGZ_CH_SIDE: xr = (l - r) * w * 0.5f; break;
+        case SGZ_CH_MIDSIDE: xr = (l + r) * w * 0.5f; xi = (l - r) * w * 0.5f; break;
+        default: xr = l * w; xi = r * w; break;
+        }
+    }
+    out[gid] = make_float2(xr, xi);
+}
+
+// Stockham autosort radix-2 DIF pass `s` (s = 0 .. log2N-1):  l = N >> (s+1), m = 1 << s
+//   y[k + 2 j m]     =  x[k + j m] + x[k + j m + l m]
+//   y[k + 2 j m + m] = (x[k + j m] - x[k + j m + l m]) * W_{2l}^j ,   W_{2l}^j = W_N^{j << s}
+__global__ void __launch_bounds__(256)
+genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, uint32_t N, uint32_t s, long ntasks)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t half = N >> 1;
+    if (gid >= size_t(ntasks) * half) return;
+    const long t = long(gid / half);
+    const uint32_t b = uint32_t(gid - size_t(t) * half);          // butterfly index = j * m + k
+    const uint32_t m = 1u << s;
+    const uint32_t k = b & (m - 1), j = b >> s;
+    const float2 *xi = x + size_t(t) * N;
+    float2 *yo = y + size_t(t) * N;
+    const float2 c0 = xi[b], c1 = xi[b + half];                   // k + j m  and  k + j m + l m  (l m = N/2)
+    const float2 w = twN[size_t(j) << s];
+    const float dr = c0.x - c1.x, di = c0.y - c1.y;
+    yo[k + 2 * j * m] = make_float2(c0.x + c1.x, c0.y + c1.y);
+    yo[k + 2 * j * m + m] = make_float2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+}
+
+__global__ void __launch_bounds__(256)
+genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long ntasks, float *bins /*[ntasks][N+1]*/)
+{
+    const size_t per = size_t(N) + 1;
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * per) return;
+    const long t = long(gid / per);
+    const uint32_t k = uint32_t(gid - size_t(t) * per);
+    const float2 *Z = z + size_t(t) * N;
+    float out;
+    if (sides == 2) {                                             // Separate / MidSide, TransformDSP.inl:858-869
+        if (k == 0) out = Z[0].x * 0.5f;
+        else if (k == N) out = Z[0].y * 0.5f;
+        else if (k == N / 2) out = 0.5f * __builtin_amdgcn_sqrtf(Z[k].x * Z[k].x + Z[k].y * Z[k].y);
+        else {
+            const float2 a = Z[k], b = Z[N - k];
+            float u, v;
+            if (k < N / 2) { u = a.x + b.x; v = a.y - b.y; }      // X1[k]
+            else { u = a.x - b.x; v = a.y + b.y; }                // X2[N-k] (magnitude)
+            out = 0.5f * __builtin_amdgcn_sqrtf(u * u + v * v);
+            if (k == N / 2 - 1) out *= 0.5f;                      // quirk Q3, :864
+        }
+    } else {                                                      // mono :553-560 / complex :993-1002 (magnitudes)
+        if (k == N) out = 0.f;
+        else {
+            out = __builtin_amdgcn_sqrtf(Z[k].x * Z[k].x + Z[k].y * Z[k].y);
+            if (k == 0 || (k == N / 2 && mode != SGZ_CH_COMPLEX)) out *= 0.5f;
+        }
+    }
+    bins[gid] = out;
+}
+
+// one thread per (task, side, pixel); exact fp32 order of the reference (contraction off)
+__global__ void __launch_bounds__(256)
+genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const PixelRec *recs, const float *weights,
+           float invSize, long ntasks, float *mapped /*[ntasks][sides][P]*/)
+{
+#pragma clang fp contract(off)
+    const uint32_t total = sides * P;
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * total) return;
+    const long t = long(gid / total);
+    const uint32_t idx = uint32_t(gid - size_t(t) * total);
+    const float *M = bins + size_t(t) * (size_t(N) + 1);
+    const PixelRec rec = recs[idx];
+    const int side = idx >= P ? 1 : 0;
+    float val;
+    if (rec.kind == 0) {
+        float acc = 0.f;
+        int k = rec.a;
+        for (int i = 0; i < rec.b; ++i) {
+            const float prod = M[k] * weights[rec.c + i];
+            acc = acc + prod;
+            k = (k == int(N)) ? 0 : k + 1;
+        }
+        val = invSize * acc;
+    } else {
+        float best = 0.f;
+        int arg = rec.c;
+        for (int i = 0; i < rec.b; ++i) {
+            const int off = rec.a + i;
+            const int k = side ? (int(N) - off) : off;
+            const float m = M[k];
+            const float sq = m * m + 0.f;
+            if (sq > best) { best = sq; arg = k; }
+        }
+        val = invSize * M[arg];
+    }
+    const float sq = val * val + 0.f;
+    mapped[gid] = __builtin_sqrtf(sq);
+}
+
+static inline unsigned gridFor(size_t total) { return unsigned((total + 255) / 256); }
+
+// Runs the generic path for tasks [0, ntasks) in slabs that fit the work buffers (work0/work1: complex [slab][N]).
+hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
+                         long slab, hipStream_t stream)
+{
+    const long tasks = prm.frames * long(prm.C);
+    uint32_t log2N = 0;
+    while ((1u << log2N) < N) ++log2N;
+    for (long t0 = 0; t0 < tasks; t0 += slab) {
+        const long nt = tasks - t0 < slab ? tasks - t0 : slab;
+        const float *bins;
+        if (prm.binsIn == nullptr) {
+            hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
+                               prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
+            float2 *src = work0, *dst = work1;
+            for (uint32_t s = 0; s < log2N; ++s) {
+                hipLaunchKernelGGL(genericStage, dim3(gridFor(size_t(nt) * (N / 2))), dim3(256), 0, stream, src, dst, twN, N, s, nt);
+                float2 *tmp = src; src = dst; dst = tmp;
+            }
+            float *bout = prm.binsOut ? prm.binsOut + size_t(t0) * (size_t(N) + 1) : binsWork;
+            hipLaunchKernelGGL(genericBins, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, prm.sides,
+                               prm.mode, nt, bout);
+            bins = bout;
+        } else {
+            bins = prm.binsIn + size_t(t0) * (size_t(N) + 1);
+        }
+        if (prm.mapped)
+            hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,
+                               prm.recs, prm.weights, prm.invSize, nt, prm.mapped + size_t(t0) * prm.sides * prm.P);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace sgz

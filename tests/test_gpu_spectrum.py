@@ -39,7 +39,7 @@ def _oracle_bins(po, p, x, frames, hop, W):
     return out
 
 
-@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2small", "midside", "left", "w3000"])
+@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2small", "midside", "left", "w3000", "n32", "n1024", "n8192", "n65536", "w100"])
 def test_bins_tolerance(gpu, oracle, cfgname):
     po = oracle
     cfg = {
@@ -49,6 +49,12 @@ def test_bins_tolerance(gpu, oracle, cfgname):
         "left": config.spectrum_config(channel_mode=config.CH_LEFT, window_size=4096, hop=1024),
         "w3000": config.spectrum_config(window_size=3000, hop=750, window_type=config.WIN_KAISER, window_beta=8.0,
                                         window_symmetry=config.WIN_SYMMETRIC),
+        # generic path (spectrum_generic.hip): every other power-of-two transform size
+        "n32": config.spectrum_config(window_size=20, hop=7, axis_points=16),
+        "n1024": config.spectrum_config(window_size=1024, hop=256, channel_mode=config.CH_MIDSIDE),
+        "n8192": config.spectrum_config(window_size=8192, hop=2048, channel_mode=config.CH_MERGE),
+        "n65536": config.cfg5(pairs=1),
+        "w100": config.spectrum_config(window_size=100, hop=50, window_type=config.WIN_TRIANGULAR, axis_points=33),
     }[cfgname]
     W, hop = cfg["window_size"], cfg["hop"]
     frames = 3
@@ -197,6 +203,21 @@ def test_full_size_cfg2_properties(gpu):
     ok = (a > -1) & (b > -1)
     assert np.abs((a - b)[ok] - 20 * np.log10(2.0) / 120.0).max() < 1e-4
     assert full[..., 3].min() == 255
+
+
+@pytest.mark.parametrize("W,hop,pairs,P", [(65536, 16384, 2, 1024), (1024, 256, 3, 200), (2048, 512, 1, 128), (600, 100, 1, 77)])
+def test_end_to_end_generic_sizes(gpu, oracle, W, hop, pairs, P):
+    """window sizes outside the fused kernel (incl. BASELINE cfg5's N = 65536) through the generic path"""
+    po = oracle
+    cfg = config.spectrum_config(sample_rate=96000.0, window_size=W, hop=hop, num_pairs=pairs, axis_points=P)
+    frames = 5
+    x = synth.gen(31, 96000, W + (frames - 1) * hop, 2 * pairs)
+    r = po.spectrogram(po.params_from_dict(cfg), x, want_lines=True)
+    plan = api.Plan(cfg).upload()
+    rgba = plan.render(_planar_cuda(x, gpu)).cpu().numpy()
+    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
+    assert rgba.shape == r["rgba"].shape
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
 
 
 def test_unsupported_and_errors(gpu):
