@@ -106,7 +106,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.recs = p.d_recs; prm.weights = p.d_weights;
-    prm.items = p.d_items; prm.nItems = uint32_t(p.items.size());
+    prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
     prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
     const long tasks = frames * long(p.C);

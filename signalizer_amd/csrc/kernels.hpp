@@ -20,6 +20,7 @@ struct StftParams {
     const float *weights;
     const MaxItem *items;     // balanced arg-max work list (null: serial per-pixel scan)
     uint32_t nItems;
+    uint32_t nItemsLeft;      // items [0, nItemsLeft) belong to left-side records (ascending k), the rest to the right side
     float invSize;
     float *mapped;            // [frames][C][sides][P] or null
     float *binsOut;           // [frames][C][N+1] or null (test hook)

@@ -392,17 +392,33 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         }
     buildPixelRecords(p);
     p.weights.insert(p.weights.end(), size_t(kMaxTaps), 0.0f);    // padding: the kernel reads kMaxTaps weights unconditionally
-    // balanced arg-max work list: every kind-1 record cut into pieces of <= 16 offsets
+    // balanced arg-max work list: every kind-1 record cut at 16-aligned csf windows (see MaxItem)
     p.items.clear();
+    p.nItemsLeft = 0;
     for (size_t r = 0; r < p.recs.size(); ++r) {
-        const PixelRec &rec = p.recs[r];
+        PixelRec &rec = p.recs[r];
         if (rec.kind != 1) continue;
-        for (int32_t o = 0; o < rec.b; o += 16) {
+        const bool right = r >= size_t(p.P);
+        rec.kind = 1 + 2 * int32_t(p.items.size());      // kind: bit 0 = arg-max record, bits 1.. = index of its first piece
+        int32_t pieces = 0;
+        // scan order = ascending offset; k = offset (left) or N - offset (right)
+        long o = rec.a;
+        const long oEnd = long(rec.a) + rec.b;            // exclusive
+        while (o < oEnd) {
+            const long k = right ? long(p.N) - o : o;
+            const long w = k >> 4;
+            long lo, hi, n;
+            if (!right) { lo = k & 15; n = std::min<long>(16 - lo, oEnd - o); hi = lo + n - 1; }
+            else { hi = k & 15; n = std::min<long>(hi + 1, oEnd - o); lo = hi - n + 1; }
             MaxItem it;
             it.slot = uint32_t(r);
-            it.off0cnt = uint32_t(rec.a + o) | (uint32_t(std::min<int32_t>(16, rec.b - o)) << 24);
+            it.win = uint32_t(w) | (uint32_t(lo) << 16) | (uint32_t(hi) << 20);
             p.items.push_back(it);
+            ++pieces;
+            o += n;
         }
+        (void)pieces;                                      // = number of 16-windows the run spans (recomputed on the device)
+        if (!right) p.nItemsLeft = uint32_t(p.items.size());
     }
     buildTwiddles(p);
     return SGZ_OK;

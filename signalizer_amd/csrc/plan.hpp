@@ -15,16 +15,20 @@ constexpr int kMaxTaps = 10;   // Lanczos a=5 => 10 taps (TransformDSP.inl:514, 
 
 // One record per (side, pixel): how mapToLinearSpace produces csp[x] (TransformDSP.inl:565-639, :878-984).
 struct PixelRec {
-    int32_t kind;    // 0 = interpolate (None/Linear/Lanczos taps), 1 = arg-max of |X|^2 over a bin run
+    int32_t kind;    // 0 = interpolate (None/Linear/Lanczos taps); odd = arg-max of |X|^2 over a bin run, kind >> 1 = index
+                     // of the run's first <=16-bin piece in the MaxItem list
     int32_t a;       // interp: first tap index into csf (already wrapped into [0,N]); max: first offset
     int32_t b;       // interp: number of taps;                                           max: run length (>=1)
     int32_t c;       // interp: offset of this pixel's weights in the weight table;         max: fallback bin
 };
 
-// Work item of the balanced arg-max: scan `cnt` (<= 16) consecutive offsets starting at off0 for record `slot`.
+// Work item ("piece") of the balanced arg-max: the part of one record's bin run that falls into one 16-aligned
+// window of csf indices k in [16 w, 16 w + 16); positions lo..hi (inclusive) of the window belong to the run.
+// Pieces of a run are listed in the reference's scan order (ascending offset: ascending k on the left side,
+// descending k on the right side, where k = N - offset).
 struct MaxItem {
-    uint32_t slot;      // side * P + pixel
-    uint32_t off0cnt;   // off0 | cnt << 24
+    uint32_t slot;      // side * P + pixel (informational)
+    uint32_t win;       // w | lo << 16 | hi << 20
 };
 
 // Scalars the kernels need (all derived on the host exactly as the reference derives them).
@@ -53,7 +57,8 @@ struct Plan {
     std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
-    std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces
+    std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces (left-side records first)
+    uint32_t nItemsLeft = 0;
     std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels (fused N = R^3 path)
     std::vector<float> twN;             // generic path: W_N^i, i < N/2
     bool fused = false;                 // N in {4096, 32768}: spectrum_fft.hip; otherwise spectrum_generic.hip

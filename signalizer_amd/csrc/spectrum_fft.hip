@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace sgz {
@@ -125,7 +127,7 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
         const PixelRec rec = prm.recs[idx];
         const int side = idx >= int(prm.P) ? 1 : 0;
         float val;
-        if (rec.kind == 0) {
+        if ((rec.kind & 1) == 0) {
             float acc = 0.f;
             int k = rec.a;
             for (int i = 0; i < rec.b; ++i) {
@@ -151,55 +153,74 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
     }
 }
 
-// balanced version; `slots` = sides*P zero-initialised 64-bit keys in LDS.  Contains one workgroup barrier.
+// balanced version; `win` = one uint32 per MaxItem in LDS.  Contains one workgroup barrier and NO atomics
+// (ds_max_u64 runs at only ~1 lane-op per 4-6 cycles: 3400 of them cost ~13k cycles per frame).
+//   (a) every <=16-bin piece finds its local winner (first strictly greater |X|^2) and stores the winner's scan offset;
+//   (c) the pixel's thread replays the reference's scan over its pieces' winners, in order -> same arg-max, same ties.
 // Table reads (items, records, tap weights) are issued in batches of independent loads: a thread's work list is
-// tiny, so what matters is the number of dependent global-load round trips (2-3 per phase), not the byte count.
+// tiny, so what matters is the number of dependent global-load round trips, not the byte count.
 template <int LR, int NT>
-__device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const float *lds, unsigned long long *slots,
-                                                  int tid, long task)
+__device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const float *lds, uint32_t *win, int tid, long task)
 {
 #pragma clang fp contract(off)
     constexpr int R = 1 << LR, N = R * R * R;
     constexpr int IB = 8;                                                // items per thread per batch
     constexpr int RB = 4;                                                // records per thread per batch
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     const int total = int(prm.sides * prm.P);
     float *out = prm.mapped + size_t(task) * total;
-    // (a) arg-max pieces
-    for (uint32_t base = 0; base < prm.nItems; base += NT * IB) {
-        MaxItem item[IB];
+    // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
+    // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
+    // to +0, which can never be "strictly greater".  Left-side pieces scan k upwards, right-side pieces downwards.
+    auto scanPieces = [&](uint32_t first, uint32_t last, auto rightSide) {
+        constexpr bool RIGHT = decltype(rightSide)::value;
+        for (uint32_t base = first; base < last; base += NT * IB) {
+            MaxItem item[IB];
 #pragma unroll
-        for (int b = 0; b < IB; ++b) {
-            const uint32_t it = base + b * NT + tid;
-            item[b] = it < prm.nItems ? prm.items[it] : MaxItem{0u, 0u};
+            for (int b = 0; b < IB; ++b) {
+                const uint32_t it = base + b * NT + tid;
+                item[b] = it < last ? prm.items[it] : MaxItem{0u, 0u};
+            }
+            float mv[IB][16];
+#pragma unroll
+            for (int b = 0; b < IB; ++b) {
+                const int k0 = int(item[b].win & 0xFFFFu) << 4;
+                const float *src = lds + (k0 + (k0 >> LR));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mv[b][j] = src[j];
+            }
+            uint32_t winner[IB];
+#pragma unroll
+            for (int b = 0; b < IB; ++b) {
+                const int k0 = int(item[b].win & 0xFFFFu) << 4;
+                const int lo = int((item[b].win >> 16) & 15u), hi = int((item[b].win >> 20) & 15u);
+                // valid-position mask: bits lo..hi
+                const uint32_t mask = (0xFFFFu >> (15 - hi)) & (0xFFFFu << lo);
+                float best = 0.f;
+                uint32_t bestK = kNone;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = RIGHT ? 15 - jj : jj;               // scan order = ascending offset
+                    const float sq = mv[b][j] * mv[b][j] + 0.f;       // Math::square(csf[offset]) with imag == 0
+                    const uint32_t keep = uint32_t(-int32_t((mask >> j) & 1u));
+                    const float sqm = __uint_as_float(__float_as_uint(sq) & keep);
+                    const bool take = sqm > best;                     // first strictly greater wins (TransformDSP.inl:965)
+                    best = take ? sqm : best;
+                    bestK = take ? uint32_t(k0 + j) : bestK;
+                }
+                winner[b] = bestK;
+            }
+#pragma unroll
+            for (int b = 0; b < IB; ++b) {
+                const uint32_t it = base + b * NT + tid;
+                if (it < last) win[it] = winner[b];
+            }
         }
-#pragma unroll
-        for (int b = 0; b < IB; ++b) {
-            const int off0 = int(item[b].off0cnt & 0xFFFFFFu), cnt = int(item[b].off0cnt >> 24);
-            const bool right = item[b].slot >= prm.P;
-            float best = 0.f;
-            uint32_t bestOff = 0;
-            float mv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {                           // 16 independent LDS reads (index clamped, not branched)
-                const int off = off0 + (i < cnt ? i : 0);
-                const int k = right ? (N - off) : off;
-                mv[i] = lds[k + (k >> LR)];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float sq = mv[i] * mv[i] + 0.f;                 // Math::square(csf[offset]) with imag == 0
-                const bool take = (i < cnt) & (sq > best);            // first strictly greater wins (TransformDSP.inl:965)
-                best = take ? sq : best;
-                bestOff = take ? uint32_t(off0 + i) : bestOff;
-            }
-            if (best > 0.f) {
-                const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(best)) << 32) | (0xFFFFFFFFu - bestOff);
-                atomicMax(&slots[item[b].slot], key);
-            }
-        }
-    }
+    };
+    scanPieces(0u, prm.nItemsLeft, std::false_type{});
+    scanPieces(prm.nItemsLeft, prm.nItems, std::true_type{});
     SGZ_CLK(10);
-    // (b) interpolated pixels (<= 10 taps, accumulated in tap order); (c) after the barrier: resolve the arg-max pixels
+    // (b) interpolated pixels (<= 10 taps, accumulated in tap order)
     const bool oneBatch = total <= NT * RB;                              // then the records stay in registers across the barrier
     PixelRec rec[RB];
     for (int base = 0; base < total; base += NT * RB) {
@@ -236,6 +257,7 @@ __device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const f
     SGZ_CLK(11);
     __syncthreads();
     SGZ_CLK(12);
+    // (c) resolve the arg-max pixels from their pieces' winners
     for (int base = 0; base < total; base += NT * RB) {
         if (!oneBatch) {
 #pragma unroll
@@ -246,13 +268,23 @@ __device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const f
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            if (rec[b].kind != 1) continue;
+            if ((rec[b].kind & 1) == 0) continue;
             const int idx = base + b * NT + tid;
-            const unsigned long long key = slots[idx];
+            const bool right = idx >= int(prm.P);
+            const int first = rec[b].kind >> 1;
+            // number of 16-aligned csf windows the run [a, a+b) spans (k = offset, or N - offset on the right side)
+            const int kLo = right ? N - (rec[b].a + rec[b].b - 1) : rec[b].a;
+            const int kHi = right ? N - rec[b].a : rec[b].a + rec[b].b - 1;
+            const int pieces = (kHi >> 4) - (kLo >> 4) + 1;
+            float best = 0.f;
             int k = rec[b].c;                                            // maxLBin = maxRBin = bin (TransformDSP.inl:953)
-            if ((key >> 32) != 0) {
-                const int off = int(0xFFFFFFFFu - uint32_t(key));
-                k = (idx >= int(prm.P)) ? (N - off) : off;
+            for (int pc = 0; pc < pieces; ++pc) {
+                const uint32_t kk = win[first + pc];
+                if (kk != kNone) {
+                    const float m = lds[kk + (kk >> LR)];
+                    const float sq = m * m + 0.f;
+                    if (sq > best) { best = sq; k = int(kk); }
+                }
             }
             out[idx] = finishPixel<LR>(prm.invSize * lds[k + (k >> LR)]);
         }
@@ -326,7 +358,7 @@ stftMapKernel(const StftParams prm)
     constexpr int N = R * T;
     constexpr int PADSTRIDE = T + (T >> LR);          // padded distance between k and k + T
     constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of column 0's 2R-float scratch
-    constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max slots (sides*P u64)
+    constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index of the arg-max piece winners (nItems u32)
     constexpr int TILE = R * (R + 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -336,7 +368,7 @@ stftMapKernel(const StftParams prm)
     const int qA = p, qB = (p == 0) ? R / 2 : R - p;
     const bool split = (prm.sides == 2);
     const int mode = prm.mode;
-    unsigned long long *slots = reinterpret_cast<unsigned long long *>(lds + SLOTS);
+    uint32_t *win = reinterpret_cast<uint32_t *>(lds + SLOTS);          // one winner offset per arg-max piece
     const bool balanced = prm.items != nullptr;
     // prepareTransform channel mixes (TransformDSP.inl:59-216): re = (mixRL*L + mixRR*R)*w*mixS, im likewise
     float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 1.f, mixS = 1.f;      // Phase / Separate / Complex
@@ -529,8 +561,6 @@ stftMapKernel(const StftParams prm)
                 lds[baseA + m3 * PADSTRIDE] = reA[brev(m3, LR)];
                 lds[baseB + m3 * PADSTRIDE] = reB[brev(m3, LR)];
             }
-            if (balanced)
-                for (int i = tid; i < int(prm.sides * prm.P); i += TR) slots[i] = 0ull;
             __syncthreads();
             if (split && tid >= 1 && tid < R / 2) {
                 // column 0: k = T m3 pairs with T (R - m3); both were held by thread 0 -> lanes 1..R/2-1 redo them
@@ -565,8 +595,6 @@ stftMapKernel(const StftParams prm)
             const float *src = prm.binsIn + size_t(task) * (N + 1);
             __syncthreads();
             for (int k = tid; k <= N; k += TR) lds[k + (k >> LR)] = src[k];
-            if (balanced)
-                for (int i = tid; i < int(prm.sides * prm.P); i += TR) slots[i] = 0ull;
             __syncthreads();
         }
         SGZ_CLK(7);
@@ -578,7 +606,7 @@ stftMapKernel(const StftParams prm)
         SGZ_CLK(8);
         // ---------------------------------------------------------------------- pixel mapping
         if (prm.mapped && !(prm.ablate & 16)) {
-            if (balanced) mapPixelsBalanced<LR, TR>(prm, lds, slots, tid, task);
+            if (balanced) mapPixelsBalanced<LR, TR>(prm, lds, win, tid, task);
             else mapPixelsSerial<LR, TR>(prm, lds, tid, task);
         }
         SGZ_CLK(9);
@@ -590,7 +618,7 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
     const size_t baseBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4) * sizeof(float);
-    const size_t slotBytes = size_t(prm.sides) * prm.P * 8;
+    const size_t slotBytes = size_t(prm.nItems) * 4;
     StftParams p2 = prm;
     size_t ldsBytes = baseBytes;
     if (p2.items && baseBytes + slotBytes <= 160 * 1024) ldsBytes += slotBytes;   // arg-max slots fit beside the |X| array

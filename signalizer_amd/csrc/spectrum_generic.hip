@@ -113,7 +113,7 @@ genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const Pixe
     const PixelRec rec = recs[idx];
     const int side = idx >= P ? 1 : 0;
     float val;
-    if (rec.kind == 0) {
+    if ((rec.kind & 1) == 0) {
         float acc = 0.f;
         int k = rec.a;
         for (int i = 0; i < rec.b; ++i) {
