@@ -201,8 +201,8 @@ __device__ __forceinline__ void mapPixelsBalanced(const StftParams &prm, const f
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     const int j = RIGHT ? 15 - jj : jj;               // scan order = ascending offset
-                    const float sq = mv[b][j] * mv[b][j] + 0.f;       // Math::square(csf[offset]) with imag == 0
-                    const uint32_t keep = uint32_t(-int32_t((mask >> j) & 1u));
+                    const float sq = mv[b][j] * mv[b][j];             // Math::square(csf[offset]) with imag == 0 (x*x + 0 == x*x)
+                    const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mask), j, 1));   // 0 or ~0
                     const float sqm = __uint_as_float(__float_as_uint(sq) & keep);
                     const bool take = sqm > best;                     // first strictly greater wins (TransformDSP.inl:965)
                     best = take ? sqm : best;

@@ -120,8 +120,8 @@ class TimeChunkRenderer:
         """one full pass; returns this rank's RGBA8 columns [local_frames, P, 4]"""
         torch = self.torch
         if self.world == 1:
-            self.state.zero_()
-            self.backend.render(self._view(), self.rgba, self.state)
+            # single device: start from a zero decay state, nobody needs the end state -> no memset, no snapshot
+            self.backend.render(self._view(), self.rgba, None)
             return self.rgba
         import torch.distributed as dist
         # A1: halo = everybody's leading W samples
