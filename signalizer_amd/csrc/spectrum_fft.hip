@@ -93,7 +93,7 @@ __device__ __forceinline__ float2 bufLoad2(__amdgpu_buffer_rsrc_t r, int voff, i
 
 #define SGZ_CLK(slot)                                                                                   \
     do {                                                                                                \
-        if (prm.phaseClock && tid == 0 && task == 0)                   \
+        if (prm.phaseClock && tid == 0 && task == long(prm.ablate >> 16))                   \
             prm.phaseClock[slot] = __builtin_readcyclecounter();                                         \
     } while (0)
 

@@ -10,7 +10,7 @@ F = plan.num_frames(S)
 mapped = torch.empty((F, 1, 2, 1024), dtype=torch.float32, device="cuda")
 clk = torch.zeros(16, dtype=torch.int64, device="cuda")
 L = api.lib()
-L.sgz_debug_set_ablate(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+L.sgz_debug_set_ablate((int(sys.argv[2]) if len(sys.argv) > 2 else 0) | ((int(sys.argv[3]) if len(sys.argv) > 3 else 0) << 16))
 L.sgz_debug_phase_clocks.argtypes = [C.c_void_p] * 2 + [C.c_size_t] * 2 + [C.c_void_p] * 3
 names = ["0:top", "1:dif1+tw1", "2:ex1", "3:dif2+tw2", "4:ex2", "5:dif3", "6:mirror", "7:Mwrite+fix", "8:binsOut+prefetch", "9:map+window"]
 for rep in range(3):
