@@ -8,7 +8,7 @@ x = torch.from_numpy(synth.gen(2, 48000, S, 2)).cuda()
 plan = api.Plan(cfg).upload()
 r = sharding.TimeChunkRenderer(plan, x)
 L = api.lib()
-names = {0: "full", 64: "full, vec4 loads (wrong layout)", 63 | 64: "nothing, vec4 loads", 63 | 128: "nothing, no window",  1: "no dif", 2: "no ex1", 4: "no ex2", 8: "no mirror", 16: "no map", 32: "no twiddle", 63: "nothing (loads+barriers only)",
+names = {0: "full", 512: "empty kernel", 63|1024: "nothing, no M write", 63|1024|64|128: "nothing, no M write, only L", 63 | 64: "nothing, no window", 63 | 128: "nothing, no R", 63 | 64 | 128: "nothing, only L", 63 | 256: "nothing, hot frames", 63|64|256: "nothing, hot, no window", 256: "full, hot frames", 64: "full, no window",  1: "no dif", 2: "no ex1", 4: "no ex2", 8: "no mirror", 16: "no map", 32: "no twiddle", 63: "nothing (loads+barriers only)",
          62: "only dif", 1 | 32: "no dif, no tw", 2 | 4 | 8: "no lds", 16 | 8: "no mirror,no map"}
 for bits, name in names.items():
     L.sgz_debug_set_ablate(bits)

@@ -1,0 +1,116 @@
+// radix-32 DIF butterflies: scalar (two sets one after the other) vs packed (v2: both sets per instruction)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../signalizer_amd/csrc/fft_common.hpp"
+using namespace sgz;
+// complex-interleaved packed DIF: c[i] = (re, im); twiddle W = (c, -s): d * W = d * (c, c) + (d.y, -d.x) * (s, s)
+template <int R, int LEN, int BASE>
+__device__ __forceinline__ void difc(v2 (&c)[R])
+{
+    constexpr int H = LEN / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const int a = BASE + i, b = BASE + i + H;
+        const v2 x = c[a], y = c[b];
+        c[a] = x + y;
+        const v2 d = x - y;
+        const int j = i * (32 / LEN);
+        if (j == 0) c[b] = d;
+        else if (j == 8) c[b] = v2{d.y, -d.x};
+        else {
+            const float cs = cos32(j), sn = sin32(j);
+            c[b] = d * v2{cs, cs} + v2{d.y, -d.x} * v2{sn, sn};
+        }
+    }
+    if constexpr (LEN > 2) {
+        difc<R, H, BASE>(c);
+        difc<R, H, BASE + H>(c);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(MODE >= 2 ? 1024 : 512) k(float *out, long long *clk, const float *in)
+{
+    constexpr int R = 32;
+    float acc = 0.f;
+    long long t0, t1;
+    if (MODE == 0) {
+        float reA[R], imA[R], reB[R], imB[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { reA[i] = in[threadIdx.x + i]; imA[i] = in[threadIdx.x + i + 64]; reB[i] = in[threadIdx.x + i + 128]; imB[i] = in[threadIdx.x + i + 192]; }
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            dif<float, R, R, 0>(reA, imA);
+            dif<float, R, R, 0>(reB, imB);
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(reA[i]), "+v"(imA[i]), "+v"(reB[i]), "+v"(imB[i]));
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc += reA[i] + imA[i] + reB[i] + imB[i];
+    } else if (MODE == 2) {          // one set per thread (V = 1): launch with 1024 threads = 4 waves / SIMD
+        float reA[R], imA[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { reA[i] = in[threadIdx.x + i]; imA[i] = in[threadIdx.x + i + 64]; }
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            dif<float, R, R, 0>(reA, imA);
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(reA[i]), "+v"(imA[i]));
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc += reA[i] + imA[i];
+    } else if (MODE == 3) {          // V = 1, complex-interleaved packed math, 1024 threads
+        v2 c[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) c[i] = v2{in[threadIdx.x + i], in[threadIdx.x + i + 64]};
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            difc<R, R, 0>(c);
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(c[i]));
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc += c[i].x + c[i].y;
+    } else {
+        v2 re[R], im[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { re[i] = v2{in[threadIdx.x + i], in[threadIdx.x + i + 128]}; im[i] = v2{in[threadIdx.x + i + 64], in[threadIdx.x + i + 192]}; }
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            dif<v2, R, R, 0>(re, im);
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(re[i]), "+v"(im[i]));
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc += re[i].x + im[i].x + re[i].y + im[i].y;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+}
+int main()
+{
+    float *out, *in; long long *clk;
+    hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&in, 4 * 4096); hipMalloc(&clk, 8 * 1024);
+    hipMemset(in, 0, 4 * 4096);
+    std::vector<long long> h(1024);
+    auto run = [&](const char *name, auto kern, int threads = 512) {
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, clk, in); hipDeviceSynchronize(); }
+        hipMemcpy(h.data(), clk, 8 * 256, hipMemcpyDeviceToHost);
+        double avg = 0; for (int i = 0; i < 256; ++i) avg += h[i]; avg /= 256;
+        printf("%-34s %.0f ticks per (2 x 32-point DIF)\n", name, avg / 16);
+    };
+    run("scalar A then B", k<0>);
+    run("packed v2", k<1>);
+    run("scalar V=1, 1024 threads", k<2>, 1024);
+    run("packed complex V=1, 1024 threads", k<3>, 1024);
+    return 0;
+}
