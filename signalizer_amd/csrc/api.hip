@@ -147,14 +147,20 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     prm.colourTables = p.d_colourTables;
     prm.sc = p.scalars;
     prm.state = d_state; prm.stateIn = d_state; prm.rgba = d_rgba; prm.lines = d_lines;
+    prm.ablate = (g_ablate >> 13) & 7u;
+    if (d_state && frames > 1) {
+        // frame 0's threads read the carry-in while the last frame's threads write the new state: snapshot it
+        const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+        sgz_status st0 = ensureCap(&p.d_stateCopy, &p.stateCopyCap, stateN);
+        if (st0 != SGZ_OK) return st0;
+        SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        prm.stateIn = p.d_stateCopy;
+    }
+    if (decayFusedApplies(prm) && !(g_ablate & 0x1000u)) {           // one launch: local scans, fold and emit in one workgroup pass
+        SGZ_HIP(launchDecayFused(prm, stream));
+        return SGZ_OK;
+    }
     if (prm.numChunks > 1) {
-        if (d_state) {      // chunk 0 reads the carry-in while the last chunk writes the new state: snapshot it
-            const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
-            sgz_status st0 = ensureCap(&p.d_stateCopy, &p.stateCopyCap, stateN);
-            if (st0 != SGZ_OK) return st0;
-            SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            prm.stateIn = p.d_stateCopy;
-        }
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
         sgz_status st = ensureCap(&p.d_agg, &p.aggCap, need);
         if (st != SGZ_OK) return st;

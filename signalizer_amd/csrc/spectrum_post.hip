@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
 }
 
 // K_B1b: exact state at the END of every chunk, in place: agg[c] <- max(agg[c], decay^chunkLen(agg[c-1])) with the
-// decay done by sequential fp32 multiplies.  thread <-> (pair, side, graph, pixel); sequential over chunks (tiny).
+// decay done by sequential fp32 multiplies.  thread <-> (pair, side, graph, pixel); sequential over chunks.
 __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
 {
     const size_t per = size_t(prm.C) * prm.sides * G * prm.P;
@@ -71,12 +71,12 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     const uint32_t k = uint32_t((e / prm.P) % G);
     const float pole = prm.sc.pole[k];
     float c = prm.agg[e];
-    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 8) {
-        float a[8];
+    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
+        float a[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = (d0 + j < prm.numChunks) ? prm.agg[size_t(d0 + j) * per + e] : 0.f;
+        for (int j = 0; j < 16; ++j) a[j] = (d0 + j < prm.numChunks) ? prm.agg[size_t(d0 + j) * per + e] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             if (d0 + j < prm.numChunks) {
 #pragma unroll
                 for (int i = 0; i < kMaxChunk; ++i) c = c * pole;      // every chunk before the last is full
@@ -94,102 +94,199 @@ __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalar
     return deltaX > 0.f ? float(log(double(deltaX))) * sc.deltaYRecip : sc.lowerClip;   // :1345
 }
 
-// K_B2: carry fix-up + dB map + colour blend.  thread <-> (chunk, pixel); loops pairs, sides, graphs.
-// agg[c] holds the exact end state of chunk c (K_B1b) when numChunks > 1.
-__global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
+// dB map + colour blend + line / state outputs of ONE (frame, pixel): replays the chunk's recurrence up to frame
+// f = f0 + t (<= 8 steps) on top of the chunk's carry-in states.  carryIn[m * carryStride] = exact state of
+// (pair, side, graph) combination m = (pair * sides + side) * G + graph at the end of the previous chunk (unused for
+// chunk 0, where the caller's carry-in state applies instead).
+// colourTab: prm.colourTables or a copy in LDS; mag0: the magnitudes of (pair 0, side 0), already loaded, or null.
+__device__ __forceinline__ void emitPixel(const DecayParams &prm, uint32_t chunk, int t, uint32_t pixel, bool allCombos,
+                                          const float *carryIn, uint32_t carryStride, const float *colourTab, float slope,
+                                          const float *mag0)
 {
-    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= size_t(prm.P) * prm.numChunks) return;
-    const uint32_t chunk = uint32_t(gid / prm.P);
-    const uint32_t pixel = uint32_t(gid - size_t(chunk) * prm.P);
     const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
-    const long f0 = long(chunk) * kMaxChunk;
-    const long f1 = min(f0 + long(kMaxChunk), prm.frames);
-    const int len = int(f1 - f0);
-    const float slope = prm.slope[pixel];
-    const bool last = (f1 == prm.frames);
-
-    float cb[kMaxChunk][3];
-#pragma unroll
-    for (int t = 0; t < kMaxChunk; ++t) cb[t][0] = cb[t][1] = cb[t][2] = 0.f;   // colourBuffer, SpectrumDSP.cpp:170-174
-
+    const long f0 = long(chunk) * kMaxChunk, f = f0 + t;
+    float cb[3] = {0.f, 0.f, 0.f};                              // colourBuffer, SpectrumDSP.cpp:170-174
     for (uint32_t pair = 0; pair < prm.C; ++pair) {
-        const float *sca = prm.colourTables + size_t(pair) * NC * 3;
+        const float *sca = colourTab + size_t(pair) * NC * 3;
         for (uint32_t side = 0; side < prm.sides; ++side) {
+            if (!allCombos && side != 0) continue;              // only (side 0, graph 0) feeds the colour column
             const uint32_t ps = pair * prm.sides + side;
             float mag[kMaxChunk];
+            if (ps == 0 && mag0) {
 #pragma unroll
-            for (int t = 0; t < kMaxChunk; ++t)                 // independent loads first
-                mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perFrame + size_t(ps) * prm.P + pixel];
+                for (int i = 0; i < kMaxChunk; ++i) mag[i] = mag0[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i)             // independent loads first
+                    mag[i] = i <= t ? prm.mapped[size_t(f0 + i) * perFrame + size_t(ps) * prm.P + pixel] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < G; ++k) {
-                // what the colour column needs is (side 0, graph 0); everything else only matters for line output
-                // and for the state after the last frame
                 const bool colour = (side == 0 && k == 0 && prm.rgba);
-                if (!colour && !prm.lines && !(last && prm.state)) continue;
+                if (!colour && !allCombos) continue;
                 const float pole = prm.sc.pole[k];
-                float cr = chunk > 0 ? prm.agg[((size_t(chunk - 1) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] : 0.f;
+                float cr = chunk > 0 ? carryIn[(ps * G + k) * carryStride] : 0.f;
                 float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
-                float s = 0.f;
 #pragma unroll
-                for (int t = 0; t < kMaxChunk; ++t) {
-                    if (t < len) {
-                        const long f = f0 + t;
-                        a = a * pole;
-                        if (mag[t] > a) a = mag[t];
+                for (int i = 0; i < kMaxChunk; ++i) {
+                    if (i <= t) {
+                        a = a * pole;                           // states[i] *= pole, TransformDSP.inl:1336,:1370
+                        if (mag[i] > a) a = mag[i];             // :1338-1341
                         cr = cr * pole;
-                        s = a > cr ? a : cr;
-                        if (colour || prm.lines) {
-                            const float result = dbMap(slope, s, prm.sc);
-                            if (prm.lines)
-                                prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
-                            if (colour) {
-                                // renderSf, SpectrumDSP.cpp:119-168
-                                const float intensity = result;
-                                if (!(intensity < 0.f)) {
-                                    float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
-                                    if (intensity < 0.999f) {
-                                        float accumulatedSum = 0.f;
-                                        for (int c = 1; c < NC; ++c) {
-                                            const float nextScale = prm.sc.ratios[c];
-                                            accumulatedSum += nextScale;
-                                            if (accumulatedSum >= intensity) {
-                                                const float mn = accumulatedSum - nextScale;
-                                                const float mx = accumulatedSum;
-                                                const float mix = (intensity - mn) / (mx - mn);
-                                                const float imix = 1.f - mix;
-                                                const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
-                                                colourv[0] = ca[0] * imix + cbb[0] * mix;
-                                                colourv[1] = ca[1] * imix + cbb[1] * mix;
-                                                colourv[2] = ca[2] * imix + cbb[2] * mix;
-                                                break;
-                                            }
-                                        }
-                                    }
-#pragma unroll
-                                    for (int c = 0; c < 3; ++c) cb[t][c] += (1.f - cb[t][c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
+                    }
+                }
+                const float s = a > cr ? a : cr;
+                if (prm.state && f == prm.frames - 1)
+                    prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = s;
+                if (!colour && !prm.lines) continue;
+                const float result = dbMap(slope, s, prm.sc);
+                if (prm.lines)
+                    prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
+                if (colour) {
+                    // renderSf, SpectrumDSP.cpp:119-168
+                    const float intensity = result;
+                    if (!(intensity < 0.f)) {
+                        float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
+                        if (intensity < 0.999f) {
+                            float accumulatedSum = 0.f;
+                            for (int c = 1; c < NC; ++c) {
+                                const float nextScale = prm.sc.ratios[c];
+                                accumulatedSum += nextScale;
+                                if (accumulatedSum >= intensity) {
+                                    const float mn = accumulatedSum - nextScale;
+                                    const float mx = accumulatedSum;
+                                    const float mix = (intensity - mn) / (mx - mn);
+                                    const float imix = 1.f - mix;
+                                    const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
+                                    colourv[0] = ca[0] * imix + cbb[0] * mix;
+                                    colourv[1] = ca[1] * imix + cbb[1] * mix;
+                                    colourv[2] = ca[2] * imix + cbb[2] * mix;
+                                    break;
                                 }
                             }
                         }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) cb[c] += (1.f - cb[c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
                     }
                 }
-                if (prm.state && last && len > 0)
-                    prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = s;
             }
         }
     }
     if (prm.rgba) {
+        uchar4 pxl;
+        pxl.x = (unsigned char)(cb[0] * 255.f);                 // static_cast<uint8_t>(c * maxByte), :195-198
+        pxl.y = (unsigned char)(cb[1] * 255.f);
+        pxl.z = (unsigned char)(cb[2] * 255.f);
+        pxl.w = 255;
+        reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = pxl;
+    }
+}
+
+// K_B2 (long inputs, after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels.
+__global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
+{
+    const int px = threadIdx.x & 31, t = threadIdx.x >> 5;
+    const uint32_t groups = (prm.P + 31) / 32;
+    const uint32_t chunk = blockIdx.x / groups;
+    const uint32_t pixel = (blockIdx.x - chunk * groups) * 32 + px;
+    const long f0 = long(chunk) * kMaxChunk;
+    const long f1 = min(f0 + long(kMaxChunk), prm.frames);
+    if (pixel >= prm.P || t >= int(f1 - f0)) return;
+    const bool allCombos = prm.lines || (f1 == prm.frames && prm.state);
+    const float *carryIn = chunk > 0 ? prm.agg + size_t(chunk - 1) * prm.C * prm.sides * G * prm.P + pixel : nullptr;
+    emitPixel(prm, chunk, t, pixel, allCombos, carryIn, prm.P, prm.colourTables, prm.slope[pixel], nullptr);
+}
+
+// K_B as ONE launch (inputs whose chunk states fit in LDS): a workgroup owns kFusedPx pixels for the WHOLE time axis.
+//   phase 1: chunk-local scans (as K_B1)                        -> LDS  st[chunk][m][px]
+//   phase 2: sequential fold over the chunks (as K_B1b), in LDS -> exact chunk-end states
+//   phase 3: one (frame, pixel) item at a time (as K_B2)
+// Three dependent kernels cost three launch latencies (~5 us each for this little data); here the dependency is two
+// workgroup barriers.  Rows of kFusedPx pixels are narrow (16 B), but the whole mapped array is only frames*P*8 B.
+constexpr int kFusedPx = 4;
+constexpr int kFusedThreads = 1024;
+
+__global__ void __launch_bounds__(kFusedThreads) decayFusedKernel(const DecayParams prm)
+{
+    extern __shared__ float st[];                               // [numChunks][combos][kFusedPx], then [C][NC][3] colour tables
+    const uint32_t tid = threadIdx.x;
+    float *colourTab = st + size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx;
+    const uint32_t pixel0 = blockIdx.x * kFusedPx;
+    const uint32_t combos = prm.C * prm.sides * G, cs = prm.C * prm.sides;
+    const size_t perFrame = size_t(cs) * prm.P;
+    // phase 1: item = (chunk, ps, px)
+    for (uint32_t it = tid; it < prm.numChunks * cs * kFusedPx && !(prm.ablate & 4); it += kFusedThreads) {
+        const uint32_t px = it % kFusedPx, ps = (it / kFusedPx) % cs, chunk = it / (kFusedPx * cs);
+        const uint32_t pixel = pixel0 + px;
+        if (pixel >= prm.P) continue;
+        const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
+        const long f0 = long(chunk) * kMaxChunk;
+        const int len = int(min(long(kMaxChunk), prm.frames - f0));
+        float mag[kMaxChunk];
 #pragma unroll
-        for (int t = 0; t < kMaxChunk; ++t) {
-            if (t < len) {
-                uchar4 px;
-                px.x = (unsigned char)(cb[t][0] * 255.f);       // static_cast<uint8_t>(c * maxByte), :195-198
-                px.y = (unsigned char)(cb[t][1] * 255.f);
-                px.z = (unsigned char)(cb[t][2] * 255.f);
-                px.w = 255;
-                reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f0 + t) * prm.P + pixel] = px;
+        for (int i = 0; i < kMaxChunk; ++i)
+            mag[i] = prm.mapped[size_t(f0 + (i < len ? i : 0)) * perFrame + size_t(ps) * prm.P + pixel];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) {
+                if (i < len) {
+                    a = a * prm.sc.pole[k];                     // states[i] *= pole, TransformDSP.inl:1336,:1370
+                    if (mag[i] > a) a = mag[i];                 // :1338-1341
+                }
             }
+            st[(chunk * combos + ps * G + k) * kFusedPx + px] = a;
         }
+    }
+    // phase-3 operands that do not depend on the fold: fetched now, consumed after the barriers
+    float mag0[kMaxChunk], slope0 = 0.f;
+    {
+        const long f = tid / kFusedPx;
+        const uint32_t pixel = pixel0 + tid % kFusedPx;
+        const bool have = f < prm.frames && pixel < prm.P;
+        const long f0 = (f / kMaxChunk) * kMaxChunk;
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) mag0[i] = (have && f0 + i <= f) ? prm.mapped[size_t(f0 + i) * perFrame + pixel] : 0.f;
+        if (have) slope0 = prm.slope[pixel];
+    }
+    for (uint32_t i = tid; i < prm.C * NC * 3; i += kFusedThreads) colourTab[i] = prm.colourTables[i];
+    __syncthreads();
+    // phase 2: item = (m, px); st[c] <- max(st[c], decay^8(st[c-1])) by sequential fp32 multiplies.  Blocks of 16 chunk
+    // states are read from LDS together, chained in registers and written back.
+    if (tid < combos * kFusedPx && !(prm.ablate & 1)) {
+        const float pole = prm.sc.pole[(tid / kFusedPx) % G];
+        const uint32_t rs = combos * kFusedPx;
+        float c = st[tid];
+        for (uint32_t j0 = 1; j0 < prm.numChunks; j0 += 16) {
+            float a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = st[min(j0 + j, prm.numChunks - 1) * rs + tid];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;   // every chunk before the last is full
+                if (a[j] > c) c = a[j];
+                a[j] = c;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j0 + j < prm.numChunks) st[(j0 + j) * rs + tid] = a[j];
+        }
+    }
+    __syncthreads();
+    // phase 3: item = (frame, px)
+    for (long it = tid; it < prm.frames * kFusedPx && !(prm.ablate & 2); it += kFusedThreads) {
+        const uint32_t px = uint32_t(it % kFusedPx);
+        const long f = it / kFusedPx;
+        const uint32_t pixel = pixel0 + px;
+        if (pixel >= prm.P) continue;
+        const uint32_t chunk = uint32_t(f / kMaxChunk);
+        const bool allCombos = prm.lines || (chunk + 1 == prm.numChunks && prm.state);
+        const bool first = it == long(tid);
+        emitPixel(prm, chunk, int(f - long(chunk) * kMaxChunk), pixel, allCombos,
+                  st + (chunk > 0 ? size_t(chunk - 1) * combos * kFusedPx : 0) + px, kFusedPx, colourTab,
+                  first ? slope0 : prm.slope[pixel], first ? mag0 : nullptr);
     }
 }
 
@@ -242,12 +339,30 @@ hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
     return hipGetLastError();
 }
 
+// the single-launch K_B applies while all chunk states of a pixel group fit in LDS
+bool decayFusedApplies(const DecayParams &prm)
+{
+    return (size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx + size_t(prm.C) * NC * 3) * sizeof(float) <= 96 * 1024;
+}
+
+hipError_t launchDecayFused(const DecayParams &prm, hipStream_t stream)
+{
+    const size_t ldsBytes = (size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx + size_t(prm.C) * NC * 3) * sizeof(float);
+    static size_t attrBytes = 0;
+    if (attrBytes < ldsBytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decayFusedKernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+        if (e != hipSuccess) return e;
+        attrBytes = ldsBytes;
+    }
+    hipLaunchKernelGGL(decayFusedKernel, dim3((prm.P + kFusedPx - 1) / kFusedPx), dim3(kFusedThreads), ldsBytes, stream, prm);
+    return hipGetLastError();
+}
+
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream)
 {
-    const size_t total = size_t(prm.P) * prm.numChunks;
-    const int block = 256;
-    const unsigned grid = unsigned((total + block - 1) / block);
-    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(block), 0, stream, prm);
+    const unsigned grid = unsigned(size_t((prm.P + 31) / 32) * prm.numChunks);
+    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(256), 0, stream, prm);
     return hipGetLastError();
 }
 
