@@ -58,6 +58,16 @@ class HipEvents:
         return float(ms.value)
 
 
+def measured_traffic():
+    """HBM bytes per K_A launch from the last committed PMC pass (tools/profile.sh -> profiles/traffic_latest.json;
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+            return int(json.load(fh)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
     """The CPU oracle (a restatement: 'port') timed on this host, 1 thread, on a bounded sample of the
     same workload: the first frames of the same buffer until ~budget_s of CPU work."""
@@ -157,8 +167,8 @@ def main() -> None:
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "stftMapKernel<5>", "kernel_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(),
+                         "kernel": "stftMapKernel<5, 0>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": frames_per_rank * BYTES_PER_FRAME},
         }
         if not args.no_cpu_baseline and world == 1:

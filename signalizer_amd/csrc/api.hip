@@ -377,7 +377,7 @@ sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t 
 
 void sgz_debug_set_ablate(uint32_t bits) { g_ablate = bits; }
 
-/* debug hook (not in sgz.h): per-phase shader clocks of workgroup 0 of K_A; d_clocks: DEVICE uint64[16] */
+/* debug hook (not in sgz.h): per-phase shader clocks of workgroup 0 of K_A; d_clocks: DEVICE uint64[16 slots x 16 waves] */
 sgz_status sgz_debug_phase_clocks(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
                                   float *d_mapped, unsigned long long *d_clocks, void *stream)
 {

@@ -31,18 +31,14 @@
 
 namespace sgz {
 
-// per-wave clocks (debug hook): slot 16 + 4 * wave + i, i = 0 start, 1 after pass 3, 2 before map, 3 end
-#define SGZ_WCLK(i)                                                                                      \
-    do {                                                                                                \
-        if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16))                        \
-            prm.phaseClock[16 + 4 * (tid >> 6) + (i)] = __builtin_readcyclecounter();                    \
-    } while (0)
-
+// debug hook (tools/phase_clocks.py): every wave of one workgroup stores s_memtime at the phase boundaries,
+// phaseClock[16 * wave + slot]
 #define SGZ_CLK(slot)                                                                                   \
     do {                                                                                                \
-        if (prm.phaseClock && tid == 0 && task == long(prm.ablate >> 16))                   \
-            prm.phaseClock[slot] = __builtin_readcyclecounter();                                         \
+        if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16))                        \
+            prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter();                     \
     } while (0)
+#define SGZ_WCLK(i) do { } while (0)
 
 // Pixel mapping of mapToLinearSpace (TransformDSP.inl:565-639, :871-985) on the csf magnitudes held in LDS
 // (bank-padded natural order).  Every operation rounds exactly like the reference's scalar fp32 code:
@@ -375,8 +371,10 @@ stftMapKernel(const StftParams prm)
             }
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the twiddle loads below the 3R sample loads (128-VGPR budget)
+        SGZ_CLK(13);
         // ---------------------------------------------------------------------- pass 1
         if (!(prm.ablate & 1)) dif<float, R, R, 0>(re, im);
+        SGZ_CLK(14);
         if (!(prm.ablate & 32)) {
             const __amdgpu_buffer_rsrc_t rs = makeRsrc(prm.tw1, uint32_t(3 + R / 4 - 1) * T * 8u);
             TwFactors<LR> tw;
