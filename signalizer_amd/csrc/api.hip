@@ -93,8 +93,8 @@ int numCUs()
 }
 
 // K_A launch over `frames` frames of `planar`; writes mapped/bins as requested.
-sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
-                          float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock)
+static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, float *d_binsOut,
+                                 const float *d_binsIn, unsigned long long *d_phaseClock)
 {
     StftParams prm{};
     prm.planar = d_planar;
@@ -108,7 +108,15 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     prm.recs = p.d_recs; prm.weights = p.d_weights;
     prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
+    prm.roundSize = uint32_t(numCUs());
     prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
+    return prm;
+}
+
+sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
+                          float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock)
+{
+    StftParams prm = fillStftParams(p, d_planar, chStride, frames, d_mapped, d_binsOut, d_binsIn, d_phaseClock);
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
@@ -133,11 +141,11 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     return SGZ_OK;
 }
 
-sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
-                                 float *d_state, hipStream_t stream)
+// DecayParams of one K_B pass (snapshots the carry-in state when the pass both reads and writes it)
+static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines, float *d_state,
+                                  hipStream_t stream, DecayParams &prm)
 {
-    if (frames <= 0) return SGZ_OK;
-    DecayParams prm{};
+    prm = DecayParams{};
     prm.mapped = d_mapped;
     prm.frames = frames;
     prm.P = p.P; prm.C = p.C; prm.sides = uint32_t(p.sides);
@@ -156,6 +164,16 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
         prm.stateIn = p.d_stateCopy;
     }
+    return SGZ_OK;
+}
+
+sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
+                                 float *d_state, hipStream_t stream)
+{
+    if (frames <= 0) return SGZ_OK;
+    DecayParams prm;
+    sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
+    if (stp != SGZ_OK) return stp;
     if (decayFusedApplies(prm) && !(g_ablate & 0x1000u)) {           // one launch: local scans, fold and emit in one workgroup pass
         SGZ_HIP(launchDecayFused(prm, stream));
         return SGZ_OK;

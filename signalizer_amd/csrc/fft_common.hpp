@@ -5,6 +5,8 @@
 
 namespace sgz {
 
+typedef float v2 __attribute__((ext_vector_type(2)));      // an aligned VGPR pair: (re, im) of one complex value
+
 // ---- compile-time twiddles W_32^j = cos(2 pi j/32) - i sin(2 pi j/32), j = 0..16 ---------------------
 __host__ __device__ constexpr float cos32(int j)
 {
@@ -24,9 +26,6 @@ __host__ __device__ constexpr int brev(int x, int bits)
     return r;
 }
 
-// v2: two independent problems side by side (packed fp32 VALU ops); used by tools/ubench/dif.hip to compare
-// scalar / packed / more-waves variants of the butterflies ("what bounds K_A").
-typedef float v2 __attribute__((ext_vector_type(2)));
 
 // In-register radix-2 DIF over LEN elements starting at BASE; result is in bit-reversed order.  V = float or v2.
 template <typename V, int R, int LEN, int BASE>
@@ -52,6 +51,55 @@ __device__ __forceinline__ void dif(V (&re)[R], V (&im)[R])
     if constexpr (LEN > 2) {
         dif<V, R, H, BASE>(re, im);
         dif<V, R, H, BASE + H>(re, im);
+    }
+}
+
+// ---- packed complex arithmetic: one value = (re, im) in an aligned VGPR pair, VOP3P ops with op_sel / neg modifiers.
+// A SIMD's VALU issue rate is per instruction (tools/ubench/valu.hip: v_pk_fma_f32 issues like v_fma_f32), so a butterfly
+// on (re, im) pairs costs half the instructions of the scalar form.  hipcc does not fold the (im, -re) swizzles of a
+// complex multiply into op_sel on its own (tools/ubench/dif.hip: 218 extra moves per 32-point DIF), hence the asm.
+// (-i) * (x - y) = (x.im - y.im, y.re - x.re)
+__device__ __forceinline__ v2 rotSub(v2 x, v2 y)
+{
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// d * (k.x - i k.y), k wave-uniform (an SGPR pair): (d.re c + d.im s, d.im c - d.re s)
+__device__ __forceinline__ v2 cmulConjK(v2 d, v2 k)
+{
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(d), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(d), "s"(k), "v"(t));
+    return r;
+}
+// c * w for a per-lane w = (w.re, w.im): (c.re w.re - c.im w.im, c.re w.im + c.im w.re)
+__device__ __forceinline__ v2 cmul(v2 c, v2 w)
+{
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(c), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(c), "v"(w), "v"(t));
+    return r;
+}
+
+// In-register radix-2 DIF over LEN packed complex elements starting at BASE; result in bit-reversed order.
+template <int R, int LEN, int BASE>
+__device__ __forceinline__ void difPacked(v2 (&c)[R])
+{
+    constexpr int H = LEN / 2;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const int a = BASE + i, b = BASE + i + H;
+        const v2 x = c[a], y = c[b];
+        c[a] = x + y;
+        const int j = i * (32 / LEN);
+        if (j == 0) c[b] = x - y;
+        else if (j == 8) c[b] = rotSub(x, y);
+        else c[b] = cmulConjK(x - y, v2{cos32(j), sin32(j)});
+    }
+    if constexpr (LEN > 2) {
+        difPacked<R, H, BASE>(c);
+        difPacked<R, H, BASE + H>(c);
     }
 }
 
@@ -87,6 +135,14 @@ __device__ __forceinline__ int opaque(int v)
 // Factorised twiddles: W^{x q} for q = 4a + b is B_a * A_b with A_b = W^{x b} (b = 1..3) and B_a = W^{x 4a}
 // (a = 1..R/4-1), so a thread fetches 3 + R/4 - 1 complex values instead of R - 1 (10 instead of 31 at R = 32)
 // and spends 4 VALU ops per product.  tw: table rows [A_1, A_2, A_3, B_1, .., B_{R/4-1}], row stride `rowBytes`.
+// Global load at a wave-uniform base + a 32-bit per-lane byte offset: the form that selects `global_load … v_off, s[base]`
+// (one offset VGPR; a 64-bit element index makes hipcc build, keep and spill a 64-bit address pair per load).
+template <typename T>
+__device__ __forceinline__ T ldg(const T *base, uint32_t byteOff)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byteOff);
+}
+
 template <int LR>
 struct TwFactors {
     static constexpr int R = 1 << LR;
@@ -99,6 +155,28 @@ struct TwFactors {
         for (int i = 0; i < 3; ++i) a[i] = bufLoad2(rs, voff, i * rowBytes);
 #pragma unroll
         for (int i = 0; i < NB; ++i) b[i] = bufLoad2(rs, voff, (3 + i) * rowBytes);
+    }
+    // plain global loads (dwordx2): measured ~1.8x the throughput of raw buffer loads on gfx950 (tools/ubench/stream.hip)
+    __device__ __forceinline__ void load(const float2 *tab, int idx, int rowElems)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[i] = ldg(tab, uint32_t(idx + i * rowElems) * 8u);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b[i] = ldg(tab, uint32_t(idx + (3 + i) * rowElems) * 8u);
+    }
+    // packed form: c[i] = (re, im)
+    __device__ __forceinline__ void apply(v2 (&c)[R]) const
+    {
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+            const int qa = q >> 2, qb = q & 3;
+            v2 w;
+            if (qa == 0) w = v2{a[qb - 1].x, a[qb - 1].y};
+            else if (qb == 0) w = v2{b[qa - 1].x, b[qa - 1].y};
+            else w = cmul(v2{b[qa - 1].x, b[qa - 1].y}, v2{a[qb - 1].x, a[qb - 1].y});
+            const int i = brev(q, LR);
+            c[i] = cmul(c[i], w);
+        }
     }
     // multiply the DIF output (bit-reversed order) by W^{x q}, q = 1..R-1
     __device__ __forceinline__ void apply(float (&re)[R], float (&im)[R]) const

@@ -27,7 +27,9 @@ struct StftParams {
     const float *binsIn;      // test hook: skip the FFT, map from these bins
     uint32_t ablate;          // debug: bit0 skip DIFs, bit1 skip exchange 1, bit2 skip exchange 2, bit3 skip mirror/M, bit4 skip map, bit5 skip twiddles
     unsigned long long *phaseClock;   // debug hook: workgroup 0 stores s_memtime at phase boundaries (16 slots) or null
+    uint32_t roundSize;       // workgroups that run concurrently (number of CUs), for the frame -> workgroup order
 };
+constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
                          long slab, hipStream_t stream);

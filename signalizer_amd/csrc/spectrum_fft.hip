@@ -21,513 +21,16 @@
 // (tools/ubench/valu.hip, dif.hip): one wave issues at most one VALU instruction per ~4.8 clocks however much ILP
 // it has, and a SIMD's throughput keeps scaling with resident waves up to at least 4.  The same butterflies run 1.9x
 // faster as 16 waves x 32 points than as 8 waves x 64 points (and 1.15x faster than 8 waves with packed fp32 math).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include <type_traits>
-
-#include "fft_common.hpp"
-#include "kernels.hpp"
+#include "stft_body.hpp"
 
 namespace sgz {
 
-// debug hook (tools/phase_clocks.py): every wave of one workgroup stores s_memtime at the phase boundaries,
-// phaseClock[16 * wave + slot]
-#define SGZ_CLK(slot)                                                                                   \
-    do {                                                                                                \
-        if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16))                        \
-            prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter();                     \
-    } while (0)
-#define SGZ_WCLK(i) do { } while (0)
-
-// Pixel mapping of mapToLinearSpace (TransformDSP.inl:565-639, :871-985) on the csf magnitudes held in LDS
-// (bank-padded natural order).  Every operation rounds exactly like the reference's scalar fp32 code:
-// contraction is off in these functions (NB: hip's __fmul_rn/__fadd_rn are plain * and + and would be fused,
-// and __fsqrt_rn is the approximate native sqrt -- neither is used here).
-//
-// The reference's arg-max scan over a bin run ("first strictly greater |X|^2 wins", :957-979) is sequential and the
-// runs are very uneven (1 .. ~140 bins at the top of a log view).  Here every run is cut into pieces of <= 16 bins
-// (plan.cpp, MaxItem); a thread scans one piece with 16 independent LDS reads and merges through ds_max_u64 on the
-// key (bits(|X|^2) << 32 | ~offset): larger square wins, equal squares -> smaller scan offset wins, which is
-// exactly "first strictly greater".  Key 0 (no square > 0) falls back to `bin` like the reference's initial value.
-template <int LR>
-__device__ __forceinline__ float finishPixel(float val)
-{
-#pragma clang fp contract(off)
-    // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365)
-    const float sq = val * val + 0.f;
-    return __builtin_sqrtf(sq);                                        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
-}
-
-template <int LR, int NT>
-__device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const float *lds, int tid, long task)
-{
-#pragma clang fp contract(off)
-    constexpr int R = 1 << LR, T = NT, N = R * R * R;
-    const int total = int(prm.sides * prm.P);
-    float *out = prm.mapped + size_t(task) * total;
-    for (int idx = tid; idx < total; idx += T) {
-        const PixelRec rec = prm.recs[idx];
-        const int side = idx >= int(prm.P) ? 1 : 0;
-        float val;
-        if ((rec.kind & 1) == 0) {
-            float acc = 0.f;
-            int k = rec.a;
-            for (int i = 0; i < rec.b; ++i) {
-                const float m = lds[k + (k >> LR)];
-                const float prod = m * prm.weights[rec.c + i];
-                acc = acc + prod;
-                k = (k == N) ? 0 : k + 1;
-            }
-            val = prm.invSize * acc;
-        } else {
-            float best = 0.f;
-            int arg = rec.c;
-            for (int i = 0; i < rec.b; ++i) {
-                const int off = rec.a + i;
-                const int k = side ? (N - off) : off;
-                const float m = lds[k + (k >> LR)];
-                const float sq = m * m + 0.f;                         // Math::square(csf[offset]) with imag == 0
-                if (sq > best) { best = sq; arg = k; }
-            }
-            val = prm.invSize * lds[arg + (arg >> LR)];
-        }
-        out[idx] = finishPixel<LR>(val);
-    }
-}
-
-// balanced version; `win` = one (k, bits(|X|^2)) pair per MaxItem in LDS.  One workgroup barrier and NO atomics
-// (ds_max_u64 runs at only ~1 lane-op per 4-6 cycles: 3400 of them cost ~13k cycles per frame).
-//   (a) every <=16-bin piece finds its local winner and stores the winner's bin and square;
-//   (c) the pixel's thread replays the reference's scan ("first strictly greater", TransformDSP.inl:957-979) over its
-//       pieces' winners, in scan order -> same arg-max, same ties.  All of a run's entries are fetched with
-//       independent LDS reads first, so the replay is register arithmetic and its latency does not grow with the run.
-// Table reads (items, records, tap weights) are issued in batches of independent loads: a thread's work list is
-// tiny, so what matters is the number of dependent global-load round trips, not the byte count.
-// The first batch of table reads is split off (prefetchTables / prefetchWeights) so that the kernel can issue it
-// while the FFT's last barriers are still pending: the map phase then starts with its operands in registers.
-template <int LR, int NT>
-struct MapPixelsBalanced {
-    static constexpr int R = 1 << LR, N = R * R * R;
-    static constexpr int IB = NT >= 1024 ? 4 : 8;                        // items per thread per batch (register budget)
-    static constexpr int RB = NT >= 1024 ? 2 : 4;                        // records per thread per batch
-    static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
-    static constexpr uint32_t kNone = 0xFFFFFFFFu;
-    uint32_t iw0[IB];
-    PixelRec rec0[RB];
-    float w0[RB][kMaxTaps];
-
-    __device__ __forceinline__ void loadItems(const StftParams &prm, uint32_t base, int tid, uint32_t (&iw)[IB]) const
-    {
-#pragma unroll
-        for (int b = 0; b < IB; ++b) {
-            const uint32_t it = base + b * NT + tid;
-            iw[b] = it < prm.nItems ? prm.items[it].win : 0u;
-        }
-    }
-    __device__ __forceinline__ void loadRecs(const StftParams &prm, int base, int tid, int total, PixelRec (&rec)[RB]) const
-    {
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int idx = base + b * NT + tid;
-            rec[b] = idx < total ? prm.recs[idx] : PixelRec{2, 0, 0, 0};
-        }
-    }
-    // tap weights: unconditional, independent loads (the weight table is padded by kMaxTaps zeros)
-    __device__ __forceinline__ void loadWeights(const StftParams &prm, const PixelRec (&rec)[RB], float (&w)[RB][kMaxTaps]) const
-    {
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int wbase = rec[b].kind == 0 ? rec[b].c : 0;
-#pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) w[b][i] = prm.weights[wbase + i];
-        }
-    }
-    __device__ __forceinline__ void prefetchTables(const StftParams &prm, int tid)
-    {
-        loadItems(prm, 0u, tid, iw0);
-        loadRecs(prm, 0, tid, int(prm.sides * prm.P), rec0);
-    }
-    __device__ __forceinline__ void prefetchWeights(const StftParams &prm) { loadWeights(prm, rec0, w0); }
-
-__device__ __forceinline__ void run(const StftParams &prm, const float *lds, uint2 *win, int tid, long task)
-{
-#pragma clang fp contract(off)
-    const int total = int(prm.sides * prm.P);
-    float *out = prm.mapped + size_t(task) * total;
-    // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
-    // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
-    // to +0, which can never win.  Both sides scan k upwards: the left side's scan order is ascending k ("first
-    // strictly greater" = first maximum), the right side's is descending k, whose first maximum is the LAST maximum
-    // of the ascending scan: take on >= instead of > (and never take a zero).  Squares are >= 0, so their bit patterns
-    // order like unsigned integers and ">=" is "bits + 1 >".
-    for (uint32_t base = 0; base < prm.nItems; base += NT * IB) {
-        uint32_t iw[IB];
-        if (base == 0) {
-#pragma unroll
-            for (int b = 0; b < IB; ++b) iw[b] = iw0[b];
-        } else loadItems(prm, base, tid, iw);
-        float mv[IB][16];
-#pragma unroll
-        for (int b = 0; b < IB; ++b) {
-            const int k0 = int(iw[b] & 0xFFFFu) << 4;
-            const float *src = lds + (k0 + (k0 >> LR));
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mv[b][j] = src[j];
-        }
-#pragma unroll
-        for (int b = 0; b < IB; ++b) {
-            const uint32_t it = base + b * NT + tid;
-            const int k0 = int(iw[b] & 0xFFFFu) << 4;
-            const int lo = int((iw[b] >> 16) & 15u), hi = int((iw[b] >> 20) & 15u);
-            const uint32_t mask = (0xFFFFu >> (15 - hi)) & (0xFFFFu << lo);   // valid positions: bits lo..hi
-            const uint32_t r = it >= prm.nItemsLeft ? 1u : 0u;
-            uint32_t best = r;                                           // right side: a zero square never wins
-            uint32_t bestK = kNone;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float sq = mv[b][j] * mv[b][j];                    // Math::square(csf[offset]) with imag == 0 (x*x + 0 == x*x)
-                const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mask), j, 1));   // 0 or ~0
-                const uint32_t sqm = __float_as_uint(sq) & keep;
-                const bool take = sqm + r > best;
-                best = sqm > best ? sqm : best;
-                bestK = take ? uint32_t(k0 + j) : bestK;
-            }
-            if (it < prm.nItems) win[it] = make_uint2(bestK, best);
-        }
-    }
-    SGZ_CLK(10);
-    // (b) interpolated pixels (<= 10 taps, accumulated in tap order)
-    const bool oneBatch = total <= NT * RB;                              // then the records stay in registers across the barrier
-    PixelRec rec[RB];
-    for (int base = 0; base < total; base += NT * RB) {
-        float w[RB][kMaxTaps], mv[RB][kMaxTaps];
-        if (base == 0) {
-#pragma unroll
-            for (int b = 0; b < RB; ++b) {
-                rec[b] = rec0[b];
-#pragma unroll
-                for (int i = 0; i < kMaxTaps; ++i) w[b][i] = w0[b][i];
-            }
-        } else {
-            loadRecs(prm, base, tid, total, rec);
-            loadWeights(prm, rec, w);
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            int k = rec[b].kind == 0 ? rec[b].a : 0;
-#pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) {
-                mv[b][i] = lds[k + (k >> LR)];
-                k = (k == N) ? 0 : k + 1;
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int idx = base + b * NT + tid;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) {
-                const float prod = mv[b][i] * w[b][i];
-                acc = (i < rec[b].b) ? acc + prod : acc;               // taps accumulate in order (lanczosFilter restatement)
-            }
-            if (rec[b].kind == 0) out[idx] = finishPixel<LR>(prm.invSize * acc);
-        }
-    }
-    SGZ_CLK(11);
-    __syncthreads();
-    SGZ_CLK(12);
-    // (c) resolve the arg-max pixels from their pieces' winners
-    for (int base = 0; base < total; base += NT * RB) {
-        if (!oneBatch) loadRecs(prm, base, tid, total, rec);
-        int first[RB], pieces[RB], maxPieces = 0;
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int idx = base + b * NT + tid;
-            const bool right = idx >= int(prm.P);
-            first[b] = rec[b].kind >> 1;
-            // number of 16-aligned csf windows the run [a, a+b) spans (k = offset, or N - offset on the right side)
-            const int kLo = right ? N - (rec[b].a + rec[b].b - 1) : rec[b].a;
-            const int kHi = right ? N - rec[b].a : rec[b].a + rec[b].b - 1;
-            pieces[b] = (rec[b].kind & 1) ? (kHi >> 4) - (kLo >> 4) + 1 : 0;
-            maxPieces = pieces[b] > maxPieces ? pieces[b] : maxPieces;
-        }
-        float best[RB];
-        int arg[RB];
-#pragma unroll
-        for (int b = 0; b < RB; ++b) { best[b] = 0.f; arg[b] = rec[b].c; }   // maxLBin = maxRBin = bin (TransformDSP.inl:953)
-        for (int p0 = 0; p0 < maxPieces; p0 += PB) {
-            uint2 e[RB][PB];
-#pragma unroll
-            for (int b = 0; b < RB; ++b)
-#pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const int pc = p0 + i;
-                    e[b][i] = win[pc < pieces[b] ? first[b] + pc : 0];
-                    if (pc >= pieces[b]) e[b][i].x = kNone;
-                }
-#pragma unroll
-            for (int b = 0; b < RB; ++b)
-#pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const float sq = __uint_as_float(e[b][i].y);
-                    const bool take = (e[b][i].x != kNone) & (sq > best[b]);
-                    best[b] = take ? sq : best[b];
-                    arg[b] = take ? int(e[b][i].x) : arg[b];
-                }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int idx = base + b * NT + tid;
-            if (rec[b].kind & 1) out[idx] = finishPixel<LR>(prm.invSize * lds[arg[b] + (arg[b] >> LR)]);
-        }
-    }
-}
-};
-
-// One workgroup = one (frame, pair).  LR = log2(R), N = R^3, T = R^2 threads of R points.
-//
-// Roles.  Pass 1: thread tid owns column t = tid.  Passes 2/3: a "slot" is 2R consecutive lanes (one wave at R = 32),
-// slot s = tid / 2R, half h = (tid / R) & 1, l = tid % R:
-//     h = 0:  q = s,                    index (t2, then q2) = l
-//     h = 1:  q = R - s (R/2 if s = 0), index               = R-1-l
-// so bin k = q + R q2 + T m3 of lane L and its mirror N-k = (R-q) + R (R-1-q2) + T (R-1-m3) sit in lanes L and L ^ R
-// of the same wave, registers m3 and R-1-m3: the two-for-one split (TransformDSP.inl:858) needs one ds_bpermute per
-// value and no LDS round trip.  Slot 0 holds q = 0 and q = R/2, which mirror onto themselves (other lane pattern);
-// column 0 (q = 0, q2 = 0) mirrors inside thread 0 and is redone from a small LDS scratch by lanes 1..R/2-1.
-// MIX = 0: Separate / Complex / Phase (re = L w, im = R w); MIX = 1: Left, Right, Merge, Side, MidSide.
-template <int LR, int MIX>
+template <int LR, int MIX, bool FULLW>
 __global__ void __launch_bounds__(1 << (2 * LR))
 stftMapKernel(const StftParams prm)
 {
-    constexpr int R = 1 << LR;
-    constexpr int T = R * R;
-    constexpr int N = R * T;
-    constexpr int PADSTRIDE = T + (T >> LR);          // padded distance between k and k + T
-    constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of column 0's 2R-float scratch
-    constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max piece winners (nItems uint2)
-    constexpr int TILE = R * (R + 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x;
-    const long tasks = prm.frames * long(prm.C);
-    const int slot = tid >> (LR + 1), half = (tid >> LR) & 1, l = tid & (R - 1);
-    const int q = half ? (slot == 0 ? R / 2 : R - slot) : slot;
-    const int ix = half ? R - 1 - l : l;                                // t2 in pass 2, q2 in pass 3
-    const bool split = (prm.sides == 2);
-    const int mode = prm.mode;
-    uint2 *win = reinterpret_cast<uint2 *>(lds + SLOTS);                // one (bin, square) winner per arg-max piece
-    const bool balanced = prm.items != nullptr;
-
-    // XCD-aware task order.  Workgroup b is observed to run on XCD b % 8 (a speed assumption only, never a
-    // correctness one): XCD x gets the contiguous task range [base(x), base(x+1)), so that the workgroups sharing an
-    // L2 walk consecutive (75 %-overlapping) frames together and each sample is fetched from HBM once per XCD.
-    // One workgroup per task, no persistent frame loop (a loop makes LLVM hoist and spill address computations).
-    long task = blockIdx.x;
-    if (tasks >= 64) {
-        const long nb = gridDim.x, x = blockIdx.x % 8, i = blockIdx.x / 8;
-        const long per = nb / 8, extra = nb % 8;                       // XCD x owns per + (x < extra) workgroups
-        task = x * per + (x < extra ? x : extra) + i;
-    }
-    MapPixelsBalanced<LR, T> mapper;
-    const bool doMap = balanced && prm.mapped && !(prm.ablate & 16);
-    SGZ_CLK(0);
-    SGZ_WCLK(0);
-    if (prm.binsIn == nullptr) {
-        float re[R], im[R];
-        {
-            // ---------------------------------------------------------------- load + window + channel mix
-            // strided dword buffer loads; reads past W return 0 = the zero padding of prepareTransform (:220-223)
-            const long frame = task / prm.C;
-            const int pair = int(task - frame * prm.C);
-            const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
-            const __amdgpu_buffer_rsrc_t rsL = makeRsrc(L, prm.W * 4u);
-            const __amdgpu_buffer_rsrc_t rsR = makeRsrc(L + prm.chStride, prm.W * 4u);
-            const __amdgpu_buffer_rsrc_t rsW = makeRsrc(prm.window, prm.W * 4u);
-            float w[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                re[j] = bufLoad(rsL, tid * 4, j * (T * 4));
-                im[j] = bufLoad(rsR, tid * 4, j * (T * 4));
-                w[j] = bufLoad(rsW, tid * 4, j * (T * 4));
-            }
-            // prepareTransform channel mixes (TransformDSP.inl:59-216).  (a*l + b*r) * w * s with a, b in {0, +-1},
-            // s in {1, 0.5} rounds exactly like the reference's `(l +- r) * w * 0.5f` / `l * w`.
-            if (MIX == 0) {
-#pragma unroll
-                for (int j = 0; j < R; ++j) { re[j] = re[j] * w[j]; im[j] = im[j] * w[j]; }
-            } else {
-                float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 0.f, mixS = 1.f;      // Left
-                if (mode == SGZ_CH_RIGHT) { mixRL = 0.f; mixRR = 1.f; }
-                else if (mode == SGZ_CH_MERGE) { mixRR = 1.f; mixS = 0.5f; }
-                else if (mode == SGZ_CH_SIDE) { mixRR = -1.f; mixS = 0.5f; }
-                else if (mode == SGZ_CH_MIDSIDE) { mixRR = 1.f; mixIL = 1.f; mixIR = -1.f; mixS = 0.5f; }
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const float lv = re[j], rv = im[j];
-                    re[j] = (mixRL * lv + mixRR * rv) * w[j] * mixS;
-                    im[j] = (mixIL * lv + mixIR * rv) * w[j] * mixS;
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);          // keep the twiddle loads below the 3R sample loads (128-VGPR budget)
-        SGZ_CLK(13);
-        // ---------------------------------------------------------------------- pass 1
-        if (!(prm.ablate & 1)) dif<float, R, R, 0>(re, im);
-        SGZ_CLK(14);
-        if (!(prm.ablate & 32)) {
-            const __amdgpu_buffer_rsrc_t rs = makeRsrc(prm.tw1, uint32_t(3 + R / 4 - 1) * T * 8u);
-            TwFactors<LR> tw;
-            tw.load(rs, tid * 8, T * 8);
-            tw.apply(re, im);                                          // times W_N^{t q}
-        }
-        SGZ_CLK(1);
-        // -------------------------------------------------------------- exchange 1 (workgroup-wide; re then im)
-        if (!(prm.ablate & 2)) {
-            const int rd = q * T + ix;
-#pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tid] = re[brev(qq, LR)];
-            __syncthreads();
-#pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) re[j2] = lds[rd + R * j2];
-            __syncthreads();
-#pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tid] = im[brev(qq, LR)];
-            __syncthreads();
-#pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) im[j2] = lds[rd + R * j2];
-        }
-        SGZ_CLK(2);
-        // ---------------------------------------------------------------------- pass 2 (t2 = ix)
-        if (!(prm.ablate & 1)) dif<float, R, R, 0>(re, im);
-        if (!(prm.ablate & 32)) {
-            const __amdgpu_buffer_rsrc_t rs = makeRsrc(prm.tw2, uint32_t(3 + R / 4 - 1) * R * 8u);
-            TwFactors<LR> tw;
-            tw.load(rs, ix * 8, R * 8);
-            tw.apply(re, im);                                          // times W_T^{t2 q2}
-        }
-        SGZ_CLK(3);
-        // ----------------------------------- exchange 2: R x R transposes inside each R-lane group (wave-local tiles)
-        __syncthreads();                                               // every wave has finished reading exchange 1
-        if (!(prm.ablate & 4)) {
-            const int tile = q * TILE;
-#pragma unroll
-            for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = re[brev(q2, LR)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int j = 0; j < R; ++j) re[j] = lds[tile + ix * (R + 1) + j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = im[brev(q2, LR)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-            for (int j = 0; j < R; ++j) im[j] = lds[tile + ix * (R + 1) + j];
-        }
-        SGZ_CLK(4);
-        // ---------------------------------------------------------------------- pass 3 (q2 = ix)
-        if (!(prm.ablate & 1)) dif<float, R, R, 0>(re, im);
-        SGZ_CLK(5);
-        SGZ_WCLK(1);
-        // Z[c + T m3] at register brev(m3),  c = q + R q2
-        const int c = q + R * ix;
-        const int base = c + (c >> LR);                                // padded LDS address of k = c
-        if (split && !(prm.ablate & 8)) {
-            if (tid == 0) {                                            // column 0 mirrors onto itself: redone below
-#pragma unroll
-                for (int m3 = 0; m3 < R; ++m3) {
-                    lds[SCRATCH + 2 * m3] = re[brev(m3, LR)];
-                    lds[SCRATCH + 2 * m3 + 1] = im[brev(m3, LR)];
-                }
-            }
-            // lane holding Z[N - k]: L ^ R, except in slot 0 (q = 0: q2' = R - q2 ; q = R/2: q2' = R-1-q2, same half)
-            const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-            int plane = lane ^ R;
-            if (slot == 0) plane = (lane & ~(R - 1)) | (half ? R - 1 - l : ((R - l) & (R - 1)));
-            plane <<= 2;
-            auto partner = [&](float v) {
-                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plane, __builtin_bit_cast(int, v)));
-            };
-#pragma unroll
-            for (int m3 = 0; m3 < R / 2; ++m3) {
-                const int ia = brev(m3, LR), ib = brev(R - 1 - m3, LR);          // k < N/2 at ia, k > N/2 at ib
-                const float mar = partner(re[ib]), mai = partner(im[ib]);        // Z[N-k] for the bin at ia
-                const float mbr = partner(re[ia]), mbi = partner(im[ia]);        // Z[N-k] for the bin at ib
-                // k < N/2: X1 = (Z[k] + conj Z[N-k])/2 ; k > N/2: X2 = (Z[N-k] - conj Z[k])/(2i)  (magnitudes only)
-                const float ua = re[ia] + mar, va = im[ia] - mai, ub = re[ib] - mbr, vb = im[ib] + mbi;
-                re[ia] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
-                re[ib] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
-            }
-        } else {
-            if (tid == 0) { lds[SCRATCH] = re[0]; lds[SCRATCH + 1] = im[0];
-                            lds[SCRATCH + R] = re[brev(R / 2, LR)]; lds[SCRATCH + R + 1] = im[brev(R / 2, LR)]; }
-#pragma unroll
-            for (int m3 = 0; m3 < R; ++m3) {                           // csf[k] = |Z[k]| (TransformDSP.inl:553-560, :993-1002)
-                const int i = brev(m3, LR);
-                re[i] = __builtin_amdgcn_sqrtf(re[i] * re[i] + im[i] * im[i]);
-            }
-        }
-        SGZ_CLK(6);
-        if (doMap) mapper.prefetchTables(prm, tid);                    // im[] is dead: its registers take the map tables
-        __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
-#pragma unroll
-        for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = re[brev(m3, LR)];
-        if (doMap) mapper.prefetchWeights(prm);
-        __syncthreads();
-        if (split && tid >= 1 && tid < R / 2) {
-            // column 0: k = T m3 pairs with T (R - m3); both were held by thread 0 -> lanes 1..R/2-1 redo them
-            const int m3 = tid;
-            const float ar = lds[SCRATCH + 2 * m3], ai = lds[SCRATCH + 2 * m3 + 1];
-            const float br = lds[SCRATCH + 2 * (R - m3)], bi = lds[SCRATCH + 2 * (R - m3) + 1];
-            const float ua = ar + br, va = ai - bi, ub = br - ar, vb = bi + ai;
-            lds[m3 * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
-            lds[(R - m3) * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
-        }
-        if (tid == 0) {
-            const float dcRe = lds[SCRATCH], dcIm = lds[SCRATCH + 1];
-            const float nyRe = lds[SCRATCH + R], nyIm = lds[SCRATCH + R + 1];      // m3 = R/2
-            if (split) {
-                lds[N + (N >> LR)] = dcIm * 0.5f;                    // csf[N]   = Im(csf[0]) * 0.5   (TransformDSP.inl:861)
-                lds[0] = dcRe * 0.5f;                                // csf[0]   = Re(csf[0]) * 0.5   (:862)
-                lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // :863
-            } else {
-                lds[N + (N >> LR)] = 0.f;
-                lds[0] = 0.5f * __builtin_amdgcn_sqrtf(dcRe * dcRe + dcIm * dcIm);
-                if (mode != SGZ_CH_COMPLEX)
-                    lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
-            }
-        }
-        if (split && tid == 2 * R) {
-            const int kq = N / 2 - 1;
-            lds[kq + (kq >> LR)] *= 0.5f;                            // csf[N/2-1] *= 0.5 (quirk Q3, :864)
-        }
-        __syncthreads();
-    } else {
-        // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM
-        const float *src = prm.binsIn + size_t(task) * (N + 1);
-        if (doMap) { mapper.prefetchTables(prm, tid); mapper.prefetchWeights(prm); }
-        for (int k = tid; k <= N; k += T) lds[k + (k >> LR)] = src[k];
-        __syncthreads();
-    }
-    SGZ_CLK(7);
-
-    if (prm.binsOut) {
-        float *dst = prm.binsOut + size_t(task) * (N + 1);
-        for (int k = tid; k <= N; k += T) dst[k] = lds[k + (k >> LR)];
-    }
-    SGZ_CLK(8);
-    SGZ_WCLK(2);
-    // -------------------------------------------------------------------------- pixel mapping
-    if (prm.mapped && !(prm.ablate & 16)) {
-        if (balanced) mapper.run(prm, lds, win, tid, task);
-        else mapPixelsSerial<LR, T>(prm, lds, tid, task);
-    }
-    SGZ_CLK(9);
-    SGZ_WCLK(3);
+    stftMapBody<LR, MIX, FULLW>(prm, lds, blockIdx.x, gridDim.x);
 }
 
 template <int LR>
@@ -541,15 +44,19 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
     if (p2.items && baseBytes + slotBytes <= 160 * 1024) ldsBytes += slotBytes;   // arg-max slots fit beside the |X| array
     else p2.items = nullptr;                                                         // very tall views: serial scan
     const bool simple = prm.mode == SGZ_CH_SEPARATE || prm.mode == SGZ_CH_COMPLEX || prm.mode == SGZ_CH_PHASE;
-    static size_t attrBytes[2] = {0, 0};
-    if (attrBytes[simple] < ldsBytes) {
-        const void *fn = simple ? reinterpret_cast<const void *>(&stftMapKernel<LR, 0>) : reinterpret_cast<const void *>(&stftMapKernel<LR, 1>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+    const bool fullw = prm.W == uint32_t(N);
+    using Kern = void (*)(const StftParams);
+    static const Kern kerns[4] = {&stftMapKernel<LR, 1, false>, &stftMapKernel<LR, 1, true>, &stftMapKernel<LR, 0, false>,
+                                  &stftMapKernel<LR, 0, true>};
+    const int which = (simple ? 2 : 0) + (fullw ? 1 : 0);
+    static size_t attrBytes[4] = {0, 0, 0, 0};
+    if (attrBytes[which] < ldsBytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(ldsBytes));
         if (e != hipSuccess) return e;
-        attrBytes[simple] = ldsBytes;
+        attrBytes[which] = ldsBytes;
     }
-    if (simple) hipLaunchKernelGGL((stftMapKernel<LR, 0>), dim3(grid), dim3(T), ldsBytes, stream, p2);
-    else hipLaunchKernelGGL((stftMapKernel<LR, 1>), dim3(grid), dim3(T), ldsBytes, stream, p2);
+    hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
     return hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ def step_time(iters=50):
     for _ in range(iters): r.render()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for bits, name in {0: "fused K_B", 0x1000: "three-kernel K_B", 0x2000: "fused, no fold", 0x4000: "fused, no emit", 0x8000: "fused, no local scan", 0xE000: "fused, empty"}.items():
+for bits, name in {0: "single-launch K_B", 0x1000: "three-kernel K_B"}.items():
     L.sgz_debug_set_ablate(bits)
     print(f"{name:32s} step {min(step_time() for _ in range(3)):8.1f} us")
 L.sgz_debug_set_ablate(0)

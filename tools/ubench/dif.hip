@@ -78,6 +78,34 @@ __global__ void __launch_bounds__(MODE >= 2 ? 1024 : 512) k(float *out, long lon
         t1 = __builtin_readcyclecounter();
 #pragma unroll
         for (int i = 0; i < R; ++i) acc += c[i].x + c[i].y;
+    } else if (MODE == 4) {          // V = 1, packed complex with explicit op_sel (fft_common.hpp difPacked), 1024 threads
+        v2 c[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) c[i] = v2{in[threadIdx.x + i], in[threadIdx.x + i + 64]};
+        t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int it = 0; it < 16; ++it) {
+            difPacked<R, R, 0>(c);
+#pragma unroll
+            for (int i = 0; i < R; ++i) asm volatile("" : "+v"(c[i]));
+        }
+        t1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc += c[i].x + c[i].y;
+    } else if (MODE == 5) {          // correctness: scalar vs packed on the same input, max |diff| -> out
+        float re[R], im[R];
+        v2 c[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { re[i] = in[threadIdx.x + i]; im[i] = in[threadIdx.x + i + 64]; c[i] = v2{re[i], im[i]}; }
+        t0 = t1 = 0;
+        dif<float, R, R, 0>(re, im);
+        difPacked<R, R, 0>(c);
+        TwFactors<5> tw;
+        tw.load(reinterpret_cast<const float2 *>(in + 1024), threadIdx.x & 31, 32);
+        tw.apply(re, im);
+        tw.apply(c);
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc = fmaxf(acc, fmaxf(fabsf(re[i] - c[i].x), fabsf(im[i] - c[i].y)));
     } else {
         v2 re[R], im[R];
 #pragma unroll
@@ -112,5 +140,15 @@ int main()
     run("packed v2", k<1>);
     run("scalar V=1, 1024 threads", k<2>, 1024);
     run("packed complex V=1, 1024 threads", k<3>, 1024);
+    run("packed complex, explicit op_sel, 1024 thr", k<4>, 1024);
+    {
+        std::vector<float> hin(4096);
+        for (int i = 0; i < 4096; ++i) hin[i] = float((i * 2654435761u) % 2001) / 1000.f - 1.f;
+        hipMemcpy(in, hin.data(), 4 * 4096, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k<5>, dim3(1), dim3(1024), 0, 0, out, clk, in); hipDeviceSynchronize();
+        std::vector<float> ho(1024); hipMemcpy(ho.data(), out, 4 * 1024, hipMemcpyDeviceToHost);
+        float m = 0; for (float v : ho) m = v > m ? v : m;
+        printf("scalar vs packed DIF + twiddles: max |diff| = %g\n", m);
+    }
     return 0;
 }

@@ -67,6 +67,32 @@ __global__ void __launch_bounds__(THREADS) k(const float *src, float *out, long 
         }
 #pragma unroll
         for (int j = 0; j < 96; ++j) acc += v[j];
+    } else if (MODE == 9) {     // buffer loads, ONE contiguous 384 KB array, 96 in flight
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 384 * 1024, 0x00020000);
+        float v[96];
+#pragma unroll
+        for (int j = 0; j < 96; ++j) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, tid * 4, j * 4096, 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 96; ++j) acc += v[j];
+    } else if (MODE == 10) {    // global loads, three arrays interleaved per j, 96 in flight
+        float v[96];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            v[3 * j] = p[tid + 1024 * j];
+            v[3 * j + 1] = p[32768 + tid + 1024 * j];
+            v[3 * j + 2] = p[65536 + tid + 1024 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 96; ++j) acc += v[j];
+    } else if (MODE == 11) {    // global loads, one array, 96 in flight, consumed after all issued
+        float v[96];
+#pragma unroll
+        for (int j = 0; j < 96; ++j) v[j] = p[tid + 1024 * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 96; ++j) acc += v[j];
     } else if (MODE == 8) {     // one array per phase, global loads, 32 in flight
         float v[96];
 #pragma unroll
@@ -130,6 +156,9 @@ int main()
             run("K_A arrays, 64 in flight", k<6, 1024>, 1024, nwg, stride);
             run("K_A arrays, 16 in flight", k<7, 1024>, 1024, nwg, stride);
             run("K_A arrays, global loads, 32 in flight", k<8, 1024>, 1024, nwg, stride);
+            run("buffer loads, one array, 96 in flight", k<9, 1024>, 1024, nwg, stride);
+            run("global loads, 3 arrays interleaved, 96", k<10, 1024>, 1024, nwg, stride);
+            run("global loads, one array, 96 in flight", k<11, 1024>, 1024, nwg, stride);
             ldsBytes = 150 * 1024;
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             run("K_A pattern 1024 thr, 150 KB LDS", k<4, 1024>, 1024, nwg, stride);

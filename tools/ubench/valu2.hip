@@ -46,12 +46,14 @@ int main()
     float *out; long long *clk;
     hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&clk, 8 * 1024);
     std::vector<long long> h(1024);
+    int threads = 512;
     auto run = [&](const char *name, auto kern, int n) {
-        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, out, clk, 1.0001f, 0.5f); hipDeviceSynchronize(); }
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, out, clk, 1.0001f, 0.5f); hipDeviceSynchronize(); }
         hipMemcpy(h.data(), clk, 8 * 256, hipMemcpyDeviceToHost);
         double avg = 0; for (int i = 0; i < 256; ++i) avg += h[i]; avg /= 256;
-        printf("%-44s %.2f ticks/instr/wave\n", name, avg / 4096 / n);
+        printf("%-44s %.2f ticks/instr/wave   %.2f ticks/instr/SIMD (%d waves/SIMD)\n", name, avg / 4096 / n, avg / 4096 / n / (threads / 256), threads / 256);
     };
+    for (threads = 512; threads <= 1024; threads += 512) {
     run("v_fma_f32", k<0>, 1); run("v_cndmask vcc", k<1>, 1); run("v_cndmask s[20:21]", k<2>, 1);
     run("v_cmp_gt_f32 vcc", k<3>, 1); run("v_cmp_gt_f32 s[20:21]", k<4>, 1); run("v_max_f32", k<5>, 1);
     run("v_max3_f32", k<6>, 1); run("v_and_b32", k<7>, 1); run("v_mul_f32", k<8>, 1); run("v_mov_b32", k<9>, 1);
@@ -59,5 +61,6 @@ int main()
     run("v_add_f32 v,s", k<13>, 1); run("v_fma_f32 v,s,v", k<14>, 1); run("v_min_u32", k<15>, 1);
     run("v_mul_f32 inline const", k<16>, 1); run("v_mul_f32 literal", k<17>, 1); run("v_fmac_f32", k<18>, 1); run("v_add_u32", k<19>, 1);
     run("cndmask s + fma interleaved (per instr)", k<20>, 2);
+    }
     return 0;
 }
