@@ -141,6 +141,8 @@ sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channe
                             float *d_mapped /*[frames][pairs][2][P]*/, void *stream);
 sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t frames,
                                    float *d_mapped, void *stream);
+/* d_rgba and d_lines may both be NULL: a state-only pass that just advances d_state over `frames` frames (what the
+ * multi-GPU carry exchange below needs from every rank before the real pass). */
 sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,
                                   uint8_t *d_rgba, float *d_lines, float *d_state, void *stream);
 

@@ -287,12 +287,12 @@ class Plan:
                                             torch.cuda.current_stream().cuda_stream))
         return out
 
-    def stage_decay_colour(self, mapped, want_lines=False, state=None):
+    def stage_decay_colour(self, mapped, want_lines=False, state=None, want_rgba=True):
         import torch
         F = mapped.shape[0]
-        rgba = torch.empty((F, self.P, 4), dtype=torch.uint8, device=mapped.device)
+        rgba = torch.empty((F, self.P, 4), dtype=torch.uint8, device=mapped.device) if want_rgba else None
         lines = torch.empty((F, self.C, NUM_GRAPHS, self.P, 2), dtype=torch.float32, device=mapped.device) if want_lines else None
-        check(lib().sgz_stage_decay_colour(self.h, mapped.data_ptr(), F, rgba.data_ptr(),
+        check(lib().sgz_stage_decay_colour(self.h, mapped.data_ptr(), F, rgba.data_ptr() if want_rgba else None,
                                            lines.data_ptr() if want_lines else None,
                                            state.data_ptr() if state is not None else None,
                                            torch.cuda.current_stream().cuda_stream))

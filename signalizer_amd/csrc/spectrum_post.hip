@@ -174,15 +174,16 @@ __global__ void __launch_bounds__(kFusedThreads) decayFusedKernel(const DecayPar
         }
     }
     __syncthreads();
-    // phase 3: item = (frame, px)
-    for (long it = tid; it < prm.frames * kFusedPx && !(prm.ablate & 2); it += kFusedThreads) {
+    // phase 3: item = (frame, px).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) emits the last frame.
+    const long itFirst = (prm.rgba || prm.lines) ? 0 : (prm.frames - 1) * kFusedPx;
+    for (long it = itFirst + tid; it < prm.frames * kFusedPx && !(prm.ablate & 2); it += kFusedThreads) {
         const uint32_t px = uint32_t(it % kFusedPx);
         const long f = it / kFusedPx;
         const uint32_t pixel = pixel0 + px;
         if (pixel >= prm.P) continue;
         const uint32_t chunk = uint32_t(f / kMaxChunk);
         const bool allCombos = prm.lines || (chunk + 1 == prm.numChunks && prm.state);
-        const bool first = it == long(tid);
+        const bool first = it == long(tid);                            // (then the operands were prefetched above)
         emitPixel(prm, chunk, int(f - long(chunk) * kMaxChunk), pixel, allCombos,
                   st + (chunk > 0 ? size_t(chunk - 1) * combos * kFusedPx : 0) + px, kFusedPx, colourTab,
                   first ? slope0 : prm.slope[pixel], first ? mag0 : nullptr);

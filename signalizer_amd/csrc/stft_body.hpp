@@ -137,10 +137,8 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
     float *out = prm.mapped + size_t(task) * total;
     // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
     // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
-    // to +0, which can never win.  Both sides scan k upwards: the left side's scan order is ascending k ("first
-    // strictly greater" = first maximum), the right side's is descending k, whose first maximum is the LAST maximum
-    // of the ascending scan: take on >= instead of > (and never take a zero).  Squares are >= 0, so their bit patterns
-    // order like unsigned integers and ">=" is "bits + 1 >".
+    // to +0, which can never win.  The left side's scan order is ascending k ("first strictly greater" = FIRST
+    // maximum), the right side's is descending k, whose first maximum is the LAST maximum in ascending order.
     for (uint32_t base = 0; base < prm.nItems; base += NT * IB) {
         uint32_t iw[IB];
         if (base == 0) {
@@ -161,18 +159,32 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
             const int k0 = int(iw[b] & 0xFFFFu) << 4;
             const int lo = int((iw[b] >> 16) & 15u), hi = int((iw[b] >> 20) & 15u);
             const uint32_t mask = (0xFFFFu >> (15 - hi)) & (0xFFFFu << lo);   // valid positions: bits lo..hi
-            const uint32_t r = it >= prm.nItemsLeft ? 1u : 0u;
-            uint32_t best = r;                                           // right side: a zero square never wins
-            uint32_t bestK = kNone;
+            const bool right = it >= prm.nItemsLeft;
+            // masked squares, their maximum (a tree of independent v_max, not a serial compare-and-select chain), then
+            // the first (left side) or last (right side) position that holds it.  Squares are >= 0, so their bit
+            // patterns order like unsigned integers; a zero square never wins (TransformDSP.inl:965 is a strict >).
+            uint32_t sqm[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const float sq = mv[b][j] * mv[b][j];                    // Math::square(csf[offset]) with imag == 0 (x*x + 0 == x*x)
                 const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mask), j, 1));   // 0 or ~0
-                const uint32_t sqm = __float_as_uint(sq) & keep;
-                const bool take = sqm + r > best;
-                best = sqm > best ? sqm : best;
-                bestK = take ? uint32_t(k0 + j) : bestK;
+                sqm[j] = __float_as_uint(sq) & keep;
             }
+            uint32_t m8[8], m4[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m8[j] = sqm[2 * j] > sqm[2 * j + 1] ? sqm[2 * j] : sqm[2 * j + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m4[j] = m8[2 * j] > m8[2 * j + 1] ? m8[2 * j] : m8[2 * j + 1];
+            const uint32_t ma = m4[0] > m4[1] ? m4[0] : m4[1], mb = m4[2] > m4[3] ? m4[2] : m4[3];
+            const uint32_t best = ma > mb ? ma : mb;
+            uint32_t first = 0u, last = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool eq = sqm[j] == best;
+                last = eq ? uint32_t(j) : last;                          // ascending: the highest position survives
+                first = (sqm[15 - j] == best) ? uint32_t(15 - j) : first;   // descending: the lowest position survives
+            }
+            const uint32_t bestK = best == 0u ? kNone : uint32_t(k0) + (right ? last : first);
             if (it < prm.nItems) win[it] = make_uint2(bestK, best);
         }
     }

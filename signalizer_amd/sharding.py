@@ -77,7 +77,8 @@ class GpuBackend:
 
     def stage_decay_colour(self, mapped, frames, rgba, state):
         from . import api
-        api.check(api.lib().sgz_stage_decay_colour(self.plan.h, mapped.data_ptr(), frames, rgba.data_ptr(), None,
+        api.check(api.lib().sgz_stage_decay_colour(self.plan.h, mapped.data_ptr(), frames,
+                                                   rgba.data_ptr() if rgba is not None else None, None,
                                                    state.data_ptr(), self._stream()))
 
     def fold_carry(self, aggs, frames_per_rank, rank, carry):
@@ -130,10 +131,10 @@ class TimeChunkRenderer:
         if self.rank + 1 < self.world:
             self.buf[:, self.S:] = self.halo_all[self.rank + 1]
         x = self._view()
-        # K_A once, K_B twice (zero carry -> aggregate; folded carry -> final)
+        # K_A once; K_B as a state-only pass (zero carry -> this chunk's end state), then the full pass with the folded carry
         self.backend.stage_mapped(x, self.mapped)
         self.state.zero_()
-        self.backend.stage_decay_colour(self.mapped, self.local_frames, self.rgba, self.state)
+        self.backend.stage_decay_colour(self.mapped, self.local_frames, None if self.rank > 0 else self.rgba, self.state)
         # A2: decay carry
         dist.all_gather_into_tensor(self.agg_all.view(-1), self.state.view(-1))
         if self.rank > 0:

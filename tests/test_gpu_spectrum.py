@@ -198,6 +198,10 @@ def test_decay_single_launch_equals_three_kernel_path(gpu, pairs, frames):
             state = torch.full((pairs, 2, plan.P, 2), 0.01, dtype=torch.float32, device=gpu)
             rgba, lines = plan.stage_decay_colour(mapped, state=state, want_lines=True)
             outs.append((rgba.cpu().numpy(), lines.cpu().numpy(), state.cpu().numpy()))
+            # a state-only pass (no colour, no lines) must leave the same end state
+            state2 = torch.full((pairs, 2, plan.P, 2), 0.01, dtype=torch.float32, device=gpu)
+            plan.stage_decay_colour(mapped, state=state2, want_rgba=False)
+            assert np.array_equal(state2.cpu().numpy(), outs[-1][2])
     finally:
         api.lib().sgz_debug_set_ablate(0)
     for a, b in zip(outs[0], outs[1]):

@@ -79,7 +79,8 @@ class OracleBackend:
                 res = po.filters(self.p, csp, states)
                 st[c, :, :, 0], st[c, :, :, 1] = states.real, states.imag
                 fr[c] = res[0]
-            rgba[f].copy_(torch.from_numpy(po.blend_column(self.p, fr)))
+            if rgba is not None:                                      # None: state-only pass (the decay carry exchange)
+                rgba[f].copy_(torch.from_numpy(po.blend_column(self.p, fr)))
 
     def render(self, x, rgba, state):
         import torch
