@@ -55,9 +55,10 @@ __device__ __forceinline__ void dif(V (&re)[R], V (&im)[R])
 }
 
 // ---- packed complex arithmetic: one value = (re, im) in an aligned VGPR pair, VOP3P ops with op_sel / neg modifiers.
-// A SIMD's VALU issue rate is per instruction (tools/ubench/valu.hip: v_pk_fma_f32 issues like v_fma_f32), so a butterfly
-// on (re, im) pairs costs half the instructions of the scalar form.  hipcc does not fold the (im, -re) swizzles of a
-// complex multiply into op_sel on its own (tools/ubench/dif.hip: 218 extra moves per 32-point DIF), hence the asm.
+// Measured (tools/ubench/valu.hip, whole-workgroup timing): a packed op occupies the SIMD for ~4.3 clocks against ~2.4
+// for a plain one (~4.1 when a source is an SGPR, as the butterflies' constant twiddles are), so a butterfly on (re, im)
+// pairs costs about 10-30 % less VALU time than the scalar form -- not half.  hipcc does not fold the (im, -re) swizzles
+// of a complex multiply into op_sel on its own (tools/ubench/dif.hip: 218 extra moves per 32-point DIF), hence the asm.
 // (-i) * (x - y) = (x.im - y.im, y.re - x.re)
 __device__ __forceinline__ v2 rotSub(v2 x, v2 y)
 {

@@ -17,10 +17,12 @@
 // HBM/L2 traffic per frame-pair: 2*W*4 B audio + W*4 B window + small L2-resident tables in, sides*P*4 B out.
 // No MFMA: the path is fp32 butterflies + LDS transposes.
 //
-// Why R points per thread and T threads (4 waves per SIMD at R = 32, <= 128 VGPRs), measured on MI355X
-// (tools/ubench/valu.hip, dif.hip): one wave issues at most one VALU instruction per ~4.8 clocks however much ILP
-// it has, and a SIMD's throughput keeps scaling with resident waves up to at least 4.  The same butterflies run 1.9x
-// faster as 16 waves x 32 points than as 8 waves x 64 points (and 1.15x faster than 8 waves with packed fp32 math).
+// Why R points per thread on T threads (16 waves, <= 128 VGPRs) rather than 2R points on T/2 threads: measured on MI355X
+// (tools/ubench/valu.hip, valu2.hip, dif.hip -- whole-workgroup timing), a SIMD retires one plain fp32 VALU instruction
+// per ~2.4 clocks, which two co-resident waves already saturate (one wave alone: one per ~4.8).  Four waves per SIMD do
+// not add VALU throughput; what they add is cover for the load, LDS-exchange and barrier latencies of a frame whose
+// phases are serialised by data dependencies.  Packed v_pk_*_f32 costs ~4.3 clocks per instruction (two plain ops: 4.8),
+// v_sqrt 8.2, and v_cmp / v_cndmask / v_max / v_min / v_bfe or any instruction with an SGPR source ~4.1.
 #include "stft_body.hpp"
 
 namespace sgz {

@@ -476,38 +476,41 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         }
         SGZ_CLK(6);
         if (doMap) mapper.prefetchTables(prm, tid);                    // im[] is dead: its registers take the map tables
+        if (split && q == R - 1 && ix == R - 1) c[brev(R / 2 - 1, LR)].x *= 0.5f;   // csf[N/2-1] *= 0.5 (quirk Q3, :864)
         __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
 #pragma unroll
         for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = c[brev(m3, LR)].x;
-        if (doMap) mapper.prefetchWeights(prm);
-        __syncthreads();
-        if (split && tid >= 1 && tid < R / 2) {
-            // column 0: k = T m3 pairs with T (R - m3); both were held by thread 0 -> lanes 1..R/2-1 redo them
-            const int m3 = tid;
-            const float ar = lds[SCRATCH + 2 * m3], ai = lds[SCRATCH + 2 * m3 + 1];
-            const float br = lds[SCRATCH + 2 * (R - m3)], bi = lds[SCRATCH + 2 * (R - m3) + 1];
-            const float ua = ar + br, va = ai - bi, ub = br - ar, vb = bi + ai;
-            lds[m3 * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
-            lds[(R - m3) * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
-        }
-        if (tid == 0) {
-            const float dcRe = lds[SCRATCH], dcIm = lds[SCRATCH + 1];
-            const float nyRe = lds[SCRATCH + R], nyIm = lds[SCRATCH + R + 1];      // m3 = R/2
-            if (split) {
-                lds[N + (N >> LR)] = dcIm * 0.5f;                    // csf[N]   = Im(csf[0]) * 0.5   (TransformDSP.inl:861)
-                lds[0] = dcRe * 0.5f;                                // csf[0]   = Re(csf[0]) * 0.5   (:862)
-                lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // :863
-            } else {
-                lds[N + (N >> LR)] = 0.f;
-                lds[0] = 0.5f * __builtin_amdgcn_sqrtf(dcRe * dcRe + dcIm * dcIm);
-                if (mode != SGZ_CH_COMPLEX)
-                    lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
+        // Column 0 (k = T m3, all held by thread 0) mirrors onto itself and DC / Nyquist are special: redone from thread 0's
+        // scratch copy by lanes of the SAME wave, after that wave's own stores above (one wave's LDS operations execute in
+        // order), so no extra workgroup barrier is needed.
+        if (tid < R / 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (split && tid >= 1) {
+                const int m3 = tid;                                    // k = T m3 pairs with T (R - m3)
+                const float ar = lds[SCRATCH + 2 * m3], ai = lds[SCRATCH + 2 * m3 + 1];
+                const float br = lds[SCRATCH + 2 * (R - m3)], bi = lds[SCRATCH + 2 * (R - m3) + 1];
+                const float ua = ar + br, va = ai - bi, ub = br - ar, vb = bi + ai;
+                lds[m3 * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
+                lds[(R - m3) * PADSTRIDE] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
+            }
+            if (tid == 0) {
+                const float dcRe = lds[SCRATCH], dcIm = lds[SCRATCH + 1];
+                const float nyRe = lds[SCRATCH + R], nyIm = lds[SCRATCH + R + 1];      // m3 = R/2
+                if (split) {
+                    lds[N + (N >> LR)] = dcIm * 0.5f;                // csf[N]   = Im(csf[0]) * 0.5   (TransformDSP.inl:861)
+                    lds[0] = dcRe * 0.5f;                            // csf[0]   = Re(csf[0]) * 0.5   (:862)
+                    lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // :863
+                } else {
+                    lds[N + (N >> LR)] = 0.f;
+                    lds[0] = 0.5f * __builtin_amdgcn_sqrtf(dcRe * dcRe + dcIm * dcIm);
+                    if (mode != SGZ_CH_COMPLEX)
+                        lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
+                }
             }
         }
-        if (split && tid == 2 * R) {
-            const int kq = N / 2 - 1;
-            lds[kq + (kq >> LR)] *= 0.5f;                            // csf[N/2-1] *= 0.5 (quirk Q3, :864)
-        }
+        if (doMap) mapper.prefetchWeights(prm);
         __syncthreads();
     } else {
         // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM

@@ -31,7 +31,16 @@ __global__ void k(float *out, long long *clk, float a, float b)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += x[i].x + x[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
-    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+    // workgroup time = last wave's end - first wave's start: the oldest wave of a SIMD gets issue priority, so a
+    // wave-0-only clock overstates what four co-resident waves achieve together
+    __shared__ long long s0[16], s1[16];
+    if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = t0; s1[threadIdx.x >> 6] = t1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long a = s0[0], b = s1[0];
+        for (int w = 1; w < int(blockDim.x) / 64; ++w) { a = s0[w] < a ? s0[w] : a; b = s1[w] > b ? s1[w] : b; }
+        clk[blockIdx.x] = b - a;
+    }
 }
 int main()
 {
