@@ -168,7 +168,7 @@ def main() -> None:
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(),
-                         "kernel": "stftMapKernel<5, 0>", "kernel_ms": kern_ms,
+                         "kernel": "stftMapKernel<5, 0, true>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": frames_per_rank * BYTES_PER_FRAME},
         }
         if not args.no_cpu_baseline and world == 1:

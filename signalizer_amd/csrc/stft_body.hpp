@@ -89,7 +89,7 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
 template <int LR, int NT>
 struct MapPixelsBalanced {
     static constexpr int R = 1 << LR, N = R * R * R;
-    static constexpr int IB = NT >= 1024 ? 4 : 8;                        // items per thread per batch (register budget)
+    static constexpr int IB = 4;                                         // items per thread per batch (register budget)
     static constexpr int RB = NT >= 1024 ? 2 : 4;                        // records per thread per batch
     static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
     static constexpr uint32_t kNone = 0xFFFFFFFFu;
