@@ -436,7 +436,9 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
         SGZ_CLK(5);
         SGZ_WCLK(1);
-        // Z[kc + T m3] at register brev(m3),  kc = q + R q2; the magnitudes end up in the .x halves
+        // Z[kc + T m3] at register brev(m3),  kc = q + R q2.  The magnitudes go to their own scalar registers so that the
+        // (re, im) pairs die as the mirror consumes them (a half-dead 64-bit tuple still holds two registers).
+        float mag[R];
         const int kc = q + R * ix;
         const int base = kc + (kc >> LR);                              // padded LDS address of k = kc
         if (split && !(prm.ablate & 8)) {
@@ -462,8 +464,8 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                 const v2 mb = v2{partner(c[ia].x), partner(c[ia].y)};            // Z[N-k] for the bin at ib
                 // k < N/2: X1 = (Z[k] + conj Z[N-k])/2 ; k > N/2: X2 = (Z[N-k] - conj Z[k])/(2i)  (magnitudes only)
                 const float ua = c[ia].x + ma.x, va = c[ia].y - ma.y, ub = c[ib].x - mb.x, vb = c[ib].y + mb.y;
-                c[ia].x = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
-                c[ib].x = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
+                mag[ia] = 0.5f * __builtin_amdgcn_sqrtf(ua * ua + va * va);
+                mag[ib] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
             }
         } else {
             if (tid == 0) { lds[SCRATCH] = c[0].x; lds[SCRATCH + 1] = c[0].y;
@@ -471,15 +473,15 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
 #pragma unroll
             for (int m3 = 0; m3 < R; ++m3) {                           // csf[k] = |Z[k]| (TransformDSP.inl:553-560, :993-1002)
                 const int i = brev(m3, LR);
-                c[i].x = __builtin_amdgcn_sqrtf(c[i].x * c[i].x + c[i].y * c[i].y);
+                mag[i] = __builtin_amdgcn_sqrtf(c[i].x * c[i].x + c[i].y * c[i].y);
             }
         }
         SGZ_CLK(6);
         if (doMap) mapper.prefetchTables(prm, tid);                    // im[] is dead: its registers take the map tables
-        if (split && q == R - 1 && ix == R - 1) c[brev(R / 2 - 1, LR)].x *= 0.5f;   // csf[N/2-1] *= 0.5 (quirk Q3, :864)
+        if (split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;   // csf[N/2-1] *= 0.5 (quirk Q3, :864)
         __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
 #pragma unroll
-        for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = c[brev(m3, LR)].x;
+        for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = mag[brev(m3, LR)];
         // Column 0 (k = T m3, all held by thread 0) mirrors onto itself and DC / Nyquist are special: redone from thread 0's
         // scratch copy by lanes of the SAME wave, after that wave's own stores above (one wave's LDS operations execute in
         // order), so no extra workgroup barrier is needed.
