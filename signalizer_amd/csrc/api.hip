@@ -155,7 +155,6 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
     prm.colourTables = p.d_colourTables;
     prm.sc = p.scalars;
     prm.state = d_state; prm.stateIn = d_state; prm.rgba = d_rgba; prm.lines = d_lines;
-    prm.ablate = (g_ablate >> 13) & 7u;
     if (d_state && frames > 1) {
         // frame 0's threads read the carry-in while the last frame's threads write the new state: snapshot it
         const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
@@ -174,10 +173,6 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     DecayParams prm;
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
-    if (decayFusedApplies(prm) && !(g_ablate & 0x1000u)) {           // one launch: local scans, fold and emit in one workgroup pass
-        SGZ_HIP(launchDecayFused(prm, stream));
-        return SGZ_OK;
-    }
     if (prm.numChunks > 1) {
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
         sgz_status st = ensureCap(&p.d_agg, &p.aggCap, need);

@@ -48,12 +48,9 @@ struct DecayParams {
     float *state;             // [C][G][P][2] (float2: left/right) out: state after the last frame, may be null
     uint8_t *rgba;            // [frames][P][4] or null
     float *lines;             // [frames][C][G][P][2] or null
-    uint32_t ablate;          // debug hook (tools/ablate_kb.py): skip phases of the single-launch K_B
 };
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream);
-bool decayFusedApplies(const DecayParams &prm);
-hipError_t launchDecayFused(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);

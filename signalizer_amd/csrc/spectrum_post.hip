@@ -81,113 +81,22 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     }
 }
 
-// K_B2 (long inputs, after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels.
-__global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm)
+// K_B2 (after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels, so the GPU sees frames*P
+// threads (the fp64 log of dbMap is ~200 instructions; with one thread per (chunk, pixel) a wave would issue eight of them
+// back to back on an otherwise empty SIMD).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) only
+// needs the workgroups of the last chunk.
+__global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm, const uint32_t firstChunk)
 {
     const int px = threadIdx.x & 31, t = threadIdx.x >> 5;
     const uint32_t groups = (prm.P + 31) / 32;
-    const uint32_t chunk = blockIdx.x / groups;
-    const uint32_t pixel = (blockIdx.x - chunk * groups) * 32 + px;
+    const uint32_t chunk = firstChunk + blockIdx.x / groups;
+    const uint32_t pixel = (blockIdx.x - (chunk - firstChunk) * groups) * 32 + px;
     const long f0 = long(chunk) * kMaxChunk;
     const long f1 = min(f0 + long(kMaxChunk), prm.frames);
     if (pixel >= prm.P || t >= int(f1 - f0)) return;
     const bool allCombos = prm.lines || (f1 == prm.frames && prm.state);
     const float *carryIn = chunk > 0 ? prm.agg + size_t(chunk - 1) * prm.C * prm.sides * G * prm.P + pixel : nullptr;
     emitPixel(prm, chunk, t, pixel, allCombos, carryIn, prm.P, prm.colourTables, prm.slope[pixel], nullptr);
-}
-
-// K_B as ONE launch (inputs whose chunk states fit in LDS): a workgroup owns kFusedPx pixels for the WHOLE time axis.
-//   phase 1: chunk-local scans (as K_B1)                        -> LDS  st[chunk][m][px]
-//   phase 2: sequential fold over the chunks (as K_B1b), in LDS -> exact chunk-end states
-//   phase 3: one (frame, pixel) item at a time (as K_B2)
-// Three dependent kernels cost three launch latencies (~5 us each for this little data); here the dependency is two
-// workgroup barriers.  Rows of kFusedPx pixels are narrow (16 B), but the whole mapped array is only frames*P*8 B.
-constexpr int kFusedPx = 4;
-constexpr int kFusedThreads = 1024;
-
-__global__ void __launch_bounds__(kFusedThreads) decayFusedKernel(const DecayParams prm)
-{
-    extern __shared__ float st[];                               // [numChunks][combos][kFusedPx], then [C][NC][3] colour tables
-    const uint32_t tid = threadIdx.x;
-    float *colourTab = st + size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx;
-    const uint32_t pixel0 = blockIdx.x * kFusedPx;
-    const uint32_t combos = prm.C * prm.sides * G, cs = prm.C * prm.sides;
-    const size_t perFrame = size_t(cs) * prm.P;
-    // phase 1: item = (chunk, ps, px)
-    for (uint32_t it = tid; it < prm.numChunks * cs * kFusedPx && !(prm.ablate & 4); it += kFusedThreads) {
-        const uint32_t px = it % kFusedPx, ps = (it / kFusedPx) % cs, chunk = it / (kFusedPx * cs);
-        const uint32_t pixel = pixel0 + px;
-        if (pixel >= prm.P) continue;
-        const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
-        const long f0 = long(chunk) * kMaxChunk;
-        const int len = int(min(long(kMaxChunk), prm.frames - f0));
-        float mag[kMaxChunk];
-#pragma unroll
-        for (int i = 0; i < kMaxChunk; ++i)
-            mag[i] = prm.mapped[size_t(f0 + (i < len ? i : 0)) * perFrame + size_t(ps) * prm.P + pixel];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
-#pragma unroll
-            for (int i = 0; i < kMaxChunk; ++i) {
-                if (i < len) {
-                    a = a * prm.sc.pole[k];                     // states[i] *= pole, TransformDSP.inl:1336,:1370
-                    if (mag[i] > a) a = mag[i];                 // :1338-1341
-                }
-            }
-            st[(chunk * combos + ps * G + k) * kFusedPx + px] = a;
-        }
-    }
-    // phase-3 operands that do not depend on the fold: fetched now, consumed after the barriers
-    float mag0[kMaxChunk], slope0 = 0.f;
-    {
-        const long f = tid / kFusedPx;
-        const uint32_t pixel = pixel0 + tid % kFusedPx;
-        const bool have = f < prm.frames && pixel < prm.P;
-        const long f0 = (f / kMaxChunk) * kMaxChunk;
-#pragma unroll
-        for (int i = 0; i < kMaxChunk; ++i) mag0[i] = (have && f0 + i <= f) ? prm.mapped[size_t(f0 + i) * perFrame + pixel] : 0.f;
-        if (have) slope0 = prm.slope[pixel];
-    }
-    for (uint32_t i = tid; i < prm.C * NC * 3; i += kFusedThreads) colourTab[i] = prm.colourTables[i];
-    __syncthreads();
-    // phase 2: item = (m, px); st[c] <- max(st[c], decay^8(st[c-1])) by sequential fp32 multiplies.  Blocks of 16 chunk
-    // states are read from LDS together, chained in registers and written back.
-    if (tid < combos * kFusedPx && !(prm.ablate & 1)) {
-        const float pole = prm.sc.pole[(tid / kFusedPx) % G];
-        const uint32_t rs = combos * kFusedPx;
-        float c = st[tid];
-        for (uint32_t j0 = 1; j0 < prm.numChunks; j0 += 16) {
-            float a[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = st[min(j0 + j, prm.numChunks - 1) * rs + tid];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-#pragma unroll
-                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;   // every chunk before the last is full
-                if (a[j] > c) c = a[j];
-                a[j] = c;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j0 + j < prm.numChunks) st[(j0 + j) * rs + tid] = a[j];
-        }
-    }
-    __syncthreads();
-    // phase 3: item = (frame, px).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) emits the last frame.
-    const long itFirst = (prm.rgba || prm.lines) ? 0 : (prm.frames - 1) * kFusedPx;
-    for (long it = itFirst + tid; it < prm.frames * kFusedPx && !(prm.ablate & 2); it += kFusedThreads) {
-        const uint32_t px = uint32_t(it % kFusedPx);
-        const long f = it / kFusedPx;
-        const uint32_t pixel = pixel0 + px;
-        if (pixel >= prm.P) continue;
-        const uint32_t chunk = uint32_t(f / kMaxChunk);
-        const bool allCombos = prm.lines || (chunk + 1 == prm.numChunks && prm.state);
-        const bool first = it == long(tid);                            // (then the operands were prefetched above)
-        emitPixel(prm, chunk, int(f - long(chunk) * kMaxChunk), pixel, allCombos,
-                  st + (chunk > 0 ? size_t(chunk - 1) * combos * kFusedPx : 0) + px, kFusedPx, colourTab,
-                  first ? slope0 : prm.slope[pixel], first ? mag0 : nullptr);
-    }
 }
 
 // carry-in state of rank `rank` from every rank's zero-carry end state (see sgz.h, sgz_decay_fold_carry)
@@ -239,30 +148,11 @@ hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
     return hipGetLastError();
 }
 
-// the single-launch K_B applies while all chunk states of a pixel group fit in LDS
-bool decayFusedApplies(const DecayParams &prm)
-{
-    return (size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx + size_t(prm.C) * NC * 3) * sizeof(float) <= 96 * 1024;
-}
-
-hipError_t launchDecayFused(const DecayParams &prm, hipStream_t stream)
-{
-    const size_t ldsBytes = (size_t(prm.numChunks) * prm.C * prm.sides * G * kFusedPx + size_t(prm.C) * NC * 3) * sizeof(float);
-    static size_t attrBytes = 0;
-    if (attrBytes < ldsBytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&decayFusedKernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
-        if (e != hipSuccess) return e;
-        attrBytes = ldsBytes;
-    }
-    hipLaunchKernelGGL(decayFusedKernel, dim3((prm.P + kFusedPx - 1) / kFusedPx), dim3(kFusedThreads), ldsBytes, stream, prm);
-    return hipGetLastError();
-}
-
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream)
 {
-    const unsigned grid = unsigned(size_t((prm.P + 31) / 32) * prm.numChunks);
-    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(256), 0, stream, prm);
+    const uint32_t firstChunk = (prm.rgba || prm.lines) ? 0u : prm.numChunks - 1;        // state-only pass: last chunk
+    const unsigned grid = unsigned(size_t((prm.P + 31) / 32) * (prm.numChunks - firstChunk));
+    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(256), 0, stream, prm, firstChunk);
     return hipGetLastError();
 }
 
