@@ -65,12 +65,13 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     const uint32_t k = uint32_t((e / prm.P) % G);
     const float pole = prm.sc.pole[k];
     float c = prm.agg[e];
-    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
-        float a[16];
+    constexpr int B = 48;                                       // aggregates fetched together: one load latency per 48 chunks
+    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += B) {
+        float a[B];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = (d0 + j < prm.numChunks) ? prm.agg[size_t(d0 + j) * per + e] : 0.f;
+        for (int j = 0; j < B; ++j) a[j] = prm.agg[size_t(min(d0 + j, prm.numChunks - 1)) * per + e];   // clamped, not predicated
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < B; ++j) {
             if (d0 + j < prm.numChunks) {
 #pragma unroll
                 for (int i = 0; i < kMaxChunk; ++i) c = c * pole;      // every chunk before the last is full
