@@ -35,10 +35,18 @@ ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len)
     s.unit0 = v.left;
     s.right = v.right;
     s.samplePos0 = sampleOffset + (-s.unit0 / s.inc * s.samplesPerPixel);                    // :826
-    size_t n = 0;
-    double unitSpacePos = s.unit0;
-    do { unitSpacePos += s.inc; ++n; } while (unitSpacePos < (s.right + s.inc));             // :883-889
-    s.points = n;
+    // number of points = trip count of the reference's do-while on a running fp64 sum (:883-889).  It depends on the view
+    // only and costs ~1 ns per point on the host, so the last view's count is remembered.
+    static thread_local double memo[3] = {0, 0, 0};
+    static thread_local size_t memoPoints = 0;
+    if (memoPoints && memo[0] == s.unit0 && memo[1] == s.inc && memo[2] == s.right) s.points = memoPoints;
+    else {
+        size_t n = 0;
+        double unitSpacePos = s.unit0;
+        do { unitSpacePos += s.inc; ++n; } while (unitSpacePos < (s.right + s.inc));
+        s.points = n;
+        memo[0] = s.unit0; memo[1] = s.inc; memo[2] = s.right; memoPoints = n;
+    }
     if (len) {
         long c = (-long(std::floor(s.samplePos0)) - 10) % long(len);                         // :829, KernelSize = 10
         if (c < 0) c += long(len);
@@ -76,25 +84,35 @@ scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channe
     double s10, c10;
     sincos(kPi * e / 10.0, &s10, &c10);
     const float ux = float(unit0 + double(p) * inc);
+    // the 20 tap weights depend on the point only: computed once, used by every channel
+    double w[20];
+    long idx0 = cur + (fl - 9);
+#pragma unroll
+    for (int t = 0; t < 20; ++t) {
+        const long i = fl - 9 + t;
+        const double d = x - double(i);
+        const long m = rn - i;                         // in [-10, 10]
+        double wt;
+        if (d == 0.0) wt = 1.0;
+        else {
+            const double pd = kPi * d;
+            const double sa = (m & 1) ? -sPi : sPi;
+            const long am = m < 0 ? -m : m;
+            const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
+            const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
+            wt = 10.0 * sa * sb / (pd * pd);
+        }
+        w[t] = (i < 0 || i >= 21) ? 0.0 : wt;          // taps outside the 21-sample kernel window are skipped (weight 0 is exact: acc += x * 0)
+    }
     for (uint32_t c = 0; c < channels; ++c) {
         const float *r = ring + size_t(c) * stride;
         double acc = 0.0;
-        for (long i = fl - 9; i <= fl + 10; ++i) {
+#pragma unroll
+        for (int t = 0; t < 20; ++t) {
+            const long i = fl - 9 + t;
             if (i < 0 || i >= 21) continue;
-            long idx = cur + i; if (idx >= long(len)) idx -= long(len);
-            const double d = x - double(i);
-            const long m = rn - i;                     // in [-10, 10]
-            double w;
-            if (d == 0.0) w = 1.0;
-            else {
-                const double pd = kPi * d;
-                const double sa = (m & 1) ? -sPi : sPi;
-                const long am = m < 0 ? -m : m;
-                const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
-                const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
-                w = 10.0 * sa * sb / (pd * pd);
-            }
-            acc += double(r[idx]) * w;
+            long idx = idx0 + t; if (idx >= long(len)) idx -= long(len);
+            acc += double(r[idx]) * w[t];
         }
         xy[size_t(c) * points + p] = make_float2(ux, float(acc));
     }
@@ -206,8 +224,26 @@ peakKernel(const float *ch, size_t stride, size_t stop, float *peaks)
 }
 
 // ------------------------------------------------------------------------------------------- K12
+// The reference's fade ramp is a running fp32 sum per SIMD lane (vSampleFade += fadePerSample * V once per iteration,
+// VectorscopeRendering.cpp:528-543,:592): sequential by construction, but it only depends on (n, lanes).  One small
+// kernel replays it -- one thread per lane, `iters` dependent adds -- into ramp[k][lane] = outFade of iteration k,
+// lane; the per-sample kernel then just looks its value up.
+__global__ void fadeRampKernel(size_t n, uint32_t lanes, long iters, float *ramp /*[iters][lanes]*/)
+{
+    const uint32_t lane = threadIdx.x;
+    if (lane >= lanes) return;
+    const float fadePerSample = 1.0f / float(n);
+    float f = fadePerSample * float(lane);
+    const float incr = fadePerSample * float(lanes);
+    for (long k = 0; k < iters; ++k) {
+        ramp[size_t(k) * lanes + lane] = f - 1.0f;
+        f += incr;
+    }
+}
+
 __global__ void __launch_bounds__(256)
-vectorPolarKernel(const float *planar, size_t stride, uint32_t pairs, size_t n, uint32_t lanes, float3 *xyz)
+vectorPolarKernel(const float *planar, size_t stride, uint32_t pairs, size_t n, uint32_t lanes, long iters, const float *ramp,
+                  float3 *xyz)
 {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint32_t pair = blockIdx.y;
@@ -222,27 +258,16 @@ vectorPolarKernel(const float *planar, size_t stride, uint32_t pairs, size_t n, 
     if (l == 0.f && r == 0.f) angle = 0.f;                                                           // :578
     float sx, cy;
     sincosf(angle, &sx, &cy);
-    // fade ramp: SIMD body for i < mainEnd (vSampleFade lane ramp), scalar tail afterwards (:528-543,:592,:600-634)
+    // fade ramp: SIMD body for i < mainEnd (table above), scalar tail afterwards (:600-634)
     const float fadePerSample = 1.0f / float(n);
     const long V = long(lanes);
-    const long iters = (long(n) > V) ? (long(n) - 1) / V : 0;
     const long mainEnd = iters * V;
     float fade;
     if (long(i) < mainEnd) {
-        const long k = long(i) / V, lane = long(i) % V;
-        // vSampleFade[lane] = fl(fadePerSample*lane) (+)= fl(fadePerSample*V), k times
-        float f = fadePerSample * float(lane);
-        const float incr = fadePerSample * float(V);
-        for (long t = 0; t < k; ++t) f += incr;
-        fade = f - 1.0f;
+        fade = ramp[i];                                       // ramp[k * V + lane], k = i / V, lane = i % V
     } else {
-        float base;
-        if (iters > 0) {
-            float f = fadePerSample * float(V - 1);
-            const float incr = fadePerSample * float(V);
-            for (long t = 0; t < iters - 1; ++t) f += incr;
-            base = f - 1.0f;                                  // outFade[vectorLength-1] of the last SIMD iteration
-        } else base = fadePerSample * float(V - 1);           // never written: initial ramp value (:535-538)
+        // outFade[vectorLength-1] of the last SIMD iteration; never written when there was none: initial ramp value (:535-538)
+        const float base = iters > 0 ? ramp[size_t(iters - 1) * V + (V - 1)] : fadePerSample * float(V - 1);
         fade = base - float(long(i) - mainEnd) * fadePerSample;
     }
     xyz[size_t(pair) * n + i] = make_float3(sx * length, cy * length, fade);
@@ -400,10 +425,28 @@ sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_
 {
     if (!d_planar || !d_xyz || pairs == 0 || lanes == 0) return fail(SGZ_EINVAL, "bad argument");
     if (n == 0) return SGZ_OK;
+    if (lanes > 64) return fail(SGZ_EINVAL, "lanes > 64");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long iters = (long(n) > long(lanes)) ? (long(n) - 1) / long(lanes) : 0;      // VectorscopeRendering.cpp:528
+    // the ramp table depends on (n, lanes) only: rebuilt when they change
+    static float *d_ramp = nullptr;
+    static size_t rampCap = 0, rampN = 0;
+    static uint32_t rampLanes = 0;
+    const size_t need = size_t(iters) * lanes + 1;
+    if (rampCap < need) {
+        if (d_ramp) (void)hipFree(d_ramp);
+        d_ramp = nullptr; rampCap = 0; rampN = 0;
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&d_ramp), need * sizeof(float)));
+        rampCap = need;
+    }
+    if (rampN != n || rampLanes != lanes) {
+        if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(64), 0, s, n, lanes, iters, d_ramp);
+        rampN = n; rampLanes = lanes;
+    }
     const int block = 256;
     dim3 grid(unsigned((n + block - 1) / block), pairs);
-    hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, reinterpret_cast<hipStream_t>(stream), d_planar, stride,
-                       pairs, n, lanes, reinterpret_cast<float3 *>(d_xyz));
+    hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, s, d_planar, stride, pairs, n, lanes, iters, d_ramp,
+                       reinterpret_cast<float3 *>(d_xyz));
     SGZ_HIP(hipGetLastError());
     return SGZ_OK;
 }
