@@ -134,7 +134,10 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
  *  bins:   per (frame,pair) the post-split magnitude array csf[0..N] of mapToLinearSpace
  *          (TransformDSP.inl:858-869 for Separate/MidSide; :553-560 mono modes) as float [N+1];
  *  mapped: csp magnitudes after pixel mapping (TransformDSP.inl:871-985), float [frames][pairs][2][P];
- *  decay+colour from given mapped magnitudes (TransformDSP.inl:1299-1435 + SpectrumDSP.cpp:111-206). */
+ *  decay+colour from given mapped magnitudes (TransformDSP.inl:1299-1435 + SpectrumDSP.cpp:111-206).
+ * SGZ_CH_PHASE (TransformDSP.inl:643-853, :1393-1432): the bins stay complex -- `bins` is float2 [N+1] (re, im) after
+ * separateTransformsIPL and the DC / Nyquist fix-ups; the two planes of `mapped` are wsp[2x] (magnitude) and wsp[2x+1]
+ * (phase cancellation); state and line results hold (magnitude, phase) where the other modes hold (left, right). */
 sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
                           float *d_bins /*[frames][pairs][N+1]*/, void *stream);
 sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,

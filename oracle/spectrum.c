@@ -6,7 +6,8 @@
  *   Source/Spectrum/SpectrumDSP.cpp       (gradient colour map + additive blend + uint8)
  *   Source/Spectrum/Spectrum.cpp:226-246  (colour ratios)
  *   JuceLibraryCode/modules/juce_graphics/colour/juce_Colour.cpp (HSB round trip)
- * Phase mode (TransformDSP.inl:643-853) is not restated (returns -1): scheduled with the "next" rows.
+ * Phase mode (TransformDSP.inl:643-853, :1393-1432) is restated with its quirks (Q3, Q6, Q7); where the reference reads
+ * working memory it never wrote (the last pixel's cancellation of a fully interpolated view) the value is defined as 0.
  */
 #include "sgz_oracle.h"
 #include <float.h>
@@ -291,8 +292,88 @@ int sgzo_map_to_linear_space(const sgzo_spectrum_params *p, const float *mf, dou
         }
         return 1;
     }
+    case SGZO_CH_PHASE: {                                                              /* :643-853 */
+        /* wsp[2x] = magnitude, wsp[2x+1] = phase cancellation: the same working memory as csp, viewed as floats (:508-509) */
+        float *wsp = (float *)csp;
+        sgzo_separate_transforms_ipl(csf, (uint32_t)N);
+        csf[N].re = csf[0].im * 0.5f; csf[N].im = 0;                                  /* :649 */
+        csf[0].re = csf[0].re * 0.5f; csf[0].im = 0;                                  /* :650 */
+        csf[N >> 1] = cf_scale(0.5f, csf[N >> 1]);                                   /* :651 */
+        csf[(N >> 1) - 1] = cf_scale(0.5f, csf[(N >> 1) - 1]);                       /* :652, quirk Q3 */
+        size_t bandWidthBreakingPoint = (size_t)P;                                    /* :665 */
+        const double fftBandwidth = 1.0 / (double)numBins;
+        if (p->bin_interp == SGZO_INTERP_LINEAR || p->bin_interp == SGZO_INTERP_LANCZOS) {
+            const size_t filterSize = p->bin_interp == SGZO_INTERP_LINEAR ? 1 : 5;    /* linearFilterSize :712 / lanczosFilterSize */
+            /* phase pass (:674-690 / :732-750): on the un-normalised vectors.  The last pixel's cancellation is never
+             * written when the loop does not break (stale working memory in the reference; defined as 0 here). */
+            wsp[(P - 1) * 2 + 1] = 0;
+            for (x = 0; x < P - 1; ++x) {
+                const double bwForLine = (double)((mf[x + 1] - mf[x]) / topFrequency);
+                if (bwForLine > fftBandwidth) { bandWidthBreakingPoint = (size_t)x; break; }
+                const float pos = mf[x] * freqToBin;
+                const sgzo_cf iLeft = interp_at(p->bin_interp, csf, csfSize, pos, numBins);
+                const sgzo_cf iRight = interp_at(p->bin_interp, csf, csfSize, (float)N - pos, numBins);
+                sgzo_cf sum; sum.re = iLeft.re + iRight.re; sum.im = iLeft.im + iRight.im;
+                const float cancellation = invSize * sqrtf(cf_square(sum));
+                const float mid = invSize * (cf_abs(iLeft) + cf_abs(iRight));
+                wsp[x * 2 + 1] = 1.0f - (mid > 0 ? (cancellation / mid) : 0);
+            }
+            /* magnitude pass (:707-727 / :759-775): bins are normalised (replaced by their magnitude) lazily, just ahead of
+             * the filter window, and only while x < breakingPoint - (filterSize + 1) -- an unsigned subtraction (Q6) */
+            size_t normalizedPosition = 0;
+            for (x = 0; x < (long)bandWidthBreakingPoint; ++x) {
+                const float binPosition = mf[x] * freqToBin;
+                while ((binPosition + (float)filterSize) > (float)normalizedPosition &&
+                       (size_t)x < bandWidthBreakingPoint - (filterSize + 1)) {
+                    csf[normalizedPosition].re = cf_abs(csf[normalizedPosition]); csf[normalizedPosition].im = 0;
+                    csf[(size_t)N - normalizedPosition].re = cf_abs(csf[(size_t)N - normalizedPosition]);
+                    csf[(size_t)N - normalizedPosition].im = 0;
+                    normalizedPosition++;
+                }
+                const sgzo_cf iLeft = interp_at(p->bin_interp, csf, csfSize, binPosition, numBins);
+                const sgzo_cf iRight = interp_at(p->bin_interp, csf, csfSize, (float)N - binPosition, numBins);
+                wsp[x * 2] = invSize * (cf_abs(iLeft) + cf_abs(iRight));
+            }
+        } else {                                                                      /* None, :779-801 */
+            for (x = 0; x < P - 1; ++x) {
+                const double bwForLine = (double)((mf[x + 1] - mf[x]) / topFrequency);
+                if (bwForLine > fftBandwidth) break;
+                const size_t index = confine((size_t)((double)(mf[x] * freqToBin) + 0.5), 0, numBins - 1);
+                const sgzo_cf iLeft = csf[index], iRight = csf[(size_t)N - index];
+                sgzo_cf sum; sum.re = iLeft.re + iRight.re; sum.im = iLeft.im + iRight.im;
+                const float cancellation = invSize * cf_abs(sum);
+                const float mid = invSize * (cf_abs(iLeft) + cf_abs(iRight));
+                wsp[x * 2] = mid;
+                wsp[x * 2 + 1] = 1.0f - (mid > 0 ? (cancellation / mid) : 0);
+            }
+        }
+        if (x < P) oldBin = (long)(mf[x] * freqToBin);                                /* :806-807 */
+        for (; x < P; ++x) {                                                          /* :811-849 */
+            size_t maxBin = 0;
+            float maxValue = 0, newMag = 0;
+            bin = (long)(size_t)(mf[x] * freqToBin);
+            long diff = bin - oldBin;
+            long counter = diff ? 1 : 0;
+            do {
+                const long offset = oldBin + counter;
+                const float a = cf_square(csf[offset]), b = cf_square(csf[N - offset]);
+                newMag = a < b ? b : a;                                               /* std::max */
+                if (newMag > maxValue) { maxValue = newMag; maxBin = (size_t)(oldBin + counter); }
+                counter++; diff--;
+            } while (diff > 0);
+            const sgzo_cf leftMax = csf[maxBin], rightMax = csf[(size_t)N - maxBin];
+            sgzo_cf sum; sum.re = leftMax.re + rightMax.re; sum.im = leftMax.im + rightMax.im;
+            const float interference = invSize * cf_abs(sum);
+            const float mid = invSize * (cf_abs(leftMax) + cf_abs(rightMax));
+            const float cancellation = interference / mid;
+            wsp[x * 2] = mid;
+            wsp[x * 2 + 1] = 1.0f - (mid > 0 ? cancellation : 0);
+            oldBin = bin;
+        }
+        return 1;
+    }
     default:
-        return -1;   /* Phase mode not restated */
+        return -1;
     }
 }
 
@@ -345,6 +426,28 @@ void sgzo_map_and_transform_filters(const sgzo_spectrum_params *p, const float *
             }
         }
         break;
+    case SGZO_CH_PHASE: {                                                              /* :1393-1432 */
+        /* std::pow<T>(pole, 0.3): restated as powf (UNVERIFIED: the explicit template argument selects an overload we cannot see) */
+        float phaseFilters[SGZO_NUM_GRAPHS];
+        for (int k = 0; k < SGZO_NUM_GRAPHS; ++k) phaseFilters[k] = powf(p->pole[k], 0.3f);
+        for (size_t i = 0; i < size; ++i) {
+            float mag = newVals[i * 2];
+            float phase = newVals[i * 2 + 1];
+            mag *= 0.5f;
+            for (int k = 0; k < SGZO_NUM_GRAPHS; ++k) {
+                sgzo_cf *st = &states[(size_t)k * size + i], *rs = &results[(size_t)k * size + i];
+                st->re *= p->pole[k];
+                if (mag > st->re) st->re = mag;
+                phase *= mag;                                                          /* inside the graph loop: quirk Q7 */
+                st->im = phase + phaseFilters[k] * (st->im - phase);
+                const float deltaX = slope[i] * st->re * minFracRecip;
+                const float deltaY = slope[i] * st->im * minFracRecip;
+                rs->re = deltaX > 0 ? logf(deltaX) * deltaYRecip : lowerClip;
+                rs->im = deltaY > 0 ? logf(deltaY) * deltaYRecip : lowerClip;
+            }
+        }
+        break;
+    }
     default: break;
     }
 }
@@ -416,7 +519,6 @@ static long spectrogram_impl(const sgzo_spectrum_params *p, const float *const *
     const long F = sgzo_num_frames(nsamples, W, p->hop);
     if (F <= 0 || P < 2) return 0;
     if (f1 > F) f1 = F;
-    if (p->channel_mode == SGZO_CH_PHASE) return -1;
     float *window = (float *)calloc(N, sizeof(float));
     float *mapped = (float *)malloc(sizeof(float) * P);
     float *slope = (float *)malloc(sizeof(float) * P);

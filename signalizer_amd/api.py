@@ -207,7 +207,7 @@ class Plan:
 
     @property
     def sides(self) -> int:
-        return 2 if self.cfg.channel_mode in (5, 6) else 1
+        return 2 if self.cfg.channel_mode in (4, 5, 6) else 1      # Phase (4): magnitude and cancellation planes
 
     @property
     def window_scale(self) -> float:
@@ -265,7 +265,9 @@ class Plan:
         import torch
         S = planar.shape[1]
         F = self.num_frames(S)
-        out = torch.empty((F, self.C, self.N + 1), dtype=torch.float32, device=planar.device)
+        # Phase mode keeps the bins complex: (re, im) pairs instead of magnitudes
+        shape = (F, self.C, self.N + 1, 2) if self.cfg.channel_mode == 4 else (F, self.C, self.N + 1)
+        out = torch.empty(shape, dtype=torch.float32, device=planar.device)
         check(lib().sgz_stage_bins(self.h, planar.data_ptr(), planar.stride(0), S, out.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream))
         return out

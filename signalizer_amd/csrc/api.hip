@@ -33,7 +33,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_phaseType, d_phaseNorm, d_phaseWork};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -65,6 +65,8 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.phaseType, &p.d_phaseType)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.phaseNorm, &p.d_phaseNorm)) != SGZ_OK) return st;
     (void)hipGetDevice(&p.device);
     p.uploaded = true;
     return SGZ_OK;
@@ -116,6 +118,7 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                           float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock)
 {
+    const bool phase = p.cfg.channel_mode == SGZ_CH_PHASE;
     StftParams prm = fillStftParams(p, d_planar, chStride, frames, d_mapped, d_binsOut, d_binsIn, d_phaseClock);
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
@@ -129,11 +132,19 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             for (float **b : {&p.d_work0, &p.d_work1, &p.d_binsWork}) if (*b) { (void)hipFree(*b); *b = nullptr; }
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_work0), size_t(slab) * perTask * sizeof(float)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_work1), size_t(slab) * perTask * sizeof(float)));
-            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_binsWork), size_t(slab) * (size_t(p.N) + 1) * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_binsWork), size_t(slab) * (size_t(p.N) + 1) * sizeof(float) * (phase ? 2 : 1)));
             p.workSlab = size_t(slab);
         }
+        PhaseTables ph{};
+        if (phase) {
+            // Phase keeps the bins complex; the float test hooks carry float2 data in this mode (sgz.h, stage hooks)
+            ph.type = p.d_phaseType; ph.norm = p.d_phaseNorm; ph.normFinal = p.phaseNormFinal;
+            ph.filtered = p.cfg.bin_interp != SGZ_INTERP_NONE;
+            ph.csfOut = reinterpret_cast<float2 *>(d_binsOut);
+            ph.csfIn = reinterpret_cast<const float2 *>(d_binsIn);
+        }
         SGZ_HIP(launchGeneric(prm, p.N, reinterpret_cast<const float2 *>(p.d_twN), reinterpret_cast<float2 *>(p.d_work0),
-                              reinterpret_cast<float2 *>(p.d_work1), p.d_binsWork, long(p.workSlab), stream));
+                              reinterpret_cast<float2 *>(p.d_work1), p.d_binsWork, long(p.workSlab), stream, phase ? &ph : nullptr));
         return SGZ_OK;
     }
     const int grid = int(tasks);                 // one workgroup per (frame, pair); the dispatcher refills CUs
@@ -173,6 +184,12 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     DecayParams prm;
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
+    if (p.cfg.channel_mode == SGZ_CH_PHASE) {
+        sgz_status stw = ensureCap(&p.d_phaseWork, &p.phaseWorkCap, size_t(frames) * p.C * p.P);
+        if (stw != SGZ_OK) return stw;
+        SGZ_HIP(launchDecayPhase(prm, p.d_phaseWork, stream));
+        return SGZ_OK;
+    }
     if (prm.numChunks > 1) {
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
         sgz_status st = ensureCap(&p.d_agg, &p.aggCap, need);
@@ -408,6 +425,8 @@ sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64
     if (st != SGZ_OK) return st;
     if (!d_aggs || !frames_per_rank || !d_carry || rank >= world || world > 64) return fail(SGZ_EINVAL, "bad argument");
     Plan &p = plan->impl;
+    if (p.cfg.channel_mode == SGZ_CH_PHASE)
+        return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
     long long fr[64];
     for (uint32_t q = 0; q < world; ++q) fr[q] = frames_per_rank[q];
     const size_t perRank = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;

@@ -22,6 +22,43 @@ __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalar
     return deltaX > 0.f ? float(log(double(deltaX))) * sc.deltaYRecip : sc.lowerClip;   // :1345
 }
 
+// renderSf + the additive blend of one pair's colour into the column buffer, SpectrumDSP.cpp:119-174
+__device__ __forceinline__ void blendColour(float (&cb)[3], float intensity, const float *sca, const DeviceScalars &sc)
+{
+    if (intensity < 0.f) return;
+    float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
+    if (intensity < 0.999f) {
+        float accumulatedSum = 0.f;
+        for (int c = 1; c < NC; ++c) {
+            const float nextScale = sc.ratios[c];
+            accumulatedSum += nextScale;
+            if (accumulatedSum >= intensity) {
+                const float mn = accumulatedSum - nextScale;
+                const float mx = accumulatedSum;
+                const float mix = (intensity - mn) / (mx - mn);
+                const float imix = 1.f - mix;
+                const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
+                colourv[0] = ca[0] * imix + cbb[0] * mix;
+                colourv[1] = ca[1] * imix + cbb[1] * mix;
+                colourv[2] = ca[2] * imix + cbb[2] * mix;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cb[c] += (1.f - cb[c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
+}
+
+__device__ __forceinline__ uchar4 toRgba8(const float (&cb)[3])
+{
+    uchar4 pxl;
+    pxl.x = (unsigned char)(cb[0] * 255.f);                     // static_cast<uint8_t>(c * maxByte), SpectrumDSP.cpp:195-198
+    pxl.y = (unsigned char)(cb[1] * 255.f);
+    pxl.z = (unsigned char)(cb[2] * 255.f);
+    pxl.w = 255;
+    return pxl;
+}
+
 // dB map + colour blend + line / state outputs of ONE (frame, pixel): replays the chunk's recurrence up to frame
 // f = f0 + t (<= 8 steps) on top of the chunk's carry-in states.  carryIn[m * carryStride] = exact state of
 // (pair, side, graph) combination m = (pair * sides + side) * G + graph at the end of the previous chunk (unused for
@@ -70,44 +107,11 @@ __device__ __forceinline__ void emitPixel(const DecayParams &prm, uint32_t chunk
                 const float result = dbMap(slope, s, prm.sc);
                 if (prm.lines)
                     prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
-                if (colour) {
-                    // renderSf, SpectrumDSP.cpp:119-168
-                    const float intensity = result;
-                    if (!(intensity < 0.f)) {
-                        float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
-                        if (intensity < 0.999f) {
-                            float accumulatedSum = 0.f;
-                            for (int c = 1; c < NC; ++c) {
-                                const float nextScale = prm.sc.ratios[c];
-                                accumulatedSum += nextScale;
-                                if (accumulatedSum >= intensity) {
-                                    const float mn = accumulatedSum - nextScale;
-                                    const float mx = accumulatedSum;
-                                    const float mix = (intensity - mn) / (mx - mn);
-                                    const float imix = 1.f - mix;
-                                    const float *ca = sca + (c - 1) * 3, *cbb = sca + c * 3;
-                                    colourv[0] = ca[0] * imix + cbb[0] * mix;
-                                    colourv[1] = ca[1] * imix + cbb[1] * mix;
-                                    colourv[2] = ca[2] * imix + cbb[2] * mix;
-                                    break;
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) cb[c] += (1.f - cb[c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
-                    }
-                }
+                if (colour) blendColour(cb, result, sca, prm.sc);
             }
         }
     }
-    if (prm.rgba) {
-        uchar4 pxl;
-        pxl.x = (unsigned char)(cb[0] * 255.f);                 // static_cast<uint8_t>(c * maxByte), :195-198
-        pxl.y = (unsigned char)(cb[1] * 255.f);
-        pxl.z = (unsigned char)(cb[2] * 255.f);
-        pxl.w = 255;
-        reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = pxl;
-    }
+    if (prm.rgba) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
 }
 
 

@@ -31,8 +31,17 @@ struct StftParams {
 };
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+// SpectrumChannels::Phase tables (plan.cpp buildPhaseRecords); null for the other modes
+struct PhaseTables {
+    const uint32_t *type;     // [P] 0 interpolated, 1 arg-max run, 2 interpolated magnitude only
+    const uint32_t *norm;     // [P] normalizedPosition at the pixel's magnitude pass
+    uint32_t normFinal;       // normalizedPosition for the arg-max pixels
+    uint32_t filtered;        // Linear / Lanczos (cancellation = sqrt(|sum|^2)) vs None (cancellation = |sum| via hypot)
+    float2 *csfOut;           // test hook: complex bins [tasks][N+1] out (or null)
+    const float2 *csfIn;      // test hook: map from these complex bins (skip the FFT)
+};
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
-                         long slab, hipStream_t stream);
+                         long slab, hipStream_t stream, const PhaseTables *phase = nullptr);
 
 struct DecayParams {
     const float *mapped;      // [frames][C][sides][P]
@@ -52,6 +61,9 @@ struct DecayParams {
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
+// SpectrumChannels::Phase: sequential-in-time K_B (the cancellation smoother is a linear recurrence: no exact chunk fold);
+// work: [frames][C][P] floats for the main graph's dB values
+hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t stream);
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
 

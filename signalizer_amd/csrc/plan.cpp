@@ -258,6 +258,79 @@ static void buildPixelRecords(Plan &p)
     }
 }
 
+// SpectrumChannels::Phase (TransformDSP.inl:643-853).  recs[0..P) = left record, recs[P..2P) = right record of the
+// interpolated pixels; phaseType[x]: 0 = interpolated (cancellation + magnitude), 1 = arg-max run, 2 = interpolated
+// magnitude only (the last pixel of a view that never leaves the interpolation branch: its cancellation is never written);
+// phaseNorm[x] = normalizedPosition when pixel x's magnitude is evaluated (bins k < phaseNorm and N-k with k < phaseNorm
+// have been replaced by their magnitudes by then, Q6); phaseNormFinal = its value for the arg-max pixels.
+static void buildPhaseRecords(Plan &p)
+{
+    const long N = long(p.N), P = long(p.P);
+    const size_t numBins = size_t(N >> 1);
+    const float *mf = p.mapped.data();
+    const float topFrequency = p.cfg.sample_rate / 2;
+    const float freqToBin = float(float(numBins) / topFrequency);
+    RecBuilder rb(p);
+    p.recs.assign(size_t(2) * size_t(P), PixelRec{});
+    p.weights.clear();
+    p.phaseType.assign(size_t(P), 1u);
+    p.phaseNorm.assign(size_t(P), 0u);
+    PixelRec *left = p.recs.data(), *right = p.recs.data() + P;
+    const double fftBandwidth = 1.0 / double(numBins);
+    const bool filtered = p.cfg.bin_interp == SGZ_INTERP_LINEAR || p.cfg.bin_interp == SGZ_INTERP_LANCZOS;
+    size_t breakingPoint = size_t(P);                                    // bandWidthBreakingPoint, :665
+    long x = 0;
+    for (x = 0; x < P - 1; ++x) {
+        const double bw = double((mf[x + 1] - mf[x]) / topFrequency);
+        if (bw > fftBandwidth) { breakingPoint = size_t(x); break; }
+        const float pos = mf[x] * freqToBin;
+        if (filtered) {
+            left[x] = rb.interp(pos, numBins);
+            right[x] = rb.interp(float(N) - pos, numBins);
+        } else {                                                         // None: clamp to numBins - 1 here (:791, Q5)
+            left[x] = rb.interp(pos, numBins - 1);
+            PixelRec r = left[x];
+            r.a = int32_t(N - long(left[x].a));
+            r.c = int32_t(p.weights.size());
+            p.weights.push_back(1.0f);
+            right[x] = r;
+        }
+        p.phaseType[size_t(x)] = 0u;
+    }
+    uint32_t normalizedPosition = 0;
+    if (filtered) {
+        const size_t filterSize = p.cfg.bin_interp == SGZ_INTERP_LINEAR ? 1 : 5;
+        if (breakingPoint == size_t(P)) {                                // no break: the magnitude pass also covers pixel P-1
+            const float pos = mf[P - 1] * freqToBin;
+            left[P - 1] = rb.interp(pos, numBins);
+            right[P - 1] = rb.interp(float(N) - pos, numBins);
+            p.phaseType[size_t(P - 1)] = 2u;
+        }
+        for (long xx = 0; xx < long(breakingPoint); ++xx) {              // :714-727 / :759-775
+            const float binPosition = mf[xx] * freqToBin;
+            while ((binPosition + float(filterSize)) > float(normalizedPosition) && size_t(xx) < breakingPoint - (filterSize + 1))
+                ++normalizedPosition;
+            p.phaseNorm[size_t(xx)] = normalizedPosition;
+        }
+    }
+    p.phaseNormFinal = normalizedPosition;
+    p.breakPixel = uint32_t(x);
+    long oldBin = 0;
+    if (x < P) oldBin = long(mf[x] * freqToBin);                         // :806-807
+    for (; x < P; ++x) {
+        const long bin = long(size_t(mf[x] * freqToBin));
+        long diff = bin - oldBin;
+        long counter = diff ? 1 : 0;
+        const long first = oldBin + counter;
+        long cnt = 0;
+        do { ++cnt; ++counter; --diff; } while (diff > 0);
+        PixelRec r{}; r.kind = 1; r.a = int32_t(first); r.b = int32_t(cnt); r.c = 0;   // maxBin starts at 0 (:813)
+        left[x] = r; right[x] = r;
+        p.phaseType[size_t(x)] = 1u;
+        oldBin = bin;
+    }
+}
+
 static void buildTwiddles(Plan &p)
 {
     // N = R^3 fast path (R = 16 or 32).  Factorised tables (see TwFactors in spectrum_fft.hip):
@@ -266,6 +339,7 @@ static void buildTwiddles(Plan &p)
     const double kTwoPi = 6.28318530717958647692;
     int R = 0;
     if (p.N == 32768) R = 32; else if (p.N == 4096) R = 16;
+    if (p.cfg.channel_mode == SGZ_CH_PHASE) R = 0;      // Phase keeps complex bins: generic (HBM-resident) path, spectrum_generic.hip
     p.fused = R != 0;
     if (!R) {   // generic radix-2 Stockham path: one table W_N^i, i < N/2
         p.twN.resize(size_t(p.N / 2) * 2);
@@ -308,17 +382,14 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         err = "invalid enum value in spectrum config";
         return SGZ_EINVAL;
     }
-    if (cfg.channel_mode == SGZ_CH_PHASE) {
-        err = "SpectrumChannels::Phase is not built yet";
-        return SGZ_EUNSUPPORTED;
-    }
     p.cfg = cfg;
     p.W = cfg.window_size;
     p.N = transformSizeFor(p.W);
     p.log2N = 0; while ((1u << p.log2N) < p.N) ++p.log2N;
     p.P = cfg.axis_points;
     p.C = cfg.num_pairs;
-    p.sides = (cfg.channel_mode == SGZ_CH_SEPARATE || cfg.channel_mode == SGZ_CH_MIDSIDE) ? 2 : 1;
+    // two planes of P values per (frame, pair): left / right magnitudes, or (Phase) magnitude / cancellation
+    p.sides = (cfg.channel_mode == SGZ_CH_SEPARATE || cfg.channel_mode == SGZ_CH_MIDSIDE || cfg.channel_mode == SGZ_CH_PHASE) ? 2 : 1;
     p.stateChannels = cfg.channel_mode > SGZ_CH_SIDE ? 2 : 1;
 
     // windowKernel (N entries; [W,N) stay zero = the zero padding of prepareTransform :220-223)
@@ -364,7 +435,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // scalars
     DeviceScalars &s = p.scalars;
     s.invSize = float(p.windowScale / (double(p.W) * 0.5));
-    for (int k = 0; k < SGZ_NUM_GRAPHS; ++k) s.pole[k] = cfg.pole[k];
+    for (int k = 0; k < SGZ_NUM_GRAPHS; ++k) { s.pole[k] = cfg.pole[k]; s.phasePole[k] = std::pow(cfg.pole[k], 0.3f); }
     {
         const double lowerFraction = std::pow(10.0, cfg.low_db / 20.0);
         const double upperFraction = std::pow(10.0, cfg.high_db / 20.0);
@@ -390,12 +461,13 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             for (int c = 0; c < 3; ++c)
                 p.colourTables[(size_t(pair) * (SGZ_NUM_SPEC_COLOURS + 1) + i) * 3 + c] = float(rgb[c]) / 255.0f;
         }
-    buildPixelRecords(p);
+    if (cfg.channel_mode == SGZ_CH_PHASE) buildPhaseRecords(p);
+    else buildPixelRecords(p);
     p.weights.insert(p.weights.end(), size_t(kMaxTaps), 0.0f);    // padding: the kernel reads kMaxTaps weights unconditionally
     // balanced arg-max work list: every kind-1 record cut at 16-aligned csf windows (see MaxItem)
     p.items.clear();
     p.nItemsLeft = 0;
-    for (size_t r = 0; r < p.recs.size(); ++r) {
+    for (size_t r = 0; r < p.recs.size() && cfg.channel_mode != SGZ_CH_PHASE; ++r) {   // (Phase runs the generic map kernel)
         PixelRec &rec = p.recs[r];
         if (rec.kind != 1) continue;
         const bool right = r >= size_t(p.P);

@@ -35,6 +35,7 @@ struct MaxItem {
 struct DeviceScalars {
     float invSize;        // windowKernelScale / (W/2), TransformDSP.inl:540
     float pole[SGZ_NUM_GRAPHS];
+    float phasePole[SGZ_NUM_GRAPHS];   // pole^0.3, the one-pole smoother of Phase mode's cancellation (TransformDSP.inl:1397-1398)
     float deltaYRecip;    // 1 / ln(upper/lower), TransformDSP.inl:1311
     float minFracRecip;   // 1 / lower,           :1312
     float lowerClip;      // (float)clipDB,       :1314
@@ -57,6 +58,8 @@ struct Plan {
     std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
+    std::vector<uint32_t> phaseType, phaseNorm;   // Phase mode only (plan.cpp buildPhaseRecords), [P] each
+    uint32_t phaseNormFinal = 0;
     std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces (left-side records first)
     uint32_t nItemsLeft = 0;
     std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels (fused N = R^3 path)
@@ -69,12 +72,14 @@ struct Plan {
     float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
     float *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twN = nullptr;
     float *d_work0 = nullptr, *d_work1 = nullptr, *d_binsWork = nullptr; size_t workSlab = 0;   // generic path buffers
+    uint32_t *d_phaseType = nullptr, *d_phaseNorm = nullptr;
     PixelRec *d_recs = nullptr;
     MaxItem *d_items = nullptr;
     // work buffers (grown on demand)
     float *d_mapped = nullptr; size_t mappedCap = 0;      // [frames][pairs][2][P]
     float *d_agg = nullptr; size_t aggCap = 0;            // decay chunk aggregates
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
+    float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
     int device = 0;
 

@@ -138,17 +138,146 @@ genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const Pixe
     mapped[gid] = __builtin_sqrtf(sq);
 }
 
+// ---- SpectrumChannels::Phase (TransformDSP.inl:643-853): the bins stay complex ------------------------------------------
+// csf after separateTransformsIPL and the DC / Nyquist fix-ups (:646-652): csf[k] = X1[k], csf[N-k] = X2[k] (1 <= k < N/2),
+// csf[0] = Re Z[0] / 2, csf[N] = Im Z[0] / 2, csf[N/2] and csf[N/2-1] halved (quirk Q3).
+__global__ void __launch_bounds__(256)
+genericBinsPhase(const float2 *z, uint32_t N, long ntasks, float2 *csf /*[ntasks][N+1]*/)
+{
+#pragma clang fp contract(off)
+    const size_t per = size_t(N) + 1;
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * per) return;
+    const long t = long(gid / per);
+    const uint32_t k = uint32_t(gid - size_t(t) * per);
+    const float2 *Z = z + size_t(t) * N;
+    float2 out;
+    if (k == 0) out = make_float2(Z[0].x * 0.5f, 0.f);
+    else if (k == N) out = make_float2(Z[0].y * 0.5f, 0.f);
+    else if (k == N / 2) out = make_float2(0.5f * Z[k].x, 0.5f * Z[k].y);
+    else {
+        const uint32_t kk = k < N / 2 ? k : N - k;                  // the pair (kk, N - kk) is split together
+        const float2 a = Z[kk], b = Z[N - kk];
+        if (k < N / 2) out = make_float2((a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f);     // X1[k]
+        else out = make_float2((a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f);               // X2[kk]
+        if (k == N / 2 - 1) out = make_float2(0.5f * out.x, 0.5f * out.y);            // :652
+    }
+    csf[gid] = out;
+}
+
+// std::abs(std::complex<float>) = hypotf: glibc evaluates it as (float)sqrt((double)x*x + (double)y*y)
+__device__ __forceinline__ float cabsHypot(float2 z)
+{
+    const double x = double(z.x), y = double(z.y);
+    return float(sqrt(x * x + y * y));
+}
+
+// one thread per (task, pixel): wsp[2x] = magnitude -> plane 0, wsp[2x+1] = cancellation measure -> plane 1
+__global__ void __launch_bounds__(256)
+genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *recs, const float *weights, PhaseTables ph,
+                float invSize, long ntasks, float *mapped /*[ntasks][2][P]*/)
+{
+#pragma clang fp contract(off)
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * P) return;
+    const long t = long(gid / P);
+    const uint32_t x = uint32_t(gid - size_t(t) * P);
+    const float2 *csf = csfAll + size_t(t) * (size_t(N) + 1);
+    const uint32_t type = ph.type[x];
+    // value of csf[j] once bins below `norm` (and their mirrors) have been replaced by their magnitudes
+    auto normalised = [&](int j, uint32_t norm) {
+        const float2 v = csf[j];
+        const bool isNorm = uint32_t(j) < norm || uint32_t(int(N) - j) < norm;
+        return isNorm ? make_float2(cabsHypot(v), 0.f) : v;
+    };
+    auto filter = [&](const PixelRec &rec, uint32_t norm) {           // taps accumulate in order, per component
+        float2 acc = make_float2(0.f, 0.f);
+        int k = rec.a;
+        for (int i = 0; i < rec.b; ++i) {
+            const float2 v = normalised(k, norm);
+            const float w = weights[rec.c + i];
+            acc.x = acc.x + v.x * w;
+            acc.y = acc.y + v.y * w;
+            k = (k == int(N)) ? 0 : k + 1;
+        }
+        return acc;
+    };
+    float mag, cancel;
+    if (type != 1u) {
+        const PixelRec rl = recs[x], rr = recs[P + x];
+        if (type == 0u) {
+            const float2 iLeft = filter(rl, 0u), iRight = filter(rr, 0u);          // phase pass: un-normalised vectors
+            const float2 sum = make_float2(iLeft.x + iRight.x, iLeft.y + iRight.y);
+            const float cancellation = invSize * (ph.filtered ? __builtin_sqrtf(sum.x * sum.x + sum.y * sum.y) : cabsHypot(sum));
+            const float mid = invSize * (cabsHypot(iLeft) + cabsHypot(iRight));
+            cancel = 1.0f - (mid > 0.f ? (cancellation / mid) : 0.f);
+            mag = mid;
+        } else cancel = 0.f;                                          // never written by the reference (see oracle/spectrum.c)
+        if (ph.filtered) {                                            // magnitude pass on the lazily normalised bins
+            const uint32_t norm = ph.norm[x];
+            const float2 iLeft = filter(rl, norm), iRight = filter(rr, norm);
+            mag = invSize * (cabsHypot(iLeft) + cabsHypot(iRight));
+        }
+    } else {
+        const PixelRec rec = recs[x];
+        float maxValue = 0.f;
+        int maxBin = rec.c;                                           // 0
+        for (int i = 0; i < rec.b; ++i) {
+            const int off = rec.a + i;
+            const float2 l = normalised(off, ph.normFinal), r = normalised(int(N) - off, ph.normFinal);
+            const float a = l.x * l.x + l.y * l.y, b = r.x * r.x + r.y * r.y;     // Math::square(complex) = |z|^2
+            const float newMag = a < b ? b : a;                        // std::max
+            if (newMag > maxValue) { maxValue = newMag; maxBin = off; }
+        }
+        const float2 leftMax = normalised(maxBin, ph.normFinal), rightMax = normalised(int(N) - maxBin, ph.normFinal);
+        const float2 sum = make_float2(leftMax.x + rightMax.x, leftMax.y + rightMax.y);
+        const float interference = invSize * cabsHypot(sum);
+        const float mid = invSize * (cabsHypot(leftMax) + cabsHypot(rightMax));
+        const float cancellation = interference / mid;
+        mag = mid;
+        cancel = 1.0f - (mid > 0.f ? cancellation : 0.f);
+    }
+    float *out = mapped + size_t(t) * 2 * P;
+    out[x] = mag;
+    out[P + x] = cancel;
+}
+
 static inline unsigned gridFor(size_t total) { return unsigned((total + 255) / 256); }
 
 // Runs the generic path for tasks [0, ntasks) in slabs that fit the work buffers (work0/work1: complex [slab][N]).
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
-                         long slab, hipStream_t stream)
+                         long slab, hipStream_t stream, const PhaseTables *phase)
 {
     const long tasks = prm.frames * long(prm.C);
     uint32_t log2N = 0;
     while ((1u << log2N) < N) ++log2N;
     for (long t0 = 0; t0 < tasks; t0 += slab) {
         const long nt = tasks - t0 < slab ? tasks - t0 : slab;
+        if (phase) {
+            // Phase: prepare -> FFT passes -> complex csf (in the first work buffer the passes leave free) -> map
+            const float2 *csf;
+            if (phase->csfIn == nullptr) {
+                hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
+                                   prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
+                float2 *src = work0, *dst = work1;
+                for (uint32_t s = 0; s < log2N; ++s) {
+                    hipLaunchKernelGGL(genericStage, dim3(gridFor(size_t(nt) * (N / 2))), dim3(256), 0, stream, src, dst, twN, N, s, nt);
+                    float2 *tmp = src; src = dst; dst = tmp;
+                }
+                // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
+                float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
+                hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout);
+                csf = cout;
+            } else {
+                csf = phase->csfIn + size_t(t0) * (size_t(N) + 1);
+            }
+            if (prm.mapped)
+                hipLaunchKernelGGL(genericMapPhase, dim3(gridFor(size_t(nt) * prm.P)), dim3(256), 0, stream, csf, N, prm.P, prm.recs,
+                                   prm.weights, *phase, prm.invSize, nt, prm.mapped + size_t(t0) * 2 * prm.P);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            continue;
+        }
         const float *bins;
         if (prm.binsIn == nullptr) {
             hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,

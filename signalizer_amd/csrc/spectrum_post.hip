@@ -100,6 +100,88 @@ __global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm, co
     emitPixel(prm, chunk, t, pixel, allCombos, carryIn, prm.P, prm.colourTables, prm.slope[pixel], nullptr);
 }
 
+// ---- SpectrumChannels::Phase (mapAndTransformDFTFilters, TransformDSP.inl:1393-1432) --------------------------------------
+// mapped plane 0 = magnitude, plane 1 = cancellation.  state / lines hold (magnitude, phase) where the other modes hold
+// (left, right).  The magnitude is the usual peak decay, the phase a one-pole smoother  s = p + pole^0.3 (s - p)  of
+// p = cancellation * mag (multiplied again for every graph: quirk Q7) -- a linear fp32 recurrence whose rounding depends on
+// the order, so this kernel walks the frames sequentially: one thread per (pair, pixel), magnitudes fetched 8 frames ahead.
+__global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams prm, float *work /*[frames][C][P] main-graph dB*/)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(prm.C) * prm.P) return;
+    const uint32_t pair = uint32_t(gid / prm.P), pixel = uint32_t(gid - size_t(pair) * prm.P);
+    const size_t perFrame = size_t(prm.C) * 2 * prm.P;
+    const float *src = prm.mapped + size_t(pair) * 2 * prm.P + pixel;
+    const float slope = prm.slope[pixel];
+    float sm[G], sp[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        sm[k] = prm.stateIn ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 0] : 0.f;
+        sp[k] = prm.stateIn ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 1] : 0.f;
+    }
+    for (long f0 = 0; f0 < prm.frames; f0 += kMaxChunk) {
+        float m[kMaxChunk], c[kMaxChunk];
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) {
+            const long f = f0 + i < prm.frames ? f0 + i : prm.frames - 1;
+            m[i] = src[size_t(f) * perFrame];
+            c[i] = src[size_t(f) * perFrame + prm.P];
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) {
+            const long f = f0 + i;
+            if (f >= prm.frames) break;
+            const float mag = m[i] * 0.5f;                          // mag *= consts::half, :1407
+            float phase = c[i];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                sm[k] = sm[k] * prm.sc.pole[k];
+                if (mag > sm[k]) sm[k] = mag;
+                phase = phase * mag;                                // inside the graph loop (Q7)
+                sp[k] = phase + prm.sc.phasePole[k] * (sp[k] - phase);
+                const float rm = dbMap(slope, sm[k], prm.sc);
+                if (prm.lines) {
+                    float *l = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
+                    l[0] = rm;
+                    l[1] = dbMap(slope, sp[k], prm.sc);
+                }
+                if (k == 0) work[(size_t(f) * prm.C + pair) * prm.P + pixel] = rm;
+            }
+        }
+    }
+    if (prm.state) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 0] = sm[k];
+            prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 1] = sp[k];
+        }
+    }
+}
+
+// colour columns from the main graph's dB magnitudes: one thread per (frame, pixel), pairs blended in order
+__global__ void __launch_bounds__(256) decayPhaseColourKernel(const DecayParams prm, const float *work)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(prm.frames) * prm.P) return;
+    const long f = long(gid / prm.P);
+    const uint32_t pixel = uint32_t(gid - size_t(f) * prm.P);
+    float cb[3] = {0.f, 0.f, 0.f};
+    for (uint32_t pair = 0; pair < prm.C; ++pair)
+        blendColour(cb, work[(size_t(f) * prm.C + pair) * prm.P + pixel], prm.colourTables + size_t(pair) * NC * 3, prm.sc);
+    reinterpret_cast<uchar4 *>(prm.rgba)[gid] = toRgba8(cb);
+}
+
+hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t stream)
+{
+    const size_t n1 = size_t(prm.C) * prm.P;
+    hipLaunchKernelGGL(decayPhaseScanKernel, dim3(unsigned((n1 + 255) / 256)), dim3(256), 0, stream, prm, work);
+    if (prm.rgba) {
+        const size_t n2 = size_t(prm.frames) * prm.P;
+        hipLaunchKernelGGL(decayPhaseColourKernel, dim3(unsigned((n2 + 255) / 256)), dim3(256), 0, stream, prm, work);
+    }
+    return hipGetLastError();
+}
+
 // carry-in state of rank `rank` from every rank's zero-carry end state (see sgz.h, sgz_decay_fold_carry)
 struct FoldFrames { long long f[64]; };
 __global__ void __launch_bounds__(256)

@@ -239,6 +239,4 @@ def test_end_to_end_generic_sizes(gpu, oracle, W, hop, pairs, P):
 
 def test_unsupported_and_errors(gpu):
     with pytest.raises(api.SgzError):
-        api.Plan(config.spectrum_config(channel_mode=config.CH_PHASE))
-    with pytest.raises(api.SgzError):
         api.Plan(config.spectrum_config(axis_points=1))

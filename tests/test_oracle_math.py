@@ -210,3 +210,36 @@ def test_spectrogram_frame_count_and_edge_cases(oracle):
     cfg = config.spectrum_config(window_size=64, hop=16, axis_points=8, colours=[(3, 2, 1)] + config.DEFAULT_COLOURS[1:])
     r = po.spectrogram(po.params_from_dict(cfg), np.zeros((2, 128), np.float32))
     assert r["frames"] == 5 and (r["rgba"][..., :3] == 0).all()      # I = clipDB < 0 -> pixel skipped -> 0
+
+
+@pytest.mark.parametrize("interp", [config.INTERP_NONE, config.INTERP_LINEAR, config.INTERP_LANCZOS])
+def test_KA14_phase_mode_cancellation(oracle, interp):
+    """Phase mode (TransformDSP.inl:643-853): wsp[2x+1] = 1 - |L+R| / (|L|+|R|) per pixel.  Identical channels cancel
+    nothing (0), opposite channels cancel completely (1), and the magnitude plane is |L| + |R| either way."""
+    po = oracle
+    cfg = config.spectrum_config(window_size=1024, hop=1024, channel_mode=config.CH_PHASE, bin_interp=interp, axis_points=200)
+    p = po.params_from_dict(cfg)
+    rng = np.random.default_rng(3)
+    L = rng.uniform(-1, 1, 1024).astype(np.float32)
+    _, _, same = po.frame_bins(p, L, L)
+    _, _, opp = po.frame_bins(p, L, -L)
+    P = 200
+    ms, cs = same[:P].real, same[:P].imag
+    mo, co = opp[:P].real, opp[:P].imag
+    # (interpolating at pos and at fl(N - pos) does not sample exactly mirrored points: ~1e-4 of residue in the filtered modes)
+    tol = 2e-6 if interp == config.INTERP_NONE else 1e-3
+    assert np.abs(cs).max() < tol and np.abs(co - 1).max() < tol
+    # (the few pixels whose taps straddle the lazily normalised / still complex boundary differ, Q6)
+    close = np.abs(ms - mo) <= 1e-5 * np.abs(ms) + 1e-7
+    assert close.mean() >= 0.9 and np.allclose(ms, mo, rtol=0.2) and ms.max() > 0
+    # the filters: magnitude halves (mag *= 0.5), the smoothed phase starts from 0 towards cancellation * mag (Q7: * mag again
+    # for the second graph)
+    st = np.zeros((2, P), np.complex64)
+    res = po.filters(p, opp, st)
+    mag = (mo * np.float32(0.5)).astype(np.float32)
+    assert np.array_equal(st[0].real, mag) and np.array_equal(st[1].real, mag)
+    pf = np.float32(np.float32(cfg["pole"][0]) ** np.float32(0.3))
+    ph0 = (co * mag).astype(np.float32)
+    want0 = (ph0 + pf * (np.float32(0) - ph0)).astype(np.float32)
+    assert np.allclose(st[0].imag, want0, rtol=1e-6, atol=1e-12)
+    assert res.shape == (2, P)
