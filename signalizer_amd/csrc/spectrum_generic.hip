@@ -2,17 +2,18 @@
 // kernel of spectrum_fft.hip): the same stages as separate HBM-resident kernels.  gfx950 only.
 //
 //   genericPrepare : prepareTransform (Source/Spectrum/TransformDSP.inl:39-231)   audio x window -> complex [tasks][N]
-//   genericStage   : one radix-2 Stockham (autosort) pass of the forward DFT; log2 N launches, ping-pong in HBM
+//   genericStage   : one radix-16 (first pass: 2/4/8 if needed) Stockham autosort pass of the forward DFT, ping-pong in HBM
 //                    (doTransform, :487-502 -- natural order, unnormalised)
 //   genericBins    : two-for-one split + DC/Nyquist fix-ups + |.|  (:858-869 ; mono :553-560)  -> csf magnitudes [N+1]
 //   genericMap     : pixel mapping from HBM-resident csf (:565-639, :871-985), same PixelRec table as the fused kernel
 //
-// This path moves ~(2 log2 N + 6) * N * 8 bytes per frame-pair through HBM/L2 instead of the fused kernel's
+// This path moves ~(2 log16 N + 6) * N * 8 bytes per frame-pair through HBM/L2 instead of the fused kernel's
 // 2*W*4: it exists for completeness (every window size the reference accepts works, e.g. BASELINE cfg5's
 // N = 65536), not for speed; fusing N = 2 R^3 is listed under "next" in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fft_common.hpp"
 #include "kernels.hpp"
 
 namespace sgz {
@@ -44,26 +45,45 @@ genericPrepare(const float *planar, size_t chStride, uint32_t hop, uint32_t W, u
     out[gid] = make_float2(xr, xi);
 }
 
-// Stockham autosort radix-2 DIF pass `s` (s = 0 .. log2N-1):  l = N >> (s+1), m = 1 << s
-//   y[k + 2 j m]     =  x[k + j m] + x[k + j m + l m]
-//   y[k + 2 j m + m] = (x[k + j m] - x[k + j m + l m]) * W_{2l}^j ,   W_{2l}^j = W_N^{j << s}
+// Stockham autosort radix-RX DIF pass (RX = 2, 4, 8 or 16).  Before the pass the transform is N = RX * l * m with m the
+// product of the earlier radices:   for j < l, k < m:
+//   y[k + (RX j + q) m] = W_{RX l}^{j q} * sum_t x[k + j m + t l m] W_RX^{t q},   q < RX
+// One thread per (j, k): RX strided loads (coalesced across threads), the RX-point DIF in registers (fft_common.hpp), one
+// twiddle per output from the W_N table (W_{RX l}^{j q} = W_N^{j q m}; the table holds i < N/2, W_N^{i + N/2} = -W_N^i).
+// Radix 16 moves the data through HBM/L2 log16 N times instead of log2 N.
+template <int RX>
 __global__ void __launch_bounds__(256)
-genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, uint32_t N, uint32_t s, long ntasks)
+genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, uint32_t N, uint32_t m, long ntasks)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const uint32_t half = N >> 1;
-    if (gid >= size_t(ntasks) * half) return;
-    const long t = long(gid / half);
-    const uint32_t b = uint32_t(gid - size_t(t) * half);          // butterfly index = j * m + k
-    const uint32_t m = 1u << s;
-    const uint32_t k = b & (m - 1), j = b >> s;
+    const uint32_t per = N / RX;                                  // butterflies per transform = l * m
+    if (gid >= size_t(ntasks) * per) return;
+    const long t = long(gid / per);
+    const uint32_t b = uint32_t(gid - size_t(t) * per);           // j * m + k
+    const uint32_t j = b / m, k = b - j * m;
     const float2 *xi = x + size_t(t) * N;
     float2 *yo = y + size_t(t) * N;
-    const float2 c0 = xi[b], c1 = xi[b + half];                   // k + j m  and  k + j m + l m  (l m = N/2)
-    const float2 w = twN[size_t(j) << s];
-    const float dr = c0.x - c1.x, di = c0.y - c1.y;
-    yo[k + 2 * j * m] = make_float2(c0.x + c1.x, c0.y + c1.y);
-    yo[k + 2 * j * m + m] = make_float2(dr * w.x - di * w.y, dr * w.y + di * w.x);
+    float re[RX], im[RX];
+#pragma unroll
+    for (int tt = 0; tt < RX; ++tt) { const float2 v = xi[b + size_t(tt) * per]; re[tt] = v.x; im[tt] = v.y; }
+    dif<float, RX, RX, 0>(re, im);                                // output q at register brev(q)
+    constexpr int LRX = RX == 16 ? 4 : (RX == 8 ? 3 : (RX == 4 ? 2 : 1));
+#pragma unroll
+    for (int q = 0; q < RX; ++q) {
+        const int r = brev(q, LRX);
+        float vr = re[r], vi = im[r];
+        if (q > 0) {
+            uint32_t idx = uint32_t((uint64_t(j) * uint32_t(q) * m) % N);     // exponent of W_N
+            float sgn = 1.f;
+            if (idx >= N / 2) { idx -= N / 2; sgn = -1.f; }
+            const float2 w = twN[idx];
+            const float wr = sgn * w.x, wi = sgn * w.y;
+            const float tr = vr * wr - vi * wi;
+            vi = vr * wi + vi * wr;
+            vr = tr;
+        }
+        yo[k + (size_t(RX) * j + q) * m] = make_float2(vr, vi);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -98,44 +118,63 @@ genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long nta
     bins[gid] = out;
 }
 
-// one thread per (task, side, pixel); exact fp32 order of the reference (contraction off)
+// 16 lanes per (task, side, pixel); exact fp32 order of the reference (contraction off).  An interpolated pixel is lane 0's
+// sequential tap sum.  An arg-max pixel's bin run (1 .. several hundred bins at large N) is scanned 16 bins at a time with
+// coalesced loads; every lane keeps the first strictly greater |X|^2 of its own subsequence and the lanes are merged with
+// "larger square, then smaller scan offset" -- which is the reference's "first strictly greater in scan order".
+constexpr int kMapLanes = 16;
+
 __global__ void __launch_bounds__(256)
 genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const PixelRec *recs, const float *weights,
            float invSize, long ntasks, float *mapped /*[ntasks][sides][P]*/)
 {
 #pragma clang fp contract(off)
     const uint32_t total = sides * P;
-    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= size_t(ntasks) * total) return;
+    const size_t gid = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) / kMapLanes;
+    const int lane = int(threadIdx.x) & (kMapLanes - 1);
+    if (gid >= size_t(ntasks) * total) return;                   // whole 16-lane groups leave together
     const long t = long(gid / total);
     const uint32_t idx = uint32_t(gid - size_t(t) * total);
     const float *M = bins + size_t(t) * (size_t(N) + 1);
     const PixelRec rec = recs[idx];
     const int side = idx >= P ? 1 : 0;
-    float val;
+    float val = 0.f;
     if ((rec.kind & 1) == 0) {
-        float acc = 0.f;
-        int k = rec.a;
-        for (int i = 0; i < rec.b; ++i) {
-            const float prod = M[k] * weights[rec.c + i];
-            acc = acc + prod;
-            k = (k == int(N)) ? 0 : k + 1;
+        if (lane == 0) {
+            float acc = 0.f;
+            int k = rec.a;
+            for (int i = 0; i < rec.b; ++i) {
+                const float prod = M[k] * weights[rec.c + i];
+                acc = acc + prod;
+                k = (k == int(N)) ? 0 : k + 1;
+            }
+            val = invSize * acc;
         }
-        val = invSize * acc;
     } else {
         float best = 0.f;
-        int arg = rec.c;
-        for (int i = 0; i < rec.b; ++i) {
+        int bestOff = 0x7fffffff;                                 // scan offset of this lane's winner (none yet)
+        for (int i = lane; i < rec.b; i += kMapLanes) {
             const int off = rec.a + i;
             const int k = side ? (int(N) - off) : off;
             const float m = M[k];
             const float sq = m * m + 0.f;
-            if (sq > best) { best = sq; arg = k; }
+            if (sq > best) { best = sq; bestOff = off; }
         }
-        val = invSize * M[arg];
+#pragma unroll
+        for (int d = 1; d < kMapLanes; d <<= 1) {
+            const float ob = __shfl_xor(best, d, kMapLanes);
+            const int oo = __shfl_xor(bestOff, d, kMapLanes);
+            if (ob > best || (ob == best && oo < bestOff)) { best = ob; bestOff = oo; }
+        }
+        if (lane == 0) {
+            const int arg = bestOff == 0x7fffffff ? rec.c : (side ? int(N) - bestOff : bestOff);   // nothing > 0: the run's `bin`
+            val = invSize * M[arg];
+        }
     }
-    const float sq = val * val + 0.f;
-    mapped[gid] = __builtin_sqrtf(sq);
+    if (lane == 0) {
+        const float sq = val * val + 0.f;
+        mapped[gid] = __builtin_sqrtf(sq);
+    }
 }
 
 // ---- SpectrumChannels::Phase (TransformDSP.inl:643-853): the bins stay complex ------------------------------------------
@@ -172,18 +211,20 @@ __device__ __forceinline__ float cabsHypot(float2 z)
     return float(sqrt(x * x + y * y));
 }
 
-// one thread per (task, pixel): wsp[2x] = magnitude -> plane 0, wsp[2x+1] = cancellation measure -> plane 1
+// 16 lanes per (task, pixel) (see genericMap): wsp[2x] = magnitude -> plane 0, wsp[2x+1] = cancellation measure -> plane 1
 __global__ void __launch_bounds__(256)
 genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *recs, const float *weights, PhaseTables ph,
                 float invSize, long ntasks, float *mapped /*[ntasks][2][P]*/)
 {
 #pragma clang fp contract(off)
-    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t gid = (size_t(blockIdx.x) * blockDim.x + threadIdx.x) / kMapLanes;
+    const int lane = int(threadIdx.x) & (kMapLanes - 1);
     if (gid >= size_t(ntasks) * P) return;
     const long t = long(gid / P);
     const uint32_t x = uint32_t(gid - size_t(t) * P);
     const float2 *csf = csfAll + size_t(t) * (size_t(N) + 1);
     const uint32_t type = ph.type[x];
+    if (type != 1u && lane != 0) return;                          // interpolated pixels: lane 0 alone (sequential tap sums)
     // value of csf[j] once bins below `norm` (and their mirrors) have been replaced by their magnitudes
     auto normalised = [&](int j, uint32_t norm) {
         const float2 v = csf[j];
@@ -221,14 +262,22 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
     } else {
         const PixelRec rec = recs[x];
         float maxValue = 0.f;
-        int maxBin = rec.c;                                           // 0
-        for (int i = 0; i < rec.b; ++i) {
+        int maxBin = 0x7fffffff;
+        for (int i = lane; i < rec.b; i += kMapLanes) {
             const int off = rec.a + i;
             const float2 l = normalised(off, ph.normFinal), r = normalised(int(N) - off, ph.normFinal);
             const float a = l.x * l.x + l.y * l.y, b = r.x * r.x + r.y * r.y;     // Math::square(complex) = |z|^2
             const float newMag = a < b ? b : a;                        // std::max
             if (newMag > maxValue) { maxValue = newMag; maxBin = off; }
         }
+#pragma unroll
+        for (int d = 1; d < kMapLanes; d <<= 1) {                      // larger value, then smaller offset = first strictly greater
+            const float ov = __shfl_xor(maxValue, d, kMapLanes);
+            const int ob = __shfl_xor(maxBin, d, kMapLanes);
+            if (ov > maxValue || (ov == maxValue && ob < maxBin)) { maxValue = ov; maxBin = ob; }
+        }
+        if (lane != 0) return;
+        if (maxBin == 0x7fffffff) maxBin = rec.c;                      // 0 (:813)
         const float2 leftMax = normalised(maxBin, ph.normFinal), rightMax = normalised(int(N) - maxBin, ph.normFinal);
         const float2 sum = make_float2(leftMax.x + rightMax.x, leftMax.y + rightMax.y);
         const float interference = invSize * cabsHypot(sum);
@@ -243,6 +292,26 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
 }
 
 static inline unsigned gridFor(size_t total) { return unsigned((total + 255) / 256); }
+
+// all passes of the forward FFT, ping-ponging between the two work buffers; on return `src` holds the spectrum.
+// Radix 16 passes, preceded by one pass of radix 2, 4 or 8 when log2 N is not a multiple of 4.
+static void runStages(float2 *&src, float2 *&dst, const float2 *twN, uint32_t N, uint32_t log2N, long nt, hipStream_t stream)
+{
+    uint32_t m = 1, left = log2N;
+    auto pass = [&](int lr) {
+        const size_t threads = size_t(nt) * (N >> lr);
+        switch (lr) {
+        case 1: hipLaunchKernelGGL(genericStage<2>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
+        case 2: hipLaunchKernelGGL(genericStage<4>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
+        case 3: hipLaunchKernelGGL(genericStage<8>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
+        default: hipLaunchKernelGGL(genericStage<16>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
+        }
+        m <<= lr; left -= uint32_t(lr);
+        float2 *tmp = src; src = dst; dst = tmp;
+    };
+    if (left % 4) pass(int(left % 4));
+    while (left) pass(4);
+}
 
 // Runs the generic path for tasks [0, ntasks) in slabs that fit the work buffers (work0/work1: complex [slab][N]).
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
@@ -260,10 +329,7 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
                 hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
                                    prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
                 float2 *src = work0, *dst = work1;
-                for (uint32_t s = 0; s < log2N; ++s) {
-                    hipLaunchKernelGGL(genericStage, dim3(gridFor(size_t(nt) * (N / 2))), dim3(256), 0, stream, src, dst, twN, N, s, nt);
-                    float2 *tmp = src; src = dst; dst = tmp;
-                }
+                runStages(src, dst, twN, N, log2N, nt, stream);
                 // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
                 float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
                 hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout);
@@ -272,7 +338,7 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
                 csf = phase->csfIn + size_t(t0) * (size_t(N) + 1);
             }
             if (prm.mapped)
-                hipLaunchKernelGGL(genericMapPhase, dim3(gridFor(size_t(nt) * prm.P)), dim3(256), 0, stream, csf, N, prm.P, prm.recs,
+                hipLaunchKernelGGL(genericMapPhase, dim3(gridFor(size_t(nt) * prm.P * kMapLanes)), dim3(256), 0, stream, csf, N, prm.P, prm.recs,
                                    prm.weights, *phase, prm.invSize, nt, prm.mapped + size_t(t0) * 2 * prm.P);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -283,10 +349,7 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
                                prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
             float2 *src = work0, *dst = work1;
-            for (uint32_t s = 0; s < log2N; ++s) {
-                hipLaunchKernelGGL(genericStage, dim3(gridFor(size_t(nt) * (N / 2))), dim3(256), 0, stream, src, dst, twN, N, s, nt);
-                float2 *tmp = src; src = dst; dst = tmp;
-            }
+            runStages(src, dst, twN, N, log2N, nt, stream);
             float *bout = prm.binsOut ? prm.binsOut + size_t(t0) * (size_t(N) + 1) : binsWork;
             hipLaunchKernelGGL(genericBins, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, prm.sides,
                                prm.mode, nt, bout);
@@ -295,7 +358,7 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             bins = prm.binsIn + size_t(t0) * (size_t(N) + 1);
         }
         if (prm.mapped)
-            hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,
+            hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,
                                prm.recs, prm.weights, prm.invSize, nt, prm.mapped + size_t(t0) * prm.sides * prm.P);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
