@@ -26,13 +26,14 @@ def _pop_all(h, P, want, timeout=10.0):
     return cols
 
 
-@pytest.mark.parametrize("block", [256, 1024, 480])
-def test_push_pop_matches_offline(gpu, oracle, block):
+@pytest.mark.parametrize("block,mode,W", [(256, config.CH_SEPARATE, 4096), (1024, config.CH_SEPARATE, 4096), (480, config.CH_SEPARATE, 4096),
+                                          (512, config.CH_PHASE, 4096), (512, config.CH_MIDSIDE, 2048)])
+def test_push_pop_matches_offline(gpu, oracle, block, mode, W):
     """history starts as W samples of silence; a column fires every `hop` samples.  The stream of columns must equal
     the offline render of [W zeros ++ audio] (and therefore the oracle, within the end-to-end tolerance)."""
     po = oracle
-    cfg = config.spectrum_config(window_size=4096, hop=1024, axis_points=300)
-    W, hop, P = 4096, 1024, 300
+    cfg = config.spectrum_config(window_size=W, hop=1024, axis_points=300, channel_mode=mode)
+    hop, P = 1024, 300
     nblocks = (9 * hop) // block
     S = nblocks * block
     x = synth.gen(8, 48000, S, 2)
@@ -53,7 +54,8 @@ def test_push_pop_matches_offline(gpu, oracle, block):
         ref = po.spectrogram(po.params_from_dict(cfg), padded)["rgba"][:frames]
         got = np.stack(cols)
         diff = np.abs(got.astype(int) - ref.astype(int))
-        assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3
+        tol = (2, 2e-2) if mode == config.CH_PHASE else (1, 5e-3)       # Phase: the cancellation ratio amplifies FFT rounding
+        assert diff.max() <= tol[0] and (diff > 0).mean() <= tol[1]
         # line results of the last frame
         line = np.zeros((P, 2), np.float32)
         api.check(api.lib().sgz_spectrum_line_results(h, 0, 0, line.ctypes.data_as(C.c_void_p)))
