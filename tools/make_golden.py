@@ -34,6 +34,12 @@ def main():
     r = po.spectrogram(po.params_from_dict(cfg), x, want_lines=True)
     np.savez_compressed(os.path.join(OUT, "cfg2_8frames.npz"), seed=2, nsamples=S, rgba=r["rgba"],
                         lines_main=r["lines"][:, 0, 0, :])
+    # Phase mode (TransformDSP.inl:643-853): 6 frames of 4096 points, Lanczos bins, both graphs' (magnitude, phase) lines
+    cfgp = config.spectrum_config(window_size=4096, hop=1024, channel_mode=config.CH_PHASE, axis_points=256)
+    S = 4096 + 5 * 1024
+    r = po.spectrogram(po.params_from_dict(cfgp), synth.gen(15, 48000, S, 2), want_lines=True, want_mapped=True)
+    np.savez_compressed(os.path.join(OUT, "phase_6frames.npz"), seed=15, nsamples=S, rgba=r["rgba"], lines=r["lines"],
+                        mapped=r["mapped"][:, :, :256])
     # colour map cases (KA8): intensities around every branch, two-pair additive blend
     cfgc = config.spectrum_config(num_pairs=2, axis_points=16, ratios=(0.1, 0.3, 0.2, 0.25, 0.15))
     p = po.params_from_dict(cfgc)
