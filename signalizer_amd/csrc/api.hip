@@ -32,8 +32,8 @@ sgz_status hipFail(hipError_t e, const char *what)
 Plan::~Plan()
 {
     // best effort; ignore errors on teardown
-    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_phaseType, d_phaseNorm, d_phaseWork};
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_phaseType, d_phaseNorm, d_phaseWork};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -63,6 +63,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.tw1odd, &p.d_tw1odd)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
     if ((st = uploadVec(p.phaseType, &p.d_phaseType)) != SGZ_OK) return st;
@@ -107,6 +108,7 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.window = p.d_window;
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
+    prm.tw1odd = reinterpret_cast<const float2 *>(p.d_tw1odd);
     prm.recs = p.d_recs; prm.weights = p.d_weights;
     prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
@@ -123,6 +125,26 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
+    if (p.halves && d_binsIn == nullptr) {
+        // N = 2 R^3: half-frame workgroups -> csf magnitudes in HBM (a slab of tasks at a time, <= 256 MiB) -> genericMap
+        const size_t perTask = size_t(p.N) + 1;
+        long slab = std::min<long>(long(std::max<size_t>(1, (size_t(64) << 20) / perTask)), tasks);
+        if (d_binsOut == nullptr && p.binsSlab < size_t(slab)) {
+            if (p.d_halfBins) { (void)hipFree(p.d_halfBins); p.d_halfBins = nullptr; }
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_halfBins), size_t(slab) * perTask * sizeof(float)));
+            p.binsSlab = size_t(slab);
+        }
+        for (long t0 = 0; t0 < tasks; t0 += slab) {
+            const long nt = std::min(slab, tasks - t0);
+            float *bins = d_binsOut ? d_binsOut + size_t(t0) * perTask : p.d_halfBins;
+            prm.taskBase = t0;
+            prm.binsOut = bins;
+            SGZ_HIP(launchStftHalves(prm, p.N, int(2 * nt), stream));
+            if (d_mapped)
+                SGZ_HIP(launchGenericMap(prm, p.N, bins, nt, d_mapped + size_t(t0) * p.sides * p.P, stream));
+        }
+        return SGZ_OK;
+    }
     if (!p.fused) {
         // generic multi-kernel path (any power-of-two N): work buffers for a slab of tasks, <= 256 MiB each
         const size_t perTask = size_t(p.N) * 2;                                  // floats of one complex buffer

@@ -1,4 +1,4 @@
-// fft_common.hpp -- device helpers shared by the fused FFT kernels (spectrum_fft.hip, spectrum_half.hip).
+// fft_common.hpp -- device helpers shared by the fused FFT kernels (spectrum_fft.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,6 +18,23 @@ __host__ __device__ constexpr float cos32(int j)
     return v[j];
 }
 __host__ __device__ constexpr float sin32(int j) { return j <= 8 ? cos32(8 - j) : cos32(j - 8); }
+
+// W_64^j = cos64(j) - i sin64(j), j = 0..32: the pre-rotation of the odd half of a 2 R^3-point frame (stft_body.hpp, HALF = 1)
+__host__ __device__ constexpr float cos64(int j)
+{
+    constexpr float v[33] = {1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f,
+                             0.92387953251128675613f, 0.88192126434835502971f, 0.83146961230254523708f,
+                             0.77301045336273696081f, 0.70710678118654752440f, 0.63439328416364549822f,
+                             0.55557023301960222474f, 0.47139673682599764856f, 0.38268343236508977173f,
+                             0.29028467725446236764f, 0.19509032201612826785f, 0.098017140329560601994f, 0.0f,
+                             -0.098017140329560601994f, -0.19509032201612826785f, -0.29028467725446236764f,
+                             -0.38268343236508977173f, -0.47139673682599764856f, -0.55557023301960222474f,
+                             -0.63439328416364549822f, -0.70710678118654752440f, -0.77301045336273696081f,
+                             -0.83146961230254523708f, -0.88192126434835502971f, -0.92387953251128675613f,
+                             -0.95694033573220886494f, -0.98078528040323044913f, -0.99518472667219688624f, -1.0f};
+    return v[j];
+}
+__host__ __device__ constexpr float sin64(int j) { return j <= 16 ? cos64(16 - j) : cos64(j - 16); }
 
 __host__ __device__ constexpr int brev(int x, int bits)
 {
@@ -144,10 +161,12 @@ __device__ __forceinline__ T ldg(const T *base, uint32_t byteOff)
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byteOff);
 }
 
-template <int LR>
+// ODD (the odd half of a 2 R^3-point frame): every product carries the extra factor U = W_{2N}^{x}; the table has one
+// more row, B_0 = U, and B_a = W^{x 4a} U.
+template <int LR, bool ODD = false>
 struct TwFactors {
     static constexpr int R = 1 << LR;
-    static constexpr int NB = R / 4 - 1;
+    static constexpr int NB = R / 4 - 1 + (ODD ? 1 : 0);
     float2 a[3];
     float2 b[NB];
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int rowBytes)
@@ -169,12 +188,13 @@ struct TwFactors {
     __device__ __forceinline__ void apply(v2 (&c)[R]) const
     {
 #pragma unroll
-        for (int q = 1; q < R; ++q) {
+        for (int q = ODD ? 0 : 1; q < R; ++q) {
             const int qa = q >> 2, qb = q & 3;
+            const int ib = ODD ? qa : qa - 1;                          // row of B_qa
             v2 w;
-            if (qa == 0) w = v2{a[qb - 1].x, a[qb - 1].y};
-            else if (qb == 0) w = v2{b[qa - 1].x, b[qa - 1].y};
-            else w = cmul(v2{b[qa - 1].x, b[qa - 1].y}, v2{a[qb - 1].x, a[qb - 1].y});
+            if (!ODD && qa == 0) w = v2{a[qb - 1].x, a[qb - 1].y};
+            else if (qb == 0) w = v2{b[ib].x, b[ib].y};
+            else w = cmul(v2{b[ib].x, b[ib].y}, v2{a[qb - 1].x, a[qb - 1].y});
             const int i = brev(q, LR);
             c[i] = cmul(c[i], w);
         }

@@ -16,6 +16,8 @@ struct StftParams {
     const float *window;      // [N]
     const float2 *tw1;        // [R][T]
     const float2 *tw2;        // [R][R]
+    const float2 *tw1odd;     // halves path (N = 2 R^3): pass-1 twiddles of the odd half, W_N^{t (2q+1)} factorised
+    long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]
     const float *weights;
     const MaxItem *items;     // balanced arg-max work list (null: serial per-pixel scan)
@@ -31,6 +33,10 @@ struct StftParams {
 };
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+// N = 2 R^3 (8192, 65536): two workgroups per (frame, pair) write the csf magnitudes of tasks [taskBase, taskBase + grid / 2)
+// to prm.binsOut ([task][N + 1]); launchGenericMap turns them into pixels
+hipError_t launchStftHalves(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream);
 // SpectrumChannels::Phase tables (plan.cpp buildPhaseRecords); null for the other modes
 struct PhaseTables {
     const uint32_t *type;     // [P] 0 interpolated, 1 arg-max run, 2 interpolated magnitude only

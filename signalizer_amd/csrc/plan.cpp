@@ -339,28 +339,47 @@ static void buildTwiddles(Plan &p)
     const double kTwoPi = 6.28318530717958647692;
     int R = 0;
     if (p.N == 32768) R = 32; else if (p.N == 4096) R = 16;
-    if (p.cfg.channel_mode == SGZ_CH_PHASE) R = 0;      // Phase keeps complex bins: generic (HBM-resident) path, spectrum_generic.hip
+    // N = 2 R^3: two half-frame workgroups (decimation in frequency) + the generic map kernel
+    int halfR = 0;
+    if (p.N == 65536) halfR = 32; else if (p.N == 8192) halfR = 16;
+    if (p.cfg.channel_mode == SGZ_CH_PHASE) R = halfR = 0;   // Phase keeps complex bins: generic (HBM-resident) path, spectrum_generic.hip
     p.fused = R != 0;
-    if (!R) {   // generic radix-2 Stockham path: one table W_N^i, i < N/2
+    p.halves = halfR != 0;
+    if (!R) {   // generic Stockham path: one table W_N^i, i < N/2 (also behind the halves path's map-from-bins test hook)
         p.twN.resize(size_t(p.N / 2) * 2);
         for (uint32_t i = 0; i < p.N / 2; ++i) {
             const double ang = -kTwoPi * double(i) / double(p.N);
             p.twN[size_t(i) * 2 + 0] = float(std::cos(ang));
             p.twN[size_t(i) * 2 + 1] = float(std::sin(ang));
         }
-        return;
+        if (!halfR) return;
+        R = halfR;
     }
+    const uint32_t fftN = p.halves ? p.N / 2 : p.N;     // size of the in-register transform
     const uint32_t T = uint32_t(R * R);
     const int rows = 3 + R / 4 - 1;
     auto mult = [&](int row) { return row < 3 ? row + 1 : 4 * (row - 3 + 1); };
     p.tw1.resize(size_t(rows) * T * 2);
     for (int row = 0; row < rows; ++row)
         for (uint32_t t = 0; t < T; ++t) {
-            const uint64_t m = (uint64_t(t) * uint64_t(mult(row))) % p.N;
-            const double ang = -kTwoPi * double(m) / double(p.N);
+            const uint64_t m = (uint64_t(t) * uint64_t(mult(row))) % fftN;
+            const double ang = -kTwoPi * double(m) / double(fftN);
             p.tw1[(size_t(row) * T + t) * 2 + 0] = float(std::cos(ang));
             p.tw1[(size_t(row) * T + t) * 2 + 1] = float(std::sin(ang));
         }
+    if (p.halves) {
+        // odd half (TwFactors<LR, true>): rows A_1..A_3 = W_M^{t b}, then B_a U = W_N^{t (8a + 1)}, a = 0..R/4-1  (M = N/2)
+        const int rowsOdd = 3 + R / 4;
+        p.tw1odd.resize(size_t(rowsOdd) * T * 2);
+        for (int row = 0; row < rowsOdd; ++row)
+            for (uint32_t t = 0; t < T; ++t) {
+                const uint64_t m = row < 3 ? (uint64_t(t) * uint64_t(2 * (row + 1))) % p.N
+                                           : (uint64_t(t) * uint64_t(8 * (row - 3) + 1)) % p.N;
+                const double ang = -kTwoPi * double(m) / double(p.N);
+                p.tw1odd[(size_t(row) * T + t) * 2 + 0] = float(std::cos(ang));
+                p.tw1odd[(size_t(row) * T + t) * 2 + 1] = float(std::sin(ang));
+            }
+    }
     p.tw2.resize(size_t(rows) * R * 2);
     for (int row = 0; row < rows; ++row)
         for (int t2 = 0; t2 < R; ++t2) {

@@ -35,6 +35,49 @@ stftMapKernel(const StftParams prm)
     stftMapBody<LR, MIX, FULLW>(prm, lds, blockIdx.x, gridDim.x);
 }
 
+// N = 2 R^3: workgroup b transforms half (b & 1) of task b >> 1 (stft_body.hpp, HALF)
+template <int LR, int MIX, bool FULLW>
+__global__ void __launch_bounds__(1 << (2 * LR))
+stftHalfKernel(const StftParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stftMapBody<LR, MIX, FULLW, 0>(prm, lds, blockIdx.x, gridDim.x);
+    stftMapBody<LR, MIX, FULLW, 1>(prm, lds, blockIdx.x, gridDim.x);
+}
+
+template <int LR>
+static hipError_t launchHalves(const StftParams &prm, int grid, hipStream_t stream)
+{
+    constexpr int R = 1 << LR, T = R * R, N = R * T;
+    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4) * sizeof(float);
+    const bool simple = prm.mode == SGZ_CH_SEPARATE || prm.mode == SGZ_CH_COMPLEX;
+    const bool fullw = prm.W == uint32_t(2 * N);
+    using Kern = void (*)(const StftParams);
+    static const Kern kerns[4] = {&stftHalfKernel<LR, 1, false>, &stftHalfKernel<LR, 1, true>, &stftHalfKernel<LR, 0, false>,
+                                  &stftHalfKernel<LR, 0, true>};
+    const int which = (simple ? 2 : 0) + (fullw ? 1 : 0);
+    static bool attrSet[4] = {false, false, false, false};
+    if (!attrSet[which]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(ldsBytes));
+        if (e != hipSuccess) return e;
+        attrSet[which] = true;
+    }
+    StftParams p2 = prm;
+    p2.items = nullptr;
+    hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
+    return hipGetLastError();
+}
+
+hipError_t launchStftHalves(const StftParams &prm, uint32_t N, int grid, hipStream_t stream)
+{
+    switch (N) {
+    case 65536: return launchHalves<5>(prm, grid, stream);
+    case 8192: return launchHalves<4>(prm, grid, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
 template <int LR>
 static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream)
 {

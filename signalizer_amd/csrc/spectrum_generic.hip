@@ -313,6 +313,13 @@ static void runStages(float2 *&src, float2 *&dst, const float2 *twN, uint32_t N,
     while (left) pass(4);
 }
 
+hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream)
+{
+    hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(ntasks) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P,
+                       prm.sides, prm.recs, prm.weights, prm.invSize, ntasks, mapped);
+    return hipGetLastError();
+}
+
 // Runs the generic path for tasks [0, ntasks) in slabs that fit the work buffers (work0/work1: complex [slab][N]).
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
                          long slab, hipStream_t stream, const PhaseTables *phase)

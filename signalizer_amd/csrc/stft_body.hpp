@@ -292,7 +292,16 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
 // 3R strided dword loads complete in ~7-8.6 k clocks as global loads and in ~13 k as raw buffer loads, so the buffer
 // form (whose out-of-range reads return 0 = the zero padding of prepareTransform, :220-223) is kept for W < N only.
 // bid / nb: index of this workgroup among the nb workgroups of the launch; lds: the dynamic LDS of the launch.
-template <int LR, int MIX, bool FULLW>
+//
+// HALF = 0 / 1: the workgroup transforms one half of a 2N-point frame (N = R^3 here), split by decimation in frequency:
+//     X[2j]   = FFT_N( z[n] + z[n + N] )[j]                 (HALF = 0)
+//     X[2j+1] = FFT_N( (z[n] - z[n + N]) W_2N^n )[j]        (HALF = 1)
+// The even half mirrors like a whole frame (X[2N - 2j] is its own bin N - j).  In the odd half bin j pairs with N-1-j
+// (2N - (2j+1) = 2(N-1-j) + 1): all three digits are complemented, so with q = R-1-s in the upper half-waves the partner is
+// lane L ^ R everywhere and there is no self-mirroring column.  W_2N^n for n = t + T a factors into the constant
+// W_2R^a (a = register, before pass 1) and W_2N^t, which rides on the pass-1 twiddles (TwFactors<LR, true>).  The
+// magnitudes go to HBM (csf of the 2N-point frame, element 2j + HALF); spectrum_generic.hip's genericMap maps them.
+template <int LR, int MIX, bool FULLW, int HALF = -1>
 __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, const long bid, const long nb)
 {
     constexpr int R = 1 << LR;
@@ -303,9 +312,9 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max piece winners (nItems uint2)
     constexpr int TILE = R * (R + 1);
     const int tid = threadIdx.x;
-    const long tasks = prm.frames * long(prm.C);
+    const long tasks = prm.frames * long(prm.C) * (HALF >= 0 ? 2 : 1);
     const int slot = tid >> (LR + 1), half = (tid >> LR) & 1, l = tid & (R - 1);
-    const int q = half ? (slot == 0 ? R / 2 : R - slot) : slot;
+    const int q = half ? (HALF == 1 ? R - 1 - slot : (slot == 0 ? R / 2 : R - slot)) : slot;
     const int ix = half ? R - 1 - l : l;                                // t2 in pass 2, q2 in pass 3
     const bool split = (prm.sides == 2);
     const int mode = prm.mode;
@@ -325,8 +334,12 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         const long per = nbr / 8, extra = nbr % 8;                     // XCD x owns per + (x < extra) workgroups of this round
         task = base + x * per + (x < extra ? x : extra) + i;
     }
+    if (HALF >= 0) {
+        if (int(task & 1) != HALF) return;                             // wave-uniform: the kernel wrapper calls both bodies
+        task >>= 1;
+    }
     MapPixelsBalanced<LR, T> mapper;
-    const bool doMap = balanced && prm.mapped && !(prm.ablate & 16);
+    const bool doMap = HALF < 0 && balanced && prm.mapped && !(prm.ablate & 16);
     SGZ_CLK(0);
     SGZ_WCLK(0);
     if (prm.binsIn == nullptr) {
@@ -334,8 +347,9 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         {
             // ---------------------------------------------------------------- load + window + channel mix
             // strided dword loads; reads past W return 0 = the zero padding of prepareTransform (:220-223)
-            const long frame = task / prm.C;
-            const int pair = int(task - frame * prm.C);
+            const long gtask = task + prm.taskBase;
+            const long frame = gtask / prm.C;
+            const int pair = int(gtask - frame * prm.C);
             const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
             // raw samples land in scalar registers; the (re, im) pairs are formed by the window multiply
             float lv[R], rv[R], w[R];
@@ -361,18 +375,67 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             }
             // prepareTransform channel mixes (TransformDSP.inl:59-216).  (a*l + b*r) * w * s with a, b in {0, +-1},
             // s in {1, 0.5} rounds exactly like the reference's `(l +- r) * w * 0.5f` / `l * w`.
-            if (MIX == 0) {
-#pragma unroll
-                for (int j = 0; j < R; ++j) c[j] = v2{lv[j] * w[j], rv[j] * w[j]};
-            } else {
-                float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 0.f, mixS = 1.f;      // Left
+            float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 0.f, mixS = 1.f;          // Left
+            if (MIX != 0) {
                 if (mode == SGZ_CH_RIGHT) { mixRL = 0.f; mixRR = 1.f; }
                 else if (mode == SGZ_CH_MERGE) { mixRR = 1.f; mixS = 0.5f; }
                 else if (mode == SGZ_CH_SIDE) { mixRR = -1.f; mixS = 0.5f; }
                 else if (mode == SGZ_CH_MIDSIDE) { mixRR = 1.f; mixIL = 1.f; mixIR = -1.f; mixS = 0.5f; }
+            }
+            auto windowed = [&](float lx, float rx, float wx) {
+                if (MIX == 0) return v2{lx * wx, rx * wx};
+                return v2{(mixRL * lx + mixRR * rx) * wx * mixS, (mixIL * lx + mixIR * rx) * wx * mixS};
+            };
 #pragma unroll
-                for (int j = 0; j < R; ++j)
-                    c[j] = v2{(mixRL * lv[j] + mixRR * rv[j]) * w[j] * mixS, (mixIL * lv[j] + mixIR * rv[j]) * w[j] * mixS};
+            for (int j = 0; j < R; ++j) c[j] = windowed(lv[j], rv[j], w[j]);
+            if (HALF >= 0) {
+                // (the empty asm pins each product above the next batch of loads: instruction selection would otherwise
+                // sink the multiplies to their first use, below all 6R loads, and spill the raw samples)
+#pragma unroll
+                for (int j = 0; j < R; ++j) asm volatile("" : "+v"(c[j]));
+                // second half of the 2N-point window, in two batches of R/2 columns (128-VGPR budget): z[n] +- z[n + N]
+#pragma unroll
+                for (int batch = 0; batch < 2; ++batch) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    float l2[R / 2], r2[R / 2], w2[R / 2];
+                    if (FULLW) {
+                        const float *Rp = L + prm.chStride;
+#pragma unroll
+                        for (int jj = 0; jj < R / 2; ++jj) {
+                            const uint32_t off = uint32_t(tid + (batch * (R / 2) + jj) * T + N) * 4u;
+                            l2[jj] = ldg(L, off);
+                            r2[jj] = ldg(Rp, off);
+                            w2[jj] = ldg(prm.window, off);
+                        }
+                    } else {
+                        const __amdgpu_buffer_rsrc_t rsL = makeRsrc(L, prm.W * 4u);
+                        const __amdgpu_buffer_rsrc_t rsR = makeRsrc(L + prm.chStride, prm.W * 4u);
+                        const __amdgpu_buffer_rsrc_t rsW = makeRsrc(prm.window, prm.W * 4u);
+#pragma unroll
+                        for (int jj = 0; jj < R / 2; ++jj) {
+                            const int so = ((batch * (R / 2) + jj) * T + N) * 4;
+                            l2[jj] = bufLoad(rsL, tid * 4, so);
+                            r2[jj] = bufLoad(rsR, tid * 4, so);
+                            w2[jj] = bufLoad(rsW, tid * 4, so);
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < R / 2; ++jj) {
+                        const int j = batch * (R / 2) + jj;
+                        const v2 z = windowed(l2[jj], r2[jj], w2[jj]);
+                        c[j] = HALF ? c[j] - z : c[j] + z;
+                        asm volatile("" : "+v"(c[j]));
+                    }
+                }
+                if (HALF == 1) {
+                    // times W_2R^a (the register part of W_2N^n, n = t + T a)
+#pragma unroll
+                    for (int a = 1; a < R; ++a) {
+                        constexpr int S = 64 / (2 * R);                // index step into the W_64 table
+                        if (a * S == 16) c[a] = v2{c[a].y, -c[a].x};   // times -i
+                        else c[a] = cmulConjK(c[a], v2{cos64(a * S), sin64(a * S)});
+                    }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);          // keep the twiddle loads below the 3R sample loads (128-VGPR budget)
@@ -381,9 +444,9 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
         SGZ_CLK(14);
         if (!(prm.ablate & 32)) {
-            TwFactors<LR> tw;
-            tw.load(prm.tw1, tid, T);
-            tw.apply(c);                                               // times W_N^{t q}
+            TwFactors<LR, HALF == 1> tw;
+            tw.load(HALF == 1 ? prm.tw1odd : prm.tw1, tid, T);
+            tw.apply(c);                                               // times W_N^{t q} (odd half: W_2N^{t (2q+1)})
         }
         SGZ_CLK(1);
         // -------------------------------------------------------------- exchange 1 (workgroup-wide; re then im)
@@ -442,7 +505,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         const int kc = q + R * ix;
         const int base = kc + (kc >> LR);                              // padded LDS address of k = kc
         if (split && !(prm.ablate & 8)) {
-            if (tid == 0) {                                            // column 0 mirrors onto itself: redone below
+            if (HALF != 1 && tid == 0) {                               // column 0 mirrors onto itself: redone below
 #pragma unroll
                 for (int m3 = 0; m3 < R; ++m3) {
                     lds[SCRATCH + 2 * m3] = c[brev(m3, LR)].x;
@@ -452,7 +515,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             // lane holding Z[N - k]: L ^ R, except in slot 0 (q = 0: q2' = R - q2 ; q = R/2: q2' = R-1-q2, same half)
             const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
             int plane = lane ^ R;
-            if (slot == 0) plane = (lane & ~(R - 1)) | (half ? R - 1 - l : ((R - l) & (R - 1)));
+            if (HALF != 1 && slot == 0) plane = (lane & ~(R - 1)) | (half ? R - 1 - l : ((R - l) & (R - 1)));
             plane <<= 2;
             auto partner = [&](float v) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plane, __builtin_bit_cast(int, v)));
@@ -468,7 +531,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                 mag[ib] = 0.5f * __builtin_amdgcn_sqrtf(ub * ub + vb * vb);
             }
         } else {
-            if (tid == 0) { lds[SCRATCH] = c[0].x; lds[SCRATCH + 1] = c[0].y;
+            if (HALF != 1 && tid == 0) { lds[SCRATCH] = c[0].x; lds[SCRATCH + 1] = c[0].y;
                             lds[SCRATCH + R] = c[brev(R / 2, LR)].x; lds[SCRATCH + R + 1] = c[brev(R / 2, LR)].y; }
 #pragma unroll
             for (int m3 = 0; m3 < R; ++m3) {                           // csf[k] = |Z[k]| (TransformDSP.inl:553-560, :993-1002)
@@ -478,14 +541,15 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         }
         SGZ_CLK(6);
         if (doMap) mapper.prefetchTables(prm, tid);                    // im[] is dead: its registers take the map tables
-        if (split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;   // csf[N/2-1] *= 0.5 (quirk Q3, :864)
+        // csf[N/2-1] *= 0.5 (quirk Q3, :864); of a 2N-point frame that bin is the odd half's j = N/2 - 1
+        if (HALF != 0 && split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;
         __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
 #pragma unroll
         for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = mag[brev(m3, LR)];
         // Column 0 (k = T m3, all held by thread 0) mirrors onto itself and DC / Nyquist are special: redone from thread 0's
         // scratch copy by lanes of the SAME wave, after that wave's own stores above (one wave's LDS operations execute in
         // order), so no extra workgroup barrier is needed.
-        if (tid < R / 2) {
+        if (HALF != 1 && tid < R / 2) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -523,6 +587,14 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     }
     SGZ_CLK(7);
 
+    if (HALF >= 0) {
+        // csf of the 2N-point frame: this half owns the elements 2j + HALF (and the even half csf[2N])
+        float *dst = prm.binsOut + size_t(task) * (2 * N + 1);
+#pragma unroll 8
+        for (int k = tid; k < N; k += T) dst[2 * k + HALF] = lds[k + (k >> LR)];
+        if (HALF == 0 && tid == 0) dst[2 * N] = lds[N + (N >> LR)];
+        return;
+    }
     if (prm.binsOut) {
         float *dst = prm.binsOut + size_t(task) * (N + 1);
         for (int k = tid; k <= N; k += T) dst[k] = lds[k + (k >> LR)];

@@ -36,10 +36,13 @@ def _oracle_bins(po, p, x, frames, hop, W):
             R = x[2 * c + 1, f * hop:f * hop + W]
             raw, csf, csp = po.frame_bins(p, L, R)
             out[f, c] = csf.real
+            if p.channel_mode == config.CH_COMPLEX:
+                out[f, c, 0] = np.abs(csf[0])      # Complex keeps csf[0] = 0.5 Z[0] complex (TransformDSP.inl:993); the hook reports |.|
     return out
 
 
-@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2small", "midside", "left", "w3000", "n32", "n1024", "n8192", "n65536", "w100"])
+@pytest.mark.parametrize("cfgname", ["cfg1", "cfg2small", "midside", "left", "w3000", "n32", "n1024", "n8192", "n65536", "w100",
+                                     "n65536pad", "n8192sep", "n65536midside", "n8192pad_left", "n65536complex"])
 def test_bins_tolerance(gpu, oracle, cfgname):
     po = oracle
     cfg = {
@@ -55,6 +58,13 @@ def test_bins_tolerance(gpu, oracle, cfgname):
         "n8192": config.spectrum_config(window_size=8192, hop=2048, channel_mode=config.CH_MERGE),
         "n65536": config.cfg5(pairs=1),
         "w100": config.spectrum_config(window_size=100, hop=50, window_type=config.WIN_TRIANGULAR, axis_points=33),
+        # N = 2 R^3 (two half-frame workgroups, stft_body.hpp HALF): zero-padded windows and every channel-mix family
+        "n65536pad": config.spectrum_config(window_size=40000, hop=9000, sample_rate=96000.0),
+        "n8192sep": config.spectrum_config(window_size=8192, hop=2048),
+        "n65536midside": config.spectrum_config(window_size=65536, hop=16384, channel_mode=config.CH_MIDSIDE,
+                                                window_type=config.WIN_BLACKMAN_HARRIS),
+        "n8192pad_left": config.spectrum_config(window_size=5000, hop=1000, channel_mode=config.CH_LEFT),
+        "n65536complex": config.spectrum_config(window_size=65536, hop=16384, channel_mode=config.CH_COMPLEX),
     }[cfgname]
     W, hop = cfg["window_size"], cfg["hop"]
     frames = 3

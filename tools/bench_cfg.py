@@ -1,5 +1,5 @@
 """frames/s of the whole spectrogram path for other configurations (not the headline metric): cfg1-like N = 4096,
-cfg5-like N = 65536 (generic HBM-resident FFT passes), Phase mode."""
+cfg5 N = 65536 (two half-frame workgroups + map kernel), N = 8192, N = 16384 (generic HBM-resident FFT passes), Phase mode."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,3 +21,6 @@ run("N=4096 stereo (cfg1 sizes), 60 s", config.spectrum_config(window_size=4096,
 run("N=32768 stereo cfg2", config.cfg2(), 60, 48000)
 run("N=32768 stereo, Phase mode", config.spectrum_config(window_size=32768, hop=8192, channel_mode=config.CH_PHASE), 60, 48000)
 run("N=65536, 4 pairs 96 kHz (cfg5 sizes), 10 s", config.cfg5(pairs=4), 10, 96000)
+run("N=65536, 32 pairs 96 kHz (cfg5, one GPU's 20 s chunk)", config.cfg5(pairs=32), 20, 96000)
+run("N=8192 stereo, 60 s", config.spectrum_config(window_size=8192, hop=2048), 60, 48000)
+run("N=16384 stereo (generic passes), 60 s", config.spectrum_config(window_size=16384, hop=4096), 60, 48000)
