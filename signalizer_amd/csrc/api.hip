@@ -33,7 +33,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_phaseType, d_phaseNorm, d_phaseWork};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -64,6 +64,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw1odd, &p.d_tw1odd)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.dcPixels, &p.d_dcPixels)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
     if ((st = uploadVec(p.phaseType, &p.d_phaseType)) != SGZ_OK) return st;
@@ -109,12 +110,23 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.tw1odd = reinterpret_cast<const float2 *>(p.d_tw1odd);
+    prm.dcPixels = p.d_dcPixels; prm.nDcPixels = uint32_t(p.dcPixels.size());
     prm.recs = p.d_recs; prm.weights = p.d_weights;
     prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
     prm.roundSize = uint32_t(numCUs());
     prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
     return prm;
+}
+
+// Complex mode, generic / halves path: csf[0] of every task of a slab
+static sgz_status ensureDcWork(Plan &p, size_t slab)
+{
+    if (p.dcSlab >= slab) return SGZ_OK;
+    if (p.d_dcWork) { (void)hipFree(p.d_dcWork); p.d_dcWork = nullptr; }
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_dcWork), slab * 2 * sizeof(float)));
+    p.dcSlab = slab;
+    return SGZ_OK;
 }
 
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
@@ -126,22 +138,35 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
     if (p.halves && d_binsIn == nullptr) {
-        // N = 2 R^3: half-frame workgroups -> csf magnitudes in HBM (a slab of tasks at a time, <= 256 MiB) -> genericMap
+        // N = 2 R^3: half-frame workgroups -> csf magnitudes in HBM (a slab of tasks at a time) -> mapSideKernel / genericMap
         const size_t perTask = size_t(p.N) + 1;
-        long slab = std::min<long>(long(std::max<size_t>(1, (size_t(64) << 20) / perTask)), tasks);
+        long slab = long(std::max<size_t>(1, (size_t(32) << 20) / perTask));       // 128 MiB of bins: stays close to the last-level cache
+        slab = std::max<long>(1, slab / long(p.C)) * long(p.C);                  // whole frames: the kernel walks a slab pair-major
+        slab = std::min<long>(slab, tasks);
         if (d_binsOut == nullptr && p.binsSlab < size_t(slab)) {
             if (p.d_halfBins) { (void)hipFree(p.d_halfBins); p.d_halfBins = nullptr; }
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_halfBins), size_t(slab) * perTask * sizeof(float)));
             p.binsSlab = size_t(slab);
         }
+        if (prm.nDcPixels) { sgz_status st = ensureDcWork(p, size_t(slab)); if (st != SGZ_OK) return st; prm.dcOut = reinterpret_cast<float2 *>(p.d_dcWork); }
         for (long t0 = 0; t0 < tasks; t0 += slab) {
             const long nt = std::min(slab, tasks - t0);
             float *bins = d_binsOut ? d_binsOut + size_t(t0) * perTask : p.d_halfBins;
             prm.taskBase = t0;
+            prm.frames = nt / long(p.C);
             prm.binsOut = bins;
+            // mapSideKernel reads the two halves' bins as they are produced (two contiguous arrays); the test hook and the
+            // generic map kernel (tall views, Complex) want csf order
+            prm.binsSplit = (d_binsOut == nullptr && p.sideMapOk && mapSidesFit(prm, p.N)) ? 1u : 0u;
             SGZ_HIP(launchStftHalves(prm, p.N, int(2 * nt), stream));
-            if (d_mapped)
-                SGZ_HIP(launchGenericMap(prm, p.N, bins, nt, d_mapped + size_t(t0) * p.sides * p.P, stream));
+            if (d_mapped) {
+                float *out = d_mapped + size_t(t0) * p.sides * p.P;
+                if (prm.binsSplit) SGZ_HIP(launchMapSides(prm, p.N, bins, nt, out, stream));
+                else {
+                    SGZ_HIP(launchGenericMap(prm, p.N, bins, nt, out, stream));
+                    SGZ_HIP(launchComplexDcFix(prm, p.N, bins, prm.dcOut, nt, out, stream));
+                }
+            }
         }
         return SGZ_OK;
     }
@@ -157,6 +182,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_binsWork), size_t(slab) * (size_t(p.N) + 1) * sizeof(float) * (phase ? 2 : 1)));
             p.workSlab = size_t(slab);
         }
+        if (prm.nDcPixels) { sgz_status st = ensureDcWork(p, p.workSlab); if (st != SGZ_OK) return st; prm.dcOut = reinterpret_cast<float2 *>(p.d_dcWork); }
         PhaseTables ph{};
         if (phase) {
             // Phase keeps the bins complex; the float test hooks carry float2 data in this mode (sgz.h, stage hooks)

@@ -17,6 +17,12 @@ struct StftParams {
     const float2 *tw1;        // [R][T]
     const float2 *tw2;        // [R][R]
     const float2 *tw1odd;     // halves path (N = 2 R^3): pass-1 twiddles of the odd half, W_N^{t (2q+1)} factorised
+    // SpectrumChannels::Complex keeps csf[0] = Z[0] / 2 complex (TransformDSP.inl:993): the pixels whose taps or arg-max run
+    // touch bin 0 (plan.cpp dcPixels) are redone with the complex value after the magnitude-only mapping
+    const uint32_t *dcPixels;
+    uint32_t nDcPixels;
+    float2 *dcOut;            // generic / halves path: csf[0] of every task of the launch (the fused kernel keeps it in LDS), or null
+    uint32_t binsSplit;       // halves path: binsOut holds [even bins 0..N/2 | odd bins] per task (launchMapSides) instead of csf order
     long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]
     const float *weights;
@@ -36,6 +42,13 @@ hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_
 // N = 2 R^3 (8192, 65536): two workgroups per (frame, pair) write the csf magnitudes of tasks [taskBase, taskBase + grid / 2)
 // to prm.binsOut ([task][N + 1]); launchGenericMap turns them into pixels
 hipError_t launchStftHalves(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+// LDS-staged map of the halves path's csf (needs Plan::sideMapOk, binsSplit layout, and mapSidesFit: the arg-max pieces of a
+// side fit in LDS beside its N/2 + 48 floats)
+bool mapSidesFit(const StftParams &prm, uint32_t N);
+hipError_t launchMapSides(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream);
+// Complex mode, after launchGenericMap: redo prm.dcPixels of every task with the complex csf[0] in dc[task]
+hipError_t launchComplexDcFix(const StftParams &prm, uint32_t N, const float *bins, const float2 *dc, long ntasks, float *mapped,
+                              hipStream_t stream);
 hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream);
 // SpectrumChannels::Phase tables (plan.cpp buildPhaseRecords); null for the other modes
 struct PhaseTables {

@@ -511,7 +511,36 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         (void)pieces;                                      // = number of 16-windows the run spans (recomputed on the device)
         if (!right) p.nItemsLeft = uint32_t(p.items.size());
     }
+    // Complex mode: csf[0] stays complex (TransformDSP.inl:993); list the pixels it reaches (complex_dc.hpp redoes them)
+    p.dcPixels.clear();
+    for (size_t r = 0; r < p.recs.size() && cfg.channel_mode == SGZ_CH_COMPLEX; ++r) {
+        const PixelRec &rec = p.recs[r];
+        bool hit = false;
+        if (rec.kind == 0) {
+            long k = rec.a;
+            for (int i = 0; i < rec.b; ++i) { hit = hit || k == 0; k = (k == long(p.N)) ? 0 : k + 1; }
+        } else if (rec.kind & 1) {
+            hit = rec.a <= 0 && long(rec.a) + rec.b > 0;
+        }
+        if (hit) p.dcPixels.push_back(uint32_t(r));
+    }
     buildTwiddles(p);
+    // halves path: mapSideKernel stages k in [N-15, N] + [0, N/2+31] for the left side, [N/2-16, N] + [0, 30] for the right
+    p.sideMapOk = p.halves;
+    for (size_t r = 0; r < p.recs.size() && p.sideMapOk; ++r) {
+        const PixelRec &rec = p.recs[r];
+        const bool right = r >= size_t(p.P);
+        const long N = long(p.N), half = N / 2;
+        auto inside = [&](long k) {
+            return right ? ((k >= half - 16 && k <= N) || (k >= 0 && k <= 30)) : ((k >= 0 && k <= half + 31) || (k >= N - 15 && k <= N));
+        };
+        if (rec.kind == 0) {
+            long k = rec.a;
+            for (int i = 0; i < rec.b; ++i) { p.sideMapOk = p.sideMapOk && inside(k); k = (k == N) ? 0 : k + 1; }
+        } else if (rec.kind & 1) {
+            for (long o = rec.a; o < long(rec.a) + rec.b; ++o) p.sideMapOk = p.sideMapOk && inside(right ? N - o : o);
+        }
+    }
     return SGZ_OK;
 }
 

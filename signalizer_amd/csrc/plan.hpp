@@ -64,8 +64,10 @@ struct Plan {
     uint32_t nItemsLeft = 0;
     std::vector<float> tw1, tw2;        // FFT twiddles (re,im interleaved), see fft kernels (fused N = R^3 path)
     std::vector<float> twN;             // generic path: W_N^i, i < N/2
+    std::vector<uint32_t> dcPixels;     // Complex mode: pixels whose taps / arg-max run include csf[0] (kept complex, TransformDSP.inl:993)
     std::vector<float> tw1odd;          // halves path: pass-1 twiddles of the odd half
     bool fused = false;                 // N in {4096, 32768}: spectrum_fft.hip; otherwise spectrum_generic.hip
+    bool sideMapOk = false;             // halves path: every record stays inside the csf range mapSideKernel stages per side
     bool halves = false;                // N in {8192, 65536} = 2 R^3: two half-frame workgroups (spectrum_fft.hip) + genericMap
     DeviceScalars scalars{};
 
@@ -74,6 +76,7 @@ struct Plan {
     float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
     float *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twN = nullptr, *d_tw1odd = nullptr;
     float *d_work0 = nullptr, *d_work1 = nullptr, *d_binsWork = nullptr; size_t workSlab = 0;
+    uint32_t *d_dcPixels = nullptr; float *d_dcWork = nullptr; size_t dcSlab = 0;   // Complex mode: pixel list, csf[0] of a slab of tasks
     float *d_halfBins = nullptr; size_t binsSlab = 0;                                            // halves path: csf magnitudes of a slab of tasks   // generic path buffers
     uint32_t *d_phaseType = nullptr, *d_phaseNorm = nullptr;
     PixelRec *d_recs = nullptr;

@@ -45,6 +45,76 @@ stftHalfKernel(const StftParams prm)
     stftMapBody<LR, MIX, FULLW, 1>(prm, lds, blockIdx.x, gridDim.x);
 }
 
+// Pixel mapping of one side of one task from HBM-resident csf magnitudes (the halves path): the csf range that side's
+// records touch -- k in [N-15, N] + [0, N/2+31] on the left, [N/2-16, N] + [0, 30] on the right (plan.cpp checks it) --
+// is staged in LDS and mapped by the fused kernel's balanced scan.  One workgroup per (task, side).
+__global__ void __launch_bounds__(1024)
+mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *mapped)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const long task = blockIdx.x / prm.sides;
+    const int side = int(blockIdx.x - task * prm.sides);
+    const int half = int(N >> 1), count = half + 48;
+    const OneSideIndex at{int(N), side ? half + 17 : 16};
+    const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
+    const MapView v{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
+                    side ? 0 : int(prm.P), mapped + (size_t(task) * prm.sides + side) * prm.P};
+    uint2 *win = reinterpret_cast<uint2 *>(lds + ((count + (count >> 5) + 2) & ~1));
+    MapPixelsBalanced<5, 1024, OneSideIndex> mapper;
+    const bool sgzClkHalf = side == int((prm.ablate >> 15) & 1u);       // debug clocks: which side reports
+    SGZ_CLK(0);
+    mapper.prefetchTables(v, tid);
+    const float *src = bins + size_t(task) * (size_t(N) + 1);
+    // csf arrives as the two half-frame workgroups wrote it: even bins [0, N/2] (csf[N] last), then the odd bins
+    constexpr int LB = 17;                                              // N = 65536: 33 elements per thread = two round trips
+    for (int i0 = tid; i0 < count; i0 += LB * 1024) {
+        float val[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * 1024;
+            int k = i - at.off;
+            k = k < 0 ? k + int(N) + 1 : k;
+            k = k > int(N) ? int(N) : k;                               // (past the end: any valid address, the value is dropped)
+            const int e = (k & 1) ? half + 1 + (k >> 1) : (k >> 1);
+            val[u] = src[e];
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * 1024;
+            if (i < count) lds[i + (i >> 5)] = val[u];
+        }
+    }
+    mapper.prefetchWeights(prm);
+    __syncthreads();
+    SGZ_CLK(7);
+    mapper.run(prm, v, at, lds, win, tid, task);
+    SGZ_CLK(9);
+}
+
+static size_t mapSidesLds(const StftParams &prm, uint32_t N)
+{
+    const int count = int(N / 2) + 48;
+    const uint32_t maxSide = prm.nItemsLeft > prm.nItems - prm.nItemsLeft ? prm.nItemsLeft : prm.nItems - prm.nItemsLeft;
+    return size_t((count + (count >> 5) + 2) & ~1) * sizeof(float) + size_t(maxSide) * 8;
+}
+bool mapSidesFit(const StftParams &prm, uint32_t N) { return mapSidesLds(prm, N) <= 160 * 1024; }
+
+hipError_t launchMapSides(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream)
+{
+    const size_t ldsBytes = mapSidesLds(prm, N);
+    if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
+    static size_t attrBytes = 0;
+    if (attrBytes < ldsBytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mapSideKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(ldsBytes));
+        if (e != hipSuccess) return e;
+        attrBytes = ldsBytes;
+    }
+    hipLaunchKernelGGL(mapSideKernel, dim3(unsigned(ntasks * prm.sides)), dim3(1024), ldsBytes, stream, prm, bins, N, mapped);
+    return hipGetLastError();
+}
+
 template <int LR>
 static hipError_t launchHalves(const StftParams &prm, int grid, hipStream_t stream)
 {
@@ -88,13 +158,13 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
     size_t ldsBytes = baseBytes;
     if (p2.items && baseBytes + slotBytes <= 160 * 1024) ldsBytes += slotBytes;   // arg-max slots fit beside the |X| array
     else p2.items = nullptr;                                                         // very tall views: serial scan
-    const bool simple = prm.mode == SGZ_CH_SEPARATE || prm.mode == SGZ_CH_COMPLEX || prm.mode == SGZ_CH_PHASE;
+    const int mix = prm.mode == SGZ_CH_SEPARATE ? 0 : (prm.mode == SGZ_CH_COMPLEX ? 2 : 1);
     const bool fullw = prm.W == uint32_t(N);
     using Kern = void (*)(const StftParams);
-    static const Kern kerns[4] = {&stftMapKernel<LR, 1, false>, &stftMapKernel<LR, 1, true>, &stftMapKernel<LR, 0, false>,
-                                  &stftMapKernel<LR, 0, true>};
-    const int which = (simple ? 2 : 0) + (fullw ? 1 : 0);
-    static size_t attrBytes[4] = {0, 0, 0, 0};
+    static const Kern kerns[6] = {&stftMapKernel<LR, 0, false>, &stftMapKernel<LR, 0, true>, &stftMapKernel<LR, 1, false>,
+                                  &stftMapKernel<LR, 1, true>,  &stftMapKernel<LR, 2, false>, &stftMapKernel<LR, 2, true>};
+    const int which = 2 * mix + (fullw ? 1 : 0);
+    static size_t attrBytes[6] = {0, 0, 0, 0, 0, 0};
     if (attrBytes[which] < ldsBytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(ldsBytes));

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "complex_dc.hpp"
 #include "fft_common.hpp"
 #include "kernels.hpp"
 
@@ -87,7 +88,8 @@ genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, u
 }
 
 __global__ void __launch_bounds__(256)
-genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long ntasks, float *bins /*[ntasks][N+1]*/)
+genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long ntasks, float *bins /*[ntasks][N+1]*/,
+            float2 *dcOut /*[ntasks] or null: Complex mode's csf[0] = Z[0] / 2 (TransformDSP.inl:993)*/)
 {
     const size_t per = size_t(N) + 1;
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -116,6 +118,7 @@ genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long nta
         }
     }
     bins[gid] = out;
+    if (k == 0 && dcOut) dcOut[t] = make_float2(0.5f * Z[0].x, 0.5f * Z[0].y);
 }
 
 // 16 lanes per (task, side, pixel); exact fp32 order of the reference (contraction off).  An interpolated pixel is lane 0's
@@ -313,6 +316,30 @@ static void runStages(float2 *&src, float2 *&dst, const float2 *twN, uint32_t N,
     while (left) pass(4);
 }
 
+// Complex mode: the pixels that touch bin 0, redone with the complex csf[0] (stft_body.hpp complexDcPixel)
+__global__ void __launch_bounds__(64)
+complexDcFixKernel(const float *bins, const float2 *dc, uint32_t N, uint32_t P, const PixelRec *recs, const float *weights,
+                   const uint32_t *dcPixels, uint32_t nDc, float invSize, long ntasks, float *mapped /*[ntasks][P]*/)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(ntasks) * nDc) return;
+    const long t = long(gid / nDc);
+    const uint32_t x = dcPixels[gid - size_t(t) * nDc];
+    const float *M = bins + size_t(t) * (size_t(N) + 1);
+    const float2 z0 = dc[t];
+    mapped[size_t(t) * P + x] = complexDcPixel(recs[x], weights, invSize, int(N), z0.x, z0.y, [&](int k) { return M[k]; });
+}
+
+hipError_t launchComplexDcFix(const StftParams &prm, uint32_t N, const float *bins, const float2 *dc, long ntasks, float *mapped,
+                              hipStream_t stream)
+{
+    if (prm.mode != SGZ_CH_COMPLEX || prm.nDcPixels == 0 || dc == nullptr) return hipSuccess;
+    const size_t n = size_t(ntasks) * prm.nDcPixels;
+    hipLaunchKernelGGL(complexDcFixKernel, dim3(unsigned((n + 63) / 64)), dim3(64), 0, stream, bins, dc, N, prm.P, prm.recs, prm.weights,
+                       prm.dcPixels, prm.nDcPixels, prm.invSize, ntasks, mapped);
+    return hipGetLastError();
+}
+
 hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream)
 {
     hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(ntasks) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P,
@@ -359,14 +386,19 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             runStages(src, dst, twN, N, log2N, nt, stream);
             float *bout = prm.binsOut ? prm.binsOut + size_t(t0) * (size_t(N) + 1) : binsWork;
             hipLaunchKernelGGL(genericBins, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, prm.sides,
-                               prm.mode, nt, bout);
+                               prm.mode, nt, bout, prm.dcOut);
             bins = bout;
         } else {
             bins = prm.binsIn + size_t(t0) * (size_t(N) + 1);
         }
-        if (prm.mapped)
+        if (prm.mapped) {
             hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,
                                prm.recs, prm.weights, prm.invSize, nt, prm.mapped + size_t(t0) * prm.sides * prm.P);
+            if (prm.binsIn == nullptr) {
+                hipError_t e2 = launchComplexDcFix(prm, N, bins, prm.dcOut, nt, prm.mapped + size_t(t0) * prm.sides * prm.P, stream);
+                if (e2 != hipSuccess) return e2;
+            }
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

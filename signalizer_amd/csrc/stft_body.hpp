@@ -6,6 +6,7 @@
 
 #include <type_traits>
 
+#include "complex_dc.hpp"
 #include "fft_common.hpp"
 #include "kernels.hpp"
 
@@ -15,7 +16,7 @@ namespace sgz {
 // phaseClock[16 * wave + slot]
 #define SGZ_CLK(slot)                                                                                   \
     do {                                                                                                \
-        if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16))                        \
+        if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16) && sgzClkHalf)          \
             prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter();                     \
     } while (0)
 #define SGZ_WCLK(i) do { } while (0)
@@ -86,9 +87,44 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
 // tiny, so what matters is the number of dependent global-load round trips, not the byte count.
 // The first batch of table reads is split off (prefetchTables / prefetchWeights) so that the kernel can issue it
 // while the FFT's last barriers are still pending: the map phase then starts with its operands in registers.
-template <int LR, int NT>
+// Where csf[k] lives in LDS.  WholeFrame: the fused kernel's bank-padded natural order, N = R^3.
+template <int LR>
+struct WholeFrameIndex {
+    static constexpr int N = (1 << LR) * (1 << LR) * (1 << LR);
+    __device__ __forceinline__ int size() const { return N; }
+    __device__ __forceinline__ int operator()(int k) const { return k + (k >> LR); }
+};
+// OneSide (mapSideKernel, N = 2 R^3): LDS holds the csf range one side of the view touches, rotated by `off` (a multiple of
+// 16, so the 16-aligned arg-max windows stay aligned and contiguous): k' = (k + off) mod (N + 1), same bank padding.
+struct OneSideIndex {
+    int n, off;
+    __device__ __forceinline__ int size() const { return n; }
+    __device__ __forceinline__ int operator()(int k) const
+    {
+        int kp = k + off;
+        kp = kp > n ? kp - (n + 1) : kp;
+        return kp + (kp >> 5);
+    }
+};
+// The slice of the plan's tables a workgroup maps: all of it (fused kernel) or one side's records and pieces.
+struct MapView {
+    const MaxItem *items;
+    uint32_t nItems;          // pieces in this view
+    uint32_t nItemsLeft;      // pieces [0, nItemsLeft) scan ascending k, the rest descending
+    uint32_t itemBase;        // index of the view's first piece in the plan's list (PixelRec::kind counts from there)
+    const PixelRec *recs;
+    int total;                // records in this view
+    int rightFrom;            // records [rightFrom, total) are right-side records (k = N - offset)
+    float *out;               // [total]
+};
+__device__ __forceinline__ MapView wholeView(const StftParams &prm, long task)
+{
+    const int total = int(prm.sides * prm.P);
+    return MapView{prm.items, prm.nItems, prm.nItemsLeft, 0u, prm.recs, total, int(prm.P), prm.mapped + size_t(task) * total};
+}
+
+template <int LR, int NT, typename Index = WholeFrameIndex<LR>>
 struct MapPixelsBalanced {
-    static constexpr int R = 1 << LR, N = R * R * R;
     static constexpr int IB = 4;                                         // items per thread per batch (register budget)
     static constexpr int RB = NT >= 1024 ? 2 : 4;                        // records per thread per batch
     static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
@@ -97,20 +133,20 @@ struct MapPixelsBalanced {
     PixelRec rec0[RB];
     float w0[RB][kMaxTaps];
 
-    __device__ __forceinline__ void loadItems(const StftParams &prm, uint32_t base, int tid, uint32_t (&iw)[IB]) const
+    __device__ __forceinline__ void loadItems(const MapView &v, uint32_t base, int tid, uint32_t (&iw)[IB]) const
     {
 #pragma unroll
         for (int b = 0; b < IB; ++b) {
             const uint32_t it = base + b * NT + tid;
-            iw[b] = it < prm.nItems ? prm.items[it].win : 0u;
+            iw[b] = it < v.nItems ? v.items[it].win : 0u;
         }
     }
-    __device__ __forceinline__ void loadRecs(const StftParams &prm, int base, int tid, int total, PixelRec (&rec)[RB]) const
+    __device__ __forceinline__ void loadRecs(const MapView &v, int base, int tid, PixelRec (&rec)[RB]) const
     {
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int idx = base + b * NT + tid;
-            rec[b] = idx < total ? prm.recs[idx] : PixelRec{2, 0, 0, 0};
+            rec[b] = idx < v.total ? v.recs[idx] : PixelRec{2, 0, 0, 0};
         }
     }
     // tap weights: unconditional, independent loads (the weight table is padded by kMaxTaps zeros)
@@ -123,33 +159,36 @@ struct MapPixelsBalanced {
             for (int i = 0; i < kMaxTaps; ++i) w[b][i] = prm.weights[wbase + i];
         }
     }
-    __device__ __forceinline__ void prefetchTables(const StftParams &prm, int tid)
+    __device__ __forceinline__ void prefetchTables(const MapView &v, int tid)
     {
-        loadItems(prm, 0u, tid, iw0);
-        loadRecs(prm, 0, tid, int(prm.sides * prm.P), rec0);
+        loadItems(v, 0u, tid, iw0);
+        loadRecs(v, 0, tid, rec0);
     }
     __device__ __forceinline__ void prefetchWeights(const StftParams &prm) { loadWeights(prm, rec0, w0); }
 
-__device__ __forceinline__ void run(const StftParams &prm, const float *lds, uint2 *win, int tid, long task)
+__device__ __forceinline__ void run(const StftParams &prm, const MapView &v, const Index at, const float *lds, uint2 *win, int tid,
+                                    long task)
 {
 #pragma clang fp contract(off)
-    const int total = int(prm.sides * prm.P);
-    float *out = prm.mapped + size_t(task) * total;
+    const int total = v.total;
+    const int N = at.size();
+    const bool sgzClkHalf = true;
+    float *out = v.out;
     // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
     // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
     // to +0, which can never win.  The left side's scan order is ascending k ("first strictly greater" = FIRST
     // maximum), the right side's is descending k, whose first maximum is the LAST maximum in ascending order.
-    for (uint32_t base = 0; base < prm.nItems; base += NT * IB) {
+    for (uint32_t base = 0; base < v.nItems; base += NT * IB) {
         uint32_t iw[IB];
         if (base == 0) {
 #pragma unroll
             for (int b = 0; b < IB; ++b) iw[b] = iw0[b];
-        } else loadItems(prm, base, tid, iw);
+        } else loadItems(v, base, tid, iw);
         float mv[IB][16];
 #pragma unroll
         for (int b = 0; b < IB; ++b) {
             const int k0 = int(iw[b] & 0xFFFFu) << 4;
-            const float *src = lds + (k0 + (k0 >> LR));
+            const float *src = lds + at(k0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) mv[b][j] = src[j];
         }
@@ -159,7 +198,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
             const int k0 = int(iw[b] & 0xFFFFu) << 4;
             const int lo = int((iw[b] >> 16) & 15u), hi = int((iw[b] >> 20) & 15u);
             const uint32_t mask = (0xFFFFu >> (15 - hi)) & (0xFFFFu << lo);   // valid positions: bits lo..hi
-            const bool right = it >= prm.nItemsLeft;
+            const bool right = it >= v.nItemsLeft;
             // masked squares, their maximum (a tree of independent v_max, not a serial compare-and-select chain), then
             // the first (left side) or last (right side) position that holds it.  Squares are >= 0, so their bit
             // patterns order like unsigned integers; a zero square never wins (TransformDSP.inl:965 is a strict >).
@@ -185,7 +224,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
                 first = (sqm[15 - j] == best) ? uint32_t(15 - j) : first;   // descending: the lowest position survives
             }
             const uint32_t bestK = best == 0u ? kNone : uint32_t(k0) + (right ? last : first);
-            if (it < prm.nItems) win[it] = make_uint2(bestK, best);
+            if (it < v.nItems) win[it] = make_uint2(bestK, best);
         }
     }
     SGZ_CLK(10);
@@ -202,7 +241,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
                 for (int i = 0; i < kMaxTaps; ++i) w[b][i] = w0[b][i];
             }
         } else {
-            loadRecs(prm, base, tid, total, rec);
+            loadRecs(v, base, tid, rec);
             loadWeights(prm, rec, w);
         }
 #pragma unroll
@@ -210,7 +249,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
             int k = rec[b].kind == 0 ? rec[b].a : 0;
 #pragma unroll
             for (int i = 0; i < kMaxTaps; ++i) {
-                mv[b][i] = lds[k + (k >> LR)];
+                mv[b][i] = lds[at(k)];
                 k = (k == N) ? 0 : k + 1;
             }
         }
@@ -231,13 +270,13 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
     SGZ_CLK(12);
     // (c) resolve the arg-max pixels from their pieces' winners
     for (int base = 0; base < total; base += NT * RB) {
-        if (!oneBatch) loadRecs(prm, base, tid, total, rec);
+        if (!oneBatch) loadRecs(v, base, tid, rec);
         int first[RB], pieces[RB], maxPieces = 0;
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int idx = base + b * NT + tid;
-            const bool right = idx >= int(prm.P);
-            first[b] = rec[b].kind >> 1;
+            const bool right = idx >= v.rightFrom;
+            first[b] = (rec[b].kind >> 1) - int(v.itemBase);
             // number of 16-aligned csf windows the run [a, a+b) spans (k = offset, or N - offset on the right side)
             const int kLo = right ? N - (rec[b].a + rec[b].b - 1) : rec[b].a;
             const int kHi = right ? N - rec[b].a : rec[b].a + rec[b].b - 1;
@@ -271,7 +310,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int idx = base + b * NT + tid;
-            if (rec[b].kind & 1) out[idx] = finishPixel<LR>(prm.invSize * lds[arg[b] + (arg[b] >> LR)]);
+            if (rec[b].kind & 1) out[idx] = finishPixel<LR>(prm.invSize * lds[at(arg[b])]);
         }
     }
 }
@@ -287,7 +326,8 @@ __device__ __forceinline__ void run(const StftParams &prm, const float *lds, uin
 // of the same wave, registers m3 and R-1-m3: the two-for-one split (TransformDSP.inl:858) needs one ds_bpermute per
 // value and no LDS round trip.  Slot 0 holds q = 0 and q = R/2, which mirror onto themselves (other lane pattern);
 // column 0 (q = 0, q2 = 0) mirrors inside thread 0 and is redone from a small LDS scratch by lanes 1..R/2-1.
-// MIX = 0: Separate / Complex / Phase (re = L w, im = R w); MIX = 1: Left, Right, Merge, Side, MidSide.
+// MIX = 0: Separate (re = L w, im = R w); MIX = 1: Left, Right, Merge, Side, MidSide; MIX = 2: Complex (the window of MIX = 0,
+// plus the pixels that touch the complex csf[0], complex_dc.hpp).
 // FULLW: W == N (no zero padding): plain global loads.  Measured on gfx950 (tools/ubench/stream.hip): a workgroup's
 // 3R strided dword loads complete in ~7-8.6 k clocks as global loads and in ~13 k as raw buffer loads, so the buffer
 // form (whose out-of-range reads return 0 = the zero padding of prepareTransform, :220-223) is kept for W < N only.
@@ -312,6 +352,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max piece winners (nItems uint2)
     constexpr int TILE = R * (R + 1);
     const int tid = threadIdx.x;
+    const bool sgzClkHalf = HALF < 0 || HALF == int((prm.ablate >> 15) & 1u);   // debug clocks: which half reports
     const long tasks = prm.frames * long(prm.C) * (HALF >= 0 ? 2 : 1);
     const int slot = tid >> (LR + 1), half = (tid >> LR) & 1, l = tid & (R - 1);
     const int q = half ? (HALF == 1 ? R - 1 - slot : (slot == 0 ? R / 2 : R - slot)) : slot;
@@ -337,6 +378,12 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     if (HALF >= 0) {
         if (int(task & 1) != HALF) return;                             // wave-uniform: the kernel wrapper calls both bodies
         task >>= 1;
+    }
+    if (prm.C > 1) {
+        // several pairs: walk the launch pair-major, so that the workgroups that share an L2 transform consecutive
+        // (overlapping) frames of the same pair rather than the same frame of unrelated pairs
+        const long pr = task / prm.frames, fr = task - pr * prm.frames;
+        task = fr * prm.C + pr;
     }
     MapPixelsBalanced<LR, T> mapper;
     const bool doMap = HALF < 0 && balanced && prm.mapped && !(prm.ablate & 16);
@@ -376,14 +423,14 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             // prepareTransform channel mixes (TransformDSP.inl:59-216).  (a*l + b*r) * w * s with a, b in {0, +-1},
             // s in {1, 0.5} rounds exactly like the reference's `(l +- r) * w * 0.5f` / `l * w`.
             float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 0.f, mixS = 1.f;          // Left
-            if (MIX != 0) {
+            if (MIX == 1) {
                 if (mode == SGZ_CH_RIGHT) { mixRL = 0.f; mixRR = 1.f; }
                 else if (mode == SGZ_CH_MERGE) { mixRR = 1.f; mixS = 0.5f; }
                 else if (mode == SGZ_CH_SIDE) { mixRR = -1.f; mixS = 0.5f; }
                 else if (mode == SGZ_CH_MIDSIDE) { mixRR = 1.f; mixIL = 1.f; mixIR = -1.f; mixS = 0.5f; }
             }
             auto windowed = [&](float lx, float rx, float wx) {
-                if (MIX == 0) return v2{lx * wx, rx * wx};
+                if (MIX != 1) return v2{lx * wx, rx * wx};
                 return v2{(mixRL * lx + mixRR * rx) * wx * mixS, (mixIL * lx + mixIR * rx) * wx * mixS};
             };
 #pragma unroll
@@ -540,7 +587,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             }
         }
         SGZ_CLK(6);
-        if (doMap) mapper.prefetchTables(prm, tid);                    // im[] is dead: its registers take the map tables
+        if (doMap) mapper.prefetchTables(wholeView(prm, task), tid);   // im[] is dead: its registers take the map tables
         // csf[N/2-1] *= 0.5 (quirk Q3, :864); of a 2N-point frame that bin is the odd half's j = N/2 - 1
         if (HALF != 0 && split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;
         __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
@@ -581,7 +628,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     } else {
         // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM
         const float *src = prm.binsIn + size_t(task) * (N + 1);
-        if (doMap) { mapper.prefetchTables(prm, tid); mapper.prefetchWeights(prm); }
+        if (doMap) { mapper.prefetchTables(wholeView(prm, task), tid); mapper.prefetchWeights(prm); }
         for (int k = tid; k <= N; k += T) lds[k + (k >> LR)] = src[k];
         __syncthreads();
     }
@@ -589,10 +636,14 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
 
     if (HALF >= 0) {
         // csf of the 2N-point frame: this half owns the elements 2j + HALF (and the even half csf[2N])
-        float *dst = prm.binsOut + size_t(task) * (2 * N + 1);
+        // (binsSplit: as two contiguous arrays for mapSideKernel -- even bins, csf[2N], odd bins -- instead of interleaved)
+        float *dst = prm.binsOut + size_t(task) * (2 * N + 1) + (prm.binsSplit ? HALF * (N + 1) : HALF);
+        const int stride = prm.binsSplit ? 1 : 2;
 #pragma unroll 8
-        for (int k = tid; k < N; k += T) dst[2 * k + HALF] = lds[k + (k >> LR)];
-        if (HALF == 0 && tid == 0) dst[2 * N] = lds[N + (N >> LR)];
+        for (int k = tid; k < N; k += T) dst[stride * k] = lds[k + (k >> LR)];
+        if (HALF == 0 && tid == 0) dst[stride * N] = lds[N + (N >> LR)];
+        if (HALF == 0 && tid == 0 && prm.dcOut) prm.dcOut[task] = make_float2(0.5f * lds[SCRATCH], 0.5f * lds[SCRATCH + 1]);
+        SGZ_CLK(8);
         return;
     }
     if (prm.binsOut) {
@@ -603,8 +654,17 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     SGZ_WCLK(2);
     // -------------------------------------------------------------------------- pixel mapping
     if (prm.mapped && !(prm.ablate & 16)) {
-        if (balanced) mapper.run(prm, lds, win, tid, task);
+        if (balanced) mapper.run(prm, wholeView(prm, task), WholeFrameIndex<LR>{}, lds, win, tid, task);
         else mapPixelsSerial<LR, T>(prm, lds, tid, task);
+    }
+    if (MIX == 2 && prm.nDcPixels != 0 && prm.mapped && prm.binsIn == nullptr && !(prm.ablate & 16)) {
+        __syncthreads();                                               // the pixels' first values are written by other threads
+        const float re0 = 0.5f * lds[SCRATCH], im0 = 0.5f * lds[SCRATCH + 1];   // csf[0] *= 0.5 (TransformDSP.inl:993)
+        float *out = prm.mapped + size_t(task) * (prm.sides * prm.P);
+        for (uint32_t i = tid; i < prm.nDcPixels; i += T) {
+            const uint32_t x = prm.dcPixels[i];
+            out[x] = complexDcPixel(prm.recs[x], prm.weights, prm.invSize, N, re0, im0, [&](int k) { return lds[k + (k >> LR)]; });
+        }
     }
     SGZ_CLK(9);
     SGZ_WCLK(3);

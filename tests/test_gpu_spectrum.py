@@ -247,6 +247,47 @@ def test_end_to_end_generic_sizes(gpu, oracle, W, hop, pairs, P):
     assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
 
 
+@pytest.mark.parametrize("W,pairs,frames,P,mode", [(8192, 3, 1500, 300, config.CH_SEPARATE), (65536, 2, 6, 4000, config.CH_SEPARATE),
+                                                  (8192, 2, 9, 256, config.CH_COMPLEX), (7000, 1, 7, 512, config.CH_MIDSIDE)])
+def test_end_to_end_halves(gpu, oracle, W, pairs, frames, P, mode):
+    """N = 2 R^3 (two half-frame workgroups + map kernel): several slabs of tasks walked pair-major, a view too tall for the
+    LDS-staged map (falls back to the generic map kernel), Complex (whole-spectrum view), zero-padded window"""
+    po = oracle
+    hop = W // 4
+    cfg = config.spectrum_config(sample_rate=96000.0, window_size=W, hop=hop, num_pairs=pairs, axis_points=P, channel_mode=mode)
+    x = synth.gen(37, 96000, W + (frames - 1) * hop, 2 * pairs)
+    r = po.spectrogram(po.params_from_dict(cfg), x)
+    plan = api.Plan(cfg).upload()
+    rgba = plan.render(_planar_cuda(x, gpu)).cpu().numpy()
+    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
+    assert rgba.shape == r["rgba"].shape
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
+
+
+@pytest.mark.parametrize("W", [4096, 2048, 8192, 32768])
+@pytest.mark.parametrize("interp,view", [(config.INTERP_LANCZOS, config.VIEW_LOG), (config.INTERP_LINEAR, config.VIEW_LINEAR),
+                                         (config.INTERP_NONE, config.VIEW_LOG)])
+def test_complex_mode_dc_bin(gpu, oracle, W, interp, view):
+    """SpectrumChannels::Complex keeps csf[0] complex (TransformDSP.inl:993): the pixels whose filter window reaches bin 0 are
+    complex sums.  Fused (4096, 32768), halves (8192) and generic (2048) paths against the oracle's mapped values."""
+    po = oracle
+    P, frames = 300, 3
+    cfg = config.spectrum_config(sample_rate=96000.0, window_size=W, hop=W // 4, axis_points=P, channel_mode=config.CH_COMPLEX,
+                                 bin_interp=interp, view_scaling=view)
+    x = synth.gen(41, 96000, W + (frames - 1) * (W // 4), 2)
+    x += 0.25                                            # a DC offset: makes csf[0] large
+    x[1] -= 0.6
+    r = po.spectrogram(po.params_from_dict(cfg), x, want_mapped=True)
+    m = r["mapped"][:, :, :P]
+    ref = np.sqrt((m.real.astype(np.float32) ** 2 + m.imag.astype(np.float32) ** 2).astype(np.float32))
+    plan = api.Plan(cfg).upload()
+    got = plan.stage_mapped(_planar_cuda(x, gpu)).cpu().numpy()[:, :, 0, :]
+    if interp != config.INTERP_NONE:
+        assert (np.abs(m.imag) > 0).any()                # the case under test exists in this view
+    err = np.abs(got - ref).max()
+    assert err <= BIN_TOL * np.abs(ref).max(), (err, np.abs(ref).max())
+
+
 def test_unsupported_and_errors(gpu):
     with pytest.raises(api.SgzError):
         api.Plan(config.spectrum_config(axis_points=1))

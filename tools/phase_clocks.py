@@ -4,12 +4,14 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from signalizer_amd import api, config, synth
-cfg = config.cfg2()
-S = int(sys.argv[1]) if len(sys.argv) > 1 else int(60 * 48000)
-x = torch.from_numpy(synth.gen(2, 48000, S, 2)).cuda()
+# SGZ_CFG5=1: the halves kernel of cfg5 (32 pairs, N = 65536); ablate bit 15 selects the odd half
+cfg5 = os.environ.get("SGZ_CFG5") == "1"
+cfg = config.cfg5(pairs=32) if cfg5 else config.cfg2()
+S = int(sys.argv[1]) if len(sys.argv) > 1 else (int(4 * 96000) if cfg5 else int(60 * 48000))
+x = torch.from_numpy(synth.gen(2, cfg["sample_rate"], S, 2 * cfg["num_pairs"])).cuda()
 plan = api.Plan(cfg).upload()
 F = plan.num_frames(S)
-mapped = torch.empty((F, 1, 2, 1024), dtype=torch.float32, device="cuda")
+mapped = torch.empty((F, cfg['num_pairs'], 2, 1024), dtype=torch.float32, device="cuda")
 clk = torch.zeros(16 * 16, dtype=torch.int64, device="cuda")
 L = api.lib()
 L.sgz_debug_set_ablate((int(sys.argv[2]) if len(sys.argv) > 2 else 0) | ((int(sys.argv[3]) if len(sys.argv) > 3 else 0) << 16))
@@ -22,6 +24,9 @@ for rep in range(3):
 c = clk.cpu().numpy().reshape(16, 16)
 t0 = c[:, 0].min()
 order = [0, 13, 14, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 9]
+if cfg5:   # the map slots are then written by mapSideKernel (a later launch): print the two kernels separately
+    order = [0, 7, 10, 11, 12, 9] if os.environ.get("SGZ_MAPCLK") == "1" else [13, 14, 1, 2, 3, 4, 5, 6, 8]
+    t0 = c[:, 0].min() if os.environ.get("SGZ_MAPCLK") == "1" else c[:, 13].min()
 print(f"{'boundary':22s} {'first wave':>10s} {'last wave':>10s} {'wave 0':>8s} {'wave 15':>8s}")
 for i in order:
     col = c[:, i] - t0
