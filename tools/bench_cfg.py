@@ -4,7 +4,9 @@ import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from signalizer_amd import api, config, synth
+only = sys.argv[1] if len(sys.argv) > 1 else ""       # substring filter on the configuration name
 def run(name, cfg, seconds, sr):
+    if only not in name: return
     nch = 2 * cfg["num_pairs"]
     x = torch.from_numpy(synth.gen(7, sr, int(seconds * sr), nch)).cuda()
     plan = api.Plan(cfg).upload()
