@@ -67,24 +67,29 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     mapper.prefetchTables(v, tid);
     const float *src = bins + size_t(task) * (size_t(N) + 1);
     // csf arrives as the two half-frame workgroups wrote it: even bins [0, N/2] (csf[N] last), then the odd bins
-    constexpr int LB = 17;                                              // N = 65536: 33 elements per thread = two round trips
-    for (int i0 = tid; i0 < count; i0 += LB * 1024) {
-        float val[LB];
+    // LB independent loads in flight per thread (N = 65536: 33 elements per thread = two round trips; N = 8192: one of 5)
+    auto stage = [&](auto lb) {
+        constexpr int LB = decltype(lb)::value;
+        for (int i0 = tid; i0 < count; i0 += LB * 1024) {
+            float val[LB];
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int i = i0 + u * 1024;
-            int k = i - at.off;
-            k = k < 0 ? k + int(N) + 1 : k;
-            k = k > int(N) ? int(N) : k;                               // (past the end: any valid address, the value is dropped)
-            const int e = (k & 1) ? half + 1 + (k >> 1) : (k >> 1);
-            val[u] = src[e];
-        }
+            for (int u = 0; u < LB; ++u) {
+                const int i = i0 + u * 1024;
+                int k = i - at.off;
+                k = k < 0 ? k + int(N) + 1 : k;
+                k = k > int(N) ? int(N) : k;                           // (past the end: any valid address, the value is dropped)
+                const int e = (k & 1) ? half + 1 + (k >> 1) : (k >> 1);
+                val[u] = src[e];
+            }
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int i = i0 + u * 1024;
-            if (i < count) lds[i + (i >> 5)] = val[u];
+            for (int u = 0; u < LB; ++u) {
+                const int i = i0 + u * 1024;
+                if (i < count) lds[i + (i >> 5)] = val[u];
+            }
         }
-    }
+    };
+    if (count <= 5 * 1024) stage(std::integral_constant<int, 5>{});
+    else stage(std::integral_constant<int, 17>{});
     mapper.prefetchWeights(prm);
     __syncthreads();
     SGZ_CLK(7);

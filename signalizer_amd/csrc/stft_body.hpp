@@ -496,20 +496,33 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             tw.apply(c);                                               // times W_N^{t q} (odd half: W_2N^{t (2q+1)})
         }
         SGZ_CLK(1);
-        // -------------------------------------------------------------- exchange 1 (workgroup-wide; re then im)
+        // -------------------------------------------------------------- exchange 1 (workgroup-wide)
+        // (re, im) pairs move as 64-bit LDS operations: measured 6.0 clocks per ds_write_b64 and 2.3 per ds_read_b64 against
+        // 2 x 4.1 and 2 x 2.1 for the dword forms (tools/ubench/lds.hip).  N complex values are 2x the LDS, so the lower and
+        // the upper half of the workgroup take turns as writers; everybody reads its R/2 values of the first round into
+        // spare registers (the twiddles are dead, the map tables not loaded yet).
         if (!(prm.ablate & 2)) {
-            const int rd = q * T + ix;
+            v2 *lds2 = reinterpret_cast<v2 *>(lds);
+            const int rd = q * (T / 2) + ix;
+            v2 lo[R / 2];
+            if (tid < T / 2) {
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tid] = c[brev(qq, LR)].x;
+                for (int qq = 0; qq < R; ++qq) lds2[qq * (T / 2) + tid] = c[brev(qq, LR)];
+            }
             __syncthreads();
 #pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) c[j2].x = lds[rd + R * j2];
+            for (int j2 = 0; j2 < R / 2; ++j2) lo[j2] = lds2[rd + R * j2];
+            __syncthreads();
+            if (tid >= T / 2) {
+#pragma unroll
+                for (int qq = 0; qq < R; ++qq) lds2[qq * (T / 2) + tid - T / 2] = c[brev(qq, LR)];
+            }
             __syncthreads();
 #pragma unroll
-            for (int qq = 0; qq < R; ++qq) lds[qq * T + tid] = c[brev(qq, LR)].y;
-            __syncthreads();
-#pragma unroll
-            for (int j2 = 0; j2 < R; ++j2) c[j2].y = lds[rd + R * j2];
+            for (int j2 = 0; j2 < R / 2; ++j2) {
+                c[j2 + R / 2] = lds2[rd + R * j2];
+                c[j2] = lo[j2];
+            }
         }
         SGZ_CLK(2);
         // ---------------------------------------------------------------------- pass 2 (t2 = ix)
