@@ -91,6 +91,7 @@ __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const flo
 template <int LR>
 struct WholeFrameIndex {
     static constexpr int N = (1 << LR) * (1 << LR) * (1 << LR);
+    static constexpr bool kSkipEmpty = false;        // both sides of a view fill the thread batches (measured: a skip gains nothing)
     __device__ __forceinline__ int size() const { return N; }
     __device__ __forceinline__ int operator()(int k) const { return k + (k >> LR); }
 };
@@ -98,6 +99,7 @@ struct WholeFrameIndex {
 // 16, so the 16-aligned arg-max windows stay aligned and contiguous): k' = (k + off) mod (N + 1), same bank padding.
 struct OneSideIndex {
     int n, off;
+    static constexpr bool kSkipEmpty = true;         // one side's work list leaves whole waves of a batch slot empty: skip those
     __device__ __forceinline__ int size() const { return n; }
     __device__ __forceinline__ int operator()(int k) const
     {
@@ -187,6 +189,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         float mv[IB][16];
 #pragma unroll
         for (int b = 0; b < IB; ++b) {
+            if (Index::kSkipEmpty && base + b * NT + (uint32_t(tid) & ~63u) >= v.nItems) continue;   // wave-uniform
             const int k0 = int(iw[b] & 0xFFFFu) << 4;
             const float *src = lds + at(k0);
 #pragma unroll
@@ -194,6 +197,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         }
 #pragma unroll
         for (int b = 0; b < IB; ++b) {
+            if (Index::kSkipEmpty && base + b * NT + (uint32_t(tid) & ~63u) >= v.nItems) continue;
             const uint32_t it = base + b * NT + tid;
             const int k0 = int(iw[b] & 0xFFFFu) << 4;
             const int lo = int((iw[b] >> 16) & 15u), hi = int((iw[b] >> 20) & 15u);
@@ -246,6 +250,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
+            if (Index::kSkipEmpty && base + b * NT + (tid & ~63) >= total) continue;
             int k = rec[b].kind == 0 ? rec[b].a : 0;
 #pragma unroll
             for (int i = 0; i < kMaxTaps; ++i) {
@@ -255,6 +260,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
+            if (Index::kSkipEmpty && base + b * NT + (tid & ~63) >= total) continue;
             const int idx = base + b * NT + tid;
             float acc = 0.f;
 #pragma unroll
