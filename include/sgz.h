@@ -100,6 +100,18 @@ sgz_status sgz_plan_upload(sgz_plan *plan);                                   /*
 uint32_t   sgz_plan_transform_size(const sgz_plan *plan);
 double     sgz_plan_window_scale(const sgz_plan *plan);                        /* windowKernelScale */
 uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /* first max-of-bins pixel */
+/* which K_A implementation the transform size and channel mode select: SGZ_PATH_FUSED: N = R^3
+ * (4096, 32768) in one workgroup; SGZ_PATH_HALVES: N = 2 R^3 (8192, 65536) as two half-frame workgroups + a map kernel;
+ * SGZ_PATH_GENERIC: HBM-resident passes (every other size, and Phase at any size).  Bit SGZ_PATH_SIDE_MAP: the halves
+ * path can use its LDS-staged per-side map kernel (the view's records stay inside the staged csf range). */
+#define SGZ_PATH_GENERIC  0u
+#define SGZ_PATH_FUSED    1u
+#define SGZ_PATH_HALVES   2u
+#define SGZ_PATH_SIDE_MAP 4u
+uint32_t   sgz_plan_path(const sgz_plan *plan);
+/* SpectrumChannels::Complex keeps csf[0] = Z[0]/2 complex (TransformDSP.inl:993): the pixels whose filter taps or arg-max run
+ * reach bin 0, redone as complex sums after the magnitude-only mapping.  Returns their count; writes at most `cap`. */
+uint32_t   sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap);
 sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out /*N*/);
 sgz_status sgz_plan_get_mapped_frequencies(const sgz_plan *plan, float *out /*P*/);
 sgz_status sgz_plan_get_slope_map(const sgz_plan *plan, float *out /*P*/);

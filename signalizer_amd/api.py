@@ -84,7 +84,7 @@ LIB_PATH = _build.LIB
 EXPORTS = [
     "sgz_last_error", "sgz_abi_version", "sgz_device_count", "sgz_set_device",
     "sgz_plan_create", "sgz_plan_destroy", "sgz_plan_upload", "sgz_plan_transform_size",
-    "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_get_window",
+    "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_path", "sgz_plan_dc_pixels", "sgz_plan_get_window",
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped",
@@ -123,6 +123,10 @@ def lib() -> C.CDLL:
     L.sgz_plan_window_scale.restype = C.c_double
     L.sgz_plan_break_pixel.argtypes = [vp]
     L.sgz_plan_break_pixel.restype = u32
+    L.sgz_plan_path.argtypes = [vp]
+    L.sgz_plan_path.restype = u32
+    L.sgz_plan_dc_pixels.argtypes = [vp, vp, u32]
+    L.sgz_plan_dc_pixels.restype = u32
     for f in ("sgz_plan_get_window", "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map",
               "sgz_plan_get_colour_ratios"):
         getattr(L, f).argtypes = [vp, vp]
@@ -216,6 +220,17 @@ class Plan:
     @property
     def break_pixel(self) -> int:
         return lib().sgz_plan_break_pixel(self.h)
+
+    @property
+    def path(self) -> int:
+        """SGZ_PATH_*: 0 generic, 1 fused, 2 halves (+4: per-side LDS map usable)"""
+        return lib().sgz_plan_path(self.h)
+
+    def dc_pixels(self) -> np.ndarray:
+        n = lib().sgz_plan_dc_pixels(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.uint32)
+        lib().sgz_plan_dc_pixels(self.h, _np_ptr(out), n)
+        return out[:n]
 
     def window(self) -> np.ndarray:
         out = np.zeros(self.N, np.float32)

@@ -300,6 +300,21 @@ sgz_status sgz_plan_upload(sgz_plan *plan)
 uint32_t sgz_plan_transform_size(const sgz_plan *plan) { return plan ? plan->impl.N : 0; }
 double sgz_plan_window_scale(const sgz_plan *plan) { return plan ? plan->impl.windowScale : 0.0; }
 uint32_t sgz_plan_break_pixel(const sgz_plan *plan) { return plan ? plan->impl.breakPixel : 0; }
+uint32_t sgz_plan_path(const sgz_plan *plan)
+{
+    if (!plan) return SGZ_PATH_GENERIC;
+    const Plan &p = plan->impl;
+    if (p.fused) return SGZ_PATH_FUSED;
+    if (p.halves) return SGZ_PATH_HALVES | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u);
+    return SGZ_PATH_GENERIC;
+}
+uint32_t sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap)
+{
+    if (!plan) return 0;
+    const std::vector<uint32_t> &v = plan->impl.dcPixels;
+    for (size_t i = 0; out && i < v.size() && i < cap; ++i) out[i] = v[i];
+    return uint32_t(v.size());
+}
 
 sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out)
 {

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from signalizer_amd import api, config
+from signalizer_amd import api, config, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -73,6 +73,37 @@ def test_config_validation_mirrors_reference_assertions():
             api.Plan(config.spectrum_config(**bad))
         assert e.value.status == api.SGZ_EINVAL
     api.Plan(config.spectrum_config(channel_mode=config.CH_PHASE))     # every channel mode has host tables
+
+
+def test_path_selection():
+    """which K_A implementation a configuration selects"""
+    P = lambda **kw: api.Plan(config.spectrum_config(**kw)).path
+    assert P(window_size=4096, hop=1024) == 1 and P(window_size=32768, hop=8192) == 1
+    assert P(window_size=3000, hop=750) == 1                                  # zero-padded to 4096
+    assert P(window_size=65536, hop=16384, sample_rate=96000.0) == 2 | 4        # cfg5: halves + per-side LDS map
+    assert P(window_size=8192, hop=2048, channel_mode=config.CH_MERGE) == 2 | 4
+    assert P(window_size=8192, hop=2048, channel_mode=config.CH_COMPLEX) == 2   # whole-spectrum view: generic map kernel
+    assert P(window_size=16384, hop=4096) == 0 and P(window_size=20, hop=7, axis_points=16) == 0
+    for W in (4096, 8192, 32768):                                              # Phase keeps complex bins: generic at any size
+        assert P(window_size=W, hop=W // 4, channel_mode=config.CH_PHASE) == 0
+
+
+def test_complex_mode_dc_pixel_list(oracle):
+    """the pixels of a Complex view whose csp is complex in the oracle (csf[0] stays complex, TransformDSP.inl:993) are
+    exactly the ones the plan lists for the complex redo"""
+    po = oracle
+    for W, interp in ((4096, config.INTERP_LANCZOS), (2048, config.INTERP_LINEAR), (8192, config.INTERP_LANCZOS), (4096, config.INTERP_NONE)):
+        cfg = config.spectrum_config(sample_rate=96000.0, window_size=W, hop=W // 4, axis_points=300, channel_mode=config.CH_COMPLEX,
+                                     bin_interp=interp)
+        x = synth.gen(41, 96000, W, 2) + 0.25
+        x[1] -= 0.6
+        r = po.spectrogram(po.params_from_dict(cfg), x.astype(np.float32), want_mapped=True)
+        complex_px = set(np.nonzero(r["mapped"][0, 0, :300].imag != 0)[0].tolist())
+        listed = set(api.Plan(cfg).dc_pixels().tolist())
+        assert complex_px <= listed, (W, interp, sorted(complex_px - listed))
+        # listed but real in the oracle: only a tap weight of exactly zero can do that
+        assert len(listed - complex_px) <= 2, (W, interp, sorted(listed - complex_px))
+    assert api.Plan(config.spectrum_config(window_size=4096, hop=1024)).dc_pixels().size == 0
 
 
 def test_library_exports_every_symbol_the_header_declares():
