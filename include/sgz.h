@@ -102,8 +102,8 @@ double     sgz_plan_window_scale(const sgz_plan *plan);                        /
 uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /* first max-of-bins pixel */
 /* which K_A implementation the transform size and channel mode select: SGZ_PATH_FUSED: N = R^3
  * (4096, 32768) in one workgroup; SGZ_PATH_HALVES: N = 2 R^3 (8192, 65536) as two half-frame workgroups + a map kernel;
- * SGZ_PATH_GENERIC: HBM-resident passes (every other size, and Phase at any size).  Bit SGZ_PATH_SIDE_MAP: the halves
- * path can use its LDS-staged per-side map kernel (the view's records stay inside the staged csf range). */
+ * SGZ_PATH_GENERIC: HBM-resident passes (every other size, and Phase at any size).  Bit SGZ_PATH_SIDE_MAP: the halves /
+ * generic path can use the LDS-staged per-side map kernel (the view's records stay inside the staged csf range). */
 #define SGZ_PATH_GENERIC  0u
 #define SGZ_PATH_FUSED    1u
 #define SGZ_PATH_HALVES   2u

@@ -192,7 +192,8 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             ph.csfIn = reinterpret_cast<const float2 *>(d_binsIn);
         }
         SGZ_HIP(launchGeneric(prm, p.N, reinterpret_cast<const float2 *>(p.d_twN), reinterpret_cast<float2 *>(p.d_work0),
-                              reinterpret_cast<float2 *>(p.d_work1), p.d_binsWork, long(p.workSlab), stream, phase ? &ph : nullptr));
+                              reinterpret_cast<float2 *>(p.d_work1), p.d_binsWork, long(p.workSlab), stream, phase ? &ph : nullptr,
+                              p.sideMapOk && !phase));
         return SGZ_OK;
     }
     const int grid = int(tasks);                 // one workgroup per (frame, pair); the dispatcher refills CUs
@@ -305,8 +306,7 @@ uint32_t sgz_plan_path(const sgz_plan *plan)
     if (!plan) return SGZ_PATH_GENERIC;
     const Plan &p = plan->impl;
     if (p.fused) return SGZ_PATH_FUSED;
-    if (p.halves) return SGZ_PATH_HALVES | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u);
-    return SGZ_PATH_GENERIC;
+    return (p.halves ? SGZ_PATH_HALVES : SGZ_PATH_GENERIC) | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u);
 }
 uint32_t sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap)
 {

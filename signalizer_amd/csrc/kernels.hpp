@@ -60,7 +60,7 @@ struct PhaseTables {
     const float2 *csfIn;      // test hook: map from these complex bins (skip the FFT)
 };
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
-                         long slab, hipStream_t stream, const PhaseTables *phase = nullptr);
+                         long slab, hipStream_t stream, const PhaseTables *phase = nullptr, bool sideMap = false);
 
 struct DecayParams {
     const float *mapped;      // [frames][C][sides][P]

@@ -525,8 +525,9 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         if (hit) p.dcPixels.push_back(uint32_t(r));
     }
     buildTwiddles(p);
-    // halves path: mapSideKernel stages k in [N-15, N] + [0, N/2+31] for the left side, [N/2-16, N] + [0, 30] for the right
-    p.sideMapOk = p.halves;
+    // halves and generic paths: mapSideKernel stages k in [N-15, N] + [0, N/2+31] for the left side, [N/2-16, N] + [0, 30] for the right
+    // (Complex: the generic map kernel, whose csf order the complex DC redo reads)
+    p.sideMapOk = !p.fused && p.cfg.channel_mode != SGZ_CH_PHASE && p.cfg.channel_mode != SGZ_CH_COMPLEX;
     for (size_t r = 0; r < p.recs.size() && p.sideMapOk; ++r) {
         const PixelRec &rec = p.recs[r];
         const bool right = r >= size_t(p.P);

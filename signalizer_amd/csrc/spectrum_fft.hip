@@ -66,7 +66,8 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     SGZ_CLK(0);
     mapper.prefetchTables(v, tid);
     const float *src = bins + size_t(task) * (size_t(N) + 1);
-    // csf arrives as the two half-frame workgroups wrote it: even bins [0, N/2] (csf[N] last), then the odd bins
+    const bool split = prm.binsSplit != 0;
+    // split: csf as the two half-frame workgroups wrote it -- even bins [0, N/2] (csf[N] last), then the odd bins
     // LB independent loads in flight per thread (N = 65536: 33 elements per thread = two round trips; N = 8192: one of 5)
     auto stage = [&](auto lb) {
         constexpr int LB = decltype(lb)::value;
@@ -78,7 +79,7 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
                 int k = i - at.off;
                 k = k < 0 ? k + int(N) + 1 : k;
                 k = k > int(N) ? int(N) : k;                           // (past the end: any valid address, the value is dropped)
-                const int e = (k & 1) ? half + 1 + (k >> 1) : (k >> 1);
+                const int e = !split ? k : ((k & 1) ? half + 1 + (k >> 1) : (k >> 1));
                 val[u] = src[e];
             }
 #pragma unroll

@@ -349,7 +349,7 @@ hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins
 
 // Runs the generic path for tasks [0, ntasks) in slabs that fit the work buffers (work0/work1: complex [slab][N]).
 hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, float2 *work0, float2 *work1, float *binsWork,
-                         long slab, hipStream_t stream, const PhaseTables *phase)
+                         long slab, hipStream_t stream, const PhaseTables *phase, bool sideMap)
 {
     const long tasks = prm.frames * long(prm.C);
     uint32_t log2N = 0;
@@ -391,7 +391,13 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
         } else {
             bins = prm.binsIn + size_t(t0) * (size_t(N) + 1);
         }
-        if (prm.mapped) {
+        if (prm.mapped && sideMap && mapSidesFit(prm, N)) {
+            // LDS-staged per-side map (spectrum_fft.hip): one coalesced pass over csf instead of 16-lane gathers per pixel
+            StftParams p2 = prm;
+            p2.binsSplit = 0;
+            hipError_t e2 = launchMapSides(p2, N, bins, nt, prm.mapped + size_t(t0) * prm.sides * prm.P, stream);
+            if (e2 != hipSuccess) return e2;
+        } else if (prm.mapped) {
             hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,
                                prm.recs, prm.weights, prm.invSize, nt, prm.mapped + size_t(t0) * prm.sides * prm.P);
             if (prm.binsIn == nullptr) {
