@@ -1,7 +1,7 @@
 // spectrum_generic.hip -- K_A for ANY power-of-two transform size (32 <= N, not only the fused 4096 / 32768
 // kernel of spectrum_fft.hip): the same stages as separate HBM-resident kernels.  gfx950 only.
 //
-//   genericPrepare : prepareTransform (Source/Spectrum/TransformDSP.inl:39-231)   audio x window -> complex [tasks][N]
+//   PrepSource     : prepareTransform (Source/Spectrum/TransformDSP.inl:39-231)   audio x window, read by the first FFT pass
 //   genericStage   : one radix-16 (first pass: 2/4/8 if needed) Stockham autosort pass of the forward DFT, ping-pong in HBM
 //                    (doTransform, :487-502 -- natural order, unnormalised)
 //   genericBins    : two-for-one split + DC/Nyquist fix-ups + |.|  (:858-869 ; mono :553-560)  -> csf magnitudes [N+1]
@@ -13,48 +13,53 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "complex_dc.hpp"
 #include "fft_common.hpp"
 #include "kernels.hpp"
 
 namespace sgz {
 
-__global__ void __launch_bounds__(256)
-genericPrepare(const float *planar, size_t chStride, uint32_t hop, uint32_t W, uint32_t N, uint32_t C, uint32_t mode,
-               const float *window, long task0, long ntasks, float2 *out)
-{
-    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= size_t(ntasks) * N) return;
-    const long t = long(gid / N);
-    const uint32_t n = uint32_t(gid - size_t(t) * N);
-    const long task = task0 + t;
-    const long frame = task / C;
-    const uint32_t pair = uint32_t(task - frame * C);
-    float xr = 0.f, xi = 0.f;
-    if (n < W) {
-        const float *L = planar + size_t(2 * pair) * chStride + size_t(frame) * hop;
-        const float l = L[n], r = L[chStride + n], w = window[n];
-        switch (mode) {                                           // TransformDSP.inl:59-216
-        case SGZ_CH_LEFT: xr = l * w; break;
-        case SGZ_CH_RIGHT: xr = r * w; break;
-        case SGZ_CH_MERGE: xr = (l + r) * w * 0.5f; break;
-        case SGZ_CH_SIDE: xr = (l - r) * w * 0.5f; break;
-        case SGZ_CH_MIDSIDE: xr = (l + r) * w * 0.5f; xi = (l - r) * w * 0.5f; break;
-        default: xr = l * w; xi = r * w; break;
+// prepareTransform (TransformDSP.inl:39-231): windowed, channel-mixed, zero-padded input sample n of task task0 + t
+struct PrepSource {
+    const float *planar;
+    size_t chStride;
+    uint32_t hop, W, C, mode;
+    const float *window;
+    long task0;
+    __device__ __forceinline__ float2 operator()(long t, uint32_t n) const
+    {
+        const long task = task0 + t;
+        const long frame = task / C;
+        const uint32_t pair = uint32_t(task - frame * C);
+        float xr = 0.f, xi = 0.f;
+        if (n < W) {
+            const float *L = planar + size_t(2 * pair) * chStride + size_t(frame) * hop;
+            const float l = L[n], r = L[chStride + n], w = window[n];
+            switch (mode) {                                       // TransformDSP.inl:59-216
+            case SGZ_CH_LEFT: xr = l * w; break;
+            case SGZ_CH_RIGHT: xr = r * w; break;
+            case SGZ_CH_MERGE: xr = (l + r) * w * 0.5f; break;
+            case SGZ_CH_SIDE: xr = (l - r) * w * 0.5f; break;
+            case SGZ_CH_MIDSIDE: xr = (l + r) * w * 0.5f; xi = (l - r) * w * 0.5f; break;
+            default: xr = l * w; xi = r * w; break;
+            }
         }
+        return make_float2(xr, xi);
     }
-    out[gid] = make_float2(xr, xi);
-}
+};
 
 // Stockham autosort radix-RX DIF pass (RX = 2, 4, 8 or 16).  Before the pass the transform is N = RX * l * m with m the
 // product of the earlier radices:   for j < l, k < m:
 //   y[k + (RX j + q) m] = W_{RX l}^{j q} * sum_t x[k + j m + t l m] W_RX^{t q},   q < RX
 // One thread per (j, k): RX strided loads (coalesced across threads), the RX-point DIF in registers (fft_common.hpp), one
 // twiddle per output from the W_N table (W_{RX l}^{j q} = W_N^{j q m}; the table holds i < N/2, W_N^{i + N/2} = -W_N^i).
-// Radix 16 moves the data through HBM/L2 log16 N times instead of log2 N.
-template <int RX>
+// Radix 16 moves the data through HBM/L2 log16 N times instead of log2 N.  FIRST: the pass reads the audio itself
+// (window, channel mix and zero padding fused: no separate prepare pass).
+template <int RX, bool FIRST>
 __global__ void __launch_bounds__(256)
-genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, uint32_t N, uint32_t m, long ntasks)
+genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, uint32_t N, uint32_t m, long ntasks, const PrepSource prep)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint32_t per = N / RX;                                  // butterflies per transform = l * m
@@ -66,7 +71,10 @@ genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, u
     float2 *yo = y + size_t(t) * N;
     float re[RX], im[RX];
 #pragma unroll
-    for (int tt = 0; tt < RX; ++tt) { const float2 v = xi[b + size_t(tt) * per]; re[tt] = v.x; im[tt] = v.y; }
+    for (int tt = 0; tt < RX; ++tt) {
+        const float2 v = FIRST ? prep(t, b + uint32_t(tt) * per) : xi[b + size_t(tt) * per];
+        re[tt] = v.x; im[tt] = v.y;
+    }
     dif<float, RX, RX, 0>(re, im);                                // output q at register brev(q)
     constexpr int LRX = RX == 16 ? 4 : (RX == 8 ? 3 : (RX == 4 ? 2 : 1));
 #pragma unroll
@@ -298,17 +306,26 @@ static inline unsigned gridFor(size_t total) { return unsigned((total + 255) / 2
 
 // all passes of the forward FFT, ping-ponging between the two work buffers; on return `src` holds the spectrum.
 // Radix 16 passes, preceded by one pass of radix 2, 4 or 8 when log2 N is not a multiple of 4.
-static void runStages(float2 *&src, float2 *&dst, const float2 *twN, uint32_t N, uint32_t log2N, long nt, hipStream_t stream)
+// The first pass reads the audio (prep) and writes `dst`; the passes ping-pong from there; on return `src` holds the transform.
+static void runStages(const PrepSource &prep, float2 *&src, float2 *&dst, const float2 *twN, uint32_t N, uint32_t log2N, long nt,
+                      hipStream_t stream)
 {
     uint32_t m = 1, left = log2N;
+    bool first = true;
+    auto launch = [&](auto rx, auto isFirst, size_t threads) {
+        hipLaunchKernelGGL((genericStage<decltype(rx)::value, decltype(isFirst)::value>), dim3(gridFor(threads)), dim3(256), 0, stream, src,
+                           dst, twN, N, m, nt, prep);
+    };
     auto pass = [&](int lr) {
         const size_t threads = size_t(nt) * (N >> lr);
+        using T = std::true_type; using F = std::false_type;
         switch (lr) {
-        case 1: hipLaunchKernelGGL(genericStage<2>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
-        case 2: hipLaunchKernelGGL(genericStage<4>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
-        case 3: hipLaunchKernelGGL(genericStage<8>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
-        default: hipLaunchKernelGGL(genericStage<16>, dim3(gridFor(threads)), dim3(256), 0, stream, src, dst, twN, N, m, nt); break;
+        case 1: first ? launch(std::integral_constant<int, 2>{}, T{}, threads) : launch(std::integral_constant<int, 2>{}, F{}, threads); break;
+        case 2: first ? launch(std::integral_constant<int, 4>{}, T{}, threads) : launch(std::integral_constant<int, 4>{}, F{}, threads); break;
+        case 3: first ? launch(std::integral_constant<int, 8>{}, T{}, threads) : launch(std::integral_constant<int, 8>{}, F{}, threads); break;
+        default: first ? launch(std::integral_constant<int, 16>{}, T{}, threads) : launch(std::integral_constant<int, 16>{}, F{}, threads); break;
         }
+        first = false;
         m <<= lr; left -= uint32_t(lr);
         float2 *tmp = src; src = dst; dst = tmp;
     };
@@ -360,10 +377,9 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             // Phase: prepare -> FFT passes -> complex csf (in the first work buffer the passes leave free) -> map
             const float2 *csf;
             if (phase->csfIn == nullptr) {
-                hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
-                                   prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
+                const PrepSource prep{prm.planar, prm.chStride, prm.hop, prm.W, prm.C, prm.mode, prm.window, t0};
                 float2 *src = work0, *dst = work1;
-                runStages(src, dst, twN, N, log2N, nt, stream);
+                runStages(prep, src, dst, twN, N, log2N, nt, stream);
                 // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
                 float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
                 hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout);
@@ -380,10 +396,9 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
         }
         const float *bins;
         if (prm.binsIn == nullptr) {
-            hipLaunchKernelGGL(genericPrepare, dim3(gridFor(size_t(nt) * N)), dim3(256), 0, stream, prm.planar, prm.chStride, prm.hop,
-                               prm.W, N, prm.C, prm.mode, prm.window, t0, nt, work0);
+            const PrepSource prep{prm.planar, prm.chStride, prm.hop, prm.W, prm.C, prm.mode, prm.window, t0};
             float2 *src = work0, *dst = work1;
-            runStages(src, dst, twN, N, log2N, nt, stream);
+            runStages(prep, src, dst, twN, N, log2N, nt, stream);
             float *bout = prm.binsOut ? prm.binsOut + size_t(t0) * (size_t(N) + 1) : binsWork;
             hipLaunchKernelGGL(genericBins, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, prm.sides,
                                prm.mode, nt, bout, prm.dcOut);
