@@ -131,7 +131,8 @@ long       sgz_num_frames(size_t nsamples, uint32_t window_size, uint32_t hop);
  * d_lines:    optional DEVICE float2 [frames][pairs][graphs][P] (lineGraphs[k].results, TransformPair.h:63-94)
  * d_state:    optional DEVICE float2 [pairs][graphs][P] peak-decay state, read as carry-in and
  *             updated to the state after the last frame (lineGraphs[k].states); NULL = start from zero.
- * Asynchronous on `stream`; the caller synchronises.
+ * Asynchronous on `stream`; the caller synchronises.  Fewer samples than one window: nothing is rendered and the call
+ * returns SGZ_SKIPPED_FRAME (prepareTransform returns false, TransformDSP.inl:45-46); sgz_spectrogram_render likewise.
  */
 sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, size_t channel_stride,
                                          size_t nsamples, uint8_t *d_rgba, float *d_lines,

@@ -373,9 +373,9 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    if (!d_planar || (!d_rgba && !d_lines)) return fail(SGZ_EINVAL, "null buffer");
     const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
-    if (frames <= 0) return SGZ_OK;
+    if (frames <= 0) return SGZ_SKIPPED_FRAME;      // less than one window: prepareTransform returns false (TransformDSP.inl:45-46)
+    if (!d_planar || (!d_rgba && !d_lines)) return fail(SGZ_EINVAL, "null buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P);
     if (st != SGZ_OK) return st;
@@ -405,7 +405,7 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
         for (hipEvent_t e : {e0, e1, e2, e3}) if (e) (void)hipEventDestroy(e);
         sgz_plan_destroy(plan);
     };
-    if (frames <= 0) { cleanup(); if (timing) *timing = sgz_timing{}; return SGZ_OK; }
+    if (frames <= 0) { cleanup(); if (timing) *timing = sgz_timing{}; return SGZ_SKIPPED_FRAME; }
 #define SGZ_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hipFail(_e, #call); } } while (0)
     SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_audio), size_t(num_channels) * nsamples * sizeof(float)));
     SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_rgba), size_t(frames) * p.P * 4));

@@ -288,6 +288,64 @@ def test_complex_mode_dc_bin(gpu, oracle, W, interp, view):
     assert err <= BIN_TOL * np.abs(ref).max(), (err, np.abs(ref).max())
 
 
+def test_full_size_cfg5_properties(gpu):
+    """BASELINE cfg5 sizes on one GPU (N = 65536, 8 of the 32 pairs, 10 s => 55 frames per pair, several slabs of the halves
+    path): (i) shift: frames [k, k+m) of the full render == render of the shifted buffer when decay is off; (ii) a pair rendered
+    alone equals its lines inside the multi-pair render (the blend is the only cross-pair step); (iii) dB linearity."""
+    import torch
+    cfg = config.cfg5(pairs=8)
+    cfg["pole"] = (0.0, 0.0)
+    S = 10 * 96000
+    x = _planar_cuda(synth.gen(5, 96000, S, 16), gpu)
+    plan = api.Plan(cfg).upload()
+    assert plan.path == 2 | 4
+    F = plan.num_frames(S)
+    assert F == 55
+    lines = torch.empty((F, 8, 2, plan.P, 2), dtype=torch.float32, device=gpu)
+    full = plan.render(x, lines=lines).cpu().numpy()
+    k, m = 20, 7
+    sub = plan.render(x[:, k * 16384:k * 16384 + 65536 + (m - 1) * 16384].contiguous()).cpu().numpy()
+    assert np.array_equal(sub, full[k:k + m])
+    one = dict(cfg, num_pairs=1)
+    plan1 = api.Plan(one).upload()
+    lines1 = torch.empty((F, 1, 2, plan.P, 2), dtype=torch.float32, device=gpu)
+    plan1.render(x[6:8].contiguous(), lines=lines1)
+    assert np.array_equal(lines1.cpu().numpy()[:, 0], lines.cpu().numpy()[:, 3])
+    lines2 = torch.empty_like(lines)
+    plan.render((x * 0.5).contiguous(), lines=lines2)
+    a, b = lines.cpu().numpy(), lines2.cpu().numpy()
+    ok = (a > -1) & (b > -1)
+    assert np.abs((a - b)[ok] - 20 * np.log10(2.0) / 120.0).max() < 1e-4
+
+
+@pytest.mark.parametrize("W,P", [(32768, 3000), (4096, 2500)])
+def test_tall_view_serial_map_fallback(gpu, oracle, W, P):
+    """views whose arg-max pieces do not fit in LDS beside the csf array: the fused kernel's serial per-pixel scan"""
+    po = oracle
+    cfg = config.spectrum_config(window_size=W, hop=W // 4, axis_points=P)
+    frames = 3
+    x = synth.gen(43, 48000, W + (frames - 1) * (W // 4), 2)
+    r = po.spectrogram(po.params_from_dict(cfg), x, want_mapped=True)
+    m = r["mapped"].reshape(frames, 1, 2, P)
+    ref = np.sqrt((m.real.astype(np.float32) ** 2 + m.imag.astype(np.float32) ** 2).astype(np.float32))
+    got = api.Plan(cfg).upload().stage_mapped(_planar_cuda(x, gpu)).cpu().numpy()
+    assert np.abs(got - ref).max() <= BIN_TOL * np.abs(ref).max()
+
+
+def test_degenerate_inputs(gpu):
+    """a buffer shorter than one window renders zero frames (the reference skips the frame, TransformDSP.inl:45-46); exactly
+    one window renders one; a ragged tail is ignored"""
+    import torch
+    for W in (4096, 8192, 2048):
+        plan = api.Plan(config.spectrum_config(window_size=W, hop=W // 4)).upload()
+        x = torch.zeros((2, W - 1), dtype=torch.float32, device=gpu)
+        assert plan.num_frames(W - 1) == 0 and plan.render(x).shape[0] == 0
+        y = torch.from_numpy(synth.gen(3, 48000, W + W // 4 + 17, 2)).to(gpu)
+        full = plan.render(y).cpu().numpy()
+        assert full.shape[0] == 2
+        assert np.array_equal(plan.render(y[:, :W].contiguous()).cpu().numpy(), full[:1])
+
+
 def test_unsupported_and_errors(gpu):
     with pytest.raises(api.SgzError):
         api.Plan(config.spectrum_config(axis_points=1))
