@@ -144,6 +144,16 @@ def main() -> None:
 
     # dominant kernel (stftMapKernel): its own launches timed with HIP events on the launch stream
     kern_ms = shard.time_stft_kernel(iters=50)
+    # outside the timed region: latency of one render from an idle GPU, and the two all-gathers on their own
+    shots = []
+    for _ in range(20):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        shots.append((time.perf_counter() - ts) * 1e3)
+    single_shot_ms = float(np.median(shots))
+    coll_ms = shard.time_collectives(iters=20) if world > 1 else 0.0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,7 +175,8 @@ def main() -> None:
             "config": {"workload": "BASELINE.json configs[1]: stereo 48 kHz spectrogram, 32768-pt FFT, 75% overlap "
                                    "(hop 8192), 60 s buffer => 348 frames/GPU, P=1024, Hann, Separate, Lanczos, log view",
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
-                       "gpu_ms_per_step_rank0": gpu_ms / args.steps},
+                       "gpu_ms_per_step_rank0": gpu_ms / args.steps, "single_shot_ms": single_shot_ms,
+                       "collectives_ms_per_step": coll_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(),
                          "kernel": "stftMapKernel<5, 0, true>", "kernel_ms": kern_ms,

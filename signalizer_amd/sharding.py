@@ -142,6 +142,23 @@ class TimeChunkRenderer:
             self.backend.stage_decay_colour(self.mapped, self.local_frames, self.rgba, self.carry)
         return self.rgba
 
+    def time_collectives(self, iters: int = 20) -> float:
+        """average wall time (ms) of one render's two all-gathers (A1 halo, A2 decay carry) on their own"""
+        import time
+        import torch.distributed as dist
+        torch = self.torch
+        if self.world == 1:
+            return 0.0
+        sync = torch.cuda.synchronize if self.buf.is_cuda else (lambda: None)
+        for i in range(iters + 3):
+            if i == 3:
+                sync(); dist.barrier(); sync()
+                t0 = time.perf_counter()
+            dist.all_gather_into_tensor(self.halo_all.view(-1), self.halo_send.view(-1))
+            dist.all_gather_into_tensor(self.agg_all.view(-1), self.state.view(-1))
+        sync(); dist.barrier(); sync()
+        return (time.perf_counter() - t0) / iters * 1e3
+
     def time_stft_kernel(self, iters: int = 50) -> float:
         """average duration (ms) of the dominant kernel's launches, HIP events on the launch stream"""
         import ctypes

@@ -120,6 +120,7 @@ def _worker(rank, world, port, cfg, S, q):
     chunk = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy())
     r = TimeChunkRenderer(_FakePlan(cfg), chunk, rank=rank, world=world, backend=OracleBackend(cfg))
     out = r.render()[:r.local_frames].numpy().copy()
+    assert r.time_collectives(iters=2) > 0.0          # bench.py's collective-share probe runs on this backend too
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
