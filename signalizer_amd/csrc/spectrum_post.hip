@@ -105,14 +105,15 @@ __global__ void __launch_bounds__(256) decayEmitKernel(const DecayParams prm, co
 // (left, right).  The magnitude is the usual peak decay, the phase a one-pole smoother  s = p + pole^0.3 (s - p)  of
 // p = cancellation * mag (multiplied again for every graph: quirk Q7) -- a linear fp32 recurrence whose rounding depends on
 // the order, so this kernel walks the frames sequentially: one thread per (pair, pixel), magnitudes fetched 8 frames ahead.
-__global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams prm, float *work /*[frames][C][P] main-graph dB*/)
+// Only the recurrences run here (C * P threads for the whole time axis): the filter states go out raw, and the fp64 log of
+// the dB map is applied by kernels with one thread per value (decayPhaseLinesKernel, decayPhaseColourKernel).
+__global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams prm, float *work /*[frames][C][P] main-graph state*/)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= size_t(prm.C) * prm.P) return;
     const uint32_t pair = uint32_t(gid / prm.P), pixel = uint32_t(gid - size_t(pair) * prm.P);
     const size_t perFrame = size_t(prm.C) * 2 * prm.P;
     const float *src = prm.mapped + size_t(pair) * 2 * prm.P + pixel;
-    const float slope = prm.slope[pixel];
     float sm[G], sp[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) {
@@ -139,13 +140,12 @@ __global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams pr
                 if (mag > sm[k]) sm[k] = mag;
                 phase = phase * mag;                                // inside the graph loop (Q7)
                 sp[k] = phase + prm.sc.phasePole[k] * (sp[k] - phase);
-                const float rm = dbMap(slope, sm[k], prm.sc);
                 if (prm.lines) {
                     float *l = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
-                    l[0] = rm;
-                    l[1] = dbMap(slope, sp[k], prm.sc);
+                    l[0] = sm[k];
+                    l[1] = sp[k];
                 }
-                if (k == 0) work[(size_t(f) * prm.C + pair) * prm.P + pixel] = rm;
+                if (k == 0) work[(size_t(f) * prm.C + pair) * prm.P + pixel] = sm[0];
             }
         }
     }
@@ -158,7 +158,16 @@ __global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams pr
     }
 }
 
-// colour columns from the main graph's dB magnitudes: one thread per (frame, pixel), pairs blended in order
+// lines: raw (magnitude, phase) filter states -> dB, in place; one thread per value
+__global__ void __launch_bounds__(256) decayPhaseLinesKernel(const DecayParams prm)
+{
+    const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= size_t(prm.frames) * prm.C * G * prm.P * 2) return;
+    const uint32_t pixel = uint32_t((gid >> 1) % prm.P);
+    prm.lines[gid] = dbMap(prm.slope[pixel], prm.lines[gid], prm.sc);
+}
+
+// colour columns from the main graph's magnitude states: one thread per (frame, pixel), dB map, pairs blended in order
 __global__ void __launch_bounds__(256) decayPhaseColourKernel(const DecayParams prm, const float *work)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -166,8 +175,10 @@ __global__ void __launch_bounds__(256) decayPhaseColourKernel(const DecayParams 
     const long f = long(gid / prm.P);
     const uint32_t pixel = uint32_t(gid - size_t(f) * prm.P);
     float cb[3] = {0.f, 0.f, 0.f};
+    const float slope = prm.slope[pixel];
     for (uint32_t pair = 0; pair < prm.C; ++pair)
-        blendColour(cb, work[(size_t(f) * prm.C + pair) * prm.P + pixel], prm.colourTables + size_t(pair) * NC * 3, prm.sc);
+        blendColour(cb, dbMap(slope, work[(size_t(f) * prm.C + pair) * prm.P + pixel], prm.sc), prm.colourTables + size_t(pair) * NC * 3,
+                    prm.sc);
     reinterpret_cast<uchar4 *>(prm.rgba)[gid] = toRgba8(cb);
 }
 
@@ -175,6 +186,10 @@ hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t str
 {
     const size_t n1 = size_t(prm.C) * prm.P;
     hipLaunchKernelGGL(decayPhaseScanKernel, dim3(unsigned((n1 + 255) / 256)), dim3(256), 0, stream, prm, work);
+    if (prm.lines) {
+        const size_t n3 = size_t(prm.frames) * prm.C * G * prm.P * 2;
+        hipLaunchKernelGGL(decayPhaseLinesKernel, dim3(unsigned((n3 + 255) / 256)), dim3(256), 0, stream, prm);
+    }
     if (prm.rgba) {
         const size_t n2 = size_t(prm.frames) * prm.P;
         hipLaunchKernelGGL(decayPhaseColourKernel, dim3(unsigned((n2 + 255) / 256)), dim3(256), 0, stream, prm, work);
