@@ -65,20 +65,45 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     const uint32_t k = uint32_t((e / prm.P) % G);
     const float pole = prm.sc.pole[k];
     float c = prm.agg[e];
-    constexpr int B = 48;                                       // aggregates fetched together: one load latency per 48 chunks
-    for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += B) {
-        float a[B];
+    // The launch has C*sides*G*P threads -- one wave per SIMD at best -- and a lone wave issues one instruction per ~4.8
+    // clocks whatever its dependencies (tools/ubench/valu.hip), so the fold costs its instruction count: per chunk one
+    // 32-bit offset bump shared by the load and the store, kMaxChunk multiplies, a compare and a select.  B aggregates are
+    // fetched together, the next batch while this one is folded.
+    constexpr int B = 32;
+    char *base = reinterpret_cast<char *>(prm.agg);
+    const uint32_t stride = uint32_t(per * sizeof(float));
+    uint32_t off = uint32_t(e * sizeof(float)) + stride;             // chunk 1 (the aggregates of a pass stay far below 4 GB)
+    uint32_t d = 1;
+    float a[B], nxt[B];
+    auto fetch = [&](uint32_t o, float (&v)[B]) {
 #pragma unroll
-        for (int j = 0; j < B; ++j) a[j] = prm.agg[size_t(min(d0 + j, prm.numChunks - 1)) * per + e];   // clamped, not predicated
+        for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const float *>(base + (o + uint32_t(j) * stride));
+    };
+    if (d + B <= prm.numChunks) fetch(off, a);
+    while (d + B <= prm.numChunks) {                                    // full batches: no per-chunk predicates
+        const bool more = d + 2 * B <= prm.numChunks;
+        if (more) fetch(off + B * stride, nxt);
 #pragma unroll
         for (int j = 0; j < B; ++j) {
-            if (d0 + j < prm.numChunks) {
 #pragma unroll
-                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;      // every chunk before the last is full
-                if (a[j] > c) c = a[j];
-                prm.agg[size_t(d0 + j) * per + e] = c;
-            }
+            for (int i = 0; i < kMaxChunk; ++i) c = c * pole;          // every chunk before the last is full
+            if (a[j] > c) c = a[j];
+            *reinterpret_cast<float *>(base + off) = c;
+            off += stride;
         }
+        d += B;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) a[j] = nxt[j];
+        }
+    }
+    for (; d < prm.numChunks; ++d) {                                    // tail
+        const float v = *reinterpret_cast<const float *>(base + off);
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) c = c * pole;
+        if (v > c) c = v;
+        *reinterpret_cast<float *>(base + off) = c;
+        off += stride;
     }
 }
 
