@@ -28,7 +28,7 @@
 namespace sgz {
 
 template <int LR, int MIX, bool FULLW>
-__global__ void __launch_bounds__(1 << (2 * LR))
+__global__ void __launch_bounds__(1 << (2 * LR), LR == 4 ? 4 : 1)      // R = 16: four 256-thread workgroups per CU (<= 128 VGPRs)
 stftMapKernel(const StftParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];

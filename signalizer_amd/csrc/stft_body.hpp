@@ -128,7 +128,7 @@ __device__ __forceinline__ MapView wholeView(const StftParams &prm, long task)
 template <int LR, int NT, typename Index = WholeFrameIndex<LR>>
 struct MapPixelsBalanced {
     static constexpr int IB = 4;                                         // items per thread per batch (register budget)
-    static constexpr int RB = NT >= 1024 ? 2 : 4;                        // records per thread per batch
+    static constexpr int RB = 2;                                         // records per thread per batch (register budget)
     static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
     static constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t iw0[IB];
