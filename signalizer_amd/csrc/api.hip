@@ -244,8 +244,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         sgz_status st = ensureCap(&p.d_agg, &p.aggCap, need);
         if (st != SGZ_OK) return st;
         prm.agg = p.d_agg;
-        SGZ_HIP(launchDecayLocal(prm, stream));
-        SGZ_HIP(launchDecayCarry(prm, stream));
+        SGZ_HIP(launchDecayLocalCarry(prm, stream));
     }
     SGZ_HIP(launchDecayEmit(prm, stream));
     return SGZ_OK;

@@ -77,6 +77,7 @@ struct DecayParams {
     uint8_t *rgba;            // [frames][P][4] or null
     float *lines;             // [frames][C][G][P][2] or null
 };
+hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream);   // local + carry, one launch when the chunks fit a workgroup
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);

@@ -107,6 +107,66 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     }
 }
 
+// K_B1 + K_B1b in one launch for renders of at most kFusedChunks time chunks (cfg2: 44): a workgroup owns 16 (pair, side,
+// pixel) entries for the whole time axis -- thread (chunk, entry) scans its chunk, the aggregates meet in LDS, 16 * G threads
+// fold them sequentially (the same multiplies as decayCarryKernel), and everybody writes the carried states back.  One
+// launch and one kernel boundary less than the two-kernel form, which long renders keep.
+constexpr int kFusedChunks = 64, kFusedEntries = 16;
+__global__ void __launch_bounds__(kFusedChunks * kFusedEntries) decayLocalCarryKernel(const DecayParams prm)
+{
+    __shared__ float aggS[kFusedChunks][G][kFusedEntries];
+    const size_t perChunk = size_t(prm.C) * prm.sides * prm.P;
+    const int en = threadIdx.x & (kFusedEntries - 1);
+    const uint32_t chunk = threadIdx.x / kFusedEntries;
+    const size_t rem = size_t(blockIdx.x) * kFusedEntries + en;   // (pair, side, pixel) linear
+    const bool live = rem < perChunk && chunk < prm.numChunks;
+    const uint32_t pixel = uint32_t(rem % prm.P);
+    const uint32_t ps = uint32_t(rem / prm.P);                  // pair * sides + side
+    const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
+    if (live) {
+        float a[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+            a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+        const long f0 = long(chunk) * kMaxChunk;
+        const int len = int(min(long(kMaxChunk), prm.frames - f0));
+        float mag[kMaxChunk];
+#pragma unroll
+        for (int t = 0; t < kMaxChunk; ++t) mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem];
+#pragma unroll
+        for (int t = 0; t < kMaxChunk; ++t) {
+            if (t < len) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    a[k] = a[k] * prm.sc.pole[k];               // states[i] *= pole, TransformDSP.inl:1336,:1370
+                    if (mag[t] > a[k]) a[k] = mag[t];           // :1338-1341
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) aggS[chunk][k][en] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < G * kFusedEntries) {
+        const int k = threadIdx.x / kFusedEntries;
+        const float pole = prm.sc.pole[k];
+        float c = aggS[0][k][en];
+        for (uint32_t d = 1; d < prm.numChunks; ++d) {
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) c = c * pole;  // every chunk before the last is full
+            const float v = aggS[d][k][en];
+            if (v > c) c = v;
+            aggS[d][k][en] = c;
+        }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < G; ++k)
+            prm.agg[((size_t(chunk) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] = aggS[chunk][k][en];
+    }
+}
+
 // K_B2 (after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels, so the GPU sees frames*P
 // threads (the fp64 log of dbMap is ~200 instructions; with one thread per (chunk, pixel) a wave would issue eight of them
 // back to back on an otherwise empty SIMD).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) only
@@ -250,6 +310,18 @@ hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, ui
     const int block = 256;
     const unsigned grid = unsigned((perRank + block - 1) / block);
     hipLaunchKernelGGL(decayFoldKernel, dim3(grid), dim3(block), 0, stream, aggs, fr, rank, perRank, P, sc.pole[0], sc.pole[1], carry);
+    return hipGetLastError();
+}
+
+hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream)
+{
+    if (prm.numChunks > uint32_t(kFusedChunks)) {
+        hipError_t e = launchDecayLocal(prm, stream);
+        return e != hipSuccess ? e : launchDecayCarry(prm, stream);
+    }
+    const size_t entries = size_t(prm.C) * prm.sides * prm.P;
+    hipLaunchKernelGGL(decayLocalCarryKernel, dim3(unsigned((entries + kFusedEntries - 1) / kFusedEntries)),
+                       dim3(kFusedChunks * kFusedEntries), 0, stream, prm);
     return hipGetLastError();
 }
 
