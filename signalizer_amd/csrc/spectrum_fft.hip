@@ -23,6 +23,8 @@
 // not add VALU throughput; what they add is cover for the load, LDS-exchange and barrier latencies of a frame whose
 // phases are serialised by data dependencies.  Packed v_pk_*_f32 costs ~4.3 clocks per instruction (two plain ops: 4.8),
 // v_sqrt 8.2, and v_cmp / v_cndmask / v_max / v_min / v_bfe or any instruction with an SGPR source ~4.1.
+#include <atomic>
+
 #include "stft_body.hpp"
 
 namespace sgz {
@@ -98,6 +100,24 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     SGZ_CLK(9);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember, per device, how much each
+// kernel has been granted (atomics: launches may come from several host threads, one process may drive several devices).
+struct LdsGrant {
+    static constexpr int kDevices = 64;
+    std::atomic<size_t> bytes[kDevices];
+    hipError_t ensure(const void *kernel, size_t need)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const bool cached = dev >= 0 && dev < kDevices;
+        if (cached && bytes[dev].load(std::memory_order_acquire) >= need) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(need));
+        if (e == hipSuccess && cached) bytes[dev].store(need, std::memory_order_release);
+        return e;
+    }
+};
+
 static size_t mapSidesLds(const StftParams &prm, uint32_t N)
 {
     const int count = int(N / 2) + 48;
@@ -110,13 +130,8 @@ hipError_t launchMapSides(const StftParams &prm, uint32_t N, const float *bins, 
 {
     const size_t ldsBytes = mapSidesLds(prm, N);
     if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
-    static size_t attrBytes = 0;
-    if (attrBytes < ldsBytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mapSideKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           int(ldsBytes));
-        if (e != hipSuccess) return e;
-        attrBytes = ldsBytes;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = grant.ensure(reinterpret_cast<const void *>(&mapSideKernel), ldsBytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(mapSideKernel, dim3(unsigned(ntasks * prm.sides)), dim3(1024), ldsBytes, stream, prm, bins, N, mapped);
     return hipGetLastError();
 }
@@ -132,13 +147,8 @@ static hipError_t launchHalves(const StftParams &prm, int grid, hipStream_t stre
     static const Kern kerns[4] = {&stftHalfKernel<LR, 1, false>, &stftHalfKernel<LR, 1, true>, &stftHalfKernel<LR, 0, false>,
                                   &stftHalfKernel<LR, 0, true>};
     const int which = (simple ? 2 : 0) + (fullw ? 1 : 0);
-    static bool attrSet[4] = {false, false, false, false};
-    if (!attrSet[which]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           int(ldsBytes));
-        if (e != hipSuccess) return e;
-        attrSet[which] = true;
-    }
+    static LdsGrant grant[4];
+    if (hipError_t e = grant[which].ensure(reinterpret_cast<const void *>(kerns[which]), ldsBytes); e != hipSuccess) return e;
     StftParams p2 = prm;
     p2.items = nullptr;
     hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
@@ -170,13 +180,8 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
     static const Kern kerns[6] = {&stftMapKernel<LR, 0, false>, &stftMapKernel<LR, 0, true>, &stftMapKernel<LR, 1, false>,
                                   &stftMapKernel<LR, 1, true>,  &stftMapKernel<LR, 2, false>, &stftMapKernel<LR, 2, true>};
     const int which = 2 * mix + (fullw ? 1 : 0);
-    static size_t attrBytes[6] = {0, 0, 0, 0, 0, 0};
-    if (attrBytes[which] < ldsBytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           int(ldsBytes));
-        if (e != hipSuccess) return e;
-        attrBytes[which] = ldsBytes;
-    }
+    static LdsGrant grant[6];
+    if (hipError_t e = grant[which].ensure(reinterpret_cast<const void *>(kerns[which]), ldsBytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
     return hipGetLastError();
 }
