@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "decay_body.hpp"      // fp contraction off from here on
 
 namespace sgz {
@@ -111,10 +113,13 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
 // pixel) entries for the whole time axis -- thread (chunk, entry) scans its chunk, the aggregates meet in LDS, 16 * G threads
 // fold them sequentially (the same multiplies as decayCarryKernel), and everybody writes the carried states back.  One
 // launch and one kernel boundary less than the two-kernel form, which long renders keep.
-constexpr int kFusedChunks = 64, kFusedEntries = 16;
-__global__ void __launch_bounds__(kFusedChunks * kFusedEntries) decayLocalCarryKernel(const DecayParams prm)
+// 1024 threads = CH chunk slots x (1024 / CH) entries; CH = the power of two that holds the render's chunks (8 .. 64).
+constexpr int kFusedChunks = 64;
+template <int CH>
+__global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams prm)
 {
-    __shared__ float aggS[kFusedChunks][G][kFusedEntries];
+    constexpr int kFusedEntries = 1024 / CH;
+    __shared__ float aggS[CH][G][kFusedEntries];
     const size_t perChunk = size_t(prm.C) * prm.sides * prm.P;
     const int en = threadIdx.x & (kFusedEntries - 1);
     const uint32_t chunk = threadIdx.x / kFusedEntries;
@@ -320,8 +325,14 @@ hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream)
         return e != hipSuccess ? e : launchDecayCarry(prm, stream);
     }
     const size_t entries = size_t(prm.C) * prm.sides * prm.P;
-    hipLaunchKernelGGL(decayLocalCarryKernel, dim3(unsigned((entries + kFusedEntries - 1) / kFusedEntries)),
-                       dim3(kFusedChunks * kFusedEntries), 0, stream, prm);
+    auto launch = [&](auto ch) {
+        constexpr int CH = decltype(ch)::value;
+        hipLaunchKernelGGL(decayLocalCarryKernel<CH>, dim3(unsigned((entries + 1024 / CH - 1) / (1024 / CH))), dim3(1024), 0, stream, prm);
+    };
+    if (prm.numChunks <= 8) launch(std::integral_constant<int, 8>{});
+    else if (prm.numChunks <= 16) launch(std::integral_constant<int, 16>{});
+    else if (prm.numChunks <= 32) launch(std::integral_constant<int, 32>{});
+    else launch(std::integral_constant<int, 64>{});
     return hipGetLastError();
 }
 
