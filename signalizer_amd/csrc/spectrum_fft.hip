@@ -47,7 +47,7 @@ stftHalfKernel(const StftParams prm)
     stftMapBody<LR, MIX, FULLW, 1>(prm, lds, blockIdx.x, gridDim.x);
 }
 
-// Pixel mapping of one side of one task from HBM-resident csf magnitudes (the halves path): the csf range that side's
+// Pixel mapping of one side of one task from HBM-resident csf magnitudes (halves and generic paths): the csf range that side's
 // records touch -- k in [N-15, N] + [0, N/2+31] on the left, [N/2-16, N] + [0, 30] on the right (plan.cpp checks it) --
 // is staged in LDS and mapped by the fused kernel's balanced scan.  One workgroup per (task, side).
 __global__ void __launch_bounds__(1024)
