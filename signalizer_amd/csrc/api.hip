@@ -124,7 +124,7 @@ static sgz_status ensureDcWork(Plan &p, size_t slab)
 {
     if (p.dcSlab >= slab) return SGZ_OK;
     if (p.d_dcWork) { (void)hipFree(p.d_dcWork); p.d_dcWork = nullptr; }
-    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_dcWork), slab * 2 * sizeof(float)));
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_dcWork), slab * 16 * 2 * sizeof(float)));          // [task][kSpecBins] float2
     p.dcSlab = slab;
     return SGZ_OK;
 }
@@ -162,10 +162,8 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             if (d_mapped) {
                 float *out = d_mapped + size_t(t0) * p.sides * p.P;
                 if (prm.binsSplit) SGZ_HIP(launchMapSides(prm, p.N, bins, nt, out, stream));
-                else {
-                    SGZ_HIP(launchGenericMap(prm, p.N, bins, nt, out, stream));
-                    SGZ_HIP(launchComplexDcFix(prm, p.N, bins, prm.dcOut, nt, out, stream));
-                }
+                else SGZ_HIP(launchGenericMap(prm, p.N, bins, nt, out, stream));
+                SGZ_HIP(launchComplexDcFix(prm, p.N, bins, prm.dcOut, nt, out, stream));
             }
         }
         return SGZ_OK;

@@ -17,11 +17,11 @@ struct StftParams {
     const float2 *tw1;        // [R][T]
     const float2 *tw2;        // [R][R]
     const float2 *tw1odd;     // halves path (N = 2 R^3): pass-1 twiddles of the odd half, W_N^{t (2q+1)} factorised
-    // SpectrumChannels::Complex keeps csf[0] = Z[0] / 2 complex (TransformDSP.inl:993): the pixels whose taps or arg-max run
-    // touch bin 0 (plan.cpp dcPixels) are redone with the complex value after the magnitude-only mapping
+    // Complex and the mono modes leave a few csf entries complex (complex_dc.hpp): the pixels that reach one (plan.cpp dcPixels)
+    // are redone with the complex values after the magnitude-only mapping
     const uint32_t *dcPixels;
     uint32_t nDcPixels;
-    float2 *dcOut;            // generic / halves path: csf[0] of every task of the launch (the fused kernel keeps it in LDS), or null
+    float2 *dcOut;            // generic / halves path: those entries, [task][kSpecBins] (the fused kernel keeps them in LDS), or null
     uint32_t binsSplit;       // halves path: binsOut holds [even bins 0..N/2 | odd bins] per task (launchMapSides) instead of csf order
     long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]
@@ -46,7 +46,7 @@ hipError_t launchStftHalves(const StftParams &prm, uint32_t N, int grid, hipStre
 // side fit in LDS beside its N/2 + 48 floats)
 bool mapSidesFit(const StftParams &prm, uint32_t N);
 hipError_t launchMapSides(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream);
-// Complex mode, after launchGenericMap: redo prm.dcPixels of every task with the complex csf[0] in dc[task]
+// after the map kernel: redo prm.dcPixels of every task with the complex csf entries dc[task][kSpecBins] (prm.binsSplit: layout of bins)
 hipError_t launchComplexDcFix(const StftParams &prm, uint32_t N, const float *bins, const float2 *dc, long ntasks, float *mapped,
                               hipStream_t stream);
 hipError_t launchGenericMap(const StftParams &prm, uint32_t N, const float *bins, long ntasks, float *mapped, hipStream_t stream);

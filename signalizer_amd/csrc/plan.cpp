@@ -511,18 +511,25 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         (void)pieces;                                      // = number of 16-windows the run spans (recomputed on the device)
         if (!right) p.nItemsLeft = uint32_t(p.items.size());
     }
-    // Complex mode: csf[0] stays complex (TransformDSP.inl:993); list the pixels it reaches (complex_dc.hpp redoes them)
+    // The csf entries the reference leaves complex (Complex: csf[0]; Left / Right / Merge / Side: csf[N/2 .. N-1], reached by
+    // filter windows that wrap below bin 0 or sit at Nyquist): list the pixels that touch one (complex_dc.hpp redoes them)
     p.dcPixels.clear();
-    for (size_t r = 0; r < p.recs.size() && cfg.channel_mode == SGZ_CH_COMPLEX; ++r) {
-        const PixelRec &rec = p.recs[r];
-        bool hit = false;
-        if (rec.kind == 0) {
-            long k = rec.a;
-            for (int i = 0; i < rec.b; ++i) { hit = hit || k == 0; k = (k == long(p.N)) ? 0 : k + 1; }
-        } else if (rec.kind & 1) {
-            hit = rec.a <= 0 && long(rec.a) + rec.b > 0;
+    {
+        const uint32_t mode = cfg.channel_mode;
+        const bool mono = mode == SGZ_CH_LEFT || mode == SGZ_CH_RIGHT || mode == SGZ_CH_MERGE || mode == SGZ_CH_SIDE;
+        const long N = long(p.N);
+        auto isComplex = [&](long k) { return mode == SGZ_CH_COMPLEX ? k == 0 : (mono && k >= N / 2 && k < N); };
+        for (size_t r = 0; r < p.recs.size() && (mono || mode == SGZ_CH_COMPLEX); ++r) {
+            const PixelRec &rec = p.recs[r];
+            bool hit = false;
+            if (rec.kind == 0) {
+                long k = rec.a;
+                for (int i = 0; i < rec.b; ++i) { hit = hit || isComplex(k); k = (k == N) ? 0 : k + 1; }
+            } else if (rec.kind & 1) {
+                for (long k = rec.a; k < long(rec.a) + rec.b; ++k) hit = hit || isComplex(k);
+            }
+            if (hit) p.dcPixels.push_back(uint32_t(r));
         }
-        if (hit) p.dcPixels.push_back(uint32_t(r));
     }
     buildTwiddles(p);
     // halves and generic paths: mapSideKernel stages k in [N-15, N] + [0, N/2+31] for the left side, [N/2-16, N] + [0, 30] for the right

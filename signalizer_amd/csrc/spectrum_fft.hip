@@ -140,7 +140,7 @@ template <int LR>
 static hipError_t launchHalves(const StftParams &prm, int grid, hipStream_t stream)
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
-    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4) * sizeof(float);
+    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
     const bool simple = prm.mode == SGZ_CH_SEPARATE || prm.mode == SGZ_CH_COMPLEX;
     const bool fullw = prm.W == uint32_t(2 * N);
     using Kern = void (*)(const StftParams);
@@ -168,7 +168,7 @@ template <int LR>
 static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream)
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
-    const size_t baseBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4) * sizeof(float);
+    const size_t baseBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
     const size_t slotBytes = size_t(prm.nItems) * 8;
     StftParams p2 = prm;
     size_t ldsBytes = baseBytes;

@@ -97,7 +97,7 @@ genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, u
 
 __global__ void __launch_bounds__(256)
 genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long ntasks, float *bins /*[ntasks][N+1]*/,
-            float2 *dcOut /*[ntasks] or null: Complex mode's csf[0] = Z[0] / 2 (TransformDSP.inl:993)*/)
+            float2 *dcOut /*[ntasks][kSpecBins] or null: the csf entries that stay complex (complex_dc.hpp)*/)
 {
     const size_t per = size_t(N) + 1;
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -126,7 +126,13 @@ genericBins(const float2 *z, uint32_t N, uint32_t sides, uint32_t mode, long nta
         }
     }
     bins[gid] = out;
-    if (k == 0 && dcOut) dcOut[t] = make_float2(0.5f * Z[0].x, 0.5f * Z[0].y);
+    if (dcOut && k < N) {
+        const int s = specSlot(mode, int(N), int(k));
+        if (s >= 0) {
+            const float f = specScale(mode, int(N), int(k));
+            dcOut[size_t(t) * kSpecBins + s] = make_float2(f * Z[k].x, f * Z[k].y);
+        }
+    }
 }
 
 // 16 lanes per (task, side, pixel); exact fp32 order of the reference (contraction off).  An interpolated pixel is lane 0's
@@ -333,27 +339,32 @@ static void runStages(const PrepSource &prep, float2 *&src, float2 *&dst, const 
     while (left) pass(4);
 }
 
-// Complex mode: the pixels that touch bin 0, redone with the complex csf[0] (stft_body.hpp complexDcPixel)
+// the pixels that reach a csf entry the reference leaves complex, redone with those entries (complex_dc.hpp); split: csf in
+// the halves path's even / odd layout
 __global__ void __launch_bounds__(64)
-complexDcFixKernel(const float *bins, const float2 *dc, uint32_t N, uint32_t P, const PixelRec *recs, const float *weights,
-                   const uint32_t *dcPixels, uint32_t nDc, float invSize, long ntasks, float *mapped /*[ntasks][P]*/)
+complexDcFixKernel(const float *bins, const float2 *dc, uint32_t N, uint32_t P, uint32_t mode, uint32_t split, const PixelRec *recs,
+                   const float *weights, const uint32_t *dcPixels, uint32_t nDc, float invSize, long ntasks,
+                   float *mapped /*[ntasks][P]*/)
 {
     const size_t gid = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= size_t(ntasks) * nDc) return;
     const long t = long(gid / nDc);
     const uint32_t x = dcPixels[gid - size_t(t) * nDc];
     const float *M = bins + size_t(t) * (size_t(N) + 1);
-    const float2 z0 = dc[t];
-    mapped[size_t(t) * P + x] = complexDcPixel(recs[x], weights, invSize, int(N), z0.x, z0.y, [&](int k) { return M[k]; });
+    const float2 *spec = dc + size_t(t) * kSpecBins;
+    const int half = int(N >> 1);
+    mapped[size_t(t) * P + x] = complexDcPixel(
+        recs[x], weights, invSize, int(N), mode,
+        [&](int k) { return M[!split ? k : ((k & 1) ? half + 1 + (k >> 1) : (k >> 1))]; }, [&](int s) { return spec[s]; });
 }
 
 hipError_t launchComplexDcFix(const StftParams &prm, uint32_t N, const float *bins, const float2 *dc, long ntasks, float *mapped,
                               hipStream_t stream)
 {
-    if (prm.mode != SGZ_CH_COMPLEX || prm.nDcPixels == 0 || dc == nullptr) return hipSuccess;
+    if (prm.nDcPixels == 0 || dc == nullptr) return hipSuccess;       // (the listed pixels are all on side 0: sides == 1 in these modes)
     const size_t n = size_t(ntasks) * prm.nDcPixels;
-    hipLaunchKernelGGL(complexDcFixKernel, dim3(unsigned((n + 63) / 64)), dim3(64), 0, stream, bins, dc, N, prm.P, prm.recs, prm.weights,
-                       prm.dcPixels, prm.nDcPixels, prm.invSize, ntasks, mapped);
+    hipLaunchKernelGGL(complexDcFixKernel, dim3(unsigned((n + 63) / 64)), dim3(64), 0, stream, bins, dc, N, prm.P, prm.mode, prm.binsSplit,
+                       prm.recs, prm.weights, prm.dcPixels, prm.nDcPixels, prm.invSize, ntasks, mapped);
     return hipGetLastError();
 }
 
@@ -411,6 +422,8 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             StftParams p2 = prm;
             p2.binsSplit = 0;
             hipError_t e2 = launchMapSides(p2, N, bins, nt, prm.mapped + size_t(t0) * prm.sides * prm.P, stream);
+            if (e2 == hipSuccess && prm.binsIn == nullptr)
+                e2 = launchComplexDcFix(p2, N, bins, prm.dcOut, nt, prm.mapped + size_t(t0) * prm.sides * prm.P, stream);
             if (e2 != hipSuccess) return e2;
         } else if (prm.mapped) {
             hipLaunchKernelGGL(genericMap, dim3(gridFor(size_t(nt) * prm.sides * prm.P * kMapLanes)), dim3(256), 0, stream, bins, N, prm.P, prm.sides,

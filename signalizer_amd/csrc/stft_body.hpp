@@ -332,8 +332,8 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
 // of the same wave, registers m3 and R-1-m3: the two-for-one split (TransformDSP.inl:858) needs one ds_bpermute per
 // value and no LDS round trip.  Slot 0 holds q = 0 and q = R/2, which mirror onto themselves (other lane pattern);
 // column 0 (q = 0, q2 = 0) mirrors inside thread 0 and is redone from a small LDS scratch by lanes 1..R/2-1.
-// MIX = 0: Separate (re = L w, im = R w); MIX = 1: Left, Right, Merge, Side, MidSide; MIX = 2: Complex (the window of MIX = 0,
-// plus the pixels that touch the complex csf[0], complex_dc.hpp).
+// MIX = 0: Separate (re = L w, im = R w); MIX = 1: Left, Right, Merge, Side, MidSide; MIX = 2: Complex (the window of MIX = 0).
+// MIX != 0 also redoes the pixels that reach a csf entry the reference leaves complex (complex_dc.hpp).
 // FULLW: W == N (no zero padding): plain global loads.  Measured on gfx950 (tools/ubench/stream.hip): a workgroup's
 // 3R strided dword loads complete in ~7-8.6 k clocks as global loads and in ~13 k as raw buffer loads, so the buffer
 // form (whose out-of-range reads return 0 = the zero padding of prepareTransform, :220-223) is kept for W < N only.
@@ -355,7 +355,8 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     constexpr int N = R * T;
     constexpr int PADSTRIDE = T + (T >> LR);          // padded distance between k and k + T
     constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of column 0's 2R-float scratch
-    constexpr int SLOTS = SCRATCH + 2 * R + 4;        // float index (even) of the arg-max piece winners (nItems uint2)
+    constexpr int SPEC = SCRATCH + 2 * R + 4;         // float index of the kSpecBins csf entries that stay complex (complex_dc.hpp)
+    constexpr int SLOTS = SPEC + 2 * kSpecBins;       // float index (even) of the arg-max piece winners (nItems uint2)
     constexpr int TILE = R * (R + 1);
     const int tid = threadIdx.x;
     const bool sgzClkHalf = HALF < 0 || HALF == int((prm.ablate >> 15) & 1u);   // debug clocks: which half reports
@@ -599,6 +600,25 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         } else {
             if (HALF != 1 && tid == 0) { lds[SCRATCH] = c[0].x; lds[SCRATCH + 1] = c[0].y;
                             lds[SCRATCH + R] = c[brev(R / 2, LR)].x; lds[SCRATCH + R + 1] = c[brev(R / 2, LR)].y; }
+            if ((MIX != 0 || HALF >= 0) && (HALF < 0 || prm.dcOut)) {     // (halves: MIX = 0 also serves Complex)
+                // The csf entries the reference leaves complex (complex_dc.hpp), with its scale factor: to LDS for this
+                // kernel's own redo, or (halves) to the task's slots in HBM.  Frame bin N_f - 8 + s lives at kc = T - 8 + s,
+                // m3 = R - 1; N_f / 2 + s at kc = s, m3 = R / 2 (a half owns every other one: bin 2 j + HALF <-> its j).
+                auto put = [&](int s, v2 z, float f) {
+                    if (HALF < 0) { lds[SPEC + 2 * s] = f * z.x; lds[SPEC + 2 * s + 1] = f * z.y; }
+                    else prm.dcOut[size_t(task) * kSpecBins + s] = make_float2(f * z.x, f * z.y);
+                };
+                if (mode == SGZ_CH_COMPLEX) {
+                    if (HALF <= 0 && tid == 0) put(0, c[0], 0.5f);
+                } else {
+                    constexpr int WR = HALF >= 0 ? 4 : 8;              // entries of this workgroup on either side
+                    if (ix == R - 1 && q >= R - WR) put(HALF >= 0 ? 2 * (q - (R - WR)) + HALF : q - (R - WR), c[R - 1], 1.f);
+                    if (ix == 0 && q < WR) {
+                        const int s = HALF >= 0 ? 2 * q + HALF : q;
+                        put(8 + s, c[brev(R / 2, LR)], s == 0 ? 0.5f : 1.f);
+                    }
+                }
+            }
 #pragma unroll
             for (int m3 = 0; m3 < R; ++m3) {                           // csf[k] = |Z[k]| (TransformDSP.inl:553-560, :993-1002)
                 const int i = brev(m3, LR);
@@ -661,7 +681,6 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
 #pragma unroll 8
         for (int k = tid; k < N; k += T) dst[stride * k] = lds[k + (k >> LR)];
         if (HALF == 0 && tid == 0) dst[stride * N] = lds[N + (N >> LR)];
-        if (HALF == 0 && tid == 0 && prm.dcOut) prm.dcOut[task] = make_float2(0.5f * lds[SCRATCH], 0.5f * lds[SCRATCH + 1]);
         SGZ_CLK(8);
         return;
     }
@@ -676,13 +695,13 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         if (balanced) mapper.run(prm, wholeView(prm, task), WholeFrameIndex<LR>{}, lds, win, tid, task);
         else mapPixelsSerial<LR, T>(prm, lds, tid, task);
     }
-    if (MIX == 2 && prm.nDcPixels != 0 && prm.mapped && prm.binsIn == nullptr && !(prm.ablate & 16)) {
+    if (MIX != 0 && prm.nDcPixels != 0 && prm.mapped && prm.binsIn == nullptr && !(prm.ablate & 16)) {
         __syncthreads();                                               // the pixels' first values are written by other threads
-        const float re0 = 0.5f * lds[SCRATCH], im0 = 0.5f * lds[SCRATCH + 1];   // csf[0] *= 0.5 (TransformDSP.inl:993)
         float *out = prm.mapped + size_t(task) * (prm.sides * prm.P);
         for (uint32_t i = tid; i < prm.nDcPixels; i += T) {
             const uint32_t x = prm.dcPixels[i];
-            out[x] = complexDcPixel(prm.recs[x], prm.weights, prm.invSize, N, re0, im0, [&](int k) { return lds[k + (k >> LR)]; });
+            out[x] = complexDcPixel(prm.recs[x], prm.weights, prm.invSize, N, uint32_t(mode), [&](int k) { return lds[k + (k >> LR)]; },
+                                    [&](int s) { return make_float2(lds[SPEC + 2 * s], lds[SPEC + 2 * s + 1]); });
         }
     }
     SGZ_CLK(9);
