@@ -314,6 +314,7 @@ static void buildPhaseRecords(Plan &p)
         }
     }
     p.phaseNormFinal = normalizedPosition;
+    if (filtered) x = long(breakingPoint);      // the magnitude pass leaves x there (:714 / :759): P when the view never breaks
     p.breakPixel = uint32_t(x);
     long oldBin = 0;
     if (x < P) oldBin = long(mf[x] * freqToBin);                         // :806-807
