@@ -109,8 +109,9 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
 #define SGZ_PATH_HALVES   2u
 #define SGZ_PATH_SIDE_MAP 4u
 uint32_t   sgz_plan_path(const sgz_plan *plan);
-/* SpectrumChannels::Complex keeps csf[0] = Z[0]/2 complex (TransformDSP.inl:993): the pixels whose filter taps or arg-max run
- * reach bin 0, redone as complex sums after the magnitude-only mapping.  Returns their count; writes at most `cap`. */
+/* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
+ * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or
+ * sit at Nyquist -- redone as complex sums after the magnitude-only mapping.  Returns their count; writes at most `cap`. */
 uint32_t   sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap);
 sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out /*N*/);
 sgz_status sgz_plan_get_mapped_frequencies(const sgz_plan *plan, float *out /*P*/);
