@@ -36,13 +36,16 @@ def _worker(rank, world, port, cfg, S, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("window,hop,pairs,S", [(4096, 1024, 1, 4096 * 5 + 300), (32768, 8192, 1, 32768 * 3 + 1234)])
-def test_two_rank_sharded_render_equals_single_device(gpu, window, hop, pairs, S):
+@pytest.mark.parametrize("window,hop,pairs,S,world,mode", [
+    (4096, 1024, 1, 4096 * 5 + 300, 2, config.CH_SEPARATE), (32768, 8192, 1, 32768 * 3 + 1234, 2, config.CH_SEPARATE),
+    (8192, 2048, 2, 8192 * 4 + 77, 3, config.CH_SEPARATE),            # halves path, three ranks
+    (2048, 700, 1, 2048 * 6 + 5, 2, config.CH_MERGE),                # generic path, a mono mode, hop not dividing the chunk
+    (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE)])             # four ranks, three pairs
+def test_sharded_render_equals_single_device(gpu, window, hop, pairs, S, world, mode):
     import torch
     import torch.multiprocessing as mp
     from signalizer_amd import api
-    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=300, pole=(0.97, 0.5))
-    world = 2
+    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=300, pole=(0.97, 0.5), channel_mode=mode)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
