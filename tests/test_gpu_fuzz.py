@@ -34,3 +34,16 @@ def test_random_configurations_match_the_oracle(gpu, oracle, seed, wild):
         if got.shape != ref.shape or d.max() > (2 if phase else 1) or (d > 0).mean() > (2e-2 if phase else 5e-3):
             bad.append((it, plan.N, plan.path, cfg["channel_mode"], int(d.max()), float((d > 0).mean())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("tool,count", [("fuzz_stages.py", 40), ("fuzz_realtime.py", 30), ("fuzz_scope.py", 30)])
+def test_stage_realtime_and_scope_sweeps(gpu, tool, count):
+    """the other seeded sweeps (tools/): bit-exact stages, the per-block path and split renders, the Oscilloscope / Vectorscope
+    kernels -- each prints one line per case and exits non-zero on any mismatch"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(count), "1"], capture_output=True, text=True, timeout=900)
+    bad = [l for l in r.stdout.splitlines() if " BAD " in l]
+    assert r.returncode == 0 and not bad, (bad[:5], r.stderr[-500:])
