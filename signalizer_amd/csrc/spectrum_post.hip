@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
 
 // K_B1b: exact state at the END of every chunk, in place: agg[c] <- max(agg[c], decay^chunkLen(agg[c-1])) with the
 // decay done by sequential fp32 multiplies.  thread <-> (pair, side, graph, pixel); sequential over chunks.
+// OFF: uint32_t while the aggregates of the pass stay below 4 GB (every render of the BASELINE configs), size_t beyond.
+template <typename OFF>
 __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
 {
     const size_t per = size_t(prm.C) * prm.sides * G * prm.P;
@@ -73,13 +75,13 @@ __global__ void __launch_bounds__(256) decayCarryKernel(const DecayParams prm)
     // fetched together, the next batch while this one is folded.
     constexpr int B = 32;
     char *base = reinterpret_cast<char *>(prm.agg);
-    const uint32_t stride = uint32_t(per * sizeof(float));
-    uint32_t off = uint32_t(e * sizeof(float)) + stride;             // chunk 1 (the aggregates of a pass stay far below 4 GB)
+    const OFF stride = OFF(per * sizeof(float));
+    OFF off = OFF(e * sizeof(float)) + stride;                       // chunk 1
     uint32_t d = 1;
     float a[B], nxt[B];
-    auto fetch = [&](uint32_t o, float (&v)[B]) {
+    auto fetch = [&](OFF o, float (&v)[B]) {
 #pragma unroll
-        for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const float *>(base + (o + uint32_t(j) * stride));
+        for (int j = 0; j < B; ++j) v[j] = *reinterpret_cast<const float *>(base + (o + OFF(j) * stride));
     };
     if (d + B <= prm.numChunks) fetch(off, a);
     while (d + B <= prm.numChunks) {                                    // full batches: no per-chunk predicates
@@ -350,7 +352,10 @@ hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
     const size_t total = size_t(prm.C) * prm.sides * G * prm.P;
     const int block = 256;
     const unsigned grid = unsigned((total + block - 1) / block);
-    hipLaunchKernelGGL(decayCarryKernel, dim3(grid), dim3(block), 0, stream, prm);
+    if (total * prm.numChunks * sizeof(float) < (size_t(1) << 32))
+        hipLaunchKernelGGL(decayCarryKernel<uint32_t>, dim3(grid), dim3(block), 0, stream, prm);
+    else
+        hipLaunchKernelGGL(decayCarryKernel<size_t>, dim3(grid), dim3(block), 0, stream, prm);
     return hipGetLastError();
 }
 
