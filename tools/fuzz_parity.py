@@ -31,12 +31,18 @@ def main():
         rgba = plan.render(torch.from_numpy(x).cuda()).cpu().numpy()
         d = np.abs(rgba.astype(int) - r["rgba"].astype(int))
         phase = cfg["channel_mode"] == config.CH_PHASE
-        ok = rgba.shape == r["rgba"].shape and d.max() <= (2 if phase else 1) and (d > 0).mean() <= (2e-2 if phase else 5e-3)
+        # Phase picks the bin with the largest max(|L|^2, |R|^2) and shows |L| + |R| of it: a stationary tone between two bins makes
+        # near-ties (relative difference ~1e-7) whose winner depends on the FFT's rounding, and the two candidates differ in
+        # |L| + |R| -- isolated pixels may differ by any amount, in any fp32 FFT; everything else must be within 2 LSB
+        ok = rgba.shape == r["rgba"].shape and (d > 0).mean() <= (2e-2 if phase else 5e-3) and \
+            (d.max() <= 1 if not phase else (d > 2).mean() <= 1e-3)
         print(it, "ok " if ok else "BAD", "N", plan.N, "path", plan.path, "mode", cfg["channel_mode"], "interp", cfg["bin_interp"], "view",
               cfg["view_scaling"], "P", cfg["axis_points"], "pairs", cfg["num_pairs"], "frames", frames, "max", int(d.max()), "frac", float((d > 0).mean()))
         if not ok:
             bad += 1
-            print("   ", json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items() if k not in ("colours",)}))
+            print("   ", "S", S, "synth seed", 100 + it, json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items() if k not in ("colours",)}))
+            f, px = [int(v[0]) for v in np.nonzero(d.max(axis=2) == d.max())]
+            print("   ", "worst at frame", f, "pixel", px, "got", rgba[f, px], "ref", r["rgba"][f, px], "bytes differing", int((d > 0).sum()))
     print("bad:", bad, "of", count)
     sys.exit(1 if bad else 0)
 
