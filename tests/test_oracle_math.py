@@ -243,3 +243,54 @@ def test_KA14_phase_mode_cancellation(oracle, interp):
     want0 = (ph0 + pf * (np.float32(0) - ph0)).astype(np.float32)
     assert np.allclose(st[0].imag, want0, rtol=1e-6, atol=1e-12)
     assert res.shape == (2, P)
+
+
+@pytest.mark.parametrize("mode", [config.CH_LEFT, config.CH_MERGE, config.CH_SIDE, config.CH_COMPLEX])
+def test_KA15_entries_left_complex(oracle, mode):
+    """The csf entries mapToLinearSpace leaves complex (mono modes: csf[N/2..N-1], TransformDSP.inl:553-560; Complex: csf[0],
+    :993) enter the Lanczos sums as complex numbers: an independent numpy restatement (fp64 FFT, complex arithmetic) of the
+    interpolated pixels of a view that starts at 0 Hz, where the filter window wraps below bin 0."""
+    po = oracle
+    W = N = 1024
+    P = 120
+    cfg = config.spectrum_config(sample_rate=48000.0, window_size=W, hop=W, channel_mode=mode, bin_interp=config.INTERP_LANCZOS,
+                                 view_scaling=config.VIEW_LINEAR, axis_points=P, view_left=0.0, view_right=0.02,
+                                 window_type=config.WIN_HANN)
+    p = po.params_from_dict(cfg)
+    rng = np.random.default_rng(15)
+    L = rng.uniform(-1, 1, W).astype(np.float32) + 0.3
+    R = rng.uniform(-1, 1, W).astype(np.float32) - 0.2
+    _, _, csp = po.frame_bins(p, L, R)
+    win, scale = po.window(cfg["window_type"], cfg["window_symmetry"], W)
+    w = win[:W].astype(np.float64)
+    l, r = L.astype(np.float64), R.astype(np.float64)
+    z = {config.CH_LEFT: l * w, config.CH_MERGE: (l + r) * w * 0.5, config.CH_SIDE: (l - r) * w * 0.5,
+         config.CH_COMPLEX: (l + 1j * r) * w}[mode]
+    Z = np.fft.fft(z)
+    csf = np.zeros(N + 1, np.complex128)
+    if mode == config.CH_COMPLEX:
+        csf[:N] = np.abs(Z)
+        csf[0] = 0.5 * Z[0]
+    else:
+        csf[:N] = Z
+        csf[0] *= 0.5
+        csf[N // 2] *= 0.5
+        csf[:N // 2] = np.abs(csf[:N // 2])
+    mf = po.remap_frequencies(p).astype(np.float64)
+    f2b = (N / 2) / (48000.0 / 2)
+    inv = scale / (W * 0.5)
+    a = 5
+    checked = 0
+    for x in range(20):                                       # well inside the interpolated region of this view
+        pos = mf[x] * f2b
+        fl = int(np.floor(pos))
+        acc = 0j
+        for i in range(fl - a + 1, fl + a + 1):
+            d = pos - i
+            wt = 1.0 if d == 0 else (0.0 if abs(d) >= a else a * np.sin(np.pi * d) * np.sin(np.pi * d / a) / (np.pi * d) ** 2)
+            acc += csf[i % (N + 1)] * wt
+        want = inv * abs(acc)
+        got = abs(complex(csp[x]))
+        assert abs(got - want) <= 2e-5 * max(want, 1e-3), (x, got, want)
+        checked += 1 if abs(acc.imag) > 1e-6 * abs(acc) else 0
+    assert checked >= 3                                      # the complex entries really took part
