@@ -34,7 +34,7 @@ def main():
         # Phase picks the bin with the largest max(|L|^2, |R|^2) and shows |L| + |R| of it: a stationary tone between two bins makes
         # near-ties (relative difference ~1e-7) whose winner depends on the FFT's rounding, and the two candidates differ in
         # |L| + |R| -- isolated pixels may differ by any amount, in any fp32 FFT; everything else must be within 2 LSB
-        ok = rgba.shape == r["rgba"].shape and (d > 0).mean() <= (2e-2 if phase else 5e-3) and \
+        ok = rgba.shape == r["rgba"].shape and (d > 0).sum() <= max(2, (2e-2 if phase else 5e-3) * d.size) and \
             (d.max() <= 1 if not phase else (d > 2).mean() <= 1e-3)
         print(it, "ok " if ok else "BAD", "N", plan.N, "path", plan.path, "mode", cfg["channel_mode"], "interp", cfg["bin_interp"], "view",
               cfg["view_scaling"], "P", cfg["axis_points"], "pairs", cfg["num_pairs"], "frames", frames, "max", int(d.max()), "frac", float((d > 0).mean()))

@@ -59,7 +59,7 @@ def main():
         if ok1 and want:
             d = np.abs(np.stack(cols).astype(int) - ref.astype(int))
             # (Phase: isolated arg-max near-ties may flip with the FFT's rounding, see fuzz_parity.py)
-            ok1 = (d > 0).mean() <= tol[1] and (d.max() <= tol[0] if not phase else (d > 2).mean() <= 1e-3)
+            ok1 = (d > 0).sum() <= max(2, tol[1] * d.size) and (d.max() <= tol[0] if not phase else (d > 2).mean() <= 1e-3)
         # (ii) split render with carried state
         ok2 = True
         if not phase or True:
@@ -72,6 +72,10 @@ def main():
                 a = plan.render(y[:, :W + (cut - 1) * hop].contiguous(), state=state).cpu().numpy()
                 b = plan.render(y[:, cut * hop:].contiguous(), state=state).cpu().numpy()
                 ok2 = np.array_equal(np.concatenate([a, b]), full)
+        if not ok1 and len(cols) == want and want:
+            dd = np.abs(np.stack(cols).astype(int) - ref.astype(int))
+            print("    rt max", int(dd.max()), "frac", float((dd > 0).mean()), "frames with diffs", np.unique(np.nonzero(dd)[0]).tolist()[:10],
+                  "pixels", np.unique(np.nonzero(dd)[1]).tolist()[:10], "block sizes unknown; cfg:", {k: v for k, v in cfg.items() if k != "colours"})
         print(it, "ok " if ok1 and ok2 else "BAD", "N", plan.N, "path", plan.path, "mode", cfg["channel_mode"], "W", W, "hop", hop, "P", P,
               "pairs", cfg["num_pairs"], "cols", len(cols), "/", want, "rt", ok1, "split", ok2)
         bad += 0 if (ok1 and ok2) else 1

@@ -40,6 +40,14 @@ def main():
     r = po.spectrogram(po.params_from_dict(cfgp), synth.gen(15, 48000, S, 2), want_lines=True, want_mapped=True)
     np.savez_compressed(os.path.join(OUT, "phase_6frames.npz"), seed=15, nsamples=S, rgba=r["rgba"], lines=r["lines"],
                         mapped=r["mapped"][:, :, :256])
+    # csf entries left complex (complex_dc.hpp): Left and Complex mode at the reference's default size, 48 kHz, a view from 10 Hz --
+    # the first pixels' Lanczos windows wrap below bin 0 onto csf[N-1..] (mono) / include the complex csf[0] (Complex)
+    for name, mode in (("left", config.CH_LEFT), ("complex", config.CH_COMPLEX)):
+        cfgm = config.spectrum_config(window_size=4096, hop=1024, channel_mode=mode, axis_points=256)
+        S = 4096 + 3 * 1024
+        r = po.spectrogram(po.params_from_dict(cfgm), synth.gen(16, 48000, S, 2) + np.float32(0.2), want_mapped=True)
+        np.savez_compressed(os.path.join(OUT, "mono_complex_entries_%s.npz" % name), seed=16, nsamples=S, mode=mode, rgba=r["rgba"],
+                            mapped=r["mapped"][:, :, :256])
     # colour map cases (KA8): intensities around every branch, two-pair additive blend
     cfgc = config.spectrum_config(num_pairs=2, axis_points=16, ratios=(0.1, 0.3, 0.2, 0.25, 0.15))
     p = po.params_from_dict(cfgc)
