@@ -46,6 +46,9 @@ def main():
                     ratios=tuple(float(v) for v in rng.uniform(0.05, 1.0, 5)))
         plan2 = api.Plan(cfg2).upload()
         F2 = int(rng.choice([1, 3, 8, 9, 37, 70, int(rng.integers(1, 200))]))
+        if W <= 4096 and rng.random() < 0.25:
+            F2 = int(rng.choice([513, 700, 1500]))            # > 64 time chunks: the two-kernel K_B path
+            cfg2["hop"] = max(1, W // 8)
         S2 = W + (F2 - 1) * cfg2["hop"]
         x2 = synth.gen(1900 + it, cfg2["sample_rate"], S2, 2 * C_)
         if S2 > 3000 and rng.random() < 0.5:
