@@ -28,14 +28,18 @@ struct PrepSource {
     uint32_t hop, W, C, mode;
     const float *window;
     long task0;
-    __device__ __forceinline__ float2 operator()(long t, uint32_t n) const
+    // base of the left channel's frame for task task0 + t (the right channel is chStride further)
+    __device__ __forceinline__ const float *frameOf(long t) const
     {
         const long task = task0 + t;
         const long frame = task / C;
         const uint32_t pair = uint32_t(task - frame * C);
+        return planar + size_t(2 * pair) * chStride + size_t(frame) * hop;
+    }
+    __device__ __forceinline__ float2 sample(const float *L, uint32_t n) const
+    {
         float xr = 0.f, xi = 0.f;
         if (n < W) {
-            const float *L = planar + size_t(2 * pair) * chStride + size_t(frame) * hop;
             const float l = L[n], r = L[chStride + n], w = window[n];
             switch (mode) {                                       // TransformDSP.inl:59-216
             case SGZ_CH_LEFT: xr = l * w; break;
@@ -70,9 +74,10 @@ genericStage(const float2 *x, float2 *y, const float2 *twN /*W_N^i, i < N/2*/, u
     const float2 *xi = x + size_t(t) * N;
     float2 *yo = y + size_t(t) * N;
     float re[RX], im[RX];
+    const float *frameL = FIRST ? prep.frameOf(t) : nullptr;
 #pragma unroll
     for (int tt = 0; tt < RX; ++tt) {
-        const float2 v = FIRST ? prep(t, b + uint32_t(tt) * per) : xi[b + size_t(tt) * per];
+        const float2 v = FIRST ? prep.sample(frameL, b + uint32_t(tt) * per) : xi[b + size_t(tt) * per];
         re[tt] = v.x; im[tt] = v.y;
     }
     dif<float, RX, RX, 0>(re, im);                                // output q at register brev(q)
