@@ -49,21 +49,28 @@ stftHalfKernel(const StftParams prm)
 
 // Pixel mapping of one side of one task from HBM-resident csf magnitudes (halves and generic paths): the csf range that side's
 // records touch -- k in [N-15, N] + [0, N/2+31] on the left, [N/2-16, N] + [0, 30] on the right (plan.cpp checks it) --
-// is staged in LDS and mapped by the fused kernel's balanced scan.  One workgroup per (task, side).
+// is staged in LDS and mapped by the fused kernel's balanced scan.  NT threads per (task, side) unit, 1024 / NT units per
+// workgroup, each with its own slice of the LDS (`unitFloats` apart): a small transform has thousands of units of ~1 pixel
+// per thread at NT = 1024, whose cost is the fixed part (table reads, barrier) -- NT = 256 shares it between four units.
+template <int NT>
 __global__ void __launch_bounds__(1024)
-mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *mapped)
+mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *mapped, const long units, const uint32_t unitFloats)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const long task = blockIdx.x / prm.sides;
-    const int side = int(blockIdx.x - task * prm.sides);
+    extern __shared__ __attribute__((aligned(16))) float ldsAll[];
+    const int tid = threadIdx.x % NT;
+    const long unit = long(blockIdx.x) * (1024 / NT) + threadIdx.x / NT;
+    const bool live = unit < units;                                     // (a dead unit of the last workgroup redoes the last one)
+    const long u = live ? unit : units - 1;
+    float *lds = ldsAll + size_t(threadIdx.x / NT) * unitFloats;
+    const long task = u / prm.sides;
+    const int side = int(u - task * prm.sides);
     const int half = int(N >> 1), count = half + 48;
     const OneSideIndex at{int(N), side ? half + 17 : 16};
     const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
     const MapView v{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
                     side ? 0 : int(prm.P), mapped + (size_t(task) * prm.sides + side) * prm.P};
     uint2 *win = reinterpret_cast<uint2 *>(lds + ((count + (count >> 5) + 2) & ~1));
-    MapPixelsBalanced<5, 1024, OneSideIndex> mapper;
+    MapPixelsBalanced<5, NT, OneSideIndex> mapper;
     const bool sgzClkHalf = side == int((prm.ablate >> 15) & 1u);       // debug clocks: which side reports
     SGZ_CLK(0);
     mapper.prefetchTables(v, tid);
@@ -73,11 +80,11 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     // LB independent loads in flight per thread (N = 65536: 33 elements per thread = two round trips; N = 8192: one of 5)
     auto stage = [&](auto lb) {
         constexpr int LB = decltype(lb)::value;
-        for (int i0 = tid; i0 < count; i0 += LB * 1024) {
+        for (int i0 = tid; i0 < count; i0 += LB * NT) {
             float val[LB];
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
-                const int i = i0 + u * 1024;
+                const int i = i0 + u * NT;
                 int k = i - at.off;
                 k = k < 0 ? k + int(N) + 1 : k;
                 k = k > int(N) ? int(N) : k;                           // (past the end: any valid address, the value is dropped)
@@ -86,12 +93,12 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
             }
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
-                const int i = i0 + u * 1024;
+                const int i = i0 + u * NT;
                 if (i < count) lds[i + (i >> 5)] = val[u];
             }
         }
     };
-    if (count <= 5 * 1024) stage(std::integral_constant<int, 5>{});
+    if (count <= 5 * NT) stage(std::integral_constant<int, 5>{});
     else stage(std::integral_constant<int, 17>{});
     mapper.prefetchWeights(prm);
     __syncthreads();
@@ -118,7 +125,7 @@ struct LdsGrant {
     }
 };
 
-static size_t mapSidesLds(const StftParams &prm, uint32_t N)
+static size_t mapSidesLds(const StftParams &prm, uint32_t N)          // bytes of one unit
 {
     const int count = int(N / 2) + 48;
     const uint32_t maxSide = prm.nItemsLeft > prm.nItems - prm.nItemsLeft ? prm.nItemsLeft : prm.nItems - prm.nItemsLeft;
@@ -130,9 +137,18 @@ hipError_t launchMapSides(const StftParams &prm, uint32_t N, const float *bins, 
 {
     const size_t ldsBytes = mapSidesLds(prm, N);
     if (ldsBytes > 160 * 1024) return hipErrorInvalidValue;
-    static LdsGrant grant;
-    if (hipError_t e = grant.ensure(reinterpret_cast<const void *>(&mapSideKernel), ldsBytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(mapSideKernel, dim3(unsigned(ntasks * prm.sides)), dim3(1024), ldsBytes, stream, prm, bins, N, mapped);
+    const long units = ntasks * long(prm.sides);
+    const uint32_t unitFloats = uint32_t((ldsBytes + 15) / 16 * 4);     // 16-byte aligned slices
+    static LdsGrant grant[2];
+    if (N <= 8192 && size_t(unitFloats) * 4 * 4 <= 160 * 1024) {        // four 256-thread units per workgroup
+        const size_t bytes = size_t(unitFloats) * 4 * 4;
+        if (hipError_t e = grant[0].ensure(reinterpret_cast<const void *>(&mapSideKernel<256>), bytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(mapSideKernel<256>, dim3(unsigned((units + 3) / 4)), dim3(1024), bytes, stream, prm, bins, N, mapped, units,
+                           unitFloats);
+    } else {
+        if (hipError_t e = grant[1].ensure(reinterpret_cast<const void *>(&mapSideKernel<1024>), ldsBytes); e != hipSuccess) return e;
+        hipLaunchKernelGGL(mapSideKernel<1024>, dim3(unsigned(units)), dim3(1024), ldsBytes, stream, prm, bins, N, mapped, units, unitFloats);
+    }
     return hipGetLastError();
 }
 
