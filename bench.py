@@ -27,7 +27,6 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_PER_FRAME = 2 * 32768 * 4 + 4 * 1024    # algorithmic bytes per stereo frame: 266 240
 
 
 def _hip():
@@ -90,6 +89,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 (default): BASELINE.json's metric; cfg5: the 64-channel 65536-pt job of BASELINE configs[4], for the "
+                         "1/2/4/8-GPU time-chunk scaling curve of SURVEY 8(e) (20 s of 32 pairs per rank)")
     args = ap.parse_args()
 
     import torch
@@ -109,12 +111,19 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = config.cfg2()
-    sr = 48000
-    S = int(config.CFG2_SECONDS * sr)                 # per-rank chunk: 2 880 000 samples
+    if args.workload == "cfg5":
+        cfg = config.cfg5()
+        sr = 96000
+        S = 20 * sr                                   # per-rank chunk: 20 s of 64 channels (491 MB)
+    else:
+        cfg = config.cfg2()
+        sr = 48000
+        S = int(config.CFG2_SECONDS * sr)             # per-rank chunk: 2 880 000 samples
     hop, W = cfg["hop"], cfg["window_size"]
-    # rank r owns samples [r*S, (r+1)*S) of a 60*world s stream (weak scaling)
-    x_host = synth.gen(config.CFG2_SEED + 100 * rank, sr, S, 2)
+    pairs = cfg["num_pairs"]
+    bytes_per_frame = 2 * W * 4 + 4 * cfg["axis_points"]      # algorithmic bytes per stereo frame
+    # rank r owns samples [r*S, (r+1)*S) of a world-times-longer stream (weak scaling)
+    x_host = synth.gen(config.CFG2_SEED + 100 * rank, sr, S, 2 * pairs)
     plan = api.Plan(cfg).upload()
     shard = sharding.TimeChunkRenderer(plan, torch.from_numpy(x_host).to(dev), rank=rank, world=world)
     frames_per_rank = shard.local_frames
@@ -165,24 +174,31 @@ def main() -> None:
         total_frames = frames_per_rank
 
     if rank == 0:
-        value = total_frames * args.steps / dt
-        achieved = frames_per_rank * BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9
+        value = total_frames * pairs * args.steps / dt
+        achieved = frames_per_rank * pairs * bytes_per_frame / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "32768-pt stereo STFT frames/sec (75% overlap); achieved HBM GB/s vs peak",
+            "metric": "32768-pt stereo STFT frames/sec (75% overlap); achieved HBM GB/s vs peak" if args.workload == "cfg2" else
+                      "65536-pt stereo-pair STFT frames/sec, 32 pairs (75% overlap), time-chunk sharded; achieved HBM GB/s vs peak",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: stereo 48 kHz spectrogram, 32768-pt FFT, 75% overlap "
-                                   "(hop 8192), 60 s buffer => 348 frames/GPU, P=1024, Hann, Separate, Lanczos, log view",
+            "config": {"workload": ("BASELINE.json configs[1]: stereo 48 kHz spectrogram, 32768-pt FFT, 75% overlap "
+                                    "(hop 8192), 60 s buffer => 348 frames/GPU, P=1024, Hann, Separate, Lanczos, log view")
+                       if args.workload == "cfg2" else
+                       ("BASELINE.json configs[4]: 64-channel 96 kHz spectrogram, 65536-pt FFT, 75% overlap (hop 16384), 20 s per GPU "
+                        "=> 114 frames x 32 pairs per GPU, P=1024, Hann, Separate, Lanczos, log view"),
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps, "single_shot_ms": single_shot_ms,
                        "collectives_ms_per_step": coll_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(),
-                         "kernel": "stftMapKernel<5, 0, true>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": frames_per_rank * BYTES_PER_FRAME},
+                         "kernel": "stftMapKernel<5, 0, true>" if args.workload == "cfg2" else
+                                   "stftHalfKernel<5, 0, true> + mapSideKernel<1024> (all slabs of one K_A pass)",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": frames_per_rank * pairs * bytes_per_frame},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.workload != "cfg2":
+            out["roofline"]["traffic"] = None          # the committed PMC numbers are cfg2's
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             out["cpu_baseline"] = cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)
     if world > 1:
