@@ -246,22 +246,29 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
     const uint32_t x = uint32_t(gid - size_t(t) * P);
     const float2 *csf = csfAll + size_t(t) * (size_t(N) + 1);
     const uint32_t type = ph.type[x];
-    if (type != 1u && lane != 0) return;                          // interpolated pixels: lane 0 alone (sequential tap sums)
     // value of csf[j] once bins below `norm` (and their mirrors) have been replaced by their magnitudes
     auto normalised = [&](int j, uint32_t norm) {
         const float2 v = csf[j];
         const bool isNorm = uint32_t(j) < norm || uint32_t(int(N) - j) < norm;
         return isNorm ? make_float2(cabsHypot(v), 0.f) : v;
     };
-    auto filter = [&](const PixelRec &rec, uint32_t norm) {           // taps accumulate in order, per component
-        float2 acc = make_float2(0.f, 0.f);
-        int k = rec.a;
-        for (int i = 0; i < rec.b; ++i) {
+    // One filter window (<= 10 taps <= kMapLanes): lane i evaluates tap i -- the (possibly normalised) entry times its weight,
+    // the expensive part -- and every lane then adds the products in tap order, so the sum rounds exactly like the sequential
+    // loop of the reference.  All lanes of the pixel call it together.
+    auto filter = [&](const PixelRec &rec, uint32_t norm) {
+        float px = 0.f, py = 0.f;
+        if (lane < rec.b) {
+            int k = rec.a + lane;
+            k = k > int(N) ? k - (int(N) + 1) : k;                     // periodic over the N + 1 entries
             const float2 v = normalised(k, norm);
-            const float w = weights[rec.c + i];
-            acc.x = acc.x + v.x * w;
-            acc.y = acc.y + v.y * w;
-            k = (k == int(N)) ? 0 : k + 1;
+            const float w = weights[rec.c + lane];
+            px = v.x * w;
+            py = v.y * w;
+        }
+        float2 acc = make_float2(0.f, 0.f);
+        for (int i = 0; i < rec.b; ++i) {
+            acc.x = acc.x + __shfl(px, i, kMapLanes);
+            acc.y = acc.y + __shfl(py, i, kMapLanes);
         }
         return acc;
     };
@@ -281,6 +288,7 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
             const float2 iLeft = filter(rl, norm), iRight = filter(rr, norm);
             mag = invSize * (cabsHypot(iLeft) + cabsHypot(iRight));
         }
+        if (lane != 0) return;
     } else {
         const PixelRec rec = recs[x];
         float maxValue = 0.f;
