@@ -162,16 +162,16 @@ genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const Pixe
     const int side = idx >= P ? 1 : 0;
     float val = 0.f;
     if ((rec.kind & 1) == 0) {
-        if (lane == 0) {
-            float acc = 0.f;
-            int k = rec.a;
-            for (int i = 0; i < rec.b; ++i) {
-                const float prod = M[k] * weights[rec.c + i];
-                acc = acc + prod;
-                k = (k == int(N)) ? 0 : k + 1;
-            }
-            val = invSize * acc;
+        // lane i fetches tap i and multiplies; the products are added in tap order (the reference's rounding)
+        float prod = 0.f;
+        if (lane < rec.b) {
+            int k = rec.a + lane;
+            k = k > int(N) ? k - (int(N) + 1) : k;                     // periodic over the N + 1 entries
+            prod = M[k] * weights[rec.c + lane];
         }
+        float acc = 0.f;
+        for (int i = 0; i < rec.b; ++i) acc = acc + __shfl(prod, i, kMapLanes);
+        val = invSize * acc;
     } else {
         float best = 0.f;
         int bestOff = 0x7fffffff;                                 // scan offset of this lane's winner (none yet)
