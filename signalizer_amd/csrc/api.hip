@@ -172,6 +172,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         // generic multi-kernel path (any power-of-two N): work buffers for a slab of tasks, <= 256 MiB each
         const size_t perTask = size_t(p.N) * 2;                                  // floats of one complex buffer
         long slab = long(std::max<size_t>(1, (size_t(64) << 20) / perTask));      // 64 Mi floats = 256 MiB
+        slab = std::max<long>(1, slab / long(p.C)) * long(p.C);                  // whole frames (the in-register FFT walks a slab pair-major)
         slab = std::min<long>(slab, tasks);
         if (p.workSlab < size_t(slab)) {
             for (float **b : {&p.d_work0, &p.d_work1, &p.d_binsWork}) if (*b) { (void)hipFree(*b); *b = nullptr; }
@@ -186,6 +187,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             // Phase keeps the bins complex; the float test hooks carry float2 data in this mode (sgz.h, stage hooks)
             ph.type = p.d_phaseType; ph.norm = p.d_phaseNorm; ph.normFinal = p.phaseNormFinal;
             ph.filtered = p.cfg.bin_interp != SGZ_INTERP_NONE;
+            ph.fusedFft = p.phaseFusedFft ? 1u : 0u;
             ph.csfOut = reinterpret_cast<float2 *>(d_binsOut);
             ph.csfIn = reinterpret_cast<const float2 *>(d_binsIn);
         }

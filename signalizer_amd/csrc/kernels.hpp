@@ -22,6 +22,7 @@ struct StftParams {
     const uint32_t *dcPixels;
     uint32_t nDcPixels;
     float2 *dcOut;            // generic / halves path: those entries, [task][kSpecBins] (the fused kernel keeps them in LDS), or null
+    float2 *zOut;             // stftComplexKernel: the raw transform Z [task][N] (Phase mode's generic split / map kernels read it)
     uint32_t binsSplit;       // halves path: binsOut holds [even bins 0..N/2 | odd bins] per task (launchMapSides) instead of csf order
     long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]
@@ -39,6 +40,8 @@ struct StftParams {
 };
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
+// the fused kernel's load + three passes only: raw transform Z of every task -> prm.zOut (N = 4096, 32768; Phase mode)
+hipError_t launchStftComplex(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
 // N = 2 R^3 (8192, 65536): two workgroups per (frame, pair) write the csf magnitudes of tasks [taskBase, taskBase + grid / 2)
 // to prm.binsOut ([task][N + 1]); launchGenericMap turns them into pixels
 hipError_t launchStftHalves(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
@@ -56,6 +59,7 @@ struct PhaseTables {
     const uint32_t *norm;     // [P] normalizedPosition at the pixel's magnitude pass
     uint32_t normFinal;       // normalizedPosition for the arg-max pixels
     uint32_t filtered;        // Linear / Lanczos (cancellation = sqrt(|sum|^2)) vs None (cancellation = |sum| via hypot)
+    uint32_t fusedFft;        // N = R^3: the transform comes from launchStftComplex instead of the HBM-resident passes
     float2 *csfOut;           // test hook: complex bins [tasks][N+1] out (or null)
     const float2 *csfIn;      // test hook: map from these complex bins (skip the FFT)
 };

@@ -343,9 +343,13 @@ static void buildTwiddles(Plan &p)
     // N = 2 R^3: two half-frame workgroups (decimation in frequency) + the generic map kernel
     int halfR = 0;
     if (p.N == 65536) halfR = 32; else if (p.N == 8192) halfR = 16;
-    if (p.cfg.channel_mode == SGZ_CH_PHASE) R = halfR = 0;   // Phase keeps complex bins: generic (HBM-resident) path, spectrum_generic.hip
+    // Phase keeps complex bins: its split and map run as HBM-resident kernels (spectrum_generic.hip); at N = R^3 the transform
+    // itself still comes from the in-register FFT (stftComplexKernel), which needs the R tables
+    const int phaseR = p.cfg.channel_mode == SGZ_CH_PHASE ? R : 0;
+    if (p.cfg.channel_mode == SGZ_CH_PHASE) R = halfR = 0;
     p.fused = R != 0;
     p.halves = halfR != 0;
+    p.phaseFusedFft = phaseR != 0;
     if (!R) {   // generic Stockham path: one table W_N^i, i < N/2 (also behind the halves path's map-from-bins test hook)
         p.twN.resize(size_t(p.N / 2) * 2);
         for (uint32_t i = 0; i < p.N / 2; ++i) {
@@ -353,8 +357,8 @@ static void buildTwiddles(Plan &p)
             p.twN[size_t(i) * 2 + 0] = float(std::cos(ang));
             p.twN[size_t(i) * 2 + 1] = float(std::sin(ang));
         }
-        if (!halfR) return;
-        R = halfR;
+        if (!halfR && !phaseR) return;
+        R = halfR ? halfR : phaseR;
     }
     const uint32_t fftN = p.halves ? p.N / 2 : p.N;     // size of the in-register transform
     const uint32_t T = uint32_t(R * R);

@@ -67,6 +67,7 @@ struct Plan {
     std::vector<uint32_t> dcPixels;     // Complex mode: pixels whose taps / arg-max run include csf[0] (kept complex, TransformDSP.inl:993)
     std::vector<float> tw1odd;          // halves path: pass-1 twiddles of the odd half
     bool fused = false;                 // N in {4096, 32768}: spectrum_fft.hip; otherwise spectrum_generic.hip
+    bool phaseFusedFft = false;         // Phase at N = R^3: the transform comes from the in-register FFT (complex output), the rest is generic
     bool sideMapOk = false;             // halves path: every record stays inside the csf range mapSideKernel stages per side
     bool halves = false;                // N in {8192, 65536} = 2 R^3: two half-frame workgroups (spectrum_fft.hip) + genericMap
     DeviceScalars scalars{};

@@ -37,6 +37,18 @@ stftMapKernel(const StftParams prm)
     stftMapBody<LR, MIX, FULLW>(prm, lds, blockIdx.x, gridDim.x);
 }
 
+// load + window + three passes only: Z -> prm.zOut (Phase mode at N = R^3)
+template <int LR, bool FULLW>
+__global__ void __launch_bounds__(1 << (2 * LR))
+stftComplexKernel(const StftParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stftMapBody<LR, 0, FULLW, -1, true>(prm, lds, blockIdx.x, gridDim.x);
+}
+
+template <int LR>
+static hipError_t launchComplex(const StftParams &prm, int grid, hipStream_t stream);
+
 // N = 2 R^3: workgroup b transforms half (b & 1) of task b >> 1 (stft_body.hpp, HALF)
 template <int LR, int MIX, bool FULLW>
 __global__ void __launch_bounds__(1 << (2 * LR))
@@ -200,6 +212,29 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
     if (hipError_t e = grant[which].ensure(reinterpret_cast<const void *>(kerns[which]), ldsBytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
     return hipGetLastError();
+}
+
+template <int LR>
+static hipError_t launchComplex(const StftParams &prm, int grid, hipStream_t stream)
+{
+    constexpr int R = 1 << LR, T = R * R, N = R * T;
+    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
+    const bool fullw = prm.W == uint32_t(N);
+    using Kern = void (*)(const StftParams);
+    static const Kern kerns[2] = {&stftComplexKernel<LR, false>, &stftComplexKernel<LR, true>};
+    static LdsGrant grant[2];
+    if (hipError_t e = grant[fullw].ensure(reinterpret_cast<const void *>(kerns[fullw]), ldsBytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kerns[fullw], dim3(grid), dim3(T), ldsBytes, stream, prm);
+    return hipGetLastError();
+}
+
+hipError_t launchStftComplex(const StftParams &prm, uint32_t N, int grid, hipStream_t stream)
+{
+    switch (N) {
+    case 32768: return launchComplex<5>(prm, grid, stream);
+    case 4096: return launchComplex<4>(prm, grid, stream);
+    default: return hipErrorNotSupported;
+    }
 }
 
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream)

@@ -403,7 +403,15 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
             if (phase->csfIn == nullptr) {
                 const PrepSource prep{prm.planar, prm.chStride, prm.hop, prm.W, prm.C, prm.mode, prm.window, t0};
                 float2 *src = work0, *dst = work1;
-                runStages(prep, src, dst, twN, N, log2N, nt, stream);
+                if (phase->fusedFft) {                                  // N = R^3: the in-register FFT writes Z
+                    StftParams pz = prm;
+                    pz.taskBase = t0;
+                    pz.frames = nt / long(prm.C);
+                    pz.zOut = work0;
+                    hipError_t e2 = launchStftComplex(pz, N, int(nt), stream);
+                    if (e2 != hipSuccess) return e2;
+                } else
+                    runStages(prep, src, dst, twN, N, log2N, nt, stream);
                 // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
                 float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
                 hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout);

@@ -347,7 +347,9 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
 // lane L ^ R everywhere and there is no self-mirroring column.  W_2N^n for n = t + T a factors into the constant
 // W_2R^a (a = register, before pass 1) and W_2N^t, which rides on the pass-1 twiddles (TwFactors<LR, true>).  The
 // magnitudes go to HBM (csf of the 2N-point frame, element 2j + HALF); spectrum_generic.hip's genericMap maps them.
-template <int LR, int MIX, bool FULLW, int HALF = -1>
+// ZOUT: stop after pass 3 and write the raw transform Z to prm.zOut in natural order (Phase mode: its bins stay complex and its
+// split / map are HBM-resident kernels).
+template <int LR, int MIX, bool FULLW, int HALF = -1, bool ZOUT = false>
 __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, const long bid, const long nb)
 {
     constexpr int R = 1 << LR;
@@ -393,7 +395,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         task = fr * prm.C + pr;
     }
     MapPixelsBalanced<LR, T> mapper;
-    const bool doMap = HALF < 0 && balanced && prm.mapped && !(prm.ablate & 16);
+    const bool doMap = HALF < 0 && !ZOUT && balanced && prm.mapped && !(prm.ablate & 16);
     SGZ_CLK(0);
     SGZ_WCLK(0);
     if (prm.binsIn == nullptr) {
@@ -566,6 +568,21 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
         SGZ_CLK(5);
         SGZ_WCLK(1);
+        if (ZOUT) {
+            // plane by plane through the csf layout (k + k / R): natural order, one coalesced pass per component
+            const int kcz = q + R * ix, bz = kcz + (kcz >> LR);
+            float *dst = reinterpret_cast<float *>(prm.zOut + size_t(task) * N);
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                __syncthreads();                                       // exchange-2 tiles / the previous plane are dead
+#pragma unroll
+                for (int m3 = 0; m3 < R; ++m3) lds[bz + m3 * PADSTRIDE] = plane ? c[brev(m3, LR)].y : c[brev(m3, LR)].x;
+                __syncthreads();
+#pragma unroll 8
+                for (int k = tid; k < N; k += T) dst[2 * k + plane] = lds[k + (k >> LR)];
+            }
+            return;
+        }
         // Z[kc + T m3] at register brev(m3),  kc = q + R q2.  The magnitudes go to their own scalar registers so that the
         // (re, im) pairs die as the mirror consumes them (a half-dead 64-bit tuple still holds two registers).
         float mag[R];
