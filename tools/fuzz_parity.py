@@ -1,6 +1,6 @@
 """Randomised end-to-end parity sweep: GPU render (C ABI) against the oracle over random configurations -- window sizes on every
 K_A path, channel modes, interpolation, view scaling and zoom, window functions, pixel counts, pairs, slope, dB range, poles.
-usage: fuzz_parity.py [count] [seed] [wild]      (needs a GPU; the oracle is test infrastructure)"""
+usage: fuzz_parity.py [count] [seed] [wild] [mode=N]      (needs a GPU; the oracle is test infrastructure)"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,12 +12,15 @@ from fuzzcfg import random_config
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    wild = len(sys.argv) > 3
+    wild = len(sys.argv) > 3 and sys.argv[3] == "wild"
+    force_mode = next((int(a.split("=")[1]) for a in sys.argv[3:] if a.startswith("mode=")), None)      # e.g. mode=4: Phase only
     po.build()
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(count):
         cfg = random_config(rng, wild)
+        if force_mode is not None:
+            cfg["channel_mode"] = force_mode
         frames = int(rng.integers(1, 12))
         W, hop = cfg["window_size"], cfg["hop"]
         S = W + (frames - 1) * hop + int(rng.integers(0, hop))
