@@ -212,14 +212,20 @@ __global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams pr
         sm[k] = prm.stateIn ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 0] : 0.f;
         sp[k] = prm.stateIn ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + 1] : 0.f;
     }
-    for (long f0 = 0; f0 < prm.frames; f0 += kMaxChunk) {
-        float m[kMaxChunk], c[kMaxChunk];
+    // batches of kMaxChunk frames; the next batch's loads are in flight while this one runs through the recurrences
+    float m[kMaxChunk], c[kMaxChunk], mn[kMaxChunk], cn[kMaxChunk];
+    auto fetch = [&](long f0, float (&mm)[kMaxChunk], float (&cc)[kMaxChunk]) {
 #pragma unroll
         for (int i = 0; i < kMaxChunk; ++i) {
             const long f = f0 + i < prm.frames ? f0 + i : prm.frames - 1;
-            m[i] = src[size_t(f) * perFrame];
-            c[i] = src[size_t(f) * perFrame + prm.P];
+            mm[i] = src[size_t(f) * perFrame];
+            cc[i] = src[size_t(f) * perFrame + prm.P];
         }
+    };
+    fetch(0, m, c);
+    for (long f0 = 0; f0 < prm.frames; f0 += kMaxChunk) {
+        const bool more = f0 + kMaxChunk < prm.frames;
+        if (more) fetch(f0 + kMaxChunk, mn, cn);
 #pragma unroll
         for (int i = 0; i < kMaxChunk; ++i) {
             const long f = f0 + i;
@@ -239,6 +245,10 @@ __global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams pr
                 }
                 if (k == 0) work[(size_t(f) * prm.C + pair) * prm.P + pixel] = sm[0];
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) { m[i] = mn[i]; c[i] = cn[i]; }
         }
     }
     if (prm.state) {
