@@ -223,28 +223,38 @@ __global__ void __launch_bounds__(256) decayPhaseScanKernel(const DecayParams pr
         }
     };
     fetch(0, m, c);
+    // the launch has C * P threads (a lone wave per SIMD issues one instruction per ~5 clocks): the loop is written for
+    // instruction count -- output pointers bumped per frame, the graph constants in registers
+    static_assert(G == 2, "the two graphs are written out explicitly below");
+    float *wp = work + size_t(pair) * prm.P + pixel;
+    const size_t wStride = size_t(prm.C) * prm.P;
+    float *lp = prm.lines ? prm.lines + (size_t(pair) * G * prm.P + pixel) * 2 : nullptr;
+    const size_t lStride = size_t(prm.C) * G * prm.P * 2, lGraph = size_t(prm.P) * 2;
+    const float pole0 = prm.sc.pole[0], pole1 = prm.sc.pole[1], pp0 = prm.sc.phasePole[0], pp1 = prm.sc.phasePole[1];
     for (long f0 = 0; f0 < prm.frames; f0 += kMaxChunk) {
         const bool more = f0 + kMaxChunk < prm.frames;
         if (more) fetch(f0 + kMaxChunk, mn, cn);
+        const int n = int(prm.frames - f0 < long(kMaxChunk) ? prm.frames - f0 : long(kMaxChunk));
 #pragma unroll
         for (int i = 0; i < kMaxChunk; ++i) {
-            const long f = f0 + i;
-            if (f >= prm.frames) break;
+            if (i >= n) break;
             const float mag = m[i] * 0.5f;                          // mag *= consts::half, :1407
             float phase = c[i];
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                sm[k] = sm[k] * prm.sc.pole[k];
-                if (mag > sm[k]) sm[k] = mag;
-                phase = phase * mag;                                // inside the graph loop (Q7)
-                sp[k] = phase + prm.sc.phasePole[k] * (sp[k] - phase);
-                if (prm.lines) {
-                    float *l = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
-                    l[0] = sm[k];
-                    l[1] = sp[k];
-                }
-                if (k == 0) work[(size_t(f) * prm.C + pair) * prm.P + pixel] = sm[0];
+            sm[0] = sm[0] * pole0;
+            if (mag > sm[0]) sm[0] = mag;
+            phase = phase * mag;                                    // inside the graph loop (Q7)
+            sp[0] = phase + pp0 * (sp[0] - phase);
+            sm[1] = sm[1] * pole1;
+            if (mag > sm[1]) sm[1] = mag;
+            phase = phase * mag;
+            sp[1] = phase + pp1 * (sp[1] - phase);
+            if (lp) {
+                lp[0] = sm[0]; lp[1] = sp[0];
+                lp[lGraph] = sm[1]; lp[lGraph + 1] = sp[1];
+                lp += lStride;
             }
+            *wp = sm[0];
+            wp += wStride;
         }
         if (more) {
 #pragma unroll
