@@ -33,7 +33,7 @@ def test_random_configurations_match_the_oracle(gpu, oracle, seed, wild):
         phase = cfg["channel_mode"] == config.CH_PHASE      # the cancellation ratio amplifies FFT rounding
         # (Phase: isolated arg-max near-ties between adjacent bins may flip with the FFT's rounding -- see tools/fuzz_parity.py)
         if got.shape != ref.shape or (d > 0).sum() > max(2, (2e-2 if phase else 5e-3) * d.size) or \
-                (d.max() > 1 if not phase else (d > 2).mean() > 1e-3):
+                (d.max() > 1 if not phase else (d > 2).sum() > max(8, 1e-3 * d.size)):
             bad.append((it, plan.N, plan.path, cfg["channel_mode"], int(d.max()), float((d > 0).mean())))
     assert not bad, bad
 

@@ -59,7 +59,7 @@ def main():
         if ok1 and want:
             d = np.abs(np.stack(cols).astype(int) - ref.astype(int))
             # (Phase: isolated arg-max near-ties may flip with the FFT's rounding, see fuzz_parity.py)
-            ok1 = (d > 0).sum() <= max(2, tol[1] * d.size) and (d.max() <= tol[0] if not phase else (d > 2).mean() <= 1e-3)
+            ok1 = (d > 0).sum() <= max(2, tol[1] * d.size) and (d.max() <= tol[0] if not phase else (d > 2).sum() <= max(8, 1e-3 * d.size))
         # (ii) split render with carried state
         ok2 = True
         if not phase or True:
