@@ -22,7 +22,7 @@ struct StftParams {
     const uint32_t *dcPixels;
     uint32_t nDcPixels;
     float2 *dcOut;            // generic / halves path: those entries, [task][kSpecBins] (the fused kernel keeps them in LDS), or null
-    float2 *zOut;             // stftComplexKernel: the raw transform Z [task][N] (Phase mode's generic split / map kernels read it)
+    float2 *zOut;             // stftComplexKernel: the raw transform, per task re[N] then im[N] (Phase mode's split kernel reads it)
     uint32_t binsSplit;       // halves path: binsOut holds [even bins 0..N/2 | odd bins] per task (launchMapSides) instead of csf order
     long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]

@@ -203,7 +203,7 @@ genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const Pixe
 // csf after separateTransformsIPL and the DC / Nyquist fix-ups (:646-652): csf[k] = X1[k], csf[N-k] = X2[k] (1 <= k < N/2),
 // csf[0] = Re Z[0] / 2, csf[N] = Im Z[0] / 2, csf[N/2] and csf[N/2-1] halved (quirk Q3).
 __global__ void __launch_bounds__(256)
-genericBinsPhase(const float2 *z, uint32_t N, long ntasks, float2 *csf /*[ntasks][N+1]*/)
+genericBinsPhase(const float2 *z, uint32_t N, long ntasks, float2 *csf /*[ntasks][N+1]*/, const uint32_t planar)
 {
 #pragma clang fp contract(off)
     const size_t per = size_t(N) + 1;
@@ -211,14 +211,18 @@ genericBinsPhase(const float2 *z, uint32_t N, long ntasks, float2 *csf /*[ntasks
     if (gid >= size_t(ntasks) * per) return;
     const long t = long(gid / per);
     const uint32_t k = uint32_t(gid - size_t(t) * per);
-    const float2 *Z = z + size_t(t) * N;
+    // planar: the in-register FFT wrote the task's transform as two arrays, re[N] then im[N] (stftComplexKernel)
+    const float2 *zt = z + size_t(t) * N;
+    const float *zf = reinterpret_cast<const float *>(zt);
+    auto Zat = [&](uint32_t i) { return planar ? make_float2(zf[i], zf[N + i]) : zt[i]; };
     float2 out;
-    if (k == 0) out = make_float2(Z[0].x * 0.5f, 0.f);
-    else if (k == N) out = make_float2(Z[0].y * 0.5f, 0.f);
-    else if (k == N / 2) out = make_float2(0.5f * Z[k].x, 0.5f * Z[k].y);
+    const float2 z0 = Zat(0);
+    if (k == 0) out = make_float2(z0.x * 0.5f, 0.f);
+    else if (k == N) out = make_float2(z0.y * 0.5f, 0.f);
+    else if (k == N / 2) { const float2 zn = Zat(k); out = make_float2(0.5f * zn.x, 0.5f * zn.y); }
     else {
         const uint32_t kk = k < N / 2 ? k : N - k;                  // the pair (kk, N - kk) is split together
-        const float2 a = Z[kk], b = Z[N - kk];
+        const float2 a = Zat(kk), b = Zat(N - kk);
         if (k < N / 2) out = make_float2((a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f);     // X1[k]
         else out = make_float2((a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f);               // X2[kk]
         if (k == N / 2 - 1) out = make_float2(0.5f * out.x, 0.5f * out.y);            // :652
@@ -414,7 +418,8 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
                     runStages(prep, src, dst, twN, N, log2N, nt, stream);
                 // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
                 float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
-                hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout);
+                hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout,
+                                   phase->fusedFft);
                 csf = cout;
             } else {
                 csf = phase->csfIn + size_t(t0) * (size_t(N) + 1);

@@ -347,8 +347,8 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
 // lane L ^ R everywhere and there is no self-mirroring column.  W_2N^n for n = t + T a factors into the constant
 // W_2R^a (a = register, before pass 1) and W_2N^t, which rides on the pass-1 twiddles (TwFactors<LR, true>).  The
 // magnitudes go to HBM (csf of the 2N-point frame, element 2j + HALF); spectrum_generic.hip's genericMap maps them.
-// ZOUT: stop after pass 3 and write the raw transform Z to prm.zOut in natural order (Phase mode: its bins stay complex and its
-// split / map are HBM-resident kernels).
+// ZOUT: stop after pass 3 and write the raw transform Z to prm.zOut as two natural-order arrays, re[N] then im[N] (Phase mode:
+// its bins stay complex and its split / map are HBM-resident kernels).
 template <int LR, int MIX, bool FULLW, int HALF = -1, bool ZOUT = false>
 __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, const long bid, const long nb)
 {
@@ -569,7 +569,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         SGZ_CLK(5);
         SGZ_WCLK(1);
         if (ZOUT) {
-            // plane by plane through the csf layout (k + k / R): natural order, one coalesced pass per component
+            // plane by plane through the csf layout (k + k / R): two natural-order arrays, re[N] then im[N], coalesced
             const int kcz = q + R * ix, bz = kcz + (kcz >> LR);
             float *dst = reinterpret_cast<float *>(prm.zOut + size_t(task) * N);
 #pragma unroll
@@ -579,7 +579,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                 for (int m3 = 0; m3 < R; ++m3) lds[bz + m3 * PADSTRIDE] = plane ? c[brev(m3, LR)].y : c[brev(m3, LR)].x;
                 __syncthreads();
 #pragma unroll 8
-                for (int k = tid; k < N; k += T) dst[2 * k + plane] = lds[k + (k >> LR)];
+                for (int k = tid; k < N; k += T) dst[plane * N + k] = lds[k + (k >> LR)];
             }
             return;
         }
