@@ -200,6 +200,25 @@ genericMap(const float *bins, uint32_t N, uint32_t P, uint32_t sides, const Pixe
 }
 
 // ---- SpectrumChannels::Phase (TransformDSP.inl:643-853): the bins stay complex ------------------------------------------
+// one entry of Phase mode's csf from the raw transform (Zat(i) = Z[i]); see genericBinsPhase
+template <typename ZAt>
+__device__ __forceinline__ float2 phaseCsfEntry(uint32_t N, uint32_t k, ZAt Zat)
+{
+#pragma clang fp contract(off)
+    float2 out;
+    if (k == 0) { const float2 z0 = Zat(0); out = make_float2(z0.x * 0.5f, 0.f); }
+    else if (k == N) { const float2 z0 = Zat(0); out = make_float2(z0.y * 0.5f, 0.f); }
+    else if (k == N / 2) { const float2 zn = Zat(k); out = make_float2(0.5f * zn.x, 0.5f * zn.y); }
+    else {
+        const uint32_t kk = k < N / 2 ? k : N - k;                  // the pair (kk, N - kk) is split together
+        const float2 a = Zat(kk), b = Zat(N - kk);
+        if (k < N / 2) out = make_float2((a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f);     // X1[k]
+        else out = make_float2((a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f);               // X2[kk]
+        if (k == N / 2 - 1) out = make_float2(0.5f * out.x, 0.5f * out.y);            // :652
+    }
+    return out;
+}
+
 // csf after separateTransformsIPL and the DC / Nyquist fix-ups (:646-652): csf[k] = X1[k], csf[N-k] = X2[k] (1 <= k < N/2),
 // csf[0] = Re Z[0] / 2, csf[N] = Im Z[0] / 2, csf[N/2] and csf[N/2-1] halved (quirk Q3).
 __global__ void __launch_bounds__(256)
@@ -215,18 +234,7 @@ genericBinsPhase(const float2 *z, uint32_t N, long ntasks, float2 *csf /*[ntasks
     const float2 *zt = z + size_t(t) * N;
     const float *zf = reinterpret_cast<const float *>(zt);
     auto Zat = [&](uint32_t i) { return planar ? make_float2(zf[i], zf[N + i]) : zt[i]; };
-    float2 out;
-    const float2 z0 = Zat(0);
-    if (k == 0) out = make_float2(z0.x * 0.5f, 0.f);
-    else if (k == N) out = make_float2(z0.y * 0.5f, 0.f);
-    else if (k == N / 2) { const float2 zn = Zat(k); out = make_float2(0.5f * zn.x, 0.5f * zn.y); }
-    else {
-        const uint32_t kk = k < N / 2 ? k : N - k;                  // the pair (kk, N - kk) is split together
-        const float2 a = Zat(kk), b = Zat(N - kk);
-        if (k < N / 2) out = make_float2((a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f);     // X1[k]
-        else out = make_float2((a.y + b.y) * 0.5f, (b.x - a.x) * 0.5f);               // X2[kk]
-        if (k == N / 2 - 1) out = make_float2(0.5f * out.x, 0.5f * out.y);            // :652
-    }
+    const float2 out = phaseCsfEntry(N, k, Zat);
     csf[gid] = out;
 }
 
@@ -237,7 +245,10 @@ __device__ __forceinline__ float cabsHypot(float2 z)
     return float(sqrt(x * x + y * y));
 }
 
-// 16 lanes per (task, pixel) (see genericMap): wsp[2x] = magnitude -> plane 0, wsp[2x+1] = cancellation measure -> plane 1
+// 16 lanes per (task, pixel) (see genericMap): wsp[2x] = magnitude -> plane 0, wsp[2x+1] = cancellation measure -> plane 1.
+// FROMZ = 0: csfAll holds csf ([task][N+1], genericBinsPhase or the test hook); 1 / 2: csfAll holds the raw transforms
+// ([task][N], interleaved / as re[N] im[N] planes) and every csf entry is split on the fly -- no csf array, no split pass.
+template <int FROMZ>
 __global__ void __launch_bounds__(256)
 genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *recs, const float *weights, PhaseTables ph,
                 float invSize, long ntasks, float *mapped /*[ntasks][2][P]*/)
@@ -248,11 +259,16 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
     if (gid >= size_t(ntasks) * P) return;
     const long t = long(gid / P);
     const uint32_t x = uint32_t(gid - size_t(t) * P);
-    const float2 *csf = csfAll + size_t(t) * (size_t(N) + 1);
+    const float2 *csf = csfAll + size_t(t) * (size_t(N) + (FROMZ ? 0 : 1));
+    const float *zf = reinterpret_cast<const float *>(csf);
+    auto entry = [&](int j) {
+        if (FROMZ == 0) return csf[j];
+        return phaseCsfEntry(N, uint32_t(j), [&](uint32_t i) { return FROMZ == 2 ? make_float2(zf[i], zf[N + i]) : csf[i]; });
+    };
     const uint32_t type = ph.type[x];
     // value of csf[j] once bins below `norm` (and their mirrors) have been replaced by their magnitudes
     auto normalised = [&](int j, uint32_t norm) {
-        const float2 v = csf[j];
+        const float2 v = entry(j);
         const bool isNorm = uint32_t(j) < norm || uint32_t(int(N) - j) < norm;
         return isNorm ? make_float2(cabsHypot(v), 0.f) : v;
     };
@@ -416,8 +432,24 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
                     if (e2 != hipSuccess) return e2;
                 } else
                     runStages(prep, src, dst, twN, N, log2N, nt, stream);
-                // complex csf needs N + 1 entries per task: the caller sized binsWork (float) as 2 * (N + 1) per task for Phase
-                float2 *cout = phase->csfOut ? phase->csfOut + size_t(t0) * (size_t(N) + 1) : reinterpret_cast<float2 *>(binsWork);
+                if (phase->csfOut == nullptr) {
+                    // production: the map kernel splits the csf entries it needs out of Z (no csf array, no split pass)
+                    if (prm.mapped) {
+                        const dim3 grid(gridFor(size_t(nt) * prm.P * kMapLanes));
+                        float *out = prm.mapped + size_t(t0) * 2 * prm.P;
+                        if (phase->fusedFft)
+                            hipLaunchKernelGGL(genericMapPhase<2>, grid, dim3(256), 0, stream, src, N, prm.P, prm.recs, prm.weights, *phase,
+                                               prm.invSize, nt, out);
+                        else
+                            hipLaunchKernelGGL(genericMapPhase<1>, grid, dim3(256), 0, stream, src, N, prm.P, prm.recs, prm.weights, *phase,
+                                               prm.invSize, nt, out);
+                    }
+                    hipError_t e = hipGetLastError();
+                    if (e != hipSuccess) return e;
+                    continue;
+                }
+                // test hook (complex bins out): csf needs N + 1 entries per task
+                float2 *cout = phase->csfOut + size_t(t0) * (size_t(N) + 1);
                 hipLaunchKernelGGL(genericBinsPhase, dim3(gridFor(size_t(nt) * (size_t(N) + 1))), dim3(256), 0, stream, src, N, nt, cout,
                                    phase->fusedFft);
                 csf = cout;
@@ -425,8 +457,8 @@ hipError_t launchGeneric(const StftParams &prm, uint32_t N, const float2 *twN, f
                 csf = phase->csfIn + size_t(t0) * (size_t(N) + 1);
             }
             if (prm.mapped)
-                hipLaunchKernelGGL(genericMapPhase, dim3(gridFor(size_t(nt) * prm.P * kMapLanes)), dim3(256), 0, stream, csf, N, prm.P, prm.recs,
-                                   prm.weights, *phase, prm.invSize, nt, prm.mapped + size_t(t0) * 2 * prm.P);
+                hipLaunchKernelGGL(genericMapPhase<0>, dim3(gridFor(size_t(nt) * prm.P * kMapLanes)), dim3(256), 0, stream, csf, N, prm.P,
+                                   prm.recs, prm.weights, *phase, prm.invSize, nt, prm.mapped + size_t(t0) * 2 * prm.P);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             continue;
