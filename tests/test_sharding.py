@@ -13,7 +13,7 @@ from signalizer_amd.sharding import ShardPlan
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-@pytest.mark.parametrize("S,W,hop", [(2880000, 32768, 8192), (5760000, 65536, 16384), (10000, 4096, 1000), (4096, 4096, 4096)])
+@pytest.mark.parametrize("S,W,hop", [(2880000, 32768, 8192), (5760000, 65536, 16384), (1920000, 65536, 16384), (10000, 4096, 1000), (4096, 4096, 4096)])
 def test_partition_covers_every_global_frame_once(world, S, W, hop):
     sps = [ShardPlan(r, world, S, W, hop) for r in range(world)]
     total = (world * S - W) // hop + 1
