@@ -28,7 +28,7 @@ typedef enum sgz_status {
     SGZ_EINVAL = -1,
     SGZ_EHIP = -2,          /* a HIP runtime call failed / no gfx950 device                     */
     SGZ_ENOMEM = -3,
-    SGZ_EUNSUPPORTED = -4   /* e.g. SpectrumChannels::Phase (not built yet)                     */
+    SGZ_EUNSUPPORTED = -4   /* e.g. the multi-GPU carry fold in SpectrumChannels::Phase            */
 } sgz_status;
 
 /* SpectrumChannels, Source/Common/CommonSignalizer.h:495-539 */
@@ -162,6 +162,10 @@ sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t f
  * multi-GPU carry exchange below needs from every rank before the real pass). */
 sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,
                                   uint8_t *d_rgba, float *d_lines, float *d_state, void *stream);
+
+/* std::log(float) as the dB map evaluates it (TransformDSP.inl:1345): glibc's logf algorithm, bit-identical to libm over every
+ * positive finite float (tests/test_gpu_spectrum.py checks all 2^31 of them).  d_x > 0; DEVICE pointers. */
+sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream);
 
 /* Multi-GPU time-chunk sharding (collective A2).  Rank q renders its frames with a zero
  * carry-in and publishes its end state A_q (the d_state output above).  Because fl(x*pole) is monotone,

@@ -114,6 +114,9 @@ def lib() -> C.CDLL:
         L.sgzo_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_spectrogram_range.restype = C.c_long
         L.sgzo_spectrogram_range.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, C.c_long, C.c_long, vp]
+        L.sgzo_decay_colour.restype = C.c_long
+        L.sgzo_decay_colour.argtypes = [C.POINTER(SpectrumParams), vp, C.c_long, vp, vp]
+        L.sgzo_logf_array.argtypes = [vp, vp, C.c_size_t]
         L.sgzo_num_frames.restype = C.c_long
         L.sgzo_num_frames.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32]
         L.sgzo_zero_crossing_process.restype = C.c_size_t
@@ -266,6 +269,33 @@ def spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False,
                                _ptr(lines) if want_lines else None, _ptr(mapped) if want_mapped else None)
     assert n == F, (n, F)
     return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F}
+
+
+def decay_colour(p: SpectrumParams, mapped: np.ndarray, want_lines: bool = False):
+    """mapAndTransformDFTFilters + blendAndDispatchSpectrums on GIVEN mapped pixels (states start from zero).
+    mapped: [F][C][sides][P] float32 as the HIP path's K_A writes them (two-plane modes: left / right magnitudes, Phase: magnitude /
+    cancellation; one-plane modes: the magnitude).  Returns (rgba [F][P][4], lines [F][C][G][P] complex64 or None)."""
+    m = np.ascontiguousarray(mapped, np.float32)
+    F, Cn, sides, P = m.shape
+    assert Cn == p.num_pairs and P == p.axis_points
+    csp = np.zeros((F, Cn, 2 * P), np.complex64)
+    if p.channel_mode == CH_PHASE:
+        csp[:, :, :P] = m[:, :, 0] + 1j * m[:, :, 1]            # wsp[2x] = magnitude, wsp[2x+1] = cancellation
+    else:
+        for s_ in range(sides):
+            csp[:, :, s_ * P:(s_ + 1) * P] = m[:, :, s_]
+    rgba = np.zeros((F, P, 4), np.uint8)
+    lines = np.zeros((F, Cn, NUM_GRAPHS, P), np.complex64) if want_lines else None
+    n = lib().sgzo_decay_colour(C.byref(p), _ptr(csp), F, _ptr(rgba), _ptr(lines) if want_lines else None)
+    assert n == F
+    return rgba, lines
+
+
+def logf(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().sgzo_logf_array(_ptr(x), _ptr(y), x.size)
+    return y
 
 
 def spectrogram_range(p: SpectrumParams, planar: np.ndarray, f0: int, f1: int) -> np.ndarray:

@@ -56,7 +56,7 @@ void sgzo_slope_map(const sgzo_spectrum_params *p, const float *mapped, float *s
 {
     const float a = (float)p->slope_a, b = (float)p->slope_b;
     for (size_t i = 0; i < p->axis_points; ++i)
-        slope[i] = b * (float)pow((double)mapped[i], (double)a);     /* std::pow(float,float) -> float */
+        slope[i] = b * powf(mapped[i], a);                           /* std::pow(float, float) is powf */
 }
 
 /* Spectrum::calculateSpectrumColourRatios, Source/Spectrum/Spectrum.cpp:226-246 */
@@ -570,4 +570,42 @@ long sgzo_spectrogram_range(const sgzo_spectrum_params *p, const float *const *p
                             long f0, long f1, uint8_t *rgba_out)
 {
     return spectrogram_impl(p, planar, nsamples, f0, f1, rgba_out, NULL, NULL);
+}
+
+/* Test hook: mapAndTransformDFTFilters + blendAndDispatchSpectrums (the two functions above, unchanged) over F frames of
+ * GIVEN csp values [F][C][2P] -- the decay / dB / colour stages on somebody else's mapped pixels, states starting from zero.
+ * This is what makes the end-to-end parity argument a chain: bins within the FFT tolerance, mapping bit-exact given bins,
+ * colour bit-exact given mapped pixels. */
+long sgzo_decay_colour(const sgzo_spectrum_params *p, const sgzo_cf *csp_all, long F, uint8_t *rgba_out, sgzo_cf *line_out)
+{
+    const uint32_t P = p->axis_points, C = p->num_pairs;
+    if (F <= 0 || P < 2) return 0;
+    float *mapped = (float *)malloc(sizeof(float) * P);
+    float *slope = (float *)malloc(sizeof(float) * P);
+    float ratios[SGZO_NUM_SPEC_COLOURS + 1];
+    sgzo_remap_frequencies(p, mapped);
+    sgzo_slope_map(p, mapped, slope);
+    sgzo_colour_ratios(p->ratios, ratios);
+    sgzo_cf *states = (sgzo_cf *)calloc((size_t)C * SGZO_NUM_GRAPHS * P, sizeof(sgzo_cf));
+    sgzo_cf *results = (sgzo_cf *)calloc((size_t)C * SGZO_NUM_GRAPHS * P, sizeof(sgzo_cf));
+    sgzo_cf *frames = (sgzo_cf *)calloc((size_t)C * P, sizeof(sgzo_cf));
+    for (long f = 0; f < F; ++f) {
+        for (uint32_t pr = 0; pr < C; ++pr) {
+            sgzo_cf *st = states + (size_t)pr * SGZO_NUM_GRAPHS * P;
+            sgzo_cf *rs = results + (size_t)pr * SGZO_NUM_GRAPHS * P;
+            sgzo_map_and_transform_filters(p, slope, csp_all + ((size_t)f * C + pr) * 2 * P, st, rs);
+            memcpy(frames + (size_t)pr * P, rs, sizeof(sgzo_cf) * P);
+            if (line_out)
+                memcpy(line_out + ((size_t)f * C + pr) * SGZO_NUM_GRAPHS * P, rs, sizeof(sgzo_cf) * SGZO_NUM_GRAPHS * P);
+        }
+        if (rgba_out) sgzo_blend_column(p, ratios, frames, C, rgba_out + (size_t)f * P * 4);
+    }
+    free(mapped); free(slope); free(states); free(results); free(frames);
+    return F;
+}
+
+/* Test hook: libm's logf over an array (the device's port of glibc's algorithm is checked against it over every float). */
+void sgzo_logf_array(const float *x, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) y[i] = logf(x[i]);
 }

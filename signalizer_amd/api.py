@@ -1,8 +1,8 @@
 """Host-side binding of libsgz.so (include/sgz.h) for Python callers, tests and bench.py.
 
-Mirrors the reference's operator surface for the path: a `SpectrumProcessor` with `on_stream_audio`
-(AudioStream::Listener::onStreamAudio, Source/Spectrum/Spectrum.h:370) / `pop_column`
-(frameQueue.popElement, SpectrumRendering.cpp:696-721) and the batch `render_spectrogram`.
+A thin ctypes layer over the C ABI: `Plan` (the TransformConstant mirror and the batch / stage entry points),
+`render_spectrogram` (host buffers), and the argtypes of the real-time handles (sgz_spectrum_* / sgz_scope_* / sgz_vector_*:
+onStreamAudio in, columns / vertices out), which the tests drive directly.
 PyTorch is used only as the device allocator / stream provider.  No CPU fallback: if libsgz.so is
 missing or no GPU is visible, compute calls raise.
 """
@@ -88,7 +88,7 @@ EXPORTS = [
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped",
-    "sgz_stage_map_from_bins", "sgz_stage_decay_colour", "sgz_decay_fold_carry",
+    "sgz_stage_map_from_bins", "sgz_stage_decay_colour", "sgz_stage_logf", "sgz_decay_fold_carry",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.sgz_stage_map_from_bins.argtypes = [vp, vp, sz, vp, vp]
     L.sgz_stage_decay_colour.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.sgz_decay_fold_carry.argtypes = [vp, vp, vp, u32, u32, vp, vp]
+    L.sgz_stage_logf.argtypes = [vp, vp, sz, vp]
     L.sgz_spectrum_create.argtypes = [C.POINTER(SpectrumConfig), C.POINTER(vp)]
     L.sgz_spectrum_destroy.argtypes = [vp]
     L.sgz_spectrum_destroy.restype = None

@@ -280,7 +280,14 @@ sgz_status sgz_plan_create(const sgz_spectrum_config *cfg, sgz_plan **out)
     sgz_plan *pl = new (std::nothrow) sgz_plan();
     if (!pl) return fail(SGZ_ENOMEM, "out of memory");
     std::string err;
-    sgz_status st = buildPlan(*cfg, pl->impl, err);
+    sgz_status st;
+    try {
+        st = buildPlan(*cfg, pl->impl, err);
+    } catch (const std::bad_alloc &) {                                // no exception crosses the ABI
+        st = SGZ_ENOMEM; err = "out of memory building the plan tables";
+    } catch (const std::exception &e) {
+        st = SGZ_EINVAL; err = e.what();
+    }
     if (st != SGZ_OK) { delete pl; return fail(st, err); }
     *out = pl;
     return SGZ_OK;
@@ -465,6 +472,13 @@ sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     return runDecayColour(plan->impl, d_mapped, long(frames), d_rgba, d_lines, d_state, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream)
+{
+    if (!d_x || !d_y) return fail(SGZ_EINVAL, "null buffer");
+    SGZ_HIP(launchLogf(d_x, d_y, n, reinterpret_cast<hipStream_t>(stream)));
+    return SGZ_OK;
 }
 
 void sgz_debug_set_ablate(uint32_t bits) { g_ablate = bits; }

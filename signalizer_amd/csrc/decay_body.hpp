@@ -15,11 +15,50 @@ constexpr int kMaxChunk = kDecayChunk;
 constexpr int G = SGZ_NUM_GRAPHS;
 constexpr int NC = SGZ_NUM_SPEC_COLOURS + 1;
 
+// std::log(float) as glibc >= 2.27 computes it (sysdeps/ieee754/flt-32/e_logf.c, Szabolcs Nagy's algorithm: x = 2^k z,
+// z in [0x3f330000, 2x), 16 sub-intervals with tabulated 1/c and log(c), a cubic in r = z/c - 1 evaluated in double, one
+// rounding to float).  This is what the reference's `std::log(T)` resolves to on Linux and what the oracle calls, so the dB
+// values -- and with them the truncated uint8 colours -- are bit-identical.  Checked exhaustively against libm's logf over every
+// positive finite float, with and without fused multiply-adds in the double arithmetic (the x86-64 ifunc variants): no
+// difference either way, the double result never sits that close to a float rounding boundary (tests/test_oracle_math.py).
+// x > 0 (possibly subnormal or +inf); the caller has excluded zero, negatives and NaN.
+__device__ static const double kLogfTab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+__device__ __forceinline__ float glibcLogf(float x)
+{
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix == 0x7f800000u) return x;                        // log(inf) = inf
+        ix = __float_as_uint(x * 0x1p23f);                      // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = int((tmp >> 19) & 15u);
+    const int k = int(tmp) >> 23;                               // arithmetic shift
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
+    const double z = double(__uint_as_float(iz));
+    const double r = z * invc - 1.0;
+    const double y0 = logc + double(k) * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return float(y);
+}
+
 __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalars &sc)
 {
     const float deltaX = slope * st * sc.minFracRecip;          // :1343 (left-to-right fp32)
-    // std::log(float): evaluated in fp64 and rounded once (matches a correctly rounded logf)
-    return deltaX > 0.f ? float(log(double(deltaX))) * sc.deltaYRecip : sc.lowerClip;   // :1345
+    return deltaX > 0.f ? glibcLogf(deltaX) * sc.deltaYRecip : sc.lowerClip;   // :1345, std::log(float) = logf
 }
 
 // renderSf + the additive blend of one pair's colour into the column buffer, SpectrumDSP.cpp:119-174
@@ -105,8 +144,11 @@ __device__ __forceinline__ void emitPixel(const DecayParams &prm, uint32_t chunk
                     prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = s;
                 if (!colour && !prm.lines) continue;
                 const float result = dbMap(slope, s, prm.sc);
-                if (prm.lines)
-                    prm.lines[(((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2 + side] = result;
+                if (prm.lines) {
+                    float *lr = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
+                    lr[side] = result;
+                    if (prm.sides == 1) lr[1] = 0.f;            // results[i].phase = 0 in the one-channel modes (:1347)
+                }
                 if (colour) blendColour(cb, result, sca, prm.sc);
             }
         }

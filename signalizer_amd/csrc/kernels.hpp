@@ -88,6 +88,7 @@ hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
 // SpectrumChannels::Phase: sequential-in-time K_B (the cancellation smoother is a linear recurrence: no exact chunk fold);
 // work: [frames][C][P] floats for the main graph's dB values
 hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t stream);
+hipError_t launchLogf(const float *x, float *y, size_t n, hipStream_t stream);   // y = std::log(x) as K_B's dB map computes it (x > 0)
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
 

@@ -17,7 +17,7 @@ namespace sgz {
 uint32_t transformSizeFor(uint32_t W)
 {
     uint32_t n = 1;
-    while (n < W) n <<= 1;
+    while (n < W && n < (1u << 31)) n <<= 1;
     return n < 32 ? 32u : n;           // max(32, nextPow2Inc(W)), TransformConstant.h:84
 }
 
@@ -406,6 +406,26 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         err = "invalid enum value in spectrum config";
         return SGZ_EINVAL;
     }
+    // The reference's GUI clamps the view to [0, 1] and only asserts on the rest in debug builds (TransformDSP.inl:571-577);
+    // a raw C ABI cannot rely on that: a frequency beyond Nyquist would index past csf[N] in every map kernel.
+    const double reals[] = {cfg.view_left, cfg.view_right, cfg.min_log_freq, cfg.low_db, cfg.high_db, cfg.clip_db, cfg.slope_a,
+                            cfg.slope_b, cfg.window_alpha, cfg.window_beta, double(cfg.pole[0]), double(cfg.pole[1]),
+                            cfg.ratios[0], cfg.ratios[1], cfg.ratios[2], cfg.ratios[3], cfg.ratios[4], double(cfg.sample_rate)};
+    for (double v : reals)
+        if (!std::isfinite(v)) { err = "non-finite value in spectrum config"; return SGZ_EINVAL; }
+    if (!(cfg.view_left >= 0.0) || !(cfg.view_right <= 1.0) || !(cfg.view_right > cfg.view_left)) {
+        err = "view must satisfy 0 <= view_left < view_right <= 1";
+        return SGZ_EINVAL;
+    }
+    if (cfg.view_scaling == SGZ_VIEW_LOG && (!(cfg.min_log_freq > 0.0) || !(cfg.min_log_freq < double(cfg.sample_rate) * 0.5))) {
+        err = "min_log_freq must lie in (0, sample_rate / 2)";
+        return SGZ_EINVAL;
+    }
+    if (cfg.window_size > (1u << 24) || cfg.axis_points > (1u << 20) || cfg.num_pairs > 4096) {
+        err = "window_size <= 2^24, axis_points <= 2^20, num_pairs <= 4096";
+        return SGZ_EINVAL;
+    }
+    if (!(cfg.high_db > cfg.low_db)) { err = "high_db must exceed low_db"; return SGZ_EINVAL; }
     p.cfg = cfg;
     p.W = cfg.window_size;
     p.N = transformSizeFor(p.W);
@@ -454,7 +474,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     p.slope.resize(p.P);
     {
         const float a = float(cfg.slope_a), b = float(cfg.slope_b);
-        for (uint32_t i = 0; i < p.P; ++i) p.slope[i] = b * float(std::pow(double(p.mapped[i]), double(a)));
+        for (uint32_t i = 0; i < p.P; ++i) p.slope[i] = b * powf(p.mapped[i], a);   // std::pow(float, float) is powf
     }
     // scalars
     DeviceScalars &s = p.scalars;

@@ -340,6 +340,19 @@ hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, ui
     return hipGetLastError();
 }
 
+// test hook (sgz_stage_logf): std::log(float) exactly as dbMap evaluates it, over an array
+__global__ void __launch_bounds__(256) logfKernel(const float *x, float *y, size_t n)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = glibcLogf(x[i]);
+}
+hipError_t launchLogf(const float *x, float *y, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(logfKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+    return hipGetLastError();
+}
+
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream)
 {
     if (prm.numChunks > uint32_t(kFusedChunks)) {

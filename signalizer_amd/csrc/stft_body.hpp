@@ -429,18 +429,16 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                     w[j] = bufLoad(rsW, tid * 4, j * (T * 4));
                 }
             }
-            // prepareTransform channel mixes (TransformDSP.inl:59-216).  (a*l + b*r) * w * s with a, b in {0, +-1},
-            // s in {1, 0.5} rounds exactly like the reference's `(l +- r) * w * 0.5f` / `l * w`.
-            float mixRL = 1.f, mixRR = 0.f, mixIL = 0.f, mixIR = 0.f, mixS = 1.f;          // Left
-            if (MIX == 1) {
-                if (mode == SGZ_CH_RIGHT) { mixRL = 0.f; mixRR = 1.f; }
-                else if (mode == SGZ_CH_MERGE) { mixRR = 1.f; mixS = 0.5f; }
-                else if (mode == SGZ_CH_SIDE) { mixRR = -1.f; mixS = 0.5f; }
-                else if (mode == SGZ_CH_MIDSIDE) { mixRR = 1.f; mixIL = 1.f; mixIR = -1.f; mixS = 0.5f; }
-            }
+            // prepareTransform channel mixes (TransformDSP.inl:59-216): `l * w`, `r * w`, `(l +- r) * w * 0.5f`.  The channel a mode
+            // does not use is SELECTED away, not multiplied by 0 (an Inf / NaN sample in it must not reach the frame, as in the
+            // reference, which never reads it); x + 0 and x * 1 are exact, so the used channel rounds like the reference's expression.
+            const bool oneCh = mode == SGZ_CH_LEFT || mode == SGZ_CH_RIGHT, midSide = mode == SGZ_CH_MIDSIDE;
+            const float mixSgn = mode == SGZ_CH_SIDE ? -1.f : 1.f, mixS = oneCh ? 1.f : 0.5f;
             auto windowed = [&](float lx, float rx, float wx) {
                 if (MIX != 1) return v2{lx * wx, rx * wx};
-                return v2{(mixRL * lx + mixRR * rx) * wx * mixS, (mixIL * lx + mixIR * rx) * wx * mixS};
+                const float a = mode == SGZ_CH_RIGHT ? rx : lx, b = oneCh ? 0.f : rx;
+                const float il = midSide ? lx : 0.f, ir = midSide ? rx : 0.f;
+                return v2{(a + mixSgn * b) * wx * mixS, (il - ir) * wx * mixS};
             };
 #pragma unroll
             for (int j = 0; j < R; ++j) c[j] = windowed(lv[j], rv[j], w[j]);

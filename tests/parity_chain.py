@@ -1,0 +1,117 @@
+"""The end-to-end parity argument as a chain (tests/test_gpu_fuzz.py, tools/fuzz_parity.py).
+
+The HIP path's FFT is a different -- equally valid -- fp32 butterfly order than the oracle's (and than pffft's, which
+nobody can reproduce here), so raw RGBA8 bytes of a whole render can differ where a 1e-7 relative difference of a
+magnitude crosses a uint8 truncation.  Instead of a blanket "x % of bytes may differ" the sweep proves three links:
+
+  1. mapped pixels:  |K_A(x) - oracle_map(x)| <= MAP_TOL * max|mapped|  per pixel  (the FFT's rounding, nothing else);
+     exceptions must be *explained*: Phase mode's arg-max takes the bin with the largest max(|L|^2, |R|^2) but shows
+     |L| + |R| of it, so two candidate bins whose keys tie to ~1e-7 can be picked differently by two fp32 FFTs -- for each
+     such pixel the candidate the HIP path picked is looked up in the ORACLE's own bins and must tie with the oracle's
+     winner to <= TIE_REL;
+  2. mapping given bins: bit-exact (tests/test_gpu_spectrum.py::test_mapping_bit_exact_given_bins, test_gpu_phase.py);
+  3. colour given mapped pixels: render(x) == oracle_decay_colour(K_A(x)) byte for byte -- checked here on every case.
+"""
+import numpy as np
+
+MAP_TOL = 4e-6          # same bar as the bins (tests/test_gpu_spectrum.py BIN_TOL)
+TIE_REL = 1e-5          # relative key distance that counts as an FFT-rounding tie
+CH_PHASE = 4
+
+
+def _ref_planes(po, p, r_mapped, sides, P):
+    """oracle csp [F][C][2P] complex -> the planes K_A writes, [F][C][sides][P] float32"""
+    F, Cn = r_mapped.shape[:2]
+    out = np.zeros((F, Cn, sides, P), np.float32)
+    if p.channel_mode == CH_PHASE:
+        out[:, :, 0] = r_mapped[:, :, :P].real
+        out[:, :, 1] = r_mapped[:, :, :P].imag
+    else:
+        for s in range(sides):
+            v = r_mapped[:, :, s * P:(s + 1) * P]
+            out[:, :, s] = np.sqrt((v.real.astype(np.float32) ** 2 + v.imag.astype(np.float32) ** 2).astype(np.float32))
+    return out
+
+
+def _phase_tie_ok(po, p, plan, x, hop, f, pair, px, got_val, tol):
+    """Is `got_val` the |L| + |R| of a bin that ties (<= TIE_REL) with the winner of pixel px's arg-max run, in the ORACLE's bins?"""
+    W = p.window_size
+    N = plan.N
+    raw, _, _ = po.frame_bins(p, x[2 * pair, f * hop:f * hop + W], x[2 * pair + 1, f * hop:f * hop + W])
+    Z = raw[:N].astype(np.complex128)
+    mf = plan.mapped_frequencies()
+    num_bins = N // 2
+    f2b = np.float32(num_bins / np.float32(p.sample_rate / 2))
+    lo = max(1, int(np.float32(mf[max(px - 1, 0)]) * f2b) - 1)
+    hi = min(num_bins - 2, int(np.float32(mf[px]) * f2b) + 1)
+    k = np.arange(lo, hi + 1)
+    Lk = (Z[k] + np.conj(Z[N - k])) * 0.5
+    Rk = (Z[k] - np.conj(Z[N - k])) * (-0.5j)
+    key = np.maximum(np.abs(Lk) ** 2, np.abs(Rk) ** 2)
+    val = (np.abs(Lk) + np.abs(Rk)) * (plan.window_scale / (W * 0.5))
+    near = key >= key.max() * (1.0 - TIE_REL)
+    return bool(near.sum() >= 2 and (np.abs(val[near] - got_val) <= tol).any())
+
+
+def check_render(po, plan, cfg, x, gpu, want_lines=False):
+    """Returns (problems: list[str], stats: dict).  x: host float32 [2C][S]."""
+    import torch
+    p = po.params_from_dict(cfg)
+    xg = torch.from_numpy(x).to(gpu)
+    P, sides = plan.P, plan.sides
+    got_mapped = plan.stage_mapped(xg).cpu().numpy()
+    lines_t = torch.empty((got_mapped.shape[0], plan.C, 2, P, 2), dtype=torch.float32, device=gpu) if want_lines else None
+    got_rgba = plan.render(xg, lines=lines_t).cpu().numpy()
+    r = po.spectrogram(p, x, want_mapped=True)
+    problems = []
+    if got_rgba.shape != r["rgba"].shape:
+        return ["shape %s vs %s" % (got_rgba.shape, r["rgba"].shape)], {}
+    # link 3: colour (and lines) given the HIP path's own mapped pixels -- byte for byte
+    chain_rgba, chain_lines = po.decay_colour(p, got_mapped, want_lines=want_lines)
+    if not np.array_equal(got_rgba, chain_rgba):
+        d = np.abs(got_rgba.astype(int) - chain_rgba.astype(int))
+        problems.append("colour given mapped: %d bytes differ (max %d)" % (int((d > 0).sum()), int(d.max())))
+    if want_lines:
+        gl = lines_t.cpu().numpy()                                    # [F][C][G][P][2]
+        rl = np.stack([chain_lines.real, chain_lines.imag], axis=-1).astype(np.float32)
+        # (sqrt(m*m) == m needs m*m normal: the oracle re-derives the magnitude from (re, 0))
+        loud = np.moveaxis(got_mapped, 2, 3)[:, :, None] > 1e-18 if p.channel_mode != CH_PHASE else np.ones_like(gl, bool)
+        same = (gl.view(np.uint32) == rl.view(np.uint32)) | ~np.broadcast_to(loud, gl.shape)
+        if p.channel_mode != CH_PHASE and sides == 1:
+            same[..., 1] = gl[..., 1] == 0                           # results[i].phase = 0
+        if not same.all():
+            problems.append("lines given mapped: %d values differ" % int((~same).sum()))
+    # link 1: mapped pixels against the oracle's, within the FFT tolerance; Phase near-ties explained one by one
+    ref = _ref_planes(po, p, r["mapped"], sides, P)
+    phase = p.channel_mode == CH_PHASE
+    scale = np.abs(ref[:, :, 0] if phase else ref).reshape(ref.shape[0], ref.shape[1], -1).max(axis=2)[:, :, None]   # per (frame, pair)
+    scale = np.maximum(scale, 1e-30)
+    ties = 0
+    finite = np.isfinite(ref) & np.isfinite(got_mapped)
+    if phase:
+        dm = np.abs(got_mapped[:, :, 0] - ref[:, :, 0])
+        bad = (dm > MAP_TOL * scale) & finite[:, :, 0]
+        for f, c, px in zip(*np.nonzero(bad)):
+            if px >= plan.break_pixel and _phase_tie_ok(po, p, plan, x, cfg["hop"], int(f), int(c), int(px),
+                                                         float(got_mapped[f, c, 0, px]), float(MAP_TOL * scale[f, c, 0])):
+                ties += 1
+            else:
+                problems.append("phase magnitude frame %d pair %d pixel %d: %g vs %g" % (f, c, px, got_mapped[f, c, 0, px], ref[f, c, 0, px]))
+        # cancellation = 1 - |L + R| / (|L| + |R|): the FFT's rounding, relative to the pixel's own magnitude
+        tolc = np.minimum(1.0, 8 * MAP_TOL * scale / np.maximum(ref[:, :, 0], 1e-30))
+        dc = np.abs(got_mapped[:, :, 1] - ref[:, :, 1])
+        badc = (dc > tolc) & ~bad & finite[:, :, 1] & finite[:, :, 0]
+        if badc.any():
+            f, c, px = [int(v[0]) for v in np.nonzero(badc)]
+            problems.append("phase cancellation: %d pixels off, first frame %d pair %d pixel %d: %g vs %g (mag %g of %g)" %
+                            (int(badc.sum()), f, c, px, got_mapped[f, c, 1, px], ref[f, c, 1, px], ref[f, c, 0, px], scale[f, c, 0]))
+    else:
+        dm = np.abs(got_mapped - ref)
+        bad = (dm > MAP_TOL * scale[:, :, None]) & finite
+        if bad.any():
+            f, c, s, px = [int(v[0]) for v in np.nonzero(bad)]
+            problems.append("mapped: %d pixels off, first frame %d pair %d side %d pixel %d: %g vs %g (max %g)" %
+                            (int(bad.sum()), f, c, s, px, got_mapped[f, c, s, px], ref[f, c, s, px], scale[f, c, 0]))
+    d = np.abs(got_rgba.astype(int) - r["rgba"].astype(int))
+    return problems, {"ties": ties, "bytes_differing": int((d > 0).sum()), "max_byte_diff": int(d.max()) if d.size else 0,
+                      "frac": float((d > 0).mean()) if d.size else 0.0}

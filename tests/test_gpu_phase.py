@@ -96,10 +96,9 @@ def test_phase_filters_and_colour_given_mapped(gpu, oracle):
     rgba, lines = plan.stage_decay_colour(torch.from_numpy(mapped).to(gpu), want_lines=True, state=state)
     lines = lines.cpu().numpy()
     ref = np.stack([r["lines"].real, r["lines"].imag], axis=-1).astype(np.float32)
-    ulp = np.abs(lines.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
-    assert ulp.max() <= 2, ulp.max()                                 # std::log(float), as in the other modes
-    mism = rgba.cpu().numpy() != r["rgba"]
-    assert mism.mean() <= 1e-4 and np.abs(rgba.cpu().numpy().astype(int) - r["rgba"].astype(int)).max() <= 1
+    # given identical mapped pixels the filters, the dB map (glibc's logf on the device) and the colours are bit-identical
+    assert np.array_equal(lines.view(np.uint32), ref.view(np.uint32)), np.abs(lines - ref).max()
+    assert np.array_equal(rgba.cpu().numpy(), r["rgba"])
 
 
 @pytest.mark.parametrize("interp", [config.INTERP_NONE, config.INTERP_LINEAR, config.INTERP_LANCZOS])
@@ -108,11 +107,11 @@ def test_phase_end_to_end(gpu, oracle, interp):
     cfg = _cfg(interp, P=400)
     frames = 9
     x = synth.gen(14, 48000, 4096 + (frames - 1) * 1024, 2)
-    r = po.spectrogram(po.params_from_dict(cfg), x)
-    rgba = api.Plan(cfg).upload().render(_cuda(x, gpu)).cpu().numpy()
-    diff = np.abs(rgba.astype(int) - r["rgba"].astype(int))
-    # the FFTs differ in rounding: colour bytes may move by one step on a small fraction of pixels
-    assert diff.max() <= 2 and (diff > 0).mean() <= 2e-2, (diff.max(), (diff > 0).mean())
+    # the parity chain (tests/parity_chain.py): mapped magnitudes / cancellations within the FFT tolerance of the oracle's -- an
+    # arg-max pixel that differs more must be a verified near-tie in the oracle's own bins -- and the colours exact given them
+    from parity_chain import check_render
+    problems, stats = check_render(po, api.Plan(cfg).upload(), cfg, x, gpu, want_lines=True)
+    assert not problems, (problems[:5], stats)
 
 
 def test_phase_has_no_carry_fold(gpu):

@@ -40,7 +40,8 @@ def _worker(rank, world, port, cfg, S, q):
     (4096, 1024, 1, 4096 * 5 + 300, 2, config.CH_SEPARATE), (32768, 8192, 1, 32768 * 3 + 1234, 2, config.CH_SEPARATE),
     (8192, 2048, 2, 8192 * 4 + 77, 3, config.CH_SEPARATE),            # halves path, three ranks
     (2048, 700, 1, 2048 * 6 + 5, 2, config.CH_MERGE),                # generic path, a mono mode, hop not dividing the chunk
-    (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE)])             # four ranks, three pairs
+    (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE),              # four ranks, three pairs
+    (65536, 16384, 4, 65536 * 3 + 999, 2, config.CH_SEPARATE)])       # cfg5's transform (N = 65536, halves path), sharded
 def test_sharded_render_equals_single_device(gpu, window, hop, pairs, S, world, mode):
     import torch
     import torch.multiprocessing as mp
