@@ -4,7 +4,7 @@ The HIP path's FFT is a different -- equally valid -- fp32 butterfly order than 
 nobody can reproduce here), so raw RGBA8 bytes of a whole render can differ where a 1e-7 relative difference of a
 magnitude crosses a uint8 truncation.  Instead of a blanket "x % of bytes may differ" the sweep proves three links:
 
-  1. mapped pixels:  |K_A(x) - oracle_map(x)| <= MAP_TOL * max|mapped|  per pixel  (the FFT's rounding, nothing else);
+  1. mapped pixels:  |K_A(x) - oracle_map(x)| <= MAP_TOL * (the frame's largest bin)  per pixel  (the FFT's rounding, nothing else);
      exceptions must be *explained*: Phase mode's arg-max takes the bin with the largest max(|L|^2, |R|^2) but shows
      |L| + |R| of it, so two candidate bins whose keys tie to ~1e-7 can be picked differently by two fp32 FFTs -- for each
      such pixel the candidate the HIP path picked is looked up in the ORACLE's own bins and must tie with the oracle's
@@ -84,7 +84,16 @@ def check_render(po, plan, cfg, x, gpu, want_lines=False):
     # link 1: mapped pixels against the oracle's, within the FFT tolerance; Phase near-ties explained one by one
     ref = _ref_planes(po, p, r["mapped"], sides, P)
     phase = p.channel_mode == CH_PHASE
-    scale = np.abs(ref[:, :, 0] if phase else ref).reshape(ref.shape[0], ref.shape[1], -1).max(axis=2)[:, :, None]   # per (frame, pair)
+    # the FFT's rounding error scales with the frame's largest bin, wherever it lies -- not with the largest pixel of a zoomed view:
+    # scale[f][c] = invSize * max_k |Z[k]| of the windowed frame (numpy fp64)
+    W, hop, N = p.window_size, cfg["hop"], plan.N
+    win = plan.window()[:W].astype(np.float64)
+    inv_size = plan.window_scale / (W * 0.5)
+    scale = np.zeros((ref.shape[0], ref.shape[1], 1))
+    for f in range(ref.shape[0]):
+        for c in range(ref.shape[1]):
+            z = (x[2 * c, f * hop:f * hop + W].astype(np.float64) + 1j * x[2 * c + 1, f * hop:f * hop + W]) * win
+            scale[f, c, 0] = inv_size * np.abs(np.fft.fft(z, N)).max()
     scale = np.maximum(scale, 1e-30)
     ties = 0
     finite = np.isfinite(ref) & np.isfinite(got_mapped)
