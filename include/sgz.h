@@ -25,6 +25,8 @@ typedef enum sgz_status {
     SGZ_OK = 0,
     SGZ_EMPTY = 1,          /* nothing to pop (frameQueue empty)                              */
     SGZ_SKIPPED_FRAME = 2,  /* prepareTransform returned false, TransformDSP.inl:45-46          */
+    SGZ_BUSY = 3,           /* a real-time push found the GPU several blocks behind (or a reconfiguration in progress): the block
+                               was NOT taken -- push never waits                                   */
     SGZ_EINVAL = -1,
     SGZ_EHIP = -2,          /* a HIP runtime call failed / no gfx950 device                     */
     SGZ_ENOMEM = -3,
@@ -45,6 +47,12 @@ enum { SGZ_WIN_RECT = 0, SGZ_WIN_HANN, SGZ_WIN_HAMMING, SGZ_WIN_FLATTOP, SGZ_WIN
 enum { SGZ_WIN_SYMMETRIC = 0, SGZ_WIN_PERIODIC };
 /* OscChannels, Source/Common/CommonSignalizer.h:458-493 */
 enum { SGZ_OSC_LEFT = 0, SGZ_OSC_RIGHT, SGZ_OSC_MID, SGZ_OSC_SIDE, SGZ_OSC_SEPARATE, SGZ_OSC_MIDSIDE };
+
+/* OscilloscopeContent::TriggeringMode, Source/Oscilloscope/OscilloscopeParameters.h:50-58 (built: None, ZeroCrossing) */
+enum { SGZ_TRIG_NONE = 0, SGZ_TRIG_SPECTRAL, SGZ_TRIG_WINDOW, SGZ_TRIG_ENVELOPE_HOLD, SGZ_TRIG_ZERO_CROSSING };
+/* EnvelopeModes / SubSampleInterpolation, Source/Common/CommonSignalizer.h:72-85 */
+enum { SGZ_ENV_NONE = 0, SGZ_ENV_RMS, SGZ_ENV_PEAK_DECAY };
+enum { SGZ_SUBSAMPLE_NONE = 0, SGZ_SUBSAMPLE_RECTANGULAR, SGZ_SUBSAMPLE_LINEAR, SGZ_SUBSAMPLE_LANCZOS };
 
 #define SGZ_NUM_SPEC_COLOURS 5   /* SpectrumContent::numSpectrumColours */
 #define SGZ_NUM_GRAPHS 2         /* SpectrumContent::LineGraphs::LineEnd (LineMain, LineSecond) */
@@ -230,6 +238,54 @@ sgz_status sgz_scope_zero_crossing_device(sgz_zero_crossing_state *st, uint32_t 
 /* peak envelope over `channels` windows of n samples; env (host, in/out, [channels]); returns gain */
 sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t channels, size_t n,
                                   uint32_t lanes, double coeff_pow, double *env, double *gain, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Oscilloscope real-time handle: replaces Oscilloscope::ProcessorShell::onStreamAudio (Source/Oscilloscope/Oscilloscope.h:293) ->
+ * StreamState::audioEntryPoint (OscilloscopeDSP.inl:401-424) on the audio thread, and on the render thread
+ * Oscilloscope::runPeakFilter (OscilloscopeDSP.inl:713-886) and drawWavePlot (OscilloscopeRendering.cpp:551-891, the Linear and
+ * Lanczos branches) -> the (x, y, z) + colour stream PrimitiveDrawer::addVertex / addColour receive.
+ * The trigger detector, TriggeringProcessor::processMutating's window selection (StreamPreprocessing.h:79-206), the back / front
+ * rings (ChannelData.h) and the envelope all live in HBM; one push = one staged copy + one kernel launch, and push never waits for
+ * the GPU (SGZ_BUSY instead).  One producer thread (push), one consumer thread (everything else).
+ * Not built (SGZ_EUNSUPPORTED): trigger modes Spectral / Window / EnvelopeHold, per-sample frequency colouring,
+ * interpolation None / Rectangular. */
+typedef struct sgz_scope_config {
+    double   sample_rate;
+    double   window_size;        /* state.effectiveWindowSize in samples (fractions allowed)                     */
+    uint32_t num_channels;       /* even, 2..64                                                                  */
+    uint32_t trigger_mode;       /* SGZ_TRIG_NONE / SGZ_TRIG_ZERO_CROSSING                                       */
+    uint32_t channel_mode;       /* SGZ_OSC_* (OscChannels): trigger mix, envelope mix                           */
+    uint32_t envelope_mode;      /* SGZ_ENV_*: RMS runs in push (audioProcessing), PEAK_DECAY in sgz_scope_peak_filter */
+    uint32_t interpolation;      /* SGZ_SUBSAMPLE_LINEAR / SGZ_SUBSAMPLE_LANCZOS                                 */
+    uint32_t max_block;          /* longest block push will be given (0: 8192)                                   */
+    double   trigger_threshold;  /* content->triggerThreshold                                                    */
+    double   trigger_channel;    /* content->triggeringChannel, 1-based (calculateTriggerIndices)                */
+    double   envelope_window;    /* content->envelopeWindow normalised value = seconds             */
+    uint8_t  colours[64][4];     /* per channel: filterStates.channels[c].defaultKey as RGBA8                    */
+} sgz_scope_config;
+typedef struct sgz_scope sgz_scope;
+sgz_status sgz_scope_create(const sgz_scope_config *cfg, sgz_scope **out);
+void       sgz_scope_destroy(sgz_scope *s);
+/* handleFlagUpdates -> TriggeringProcessor::setSettings (Oscilloscope.cpp:310).  A changed ceil(window) resizes (and clears) the rings. */
+sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg);
+/* onStreamAudio(ctx, float** buffer, numChannels, numSamples); the steady clock is the running count of pushed samples */
+sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
+/* runPeakFilter once per rendered frame: delta_time = openGLDeltaTime(), lanes = the SIMD width whose tail the reference drops
+ * (8 = AVX); *auto_gain = state.autoGain (optional; reading it waits for the kernel) */
+sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain);
+/* envelopeGain of the RMS mode and the per-channel envelope states (either may be NULL) */
+sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes /*num_channels*/);
+size_t     sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view);
+/* One evaluator's line strip.  evaluator: SGZ_OSC_LEFT / RIGHT (channel `channel` / `channel` + 1) or SGZ_OSC_MID / SIDE (0.5 (l +- r)
+ * of the pair at `channel`); view->window_size is ignored (the stream's is used).  xyz: float3 per vertex, rgba: RGBA8 per vertex
+ * (may be NULL); *count: in = capacity of the buffers in vertices, out = vertices written.  Lanczos below one pixel per sample
+ * falls back to Linear like the reference (OscilloscopeRendering.cpp:575-578): x is then the sample index (sample space). */
+sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz,
+                              uint8_t *rgba, uint32_t *count);
+/* parity hooks: front buffer memory of one channel (begin()) + its write cursor; TriggeringProcessor counters
+ * {frontOrigin, bufferedSamples, oldPeak, currentPeak, steadyClock, peaks.size(), isWorkingOnPeak, swaps} */
+sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out /*size*/, uint32_t *size, uint32_t *cursor);
+sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * Vectorscope: polar transform (drawPolarPlot, VectorscopeRendering.cpp:500-746) and the audio-thread

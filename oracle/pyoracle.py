@@ -70,7 +70,7 @@ class VectorFilters(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "sgz_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "sgz_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -130,6 +130,23 @@ def lib() -> C.CDLL:
         L.sgzo_vector_polar.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
         L.sgzo_vector_audio_processing.argtypes = [C.POINTER(VectorFilters), vp, vp, C.c_size_t, C.c_uint32,
                                                    C.c_float, C.c_float, C.c_float, C.c_int, vp]
+        L.sgzo_scope_wave_plot.restype = C.c_size_t
+        L.sgzo_scope_wave_plot.argtypes = [C.POINTER(ScopeView), C.c_int, C.c_int, vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t]
+        L.sgzo_scope_stream_create.restype = vp
+        L.sgzo_scope_stream_create.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int, C.c_double, C.c_uint32, C.c_double,
+                                               C.c_uint32, C.c_double]
+        L.sgzo_scope_stream_destroy.argtypes = [vp]
+        L.sgzo_scope_stream_audio.argtypes = [vp, vp, C.c_size_t]
+        L.sgzo_scope_stream_size.restype = C.c_size_t
+        L.sgzo_scope_stream_size.argtypes = [vp]
+        L.sgzo_scope_stream_front.restype = C.c_size_t
+        L.sgzo_scope_stream_front.argtypes = [vp, C.c_uint32, vp]
+        L.sgzo_scope_stream_envelope_gain.restype = C.c_double
+        L.sgzo_scope_stream_envelope_gain.argtypes = [vp]
+        L.sgzo_scope_stream_envelopes.argtypes = [vp, vp]
+        L.sgzo_scope_stream_state.argtypes = [vp, vp]
+        L.sgzo_scope_stream_peak_filter.restype = C.c_double
+        L.sgzo_scope_stream_peak_filter.argtypes = [vp, C.c_uint32, C.c_double]
         _lib = L
     return _lib
 
@@ -347,3 +364,74 @@ def vector_audio_processing(f: VectorFilters, L, R, envelope_coeff, stereo_coeff
     lib().sgzo_vector_audio_processing(C.byref(f), _ptr(L), _ptr(R), L.size, lanes, envelope_coeff,
                                        stereo_coeff, second_speed, env_mode, C.byref(gain))
     return gain.value
+
+
+TRIG_NONE, TRIG_ZERO_CROSSING = 0, 4
+ENV_NONE, ENV_RMS, ENV_PEAK_DECAY = 0, 1, 2
+OSC_LEFT, OSC_RIGHT, OSC_MID, OSC_SIDE, OSC_SEPARATE, OSC_MIDSIDE = range(6)
+
+
+class ScopeStream:
+    """Oscilloscope::StreamState for TriggeringMode None / ZeroCrossing (oracle/scope_stream.c)."""
+
+    def __init__(self, channels, sample_rate, window_size, trigger_mode=TRIG_ZERO_CROSSING, threshold=0.0, osc_mode=OSC_LEFT,
+                 trigger_channel=1.0, env_mode=ENV_NONE, envelope_window=0.3):
+        self.channels = channels
+        self.h = lib().sgzo_scope_stream_create(channels, sample_rate, window_size, trigger_mode, threshold, osc_mode,
+                                                trigger_channel, env_mode, envelope_window)
+
+    def __del__(self):
+        try:
+            lib().sgzo_scope_stream_destroy(self.h)
+        except Exception:
+            pass
+
+    def audio(self, block: np.ndarray):
+        b = np.ascontiguousarray(block, np.float32)
+        assert b.shape[0] == self.channels
+        ptrs = (C.c_void_p * self.channels)(*[b[c].ctypes.data for c in range(self.channels)])
+        lib().sgzo_scope_stream_audio(self.h, ptrs, b.shape[1])
+
+    @property
+    def size(self) -> int:
+        return lib().sgzo_scope_stream_size(self.h)
+
+    def front(self, c: int):
+        """(raw ring memory [size], cursor)"""
+        out = np.zeros(self.size, np.float32)
+        cur = lib().sgzo_scope_stream_front(self.h, c, _ptr(out))
+        return out, int(cur)
+
+    def front_in_time_order(self, c: int) -> np.ndarray:
+        m, cur = self.front(c)
+        return np.concatenate([m[cur:], m[:cur]])
+
+    @property
+    def envelope_gain(self) -> float:
+        return lib().sgzo_scope_stream_envelope_gain(self.h)
+
+    def envelopes(self) -> np.ndarray:
+        out = np.zeros(self.channels, np.float32)
+        lib().sgzo_scope_stream_envelopes(self.h, _ptr(out))
+        return out
+
+    def state(self) -> dict:
+        out = np.zeros(8, np.uint64)
+        lib().sgzo_scope_stream_state(self.h, _ptr(out))
+        keys = ("frontOrigin", "bufferedSamples", "oldPeak", "currentPeak", "steadyClock", "peaks", "isWorkingOnPeak", "swaps")
+        return {k: int(v) for k, v in zip(keys, out)}
+
+    def peak_filter(self, lanes: int, coeff: float) -> float:
+        return lib().sgzo_scope_stream_peak_filter(self.h, lanes, coeff)
+
+
+def scope_wave_plot(view: ScopeView, trigger_mode: int, interpolation: int, mem_a: np.ndarray, mem_b: np.ndarray, eval_mode: int,
+                    cursor: int, max_points: int = 1 << 22) -> np.ndarray:
+    """drawWavePlot for one evaluator -> vertices [n][3]"""
+    a = np.ascontiguousarray(mem_a, np.float32)
+    b = np.ascontiguousarray(mem_b, np.float32)
+    n = lib().sgzo_scope_wave_plot(C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, None, 0)
+    out = np.zeros((n, 3), np.float32)
+    m = lib().sgzo_scope_wave_plot(C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, _ptr(out), n)
+    assert m == n
+    return out

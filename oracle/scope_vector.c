@@ -219,3 +219,72 @@ void sgzo_vector_audio_processing(sgzo_vector_filters *f, const float *L, const 
         for (int j = 0; j < 2; ++j) f->balance[i][j] = balance[i][j];
     }
 }
+
+/* drawWavePlot (OscilloscopeRendering.cpp:551-891) for TriggeringMode None (0) / ZeroCrossing (4) and SubSampleInterpolation
+ * Linear (2) / Lanczos (3), one evaluator (SampleColourEvaluators.h): eval_mode 0 = *A, 1 = 0.5 (A + B), 2 = 0.5 (A - B).
+ * memA / memB: front-buffer memory (proxy view begin()) of `size` samples, `cursor` = cursorPosition().  xyz: (x, y, 0) per vertex
+ * as handed to PrimitiveDrawer::addVertex.  Returns the vertex count. */
+static float wave_eval(const float *a, const float *b, int mode, long idx)
+{
+    if (mode == 1) return 0.5f * (a[idx] + b[idx]);
+    if (mode == 2) return 0.5f * (a[idx] - b[idx]);
+    return a[idx];
+}
+
+size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                            int eval_mode, size_t size, size_t cursor, float *xyz, size_t max_points)
+{
+    enum { KernelSize = 10, KernelBufferSize = 21 };
+    if (size == 0) return 0;
+    const double horizontalDelta = v->right - v->left;
+    long roundedWindow = (long)ceil(v->window_size);                                   /* :563 */
+    const double sizeMinusOne = fmax(1.0, v->window_size - 1);
+    const double pixelsPerSample = v->rendering_scale * fabs(((double)v->width - 1) / (sizeMinusOne * horizontalDelta));
+    if (pixelsPerSample < 1 && interpolation != 0) interpolation = 2;                  /* :575-578: Linear below one pixel per sample */
+    const double triggerSampleOffset = trigger_mode == 4 ? (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5 : 0.0;
+    long bufferOffset;
+    if (trigger_mode == 4) bufferOffset = (long)ceil(triggerSampleOffset);             /* :590-596 */
+    else bufferOffset = roundedWindow;                                                 /* :598-612, triggering off: no cycle samples */
+    roundedWindow = roundedWindow > 2 ? roundedWindow : 2;                             /* :615 */
+    size_t n = 0;
+    if (interpolation == 2) {                                                          /* Linear, :707-741 */
+        long p = ((long)cursor - bufferOffset) % (long)size;                           /* eval.startFrom(-(bufferOffset + 0)) */
+        if (p < 0) p += (long)size;
+        const float endCondition = (float)roundedWindow;
+        for (float i = 0; i < endCondition; i += 1) {
+            if (n < max_points) { xyz[n * 3] = i; xyz[n * 3 + 1] = wave_eval(memA, memB, eval_mode, p); xyz[n * 3 + 2] = 0; }
+            ++n;
+            if (++p == (long)size) p = 0;
+        }
+        return n;
+    }
+    /* Lanczos, :790-891 */
+    double samplePos;
+    if (trigger_mode == 4) samplePos = triggerSampleOffset;
+    else samplePos = ceil(0.0 * 2 + v->window_size - 0.0);                              /* :813, :817-821 */
+    const double inc = horizontalDelta / (v->rendering_scale * ((double)v->width - 1));
+    double unitSpacePos = v->left;
+    const double samplesPerPixel = 1.0 / pixelsPerSample;
+    samplePos += -unitSpacePos / inc * samplesPerPixel;
+    double currentSample = floor(samplePos);
+    long p = ((long)cursor + (-(long)floor(samplePos) - KernelSize)) % (long)size;       /* eval.startFrom, :829 */
+    if (p < 0) p += (long)size;
+    float kernel[KernelBufferSize];
+    for (int i = 0; i < KernelBufferSize; ++i) { kernel[i] = wave_eval(memA, memB, eval_mode, p); if (++p == (long)size) p = 0; }
+    do {
+        double delta = currentSample - samplePos;
+        while (delta > 1) {
+            samplePos += 1;
+            delta -= 1;
+            memmove(kernel, kernel + 1, sizeof(float) * (KernelBufferSize - 1));
+            kernel[KernelBufferSize - 1] = wave_eval(memA, memB, eval_mode, p);
+            if (++p == (long)size) p = 0;
+        }
+        const double y = sgzo_lanczos_filter_f64(kernel, KernelBufferSize, (double)KernelSize + delta, KernelSize);
+        if (n < max_points) { xyz[n * 3] = (float)unitSpacePos; xyz[n * 3 + 1] = (float)y; xyz[n * 3 + 2] = 0; }
+        ++n;
+        currentSample += samplesPerPixel;
+        unitSpacePos += inc;
+    } while (unitSpacePos < (v->right + inc));
+    return n;
+}

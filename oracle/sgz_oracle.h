@@ -146,9 +146,29 @@ size_t sgzo_scope_lanczos(const sgzo_scope_view *v, const float *ring, size_t le
                           float *out_x, float *out_y, size_t max_points);
 size_t sgzo_scope_num_points(const sgzo_scope_view *v);
 
+/* drawWavePlot for one evaluator on front-buffer memory + cursor (trigger_mode 0 None / 4 ZeroCrossing; interpolation 2 Linear / 3 Lanczos) */
+size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                            int eval_mode, size_t size, size_t cursor, float *xyz, size_t max_points);
+
 /* a12: peak envelope, OscilloscopeDSP.inl:713-886 / VectorscopeRendering.cpp:826-889 */
 double sgzo_peak_filter(const float *const *ch, uint32_t nch, size_t n, uint32_t lanes,
                         double coeff_pow, double *env /*nch, in/out*/);
+
+/* ---------------- Oscilloscope audio-thread state machine (a11, a12; scope_stream.c) ---------------- */
+/* StreamState::audioEntryPoint for TriggeringMode None (0) / ZeroCrossing (4): trigger detection, TriggeringProcessor::processMutating
+ * (window selection, back -> front swapBuffers), RMS envelope, ring writes.  env_mode: 0 none, 1 RMS, 2 peak decay. */
+typedef struct sgzo_scope_stream sgzo_scope_stream;
+sgzo_scope_stream *sgzo_scope_stream_create(uint32_t channels, double sample_rate, double window_size, int trigger_mode,
+                                            double threshold, uint32_t osc_mode, double trigger_channel_1based,
+                                            uint32_t env_mode, double envelope_window_s);
+void   sgzo_scope_stream_destroy(sgzo_scope_stream *s);
+void   sgzo_scope_stream_audio(sgzo_scope_stream *s, const float *const *planar, size_t n);
+size_t sgzo_scope_stream_size(const sgzo_scope_stream *s);                          /* front buffer size = ceil(window + 1) */
+size_t sgzo_scope_stream_front(const sgzo_scope_stream *s, uint32_t c, float *out); /* raw ring memory; returns the cursor */
+double sgzo_scope_stream_envelope_gain(const sgzo_scope_stream *s);
+void   sgzo_scope_stream_envelopes(const sgzo_scope_stream *s, float *out);
+void   sgzo_scope_stream_state(const sgzo_scope_stream *s, uint64_t out[8]);
+double sgzo_scope_stream_peak_filter(sgzo_scope_stream *s, uint32_t lanes, double coeff);   /* runPeakFilter, all channel modes */
 
 /* ---------------- Vectorscope (a13, a14) ---------------- */
 void sgzo_vector_polar(const float *L, const float *R, size_t n, int fade, float *xyz /*n*3*/);

@@ -18,7 +18,7 @@ from . import build as _build
 NUM_SPEC_COLOURS = 5
 NUM_GRAPHS = 2
 
-SGZ_OK, SGZ_EMPTY, SGZ_SKIPPED_FRAME = 0, 1, 2
+SGZ_OK, SGZ_EMPTY, SGZ_SKIPPED_FRAME, SGZ_BUSY = 0, 1, 2, 3
 SGZ_EINVAL, SGZ_EHIP, SGZ_ENOMEM, SGZ_EUNSUPPORTED = -1, -2, -3, -4
 
 
@@ -53,6 +53,13 @@ class ScopeView(C.Structure):
 class ZeroCrossingState(C.Structure):
     _fields_ = [("state", C.c_double), ("threshold", C.c_double), ("steady_clock", C.c_uint64),
                 ("cross_origin", C.c_uint64), ("count", C.c_uint64), ("armed", C.c_int32), ("_pad", C.c_int32)]
+
+
+class ScopeConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("window_size", C.c_double), ("num_channels", C.c_uint32), ("trigger_mode", C.c_uint32),
+                ("channel_mode", C.c_uint32), ("envelope_mode", C.c_uint32), ("interpolation", C.c_uint32), ("max_block", C.c_uint32),
+                ("trigger_threshold", C.c_double), ("trigger_channel", C.c_double), ("envelope_window", C.c_double),
+                ("colours", (C.c_uint8 * 4) * 64)]
 
 
 class VectorFilters(C.Structure):
@@ -91,6 +98,8 @@ EXPORTS = [
     "sgz_stage_map_from_bins", "sgz_stage_decay_colour", "sgz_stage_logf", "sgz_decay_fold_carry",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state",
+    "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
+    "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
     "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
 ]
@@ -151,6 +160,18 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_pop_column.argtypes = [vp, vp, C.POINTER(u32)]
     L.sgz_spectrum_line_results.argtypes = [vp, u32, u32, vp]
     L.sgz_spectrum_clear_state.argtypes = [vp]
+    L.sgz_scope_create.argtypes = [C.POINTER(ScopeConfig), C.POINTER(vp)]
+    L.sgz_scope_destroy.argtypes = [vp]
+    L.sgz_scope_destroy.restype = None
+    L.sgz_scope_configure.argtypes = [vp, C.POINTER(ScopeConfig)]
+    L.sgz_scope_push.argtypes = [vp, vp, u32, u32]
+    L.sgz_scope_peak_filter.argtypes = [vp, C.c_double, u32, C.POINTER(C.c_double)]
+    L.sgz_scope_gains.argtypes = [vp, C.POINTER(C.c_double), vp]
+    L.sgz_scope_vertex_count.argtypes = [vp, C.POINTER(ScopeView)]
+    L.sgz_scope_vertex_count.restype = sz
+    L.sgz_scope_vertices.argtypes = [vp, C.POINTER(ScopeView), u32, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_scope_front.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
+    L.sgz_scope_debug_state.argtypes = [vp, vp]
     L.sgz_scope_num_points.argtypes = [C.POINTER(ScopeView)]
     L.sgz_scope_num_points.restype = sz
     L.sgz_scope_lanczos_device.argtypes = [C.POINTER(ScopeView), vp, sz, sz, u32, vp, vp]
@@ -347,3 +368,73 @@ def rotate_hue(rgb, amount: float) -> np.ndarray:
     out = np.zeros(3, np.uint8)
     lib().sgz_rotate_hue_rgb8(_np_ptr(a), C.c_float(amount), _np_ptr(out))
     return out
+
+
+class Scope:
+    """sgz_scope_* handle: the Oscilloscope's audio-thread state machine in HBM + drawWavePlot vertices."""
+
+    def __init__(self, **kw):
+        self.cfg = ScopeConfig()
+        colours = kw.pop("colours", None)
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        for c in range(64):
+            col = colours[c] if colours is not None and c < len(colours) else (255, 255, 255, 255)
+            for j in range(4):
+                self.cfg.colours[c][j] = int(col[j])
+        self.h = C.c_void_p()
+        check(lib().sgz_scope_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sgz_scope_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, **kw):
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        check(lib().sgz_scope_configure(self.h, C.byref(self.cfg)))
+
+    def push(self, block: np.ndarray) -> int:
+        b = np.ascontiguousarray(block, np.float32)
+        ptrs = (C.c_void_p * b.shape[0])(*[b[c].ctypes.data for c in range(b.shape[0])])
+        return check(lib().sgz_scope_push(self.h, ptrs, b.shape[0], b.shape[1]))
+
+    def front(self, channel: int):
+        size, cur = C.c_uint32(0), C.c_uint32(0)
+        check(lib().sgz_scope_front(self.h, channel, None, C.byref(size), C.byref(cur)))
+        out = np.zeros(size.value, np.float32)
+        check(lib().sgz_scope_front(self.h, channel, _np_ptr(out), C.byref(size), C.byref(cur)))
+        return out, int(cur.value)
+
+    def state(self) -> dict:
+        out = np.zeros(8, np.uint64)
+        check(lib().sgz_scope_debug_state(self.h, _np_ptr(out)))
+        keys = ("frontOrigin", "bufferedSamples", "oldPeak", "currentPeak", "steadyClock", "peaks", "isWorkingOnPeak", "swaps")
+        return {k: int(v) for k, v in zip(keys, out)}
+
+    def gains(self):
+        g = C.c_double(0)
+        env = np.zeros(self.cfg.num_channels, np.float32)
+        check(lib().sgz_scope_gains(self.h, C.byref(g), _np_ptr(env)))
+        return g.value, env
+
+    def peak_filter(self, delta_time: float, lanes: int = 8) -> float:
+        g = C.c_double(0)
+        check(lib().sgz_scope_peak_filter(self.h, delta_time, lanes, C.byref(g)))
+        return g.value
+
+    def vertices(self, view: ScopeView, evaluator: int, channel: int = 0, want_colours: bool = True):
+        n = lib().sgz_scope_vertex_count(self.h, C.byref(view))
+        xyz = np.zeros((n, 3), np.float32)
+        rgba = np.zeros((n, 4), np.uint8) if want_colours else None
+        cnt = C.c_uint32(n)
+        check(lib().sgz_scope_vertices(self.h, C.byref(view), evaluator, channel, _np_ptr(xyz),
+                                       _np_ptr(rgba) if want_colours else None, C.byref(cnt)))
+        return xyz[:cnt.value], (rgba[:cnt.value] if want_colours else None)

@@ -21,20 +21,26 @@ using namespace sgz;
 namespace {
 
 // ------------------------------------------------------------------------------------------- K9
-struct ScopeScalars { double samplePos0, inc, samplesPerPixel, unit0, right; long cursor0; size_t points; };
+struct ScopeScalars { double samplePos0, inc, samplesPerPixel, unit0, right, pixelsPerSample; long cursor0; size_t points; };
 
-ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len)
+// triggerMode: OscilloscopeContent::TriggeringMode (0 None, 4 ZeroCrossing)
+ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMode = SGZ_TRIG_ZERO_CROSSING)
 {
     ScopeScalars s{};
     const double horizontalDelta = v.right - v.left;
     const double sizeMinusOne = std::max(1.0, v.window_size - 1);                            // :568
     const double pixelsPerSample = v.rendering_scale * std::fabs((double(v.width) - 1) / (sizeMinusOne * horizontalDelta));   // :572
-    const double sampleOffset = (v.window_size * 0.5 - double(int(v.window_size * 0.5))) - 1.5;   // OscilloscopeDSP.inl:238
+    s.pixelsPerSample = pixelsPerSample;
+    double samplePos;
+    if (triggerMode == SGZ_TRIG_ZERO_CROSSING)
+        samplePos = (v.window_size * 0.5 - double(int(v.window_size * 0.5))) - 1.5;          // triggerState.sampleOffset, OscilloscopeDSP.inl:238
+    else
+        samplePos = std::ceil(0.0 * 2 + v.window_size - 0.0);                                // :806-816 (cycleSamples = sampleOffset = 0)
     s.inc = horizontalDelta / (v.rendering_scale * (double(v.width) - 1));                   // :822
     s.samplesPerPixel = 1.0 / pixelsPerSample;                                               // :824
     s.unit0 = v.left;
     s.right = v.right;
-    s.samplePos0 = sampleOffset + (-s.unit0 / s.inc * s.samplesPerPixel);                    // :826
+    s.samplePos0 = samplePos + (-s.unit0 / s.inc * s.samplesPerPixel);                       // :826
     // number of points = trip count of the reference's do-while on a running fp64 sum (:883-889).  It depends on the view
     // only and costs ~1 ns per point on the host, so the last view's count is remembered.
     static thread_local double memo[3] = {0, 0, 0};
@@ -116,6 +122,72 @@ scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channe
         }
         xy[size_t(c) * points + p] = make_float2(ux, float(acc));
     }
+}
+
+// ---- drawWavePlot on the handle's front ring (sgz_scope_vertices): the ring's write cursor is read from device memory, the
+// sample comes from an evaluator (SampleColourEvaluators.h: one channel, or 0.5 (l +- r)), and a vertex is (x, y, 0) + RGBA8.
+__device__ __forceinline__ float evalSample(const float *a, const float *b, uint32_t mode, uint32_t idx)
+{
+    if (mode == 1u) return 0.5f * (a[idx] + b[idx]);       // MidSideEvaluatorBase<0, std::plus<>>::evaluateSample
+    if (mode == 2u) return 0.5f * (a[idx] - b[idx]);       // <1, std::minus<>>
+    return a[idx];
+}
+
+__global__ void __launch_bounds__(256)
+scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, const uint32_t *d_cursor, size_t points,
+                       double samplePos0, double spp, double unit0, double inc, long cursor0, uint32_t key, float3 *xyz, uint32_t *rgba)
+{
+    const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= points) return;
+    const long base = long(*d_cursor);                      // cursorPosition(): the evaluator's offsets count from it
+    const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
+    const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
+    const double delta = D - shifts;
+    const double x = 10.0 + delta;
+    const long fl = long(floor(x));
+    const long cur = (base + cursor0 + long(shifts)) % long(len);
+    const double kPi = 3.14159265358979323846;
+    const long rn = long(rint(x));
+    const double e = x - double(rn);
+    const double sPi = sin(kPi * e);
+    double s10, c10;
+    sincos(kPi * e / 10.0, &s10, &c10);
+    double acc = 0.0;
+    const long idx0 = cur + (fl - 9);
+#pragma unroll
+    for (int t = 0; t < 20; ++t) {
+        const long i = fl - 9 + t;
+        if (i < 0 || i >= 21) continue;
+        const double d = x - double(i);
+        const long m = rn - i;
+        double wt;
+        if (d == 0.0) wt = 1.0;
+        else {
+            const double pd = kPi * d;
+            const double sa = (m & 1) ? -sPi : sPi;
+            const long am = m < 0 ? -m : m;
+            const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
+            const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
+            wt = 10.0 * sa * sb / (pd * pd);
+        }
+        long idx = (idx0 + t) % long(len); if (idx < 0) idx += long(len);
+        acc += double(evalSample(ringA, ringB, evalMode, uint32_t(idx))) * wt;
+    }
+    xyz[p] = make_float3(float(unit0 + double(p) * inc), float(acc), 0.f);
+    if (rgba) rgba[p] = key;
+}
+
+// Linear: vertex i = (i, sample[cursor - bufferOffset + i], 0), i < endCondition (OscilloscopeRendering.cpp:707-741)
+__global__ void __launch_bounds__(256)
+scopeWaveLinearKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, const uint32_t *d_cursor, size_t points,
+                      long start0, uint32_t key, float3 *xyz, uint32_t *rgba)
+{
+    const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= points) return;
+    long idx = (long(*d_cursor) + start0 + long(p)) % long(len);
+    if (idx < 0) idx += long(len);
+    xyz[p] = make_float3(float(p), evalSample(ringA, ringB, evalMode, uint32_t(idx)), 0.f);
+    if (rgba) rgba[p] = key;
 }
 
 // ------------------------------------------------------------------------------------------- K10
@@ -327,6 +399,7 @@ sgz_status scratch(size_t bytes, void **out)
 }
 
 bool g_constInit = false;
+sgz_status initConst();
 sgz_status initConst()
 {
     if (g_constInit) return SGZ_OK;
@@ -339,7 +412,55 @@ sgz_status initConst()
     return SGZ_OK;
 }
 
+// which branch drawWavePlot takes: Lanczos falls back to Linear below one pixel per sample (:575-578)
+bool waveIsLanczos(const sgz_scope_view &v, uint32_t interpolation)
+{
+    if (interpolation != SGZ_SUBSAMPLE_LANCZOS) return false;
+    const double sizeMinusOne = std::max(1.0, v.window_size - 1);
+    const double pps = v.rendering_scale * std::fabs((double(v.width) - 1) / (sizeMinusOne * (v.right - v.left)));
+    return !(pps < 1);
+}
+
 }  // namespace
+
+namespace sgz {
+
+size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation)
+{
+    if (waveIsLanczos(view, interpolation)) return scopeDerive(view, 0).points;
+    return size_t(std::max<long>(2, long(std::ceil(view.window_size))));            // endCondition = roundedWindow (:614, :631)
+}
+
+hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
+                               const float *ringB, uint32_t evalMode, uint32_t size, const uint32_t *d_cursor, uint32_t rgba,
+                               float *d_xyz, uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
+{
+    if (initConst() != SGZ_OK) return hipErrorUnknown;
+    const int block = 256;
+    if (waveIsLanczos(view, interpolation)) {
+        const ScopeScalars s = scopeDerive(view, size, triggerMode);
+        if (s.points > capacity) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(scopeWaveLanczosKernel, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, ringA, ringB,
+                           evalMode, size, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0, rgba,
+                           reinterpret_cast<float3 *>(d_xyz), d_rgba);
+        *points = s.points;
+    } else {
+        const long roundedWindow = long(std::ceil(view.window_size));
+        long bufferOffset;
+        if (triggerMode == SGZ_TRIG_ZERO_CROSSING) {
+            const double realOffset = (view.window_size * 0.5 - double(int(view.window_size * 0.5))) - 1.5;
+            bufferOffset = long(std::ceil(realOffset));                                 // :593-594
+        } else bufferOffset = roundedWindow;                                            // :611 (no cycle buffers: triggering is off)
+        const size_t n = size_t(std::max<long>(2, roundedWindow));
+        if (n > capacity) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(scopeWaveLinearKernel, dim3(unsigned((n + block - 1) / block)), dim3(block), 0, stream, ringA, ringB, evalMode,
+                           size, d_cursor, n, -bufferOffset, rgba, reinterpret_cast<float3 *>(d_xyz), d_rgba);
+        *points = n;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sgz
 
 extern "C" {
 
