@@ -299,6 +299,36 @@ sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float
                                               size_t n, uint32_t lanes, float envelope_coeff, float stereo_coeff,
                                               float second_speed, int env_mode, float *gain_out, void *stream);
 
+/* Vectorscope real-time handle: replaces VectorScope::Processor::onStreamAudio -> audioProcessing (Source/Vectorscope/Vectorscope.h:141,
+ * Vectorscope.cpp:268-392) and the cpl::AudioStream history the renderer reads, and on the render thread VectorScope::runPeakFilter
+ * (VectorscopeRendering.cpp:826-889) and drawPolarPlot (:500-746) for every channel pair -> the (x, y, z) + (r, g, b) stream
+ * PrimitiveDrawer::addVertex / addColour receive.  History ring, filter states and gain live in HBM; push = one staged copy + one
+ * launch and never waits for the GPU (SGZ_BUSY instead).  One producer thread (push), one consumer thread (everything else). */
+typedef struct sgz_vector_config {
+    double   sample_rate;
+    uint32_t num_channels;       /* even, 2..64; pair p = channels 2p, 2p+1; the filters listen to channels 0, 1       */
+    uint32_t window_size;        /* audio history in samples = vertices per pair                                       */
+    uint32_t envelope_mode;      /* SGZ_ENV_*: RMS updates the gain in push, PEAK_DECAY in sgz_vector_peak_filter      */
+    uint32_t lanes;              /* SIMD width of the reference build (8 = AVX): tails it drops / handles in scalar code */
+    uint32_t fade_history;       /* state.fadeHistory: colours fade with age (VectorscopeRendering.cpp:637-746)         */
+    uint32_t max_block;          /* longest block push will be given (0: 8192)                                          */
+    double   envelope_window;    /* seconds (content->envelopeWindow normalised)                                        */
+    double   stereo_window;      /* seconds (content->stereoWindow normalised)                                          */
+    float    colours[32][3];     /* per pair: the waveform colour as getFloatRed / Green / Blue                         */
+} sgz_vector_config;
+typedef struct sgz_vector sgz_vector;
+sgz_status sgz_vector_create(const sgz_vector_config *cfg, sgz_vector **out);
+void       sgz_vector_destroy(sgz_vector *s);
+sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg);
+sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
+sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain /*optional: reading it waits*/);
+sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain);
+/* xyz: float3 [window_size], rgb: float3 [window_size] or NULL; *count: in = capacity in vertices, out = window_size.  Vertex
+ * order = the reference's: the older section of the ring ([cursor, size)) first, then [0, cursor). */
+sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count);
+/* parity hook: history ring memory of one channel + the write cursor */
+sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out /*window_size*/, uint32_t *size, uint32_t *cursor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         L.sgzo_vector_polar.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
         L.sgzo_vector_audio_processing.argtypes = [C.POINTER(VectorFilters), vp, vp, C.c_size_t, C.c_uint32,
                                                    C.c_float, C.c_float, C.c_float, C.c_int, vp]
+        L.sgzo_vector_polar_view.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int, vp, vp, vp]
         L.sgzo_scope_wave_plot.restype = C.c_size_t
         L.sgzo_scope_wave_plot.argtypes = [C.POINTER(ScopeView), C.c_int, C.c_int, vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, C.c_size_t]
         L.sgzo_scope_stream_create.restype = vp
@@ -435,3 +436,15 @@ def scope_wave_plot(view: ScopeView, trigger_mode: int, interpolation: int, mem_
     m = lib().sgzo_scope_wave_plot(C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, _ptr(out), n)
     assert m == n
     return out
+
+
+def vector_polar_view(mem_l: np.ndarray, mem_r: np.ndarray, cursor: int, lanes: int = 8, fade_history: bool = False,
+                      colour=(1.0, 1.0, 1.0)):
+    """drawPolarPlot over the two sections of a history ring -> (xyz [size][3], rgb [size][3])"""
+    L = np.ascontiguousarray(mem_l, np.float32)
+    R = np.ascontiguousarray(mem_r, np.float32)
+    col = np.asarray(colour, np.float32)
+    xyz = np.zeros((L.size, 3), np.float32)
+    rgb = np.zeros((L.size, 3), np.float32)
+    lib().sgzo_vector_polar_view(_ptr(L), _ptr(R), L.size, cursor, lanes, int(fade_history), _ptr(col), _ptr(xyz), _ptr(rgb))
+    return xyz, rgb

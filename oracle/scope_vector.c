@@ -210,7 +210,8 @@ void sgzo_vector_audio_processing(sgzo_vector_filters *f, const float *L, const 
         phase[1] = outPhase + stereoPoles[1] * (phase[1] - outPhase);
     }
     if (env_mode == 1) {
-        const double currentEnvelope = 1.0 / fmax(sqrt((double)filterEnv[0]), sqrt((double)filterEnv[1]));
+        /* std::sqrt(T) with T = float (Vectorscope.cpp:351) */
+        const double currentEnvelope = 1.0 / (double)fmaxf(sqrtf(filterEnv[0]), sqrtf(filterEnv[1]));
         f->env[0] = filterEnv[0]; f->env[1] = filterEnv[1];
         if (isnormal(currentEnvelope) && gain_out) *gain_out = (float)currentEnvelope;
     }
@@ -287,4 +288,61 @@ size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int inte
         unitSpacePos += inc;
     } while (unitSpacePos < (v->right + inc));
     return n;
+}
+
+/* drawPolarPlot (VectorscopeRendering.cpp:500-746) over an AudioBufferView of the history ring: memory memL / memR of `size` samples
+ * with write cursor `cursor` -- section 0 = [cursor, size), section 1 = [0, cursor) (getItIndex / getItRange; UNVERIFIED vs cpl).
+ * The fade ramp is one running fp32 SIMD sum across both sections (:528-543, :592, :634).  fade_history selects the colour variant
+ * (:637-746): rgb_out gets colour * vSampleFade (SIMD body) or colour * (fade + 1) (scalar tail); without it rgb_out = colour.
+ * lanes = elements_of<V> (8 = AVX).  xyz: (X len, Y len, fade - 1). */
+void sgzo_vector_polar_view(const float *memL, const float *memR, size_t size, size_t cursor, uint32_t lanes, int fade_history,
+                            const float colour[3], float *xyz, float *rgb_out)
+{
+    const float cosineRotation = -0.70710678118654752440f, sineRotation = 0.70710678118654752440f;
+    const long V = (long)lanes;
+    const float fadePerSample = 1.0f / (float)size;
+    const float incremental = fadePerSample * (float)V;
+    float sampleFade[64], outFade[64];
+    for (long l = 0; l < V; ++l) { outFade[l] = fadePerSample * (float)l; sampleFade[l] = outFade[l]; }
+    size_t out = 0;
+    for (int section = 0; section < 2; ++section) {
+        const float *left = section == 0 ? memL + cursor : memL;
+        const float *right = section == 0 ? memR + cursor : memR;
+        const long sectionSamples = section == 0 ? (long)(size - cursor) : (long)cursor;
+        long i = 0;
+        for (; i < (sectionSamples - V); i += V) {
+            for (long l = 0; l < V; ++l) {
+                const float vl = left[i + l], vr = right[i + l];
+                const float length = fmaxf(fabsf(vl), fabsf(vr));
+                const float vY = vl * cosineRotation - vr * sineRotation;
+                const float vX = vl * sineRotation + vr * cosineRotation;
+                float angle = atanf(vX / vY);
+                if (vl == 0.0f && vr == 0.0f) angle = 0.0f;
+                outFade[l] = sampleFade[l] - 1.0f;
+                xyz[out * 3 + 0] = sinf(angle) * length;
+                xyz[out * 3 + 1] = cosf(angle) * length;
+                xyz[out * 3 + 2] = outFade[l];
+                if (rgb_out) for (int k = 0; k < 3; ++k) rgb_out[out * 3 + k] = fade_history ? colour[k] * sampleFade[l] : colour[k];
+                ++out;
+            }
+            for (long l = 0; l < V; ++l) sampleFade[l] += incremental;
+        }
+        long remaining = 0;
+        const float currentSampleFade = outFade[V - 1];
+        for (; i < sectionSamples; ++i, ++remaining) {
+            const float vl = left[i], vr = right[i];
+            const float length = fmaxf(fabsf(vl), fabsf(vr));
+            const float vY = vl * cosineRotation - vr * sineRotation;
+            const float vX = vl * sineRotation + vr * cosineRotation;
+            float angle = atanf(vX / vY);
+            if (vl == 0.0f && vr == 0.0f) angle = 0.0f;
+            const float currentFade = currentSampleFade - (float)remaining * fadePerSample;
+            xyz[out * 3 + 0] = sinf(angle) * length;
+            xyz[out * 3 + 1] = cosf(angle) * length;
+            xyz[out * 3 + 2] = currentFade;
+            if (rgb_out) for (int k = 0; k < 3; ++k) rgb_out[out * 3 + k] = fade_history ? colour[k] * (currentFade + 1) : colour[k];
+            ++out;
+        }
+        for (long l = 0; l < V; ++l) sampleFade[l] += fadePerSample * (float)remaining;
+    }
 }

@@ -172,6 +172,9 @@ double sgzo_scope_stream_peak_filter(sgzo_scope_stream *s, uint32_t lanes, doubl
 
 /* ---------------- Vectorscope (a13, a14) ---------------- */
 void sgzo_vector_polar(const float *L, const float *R, size_t n, int fade, float *xyz /*n*3*/);
+/* drawPolarPlot over a two-section view of the history ring (memory + write cursor), fade ramp and colours included */
+void sgzo_vector_polar_view(const float *memL, const float *memR, size_t size, size_t cursor, uint32_t lanes, int fade_history,
+                            const float colour[3], float *xyz /*size*3*/, float *rgb_out /*size*3 or NULL*/);
 typedef struct sgzo_vector_filters {          /* Source/Vectorscope/Vectorscope.h filters */
     float env[2];
     float balance[2][2];

@@ -66,6 +66,12 @@ class VectorFilters(C.Structure):
     _fields_ = [("env", C.c_float * 2), ("balance", (C.c_float * 2) * 2), ("phase", C.c_float * 2)]
 
 
+class VectorConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_double), ("num_channels", C.c_uint32), ("window_size", C.c_uint32), ("envelope_mode", C.c_uint32),
+                ("lanes", C.c_uint32), ("fade_history", C.c_uint32), ("max_block", C.c_uint32), ("envelope_window", C.c_double),
+                ("stereo_window", C.c_double), ("colours", (C.c_float * 3) * 32)]
+
+
 def config_from_dict(d: dict) -> SpectrumConfig:
     c = SpectrumConfig()
     for k, v in d.items():
@@ -100,6 +106,8 @@ EXPORTS = [
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state",
+    "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
+    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
     "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
 ]
@@ -172,6 +180,15 @@ def lib() -> C.CDLL:
     L.sgz_scope_vertices.argtypes = [vp, C.POINTER(ScopeView), u32, u32, vp, vp, C.POINTER(u32)]
     L.sgz_scope_front.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_debug_state.argtypes = [vp, vp]
+    L.sgz_vector_create.argtypes = [C.POINTER(VectorConfig), C.POINTER(vp)]
+    L.sgz_vector_destroy.argtypes = [vp]
+    L.sgz_vector_destroy.restype = None
+    L.sgz_vector_configure.argtypes = [vp, C.POINTER(VectorConfig)]
+    L.sgz_vector_push.argtypes = [vp, vp, u32, u32]
+    L.sgz_vector_peak_filter.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+    L.sgz_vector_filters_get.argtypes = [vp, C.POINTER(VectorFilters), C.POINTER(C.c_double)]
+    L.sgz_vector_vertices.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_vector_history.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_num_points.argtypes = [C.POINTER(ScopeView)]
     L.sgz_scope_num_points.restype = sz
     L.sgz_scope_lanczos_device.argtypes = [C.POINTER(ScopeView), vp, sz, sz, u32, vp, vp]
@@ -438,3 +455,59 @@ class Scope:
         check(lib().sgz_scope_vertices(self.h, C.byref(view), evaluator, channel, _np_ptr(xyz),
                                        _np_ptr(rgba) if want_colours else None, C.byref(cnt)))
         return xyz[:cnt.value], (rgba[:cnt.value] if want_colours else None)
+
+
+class Vector:
+    """sgz_vector_* handle: history ring + audio-thread filters + polar vertices in HBM."""
+
+    def __init__(self, **kw):
+        self.cfg = VectorConfig()
+        colours = kw.pop("colours", None)
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        for p in range(32):
+            col = colours[p] if colours is not None and p < len(colours) else (1.0, 1.0, 1.0)
+            for j in range(3):
+                self.cfg.colours[p][j] = float(col[j])
+        self.h = C.c_void_p()
+        check(lib().sgz_vector_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sgz_vector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, block: np.ndarray) -> int:
+        b = np.ascontiguousarray(block, np.float32)
+        ptrs = (C.c_void_p * b.shape[0])(*[b[c].ctypes.data for c in range(b.shape[0])])
+        return check(lib().sgz_vector_push(self.h, ptrs, b.shape[0], b.shape[1]))
+
+    def history(self, channel: int):
+        size, cur = C.c_uint32(0), C.c_uint32(0)
+        out = np.zeros(self.cfg.window_size, np.float32)
+        check(lib().sgz_vector_history(self.h, channel, _np_ptr(out), C.byref(size), C.byref(cur)))
+        return out, int(cur.value)
+
+    def filters(self):
+        f, g = VectorFilters(), C.c_double(0)
+        check(lib().sgz_vector_filters_get(self.h, C.byref(f), C.byref(g)))
+        return f, g.value
+
+    def peak_filter(self, delta_time: float) -> float:
+        g = C.c_double(0)
+        check(lib().sgz_vector_peak_filter(self.h, delta_time, C.byref(g)))
+        return g.value
+
+    def vertices(self, pair: int = 0, want_colours: bool = True):
+        n = self.cfg.window_size
+        xyz = np.zeros((n, 3), np.float32)
+        rgb = np.zeros((n, 3), np.float32) if want_colours else None
+        cnt = C.c_uint32(n)
+        check(lib().sgz_vector_vertices(self.h, pair, _np_ptr(xyz), _np_ptr(rgb) if want_colours else None, C.byref(cnt)))
+        return xyz, rgb

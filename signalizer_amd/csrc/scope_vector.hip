@@ -598,7 +598,7 @@ sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float
     SGZ_HIP(hipMemcpyAsync(&h, scr, sizeof(h), hipMemcpyDeviceToHost, s));
     SGZ_HIP(hipStreamSynchronize(s));
     if (env_mode == 1) {                                                      // :346-363
-        const double currentEnvelope = 1.0 / std::max(std::sqrt(double(h.env[0])), std::sqrt(double(h.env[1])));
+        const double currentEnvelope = 1.0 / double(std::max(std::sqrt(h.env[0]), std::sqrt(h.env[1])));   // std::sqrt(T), T = float (:351)
         f->env[0] = h.env[0]; f->env[1] = h.env[1];
         if (std::isnormal(currentEnvelope) && gain_out) *gain_out = float(currentEnvelope);
     }

@@ -1,0 +1,393 @@
+// vector_stream.hip -- the Vectorscope's real-time handle (sgz_vector_*): audio history ring, the audio thread's one-pole
+// filters and the polar plot's vertex / colour stream, all resident in HBM.  gfx950 only.
+//
+// Replaces VectorScope::Processor::onStreamAudio -> audioProcessing (Source/Vectorscope/Vectorscope.cpp:268-392) on the audio
+// thread -- plus the cpl::AudioStream history the renderer reads (a CLIFOStream per channel) -- and on the render thread
+// VectorScope::runPeakFilter (VectorscopeRendering.cpp:826-889) and drawPolarPlot (:500-746) for every channel pair.
+//
+// Layout: ring [channels][size], size = the audio history window in samples, one write cursor.  A render sees the ring as the
+// reference's AudioBufferView does: section 0 = memory [cursor, size), section 1 = [0, cursor) (getItIndex / getItRange).
+// One push = one staged copy + one launch (ring append + the eight one-pole recurrences + the RMS epilogue); push never waits.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "rt_common.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace sgz;
+
+namespace {
+
+struct VecDev {
+    float env[2], bal[2][2], phase[2];        // FilterStates (Vectorscope.h:97-111): envelope, balance[Slow/Fast][L/R], phase[Slow/Fast]
+    double envelopeGain;                      // Processor::envelopeGain (relaxed_atomic<double>, starts at 1)
+    unsigned int cursor, pad;
+    unsigned long long written;
+};
+
+struct VecIngest {
+    VecDev *st;
+    const float *block; uint32_t n, channels;
+    float *ring; uint32_t size;
+    uint32_t lanes, envMode;
+    float envelope, pole0, pole1;
+};
+
+__global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
+{
+    __shared__ float sL[64], sR[64], sP[64];
+    VecDev *st = prm.st;
+    const int tid = threadIdx.x;
+    const uint32_t n = prm.n, size = prm.size, C = prm.channels;
+    const uint32_t cursor0 = st->cursor;
+    // ring append (only the newest `size` samples of a longer block survive)
+    const uint32_t skip = n > size ? n - size : 0, m = n - skip;
+    const uint32_t cur0 = (cursor0 + skip) % size;
+    for (uint32_t e = tid; e < m * C; e += blockDim.x) {
+        const uint32_t c = e / m, i = e - c * m;
+        uint32_t d = cur0 + i; if (d >= size) d -= size;
+        prm.ring[size_t(c) * size + d] = prm.block[size_t(c) * n + skip + i];
+    }
+    // audioProcessing on channels 0 / 1 (Vectorscope.cpp:268-377): wave 0; lane k < 8 owns one recurrence:
+    // 0,1 envelope L/R; 2,3 slow balance L/R; 4,5 fast balance L/R; 6 slow phase; 7 fast phase
+    const uint32_t np = n - (n & (prm.lanes - 1));                        // :292, the SIMD tail of the block is dropped
+    if (tid < 64) {
+        const int lane = tid;
+        float y = 0.f, a = 0.f;
+        if (lane < 8) {
+            const float *s = reinterpret_cast<const float *>(st);
+            y = s[lane];
+            a = lane < 2 ? prm.envelope : ((lane == 2 || lane == 3 || lane == 6) ? prm.pole0 : prm.pole1);
+        }
+        const int sel = (lane == 0 || lane == 2 || lane == 4) ? 0 : ((lane == 1 || lane == 3 || lane == 5) ? 1 : 2);
+        const float *L = prm.block, *R = prm.block + n;
+        for (uint32_t base = 0; base < np; base += 64) {
+            const uint32_t i = base + lane;
+            if (i < np) {
+                const float l = L[i], r = R[i];
+                const float mReal = -0.70710678118654752440f, mImag = 0.70710678118654752440f;
+                const float vX = l * mReal - r * mImag;                    // :303
+                const float vY = r * mImag + l * mReal;                    // :304
+                const float radians = atanf(vY / vX);                      // :310
+                const float ang = (vX == 0.f && vY == 0.f) ? 0.78539816339744830962f : radians;   // :311
+                sP[lane] = cosf(ang * 2.0f);                               // :316
+                sL[lane] = l * l; sR[lane] = r * r;                        // :323-324
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane < 8) {
+                const float *src = sel == 0 ? sL : (sel == 1 ? sR : sP);
+                const int cnt = int(min(64u, np - base));
+                for (int k = 0; k < cnt; ++k) { const float x = src[k]; y = x + a * (y - x); }   // :327-342
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // :346-376: the envelope filters are stored (and the gain refreshed) only in the RMS mode; balance and phase always
+        const float e0 = __shfl(y, 0), e1 = __shfl(y, 1);
+        if (lane < 8 && (lane >= 2 || prm.envMode == 1u)) reinterpret_cast<float *>(st)[lane] = y;
+        if (lane == 0 && prm.envMode == 1u) {
+            const double currentEnvelope = 1.0 / double(fmaxf(__builtin_sqrtf(e0), __builtin_sqrtf(e1)));   // std::sqrt(T), T = float
+            const double ax = fabs(currentEnvelope);
+            if (ax >= 2.2250738585072014e-308 && ax < INFINITY) st->envelopeGain = currentEnvelope;         // std::isnormal
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { st->cursor = (cursor0 + n) % size; st->written += n; }
+}
+
+// VectorScope::runPeakFilter: memory-order maximum of |x| over channels 0 / 1 (the last size mod lanes slots dropped), then
+// envelope = max(envelope * coeff, peak^2) in double, stored as float; envelopeGain = 1 / max sqrt, if normal
+__global__ void __launch_bounds__(1024) vectorPeakKernel(VecDev *st, const float *ring, uint32_t size, uint32_t lanes, double coeff)
+{
+    __shared__ float sm[2][16];
+    const uint32_t stop = size - (size & (lanes - 1));
+    const int tid = threadIdx.x, wave = tid >> 6;
+    float ml = 0.f, mr = 0.f;
+    for (uint32_t i = tid; i < stop; i += blockDim.x) { ml = fmaxf(ml, fabsf(ring[i])); mr = fmaxf(mr, fabsf(ring[size + i])); }
+    for (int o = 32; o > 0; o >>= 1) { ml = fmaxf(ml, __shfl_xor(ml, o)); mr = fmaxf(mr, __shfl_xor(mr, o)); }
+    if ((tid & 63) == 0) { sm[0][wave] = ml; sm[1][wave] = mr; }
+    __syncthreads();
+    if (tid != 0) return;
+    float hl = 0.f, hr = 0.f;
+    for (unsigned w = 0; w < blockDim.x / 64; ++w) { hl = fmaxf(hl, sm[0][w]); hr = fmaxf(hr, sm[1][w]); }
+    const double highestLeft = hl, highestRight = hr;
+    st->env[0] = float(fmax(double(st->env[0]) * coeff, highestLeft * highestLeft));       // :873-874
+    st->env[1] = float(fmax(double(st->env[1]) * coeff, highestRight * highestRight));
+    const double currentEnvelope = 1.0 / fmax(sqrt(double(st->env[0])), sqrt(double(st->env[1])));   // :876
+    const double ax = fabs(currentEnvelope);
+    if (ax >= 2.2250738585072014e-308 && ax < INFINITY) st->envelopeGain = currentEnvelope;
+}
+
+// The fade ramp is a running fp32 SIMD sum (vSampleFade += fadePerSample * V once per SIMD iteration, += fadePerSample *
+// remainder after each section, VectorscopeRendering.cpp:528-543, :592, :634): sequential by construction but a function of
+// (size, cursor, lanes) only.  One lane per SIMD lane replays it into ramp[] = vSampleFade of every SIMD-body sample (in vertex
+// order), and tail[s] = outFade[V-1] as the scalar tail of section s sees it.
+__global__ void vectorRampKernel(const VecDev *st, uint32_t size, uint32_t lanes, float *ramp, float *tail)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cursor = st->cursor;
+    const long V = long(lanes);
+    const float fadePerSample = 1.0f / float(size);
+    const float incr = fadePerSample * float(V);
+    float f = fadePerSample * float(lane);                  // vSampleFade = outFade = fadePerSample * i
+    float lastOut = f;                                       // outFade[lane] (only lane V-1's matters)
+    size_t base = 0;
+    for (int section = 0; section < 2; ++section) {
+        const long n = section == 0 ? long(size - cursor) : long(cursor);
+        long i = 0;
+        for (; i < n - V; i += V) {
+            if (lane < lanes) ramp[base + size_t(i) + lane] = f;
+            lastOut = f - 1.0f;
+            f += incr;
+        }
+        if (lane == lanes - 1) tail[section] = lastOut;
+        const long remaining = n - i > 0 ? n - i : 0;
+        f += fadePerSample * float(remaining);
+        base += size_t(n);
+    }
+}
+
+struct PolarParams {
+    const VecDev *st;
+    const float *ring; uint32_t size, lanes, fade;
+    const float *ramp, *tail;
+    float3 *xyz, *rgb;
+    float colour[3];
+    uint32_t pair;
+};
+__global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams prm)
+{
+    const size_t v = size_t(blockIdx.x) * blockDim.x + threadIdx.x;     // vertex index: section 0 then section 1
+    const uint32_t size = prm.size;
+    if (v >= size) return;
+    const uint32_t cursor = prm.st->cursor;
+    const long V = long(prm.lanes);
+    const long n0 = long(size - cursor);
+    const int section = long(v) < n0 ? 0 : 1;
+    const long n = section == 0 ? n0 : long(cursor);
+    const long i = section == 0 ? long(v) : long(v) - n0;               // index inside the section
+    const uint32_t mem = section == 0 ? cursor + uint32_t(i) : uint32_t(i);
+    const float l = prm.ring[size_t(2 * prm.pair) * size + mem];
+    const float r = prm.ring[size_t(2 * prm.pair + 1) * size + mem];
+    const float cosineRotation = -0.70710678118654752440f, sineRotation = 0.70710678118654752440f;   // :521-524
+    const float length = fmaxf(fabsf(l), fabsf(r));                                                 // :563
+    const float vY = l * cosineRotation - r * sineRotation;                                          // :566
+    const float vX = l * sineRotation + r * cosineRotation;                                          // :567
+    float angle = atanf(vX / vY);                                                                    // :576
+    if (l == 0.f && r == 0.f) angle = 0.f;                                                           // :578
+    float sx, cy;
+    sincosf(angle, &sx, &cy);
+    // SIMD body covers i < mainEnd = V * ceil((n - V) / V) (the loop `for (; i < n - V; i += V)`), the scalar tail the rest
+    const long iters = n > V ? (n - V + V - 1) / V : 0;
+    const long mainEnd = iters * V;
+    const float fadePerSample = 1.0f / float(size);
+    float z, cf;
+    if (i < mainEnd) {
+        const float sf = prm.ramp[v];
+        z = sf - 1.0f;                                       // outFade = vSampleFade - 1 (:592)
+        cf = sf;                                             // colour * vSampleFade (:697-699)
+    } else {
+        z = prm.tail[section] - float(i - mainEnd) * fadePerSample;      // :600, :634
+        cf = z + 1.0f;                                       // colour * (currentFade + 1) (:738)
+    }
+    prm.xyz[v] = make_float3(sx * length, cy * length, z);
+    if (prm.rgb) prm.rgb[v] = prm.fade ? make_float3(prm.colour[0] * cf, prm.colour[1] * cf, prm.colour[2] * cf)
+                                       : make_float3(prm.colour[0], prm.colour[1], prm.colour[2]);
+}
+
+}  // namespace
+
+struct sgz_vector {
+    sgz_vector_config cfg{};
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    StageRing stage;
+    VecDev *d_state = nullptr;
+    float *d_ring = nullptr;
+    uint32_t size = 0;
+    float envelopeCoeff = 0.f, stereoCoeff = 0.f, pole1 = 0.f;
+    float *d_ramp = nullptr, *d_tail = nullptr, *d_xyz = nullptr, *d_rgb = nullptr;
+    void *h_out = nullptr;
+    uint64_t busy = 0;
+};
+
+static void vectorFree(sgz_vector *s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    s->stage.release();
+    for (void *p : {(void *)s->d_state, (void *)s->d_ring, (void *)s->d_ramp, (void *)s->d_tail, (void *)s->d_xyz, (void *)s->d_rgb})
+        if (p) (void)hipFree(p);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool fresh)
+{
+    if (!(cfg->sample_rate >= 1) || !std::isfinite(cfg->sample_rate)) return fail(SGZ_EINVAL, "sample_rate");
+    if (cfg->num_channels < 2 || (cfg->num_channels & 1) || cfg->num_channels > 64) return fail(SGZ_EINVAL, "num_channels must be even, 2..64");
+    if (cfg->window_size < 1 || cfg->window_size > (1u << 26)) return fail(SGZ_EINVAL, "window_size");
+    if (cfg->lanes == 0 || (cfg->lanes & (cfg->lanes - 1)) || cfg->lanes > 64) return fail(SGZ_EINVAL, "lanes must be a power of two <= 64");
+    if (cfg->envelope_mode > SGZ_ENV_PEAK_DECAY) return fail(SGZ_EINVAL, "envelope_mode");
+    if (!std::isfinite(cfg->envelope_window) || !std::isfinite(cfg->stereo_window) || cfg->envelope_window < 0 || cfg->stereo_window < 0)
+        return fail(SGZ_EINVAL, "window times");
+    if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    const uint32_t C = cfg->num_channels, size = cfg->window_size;
+    const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
+    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock;
+    if (realloc) {
+        for (void **p : {(void **)&s->d_ring, (void **)&s->d_ramp, (void **)&s->d_xyz, (void **)&s->d_rgb}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (s->h_out) { (void)hipHostFree(s->h_out); s->h_out = nullptr; }
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ring), size_t(C) * size * sizeof(float)));
+        SGZ_HIP(hipMemset(s->d_ring, 0, size_t(C) * size * sizeof(float)));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ramp), size_t(size) * sizeof(float)));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_xyz), size_t(size) * 3 * sizeof(float)));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rgb), size_t(size) * 3 * sizeof(float)));
+        SGZ_HIP(hipHostMalloc(&s->h_out, size_t(size) * 6 * sizeof(float), hipHostMallocDefault));
+        sgz_status st = s->stage.init(C, maxBlock);
+        if (st != SGZ_OK) return st;
+        if (!s->d_state) {
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(VecDev)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_tail), 2 * sizeof(float)));
+            VecDev h{};
+            h.envelopeGain = 1.0;                          // Processor(): envelopeGain(1)
+            SGZ_HIP(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
+        } else {
+            VecDev h{};
+            SGZ_HIP(hipMemcpy(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost));
+            h.cursor = 0; h.written = 0;
+            SGZ_HIP(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
+        }
+    }
+    s->size = size;
+    // handleFlagUpdates, Vectorscope.cpp:201-202: relaxed_atomic<float> coefficients
+    s->envelopeCoeff = float(std::exp(-1.0 / (cfg->envelope_window * cfg->sample_rate)));
+    s->stereoCoeff = float(std::exp(-1.0 / (cfg->stereo_window * cfg->sample_rate)));
+    s->pole1 = std::pow(s->stereoCoeff, 0.25f);           // secondStereoFilterSpeed(0.25f), Vectorscope.cpp:281
+    s->cfg = *cfg;
+    return SGZ_OK;
+}
+
+extern "C" {
+
+sgz_status sgz_vector_create(const sgz_vector_config *cfg, sgz_vector **out)
+{
+    if (!cfg || !out) return fail(SGZ_EINVAL, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(SGZ_EHIP, "no HIP device visible (libsgz has no CPU fallback)");
+    sgz_vector *s = new (std::nothrow) sgz_vector();
+    if (!s) return fail(SGZ_ENOMEM, "out of memory");
+    const sgz_status st = vectorSetup(s, cfg, true);
+    if (st != SGZ_OK) { vectorFree(s); return st; }
+    *out = s;
+    return SGZ_OK;
+}
+
+void sgz_vector_destroy(sgz_vector *s) { vectorFree(s); }
+
+sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg)
+{
+    if (!s || !cfg) return fail(SGZ_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    return vectorSetup(s, cfg, false);
+}
+
+sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
+{
+    if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
+    std::unique_lock<std::mutex> lk(s->mu, std::try_to_lock);
+    if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
+    if (num_channels != s->cfg.num_channels) return fail(SGZ_EINVAL, "num_channels differs from the configuration");
+    if (nsamples == 0) return SGZ_OK;
+    if (nsamples > s->stage.maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_vector_config::max_block");
+    sgz_status st;
+    const float *d_block = s->stage.stage(planar, nsamples, s->stream, &st);
+    if (!d_block) { if (st == SGZ_BUSY) s->busy++; return st; }
+    VecIngest prm{s->d_state, d_block, nsamples, num_channels, s->d_ring, s->size, s->cfg.lanes, s->cfg.envelope_mode,
+                  s->envelopeCoeff, s->stereoCoeff, s->pole1};
+    hipLaunchKernelGGL(vectorIngestKernel, dim3(1), dim3(256), 0, s->stream, prm);
+    SGZ_HIP(hipGetLastError());
+    return s->stage.commit(s->stream);
+}
+
+sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    // coeff = pow(envelopeCoeff, numSamples * openGLDeltaTime()), VectorscopeRendering.cpp:838-842 (envelopeCoeff is a float)
+    const double coeff = std::pow(double(s->envelopeCoeff), double(s->size) * delta_time);
+    hipLaunchKernelGGL(vectorPeakKernel, dim3(1), dim3(1024), 0, s->stream, s->d_state, s->d_ring, s->size, s->cfg.lanes, coeff);
+    SGZ_HIP(hipGetLastError());
+    if (envelope_gain) {
+        SGZ_HIP(hipMemcpyAsync(envelope_gain, reinterpret_cast<const char *>(s->d_state) + offsetof(VecDev, envelopeGain), sizeof(double),
+                               hipMemcpyDeviceToHost, s->stream));
+        SGZ_HIP(hipStreamSynchronize(s->stream));
+    }
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    VecDev h;
+    SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    if (filters) {
+        filters->env[0] = h.env[0]; filters->env[1] = h.env[1];
+        for (int i = 0; i < 2; ++i) { filters->phase[i] = h.phase[i]; for (int j = 0; j < 2; ++j) filters->balance[i][j] = h.bal[i][j]; }
+    }
+    if (envelope_gain) *envelope_gain = h.envelopeGain;
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint32_t *size, uint32_t *cursor)
+{
+    if (!s || channel >= s->cfg.num_channels) return fail(SGZ_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    VecDev h;
+    if (out) SGZ_HIP(hipMemcpyAsync(out, s->d_ring + size_t(channel) * s->size, size_t(s->size) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    if (size) *size = s->size;
+    if (cursor) *cursor = h.cursor;
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count)
+{
+    if (!s || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
+    const uint32_t size = s->size;
+    if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
+    hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(64), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
+    PolarParams prm{};
+    prm.st = s->d_state; prm.ring = s->d_ring; prm.size = size; prm.lanes = s->cfg.lanes; prm.fade = s->cfg.fade_history ? 1u : 0u;
+    prm.ramp = s->d_ramp; prm.tail = s->d_tail;
+    prm.xyz = reinterpret_cast<float3 *>(s->d_xyz); prm.rgb = rgb ? reinterpret_cast<float3 *>(s->d_rgb) : nullptr;
+    for (int k = 0; k < 3; ++k) prm.colour[k] = s->cfg.colours[pair][k];
+    prm.pair = pair;
+    hipLaunchKernelGGL(vectorPolarViewKernel, dim3((size + 255) / 256), dim3(256), 0, s->stream, prm);
+    SGZ_HIP(hipGetLastError());
+    float *hx = static_cast<float *>(s->h_out);
+    SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    if (rgb) SGZ_HIP(hipMemcpyAsync(hx + size_t(size) * 3, s->d_rgb, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    std::memcpy(xyz, hx, size_t(size) * 3 * sizeof(float));
+    if (rgb) std::memcpy(rgb, hx + size_t(size) * 3, size_t(size) * 3 * sizeof(float));
+    *count = size;
+    return SGZ_OK;
+}
+
+}  // extern "C"

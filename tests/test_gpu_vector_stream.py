@@ -1,0 +1,122 @@
+"""The Vectorscope real-time handle (sgz_vector_*, csrc/vector_stream.hip) against the oracle: history ring, the audio thread's
+one-pole filters (Processor::audioProcessing), runPeakFilter, and drawPolarPlot's vertex / colour stream over the two sections of
+the ring for every channel pair.
+
+Bars: ring contents, cursors, the envelope / balance recurrences (plain fp32 multiply-adds) and the fade ramp: bit-exact.  The
+phase recurrence and the polar coordinates go through atan / sincos (libm in the oracle, ocml on the device; cpl's SIMD
+polynomials in the reference): <= 1e-5 / <= 2e-6."""
+import numpy as np
+import pytest
+
+from signalizer_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+SR = 96000.0
+
+
+def _push(dev, blk):
+    while True:
+        st = dev.push(blk)
+        if st == api.SGZ_OK:
+            return
+        assert st == api.SGZ_BUSY
+
+
+class RefVector:
+    """the oracle side: a CLIFOStream-like ring per channel + sgzo_vector_audio_processing + sgzo_peak_filter"""
+
+    def __init__(self, po, channels, size, env_mode, envelope_window, stereo_window, lanes):
+        self.po, self.size, self.cursor, self.lanes, self.env_mode = po, size, 0, lanes, env_mode
+        self.mem = np.zeros((channels, size), np.float32)
+        self.f = po.VectorFilters()
+        self.gain = 1.0
+        self.ec = float(np.float32(np.exp(-1.0 / (envelope_window * SR))))
+        self.sc = float(np.float32(np.exp(-1.0 / (stereo_window * SR))))
+
+    def audio(self, blk):
+        for i in range(blk.shape[1]):
+            pass
+        n = blk.shape[1]
+        idx = (self.cursor + np.arange(n)) % self.size
+        self.mem[:, idx] = blk                      # later samples overwrite earlier ones where a long block laps the ring
+        self.cursor = int((self.cursor + n) % self.size)
+        g = self.po.vector_audio_processing(self.f, blk[0], blk[1], self.ec, self.sc, 0.25, 1 if self.env_mode == 1 else 0, self.lanes)
+        if self.env_mode == 1 and np.isfinite(g):
+            self.gain = g
+
+
+@pytest.mark.parametrize("channels,size,env_mode,fade", [(2, 9600, 1, 0), (8, 9600, 1, 1), (2, 1000, 0, 1), (4, 777, 2, 0), (2, 13, 1, 1)])
+def test_vector_stream_against_the_oracle(gpu, oracle, channels, size, env_mode, fade):
+    po = oracle
+    colours = [(1.0, 0.5, 0.25), (0.2, 0.9, 0.4), (0.3, 0.3, 1.0), (0.9, 0.9, 0.1)]
+    dev = api.Vector(sample_rate=SR, num_channels=channels, window_size=size, envelope_mode=env_mode, lanes=8, fade_history=fade,
+                     max_block=4096, envelope_window=0.3, stereo_window=0.05, colours=colours)
+    ref = RefVector(po, channels, size, env_mode, 0.3, 0.05, 8)
+    x = synth.gen(4, SR, 60000, channels)
+    x[:, 5000:5200] = 0                                      # both channels silent: the angle is defined as 0 / pi/4 there
+    rng = np.random.default_rng(9)
+    pos = 0
+    while pos < x.shape[1]:
+        n = int(rng.integers(1, 3000))
+        blk = x[:, pos:pos + n]
+        _push(dev, blk); ref.audio(blk)
+        pos += blk.shape[1]
+    for c in range(channels):
+        mem, cur = dev.history(c)
+        assert cur == ref.cursor
+        assert np.array_equal(mem.view(np.uint32), ref.mem[c].view(np.uint32))
+    f, gain = dev.filters()
+    if env_mode == 1:
+        assert np.array_equal(np.array(f.env[:], np.float32).view(np.uint32), np.array(ref.f.env[:], np.float32).view(np.uint32))
+        # the oracle hands the gain back as a float (the old stage entry point's type); the handle keeps Processor::envelopeGain's double
+        assert np.float32(gain) == np.float32(ref.gain)
+    gb = np.array([list(r) for r in f.balance], np.float32)
+    rb = np.array([list(r) for r in ref.f.balance], np.float32)
+    assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32))
+    assert np.abs(np.array(f.phase[:]) - np.array(ref.f.phase[:])).max() <= 1e-5
+    # polar vertices of every pair
+    for pair in range(channels // 2):
+        xyz, rgb = dev.vertices(pair)
+        want, wrgb = po.vector_polar_view(ref.mem[2 * pair], ref.mem[2 * pair + 1], ref.cursor, 8, bool(fade), colours[pair])
+        assert np.abs(xyz[:, :2] - want[:, :2]).max() <= 2e-6
+        assert np.array_equal(xyz[:, 2].view(np.uint32), want[:, 2].view(np.uint32))          # the fade ramp: bit-exact
+        assert np.array_equal(rgb.view(np.uint32), wrgb.view(np.uint32))
+    # runPeakFilter (PeakDecay): memory-order peak of channels 0 / 1, SIMD tail dropped
+    if env_mode == 2:
+        env = np.zeros(2, np.float64)
+        for frame in range(4):
+            dt = 1 / 60
+            coeff = float(np.power(np.float64(np.float32(np.exp(-1.0 / (0.3 * SR)))), size * dt))
+            want_gain = po.peak_filter(ref.mem[:2], coeff, env, 8)
+            got_gain = dev.peak_filter(dt)
+            assert got_gain == want_gain
+            more = synth.gen(40 + frame, SR, 500, channels) * np.float32(0.3)
+            _push(dev, more); ref.audio(more)
+
+
+def test_cfg4_shape(gpu, oracle):
+    """BASELINE configs[3]: 8 channels 96 kHz, 100 ms window = 9600 samples per pair, blocks of 480"""
+    po = oracle
+    dev = api.Vector(sample_rate=SR, num_channels=8, window_size=9600, envelope_mode=1, lanes=8, fade_history=1, max_block=512,
+                     envelope_window=0.3, stereo_window=0.05)
+    ref = RefVector(po, 8, 9600, 1, 0.3, 0.05, 8)
+    x = synth.gen(4, SR, 48000, 8)
+    for pos in range(0, x.shape[1], 480):
+        _push(dev, x[:, pos:pos + 480]); ref.audio(x[:, pos:pos + 480])
+    for pair in range(4):
+        xyz, rgb = dev.vertices(pair)
+        want, wrgb = po.vector_polar_view(ref.mem[2 * pair], ref.mem[2 * pair + 1], ref.cursor, 8, True)
+        assert np.abs(xyz[:, :2] - want[:, :2]).max() <= 2e-6 and np.array_equal(xyz[:, 2], want[:, 2]) and np.array_equal(rgb, wrgb)
+
+
+def test_vector_push_rejects_bad_input(gpu):
+    with pytest.raises(api.SgzError):
+        api.Vector(sample_rate=SR, num_channels=3, window_size=100, envelope_mode=0, lanes=8, fade_history=0, max_block=0,
+                   envelope_window=0.3, stereo_window=0.05)
+    dev = api.Vector(sample_rate=SR, num_channels=2, window_size=100, envelope_mode=0, lanes=8, fade_history=0, max_block=64,
+                     envelope_window=0.3, stereo_window=0.05)
+    with pytest.raises(api.SgzError):
+        dev.push(np.zeros((2, 65), np.float32))
+    with pytest.raises(api.SgzError):
+        dev.push(np.zeros((4, 8), np.float32))
