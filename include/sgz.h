@@ -188,8 +188,12 @@ sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64
 /* ------------------------------------------------------------------------------------------------
  * Real-time per-block path: replaces Spectrum::ProcessorShell::onStreamAudio (SpectrumDSP.cpp:210-216)
  * -> AudioDispatcher::dispatch (:63-108) and the consumer side Spectrum::renderColourSpectrum's
- * frameQueue.popElement (SpectrumRendering.cpp:696-721).  One producer thread (push) and one consumer
- * thread (pop) may run concurrently.  push never blocks on the GPU.
+ * frameQueue.popElement (SpectrumRendering.cpp:696-721) -- plus the two steps before the path: the additive
+ * channel routing of MixGraphListener::deliver (Source/Common/MixGraphListener.cpp:247-334, sgz_spectrum_set_mix) and the audio
+ * history ring, which lives in HBM (mirrored: the transform reads its window in place).  One producer thread (push) and one
+ * consumer thread (pop_column, line_results, configure, set_mix, clear_state) may run concurrently.  push never waits for the GPU
+ * and allocates nothing: when the GPU is several blocks behind, or a configure is in progress, it returns SGZ_BUSY and the block
+ * is not taken.  At most 131072 samples per push.
  */
 typedef struct sgz_spectrum sgz_spectrum;
 sgz_status sgz_spectrum_create(const sgz_spectrum_config *cfg, sgz_spectrum **out);
@@ -202,6 +206,15 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint3
 /* lineGraphs[graph].getResults(P) for pair `pair`: float2 [P] (TransformPair.h:72-76) */
 sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t graph, float *out /*2*P*/);
 sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                                   /* clearAudioState, TransformPair.h:177-184 */
+/* MixGraphListener::deliver's routing: destination channel d (of the 2*num_pairs the transform sees) = the sum of the source channels
+ * c with matrix[d * num_sources + c] != 0, added in ascending c onto a cleared row (copyFromHead<true> into matrix.clear()'ed
+ * rows).  push then takes num_sources channels.  Default: identity over 2*num_pairs sources. */
+sgz_status sgz_spectrum_set_mix(sgz_spectrum *s, uint32_t num_sources, const uint8_t *matrix /*[2*num_pairs][num_sources]*/);
+/* columns dropped because the queue was full (SpectrumDSP.cpp:185-186) and pushes refused with SGZ_BUSY, since create */
+sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes);
+/* parity hook: the W newest samples of destination channel `channel`, exactly the range of the device ring a frame firing now
+ * would transform (call it from the producer's thread, or with the producer idle) */
+sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out /*W*/);
 
 /* ------------------------------------------------------------------------------------------------
  * Oscilloscope: Lanczos-10 per-point resampler (drawWavePlot, OscilloscopeRendering.cpp:790-891),

@@ -103,7 +103,8 @@ EXPORTS = [
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped",
     "sgz_stage_map_from_bins", "sgz_stage_decay_colour", "sgz_stage_logf", "sgz_decay_fold_carry",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
-    "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state",
+    "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
+    "sgz_spectrum_stats", "sgz_spectrum_history",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
@@ -168,6 +169,9 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_pop_column.argtypes = [vp, vp, C.POINTER(u32)]
     L.sgz_spectrum_line_results.argtypes = [vp, u32, u32, vp]
     L.sgz_spectrum_clear_state.argtypes = [vp]
+    L.sgz_spectrum_set_mix.argtypes = [vp, u32, vp]
+    L.sgz_spectrum_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sgz_spectrum_history.argtypes = [vp, u32, vp]
     L.sgz_scope_create.argtypes = [C.POINTER(ScopeConfig), C.POINTER(vp)]
     L.sgz_scope_destroy.argtypes = [vp]
     L.sgz_scope_destroy.restype = None

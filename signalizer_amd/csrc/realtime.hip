@@ -1,75 +1,120 @@
 // realtime.hip -- the per-block real-time Spectrum path behind sgz_spectrum_push / sgz_spectrum_pop_column.
 //
-// Replaces Spectrum::ProcessorShell::onStreamAudio -> AudioDispatcher::dispatch
-// (Source/Spectrum/SpectrumDSP.cpp:63-108, :210-216), TransformPair::audioEntryPoint's frame cadence
-// (TransformDSP.inl:1165-1211: processedSamplesSinceLastFrame / sampleBufferSize) and the consumer side of
-// the frameQueue (SpectrumRendering.cpp:696-721).  The audio history (cpl::AudioStream's circular
-// buffer in the reference) is mirrored in HBM as a planar linear buffer per channel; frames read their W
-// newest samples straight from it.  Framing is the ideal STFT framing (a frame fires every `hop` samples
-// and covers the W samples that end at the firing point): the reference's within-callback offset quirk
-//  is deliberately not reproduced.
+// Replaces Spectrum::ProcessorShell::onStreamAudio -> AudioDispatcher::dispatch (Source/Spectrum/SpectrumDSP.cpp:63-108,
+// :210-216), TransformPair::audioEntryPoint's frame cadence (TransformDSP.inl:1165-1211: processedSamplesSinceLastFrame /
+// sampleBufferSize), the consumer side of the frameQueue (SpectrumRendering.cpp:696-721) -- and the two steps BEFORE the path
+// (SURVEY.md 8(f) #2): MixGraphListener::deliver's additive routing of source channels into destination ports
+// (Source/Common/MixGraphListener.cpp:247-334) and the cpl::AudioStream history ring prepareTransform gathers its two segments
+// from (TransformDSP.inl:65-88, :234-484).
 //
-// Threading: one producer thread (push) and one consumer thread (pop_column / line_results); push only
-// enqueues work on the handle's stream and returns.
+// Device-resident ring.  Every destination channel owns a MIRRORED ring in HBM: capacity `cap`, every sample stored twice, at
+// p and p + cap.  Any window of <= cap samples is therefore one contiguous range of memory, whatever the write position: K_A's
+// load stage reads a frame's W newest samples IN PLACE with its ordinary linear addressing -- no two-segment gather, no
+// compaction copies, no modular arithmetic in the hot kernel; the price is that the ingest kernel writes each (tiny) block twice.
+// The ingest kernel applies the mix matrix on the way in: destination d = sum over the source channels c routed to it, in
+// ascending c, starting from the cleared matrix (0 + a + b ...: the reference's copyFromHead<true> into matrix.clear()'ed rows).
+//
+// Framing is the ideal STFT framing (a frame fires every `hop` samples and covers the W samples that end at the firing point):
+// the reference's within-callback offset quirk is deliberately not reproduced.  All frames that fire inside one
+// staged piece go through K_A and K_B as ONE launch each (their windows are hop-spaced ranges of the same ring).
+//
+// Threading: one producer thread (push) and one consumer thread (pop_column / line_results / configure / clear_state).
+// push never waits for the GPU: staging slots and column slots are checked with hipEventQuery / atomics, allocations and LDS
+// grants happen in create / configure (a warm-up render of the largest batch), and a push that finds the GPU too far behind
+// returns SGZ_BUSY without having consumed anything.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
-#include <deque>
 #include <mutex>
 #include <new>
 #include <vector>
 
-#include "runtime.hpp"
+#include "rt_common.hpp"
 
 using namespace sgz;
 
 namespace {
-constexpr int kQueueDepth = 10;            // frameQueue(10), SpectrumDSP.cpp:47
-constexpr size_t kStageSamples = 1 << 16;  // pinned staging slot, samples per channel
-constexpr int kStageSlots = 4;
+constexpr int kQueueDepth = 10;              // frameQueue(10), SpectrumDSP.cpp:47
+constexpr uint32_t kPiece = 16384;           // samples per staged piece (a push is cut into pieces of at most this)
+constexpr uint32_t kMaxSources = 64;
+
+// dest[d][i] = sum_{c : mix[d][c]} src[c][i]  (ascending c, from 0), written at ring position (head + i) mod cap and + cap
+__global__ void __launch_bounds__(256)
+ringIngestKernel(const float *src, uint32_t n, uint32_t numSrc, const uint8_t *mix, float *ring, uint32_t cap, uint32_t numDst,
+                 uint32_t head)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
+    if (i >= n || d >= numDst) return;
+    float v = 0.f;
+    for (uint32_t c = 0; c < numSrc; ++c)
+        if (mix[d * numSrc + c]) v = v + src[size_t(c) * n + i];
+    uint32_t p = head + i; if (p >= cap) p -= cap;
+    float *r = ring + size_t(d) * 2 * cap;
+    r[p] = v;
+    r[p + cap] = v;
 }
+}  // namespace
 
 struct sgz_spectrum {
     Plan *plan = nullptr;
-    std::mutex mu;                    // guards queue + (re)configuration
+    std::mutex cfgMu;                 // configure (consumer thread) against push (producer, try_lock only)
     hipStream_t stream = nullptr;
-    // device audio history: [2C][cap], two buffers for compaction
-    float *d_hist[2] = {nullptr, nullptr};
-    int cur = 0;
-    size_t cap = 0, fill = 0;
+    StageRing stage;
+    // mirrored rings [2C][2 cap]
+    float *d_ring = nullptr;
+    uint32_t cap = 0, head = 0;       // producer-owned write position (mod cap)
     uint32_t sinceLast = 0;           // processedSamplesSinceLastFrame
-    float *d_mapped = nullptr, *d_state = nullptr, *d_lines = nullptr;
-    uint8_t *d_cols = nullptr, *h_cols = nullptr;
+    uint32_t maxFrames = 1;
+    uint8_t *d_mix = nullptr;
+    uint32_t numSources = 0;
+    float *d_mapped = nullptr, *d_state = nullptr, *d_lines = nullptr, *d_linesBatch = nullptr;
+    uint8_t *d_colsBatch = nullptr;   // [maxFrames][P][4]
+    uint8_t *h_cols = nullptr;        // pinned [kQueueDepth][P][4]
     hipEvent_t colEvents[kQueueDepth] = {};
-    std::deque<int> pending;          // slots with a column in flight / ready
-    int nextSlot = 0;
-    float *h_stage = nullptr;         // pinned [kStageSlots][2C][kStageSamples]
-    hipEvent_t stageEvents[kStageSlots] = {};
-    int stageSlot = 0;
-    uint64_t dropped = 0;
+    // SPSC column queue: the producer fills slot tail % depth and bumps tail, the consumer reads slot head % depth and bumps head
+    std::atomic<uint64_t> qHead{0}, qTail{0};
+    std::atomic<uint64_t> dropped{0}, busy{0};
 };
 
 static void freeHandle(sgz_spectrum *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (float *p : {s->d_hist[0], s->d_hist[1], s->d_mapped, s->d_state, s->d_lines}) if (p) (void)hipFree(p);
-    if (s->d_cols) (void)hipFree(s->d_cols);
+    s->stage.release();
+    for (float *p : {s->d_ring, s->d_mapped, s->d_state, s->d_lines, s->d_linesBatch}) if (p) (void)hipFree(p);
+    if (s->d_colsBatch) (void)hipFree(s->d_colsBatch);
+    if (s->d_mix) (void)hipFree(s->d_mix);
     if (s->h_cols) (void)hipHostFree(s->h_cols);
-    if (s->h_stage) (void)hipHostFree(s->h_stage);
     for (auto &e : s->colEvents) if (e) (void)hipEventDestroy(e);
-    for (auto &e : s->stageEvents) if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s->plan;
     delete s;
 }
 
+static sgz_status uploadMix(sgz_spectrum *s, uint32_t numSources, const uint8_t *matrix)
+{
+    const uint32_t numDst = 2 * s->plan->C;
+    std::vector<uint8_t> m(size_t(numDst) * numSources, 0);
+    if (matrix) std::memcpy(m.data(), matrix, m.size());
+    else for (uint32_t d = 0; d < numDst && d < numSources; ++d) m[size_t(d) * numSources + d] = 1;     // identity routing
+    if (s->d_mix) { (void)hipFree(s->d_mix); s->d_mix = nullptr; }
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mix), m.size()));
+    SGZ_HIP(hipMemcpy(s->d_mix, m.data(), m.size(), hipMemcpyHostToDevice));
+    s->numSources = numSources;
+    return s->stage.init(numSources, kPiece);
+}
+
+// builds everything for a configuration into the handle (the caller holds cfgMu, or the handle is not shared yet)
 static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
 {
     Plan *pl = new (std::nothrow) Plan();
     if (!pl) return fail(SGZ_ENOMEM, "out of memory");
     std::string err;
-    sgz_status st = buildPlan(*cfg, *pl, err);
+    sgz_status st;
+    try { st = buildPlan(*cfg, *pl, err); }
+    catch (const std::bad_alloc &) { st = SGZ_ENOMEM; err = "out of memory building the plan tables"; }
     if (st == SGZ_OK) st = uploadPlan(*pl, err);
     if (st != SGZ_OK) { delete pl; return fail(st, err); }
     if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -78,28 +123,38 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     s->plan = pl;
     Plan &p = *pl;
     const size_t nch = size_t(2) * p.C;
-    for (float **q : {&s->d_hist[0], &s->d_hist[1], &s->d_mapped, &s->d_state, &s->d_lines}) if (*q) { (void)hipFree(*q); *q = nullptr; }
-    if (s->d_cols) { (void)hipFree(s->d_cols); s->d_cols = nullptr; }
+    for (float **q : {&s->d_ring, &s->d_mapped, &s->d_state, &s->d_lines, &s->d_linesBatch}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    if (s->d_colsBatch) { (void)hipFree(s->d_colsBatch); s->d_colsBatch = nullptr; }
     if (s->h_cols) { (void)hipHostFree(s->h_cols); s->h_cols = nullptr; }
-    s->cap = size_t(p.W) + 8 * std::max<size_t>(p.cfg.hop, kStageSamples);
-    for (int b = 0; b < 2; ++b) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_hist[b]), nch * s->cap * sizeof(float)));
-    SGZ_HIP(hipMemsetAsync(s->d_hist[0], 0, nch * s->cap * sizeof(float), s->stream));
-    s->cur = 0;
-    s->fill = p.W;                    // history starts as W samples of silence (a full, zeroed ring)
+    // a piece's frames read windows that end inside the piece: the ring must hold W + one piece
+    s->cap = (p.W + kPiece + 63u) & ~63u;
+    s->maxFrames = kPiece / p.cfg.hop + 1;
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ring), nch * 2 * s->cap * sizeof(float)));
+    SGZ_HIP(hipMemsetAsync(s->d_ring, 0, nch * 2 * s->cap * sizeof(float), s->stream));    // history starts as silence
+    s->head = 0;
     s->sinceLast = 0;
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
-    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mapped), size_t(p.C) * p.sides * p.P * sizeof(float)));
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mapped), size_t(s->maxFrames) * p.C * p.sides * p.P * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), stateN * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_lines), stateN * sizeof(float)));
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_linesBatch), size_t(s->maxFrames) * stateN * sizeof(float)));
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsBatch), size_t(s->maxFrames) * p.P * 4));
+    SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_cols), size_t(kQueueDepth) * p.P * 4, hipHostMallocDefault));
+    for (auto &e : s->colEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->qHead.store(0); s->qTail.store(0);
+    if ((st = uploadMix(s, uint32_t(nch), nullptr)) != SGZ_OK) return st;
+    // warm-up: the largest batch a push can produce, on the silent ring -- every lazy allocation and LDS grant of the kernels
+    // happens here, not on the audio thread.  The state it leaves is cleared again.
+    st = runStft(p, s->d_ring, size_t(2) * s->cap, long(s->maxFrames), s->d_mapped, nullptr, nullptr, s->stream);
+    if (st == SGZ_OK) st = runDecayColour(p, s->d_mapped, long(s->maxFrames), s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
+    if (st == SGZ_OK && s->maxFrames > 1) {
+        st = runStft(p, s->d_ring, size_t(2) * s->cap, 1, s->d_mapped, nullptr, nullptr, s->stream);
+        if (st == SGZ_OK) st = runDecayColour(p, s->d_mapped, 1, s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
+    }
+    if (st != SGZ_OK) return st;
     SGZ_HIP(hipMemsetAsync(s->d_state, 0, stateN * sizeof(float), s->stream));
     SGZ_HIP(hipMemsetAsync(s->d_lines, 0, stateN * sizeof(float), s->stream));
-    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_cols), size_t(kQueueDepth) * p.P * 4));
-    SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_cols), size_t(kQueueDepth) * p.P * 4, hipHostMallocDefault));
-    if (!s->h_stage) SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_stage), size_t(kStageSlots) * 32 * kStageSamples * sizeof(float), hipHostMallocDefault));
-    for (auto &e : s->colEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : s->stageEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    s->pending.clear();
-    s->nextSlot = 0;
+    SGZ_HIP(hipStreamSynchronize(s->stream));
     return SGZ_OK;
 }
 
@@ -123,14 +178,21 @@ sgz_status sgz_spectrum_configure(sgz_spectrum *s, const sgz_spectrum_config *cf
 {
     if (!s || !cfg) return fail(SGZ_EINVAL, "null argument");
     if (cfg->num_pairs > 16) return fail(SGZ_EINVAL, "real-time handle supports at most 32 channels");
-    std::lock_guard<std::mutex> lk(s->mu);
+    std::lock_guard<std::mutex> lk(s->cfgMu);
     return setup(s, cfg);
+}
+
+sgz_status sgz_spectrum_set_mix(sgz_spectrum *s, uint32_t num_sources, const uint8_t *matrix)
+{
+    if (!s || !matrix || num_sources == 0 || num_sources > kMaxSources) return fail(SGZ_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lk(s->cfgMu);
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    return uploadMix(s, num_sources, matrix);
 }
 
 sgz_status sgz_spectrum_clear_state(sgz_spectrum *s)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
-    std::lock_guard<std::mutex> lk(s->mu);
     Plan &p = *s->plan;
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     SGZ_HIP(hipMemsetAsync(s->d_state, 0, stateN * sizeof(float), s->stream));
@@ -138,67 +200,61 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s)
     return SGZ_OK;
 }
 
-// one frame over the W newest samples of the history
-static sgz_status fireFrame(sgz_spectrum *s)
-{
-    Plan &p = *s->plan;
-    const float *base = s->d_hist[s->cur] + (s->fill - p.W);
-    sgz_status st = runStft(p, base, s->cap, 1, s->d_mapped, nullptr, nullptr, s->stream);
-    if (st != SGZ_OK) return st;
-    int slot = -1;
-    {
-        std::lock_guard<std::mutex> lk(s->mu);
-        if (int(s->pending.size()) < kQueueDepth) { slot = s->nextSlot; s->nextSlot = (s->nextSlot + 1) % kQueueDepth; }
-        else s->dropped++;            // acquireFreeElement failed: frame dropped (SpectrumDSP.cpp:185-186)
-    }
-    uint8_t *d_col = slot >= 0 ? s->d_cols + size_t(slot) * p.P * 4 : nullptr;
-    st = runDecayColour(p, s->d_mapped, 1, d_col, s->d_lines, s->d_state, s->stream);
-    if (st != SGZ_OK) return st;
-    if (slot >= 0) {
-        SGZ_HIP(hipMemcpyAsync(s->h_cols + size_t(slot) * p.P * 4, d_col, size_t(p.P) * 4, hipMemcpyDeviceToHost, s->stream));
-        SGZ_HIP(hipEventRecord(s->colEvents[slot], s->stream));
-        std::lock_guard<std::mutex> lk(s->mu);
-        s->pending.push_back(slot);
-    }
-    return SGZ_OK;
-}
-
 sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
 {
     if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
+    std::unique_lock<std::mutex> lk(s->cfgMu, std::try_to_lock);     // never waits: a reconfiguration in progress refuses the block
+    if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
     Plan &p = *s->plan;
-    if (num_channels != 2 * p.C) return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72)");
-    uint32_t done = 0;
-    while (done < nsamples) {
-        // consume up to the next frame boundary (TransformDSP.inl:1172-1183)
-        const uint32_t remaining = s->sinceLast >= p.cfg.hop ? 0 : p.cfg.hop - s->sinceLast;
-        uint32_t m = std::min<uint32_t>(nsamples - done, remaining ? remaining : 1);
-        m = std::min<uint32_t>(m, uint32_t(kStageSamples));
-        if (s->fill + m > s->cap) {          // compact: keep the W newest samples
-            const int nxt = s->cur ^ 1;
-            SGZ_HIP(hipMemcpy2DAsync(s->d_hist[nxt], s->cap * sizeof(float), s->d_hist[s->cur] + (s->fill - p.W),
-                                     s->cap * sizeof(float), size_t(p.W) * sizeof(float), num_channels,
-                                     hipMemcpyDeviceToDevice, s->stream));
-            s->cur = nxt;
-            s->fill = p.W;
-        }
-        // stage through pinned memory so the copy is truly asynchronous
-        const int slot = s->stageSlot;
-        s->stageSlot = (s->stageSlot + 1) % kStageSlots;
-        (void)hipEventSynchronize(s->stageEvents[slot]);     // slot reuse: normally long complete
-        float *stage = s->h_stage + size_t(slot) * 32 * kStageSamples;
-        for (uint32_t c = 0; c < num_channels; ++c) std::memcpy(stage + size_t(c) * m, planar[c] + done, size_t(m) * sizeof(float));
-        SGZ_HIP(hipMemcpy2DAsync(s->d_hist[s->cur] + s->fill, s->cap * sizeof(float), stage, size_t(m) * sizeof(float),
-                                 size_t(m) * sizeof(float), num_channels, hipMemcpyHostToDevice, s->stream));
-        SGZ_HIP(hipEventRecord(s->stageEvents[slot], s->stream));
-        s->fill += m;
-        s->sinceLast += m;
-        done += m;
-        if (s->sinceLast >= p.cfg.hop) {     // :1185
-            sgz_status st = fireFrame(s);
+    if (num_channels != s->numSources)
+        return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72), or the source count of sgz_spectrum_set_mix");
+    const uint32_t pieces = (nsamples + kPiece - 1) / kPiece;
+    if (pieces > uint32_t(StageRing::kSlots)) return fail(SGZ_EINVAL, "push takes at most 131072 samples per call");
+    // all or nothing: every piece's staging slot must be free now
+    for (uint32_t k = 0; k < pieces; ++k) {
+        const int slot = int((s->stage.seq + k) % StageRing::kSlots);
+        if (s->stage.used[slot] && hipEventQuery(s->stage.ev[slot]) == hipErrorNotReady) { s->busy++; return SGZ_BUSY; }
+    }
+    const uint32_t numDst = 2 * p.C, W = p.W, hop = p.cfg.hop;
+    const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+    const float *ptrs[kMaxSources];
+    for (uint32_t done = 0; done < nsamples;) {
+        const uint32_t m = std::min(nsamples - done, kPiece);
+        for (uint32_t c = 0; c < num_channels; ++c) ptrs[c] = planar[c] + done;
+        sgz_status st;
+        const float *d_block = s->stage.stage(ptrs, m, s->stream, &st);
+        if (!d_block) return st;
+        hipLaunchKernelGGL(ringIngestKernel, dim3((m + 255) / 256, numDst), dim3(256), 0, s->stream, d_block, m, num_channels, s->d_mix,
+                           s->d_ring, s->cap, numDst, s->head);
+        SGZ_HIP(hipGetLastError());
+        if ((st = s->stage.commit(s->stream)) != SGZ_OK) return st;
+        // frames that fire inside this piece (TransformDSP.inl:1172-1185): the first after hop - sinceLast samples, then every hop
+        const uint32_t first = s->sinceLast >= hop ? 0u : hop - s->sinceLast;
+        uint32_t frames = 0;
+        if (first <= m && (first > 0 || s->sinceLast >= hop)) frames = (m - first) / hop + 1;
+        if (frames) {
+            // frame k's window ends `first + k hop` samples into the piece; in the mirrored ring it starts at q + k hop, contiguous
+            const uint32_t end0 = (s->head + first) % s->cap;
+            const uint32_t q = (end0 + s->cap - (W % s->cap)) % s->cap;
+            st = runStft(p, s->d_ring + q, size_t(2) * s->cap, long(frames), s->d_mapped, nullptr, nullptr, s->stream);
             if (st != SGZ_OK) return st;
-            s->sinceLast = 0;
-        }
+            st = runDecayColour(p, s->d_mapped, long(frames), s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
+            if (st != SGZ_OK) return st;
+            SGZ_HIP(hipMemcpyAsync(s->d_lines, s->d_linesBatch + size_t(frames - 1) * stateN, stateN * sizeof(float), hipMemcpyDeviceToDevice,
+                                   s->stream));
+            for (uint32_t k = 0; k < frames; ++k) {
+                const uint64_t tail = s->qTail.load(std::memory_order_relaxed);
+                if (tail - s->qHead.load(std::memory_order_acquire) >= uint64_t(kQueueDepth)) { s->dropped++; continue; }   // SpectrumDSP.cpp:185-186
+                const int slot = int(tail % kQueueDepth);
+                SGZ_HIP(hipMemcpyAsync(s->h_cols + size_t(slot) * p.P * 4, s->d_colsBatch + size_t(k) * p.P * 4, size_t(p.P) * 4,
+                                       hipMemcpyDeviceToHost, s->stream));
+                SGZ_HIP(hipEventRecord(s->colEvents[slot], s->stream));
+                s->qTail.store(tail + 1, std::memory_order_release);
+            }
+            s->sinceLast = (m - first) - (frames - 1) * hop;
+        } else s->sinceLast += m;
+        s->head = (s->head + m) % s->cap;
+        done += m;
     }
     return SGZ_OK;
 }
@@ -206,16 +262,16 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
 sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba, uint32_t *axis_points)
 {
     if (!s || !rgba) return fail(SGZ_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(s->mu);
-    if (s->pending.empty()) return SGZ_EMPTY;
-    const int slot = s->pending.front();
+    const uint64_t head = s->qHead.load(std::memory_order_relaxed);
+    if (head == s->qTail.load(std::memory_order_acquire)) return SGZ_EMPTY;
+    const int slot = int(head % kQueueDepth);
     const hipError_t q = hipEventQuery(s->colEvents[slot]);
     if (q == hipErrorNotReady) return SGZ_EMPTY;
     if (q != hipSuccess) return hipFail(q, "hipEventQuery");
     const Plan &p = *s->plan;
     std::memcpy(rgba, s->h_cols + size_t(slot) * p.P * 4, size_t(p.P) * 4);
     if (axis_points) *axis_points = p.P;
-    s->pending.pop_front();
+    s->qHead.store(head + 1, std::memory_order_release);
     return SGZ_OK;
 }
 
@@ -226,6 +282,26 @@ sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t gr
     if (pair >= p.C || graph >= SGZ_NUM_GRAPHS) return fail(SGZ_EINVAL, "pair/graph out of range");
     const float *src = s->d_lines + (size_t(pair) * SGZ_NUM_GRAPHS + graph) * p.P * 2;
     SGZ_HIP(hipMemcpyAsync(out, src, size_t(p.P) * 2 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (dropped_columns) *dropped_columns = s->dropped.load();
+    if (refused_pushes) *refused_pushes = s->busy.load();
+    return SGZ_OK;
+}
+
+/* parity hook: the W newest samples of destination channel `channel` as K_A would read them (one contiguous range of the mirrored
+ * ring) */
+sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out)
+{
+    if (!s || !out || channel >= 2 * s->plan->C) return fail(SGZ_EINVAL, "bad argument");
+    const uint32_t W = s->plan->W;
+    const uint32_t q = (s->head + s->cap - (W % s->cap)) % s->cap;
+    SGZ_HIP(hipMemcpyAsync(out, s->d_ring + size_t(channel) * 2 * s->cap + q, size_t(W) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
     return SGZ_OK;
 }

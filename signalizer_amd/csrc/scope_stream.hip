@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
 
 struct sgz_scope {
     sgz_scope_config cfg{};
-    std::mutex mu;                    // configure / destroy against the consumer calls; push takes it with try_lock only
+    std::mutex mu;                    // configure (consumer thread) against push (producer: try_lock only, never waits)
     hipStream_t stream = nullptr;
     StageRing stage;
     ScopeDev *d_state = nullptr;
@@ -616,7 +616,6 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain)
 {
     if (!s || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
     // coeff = pow(exp(-lanes / (envelopeWindow * sampleRate)), numSamples * dt), OscilloscopeDSP.inl:745-747
     const double power = double(s->size) * delta_time;
     const double coeff = std::pow(std::exp(-double(lanes) / (s->cfg.envelope_window * s->cfg.sample_rate)), power);
@@ -634,7 +633,6 @@ sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes
 sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
-    std::lock_guard<std::mutex> lk(s->mu);
     ScopeDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -646,7 +644,6 @@ sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes
 sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out, uint32_t *size, uint32_t *cursor)
 {
     if (!s || channel >= s->cfg.num_channels) return fail(SGZ_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
     ScopeDev h;
     if (out) SGZ_HIP(hipMemcpyAsync(out, s->d_front + size_t(channel) * s->size, size_t(s->size) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
@@ -659,7 +656,6 @@ sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out, uint32_t 
 sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8])
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(s->mu);
     ScopeDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -681,7 +677,6 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
 {
     if (!s || !view || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
     if (view->width < 2 || !(view->right > view->left)) return fail(SGZ_EINVAL, "bad view");
-    std::lock_guard<std::mutex> lk(s->mu);
     const uint32_t C = s->cfg.num_channels;
     // SampleColourEvaluator<OscChannels::...>, SampleColourEvaluators.h: Left / Right read one channel, Mid / Side 0.5 (l +- r)
     uint32_t chA, chB, evalMode, colourCh;

@@ -323,7 +323,6 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
-    std::lock_guard<std::mutex> lk(s->mu);
     // coeff = pow(envelopeCoeff, numSamples * openGLDeltaTime()), VectorscopeRendering.cpp:838-842 (envelopeCoeff is a float)
     const double coeff = std::pow(double(s->envelopeCoeff), double(s->size) * delta_time);
     hipLaunchKernelGGL(vectorPeakKernel, dim3(1), dim3(1024), 0, s->stream, s->d_state, s->d_ring, s->size, s->cfg.lanes, coeff);
@@ -339,7 +338,6 @@ sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *enve
 sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
-    std::lock_guard<std::mutex> lk(s->mu);
     VecDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -354,7 +352,6 @@ sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, do
 sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint32_t *size, uint32_t *cursor)
 {
     if (!s || channel >= s->cfg.num_channels) return fail(SGZ_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
     VecDev h;
     if (out) SGZ_HIP(hipMemcpyAsync(out, s->d_ring + size_t(channel) * s->size, size_t(s->size) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
@@ -367,7 +364,6 @@ sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint3
 sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count)
 {
     if (!s || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lk(s->mu);
     if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
     const uint32_t size = s->size;
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
