@@ -16,7 +16,9 @@
 namespace sgz {
 
 thread_local std::string g_lastError;
-uint32_t g_ablate = 0;
+#ifdef SGZ_DEBUG
+uint32_t g_ablate = 0;      // tools/ablate.py
+#endif
 
 sgz_status fail(sgz_status st, const std::string &msg)
 {
@@ -115,7 +117,10 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
     prm.roundSize = uint32_t(numCUs());
-    prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock; prm.ablate = g_ablate;
+    prm.mapped = d_mapped; prm.binsOut = d_binsOut; prm.binsIn = d_binsIn; prm.phaseClock = d_phaseClock;
+#ifdef SGZ_DEBUG
+    prm.ablate = g_ablate;
+#endif
     return prm;
 }
 
@@ -481,9 +486,11 @@ sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream)
     return SGZ_OK;
 }
 
+#ifdef SGZ_DEBUG
+/* debug hooks of a -DSGZ_DEBUG build only (not in sgz.h): phase ablation bits, and per-phase shader clocks of one workgroup of K_A;
+ * d_clocks: DEVICE uint64[16 slots x 16 waves] */
 void sgz_debug_set_ablate(uint32_t bits) { g_ablate = bits; }
 
-/* debug hook (not in sgz.h): per-phase shader clocks of workgroup 0 of K_A; d_clocks: DEVICE uint64[16 slots x 16 waves] */
 sgz_status sgz_debug_phase_clocks(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
                                   float *d_mapped, unsigned long long *d_clocks, void *stream)
 {
@@ -493,6 +500,7 @@ sgz_status sgz_debug_phase_clocks(sgz_plan *plan, const float *d_planar, size_t 
     const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
     return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), d_clocks);
 }
+#endif
 
 sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64_t *frames_per_rank, uint32_t world,
                                 uint32_t rank, float *d_carry, void *stream)

@@ -22,7 +22,9 @@ int numCUs();
 // K_A over `frames` frames (ideal STFT framing from d_planar); any of mapped/binsOut may be null
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                    float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock = nullptr);
+#ifdef SGZ_DEBUG
 extern uint32_t g_ablate;   // debug only (tools/ablate.py)
+#endif
 // K_B: decay recurrence + dB map + colour blend
 sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
                           float *d_state, hipStream_t stream);

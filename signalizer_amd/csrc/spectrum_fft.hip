@@ -83,7 +83,7 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
                     side ? 0 : int(prm.P), mapped + (size_t(task) * prm.sides + side) * prm.P};
     uint2 *win = reinterpret_cast<uint2 *>(lds + ((count + (count >> 5) + 2) & ~1));
     MapPixelsBalanced<5, NT, OneSideIndex> mapper;
-    const bool sgzClkHalf = side == int((prm.ablate >> 15) & 1u);       // debug clocks: which side reports
+    SGZ_CLK_HALF(side == int((prm.ablate >> 15) & 1u));       // debug clocks: which side reports
     SGZ_CLK(0);
     mapper.prefetchTables(v, tid);
     const float *src = bins + size_t(task) * (size_t(N) + 1);

@@ -12,13 +12,23 @@
 
 namespace sgz {
 
-// debug hook (tools/phase_clocks.py): every wave of one workgroup stores s_memtime at the phase boundaries,
-// phaseClock[16 * wave + slot]
+// Debug plumbing (tools/phase_clocks.py, tools/ablate.py) exists only in a -DSGZ_DEBUG build (SGZ_EXTRA_HIPCC_FLAGS=-DSGZ_DEBUG python
+// signalizer_amd/build.py --force): every wave of one workgroup stores the shader clock at the phase boundaries,
+// phaseClock[16 * wave + slot], and prm.ablate switches phases off.  The shipped kernel carries none of it: no branch around a
+// phase, nothing that keeps the scheduler from interleaving one phase's LDS traffic with the next phase's arithmetic.
+#ifdef SGZ_DEBUG
 #define SGZ_CLK(slot)                                                                                   \
     do {                                                                                                \
         if (prm.phaseClock && (tid & 63) == 0 && task == long(prm.ablate >> 16) && sgzClkHalf)          \
             prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter();                     \
     } while (0)
+#define SGZ_ABLATED(bits) ((prm.ablate & (bits)) != 0u)
+#define SGZ_CLK_HALF(expr) const bool sgzClkHalf = (expr)
+#else
+#define SGZ_CLK(slot) do { } while (0)
+#define SGZ_ABLATED(bits) false
+#define SGZ_CLK_HALF(expr) do { } while (0)
+#endif
 #define SGZ_WCLK(i) do { } while (0)
 
 // Pixel mapping of mapToLinearSpace (TransformDSP.inl:565-639, :871-985) on the csf magnitudes held in LDS
@@ -174,7 +184,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
 #pragma clang fp contract(off)
     const int total = v.total;
     const int N = at.size();
-    const bool sgzClkHalf = true;
+    SGZ_CLK_HALF(true);
     float *out = v.out;
     // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
     // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
@@ -361,7 +371,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     constexpr int SLOTS = SPEC + 2 * kSpecBins;       // float index (even) of the arg-max piece winners (nItems uint2)
     constexpr int TILE = R * (R + 1);
     const int tid = threadIdx.x;
-    const bool sgzClkHalf = HALF < 0 || HALF == int((prm.ablate >> 15) & 1u);   // debug clocks: which half reports
+    SGZ_CLK_HALF(HALF < 0 || HALF == int((prm.ablate >> 15) & 1u));   // debug clocks: which half reports
     const long tasks = prm.frames * long(prm.C) * (HALF >= 0 ? 2 : 1);
     const int slot = tid >> (LR + 1), half = (tid >> LR) & 1, l = tid & (R - 1);
     const int q = half ? (HALF == 1 ? R - 1 - slot : (slot == 0 ? R / 2 : R - slot)) : slot;
@@ -395,7 +405,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         task = fr * prm.C + pr;
     }
     MapPixelsBalanced<LR, T> mapper;
-    const bool doMap = HALF < 0 && !ZOUT && balanced && prm.mapped && !(prm.ablate & 16);
+    const bool doMap = HALF < 0 && !ZOUT && balanced && prm.mapped && !SGZ_ABLATED(16u);
     SGZ_CLK(0);
     SGZ_WCLK(0);
     if (prm.binsIn == nullptr) {
@@ -495,9 +505,9 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         __builtin_amdgcn_sched_barrier(0);          // keep the twiddle loads below the 3R sample loads (128-VGPR budget)
         SGZ_CLK(13);
         // ---------------------------------------------------------------------- pass 1
-        if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
         SGZ_CLK(14);
-        if (!(prm.ablate & 32)) {
+        if (!SGZ_ABLATED(32u)) {
             TwFactors<LR, HALF == 1> tw;
             tw.load(HALF == 1 ? prm.tw1odd : prm.tw1, tid, T);
             tw.apply(c);                                               // times W_N^{t q} (odd half: W_2N^{t (2q+1)})
@@ -508,7 +518,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         // 2 x 4.1 and 2 x 2.1 for the dword forms (tools/ubench/lds.hip).  N complex values are 2x the LDS, so the lower and
         // the upper half of the workgroup take turns as writers; everybody reads its R/2 values of the first round into
         // spare registers (the twiddles are dead, the map tables not loaded yet).
-        if (!(prm.ablate & 2)) {
+        if (!SGZ_ABLATED(2u)) {
             v2 *lds2 = reinterpret_cast<v2 *>(lds);
             const int rd = q * (T / 2) + ix;
             v2 lo[R / 2];
@@ -531,18 +541,22 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                 c[j2] = lo[j2];
             }
         }
+        // Exchange 2's tiles alias exchange 1's array, so every wave must have finished READING exchange 1 before any wave writes a
+        // tile.  The barrier sits here, before pass 2, not after it: from here to the |X| barrier a wave depends on nobody, so a wave
+        // that is done with pass 2 goes straight into its (LDS-bound) transposes while the other waves of its SIMD are still in their
+        // (VALU-bound) butterflies -- with the barrier after pass 2 all sixteen waves entered the LDS phase together.
+        __syncthreads();
         SGZ_CLK(2);
         // ---------------------------------------------------------------------- pass 2 (t2 = ix)
-        if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
-        if (!(prm.ablate & 32)) {
+        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(32u)) {
             TwFactors<LR> tw;
             tw.load(prm.tw2, ix, R);
             tw.apply(c);                                               // times W_T^{t2 q2}
         }
         SGZ_CLK(3);
         // ----------------------------------- exchange 2: R x R transposes inside each R-lane group (wave-local tiles)
-        __syncthreads();                                               // every wave has finished reading exchange 1
-        if (!(prm.ablate & 4)) {
+        if (!SGZ_ABLATED(4u)) {
             const int tile = q * TILE;
 #pragma unroll
             for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].x;
@@ -563,7 +577,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         }
         SGZ_CLK(4);
         // ---------------------------------------------------------------------- pass 3 (q2 = ix)
-        if (!(prm.ablate & 1)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
         SGZ_CLK(5);
         SGZ_WCLK(1);
         if (ZOUT) {
@@ -586,7 +600,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         float mag[R];
         const int kc = q + R * ix;
         const int base = kc + (kc >> LR);                              // padded LDS address of k = kc
-        if (split && !(prm.ablate & 8)) {
+        if (split && !SGZ_ABLATED(8u)) {
             if (HALF != 1 && tid == 0) {                               // column 0 mirrors onto itself: redone below
 #pragma unroll
                 for (int m3 = 0; m3 < R; ++m3) {
@@ -645,6 +659,8 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         // csf[N/2-1] *= 0.5 (quirk Q3, :864); of a 2N-point frame that bin is the odd half's j = N/2 - 1
         if (HALF != 0 && split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;
         __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
+                                                                       // (measured: moving this barrier up behind the tile reads, as was
+                                                                       // done for exchange 1, costs 7 % on a tail-free launch)
 #pragma unroll
         for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = mag[brev(m3, LR)];
         // Column 0 (k = T m3, all held by thread 0) mirrors onto itself and DC / Nyquist are special: redone from thread 0's
@@ -706,11 +722,11 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     SGZ_CLK(8);
     SGZ_WCLK(2);
     // -------------------------------------------------------------------------- pixel mapping
-    if (prm.mapped && !(prm.ablate & 16)) {
+    if (prm.mapped && !SGZ_ABLATED(16u)) {
         if (balanced) mapper.run(prm, wholeView(prm, task), WholeFrameIndex<LR>{}, lds, win, tid, task);
         else mapPixelsSerial<LR, T>(prm, lds, tid, task);
     }
-    if (MIX != 0 && prm.nDcPixels != 0 && prm.mapped && prm.binsIn == nullptr && !(prm.ablate & 16)) {
+    if (MIX != 0 && prm.nDcPixels != 0 && prm.mapped && prm.binsIn == nullptr && !SGZ_ABLATED(16u)) {
         __syncthreads();                                               // the pixels' first values are written by other threads
         float *out = prm.mapped + size_t(task) * (prm.sides * prm.P);
         for (uint32_t i = tid; i < prm.nDcPixels; i += T) {

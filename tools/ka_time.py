@@ -1,0 +1,42 @@
+"""K_A timing loop for kernel work: average launch duration (HIP events on the launch stream) of sgz_stage_mapped at
+cfg2 (348 frames, 2 rounds on 256 CUs) and at a tail-free size (8 pairs x 348 = 2784 tasks), plus the whole step.
+usage: ka_time.py [iters]"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from signalizer_amd import api, config, synth
+
+def timeit(fn, iters):
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
+    for _ in range(10): fn()
+    tot = []
+    for _ in range(iters):
+        hip.hipEventRecord(e0, ctypes.c_void_p(stream)); fn(); hip.hipEventRecord(e1, ctypes.c_void_p(stream))
+        hip.hipEventSynchronize(e1)
+        ms = ctypes.c_float(); hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1); tot.append(ms.value * 1e3)
+    return float(np.mean(tot)), float(np.min(tot))
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    out = {}
+    for name, pairs in (("cfg2_348", 1), ("notail_2784", 8)):
+        cfg = config.cfg2(); cfg["num_pairs"] = pairs
+        S = int(config.CFG2_SECONDS * 48000)
+        x = torch.from_numpy(synth.gen(2, 48000, S, 2 * pairs)).cuda()
+        plan = api.Plan(cfg).upload()
+        F = plan.num_frames(S)
+        mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        ka = lambda: api.check(api.lib().sgz_stage_mapped(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), stream))
+        rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device="cuda")
+        full = lambda: plan.render(x, rgba=rgba)
+        m, mn = timeit(ka, iters)
+        fm, fmn = timeit(full, iters)
+        byts = F * pairs * (2 * 32768 * 4 + 4 * 1024)
+        out[name] = dict(ka_us=round(m, 2), ka_min_us=round(mn, 2), frac=round(byts / (m * 1e-6) / 8e12, 4), step_us=round(fm, 2),
+                         per_task_ns=round(m * 1e3 / (F * pairs), 1))
+    print(out)
+main()
