@@ -5,7 +5,8 @@ A "step" = one pass of the whole Spectrum hot path (window x audio -> FFT -> spl
 pixel mapping -> peak decay -> dB -> colour map -> RGBA8 columns) over BASELINE.json configs[1]:
 stereo 48 kHz, 60 s, N = W = 32768, hop 8192 => 348 frames, P = 1024.  Audio is resident in HBM when the
 timed region starts.  N GPUs: time-chunk sharding -- every rank renders its own 60 s chunk of a
-60*N s stream (weak scaling), halo frames and the decay carry exchanged with RCCL all-gathers.
+60*N s stream (weak scaling); halo samples travel neighbour to neighbour (ncclSend / ncclRecv), the decay carry in one RCCL
+all-gather; `--workload cfg5` splits ONE 64-channel 65536-pt job over the ranks instead (strong scaling).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -83,6 +84,45 @@ def cpu_baseline(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
             "sample": f"first {nfr} of 348 frames of the same 60 s stereo buffer, oracle/libsgz_oracle.so (gcc -O3, strict fp), 1 thread of {os.cpu_count()}"}
 
 
+class CAbiShard:
+    """this rank's share of the job through sgz_spectrogram_render_sharded on an RCCL communicator of its own (the ids travel over
+    torch.distributed, which is only the launcher's rendezvous here)"""
+
+    def __init__(self, plan, chunk, rank, world, dev):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from signalizer_amd import api
+        self.C, self.torch, self.api, self.plan, self.rank, self.world = C, torch, api, plan, rank, world
+        L = api.lib()
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            api.check(L.sgz_comm_unique_id(uid))
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self.comm = C.c_void_p()
+        api.check(L.sgz_comm_create(uid, rank, world, C.byref(self.comm)))
+        nch, S = chunk.shape
+        self.S = S
+        self.buf = torch.zeros((nch, S + plan.cfg.window_size), dtype=torch.float32, device=dev)
+        self.buf[:, :S] = chunk
+        lf = C.c_uint64(0)
+        api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), None, None, None))
+        self.local_frames = int(lf.value)
+        self.rgba = torch.empty((max(self.local_frames, 1), plan.P, 4), dtype=torch.uint8, device=dev)
+
+    def render(self):
+        lf = self.C.c_uint64(0)
+        self.api.check(self.api.lib().sgz_spectrogram_render_sharded(
+            self.plan.h, self.comm, self.rank, self.world, self.buf.data_ptr(), self.buf.stride(0), self.S, self.rgba.data_ptr(),
+            self.C.byref(lf), self.torch.cuda.current_stream().cuda_stream))
+        return self.rgba
+
+    def close(self):
+        self.api.lib().sgz_comm_destroy(self.comm)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,8 +130,13 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
-                    help="cfg2 (default): BASELINE.json's metric; cfg5: the 64-channel 65536-pt job of BASELINE configs[4], for the "
-                         "1/2/4/8-GPU time-chunk scaling curve of SURVEY 8(e) (20 s of 32 pairs per rank)")
+                    help="cfg2 (default): BASELINE.json's metric; with N GPUs every rank renders its own 60 s (weak scaling).  cfg5: the "
+                         "64-channel 65536-pt job of BASELINE configs[4] -- ONE 60 s x 32-pair job split over the N ranks by time "
+                         "chunk (strong scaling, 7.5 s per rank at N = 8): the curve SURVEY 8(e) asks for")
+    ap.add_argument("--shard-impl", choices=("c_abi", "torch"), default="c_abi",
+                    help="N > 1: sgz_spectrogram_render_sharded on its own RCCL communicator (default), or signalizer_amd.sharding over "
+                         "torch.distributed's nccl backend")
+    ap.add_argument("--halo", choices=("p2p", "allgather"), default="p2p", help="torch implementation only: halo exchange form")
     args = ap.parse_args()
 
     import torch
@@ -111,21 +156,26 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.workload == "cfg5":
+    strong = args.workload == "cfg5"
+    if strong:
         cfg = config.cfg5()
         sr = 96000
-        S = 20 * sr                                   # per-rank chunk: 20 s of 64 channels (491 MB)
+        total = 60 * sr
+        S = total // world                            # ONE 60 s job of 64 channels, cut into `world` time chunks
+        assert S * world == total and S >= cfg["window_size"]
     else:
         cfg = config.cfg2()
         sr = 48000
-        S = int(config.CFG2_SECONDS * sr)             # per-rank chunk: 2 880 000 samples
+        S = int(config.CFG2_SECONDS * sr)             # per-rank chunk: 2 880 000 samples (weak scaling: a world-times-longer stream)
     hop, W = cfg["hop"], cfg["window_size"]
     pairs = cfg["num_pairs"]
     bytes_per_frame = 2 * W * 4 + 4 * cfg["axis_points"]      # algorithmic bytes per stereo frame
-    # rank r owns samples [r*S, (r+1)*S) of a world-times-longer stream (weak scaling)
+    # rank r owns samples [r*S, (r+1)*S) of the stream
     x_host = synth.gen(config.CFG2_SEED + 100 * rank, sr, S, 2 * pairs)
     plan = api.Plan(cfg).upload()
-    shard = sharding.TimeChunkRenderer(plan, torch.from_numpy(x_host).to(dev), rank=rank, world=world)
+    x_dev = torch.from_numpy(x_host).to(dev)
+    timer = sharding.TimeChunkRenderer(plan, x_dev, rank=rank, world=world, halo=args.halo)   # kernel / collective probes (and the torch path)
+    shard = timer if (world == 1 or args.shard_impl == "torch") else CAbiShard(plan, x_dev, rank, world, dev)
     frames_per_rank = shard.local_frames
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -151,9 +201,10 @@ def main() -> None:
     dt = time.perf_counter() - t0
     gpu_ms = ev.elapsed_ms(0, 1)
 
-    # dominant kernel (stftMapKernel): its own launches timed with HIP events on the launch stream
-    kern_ms = shard.time_stft_kernel(iters=50)
-    # outside the timed region: latency of one render from an idle GPU, and the two all-gathers on their own
+    # ---- outside the timed region ------------------------------------------------------------------------------------------------
+    # dominant kernel (K_A): its own launches timed with HIP events on the launch stream
+    kern_ms = timer.time_stft_kernel(iters=50)
+    # latency of one render from an idle GPU, and the collectives on their own
     shots = []
     for _ in range(20):
         torch.cuda.synchronize()
@@ -162,7 +213,34 @@ def main() -> None:
         torch.cuda.synchronize()
         shots.append((time.perf_counter() - ts) * 1e3)
     single_shot_ms = float(np.median(shots))
-    coll_ms = shard.time_collectives(iters=20) if world > 1 else 0.0
+    coll_ms = timer.time_collectives(iters=20) if world > 1 else 0.0
+    extra = {}
+    if world == 1 and not strong:
+        # (i) the same kernel on a tail-free launch: 8 stereo pairs of the same buffer = 2784 workgroups on 256 CUs, so that the
+        #     2-rounds-for-1.36-rounds-of-work tail of the 348-frame headline and the kernel's own efficiency can be told apart
+        cfg8 = dict(cfg, num_pairs=8)
+        plan8 = api.Plan(cfg8).upload()
+        x8 = torch.from_numpy(synth.gen(config.CFG2_SEED, sr, S, 16)).to(dev)
+        t8 = sharding.TimeChunkRenderer(plan8, x8, rank=0, world=1)
+        k8 = t8.time_stft_kernel(iters=20)
+        extra["no_tail"] = {"tasks": t8.local_frames * 8, "kernel_ms": k8,
+                            "achieved": t8.local_frames * 8 * bytes_per_frame / (k8 * 1e-3) / 1e9}
+        del t8, x8, plan8
+        # (ii) the step that also produces what the reference updates on every frame -- lineGraphs[k].states and .results
+        #      (TransformDSP.inl:1299-1435): line results of both graphs for every frame + the decay state after the last one
+        F = frames_per_rank
+        lines = torch.empty((F, pairs, 2, plan.P, 2), dtype=torch.float32, device=dev)
+        state = torch.zeros((pairs, 2, plan.P, 2), dtype=torch.float32, device=dev)
+        rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
+        view = timer._view()
+        for _ in range(5):
+            state.zero_(); plan.render(view, rgba=rgba, lines=lines, state=state)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(50):
+            state.zero_(); plan.render(view, rgba=rgba, lines=lines, state=state)
+        torch.cuda.synchronize()
+        extra["ms_per_step_with_state"] = (time.perf_counter() - ts) / 50 * 1e3
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,32 +254,45 @@ def main() -> None:
     if rank == 0:
         value = total_frames * pairs * args.steps / dt
         achieved = frames_per_rank * pairs * bytes_per_frame / (kern_ms * 1e-3) / 1e9
+        traffic = measured_traffic() if not strong else None
         out = {
-            "metric": "32768-pt stereo STFT frames/sec (75% overlap); achieved HBM GB/s vs peak" if args.workload == "cfg2" else
+            "metric": "32768-pt stereo STFT frames/sec (75% overlap); achieved HBM GB/s vs peak" if not strong else
                       "65536-pt stereo-pair STFT frames/sec, 32 pairs (75% overlap), time-chunk sharded; achieved HBM GB/s vs peak",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[1]: stereo 48 kHz spectrogram, 32768-pt FFT, 75% overlap "
                                     "(hop 8192), 60 s buffer => 348 frames/GPU, P=1024, Hann, Separate, Lanczos, log view")
-                       if args.workload == "cfg2" else
-                       ("BASELINE.json configs[4]: 64-channel 96 kHz spectrogram, 65536-pt FFT, 75% overlap (hop 16384), 20 s per GPU "
-                        "=> 114 frames x 32 pairs per GPU, P=1024, Hann, Separate, Lanczos, log view"),
+                       if not strong else
+                       ("BASELINE.json configs[4]: 64-channel 96 kHz spectrogram, 65536-pt FFT, 75% overlap (hop 16384), ONE 60 s job "
+                        f"(348 frames x 32 pairs) split into {world} time chunks, P=1024, Hann, Separate, Lanczos, log view"),
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
+                       "step": "K_A + K_B -> RGBA8 columns; line results and the decay end state are not requested in the timed step "
+                               "(the image does not depend on them; ms_per_step_with_state times the step that writes them)",
+                       "shard_impl": "single device" if world == 1 else args.shard_impl,
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps, "single_shot_ms": single_shot_ms,
                        "collectives_ms_per_step": coll_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(),
-                         "kernel": "stftMapKernel<5, 0, true>" if args.workload == "cfg2" else
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/traffic_latest.json (committed rocprofv3 --pmc pass of this "
+                                                                        "workload, gfx950 correction applied; not collected in this run)",
+                         "kernel": "stftMapKernel<5, 0, true>" if not strong else
                                    "stftHalfKernel<5, 0, true> + mapSideKernel<1024> (all slabs of one K_A pass)",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": frames_per_rank * pairs * bytes_per_frame},
         }
-        if args.workload != "cfg2":
-            out["roofline"]["traffic"] = None          # the committed PMC numbers are cfg2's
-        if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
+        if "no_tail" in extra:
+            nt = extra["no_tail"]
+            out["roofline"]["frac_no_tail"] = nt["achieved"] / HBM_PEAK_GBPS
+            out["roofline"]["no_tail"] = {"tasks": nt["tasks"], "kernel_ms": nt["kernel_ms"], "achieved": nt["achieved"],
+                                          "note": "same kernel, 8 stereo pairs of the cfg2 buffer: no partial second round of workgroups"}
+        if "ms_per_step_with_state" in extra:
+            out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
+        if not args.no_cpu_baseline and world == 1 and not strong:
             out["cpu_baseline"] = cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if shard is not timer:
+            shard.close()
         dist.destroy_process_group()
 
 

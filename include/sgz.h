@@ -171,6 +171,15 @@ sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t f
 sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,
                                   uint8_t *d_rgba, float *d_lines, float *d_state, void *stream);
 
+/* K_B in two steps, for the multi-GPU carry exchange (collective A2).  scan: the chunk scans of `frames` frames from a
+ * ZERO carry-in; writes that zero-carry end state (what a rank publishes) to d_end_state [pairs][graphs][P][2] and keeps the chunk
+ * aggregates inside the plan.  emit: folds the true carry-in d_carry (NULL = zero) into the kept aggregates -- one pass over the
+ * aggregates, no second scan of the magnitudes -- and renders; d_state_out (optional) receives the state after the last frame.
+ * Result == sgz_stage_decay_colour(..., d_state = carry) bit for bit. */
+sgz_status sgz_stage_decay_scan(sgz_plan *plan, const float *d_mapped, size_t frames, float *d_end_state, void *stream);
+sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t frames, const float *d_carry, uint8_t *d_rgba,
+                                float *d_lines, float *d_state_out, void *stream);
+
 /* std::log(float) as the dB map evaluates it (TransformDSP.inl:1345): glibc's logf algorithm, bit-identical to libm over every
  * positive finite float (tests/test_gpu_spectrum.py checks all 2^31 of them).  d_x > 0; DEVICE pointers. */
 sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream);
@@ -184,6 +193,22 @@ sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream);
  * frames_per_rank: HOST int64 [world]; d_carry: DEVICE float [pairs][graphs][P][2] (out). */
 sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64_t *frames_per_rank,
                                 uint32_t world, uint32_t rank, float *d_carry, void *stream);
+
+/* The whole sharded render behind the ABI, on the host's own RCCL communicator (no torch, no Python): halo ncclSend / ncclRecv with
+ * the neighbours (exactly the samples the last frames reach into the next rank's chunk), K_A, zero-carry K_B scan, ncclAllGather of
+ * the end states, exact fold, K_B emit.  Rank r holds samples [r S, (r+1) S) of the stream in d_chunk (2*num_pairs channels, S =
+ * chunk_samples, channel_stride >= S + halo_in: the halo is written behind the chunk); d_rgba receives this rank's columns
+ * [local_frames][P][4].  Bit-identical to a single-device render of the concatenated stream.  nccl_comm: an ncclComm_t (RCCL is
+ * bound with dlopen at first use; sgz_comm_* are conveniences for hosts that do not link RCCL themselves: sgz_comm_unique_id on
+ * one rank, the 128 bytes handed to every rank by the host's own means, sgz_comm_create on all). */
+sgz_status sgz_comm_unique_id(uint8_t out[128]);
+sgz_status sgz_comm_create(const uint8_t id[128], uint32_t rank, uint32_t world, void **comm);
+void       sgz_comm_destroy(void *comm);
+sgz_status sgz_shard_layout(const sgz_plan *plan, uint32_t rank, uint32_t world, size_t chunk_samples, uint64_t *local_frames,
+                            uint64_t *first_frame, uint64_t *halo_in, uint64_t *halo_out);
+sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint32_t rank, uint32_t world, float *d_chunk,
+                                          size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
+                                          void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Real-time per-block path: replaces Spectrum::ProcessorShell::onStreamAudio (SpectrumDSP.cpp:210-216)

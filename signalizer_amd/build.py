@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgz.so")
-SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_generic.hip", "spectrum_post.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "api.hip", "realtime.hip"]
+SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_generic.hip", "spectrum_post.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "api.hip", "realtime.hip"]
 HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

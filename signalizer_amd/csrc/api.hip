@@ -35,7 +35,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -220,6 +220,7 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
     prm.colourTables = p.d_colourTables;
     prm.sc = p.scalars;
     prm.state = d_state; prm.stateIn = d_state; prm.rgba = d_rgba; prm.lines = d_lines;
+    prm.colourOnly = (!d_state && !d_lines && d_rgba) ? 1u : 0u;
     if (d_state && frames > 1) {
         // frame 0's threads read the carry-in while the last frame's threads write the new state: snapshot it
         const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
@@ -251,6 +252,33 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         prm.agg = p.d_agg;
         SGZ_HIP(launchDecayLocalCarry(prm, stream));
     }
+    SGZ_HIP(launchDecayEmit(prm, stream));
+    return SGZ_OK;
+}
+
+// second half of the two-step K_B (sgz_stage_decay_scan / sgz_stage_decay_emit): the aggregates of the preceding zero-carry scan of
+// the same (mapped, frames) are still in p.d_agg; fold the true carry-in into them and emit
+sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, const float *d_carry, uint8_t *d_rgba, float *d_lines,
+                                 float *d_stateOut, hipStream_t stream)
+{
+    if (frames <= 0) return SGZ_OK;
+    DecayParams prm{};
+    prm.mapped = d_mapped;
+    prm.frames = frames;
+    prm.P = p.P; prm.C = p.C; prm.sides = uint32_t(p.sides);
+    prm.chunk = 8;
+    prm.numChunks = uint32_t((frames + prm.chunk - 1) / prm.chunk);
+    prm.slope = p.d_slope;
+    prm.colourTables = p.d_colourTables;
+    prm.sc = p.scalars;
+    prm.state = d_stateOut; prm.stateIn = d_carry; prm.rgba = d_rgba; prm.lines = d_lines;
+    if (prm.numChunks > 1) {
+        const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
+        if (!p.d_agg || p.aggCap < need) return fail(SGZ_EINVAL, "sgz_stage_decay_emit without a preceding sgz_stage_decay_scan of the same frames");
+        prm.agg = p.d_agg;
+        if (d_carry) SGZ_HIP(launchDecayApplyCarry(prm, d_carry, stream));
+    }
+    if (!d_rgba && !d_lines && !d_stateOut) return SGZ_OK;
     SGZ_HIP(launchDecayEmit(prm, stream));
     return SGZ_OK;
 }
@@ -477,6 +505,29 @@ sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     return runDecayColour(plan->impl, d_mapped, long(frames), d_rgba, d_lines, d_state, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_decay_scan(sgz_plan *plan, const float *d_mapped, size_t frames, float *d_end_state, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    if (!d_mapped || !d_end_state) return fail(SGZ_EINVAL, "null buffer");
+    if (p.cfg.channel_mode == SGZ_CH_PHASE)
+        return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    SGZ_HIP(hipMemsetAsync(d_end_state, 0, size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float), s));
+    return runDecayColour(p, d_mapped, long(frames), nullptr, nullptr, d_end_state, s);     // scans + state-only emit of the last chunk
+}
+
+sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t frames, const float *d_carry, uint8_t *d_rgba,
+                                float *d_lines, float *d_state_out, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    if (!d_mapped) return fail(SGZ_EINVAL, "null buffer");
+    if (plan->impl.cfg.channel_mode == SGZ_CH_PHASE) return fail(SGZ_EUNSUPPORTED, "Phase mode has no carry fold");
+    return runDecayEmitWithCarry(plan->impl, d_mapped, long(frames), d_carry, d_rgba, d_lines, d_state_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream)

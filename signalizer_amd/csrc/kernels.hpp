@@ -80,11 +80,14 @@ struct DecayParams {
     float *state;             // [C][G][P][2] (float2: left/right) out: state after the last frame, may be null
     uint8_t *rgba;            // [frames][P][4] or null
     float *lines;             // [frames][C][G][P][2] or null
+    uint32_t colourOnly;      // neither lines nor state are wanted: only (side 0, LineMain) of every pair feeds the colour column, the scans skip the rest
 };
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream);   // local + carry, one launch when the chunks fit a workgroup
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream);
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
+// agg[d] <- max(agg[d], decay(carry)) for aggregates that were scanned from a zero carry-in (multi-GPU carry-apply pass)
+hipError_t launchDecayApplyCarry(const DecayParams &prm, const float *carry, hipStream_t stream);
 // SpectrumChannels::Phase: sequential-in-time K_B (the cancellation smoother is a linear recurrence: no exact chunk fold);
 // work: [frames][C][P] floats for the main graph's dB values
 hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t stream);

@@ -88,6 +88,7 @@ struct Plan {
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
+    float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;
 
     ~Plan();

@@ -125,11 +125,15 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
     const size_t perChunk = size_t(prm.C) * prm.sides * prm.P;
     const int en = threadIdx.x & (kFusedEntries - 1);
     const uint32_t chunk = threadIdx.x / kFusedEntries;
-    const size_t rem = size_t(blockIdx.x) * kFusedEntries + en;   // (pair, side, pixel) linear
-    const bool live = rem < perChunk && chunk < prm.numChunks;
-    const uint32_t pixel = uint32_t(rem % prm.P);
-    const uint32_t ps = uint32_t(rem / prm.P);                  // pair * sides + side
+    // colourOnly: the launch covers (pair, pixel) only -- side 0 of every pair -- and only LineMain is scanned
+    const size_t lin = size_t(blockIdx.x) * kFusedEntries + en;
+    const size_t nEntries = prm.colourOnly ? size_t(prm.C) * prm.P : perChunk;
+    const uint32_t pixel = uint32_t(lin % prm.P);
+    const uint32_t ps = prm.colourOnly ? uint32_t(lin / prm.P) * prm.sides : uint32_t(lin / prm.P);   // pair * sides + side
+    const size_t rem = size_t(ps) * prm.P + pixel;             // (pair, side, pixel) linear
+    const bool live = lin < nEntries && chunk < prm.numChunks;
     const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
+    const int graphs = prm.colourOnly ? 1 : G;
     if (live) {
         float a[G];
 #pragma unroll
@@ -145,8 +149,10 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
             if (t < len) {
 #pragma unroll
                 for (int k = 0; k < G; ++k) {
-                    a[k] = a[k] * prm.sc.pole[k];               // states[i] *= pole, TransformDSP.inl:1336,:1370
-                    if (mag[t] > a[k]) a[k] = mag[t];           // :1338-1341
+                    if (k < graphs) {
+                        a[k] = a[k] * prm.sc.pole[k];           // states[i] *= pole, TransformDSP.inl:1336,:1370
+                        if (mag[t] > a[k]) a[k] = mag[t];       // :1338-1341
+                    }
                 }
             }
         }
@@ -154,7 +160,7 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
         for (int k = 0; k < G; ++k) aggS[chunk][k][en] = a[k];
     }
     __syncthreads();
-    if (threadIdx.x < G * kFusedEntries) {
+    if (threadIdx.x < graphs * kFusedEntries) {
         const int k = threadIdx.x / kFusedEntries;
         const float pole = prm.sc.pole[k];
         float c = aggS[0][k][en];
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
     if (live) {
 #pragma unroll
         for (int k = 0; k < G; ++k)
-            prm.agg[((size_t(chunk) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] = aggS[chunk][k][en];
+            if (k < graphs) prm.agg[((size_t(chunk) * prm.C * prm.sides + ps) * G + k) * prm.P + pixel] = aggS[chunk][k][en];
     }
 }
 
@@ -353,13 +359,43 @@ hipError_t launchLogf(const float *x, float *y, size_t n, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Carry-apply pass of the multi-GPU exchange: the chunk aggregates were scanned from a ZERO carry-in; the true carry-in c0 of this
+// rank arrives later.  By the monotonicity identity the state at the end of chunk d is max(agg[d], decay^{frames so far}(c0)), the
+// decay done with the reference's sequential fp32 multiplies -- one thread per (pair, side, graph, pixel), no second scan of the
+// mapped magnitudes.  carry: [C][G][P][2].
+__global__ void __launch_bounds__(256) decayApplyCarryKernel(const DecayParams prm, const float *carry)
+{
+    const size_t per = size_t(prm.C) * prm.sides * G * prm.P;
+    const size_t e = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= per) return;
+    const uint32_t pixel = uint32_t(e % prm.P);
+    const uint32_t k = uint32_t((e / prm.P) % G);
+    const uint32_t ps = uint32_t(e / (size_t(prm.P) * G));
+    const uint32_t pair = ps / prm.sides, side = ps - pair * prm.sides;
+    const float pole = prm.sc.pole[k];
+    float c = carry[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side];
+    for (uint32_t d = 0; d < prm.numChunks; ++d) {
+        const long f0 = long(d) * kMaxChunk;
+        const int len = int(min(long(kMaxChunk), prm.frames - f0));
+        for (int i = 0; i < len; ++i) c = c * pole;
+        float *a = prm.agg + size_t(d) * per + e;
+        if (c > *a) *a = c;
+    }
+}
+hipError_t launchDecayApplyCarry(const DecayParams &prm, const float *carry, hipStream_t stream)
+{
+    const size_t per = size_t(prm.C) * prm.sides * G * prm.P;
+    hipLaunchKernelGGL(decayApplyCarryKernel, dim3(unsigned((per + 255) / 256)), dim3(256), 0, stream, prm, carry);
+    return hipGetLastError();
+}
+
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream)
 {
-    if (prm.numChunks > uint32_t(kFusedChunks)) {
+    if (prm.numChunks > uint32_t(kFusedChunks)) {                       // (long renders scan everything: colourOnly is the fused kernel's)
         hipError_t e = launchDecayLocal(prm, stream);
         return e != hipSuccess ? e : launchDecayCarry(prm, stream);
     }
-    const size_t entries = size_t(prm.C) * prm.sides * prm.P;
+    const size_t entries = prm.colourOnly ? size_t(prm.C) * prm.P : size_t(prm.C) * prm.sides * prm.P;
     auto launch = [&](auto ch) {
         constexpr int CH = decltype(ch)::value;
         hipLaunchKernelGGL(decayLocalCarryKernel<CH>, dim3(unsigned((entries + 1024 / CH - 1) / (1024 / CH))), dim3(1024), 0, stream, prm);

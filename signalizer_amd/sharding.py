@@ -2,12 +2,16 @@
 
 The global stream is the concatenation of every rank's chunk (rank r holds samples [r*S, (r+1)*S)).
 A frame belongs to the rank that owns its first sample.  Per render:
-  A1  all-gather of every rank's leading W samples (the "overlap frames" halo); rank r appends rank r+1's
+  A1  halo: rank r needs the samples its last frames reach into rank r+1's chunk (W - hop when hop divides S; ShardPlan.halo) --
+      a neighbour send / recv of exactly those samples (one xGMI link each way), or (halo="allgather", the north star's wording) an
+      all-gather of every rank's leading max-halo samples
   K_A window x FFT x map over the local frames (no collective)
-  A2  all-gather of every rank's zero-carry decay end state; exact carry fold (sgz_decay_fold_carry)
-  K_B decay + dB + colour with the folded carry as state
+  K_B scan: chunk scans from a zero carry-in -> this rank's zero-carry end state (sgz_stage_decay_scan)
+  A2  all-gather of the end states; exact carry fold (sgz_decay_fold_carry)
+  K_B emit: the carry folded into the kept aggregates, dB, colour (sgz_stage_decay_emit) -- the magnitudes are scanned once
 With world == 1 this degenerates to a single sgz_spectrogram_render_device call.
-One process per GPU; torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" for the CPU plan tests).
+One process per GPU; torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" for the CPU plan tests).  A C++ host uses
+sgz_spectrogram_render_sharded (include/sgz.h) on its own ncclComm_t instead: the same protocol without torch.
 """
 from __future__ import annotations
 
@@ -75,40 +79,51 @@ class GpuBackend:
         from . import api
         api.check(api.lib().sgz_stage_mapped(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1], mapped.data_ptr(), self._stream()))
 
-    def stage_decay_colour(self, mapped, frames, rgba, state):
+    def decay_scan(self, mapped, frames, end_state):
         from . import api
-        api.check(api.lib().sgz_stage_decay_colour(self.plan.h, mapped.data_ptr(), frames,
-                                                   rgba.data_ptr() if rgba is not None else None, None,
-                                                   state.data_ptr(), self._stream()))
+        api.check(api.lib().sgz_stage_decay_scan(self.plan.h, mapped.data_ptr(), frames, end_state.data_ptr(), self._stream()))
+
+    def decay_emit(self, mapped, frames, carry, rgba):
+        from . import api
+        api.check(api.lib().sgz_stage_decay_emit(self.plan.h, mapped.data_ptr(), frames, carry.data_ptr() if carry is not None else None,
+                                                 rgba.data_ptr(), None, None, self._stream()))
 
     def fold_carry(self, aggs, frames_per_rank, rank, carry):
         self.plan.fold_carry(aggs, frames_per_rank, rank, carry)
 
 
 class TimeChunkRenderer:
-    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1, backend=None):
+    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1, backend=None, halo: str = "p2p", always_collective: bool = False):
         import torch
         self.torch = torch
         self.plan = plan
         self.backend = backend if backend is not None else GpuBackend(plan)
         self.rank, self.world = rank, world
+        self.halo_mode = halo
+        self.collective = world > 1 or always_collective
         self.nch, S = chunk_audio.shape
         W, hop = plan.cfg.window_size, plan.cfg.hop
         assert S >= W, "chunk must hold at least one window"
         self.sp = ShardPlan(rank, world, S, W, hop)
         dev = chunk_audio.device
-        # local buffer = own chunk followed by the next rank's leading W samples
-        self.buf = torch.zeros((self.nch, S + W), dtype=torch.float32, device=dev)
+        halos = [ShardPlan(r, world, S, W, hop).halo for r in range(world)]
+        self.halo_in = halos[rank]                                   # samples wanted from rank + 1
+        self.halo_out = halos[rank - 1] if rank > 0 else 0           # samples rank - 1 wants from this rank's head
+        self.halo_max = max(halos) if halos else 0
+        # local buffer = own chunk followed by the next rank's leading samples
+        self.buf = torch.zeros((self.nch, S + max(self.halo_max, 1)), dtype=torch.float32, device=dev)
         self.buf[:, :S] = chunk_audio
         self.S, self.W = S, W
         self.local_frames = self.sp.local_frames
         P, C = plan.P, plan.C
         self.rgba = torch.empty((max(self.local_frames, 1), P, 4), dtype=torch.uint8, device=dev)
-        self.state = torch.zeros((C, 2, P, 2), dtype=torch.float32, device=dev)
-        if world > 1:
+        if self.collective:
             self.mapped = torch.empty((max(self.local_frames, 1), C, plan.sides, P), dtype=torch.float32, device=dev)
-            self.halo_send = torch.empty((self.nch, W), dtype=torch.float32, device=dev)
-            self.halo_all = torch.empty((world, self.nch, W), dtype=torch.float32, device=dev)
+            self.send_halo = torch.empty((self.nch, max(self.halo_out, 1)), dtype=torch.float32, device=dev)
+            self.recv_halo = torch.empty((self.nch, max(self.halo_in, 1)), dtype=torch.float32, device=dev)
+            self.halo_send_all = torch.empty((self.nch, max(self.halo_max, 1)), dtype=torch.float32, device=dev)
+            self.halo_all = torch.empty((world, self.nch, max(self.halo_max, 1)), dtype=torch.float32, device=dev)
+            self.end_state = torch.zeros((C, 2, P, 2), dtype=torch.float32, device=dev)
             self.agg_all = torch.empty((world, C, 2, P, 2), dtype=torch.float32, device=dev)
             self.carry = torch.zeros((C, 2, P, 2), dtype=torch.float32, device=dev)
             self.frames_per_rank = [self.sp.frames_of(r) for r in range(world)]
@@ -117,45 +132,65 @@ class TimeChunkRenderer:
         off = self.sp.local_offset
         return self.buf[:, off:off + self.sp.local_samples]
 
+    def _exchange_halo(self):
+        import torch.distributed as dist
+        if self.halo_mode == "allgather":
+            if self.halo_max == 0:
+                return
+            self.halo_send_all.copy_(self.buf[:, :self.halo_max])
+            dist.all_gather_into_tensor(self.halo_all.view(-1), self.halo_send_all.view(-1))
+            if self.rank + 1 < self.world and self.halo_in:
+                self.buf[:, self.S:self.S + self.halo_in] = self.halo_all[self.rank + 1][:, :self.halo_in]
+            return
+        ops = []
+        if self.rank > 0 and self.halo_out:
+            self.send_halo.copy_(self.buf[:, :self.halo_out])
+            ops.append(dist.P2POp(dist.isend, self.send_halo, self.rank - 1))
+        if self.rank + 1 < self.world and self.halo_in:
+            ops.append(dist.P2POp(dist.irecv, self.recv_halo, self.rank + 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.rank + 1 < self.world and self.halo_in:
+            self.buf[:, self.S:self.S + self.halo_in] = self.recv_halo
+
     def render(self):
         """one full pass; returns this rank's RGBA8 columns [local_frames, P, 4]"""
-        torch = self.torch
-        if self.world == 1:
+        if not self.collective:
             # single device: start from a zero decay state, nobody needs the end state -> no memset, no snapshot
             self.backend.render(self._view(), self.rgba, None)
             return self.rgba
         import torch.distributed as dist
-        # A1: halo = everybody's leading W samples
-        self.halo_send.copy_(self.buf[:, :self.W])
-        dist.all_gather_into_tensor(self.halo_all.view(-1), self.halo_send.view(-1))
-        if self.rank + 1 < self.world:
-            self.buf[:, self.S:] = self.halo_all[self.rank + 1]
-        x = self._view()
-        # K_A once; K_B as a state-only pass (zero carry -> this chunk's end state), then the full pass with the folded carry
-        self.backend.stage_mapped(x, self.mapped)
-        self.state.zero_()
-        self.backend.stage_decay_colour(self.mapped, self.local_frames, None if self.rank > 0 else self.rgba, self.state)
-        # A2: decay carry
-        dist.all_gather_into_tensor(self.agg_all.view(-1), self.state.view(-1))
+        self._exchange_halo()                                         # A1
+        F = self.local_frames
+        if F:
+            self.backend.stage_mapped(self._view(), self.mapped)      # K_A, once
+            self.backend.decay_scan(self.mapped, F, self.end_state)   # zero-carry scans -> end state; aggregates stay in the plan
+        else:
+            self.end_state.zero_()
+        dist.all_gather_into_tensor(self.agg_all.view(-1), self.end_state.view(-1))      # A2
+        carry = None
         if self.rank > 0:
             self.backend.fold_carry(self.agg_all, self.frames_per_rank, self.rank, self.carry)
-            self.backend.stage_decay_colour(self.mapped, self.local_frames, self.rgba, self.carry)
+            carry = self.carry
+        if F:
+            self.backend.decay_emit(self.mapped, F, carry, self.rgba)
         return self.rgba
 
     def time_collectives(self, iters: int = 20) -> float:
-        """average wall time (ms) of one render's two all-gathers (A1 halo, A2 decay carry) on their own"""
+        """average wall time (ms) of one render's collectives (A1 halo, A2 decay carry) on their own"""
         import time
         import torch.distributed as dist
         torch = self.torch
-        if self.world == 1:
+        if not self.collective:
             return 0.0
         sync = torch.cuda.synchronize if self.buf.is_cuda else (lambda: None)
         for i in range(iters + 3):
             if i == 3:
                 sync(); dist.barrier(); sync()
                 t0 = time.perf_counter()
-            dist.all_gather_into_tensor(self.halo_all.view(-1), self.halo_send.view(-1))
-            dist.all_gather_into_tensor(self.agg_all.view(-1), self.state.view(-1))
+            self._exchange_halo()
+            dist.all_gather_into_tensor(self.agg_all.view(-1), self.end_state.view(-1))
         sync(); dist.barrier(); sync()
         return (time.perf_counter() - t0) / iters * 1e3
 

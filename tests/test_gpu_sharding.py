@@ -62,3 +62,90 @@ def test_sharded_render_equals_single_device(gpu, window, hop, pairs, S, world, 
     out = np.concatenate([got[r] for r in range(world)])
     assert out.shape == ref.shape
     assert np.array_equal(out, ref)
+
+
+def test_two_step_decay_equals_one_step_with_state(gpu):
+    """sgz_stage_decay_scan + sgz_stage_decay_emit(carry) == sgz_stage_decay_colour(state = carry), byte for byte and state for
+    state: the carry-apply pass over the kept aggregates replaces the second scan of the magnitudes (VERDICT r1 #13)"""
+    import torch
+    from signalizer_amd import api
+    cfg = config.spectrum_config(window_size=4096, hop=1024, num_pairs=3, axis_points=333, pole=(0.97, 0.5))
+    plan = api.Plan(cfg).upload()
+    for frames in (1, 5, 8, 37, 600):                                 # one chunk, the fused scan, and the two-kernel scan (> 64 chunks)
+        g = torch.Generator(device="cpu").manual_seed(frames)
+        mapped = (torch.rand((frames, 3, 2, 333), generator=g) ** 4).to(gpu)
+        carry = (torch.rand((3, 2, 333, 2), generator=g) * 0.7).to(gpu)
+        state = carry.clone()
+        want, _ = plan.stage_decay_colour(mapped, state=state)
+        end = torch.empty_like(carry)
+        L, s = api.lib(), torch.cuda.current_stream().cuda_stream
+        api.check(L.sgz_stage_decay_scan(plan.h, mapped.data_ptr(), frames, end.data_ptr(), s))
+        zero_state = torch.zeros_like(carry)
+        plan.stage_decay_colour(mapped, state=zero_state, want_rgba=False)
+        assert torch.equal(end, zero_state)                           # the published end state is the zero-carry one
+        api.check(L.sgz_stage_decay_scan(plan.h, mapped.data_ptr(), frames, end.data_ptr(), s))
+        got = torch.empty((frames, 333, 4), dtype=torch.uint8, device=gpu)
+        out_state = torch.empty_like(carry)
+        api.check(L.sgz_stage_decay_emit(plan.h, mapped.data_ptr(), frames, carry.data_ptr(), got.data_ptr(), None, out_state.data_ptr(), s))
+        assert torch.equal(got, want), frames
+        assert torch.equal(out_state, state), frames
+
+
+def _rccl_worker(q, S, cfg):
+    """world = 1 on the real backends: torch.distributed 'nccl' (= RCCL) through TimeChunkRenderer with the collective path forced,
+    and the C ABI's sgz_spectrogram_render_sharded on an RCCL communicator of its own"""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from signalizer_amd import api
+    from signalizer_amd.sharding import TimeChunkRenderer
+    x = torch.from_numpy(synth.gen(79, 48000, S, 2 * cfg["num_pairs"])).to(dev)
+    plan = api.Plan(cfg).upload()
+    ref = plan.render(x).cpu().numpy()
+    out = {}
+    for halo in ("p2p", "allgather"):
+        r = TimeChunkRenderer(plan, x, rank=0, world=1, halo=halo, always_collective=True)
+        out[halo] = r.render()[:r.local_frames].cpu().numpy().copy()
+        assert r.time_collectives(iters=2) > 0.0
+    # C ABI on its own communicator
+    L = api.lib()
+    uid = (C.c_uint8 * 128)()
+    api.check(L.sgz_comm_unique_id(uid))
+    comm = C.c_void_p()
+    api.check(L.sgz_comm_create(uid, 0, 1, C.byref(comm)))
+    buf = torch.zeros((x.shape[0], S + cfg["window_size"]), dtype=torch.float32, device=dev)
+    buf[:, :S] = x
+    frames = C.c_uint64(0)
+    rgba = torch.empty((plan.num_frames(S), plan.P, 4), dtype=torch.uint8, device=dev)
+    api.check(L.sgz_spectrogram_render_sharded(plan.h, comm, 0, 1, buf.data_ptr(), buf.stride(0), S, rgba.data_ptr(), C.byref(frames),
+                                               torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    out["c_abi"] = rgba.cpu().numpy().copy()
+    out["frames"] = int(frames.value)
+    L.sgz_comm_destroy(comm)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((ref, out))
+
+
+@pytest.mark.parametrize("window,hop,pairs,S", [(32768, 8192, 1, 32768 * 4 + 100), (65536, 16384, 4, 65536 * 3)])
+def test_rccl_paths_at_world_one(gpu, window, hop, pairs, S):
+    """the `nccl` backend and the RCCL communicator of the C ABI really run (VERDICT r1: 'the nccl path has never executed'): one
+    rank, collectives over a group of one, result == the plain single-device render"""
+    import torch.multiprocessing as mp
+    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=256, pole=(0.97, 0.5))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q, S, cfg))
+    p.start()
+    ref, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert out["frames"] == ref.shape[0]
+    for k in ("p2p", "allgather", "c_abi"):
+        assert np.array_equal(out[k], ref), k

@@ -1,7 +1,7 @@
 """Time-chunk sharding: partition arithmetic, and the N>1 exchange path run with
 world_size 2 over gloo on CPU.  On CPU the per-stage compute is supplied by the oracle (TEST stand-in for
-the HIP kernels -- the choreography under test is signalizer_amd.sharding: halo all-gather, zero-carry
-render, end-state all-gather, exact carry fold, final render)."""
+the HIP kernels -- the choreography under test is signalizer_amd.sharding: neighbour halo send / recv (or the
+all-gather form), zero-carry scan, end-state all-gather, exact carry fold, emit with the carry)."""
 import os
 import socket
 
@@ -88,6 +88,15 @@ class OracleBackend:
         mapped = torch.from_numpy(self._mapped(x))
         self.stage_decay_colour(mapped, F, rgba, state)
 
+    def decay_scan(self, mapped, frames, end_state):
+        end_state.zero_()
+        self.stage_decay_colour(mapped, frames, None, end_state)
+
+    def decay_emit(self, mapped, frames, carry, rgba):
+        import torch
+        state = carry.clone() if carry is not None else torch.zeros((self.C, 2, self.P, 2), dtype=torch.float32)
+        self.stage_decay_colour(mapped, frames, rgba, state)
+
     def fold_carry(self, aggs, frames_per_rank, rank, carry):
         # same identity as sgz_decay_fold_carry: sequential fp32 decay, max with each predecessor's end state
         a = aggs.numpy()
@@ -109,7 +118,7 @@ class _FakePlan:
         self.cfg = _C
 
 
-def _worker(rank, world, port, cfg, S, q):
+def _worker(rank, world, port, cfg, S, q, halo="p2p"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -118,7 +127,7 @@ def _worker(rank, world, port, cfg, S, q):
     from signalizer_amd.sharding import TimeChunkRenderer
     full = synth.gen(77, 48000, S * world, 2 * cfg["num_pairs"])
     chunk = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy())
-    r = TimeChunkRenderer(_FakePlan(cfg), chunk, rank=rank, world=world, backend=OracleBackend(cfg))
+    r = TimeChunkRenderer(_FakePlan(cfg), chunk, rank=rank, world=world, backend=OracleBackend(cfg), halo=halo)
     out = r.render()[:r.local_frames].numpy().copy()
     assert r.time_collectives(iters=2) > 0.0          # bench.py's collective-share probe runs on this backend too
     q.put((rank, out))
@@ -126,15 +135,16 @@ def _worker(rank, world, port, cfg, S, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_render_equals_single_process():
+@pytest.mark.parametrize("halo,world", [("p2p", 2), ("allgather", 2), ("p2p", 3)])
+def test_gloo_render_equals_single_process(halo, world):
     import torch.multiprocessing as mp
     from oracle import pyoracle as po
     cfg = config.spectrum_config(window_size=512, hop=96, axis_points=40, num_pairs=2, pole=(0.97, 0.5))
-    S, world = 1500, 2                      # S is not a multiple of hop: frames straddle the chunk boundary
+    S = 1500                                # S is not a multiple of hop: frames straddle the chunk boundary
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, S, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, S, q, halo)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
