@@ -105,7 +105,7 @@ class CAbiShard:
         api.check(L.sgz_comm_create(uid, rank, world, C.byref(self.comm)))
         nch, S = chunk.shape
         self.S = S
-        self.buf = torch.zeros((nch, S + plan.cfg.window_size), dtype=torch.float32, device=dev)
+        self.buf = torch.zeros((nch, (S + plan.cfg.window_size + 63) // 64 * 64), dtype=torch.float32, device=dev)
         self.buf[:, :S] = chunk
         lf = C.c_uint64(0)
         api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), None, None, None))

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgz.so")
-SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_generic.hip", "spectrum_post.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "api.hip", "realtime.hip"]
+SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_generic.hip", "spectrum_post.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "api.hip", "realtime.hip"]
 HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         else:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",
                    "-x", "hip", "-c", s, "-o", o] + os.environ.get("SGZ_EXTRA_HIPCC_FLAGS", "").split()
-            if s.endswith("spectrum_fft.hip"):
+            if s.endswith("spectrum_fft.hip") or s.endswith("spectrum_real.hip"):
                 cmd.append("-fno-slp-vectorize")   # packed-f32 SLP adds v_mov shuffles around the butterflies (measured -2.5 %)
         if verbose:
             print(" ".join(cmd))

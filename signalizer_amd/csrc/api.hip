@@ -35,7 +35,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_ny, d_nyFlag, d_nyBest};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -66,6 +66,9 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw1odd, &p.d_tw1odd)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.twReal1, &p.d_twReal1)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.twRealPost, &p.d_twRealPost)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.winPhase, &p.d_winPhase)) != SGZ_OK) return st;
     if ((st = uploadVec(p.dcPixels, &p.d_dcPixels)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
@@ -142,6 +145,46 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
+    if (p.realSplit && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
+        // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
+        const size_t units = size_t(tasks) * 2;
+        if (p.nyCap < units) {
+            if (p.d_ny) { (void)hipFree(p.d_ny); p.d_ny = nullptr; }
+            if (p.d_nyFlag) { (void)hipFree(p.d_nyFlag); p.d_nyFlag = nullptr; }
+            if (p.d_nyBest) { (void)hipFree(p.d_nyBest); p.d_nyBest = nullptr; }
+            p.nyCap = 0;
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyBest), units * 64 * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyFlag), units * sizeof(uint32_t)));
+            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * sizeof(uint32_t), stream));
+            p.nyCap = units;
+            p.nyEpoch = 0;
+        }
+        if (++p.nyEpoch == 0) {                                          // the epoch wrapped: start over from clean flags
+            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, p.nyCap * sizeof(uint32_t), stream));
+            p.nyEpoch = 1;
+        }
+        RealParams rp{};
+        rp.planar = d_planar; rp.chStride = chStride; rp.frames = frames;
+        rp.hop = p.cfg.hop; rp.C = p.C; rp.P = p.P;
+        rp.window = p.d_window;
+        rp.winPhase = reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = p.winP0; rp.winP1 = p.winP1;
+        rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
+        rp.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
+        rp.twPost = reinterpret_cast<const float2 *>(p.d_twRealPost);
+        rp.recs = p.d_recs; rp.weights = p.d_weights; rp.items = p.d_items;
+        rp.nItems = uint32_t(p.items.size()); rp.nItemsLeft = p.nItemsLeft;
+        rp.invSize = p.scalars.invSize;
+        rp.mapped = d_mapped; rp.binsOut = d_binsOut;
+        rp.ny = p.d_ny; rp.nyFlag = p.d_nyFlag; rp.nyBest = p.d_nyBest; rp.epoch = p.nyEpoch;
+        rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
+        rp.roundSize = uint32_t(numCUs()) * (p.N == 32768 ? 2u : 1u);
+#ifdef SGZ_DEBUG
+        rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
+#endif
+        SGZ_HIP(launchStftReal(rp, p.N, stream));
+        return SGZ_OK;
+    }
     if (p.halves && d_binsIn == nullptr) {
         // N = 2 R^3: half-frame workgroups -> csf magnitudes in HBM (a slab of tasks at a time) -> mapSideKernel / genericMap
         const size_t perTask = size_t(p.N) + 1;
@@ -344,8 +387,9 @@ uint32_t sgz_plan_path(const sgz_plan *plan)
 {
     if (!plan) return SGZ_PATH_GENERIC;
     const Plan &p = plan->impl;
-    if (p.fused) return SGZ_PATH_FUSED;
-    return (p.halves ? SGZ_PATH_HALVES : SGZ_PATH_GENERIC) | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u);
+    const uint32_t real = p.realSplit ? SGZ_PATH_CHANNEL_SPLIT : 0u;
+    if (p.fused) return SGZ_PATH_FUSED | real;
+    return (p.halves ? SGZ_PATH_HALVES : SGZ_PATH_GENERIC) | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u) | real;
 }
 uint32_t sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap)
 {

@@ -141,6 +141,16 @@ __device__ __forceinline__ float2 bufLoad2(__amdgpu_buffer_rsrc_t r, int voff, i
     return make_float2(x, y);
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is fence(all address spaces) + s_barrier: the fence makes
+// every wave wait for its outstanding GLOBAL loads too (s_waitcnt vmcnt(0)) -- the map tables and twiddles that are prefetched
+// across a barrier on purpose.  With the fence restricted to the local address space only LDS traffic is waited for.
+__device__ __forceinline__ void ldsBarrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // An opaque copy of a per-thread constant: address arithmetic derived from it cannot be hoisted out of the frame
 // loop (where it would pin VGPRs for the whole iteration and spill); it is recomputed where it is used instead.
 __device__ __forceinline__ int opaque(int v)

@@ -38,6 +38,34 @@ struct StftParams {
     unsigned long long *phaseClock;   // debug hook: workgroup 0 stores s_memtime at phase boundaries (16 slots) or null
     uint32_t roundSize;       // workgroups that run concurrently (number of CUs), for the frame -> workgroup order
 };
+// channel-split K_A (spectrum_real.hip): one workgroup per (frame, pair, channel), Separate mode, N = 32768 / 65536, W == N
+struct RealParams {
+    const float *planar;      // device, channel c at planar + c*chStride (8-byte aligned rows, even hop: the samples are fetched in pairs)
+    size_t chStride;
+    long frames;
+    uint32_t hop, C, P;
+    const float *window;      // [N]
+    // Hann / Hamming, periodic: w[n] = p0 + p1 cos(2 pi n / N) is evaluated in the kernel instead of fetched (a third of the kernel's
+    // L2 -> L1 traffic is the window, the same 4 N bytes for every workgroup): winPhase[c] = (cos, sin) of 2 pi (2c) / N and of
+    // 2 pi (2c + 1) / N for the 1024 columns; the step to a column's next sample pair is a compile-time rotation.  Null: fetch.
+    const float4 *winPhase; float winP0, winP1;
+    const float2 *tw1;        // [3 + R1/4 - 1][1024]  pass-1 twiddles W_{N/2}^{c q}
+    const float2 *tw2;        // [10][32]  (the whole-frame kernels' pass-2 table)
+    const float2 *twPost;     // [R1 * 32]  W_N^{kc}
+    const PixelRec *recs; const float *weights; const MaxItem *items;
+    uint32_t nItems, nItemsLeft;
+    float invSize;
+    float *mapped;            // [frames][C][2][P] or null
+    float *binsOut;           // test hook: [frames][C][N+1] csf magnitudes, or null
+    // csf[N/2] = |X_L[M] + i X_R[M]| / 2 needs both channels.  Nobody waits for it: a workgroup maps with 0 there, publishes its Nyquist bin
+    // (ny), the winning squares of the pixels whose arg-max run ends on csf[N/2] (nyBest, [unit][64]) and then its epoch flag; whichever
+    // of the two channels finishes second finds the other's flag set and settles those pixels for both sides.
+    float *ny; uint32_t *nyFlag; float *nyBest; uint32_t epoch;
+    uint32_t fixFrom[2];      // per side: pixels [fixFrom, P) have runs that end on csf[N/2]
+    unsigned long long *phaseClock; uint32_t clkUnit;   // -DSGZ_DEBUG builds: shader clocks of workgroup `clkUnit` at the phase boundaries
+    uint32_t roundSize;       // workgroups that run concurrently, for the XCD-aware order
+};
+hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream);
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
 // the fused kernel's load + three passes only: raw transform Z of every task -> prm.zOut (N = 4096, 32768; Phase mode)

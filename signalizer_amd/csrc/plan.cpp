@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace sgz {
@@ -572,6 +573,79 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             for (int i = 0; i < rec.b; ++i) { p.sideMapOk = p.sideMapOk && inside(k); k = (k == N) ? 0 : k + 1; }
         } else if (rec.kind & 1) {
             for (long o = rec.a; o < long(rec.a) + rec.b; ++o) p.sideMapOk = p.sideMapOk && inside(right ? N - o : o);
+        }
+    }
+    // channel-split path (spectrum_real.hip): eligibility and tables
+    p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
+                  p.dcPixels.empty() && !p.items.empty();
+    if (p.realSplit) {
+        const long N = long(p.N), M = N / 2;
+        for (size_t r = 0; r < p.recs.size() && p.realSplit; ++r) {
+            const PixelRec &rec = p.recs[r];
+            const bool right = r >= size_t(p.P);
+            auto inside = [&](long k) { return right ? (k >= M && k <= N) : (k >= 0 && k <= M); };
+            if (rec.kind == 0) {
+                // interpolation taps must stay on their side and clear of csf[N/2], the one entry that needs both channels
+                long k = rec.a;
+                for (int i = 0; i < rec.b; ++i) { p.realSplit = p.realSplit && inside(k) && k != M && !(i + 1 < rec.b && k == N); k = (k == N) ? 0 : k + 1; }
+            } else if (rec.kind & 1) {
+                for (long o = rec.a; o < long(rec.a) + rec.b; ++o) p.realSplit = p.realSplit && inside(right ? N - o : o);
+            }
+        }
+        // arg-max runs that include offset N/2 (csf[N/2] on either side: it is the LAST offset of a scan): the top pixels of a side
+        for (int side = 0; side < 2 && p.realSplit; ++side) {
+            uint32_t from = p.P;
+            for (uint32_t x = 0; x < p.P; ++x) {
+                const PixelRec &rec = p.recs[size_t(side) * p.P + x];
+                const bool hit = (rec.kind & 1) && long(rec.a) <= M && M < long(rec.a) + rec.b;
+                if (hit && from == p.P) from = x;
+                if (!hit && from != p.P) p.realSplit = false;            // (not a suffix of the pixel axis: leave it to the whole-frame kernel)
+                if (!hit && (rec.kind & 1) && rec.c == M) p.realSplit = false;   // fallback bin N/2 without N/2 in the run
+            }
+            if (p.P - from > 64) p.realSplit = false;
+            p.realFixFrom[side] = from;
+        }
+        const size_t nLeft = p.nItemsLeft, nRight = p.items.size() - p.nItemsLeft;
+        const size_t ldsFloats = size_t(M + 1) + size_t((M + 1) >> 5) + 2;
+        const size_t budget = (p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
+        if (std::max(nLeft, nRight) * 4 > budget) p.realSplit = false;
+    }
+    // Which eligible plans take it.  Measured on MI355X (tools/ka_time.py): at N = 65536 the fused channel workgroups beat the half-frame
+    // kernels + map kernel by 30 % (cfg5, 32 pairs: 842 us against 1199 us per K_A pass); at N = 32768 two co-resident 512-thread
+    // tasks still trail the whole-frame kernel (53.7 us against 47.4 us at 348 frames), so that size stays on stftMapKernel unless asked
+    // for.  SGZ_CHANNEL_SPLIT=1 / 0 forces the choice for every eligible plan (A/B runs, and the tests of the N = 32768 variant).
+    if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
+    else if (p.N != 65536) p.realSplit = false;
+    if (p.realSplit) {
+        const double kTwoPi = 6.28318530717958647692;
+        const uint32_t M = p.N / 2, R1 = M / 1024, T = R1 * 32;
+        const int rows = 3 + int(R1) / 4 - 1;
+        auto mult = [&](int row) { return row < 3 ? row + 1 : 4 * (row - 3 + 1); };
+        p.twReal1.resize(size_t(rows) * 1024 * 2);
+        for (int row = 0; row < rows; ++row)
+            for (uint32_t c = 0; c < 1024; ++c) {
+                const uint64_t m = (uint64_t(c) * uint64_t(mult(row))) % M;
+                const double ang = -kTwoPi * double(m) / double(M);
+                p.twReal1[(size_t(row) * 1024 + c) * 2 + 0] = float(std::cos(ang));
+                p.twReal1[(size_t(row) * 1024 + c) * 2 + 1] = float(std::sin(ang));
+            }
+        if ((cfg.window_type == SGZ_WIN_HANN || cfg.window_type == SGZ_WIN_HAMMING) && cfg.window_symmetry == SGZ_WIN_PERIODIC) {
+            // w[n] = a0 - a1 cos(2 pi n / W) (designWindow): evaluated in the kernel from these phases
+            p.winP0 = cfg.window_type == SGZ_WIN_HANN ? 0.5f : 0.54f;
+            p.winP1 = cfg.window_type == SGZ_WIN_HANN ? -0.5f : -0.46f;
+            p.winPhase.resize(1024 * 4);
+            for (uint32_t c = 0; c < 1024; ++c)
+                for (int e = 0; e < 2; ++e) {
+                    const double ang = kTwoPi * double(2 * c + e) / double(p.N);
+                    p.winPhase[size_t(c) * 4 + 2 * e + 0] = float(std::cos(ang));
+                    p.winPhase[size_t(c) * 4 + 2 * e + 1] = float(std::sin(ang));
+                }
+        }
+        p.twRealPost.resize(size_t(T) * 2);
+        for (uint32_t kc = 0; kc < T; ++kc) {
+            const double ang = -kTwoPi * double(kc) / double(p.N);
+            p.twRealPost[size_t(kc) * 2 + 0] = float(std::cos(ang));
+            p.twRealPost[size_t(kc) * 2 + 1] = float(std::sin(ang));
         }
     }
     return SGZ_OK;

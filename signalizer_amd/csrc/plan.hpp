@@ -70,6 +70,14 @@ struct Plan {
     bool phaseFusedFft = false;         // Phase at N = R^3: the transform comes from the in-register FFT (complex output), the rest is generic
     bool sideMapOk = false;             // halves path: every record stays inside the csf range mapSideKernel stages per side
     bool halves = false;                // N in {8192, 65536} = 2 R^3: two half-frame workgroups (spectrum_fft.hip) + genericMap
+    // Channel-split path (spectrum_real.hip): Separate mode at N = 32768 / 65536 with W == N -- every (frame, pair, channel) is its own
+    // workgroup: a real-input FFT of N/2 complex points, that channel's csf side and that side's pixels.  Eligible when every record
+    // of a side stays inside that side's half of csf (no wrap-around taps) and a side's arg-max pieces fit beside |X| in LDS.
+    bool realSplit = false;
+    std::vector<float> twReal1;         // pass-1 twiddles W_{N/2}^{c q}, factorised rows [3 + R1/4 - 1][1024] (re, im)
+    uint32_t realFixFrom[2] = {0, 0};   // per side: first pixel whose arg-max run ends on csf[N/2] (the one cross-channel entry); [from, P) are settled late
+    std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
+    std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
     DeviceScalars scalars{};
 
     // device mirrors (owned)
@@ -88,6 +96,8 @@ struct Plan {
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
+    float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr;
+    float *d_ny = nullptr; uint32_t *d_nyFlag = nullptr; float *d_nyBest = nullptr; size_t nyCap = 0; uint32_t nyEpoch = 0;   // channel-split path: Nyquist exchange of a frame's two workgroups
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;
 

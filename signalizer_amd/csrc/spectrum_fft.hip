@@ -81,7 +81,7 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
     const MapView v{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
                     side ? 0 : int(prm.P), mapped + (size_t(task) * prm.sides + side) * prm.P};
-    uint2 *win = reinterpret_cast<uint2 *>(lds + ((count + (count >> 5) + 2) & ~1));
+    float *win = lds + ((count + (count >> 5) + 2) & ~1);
     MapPixelsBalanced<5, NT, OneSideIndex> mapper;
     SGZ_CLK_HALF(side == int((prm.ablate >> 15) & 1u));       // debug clocks: which side reports
     SGZ_CLK(0);
@@ -113,7 +113,7 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     if (count <= 5 * NT) stage(std::integral_constant<int, 5>{});
     else stage(std::integral_constant<int, 17>{});
     mapper.prefetchWeights(prm);
-    __syncthreads();
+    ldsBarrier();
     SGZ_CLK(7);
     mapper.run(prm, v, at, lds, win, tid, task);
     SGZ_CLK(9);
@@ -141,7 +141,7 @@ static size_t mapSidesLds(const StftParams &prm, uint32_t N)          // bytes o
 {
     const int count = int(N / 2) + 48;
     const uint32_t maxSide = prm.nItemsLeft > prm.nItems - prm.nItemsLeft ? prm.nItemsLeft : prm.nItems - prm.nItemsLeft;
-    return size_t((count + (count >> 5) + 2) & ~1) * sizeof(float) + size_t(maxSide) * 8;
+    return size_t((count + (count >> 5) + 2) & ~1) * sizeof(float) + size_t(maxSide) * 4;
 }
 bool mapSidesFit(const StftParams &prm, uint32_t N) { return mapSidesLds(prm, N) <= 160 * 1024; }
 
@@ -197,7 +197,7 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
     const size_t baseBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
-    const size_t slotBytes = size_t(prm.nItems) * 8;
+    const size_t slotBytes = size_t(prm.nItems) * 4;
     StftParams p2 = prm;
     size_t ldsBytes = baseBytes;
     if (p2.items && baseBytes + slotBytes <= 160 * 1024) ldsBytes += slotBytes;   // arg-max slots fit beside the |X| array

@@ -1,0 +1,404 @@
+// spectrum_real.hip -- K_A, channel-split form: one workgroup per (frame, pair, CHANNEL).  gfx950 only.
+//
+// SpectrumChannels::Separate transforms z = L w + i R w with one N-point complex FFT and splits the result (TransformDSP.inl:858-869).
+// The two channels never meet again except in one bin (csf[N/2], see below): left pixels read csf[0 .. N/2], right pixels
+// csf[N/2 .. N].  So the frame is cut along that line: each channel gets its own workgroup, which computes the channel's spectrum
+// with a REAL-input FFT -- M = N/2 complex points z[n] = x[2n] + i x[2n+1], then X[k] = E[k] + W_N^k O[k] -- keeps the M + 1
+// magnitudes of its side of csf in LDS and maps its side's pixels.  Same flops as the two-for-one transform, but:
+//   * N = 32768: a task is 512 threads x <= 128 VGPRs and <= 80 KB of LDS, so TWO tasks share a CU.  They are in different phases
+//     (one in its LDS-bound transposes while the other is in its VALU-bound butterflies), which is the overlap the sixteen
+//     lock-stepped waves of the whole-frame kernel could not find among themselves; and the work list is twice as fine (696 tasks
+//     on 512 slots instead of 348 on 256), so the partial last round of workgroups costs half as much;
+//   * N = 65536: the transform is the R^3 = 32768-point in-register FFT itself, fused with the map -- no half-frame workgroups, no
+//     csf round trip through HBM, no second kernel.
+// Layout: M = R1 R^2 complex points, R = 32, R1 = 16 (N = 32768) or 32 (N = 65536); T = R1 R threads of R points.
+//   pass 1  thread t owns the columns c = t + T u (u < R / R1), R1 points z[c + R^2 j] each: radix-R1 DIF, times W_M^{c q1}
+//   exch 1  workgroup-wide, 64-bit LDS operations, two rounds of R1 x 512 values
+//   pass 2  role (q1, c_lo): radix-R DIF over c_hi, times W_{R^2}^{c_lo q2}
+//   exch 2  R x R transposes inside each R-lane group (wave-local)
+//   pass 3  role (q1, q2): radix-R DIF over c_lo -> Z[q1 + R1 q2 + T m3]
+//   recombination: Z[M - k] sits in lane L ^ R, register R-1-m3 (same construction as stft_body.hpp) ->
+//           X[k] = ( Z[k] + conj Z[M-k] ) / 2  -  i W_N^k ( Z[k] - conj Z[M-k] ) / 2 ,   |X[k]| -> LDS (this side's csf order)
+//   map     MapPixelsBalanced (stft_body.hpp) on this side's records and arg-max pieces.
+// csf[N/2] is the one entry that mixes the channels: the reference halves the PACKED bin there, |X_L[M] + i X_R[M]| / 2
+// (TransformDSP.inl:863).  It is the last offset of either side's arg-max scan and is compared with a strict >, so nobody waits for
+// it: a workgroup maps with 0 in its place, publishes its own Nyquist bin and the winning squares of the (top) pixels whose run ends
+// there, then raises its epoch flag; the channel that finishes second sees the other's flag and settles those pixels for both
+// sides (store own flag, load the partner's, both sequentially consistent: at least one of the two sees the other).
+// Everything else the path needs (mono modes, Complex, Phase, zero-padded windows, views whose filter taps wrap around csf) stays
+// on the whole-frame kernels; plan.cpp decides (Plan::realSplit).
+#include <algorithm>
+
+#include "stft_body.hpp"
+
+#ifdef SGZ_DEBUG
+#define RCLK(slot)                                                                                                     \
+    do {                                                                                                               \
+        if (prm.phaseClock && (tid & 63) == 0 && unit == long(prm.clkUnit)) prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define RCLK(slot) do { } while (0)
+#endif
+
+namespace sgz {
+
+// csf index -> LDS float index of this side's array: left holds csf[0 .. M], right csf[M .. N], both at positions 0 .. M
+struct ChannelIndex {
+    int n, off;
+    static constexpr bool kSkipEmpty = true;
+    __device__ __forceinline__ int size() const { return n; }
+    __device__ __forceinline__ int operator()(int k) const { const int i = k - off; return i + (i >> 5); }
+    __device__ __forceinline__ bool holds(int k) const { return k >= off && k <= off + n / 2; }
+};
+
+// |X[k]| of the real-input transform from a = Z[k], b = Z[M - k] and w = W_N^k = (cos, -sin):
+//   2 X = (a + conj b) - i w (a - conj b)
+__device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
+{
+    const float ex = a.x + b.x, ey = a.y - b.y;          // a + conj b
+    const float dx = a.x - b.x, dy = a.y + b.y;          // a - conj b
+    // -i w d = -i (w.x + i w.y)(dx + i dy) = (w.x dy + w.y dx) + i (w.y dy - w.x dx)
+    const float xr = ex + (w.x * dy + w.y * dx);
+    const float xi = ey + (w.y * dy - w.x * dx);
+    return 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
+}
+
+template <int LR1, bool WCOS>
+__global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams prm)
+{
+    constexpr int LR = 5, R = 32, R1 = 1 << LR1, T = R1 * R, RR = R * R, M = R1 * RR, N = 2 * M, U = R / R1;
+    constexpr int PADSTRIDE = T + (T >> 5);             // padded distance between k and k + T
+    constexpr int TILE = R * (R + 1);
+    constexpr int XFLOATS = ((M + 1) + ((M + 1) >> 5) + 2) & ~1;      // this side's |X| array (padded) -- the winners follow it
+    constexpr int SCRATCH = XFLOATS;                    // column 0's 2R floats live where the winners will be written later
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
+    const int q1 = half ? (slot == 0 ? R1 / 2 : R1 - slot) : slot;
+    const int ix = half ? R - 1 - l : l;                // c_lo in pass 2, q2 in pass 3
+
+    // ---- work list: unit = (frame, pair, channel); XCD-aware order as in stft_body.hpp (a speed assumption only)
+    const long units = prm.frames * long(prm.C) * 2;
+    long unit = blockIdx.x;
+    if (units >= 64 && prm.roundSize >= 8 && prm.roundSize % 8 == 0) {
+        const long nb = gridDim.x, bid = blockIdx.x;
+        const long base = (bid / prm.roundSize) * prm.roundSize;
+        const long nbr = nb - base < long(prm.roundSize) ? nb - base : long(prm.roundSize);
+        const long x = (bid - base) % 8, i = (bid - base) / 8;
+        const long per = nbr / 8, extra = nbr % 8;
+        unit = base + x * per + (x < extra ? x : extra) + i;
+    }
+    const int side = int(unit & 1);
+    long task = unit >> 1;                              // (frame, pair)
+    if (prm.C > 1) { const long pr = task / prm.frames, fr = task - pr * prm.frames; task = fr * prm.C + pr; }
+    const long frame = task / prm.C;
+    const int pair = int(task - frame * prm.C);
+    const long partner = (task << 1) | (side ^ 1);      // ny / flag / best slots are indexed by task * 2 + side
+    const long self = (task << 1) | side;
+
+    // map tables of this side
+    const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
+    const MapView view{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
+                       side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * 2 + side) * prm.P : nullptr,
+                       prm.nyBest + size_t(self) * 64, int(prm.fixFrom[side])};
+    const ChannelIndex at{N, side ? M : 0};
+    float *win = lds + XFLOATS;
+    MapPixelsBalanced<5, T, ChannelIndex> mapper;
+    StftParams sp{};
+    sp.weights = prm.weights; sp.invSize = prm.invSize;
+#ifdef SGZ_DEBUG
+    sp.phaseClock = prm.phaseClock; sp.ablate = prm.clkUnit << 16;
+#endif
+
+    RCLK(0);
+    v2 c[R];
+    {
+        // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
+        // 8-byte loads, R of them per thread, in batches of B with the next batch in flight while this one is multiplied (the
+        // scheduling barriers keep instruction selection from hoisting all 2R loads to the top: 128 registers of raw samples)
+        const float *X = prm.planar + size_t(2 * pair + side) * prm.chStride + size_t(frame) * prm.hop;
+        // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
+        auto offOf = [&](int e) { const int u = e / R1, j = e % R1; return uint32_t(tid + T * u + RR * j) * 8u; };
+#pragma unroll
+        for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X), offOf(i)); c[i] = v2{xv.x, xv.y}; }
+        if (WCOS) {
+            // w[n] = p0 + p1 cos(theta_n), theta_n = 2 pi n / N, n = 2 (col + R^2 j) + e: theta = phi(col, e) + 2 pi j / R1 -- the phase of the
+            // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 ph = ldg(prm.winPhase, uint32_t(tid + T * u) * 16u);
+#pragma unroll
+                for (int j = 0; j < R1; ++j) {
+                    constexpr int S32 = 32 / R1;
+                    const float cj = cos32((j * S32) % 32 <= 16 ? (j * S32) % 32 : 32 - (j * S32) % 32);
+                    const float sj = (j * S32) % 32 <= 16 ? sin32((j * S32) % 32) : -sin32(32 - (j * S32) % 32);
+                    const float ce = ph.x * cj - ph.y * sj, co = ph.z * cj - ph.w * sj;
+                    const int i = u * R1 + j;
+                    c[i] = v2{c[i].x * (prm.winP0 + prm.winP1 * ce), c[i].y * (prm.winP0 + prm.winP1 * co)};
+                }
+            }
+        } else {
+            // the window in batches of B pairs, two batches in flight
+            constexpr int B = 8;
+            float2 wa[B], wb[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(i));
+#pragma unroll
+            for (int b0 = 0; b0 < R; b0 += 2 * B) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) wb[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(b0 + B + i));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < B; ++i) { c[b0 + i] = v2{c[b0 + i].x * wa[i].x, c[b0 + i].y * wa[i].y}; asm volatile("" : "+v"(c[b0 + i])); }
+                if (b0 + 2 * B < R) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(b0 + 2 * B + i));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < B; ++i) { c[b0 + B + i] = v2{c[b0 + B + i].x * wb[i].x, c[b0 + B + i].y * wb[i].y}; asm volatile("" : "+v"(c[b0 + B + i])); }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    RCLK(13);
+    // -------------------------------------------------------------------------- pass 1: radix R1 per column, times W_M^{c q1}
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (u == 0) difPacked<R, R1, 0>(c); else difPacked<R, R1, (U > 1 ? R1 : 0)>(c);
+        constexpr int NB = R1 / 4 - 1;
+        float2 a[3], b[NB];
+        const int col = tid + T * u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[i] = ldg(prm.tw1, uint32_t(col + i * RR) * 8u);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b[i] = ldg(prm.tw1, uint32_t(col + (3 + i) * RR) * 8u);
+#pragma unroll
+        for (int q = 1; q < R1; ++q) {
+            const int qa = q >> 2, qb = q & 3;
+            v2 w;
+            if (qa == 0) w = v2{a[qb - 1].x, a[qb - 1].y};
+            else if (qb == 0) w = v2{b[qa - 1].x, b[qa - 1].y};
+            else w = cmul(v2{b[qa - 1].x, b[qa - 1].y}, v2{a[qb - 1].x, a[qb - 1].y});
+            const int i = u * R1 + brev(q, LR1);
+            c[i] = cmul(c[i], w);
+        }
+    }
+    RCLK(1);
+    // -------------------------------------------------------------------------- exchange 1: two rounds of R1 x 512 complex values
+    {
+        v2 *lds2 = reinterpret_cast<v2 *>(lds);
+        auto writeRound = [&](int r) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int col = tid + T * u;
+                if ((col >> 9) == r) {
+#pragma unroll
+                    for (int q = 0; q < R1; ++q) lds2[q * 512 + (col & 511)] = c[u * R1 + brev(q, LR1)];
+                }
+            }
+        };
+        const int rd = q1 * 512 + ix;
+        v2 lo[R / 2];
+        writeRound(0);
+        ldsBarrier();
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) lo[h] = lds2[rd + R * h];           // c_hi = h
+        ldsBarrier();
+        writeRound(1);
+        ldsBarrier();
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+            c[h + R / 2] = lds2[rd + R * h];                                // c_hi = 16 + h
+            c[h] = lo[h];
+        }
+    }
+    ldsBarrier();                                                        // every wave has read exchange 1: the tiles may overwrite it
+    RCLK(2);
+    // -------------------------------------------------------------------------- pass 2 (c_lo = ix): radix R over c_hi
+    difPacked<R, R, 0>(c);
+    {
+        TwFactors<LR> tw;
+        tw.load(prm.tw2, ix, R);
+        tw.apply(c);
+    }
+    RCLK(3);
+    // -------------------------------------------------------------------------- exchange 2: wave-local R x R transposes
+    {
+        const int tile = group * TILE;
+#pragma unroll
+        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int j = 0; j < R; ++j) c[j].x = lds[tile + ix * (R + 1) + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int j = 0; j < R; ++j) c[j].y = lds[tile + ix * (R + 1) + j];
+    }
+    RCLK(4);
+    // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
+    const float2 wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
+    difPacked<R, R, 0>(c);
+    RCLK(5);
+    // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
+    const int kc = q1 + R1 * ix;
+    if (tid == 0) {                                                         // column 0 (k = T m3) pairs registers inside thread 0
+#pragma unroll
+        for (int m3 = 0; m3 < R; ++m3) {
+            lds[SCRATCH + 2 * m3] = c[brev(m3, LR)].x;
+            lds[SCRATCH + 2 * m3 + 1] = c[brev(m3, LR)].y;
+        }
+        // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] is settled by whichever channel finishes second (below)
+        __hip_atomic_store(prm.ny + self, c[0].x - c[0].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Column 0 (k = T m3, all in thread 0) pairs m3 with R - m3 inside one thread and holds DC / Nyquist: lanes 0 .. R/2 of wave 0 redo it
+    // from thread 0's scratch copy right away (the scratch is not part of the tiles), keep the values and store them after the
+    // workgroup's own stores.
+    float fixA = 0.f, fixB = 0.f;
+    if (tid <= R / 2) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (tid >= 1) {
+            const int m3 = tid;                                             // k1 = T m3 and its mirror k2 = T (R - m3)  (m3 = R/2: one bin)
+            const v2 a = v2{lds[SCRATCH + 2 * m3], lds[SCRATCH + 2 * m3 + 1]};
+            const v2 b = v2{lds[SCRATCH + 2 * (R - m3)], lds[SCRATCH + 2 * (R - m3) + 1]};
+            const float cs = cospif(float(m3) * (1.0f / 32.0f)), sn = sinpif(float(m3) * (1.0f / 32.0f));   // W_N^{T m3} = W_{2R}^{m3} = (cos, -sin)
+            fixA = realBinMag(a, b, v2{cs, -sn});
+            fixB = realBinMag(b, a, v2{-cs, -sn});                          // W_{2R}^{R - m3} = (-cos, -sin)
+        } else {
+            fixA = 0.5f * (lds[SCRATCH] + lds[SCRATCH + 1]);                // csf[0] = Re(csf[0]) * 0.5 / csf[N] = Im(csf[0]) * 0.5 (:861-862): X_c[0] / 2, signed
+        }
+    }
+    // ---- recombination.  a = Z[k] (own register m3 < R/2), b = Z[M - k] (lane L ^ R, register R-1-m3):
+    //   2 E = a + conj b,  2 W O = -i w (a - conj b):   2 X[k] = 2E + 2WO   and   2 X[M - k] = conj(2E - 2WO)
+    // so ONE evaluation gives the magnitudes of both bins of the pair.  A lane does this for its registers m3 < R/2; their mirrors are
+    // the partner lane's registers >= R/2, and the partner does the same for ITS lower registers, whose mirrors are this lane's upper
+    // ones: every bin of the lane pair is produced exactly once, with half the permutes, twiddles and adds of bin-by-bin evaluation.
+    float magA[R / 2], magB[R / 2];
+    {
+        // lane holding Z[M - k]: L ^ R, except in slot 0 (q1 = 0: q2' = R - q2 ; q1 = R1/2: q2' = R-1-q2, same half)
+        const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+        int plane = lane ^ R;
+        if (slot == 0) plane = (lane & ~(R - 1)) | (half ? R - 1 - l : ((R - l) & (R - 1)));
+        plane <<= 2;
+        auto partnerOf = [&](float v) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plane, __builtin_bit_cast(int, v)));
+        };
+#pragma unroll
+        for (int m3 = 0; m3 < R / 2; ++m3) {
+            const int i = brev(m3, LR), ip = brev(R - 1 - m3, LR);
+            const v2 a = c[i];
+            const v2 b = v2{partnerOf(c[ip].x), partnerOf(c[ip].y)};
+            const v2 w = m3 == 0 ? v2{wk.x, wk.y} : cmulConjK(v2{wk.x, wk.y}, v2{cos64(m3), sin64(m3)});
+            const float ex = a.x + b.x, ey = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            const float ox = w.x * dy + w.y * dx, oy = w.y * dy - w.x * dx;      // -i w (dx + i dy)
+            const float pr = ex + ox, pi = ey + oy, mr = ex - ox, mi = ey - oy;
+            magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
+            magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(mr * mr + mi * mi);
+        }
+    }
+    RCLK(6);
+    // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
+    if (side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
+    if (nSide) mapper.prefetchTables(view, tid);
+    ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
+    {
+        // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
+        const int up = kc + (kc >> 5), down = (M - kc) + ((M - kc) >> 5);
+        float *pa = lds + (side ? down : up), *pb = lds + (side ? up : down);
+        const int sa = side ? -PADSTRIDE : PADSTRIDE;
+#pragma unroll
+        for (int m3 = 0; m3 < R / 2; ++m3) { pa[m3 * sa] = magA[m3]; pb[-m3 * sa] = magB[m3]; }
+    }
+    if (tid <= R / 2) {                                                     // column 0, after this wave's own stores (one wave's LDS operations execute in order)
+        auto put = [&](int k, float v) { const int i = side ? M - k : k; lds[i + (i >> 5)] = v; };
+        if (tid >= 1) {
+            put(T * tid, fixA);
+            if (tid != R / 2) put(T * (R - tid), fixB);
+        } else {
+            put(0, fixA);
+            put(M, 0.f);                                                    // csf[N/2]: settled late, can never win meanwhile (strict >)
+        }
+    }
+    if (nSide && prm.mapped) mapper.prefetchWeights(sp);
+    ldsBarrier();
+    RCLK(7);
+    if (prm.binsOut) {                                                      // test hook: this side's half of csf, csf order
+        float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
+        for (int i = tid; i <= M; i += T) dst[i] = lds[i + (i >> 5)];
+    }
+    if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
+    RCLK(9);
+    // ---- csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) and the pixels whose arg-max run ends on it (it is the last offset of
+    // either side's scan, compared with a strict >).  Store own flag, then look at the partner's (both sequentially consistent): at
+    // least the later of the two workgroups sees the other's flag and settles both sides; if both do, they write identical values.
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(prm.nyFlag + self, prm.epoch, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(prm.nyFlag + partner, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch) {
+#pragma clang fp contract(off)
+            const float nyRe = __hip_atomic_load(prm.ny + (task << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float nyIm = __hip_atomic_load(prm.ny + (task << 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float vM = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
+            const float sqM = vM * vM + 0.f;                                // Math::square(csf[offset]) with imag == 0
+            if (prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
+            if (prm.mapped) {
+                for (int s = 0; s < 2; ++s) {
+                    const float *best = prm.nyBest + (size_t(task) * 2 + s) * 64;
+                    float *out = prm.mapped + (size_t(task) * 2 + s) * prm.P;
+                    for (uint32_t x = prm.fixFrom[s]; x < prm.P; ++x) {
+                        const float b = __hip_atomic_load(best + (x - prm.fixFrom[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sqM > b) out[x] = finishPixel<5>(prm.invSize * vM);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
+static hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && granted[dev] >= need) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(need));
+    if (e == hipSuccess && dev >= 0 && dev < 64) granted[dev] = need;
+    return e;
+}
+
+hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
+{
+    const long units = prm.frames * long(prm.C) * 2;
+    if (units <= 0) return hipSuccess;
+    const uint32_t M = N / 2;
+    const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
+    const uint32_t maxSide = std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
+    const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4;
+    static size_t granted[4][64] = {};
+    const bool wcos = prm.winPhase != nullptr;
+    auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
+        if (ldsBytes > limit) return hipErrorInvalidValue;
+        if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (N == 32768) e = wcos ? go(&stftRealKernel<4, true>, 0, 512, 80 * 1024) : go(&stftRealKernel<4, false>, 1, 512, 80 * 1024);
+    else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true>, 2, 1024, 160 * 1024) : go(&stftRealKernel<5, false>, 3, 1024, 160 * 1024);
+    else return hipErrorNotSupported;
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace sgz

@@ -104,6 +104,7 @@ struct WholeFrameIndex {
     static constexpr bool kSkipEmpty = false;        // both sides of a view fill the thread batches (measured: a skip gains nothing)
     __device__ __forceinline__ int size() const { return N; }
     __device__ __forceinline__ int operator()(int k) const { return k + (k >> LR); }
+    __device__ __forceinline__ bool holds(int) const { return true; }
 };
 // OneSide (mapSideKernel, N = 2 R^3): LDS holds the csf range one side of the view touches, rotated by `off` (a multiple of
 // 16, so the 16-aligned arg-max windows stay aligned and contiguous): k' = (k + off) mod (N + 1), same bank padding.
@@ -117,6 +118,13 @@ struct OneSideIndex {
         kp = kp > n ? kp - (n + 1) : kp;
         return kp + (kp >> 5);
     }
+    // is csf[k] inside the staged range (n/2 + 48 entries from csf index -off on)?
+    __device__ __forceinline__ bool holds(int k) const
+    {
+        int kp = k + off;
+        kp = kp > n ? kp - (n + 1) : kp;
+        return kp >= 0 && kp < n / 2 + 48;
+    }
 };
 // The slice of the plan's tables a workgroup maps: all of it (fused kernel) or one side's records and pieces.
 struct MapView {
@@ -128,6 +136,8 @@ struct MapView {
     int total;                // records in this view
     int rightFrom;            // records [rightFrom, total) are right-side records (k = N - offset)
     float *out;               // [total]
+    float *bestOut = nullptr; // optional: the winning SQUARE of the arg-max records [bestFrom, total) -> bestOut[idx - bestFrom]
+    int bestFrom = 0;         // (spectrum_real.hip: the pixels whose run ends on csf[N/2] are settled after both channels are done)
 };
 __device__ __forceinline__ MapView wholeView(const StftParams &prm, long task)
 {
@@ -140,7 +150,6 @@ struct MapPixelsBalanced {
     static constexpr int IB = 4;                                         // items per thread per batch (register budget)
     static constexpr int RB = 2;                                         // records per thread per batch (register budget)
     static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
-    static constexpr uint32_t kNone = 0xFFFFFFFFu;
     uint32_t iw0[IB];
     PixelRec rec0[RB];
     float w0[RB][kMaxTaps];
@@ -178,7 +187,7 @@ struct MapPixelsBalanced {
     }
     __device__ __forceinline__ void prefetchWeights(const StftParams &prm) { loadWeights(prm, rec0, w0); }
 
-__device__ __forceinline__ void run(const StftParams &prm, const MapView &v, const Index at, const float *lds, uint2 *win, int tid,
+__device__ __forceinline__ void run(const StftParams &prm, const MapView &v, const Index at, const float *lds, float *win, int tid,
                                     long task)
 {
 #pragma clang fp contract(off)
@@ -186,10 +195,12 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
     const int N = at.size();
     SGZ_CLK_HALF(true);
     float *out = v.out;
-    // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats
-    // are contiguous: one base address + immediate offsets) with positions lo..hi valid; values outside are ANDed
-    // to +0, which can never win.  The left side's scan order is ascending k ("first strictly greater" = FIRST
-    // maximum), the right side's is descending k, whose first maximum is the LAST maximum in ascending order.
+    // (a) arg-max pieces.  A piece is a 16-aligned window of csf (one 32-block of the padded layout, so its 16 floats are contiguous: one
+    // base address + immediate offsets) with positions lo..hi valid.  The reference keeps the first offset whose SQUARE is strictly
+    // greater (:957-979) and then reads csf there.  fl(m^2) is strictly increasing in |m| as long as the square is a normal float
+    // (adjacent floats are >= 1.41 ulp(m^2) apart in m^2), so equal squares mean equal |m|: whichever of several tied offsets the scan
+    // order picks, the VALUE is max |m| -- a plain float maximum (v_max3_f32 with |.| source modifiers), no squares, no positions, no
+    // scan direction.  Runs whose maximum is too small for that argument (|m| < 2^-62: silence) are redone by the literal scan in (c).
     for (uint32_t base = 0; base < v.nItems; base += NT * IB) {
         uint32_t iw[IB];
         if (base == 0) {
@@ -209,36 +220,18 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         for (int b = 0; b < IB; ++b) {
             if (Index::kSkipEmpty && base + b * NT + (uint32_t(tid) & ~63u) >= v.nItems) continue;
             const uint32_t it = base + b * NT + tid;
-            const int k0 = int(iw[b] & 0xFFFFu) << 4;
             const int lo = int((iw[b] >> 16) & 15u), hi = int((iw[b] >> 20) & 15u);
             const uint32_t mask = (0xFFFFu >> (15 - hi)) & (0xFFFFu << lo);   // valid positions: bits lo..hi
-            const bool right = it >= v.nItemsLeft;
-            // masked squares, their maximum (a tree of independent v_max, not a serial compare-and-select chain), then
-            // the first (left side) or last (right side) position that holds it.  Squares are >= 0, so their bit
-            // patterns order like unsigned integers; a zero square never wins (TransformDSP.inl:965 is a strict >).
-            uint32_t sqm[16];
+            float m[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float sq = mv[b][j] * mv[b][j];                    // Math::square(csf[offset]) with imag == 0 (x*x + 0 == x*x)
-                const uint32_t keep = uint32_t(__builtin_amdgcn_sbfe(int(mask), j, 1));   // 0 or ~0
-                sqm[j] = __float_as_uint(sq) & keep;
-            }
-            uint32_t m8[8], m4[4];
+            for (int j = 0; j < 16; ++j)                                     // positions outside the run become +0, which can never win
+                m[j] = __uint_as_float(__float_as_uint(mv[b][j]) & uint32_t(__builtin_amdgcn_sbfe(int(mask), j, 1)));
+            float m5[5];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m8[j] = sqm[2 * j] > sqm[2 * j + 1] ? sqm[2 * j] : sqm[2 * j + 1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m4[j] = m8[2 * j] > m8[2 * j + 1] ? m8[2 * j] : m8[2 * j + 1];
-            const uint32_t ma = m4[0] > m4[1] ? m4[0] : m4[1], mb = m4[2] > m4[3] ? m4[2] : m4[3];
-            const uint32_t best = ma > mb ? ma : mb;
-            uint32_t first = 0u, last = 0u;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool eq = sqm[j] == best;
-                last = eq ? uint32_t(j) : last;                          // ascending: the highest position survives
-                first = (sqm[15 - j] == best) ? uint32_t(15 - j) : first;   // descending: the lowest position survives
-            }
-            const uint32_t bestK = best == 0u ? kNone : uint32_t(k0) + (right ? last : first);
-            if (it < v.nItems) win[it] = make_uint2(bestK, best);
+            for (int j = 0; j < 5; ++j) m5[j] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(m[3 * j]), __builtin_fabsf(m[3 * j + 1])), __builtin_fabsf(m[3 * j + 2]));
+            const float ma = __builtin_fmaxf(__builtin_fmaxf(m5[0], m5[1]), m5[2]);
+            const float mb = __builtin_fmaxf(__builtin_fmaxf(m5[3], m5[4]), __builtin_fabsf(m[15]));
+            if (it < v.nItems) win[it] = __builtin_fmaxf(ma, mb);
         }
     }
     SGZ_CLK(10);
@@ -282,7 +275,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
         }
     }
     SGZ_CLK(11);
-    __syncthreads();
+    ldsBarrier();
     SGZ_CLK(12);
     // (c) resolve the arg-max pixels from their pieces' winners
     for (int base = 0; base < total; base += NT * RB) {
@@ -300,33 +293,47 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
             maxPieces = pieces[b] > maxPieces ? pieces[b] : maxPieces;
         }
         float best[RB];
-        int arg[RB];
 #pragma unroll
-        for (int b = 0; b < RB; ++b) { best[b] = 0.f; arg[b] = rec[b].c; }   // maxLBin = maxRBin = bin (TransformDSP.inl:953)
+        for (int b = 0; b < RB; ++b) best[b] = 0.f;
         for (int p0 = 0; p0 < maxPieces; p0 += PB) {
-            uint2 e[RB][PB];
+            float e[RB][PB];
 #pragma unroll
             for (int b = 0; b < RB; ++b)
 #pragma unroll
                 for (int i = 0; i < PB; ++i) {
                     const int pc = p0 + i;
                     e[b][i] = win[pc < pieces[b] ? first[b] + pc : 0];
-                    if (pc >= pieces[b]) e[b][i].x = kNone;
+                    if (pc >= pieces[b]) e[b][i] = 0.f;
                 }
 #pragma unroll
             for (int b = 0; b < RB; ++b)
 #pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const float sq = __uint_as_float(e[b][i].y);
-                    const bool take = (e[b][i].x != kNone) & (sq > best[b]);
-                    best[b] = take ? sq : best[b];
-                    arg[b] = take ? int(e[b][i].x) : arg[b];
-                }
+                for (int i = 0; i < PB; ++i) best[b] = __builtin_fmaxf(best[b], e[b][i]);
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int idx = base + b * NT + tid;
-            if (rec[b].kind & 1) out[idx] = finishPixel<LR>(prm.invSize * lds[at(arg[b])]);
+            if (!(rec[b].kind & 1)) continue;
+            float val = best[b], bestSq = best[b] * best[b] + 0.f;          // Math::square(csf[offset]) of the winner (imag == 0)
+            if (!(best[b] >= 0x1p-62f)) {
+                // the run's squares are denormal, zero or NaN: distinct values can tie there -- the reference's scan, literally
+                // (first strictly greater square in offset order; initial arg = bin, :953)
+                const bool right = idx >= v.rightFrom;
+                int arg = rec[b].c;
+                bestSq = 0.f;
+                for (int o = rec[b].a; o < rec[b].a + rec[b].b; ++o) {
+                    const int k = right ? N - o : o;
+                    const float mm = lds[at(k)];
+                    const float sq = mm * mm + 0.f;
+                    if (sq > bestSq) { bestSq = sq; arg = k; }
+                }
+                // (a right-side run without a positive square keeps arg = bin, a LEFT-side index (maxRBin = maxLBin = bin, :953): the
+                // kernels that hold one side of csf per workgroup cannot read it and show 0 -- what the run's own bins say; with a real
+                // FFT's rounding noise in a silent channel the reference does not get here either)
+                val = at.holds(arg) ? lds[at(arg)] : 0.f;
+            }
+            out[idx] = finishPixel<LR>(prm.invSize * val);
+            if (v.bestOut && idx >= v.bestFrom) v.bestOut[idx - v.bestFrom] = bestSq;
         }
     }
 }
@@ -378,7 +385,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     const int ix = half ? R - 1 - l : l;                                // t2 in pass 2, q2 in pass 3
     const bool split = (prm.sides == 2);
     const int mode = prm.mode;
-    uint2 *win = reinterpret_cast<uint2 *>(lds + SLOTS);                // one (bin, square) winner per arg-max piece
+    float *win = lds + SLOTS;                                           // one |csf| maximum per arg-max piece
     const bool balanced = prm.items != nullptr;
 
     // XCD-aware task order.  Workgroup b is observed to run on XCD b % 8 (a speed assumption only, never a
@@ -526,15 +533,15 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
 #pragma unroll
                 for (int qq = 0; qq < R; ++qq) lds2[qq * (T / 2) + tid] = c[brev(qq, LR)];
             }
-            __syncthreads();
+            ldsBarrier();
 #pragma unroll
             for (int j2 = 0; j2 < R / 2; ++j2) lo[j2] = lds2[rd + R * j2];
-            __syncthreads();
+            ldsBarrier();
             if (tid >= T / 2) {
 #pragma unroll
                 for (int qq = 0; qq < R; ++qq) lds2[qq * (T / 2) + tid - T / 2] = c[brev(qq, LR)];
             }
-            __syncthreads();
+            ldsBarrier();
 #pragma unroll
             for (int j2 = 0; j2 < R / 2; ++j2) {
                 c[j2 + R / 2] = lds2[rd + R * j2];
@@ -545,7 +552,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         // tile.  The barrier sits here, before pass 2, not after it: from here to the |X| barrier a wave depends on nobody, so a wave
         // that is done with pass 2 goes straight into its (LDS-bound) transposes while the other waves of its SIMD are still in their
         // (VALU-bound) butterflies -- with the barrier after pass 2 all sixteen waves entered the LDS phase together.
-        __syncthreads();
+        ldsBarrier();
         SGZ_CLK(2);
         // ---------------------------------------------------------------------- pass 2 (t2 = ix)
         if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
@@ -586,10 +593,10 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             float *dst = reinterpret_cast<float *>(prm.zOut + size_t(task) * N);
 #pragma unroll
             for (int plane = 0; plane < 2; ++plane) {
-                __syncthreads();                                       // exchange-2 tiles / the previous plane are dead
+                ldsBarrier();                                       // exchange-2 tiles / the previous plane are dead
 #pragma unroll
                 for (int m3 = 0; m3 < R; ++m3) lds[bz + m3 * PADSTRIDE] = plane ? c[brev(m3, LR)].y : c[brev(m3, LR)].x;
-                __syncthreads();
+                ldsBarrier();
 #pragma unroll 8
                 for (int k = tid; k < N; k += T) dst[plane * N + k] = lds[k + (k >> LR)];
             }
@@ -658,7 +665,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         if (doMap) mapper.prefetchTables(wholeView(prm, task), tid);   // im[] is dead: its registers take the map tables
         // csf[N/2-1] *= 0.5 (quirk Q3, :864); of a 2N-point frame that bin is the odd half's j = N/2 - 1
         if (HALF != 0 && split && q == R - 1 && ix == R - 1) mag[brev(R / 2 - 1, LR)] *= 0.5f;
-        __syncthreads();                                               // exchange-2 tiles are dead: M may overwrite them
+        ldsBarrier();                                               // exchange-2 tiles are dead: M may overwrite them
                                                                        // (measured: moving this barrier up behind the tile reads, as was
                                                                        // done for exchange 1, costs 7 % on a tail-free launch)
 #pragma unroll
@@ -694,13 +701,13 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             }
         }
         if (doMap) mapper.prefetchWeights(prm);
-        __syncthreads();
+        ldsBarrier();
     } else {
         // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM
         const float *src = prm.binsIn + size_t(task) * (N + 1);
         if (doMap) { mapper.prefetchTables(wholeView(prm, task), tid); mapper.prefetchWeights(prm); }
         for (int k = tid; k <= N; k += T) lds[k + (k >> LR)] = src[k];
-        __syncthreads();
+        ldsBarrier();
     }
     SGZ_CLK(7);
 

@@ -111,7 +111,8 @@ class TimeChunkRenderer:
         self.halo_out = halos[rank - 1] if rank > 0 else 0           # samples rank - 1 wants from this rank's head
         self.halo_max = max(halos) if halos else 0
         # local buffer = own chunk followed by the next rank's leading samples
-        self.buf = torch.zeros((self.nch, S + max(self.halo_max, 1)), dtype=torch.float32, device=dev)
+        # (row stride a multiple of 64 samples: the channel-split K_A fetches sample pairs and needs 8-byte aligned rows)
+        self.buf = torch.zeros((self.nch, (S + max(self.halo_max, 1) + 63) // 64 * 64), dtype=torch.float32, device=dev)
         self.buf[:, :S] = chunk_audio
         self.S, self.W = S, W
         self.local_frames = self.sp.local_frames

@@ -313,7 +313,7 @@ def test_cfg5_defining_shape_against_the_oracle(gpu, oracle):
     S = int(7.5 * 96000)
     x = synth.gen(5, 96000, S, 64)
     plan = api.Plan(cfg).upload()
-    assert plan.N == 65536 and plan.C == 32 and plan.path == 2 | 4 and plan.num_frames(S) == 40
+    assert plan.N == 65536 and plan.C == 32 and (plan.path & 7) == 2 | 4 and plan.num_frames(S) == 40
     problems, stats = check_render(oracle, plan, cfg, x, gpu, want_lines=True)
     assert not problems, (problems[:5], stats)
     assert stats["max_byte_diff"] <= 1 and stats["frac"] <= 5e-3, stats        # raw bytes against the oracle's own render
@@ -329,7 +329,7 @@ def test_full_size_cfg5_properties(gpu):
     S = 10 * 96000
     x = _planar_cuda(synth.gen(5, 96000, S, 16), gpu)
     plan = api.Plan(cfg).upload()
-    assert plan.path == 2 | 4
+    assert (plan.path & 7) == 2 | 4
     F = plan.num_frames(S)
     assert F == 55
     lines = torch.empty((F, 8, 2, plan.P, 2), dtype=torch.float32, device=gpu)
@@ -380,3 +380,36 @@ def test_degenerate_inputs(gpu):
 def test_unsupported_and_errors(gpu):
     with pytest.raises(api.SgzError):
         api.Plan(config.spectrum_config(axis_points=1))
+
+
+@pytest.mark.parametrize("N,pairs,frames", [(32768, 1, 5), (32768, 3, 4), (65536, 2, 3)])
+def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, pairs, frames):
+    """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 65536, forced here at N = 32768
+    too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including
+    csf[0], csf[N], csf[N/2 - 1] (quirk Q3) and csf[N/2], the one entry that needs both channels and is settled by whichever
+    workgroup finishes second -- and identical pixels given identical bins."""
+    from parity_chain import check_render
+    sr = 48000.0 if N == 32768 else 96000.0          # (the 10 Hz view start must keep the Lanczos taps above bin 0: eligibility)
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs)
+    S = N + (frames - 1) * (N // 4)
+    x = synth.gen(23, int(sr), S, 2 * pairs)
+    monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "1")
+    split = api.Plan(cfg).upload()
+    monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "0")
+    whole = api.Plan(cfg).upload()
+    assert split.path & 8 and not whole.path & 8
+    xg = _planar_cuda(x, gpu)
+    a, b = split.stage_bins(xg).cpu().numpy(), whole.stage_bins(xg).cpu().numpy()
+    assert np.abs(a - b).max() <= BIN_TOL * np.abs(b).max()
+    for k in (0, N, N // 2, N // 2 - 1):
+        assert np.abs(a[..., k] - b[..., k]).max() <= BIN_TOL * np.abs(b).max(), k
+    problems, stats = check_render(oracle, split, cfg, x, gpu, want_lines=True)
+    assert not problems, (problems[:5], stats)
+    # digital silence on both channels of a pair: every arg-max run takes the literal-scan fallback (all squares zero), nothing but zeros
+    # may come out, and the other pairs are untouched
+    x[0] = 0; x[1] = 0
+    m = split.stage_mapped(_planar_cuda(x, gpu)).cpu().numpy()
+    assert not m[:, 0].any() and np.isfinite(m).all()
+    if pairs > 1:
+        problems, stats = check_render(oracle, split, cfg, x, gpu)
+        assert not problems, (problems[:5], stats)

@@ -1,6 +1,6 @@
 """K_A timing loop for kernel work: average launch duration (HIP events on the launch stream) of sgz_stage_mapped at
 cfg2 (348 frames, 2 rounds on 256 CUs) and at a tail-free size (8 pairs x 348 = 2784 tasks), plus the whole step.
-usage: ka_time.py [iters]"""
+usage: [SGZ_CHANNEL_SPLIT=0|1] ka_time.py [iters]     (the variable forces / forbids the channel-split kernel where eligible)"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,10 +22,11 @@ def timeit(fn, iters):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     out = {}
-    for name, pairs in (("cfg2_348", 1), ("notail_2784", 8)):
-        cfg = config.cfg2(); cfg["num_pairs"] = pairs
-        S = int(config.CFG2_SECONDS * 48000)
-        x = torch.from_numpy(synth.gen(2, 48000, S, 2 * pairs)).cuda()
+    for name, pairs in (("cfg2_348", 1), ("notail_2784", 8), ("cfg5_20s", 32)):
+        cfg = config.cfg2() if name != "cfg5_20s" else config.cfg5(); cfg["num_pairs"] = pairs
+        sr = int(cfg["sample_rate"])
+        S = int(config.CFG2_SECONDS * 48000) if name != "cfg5_20s" else 20 * sr
+        x = torch.from_numpy(synth.gen(2, sr, S, 2 * pairs)).cuda()
         plan = api.Plan(cfg).upload()
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
@@ -35,7 +36,7 @@ def main():
         full = lambda: plan.render(x, rgba=rgba)
         m, mn = timeit(ka, iters)
         fm, fmn = timeit(full, iters)
-        byts = F * pairs * (2 * 32768 * 4 + 4 * 1024)
+        byts = F * pairs * (2 * cfg['window_size'] * 4 + 4 * 1024)
         out[name] = dict(ka_us=round(m, 2), ka_min_us=round(mn, 2), frac=round(byts / (m * 1e-6) / 8e12, 4), step_us=round(fm, 2),
                          per_task_ns=round(m * 1e3 / (F * pairs), 1))
     print(out)
