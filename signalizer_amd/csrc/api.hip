@@ -35,7 +35,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_ny, d_nyFlag, d_nyBest};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyFlag, d_nyBest};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -69,6 +69,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.twReal1, &p.d_twReal1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twRealPost, &p.d_twRealPost)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhase, &p.d_winPhase)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.winPhaseT, &p.d_winPhaseT)) != SGZ_OK) return st;
     if ((st = uploadVec(p.dcPixels, &p.d_dcPixels)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
@@ -112,6 +113,7 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.hop = p.cfg.hop; prm.W = p.W; prm.P = p.P; prm.C = p.C;
     prm.sides = uint32_t(p.sides); prm.mode = p.cfg.channel_mode;
     prm.window = p.d_window;
+    prm.winPhase = reinterpret_cast<const float2 *>(p.d_winPhaseT); prm.winP0 = p.winP0; prm.winP1 = p.winP1;
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.tw1odd = reinterpret_cast<const float2 *>(p.d_tw1odd);

@@ -14,6 +14,9 @@ struct StftParams {
     uint32_t hop, W, P, C;
     uint32_t sides, mode;
     const float *window;      // [N]
+    // fused kernel, W == N, Hann / Hamming periodic: w[t + T j] = p0 + p1 cos(phi_t + 2 pi j / R) is evaluated from winPhase[t] = (cos, sin)
+    // of phi_t = 2 pi t / N instead of fetched -- the window is a third of the kernel's L2 -> L1 traffic.  Null: fetch it.
+    const float2 *winPhase; float winP0, winP1;
     const float2 *tw1;        // [R][T]
     const float2 *tw2;        // [R][R]
     const float2 *tw1odd;     // halves path (N = 2 R^3): pass-1 twiddles of the odd half, W_N^{t (2q+1)} factorised

@@ -575,6 +575,22 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             for (long o = rec.a; o < long(rec.a) + rec.b; ++o) p.sideMapOk = p.sideMapOk && inside(right ? N - o : o);
         }
     }
+    // the window evaluated inside the kernels (Hann / Hamming, periodic, W == N): w[n] = a0 - a1 cos(2 pi n / N)
+    const bool cosWindow = (cfg.window_type == SGZ_WIN_HANN || cfg.window_type == SGZ_WIN_HAMMING) && cfg.window_symmetry == SGZ_WIN_PERIODIC &&
+                           p.W == p.N && !std::getenv("SGZ_FETCH_WINDOW");
+    if (cosWindow) {
+        p.winP0 = cfg.window_type == SGZ_WIN_HANN ? 0.5f : 0.54f;
+        p.winP1 = cfg.window_type == SGZ_WIN_HANN ? -0.5f : -0.46f;
+    }
+    if (cosWindow && p.fused) {
+        const uint32_t T = p.N == 32768 ? 1024u : 256u;
+        p.winPhaseT.resize(size_t(T) * 2);
+        for (uint32_t t = 0; t < T; ++t) {
+            const double ang = 6.28318530717958647692 * double(t) / double(p.N);
+            p.winPhaseT[size_t(t) * 2 + 0] = float(std::cos(ang));
+            p.winPhaseT[size_t(t) * 2 + 1] = float(std::sin(ang));
+        }
+    }
     // channel-split path (spectrum_real.hip): eligibility and tables
     p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
                   p.dcPixels.empty() && !p.items.empty();
@@ -629,10 +645,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                 p.twReal1[(size_t(row) * 1024 + c) * 2 + 0] = float(std::cos(ang));
                 p.twReal1[(size_t(row) * 1024 + c) * 2 + 1] = float(std::sin(ang));
             }
-        if ((cfg.window_type == SGZ_WIN_HANN || cfg.window_type == SGZ_WIN_HAMMING) && cfg.window_symmetry == SGZ_WIN_PERIODIC) {
-            // w[n] = a0 - a1 cos(2 pi n / W) (designWindow): evaluated in the kernel from these phases
-            p.winP0 = cfg.window_type == SGZ_WIN_HANN ? 0.5f : 0.54f;
-            p.winP1 = cfg.window_type == SGZ_WIN_HANN ? -0.5f : -0.46f;
+        if (cosWindow) {
             p.winPhase.resize(1024 * 4);
             for (uint32_t c = 0; c < 1024; ++c)
                 for (int e = 0; e < 2; ++e) {

@@ -76,6 +76,7 @@ struct Plan {
     bool realSplit = false;
     std::vector<float> twReal1;         // pass-1 twiddles W_{N/2}^{c q}, factorised rows [3 + R1/4 - 1][1024] (re, im)
     uint32_t realFixFrom[2] = {0, 0};   // per side: first pixel whose arg-max run ends on csf[N/2] (the one cross-channel entry); [from, P) are settled late
+    std::vector<float> winPhaseT;       // fused whole-frame kernel, same idea: (cos, sin) of 2 pi t / N, t < R^2
     std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
     std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
     DeviceScalars scalars{};
@@ -96,7 +97,7 @@ struct Plan {
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
-    float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr;
+    float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr, *d_winPhaseT = nullptr;
     float *d_ny = nullptr; uint32_t *d_nyFlag = nullptr; float *d_nyBest = nullptr; size_t nyCap = 0; uint32_t nyEpoch = 0;   // channel-split path: Nyquist exchange of a frame's two workgroups
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;

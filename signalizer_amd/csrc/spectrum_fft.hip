@@ -29,12 +29,12 @@
 
 namespace sgz {
 
-template <int LR, int MIX, bool FULLW>
+template <int LR, int MIX, bool FULLW, bool WCOS = false>
 __global__ void __launch_bounds__(1 << (2 * LR), LR == 4 ? 4 : 1)      // R = 16: four 256-thread workgroups per CU (<= 128 VGPRs)
 stftMapKernel(const StftParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stftMapBody<LR, MIX, FULLW>(prm, lds, blockIdx.x, gridDim.x);
+    stftMapBody<LR, MIX, FULLW, -1, false, WCOS>(prm, lds, blockIdx.x, gridDim.x);
 }
 
 // load + window + three passes only: Z -> prm.zOut (Phase mode at N = R^3)
@@ -205,10 +205,12 @@ static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream
     const int mix = prm.mode == SGZ_CH_SEPARATE ? 0 : (prm.mode == SGZ_CH_COMPLEX ? 2 : 1);
     const bool fullw = prm.W == uint32_t(N);
     using Kern = void (*)(const StftParams);
-    static const Kern kerns[6] = {&stftMapKernel<LR, 0, false>, &stftMapKernel<LR, 0, true>, &stftMapKernel<LR, 1, false>,
-                                  &stftMapKernel<LR, 1, true>,  &stftMapKernel<LR, 2, false>, &stftMapKernel<LR, 2, true>};
-    const int which = 2 * mix + (fullw ? 1 : 0);
-    static LdsGrant grant[6];
+    // (the last three: full window evaluated in the kernel -- Hann / Hamming periodic, Plan::winPhaseT)
+    static const Kern kerns[9] = {&stftMapKernel<LR, 0, false>, &stftMapKernel<LR, 0, true>, &stftMapKernel<LR, 1, false>,
+                                  &stftMapKernel<LR, 1, true>,  &stftMapKernel<LR, 2, false>, &stftMapKernel<LR, 2, true>,
+                                  &stftMapKernel<LR, 0, true, true>, &stftMapKernel<LR, 1, true, true>, &stftMapKernel<LR, 2, true, true>};
+    const int which = (fullw && prm.winPhase) ? 6 + mix : 2 * mix + (fullw ? 1 : 0);
+    static LdsGrant grant[9];
     if (hipError_t e = grant[which].ensure(reinterpret_cast<const void *>(kerns[which]), ldsBytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(kerns[which], dim3(grid), dim3(T), ldsBytes, stream, p2);
     return hipGetLastError();

@@ -366,7 +366,7 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
 // magnitudes go to HBM (csf of the 2N-point frame, element 2j + HALF); spectrum_generic.hip's genericMap maps them.
 // ZOUT: stop after pass 3 and write the raw transform Z to prm.zOut as two natural-order arrays, re[N] then im[N] (Phase mode:
 // its bins stay complex and its split / map are HBM-resident kernels).
-template <int LR, int MIX, bool FULLW, int HALF = -1, bool ZOUT = false>
+template <int LR, int MIX, bool FULLW, int HALF = -1, bool ZOUT = false, bool WCOS = false>
 __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, const long bid, const long nb)
 {
     constexpr int R = 1 << LR;
@@ -426,7 +426,23 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
             const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
             // raw samples land in scalar registers; the (re, im) pairs are formed by the window multiply
             float lv[R], rv[R], w[R];
-            if (FULLW) {
+            if (WCOS) {                                            // (FULLW, whole frame: spectrum_fft.hip instantiates it that way)
+                const float *Rp = L + prm.chStride;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const uint32_t off = uint32_t(tid + j * T) * 4u;
+                    lv[j] = ldg(L, off);
+                    rv[j] = ldg(Rp, off);
+                }
+                const float2 ph = ldg(prm.winPhase, uint32_t(tid) * 8u);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {                          // cos(phi + 2 pi j / R) by the compile-time rotation
+                    constexpr int S32 = 32 / R;
+                    const int a = (j * S32) % 32;
+                    const float cj = a <= 16 ? cos32(a) : cos32(32 - a), sj = a <= 16 ? sin32(a) : -sin32(32 - a);
+                    w[j] = prm.winP0 + prm.winP1 * (ph.x * cj - ph.y * sj);
+                }
+            } else if (FULLW) {
                 const float *Rp = L + prm.chStride;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
