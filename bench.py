@@ -129,6 +129,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the contract line (tail-free launch, step with state "
+                                                              "outputs): tools/profile.sh, so that the profiled dispatches are the workload's only")
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 (default): BASELINE.json's metric; with N GPUs every rank renders its own 60 s (weak scaling).  cfg5: the "
                          "64-channel 65536-pt job of BASELINE configs[4] -- ONE 60 s x 32-pair job split over the N ranks by time "
@@ -215,7 +217,7 @@ def main() -> None:
     single_shot_ms = float(np.median(shots))
     coll_ms = timer.time_collectives(iters=20) if world > 1 else 0.0
     extra = {}
-    if world == 1 and not strong:
+    if world == 1 and not strong and not args.no_extras:
         # (i) the same kernel on a tail-free launch: 8 stereo pairs of the same buffer = 2784 workgroups on 256 CUs, so that the
         #     2-rounds-for-1.36-rounds-of-work tail of the 348-frame headline and the kernel's own efficiency can be told apart
         cfg8 = dict(cfg, num_pairs=8)

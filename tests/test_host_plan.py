@@ -80,7 +80,7 @@ def test_path_selection():
     P = lambda **kw: api.Plan(config.spectrum_config(**kw)).path
     assert P(window_size=4096, hop=1024) == 1 and P(window_size=32768, hop=8192) == 1
     assert P(window_size=3000, hop=750) == 1                                  # zero-padded to 4096
-    assert P(window_size=65536, hop=16384, sample_rate=96000.0) == 2 | 4        # cfg5: halves + per-side LDS map
+    assert P(window_size=65536, hop=16384, sample_rate=96000.0) == 2 | 4 | 8    # cfg5: channel-split workgroups (halves + per-side LDS map behind them)
     assert P(window_size=8192, hop=2048, channel_mode=config.CH_MERGE) == 2 | 4
     assert P(window_size=8192, hop=2048, channel_mode=config.CH_COMPLEX) == 2   # whole-spectrum view: generic map kernel
     assert P(window_size=16384, hop=4096) == 0 | 4 and P(window_size=20, hop=7, axis_points=16) == 0 | 4

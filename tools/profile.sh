@@ -8,7 +8,7 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-extras $*"
 cd /tmp
 rocprofv3 -f csv --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 rocprofv3 -f csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o fetch -- python "$ROOT/bench.py" $ARGS > "$OUT/bench_fetch.log" 2>&1
