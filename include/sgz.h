@@ -174,6 +174,21 @@ sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t f
 sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,
                                   uint8_t *d_rgba, float *d_lines, float *d_state, void *stream);
 
+/* Frequency tracker, the raw-FFT branch of Spectrum::drawFrequencyTracking (Source/Spectrum/SpectrumRendering.cpp:379-469; SURVEY 8(f)
+ * #4): nearest peak of the raw transform around the mouse position (fraction of the frequency axis, :267 / :292), walk along a rising
+ * edge at the range boundary, parabolic fit in the dB domain.  peak_dbs is the value before the slope correction (:453: the caller
+ * adds 20 log10(slopeMap[x])).  d_bins: DEVICE csf magnitudes [N + 1] of one (frame, pair) as sgz_stage_bins writes them.
+ * Magnitude modes except Complex (:301).  The call waits for its result. */
+typedef struct sgz_peak {
+    double peak_offset;          /* bin of the peak                         */
+    double peak_fraction;        /* 2 (bin + phi) / N                       */
+    double peak_frequency;       /* Hz                                      */
+    double peak_dbs;
+    double alpha, beta, gamma;   /* 20 log10 of the three bins around it    */
+    double phi;                  /* fractional bin offset of the parabola   */
+} sgz_peak;
+sgz_status sgz_stage_track_peak(sgz_plan *plan, const float *d_bins, double mouse_fraction, sgz_peak *out, void *stream);
+
 /* K_B in two steps, for the multi-GPU carry exchange (collective A2).  scan: the chunk scans of `frames` frames from a
  * ZERO carry-in; writes that zero-carry end state (what a rank publishes) to d_end_state [pairs][graphs][P][2] and keeps the chunk
  * aggregates inside the plan.  emit: folds the true carry-in d_carry (NULL = zero) into the kept aggregates -- one pass over the
@@ -240,6 +255,9 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                           
 sgz_status sgz_spectrum_set_mix(sgz_spectrum *s, uint32_t num_sources, const uint8_t *matrix /*[2*num_pairs][num_sources]*/);
 /* columns dropped because the queue was full (SpectrumDSP.cpp:185-186) and pushes refused with SGZ_BUSY, since create */
 sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes);
+/* the frequency tracker on the newest window of pair `pair` (consumer thread): transforms the device ring's current window and runs
+ * sgz_stage_track_peak's search on it */
+sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_fraction, sgz_peak *out);
 /* parity hook: the W newest samples of destination channel `channel`, exactly the range of the device ring a frame firing now
  * would transform (call it from the producer's thread, or with the producer idle) */
 sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out /*W*/);

@@ -114,6 +114,7 @@ def lib() -> C.CDLL:
         L.sgzo_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_spectrogram_range.restype = C.c_long
         L.sgzo_spectrogram_range.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, C.c_long, C.c_long, vp]
+        L.sgzo_track_peak.argtypes = [C.POINTER(SpectrumParams), vp, C.c_uint32, vp, C.c_double, C.c_double, vp]
         L.sgzo_decay_colour.restype = C.c_long
         L.sgzo_decay_colour.argtypes = [C.POINTER(SpectrumParams), vp, C.c_long, vp, vp]
         L.sgzo_logf_array.argtypes = [vp, vp, C.c_size_t]
@@ -448,3 +449,13 @@ def vector_polar_view(mem_l: np.ndarray, mem_r: np.ndarray, cursor: int, lanes: 
     rgb = np.zeros((L.size, 3), np.float32)
     lib().sgzo_vector_polar_view(_ptr(L), _ptr(R), L.size, cursor, lanes, int(fade_history), _ptr(col), _ptr(xyz), _ptr(rgb))
     return xyz, rgb
+
+
+def track_peak(p: SpectrumParams, source: np.ndarray, scale: float, mouse_fraction: float) -> dict:
+    """raw-FFT frequency tracker on csf (complex64 [N+1], as mapToLinearSpace left it)"""
+    src = np.ascontiguousarray(source, np.complex64)
+    mapped = remap_frequencies(p)
+    out = np.zeros(8, np.float64)
+    lib().sgzo_track_peak(C.byref(p), _ptr(src), src.size - 1, _ptr(mapped), scale, mouse_fraction, _ptr(out))
+    keys = ("peak_offset", "peak_fraction", "peak_frequency", "peak_dbs", "alpha", "beta", "gamma", "phi")
+    return dict(zip(keys, out.tolist()))

@@ -609,3 +609,60 @@ void sgzo_logf_array(const float *x, float *y, size_t n)
 {
     for (size_t i = 0; i < n; ++i) y[i] = logf(x[i]);
 }
+
+/* Frequency tracker, the raw-FFT branch of Spectrum::drawFrequencyTracking (Source/Spectrum/SpectrumRendering.cpp:379-469; SURVEY 8(f)
+ * #4): nearest peak of |source|^2 around the mouse position (first maximum, then the walk along a still rising edge at a boundary of
+ * the search range), parabolic fit through the three dB values around it (the log-domain fit of JOS's PARSHL notes, :426-444).
+ * source: the transform's working memory after mapToLinearSpace (csf, N + 1 entries); mapped: mappedFrequencies[P].
+ * out: {peakOffset, peakFraction, peakFrequency, peakDBs (before the slope correction), alpha, beta, gamma, phi}. */
+void sgzo_track_peak(const sgzo_spectrum_params *p, const sgzo_cf *source, uint32_t Nt, const float *mapped, double window_scale,
+                     double mouse_fraction, double out[8])
+{
+    const double nearbyFractionToConsider = 0.03;
+    const double sampleRate = (double)p->sample_rate;
+    const size_t N = Nt;
+    const int points = (int)p->axis_points;                                            /* getNumFilters() */
+    long lowerBound = (long)llround((double)points * (mouse_fraction - nearbyFractionToConsider));
+    long c = lowerBound < 0 ? 0 : (lowerBound > points - 1 ? points - 1 : lowerBound);
+    lowerBound = (long)llround((double)((float)N * mapped[c]) / sampleRate);           /* N * mapFrequency(..): size_t * float */
+    long higherBound = (long)llround((double)points * (mouse_fraction + nearbyFractionToConsider));
+    c = higherBound < 0 ? 0 : (higherBound > points - 1 ? points - 1 : higherBound);
+    higherBound = (long)llround((double)((float)N * mapped[c]) / sampleRate);
+    lowerBound = lowerBound < 0 ? 0 : (lowerBound > (long)N ? (long)N : lowerBound);
+    higherBound = higherBound < 0 ? 0 : (higherBound > (long)N ? (long)N : higherBound);
+#define SQ(z) ((z).re * (z).re + (z).im * (z).im)                                      /* cpl::Math::square(complex), UNVERIFIED vs cpl */
+    long peak = lowerBound;                                                            /* std::max_element: the first largest */
+    for (long k = lowerBound + 1; k <= higherBound; ++k)
+        if (SQ(source[peak]) < SQ(source[k])) peak = k;
+    if (peak == lowerBound && lowerBound != 0) {                                       /* :400-413 */
+        for (;;) {
+            const long next = peak - 1;
+            if (next == 0) break;
+            else if (SQ(source[next]) < SQ(source[peak])) break;
+            else peak = next;
+        }
+    } else if (peak == higherBound - 1) {                                              /* :414-427 */
+        for (;;) {
+            const long next = peak + 1;
+            if (next == (long)N) break;                                                /* source.end() */
+            else if (SQ(source[next]) < SQ(source[peak])) break;
+            else peak = next;
+        }
+    }
+#undef SQ
+    const long peakOffset = peak;
+    const float invSize = (float)(window_scale / ((double)p->window_size * 0.5));
+    const long ia = peakOffset == 0 ? 0 : peakOffset - 1, ic = peakOffset == (long)N ? peakOffset : peakOffset + 1;
+#define ABSI(z) hypotf((z).re * invSize, (z).im * invSize)                              /* std::abs(source[k] * invSize) */
+    const float alpha = 20 * log10f(ABSI(source[ia]));
+    const float beta = 20 * log10f(ABSI(source[peakOffset]));
+    const float gamma = 20 * log10f(ABSI(source[ic]));
+#undef ABSI
+    const double phi = 0.5 * (alpha - gamma) / (alpha - 2 * beta + gamma);
+    const double peakFraction = 2 * ((double)peakOffset + (isnormal(phi) ? phi : 0)) / (double)N;
+    const double peakFrequency = 0.5 * peakFraction * sampleRate;
+    double peakDBs = beta - 0.25 * (alpha - gamma) * phi;
+    if (!isnormal(peakDBs)) peakDBs = 20 * log10((double)hypotf(source[peakOffset].re, source[peakOffset].im) / ((double)N * 0.5));
+    out[0] = (double)peakOffset; out[1] = peakFraction; out[2] = peakFrequency; out[3] = peakDBs;
+    out[4] = alpha; out[5] = beta; out[6] = gamma; out[7] = phi;
+}

@@ -64,12 +64,14 @@ struct sgz_spectrum {
     StageRing stage;
     // mirrored rings [2C][2 cap]
     float *d_ring = nullptr;
-    uint32_t cap = 0, head = 0;       // producer-owned write position (mod cap)
+    uint32_t cap = 0;
+    std::atomic<uint32_t> head{0};    // write position (mod cap): written by the producer, read by the tracker on the consumer thread
     uint32_t sinceLast = 0;           // processedSamplesSinceLastFrame
     uint32_t maxFrames = 1;
     uint8_t *d_mix = nullptr;
     uint32_t numSources = 0;
     float *d_mapped = nullptr, *d_state = nullptr, *d_lines = nullptr, *d_linesBatch = nullptr;
+    float *d_trackBins = nullptr; sgz_peak *d_peak = nullptr;     // frequency tracker: csf of the newest window [C][N + 1], its result
     uint8_t *d_colsBatch = nullptr;   // [maxFrames][P][4]
     uint8_t *h_cols = nullptr;        // pinned [kQueueDepth][P][4]
     hipEvent_t colEvents[kQueueDepth] = {};
@@ -83,7 +85,8 @@ static void freeHandle(sgz_spectrum *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->stage.release();
-    for (float *p : {s->d_ring, s->d_mapped, s->d_state, s->d_lines, s->d_linesBatch}) if (p) (void)hipFree(p);
+    for (float *p : {s->d_ring, s->d_mapped, s->d_state, s->d_lines, s->d_linesBatch, s->d_trackBins}) if (p) (void)hipFree(p);
+    if (s->d_peak) (void)hipFree(s->d_peak);
     if (s->d_colsBatch) (void)hipFree(s->d_colsBatch);
     if (s->d_mix) (void)hipFree(s->d_mix);
     if (s->h_cols) (void)hipHostFree(s->h_cols);
@@ -123,7 +126,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     s->plan = pl;
     Plan &p = *pl;
     const size_t nch = size_t(2) * p.C;
-    for (float **q : {&s->d_ring, &s->d_mapped, &s->d_state, &s->d_lines, &s->d_linesBatch}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    for (float **q : {&s->d_ring, &s->d_mapped, &s->d_state, &s->d_lines, &s->d_linesBatch, &s->d_trackBins}) if (*q) { (void)hipFree(*q); *q = nullptr; }
     if (s->d_colsBatch) { (void)hipFree(s->d_colsBatch); s->d_colsBatch = nullptr; }
     if (s->h_cols) { (void)hipHostFree(s->h_cols); s->h_cols = nullptr; }
     // a piece's frames read windows that end inside the piece: the ring must hold W + one piece
@@ -131,7 +134,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     s->maxFrames = kPiece / p.cfg.hop + 1;
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ring), nch * 2 * s->cap * sizeof(float)));
     SGZ_HIP(hipMemsetAsync(s->d_ring, 0, nch * 2 * s->cap * sizeof(float), s->stream));    // history starts as silence
-    s->head = 0;
+    s->head.store(0);
     s->sinceLast = 0;
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mapped), size_t(s->maxFrames) * p.C * p.sides * p.P * sizeof(float)));
@@ -139,6 +142,8 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_lines), stateN * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_linesBatch), size_t(s->maxFrames) * stateN * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsBatch), size_t(s->maxFrames) * p.P * 4));
+    if (p.cfg.channel_mode != SGZ_CH_PHASE) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_trackBins), size_t(p.C) * (size_t(p.N) + 1) * sizeof(float)));
+    if (!s->d_peak) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peak), sizeof(sgz_peak)));
     SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_cols), size_t(kQueueDepth) * p.P * 4, hipHostMallocDefault));
     for (auto &e : s->colEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s->qHead.store(0); s->qTail.store(0);
@@ -225,7 +230,7 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
         const float *d_block = s->stage.stage(ptrs, m, s->stream, &st);
         if (!d_block) return st;
         hipLaunchKernelGGL(ringIngestKernel, dim3((m + 255) / 256, numDst), dim3(256), 0, s->stream, d_block, m, num_channels, s->d_mix,
-                           s->d_ring, s->cap, numDst, s->head);
+                           s->d_ring, s->cap, numDst, s->head.load(std::memory_order_relaxed));
         SGZ_HIP(hipGetLastError());
         if ((st = s->stage.commit(s->stream)) != SGZ_OK) return st;
         // frames that fire inside this piece (TransformDSP.inl:1172-1185): the first after hop - sinceLast samples, then every hop
@@ -234,7 +239,7 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
         if (first <= m && (first > 0 || s->sinceLast >= hop)) frames = (m - first) / hop + 1;
         if (frames) {
             // frame k's window ends `first + k hop` samples into the piece; in the mirrored ring it starts at q + k hop, contiguous
-            const uint32_t end0 = (s->head + first) % s->cap;
+            const uint32_t end0 = (s->head.load(std::memory_order_relaxed) + first) % s->cap;
             const uint32_t q = (end0 + s->cap - (W % s->cap)) % s->cap;
             st = runStft(p, s->d_ring + q, size_t(2) * s->cap, long(frames), s->d_mapped, nullptr, nullptr, s->stream);
             if (st != SGZ_OK) return st;
@@ -253,7 +258,7 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
             }
             s->sinceLast = (m - first) - (frames - 1) * hop;
         } else s->sinceLast += m;
-        s->head = (s->head + m) % s->cap;
+        s->head.store((s->head.load(std::memory_order_relaxed) + m) % s->cap, std::memory_order_release);
         done += m;
     }
     return SGZ_OK;
@@ -294,13 +299,29 @@ sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64
     return SGZ_OK;
 }
 
+sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_fraction, sgz_peak *out)
+{
+    if (!s || !out) return fail(SGZ_EINVAL, "null argument");
+    Plan &p = *s->plan;
+    if (pair >= p.C) return fail(SGZ_EINVAL, "pair out of range");
+    if (!s->d_trackBins) return fail(SGZ_EUNSUPPORTED, "frequency tracker: magnitude modes only");
+    // the window a frame firing now would transform (work already enqueued by push precedes this on the stream)
+    const uint32_t q = (s->head.load(std::memory_order_acquire) + s->cap - (p.W % s->cap)) % s->cap;
+    sgz_status st = runStft(p, s->d_ring + q, size_t(2) * s->cap, 1, nullptr, s->d_trackBins, nullptr, s->stream);
+    if (st != SGZ_OK) return st;
+    if ((st = runTrackPeak(p, s->d_trackBins + size_t(pair) * (size_t(p.N) + 1), mouse_fraction, s->d_peak, s->stream)) != SGZ_OK) return st;
+    SGZ_HIP(hipMemcpyAsync(out, s->d_peak, sizeof(sgz_peak), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    return SGZ_OK;
+}
+
 /* parity hook: the W newest samples of destination channel `channel` as K_A would read them (one contiguous range of the mirrored
  * ring) */
 sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out)
 {
     if (!s || !out || channel >= 2 * s->plan->C) return fail(SGZ_EINVAL, "bad argument");
     const uint32_t W = s->plan->W;
-    const uint32_t q = (s->head + s->cap - (W % s->cap)) % s->cap;
+    const uint32_t q = (s->head.load(std::memory_order_acquire) + s->cap - (W % s->cap)) % s->cap;
     SGZ_HIP(hipMemcpyAsync(out, s->d_ring + size_t(channel) * 2 * s->cap + q, size_t(W) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
     return SGZ_OK;

@@ -30,4 +30,6 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
                           float *d_state, hipStream_t stream);
 sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, const float *d_carry, uint8_t *d_rgba, float *d_lines,
                                  float *d_stateOut, hipStream_t stream);
+// frequency tracker (tracker.hip): peak search + parabolic fit on one (frame, pair)'s csf magnitudes; d_out: DEVICE sgz_peak
+sgz_status runTrackPeak(const Plan &p, const float *d_bins, double mouseFraction, sgz_peak *d_out, hipStream_t stream);
 }  // namespace sgz

@@ -1,0 +1,83 @@
+"""Frequency tracker (SpectrumRendering.cpp:379-469): known answers for the oracle's restatement, and the HIP kernel against it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from signalizer_amd import config, synth
+
+
+def _tone(freq, sr, n, amp=0.5):
+    t = np.arange(n) / sr
+    return np.stack([amp * np.sin(2 * np.pi * freq * t), 0.25 * np.sin(2 * np.pi * 3.3 * freq * t)]).astype(np.float32)
+
+
+def _mouse_fraction_of(freq, cfg):
+    # log view [0, 1]: f = minFreq (top / minFreq)^fraction
+    top = cfg["sample_rate"] / 2
+    return float(np.log(freq / cfg["min_log_freq"]) / np.log(top / cfg["min_log_freq"]))
+
+
+@pytest.mark.parametrize("freq", [440.0, 997.3, 5000.5])
+def test_oracle_tracker_finds_the_tone(oracle, freq):
+    """KA: a Hann-windowed sine between two bins: the parabolic fit in the dB domain lands within a few hundredths of a bin of the
+    true frequency, and the peak level within 0.3 dB of the tone's 20 log10(amp) (the parabola's known bias on a Hann main lobe)"""
+    po = oracle
+    cfg = config.spectrum_config(window_size=8192, hop=2048)
+    p = po.params_from_dict(cfg)
+    x = _tone(freq, 48000, 8192)
+    raw, csf, csp = po.frame_bins(p, x[0], x[1])
+    _, scale = po.window(p.window_type, p.window_symmetry, p.window_size)
+    r = po.track_peak(p, csf, scale, _mouse_fraction_of(freq * 1.01, cfg))
+    assert abs(r["peak_frequency"] - freq) < 0.05 * 48000 / 8192, r
+    assert abs(r["peak_dbs"] - 20 * np.log10(0.5)) < 0.3, r
+    assert r["peak_offset"] == round(freq * 8192 / 48000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,mode", [(4096, config.CH_SEPARATE), (32768, config.CH_SEPARATE), (65536, config.CH_SEPARATE), (3000, config.CH_LEFT),
+                                    (8192, config.CH_MIDSIDE)])
+def test_gpu_tracker_against_the_oracle(gpu, oracle, W, mode):
+    """peak bin (integer work): exact; the fit (log10f of libm vs ocml): 1e-4 dB / 1e-5 of a bin"""
+    import torch
+    from signalizer_amd import api
+    po = oracle
+    cfg = config.spectrum_config(window_size=W, hop=max(2, W // 4 // 2 * 2), channel_mode=mode, sample_rate=96000.0 if W == 65536 else 48000.0)
+    p = po.params_from_dict(cfg)
+    sr = int(cfg["sample_rate"])
+    x = synth.gen(31, sr, W, 2)
+    plan = api.Plan(cfg).upload()
+    bins = plan.stage_bins(torch.from_numpy(x).to(gpu))                       # [1][1][N+1]
+    raw, csf, csp = po.frame_bins(p, x[0], x[1])
+    _, scale = po.window(p.window_type, p.window_symmetry, p.window_size)
+    L = api.lib()
+    for mf in (0.0, 0.07, 0.33, 0.5, 0.61, 0.8, 0.97, 1.0):
+        want = po.track_peak(p, csf, scale, mf)
+        got = api.Peak()
+        api.check(L.sgz_stage_track_peak(plan.h, bins.data_ptr(), mf, C.byref(got), torch.cuda.current_stream().cuda_stream))
+        g = got.asdict()
+        # the two FFTs differ by rounding: a range whose top two bins tie to 1e-7 could pick either; not in this signal
+        assert g["peak_offset"] == want["peak_offset"], (mf, g, want)
+        for k in ("alpha", "beta", "gamma", "peak_dbs"):
+            assert abs(g[k] - want[k]) <= 2e-3, (mf, k, g[k], want[k])             # 20 log10 of magnitudes that agree to 4e-6 of the maximum
+        assert abs(g["peak_fraction"] - want["peak_fraction"]) <= 1e-3 * 2 / plan.N + 1e-9 or abs(g["phi"] - want["phi"]) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_on_the_realtime_handle(gpu, oracle):
+    """sgz_spectrum_track_peak: the newest window of the device ring, transformed on demand"""
+    from signalizer_amd import api
+    cfg = config.spectrum_config(window_size=8192, hop=2048, axis_points=512)
+    c = api.config_from_dict(cfg)
+    h = C.c_void_p()
+    api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)))
+    try:
+        x = _tone(1234.5, 48000, 8192 * 3)
+        ptrs = (C.c_void_p * 2)(x[0].ctypes.data, x[1].ctypes.data)
+        api.check(api.lib().sgz_spectrum_push(h, ptrs, 2, x.shape[1]))
+        got = api.Peak()
+        api.check(api.lib().sgz_spectrum_track_peak(h, 0, _mouse_fraction_of(1250.0, cfg), C.byref(got)))
+        assert abs(got.peak_frequency - 1234.5) < 0.05 * 48000 / 8192
+        assert abs(got.peak_dbs - 20 * np.log10(0.5)) < 0.3
+    finally:
+        api.lib().sgz_spectrum_destroy(h)
