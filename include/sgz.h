@@ -100,6 +100,12 @@ sgz_status  sgz_set_device(int device);
  * :580 generateSlopeMap, :586 regenerateWindowKernel, :226-246 colour ratios).
  * Host-side tables are built on the CPU in fp64 with the reference's expression order and uploaded
  * once; the query functions below expose them for parity tests (they need no GPU).
+ *
+ * Threading: a plan belongs to the device that was current at its first compute call, and owns the
+ * per-launch scratch of its kernels -- like the reference's TransformConstant + TransformPair, which one
+ * audio thread uses at a time.  One host thread / stream per plan at a time; concurrent renders use one plan
+ * each (the tables are small).  The library itself keeps no process-wide device state: the stage calls'
+ * scratch is stream-ordered, the real-time handles own theirs.
  */
 typedef struct sgz_plan sgz_plan;
 sgz_status sgz_plan_create(const sgz_spectrum_config *cfg, sgz_plan **out);   /* host tables only, no GPU needed */

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -91,13 +92,15 @@ sgz_status ensureCap(float **buf, size_t *cap, size_t need)
 
 int numCUs()
 {
-    static int cus = 0;
+    // cached per device: sgz_set_device may move a host thread between devices of different sizes
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool slot = dev >= 0 && dev < 64;
+    int cus = slot ? cache[dev].load(std::memory_order_relaxed) : 0;
     if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (slot) cache[dev].store(cus, std::memory_order_relaxed);
     }
     return cus;
 }

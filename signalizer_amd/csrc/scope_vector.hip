@@ -61,8 +61,9 @@ ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMo
     return s;
 }
 
-__constant__ double kCosPiI10[21];
-__constant__ double kSinPiI10[21];
+// cos / sin(pi * i / 10) as libm rounds them (the values std::cos / std::sin return for the double nearest pi*i/10), i = 0 .. 20
+__constant__ const double kCosPiI10[21] = {1.0, 0.9510565162951535, 0.8090169943749475, 0.5877852522924731, 0.30901699437494745, 6.123233995736766e-17, -0.30901699437494734, -0.587785252292473, -0.8090169943749473, -0.9510565162951535, -1.0, -0.9510565162951538, -0.8090169943749476, -0.5877852522924732, -0.30901699437494756, -1.8369701987210297e-16, 0.30901699437494723, 0.5877852522924729, 0.8090169943749473, 0.9510565162951535, 1.0};
+__constant__ const double kSinPiI10[21] = {0.0, 0.3090169943749474, 0.5877852522924731, 0.8090169943749475, 0.9510565162951535, 1.0, 0.9510565162951536, 0.8090169943749475, 0.5877852522924732, 0.3090169943749475, 1.2246467991473532e-16, -0.3090169943749469, -0.587785252292473, -0.8090169943749473, -0.9510565162951535, -1.0, -0.9510565162951536, -0.8090169943749476, -0.5877852522924734, -0.3090169943749476, -2.4492935982947064e-16};
 
 // one thread per output point.  y = sum_i ring[cursor + i] * L(10 + delta - i), L = Lanczos a = 10, fp64.
 __global__ void __launch_bounds__(256)
@@ -384,33 +385,17 @@ vectorAudioKernel(const float *L, const float *R, size_t n, float envelope, floa
     if (lane < 8) reinterpret_cast<float *>(st)[lane] = y;
 }
 
-float *g_scratch = nullptr;
-size_t g_scratchBytes = 0;
-sgz_status scratch(size_t bytes, void **out)
-{
-    if (g_scratchBytes < bytes) {
-        if (g_scratch) (void)hipFree(g_scratch);
-        g_scratch = nullptr; g_scratchBytes = 0;
-        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&g_scratch), bytes));
-        g_scratchBytes = bytes;
-    }
-    *out = g_scratch;
-    return SGZ_OK;
-}
-
-bool g_constInit = false;
-sgz_status initConst();
-sgz_status initConst()
-{
-    if (g_constInit) return SGZ_OK;
-    double c[21], s[21];
-    const double kPi = 3.14159265358979323846;
-    for (int i = 0; i < 21; ++i) { c[i] = std::cos(kPi * i / 10.0); s[i] = std::sin(kPi * i / 10.0); }
-    SGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kCosPiI10), c, sizeof(c)));
-    SGZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(kSinPiI10), s, sizeof(s)));
-    g_constInit = true;
-    return SGZ_OK;
-}
+// Scratch of the stage calls: stream-ordered allocations (hipMallocAsync / hipFreeAsync on the caller's stream), so the library keeps
+// no process-wide device state -- any number of host threads, streams and devices may use the stage calls at once.
+struct StreamScratch {
+    void *p = nullptr;
+    hipStream_t s;
+    explicit StreamScratch(hipStream_t stream) : s(stream) {}
+    hipError_t get(size_t bytes) { return hipMallocAsync(&p, bytes, s); }
+    ~StreamScratch() { if (p) (void)hipFreeAsync(p, s); }
+    StreamScratch(const StreamScratch &) = delete;
+    StreamScratch &operator=(const StreamScratch &) = delete;
+};
 
 // which branch drawWavePlot takes: Lanczos falls back to Linear below one pixel per sample (:575-578)
 bool waveIsLanczos(const sgz_scope_view &v, uint32_t interpolation)
@@ -435,7 +420,6 @@ hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode,
                                const float *ringB, uint32_t evalMode, uint32_t size, const uint32_t *d_cursor, uint32_t rgba,
                                float *d_xyz, uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
 {
-    if (initConst() != SGZ_OK) return hipErrorUnknown;
     const int block = 256;
     if (waveIsLanczos(view, interpolation)) {
         const ScopeScalars s = scopeDerive(view, size, triggerMode);
@@ -475,8 +459,6 @@ sgz_status sgz_scope_lanczos_device(const sgz_scope_view *view, const float *d_r
 {
     if (!view || !d_ring || !d_xy || len == 0 || view->width < 2 || !(view->right > view->left))
         return fail(SGZ_EINVAL, "bad scope arguments");
-    sgz_status st = initConst();
-    if (st != SGZ_OK) return st;
     const ScopeScalars s = scopeDerive(*view, len);
     const int block = 256;
     const unsigned grid = unsigned((s.points + block - 1) / block);
@@ -494,11 +476,10 @@ sgz_status sgz_scope_zero_crossing_device(sgz_zero_crossing_state *zs, uint32_t 
     if (!zs || !d_a || !d_triggers || !num_triggers) return fail(SGZ_EINVAL, "null argument");
     if (!d_b) d_b = d_a;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    void *scr = nullptr;
-    sgz_status st = scratch(sizeof(ZcResult), &scr);
-    if (st != SGZ_OK) return st;
-    ZcResult *d_res = reinterpret_cast<ZcResult *>(scr);
     if (n == 0) { *num_triggers = 0; return SGZ_OK; }
+    StreamScratch scr(s);
+    SGZ_HIP(scr.get(sizeof(ZcResult)));
+    ZcResult *d_res = reinterpret_cast<ZcResult *>(scr.p);
     hipLaunchKernelGGL(zeroCrossingKernel, dim3(1), dim3(1024), 0, s, osc_mode, d_a, d_b, n, zs->state, zs->threshold,
                        int(zs->armed), (unsigned long long)zs->cross_origin,
                        (unsigned long long)(zs->steady_clock + zs->count), reinterpret_cast<unsigned long long *>(d_triggers),
@@ -520,10 +501,9 @@ sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t cha
 {
     if (!d_ch || !env || !gain || channels == 0 || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    void *scr = nullptr;
-    sgz_status st = scratch(sizeof(float) * channels + 64, &scr);
-    if (st != SGZ_OK) return st;
-    float *d_peaks = reinterpret_cast<float *>(scr);
+    StreamScratch scr(s);
+    SGZ_HIP(scr.get(sizeof(float) * channels + 64));
+    float *d_peaks = reinterpret_cast<float *>(scr.p);
     const size_t stop = n - (n & size_t(lanes - 1));          // SIMD tail dropped, :740 / :860
     hipLaunchKernelGGL(peakKernel, dim3(channels), dim3(1024), 0, s, d_ch, stride, stop, d_peaks);
     SGZ_HIP(hipGetLastError());
@@ -549,21 +529,12 @@ sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_
     if (lanes > 64) return fail(SGZ_EINVAL, "lanes > 64");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long iters = (long(n) > long(lanes)) ? (long(n) - 1) / long(lanes) : 0;      // VectorscopeRendering.cpp:528
-    // the ramp table depends on (n, lanes) only: rebuilt when they change
-    static float *d_ramp = nullptr;
-    static size_t rampCap = 0, rampN = 0;
-    static uint32_t rampLanes = 0;
-    const size_t need = size_t(iters) * lanes + 1;
-    if (rampCap < need) {
-        if (d_ramp) (void)hipFree(d_ramp);
-        d_ramp = nullptr; rampCap = 0; rampN = 0;
-        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&d_ramp), need * sizeof(float)));
-        rampCap = need;
-    }
-    if (rampN != n || rampLanes != lanes) {
-        if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(64), 0, s, n, lanes, iters, d_ramp);
-        rampN = n; rampLanes = lanes;
-    }
+    // the ramp table depends on (n, lanes) only; this stateless stage call rebuilds it in stream order (the sgz_vector_* handle keeps
+    // its own and rebuilds it on configure only)
+    StreamScratch ramp(s);
+    SGZ_HIP(ramp.get((size_t(iters) * lanes + 1) * sizeof(float)));
+    float *d_ramp = reinterpret_cast<float *>(ramp.p);
+    if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(64), 0, s, n, lanes, iters, d_ramp);
     const int block = 256;
     dim3 grid(unsigned((n + block - 1) / block), pairs);
     hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, s, d_planar, stride, pairs, n, lanes, iters, d_ramp,
@@ -578,9 +549,9 @@ sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float
 {
     if (!f || !d_left || !d_right || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    void *scr = nullptr;
-    sgz_status st = scratch(sizeof(VecState), &scr);
-    if (st != SGZ_OK) return st;
+    StreamScratch scratch(s);
+    SGZ_HIP(scratch.get(sizeof(VecState)));
+    void *scr = scratch.p;
     VecState h{};
     h.env[0] = f->env[0]; h.env[1] = f->env[1];
     // lane order of the kernel: env L,R ; slow bal L,R ; fast bal L,R ; slow phase ; fast phase
