@@ -149,6 +149,29 @@ def lib() -> C.CDLL:
         L.sgzo_scope_stream_state.argtypes = [vp, vp]
         L.sgzo_scope_stream_peak_filter.restype = C.c_double
         L.sgzo_scope_stream_peak_filter.argtypes = [vp, C.c_uint32, C.c_double]
+        L.sgzo_scope_stream_enable_colours.restype = None
+        L.sgzo_scope_stream_enable_colours.argtypes = [vp, vp, C.c_double, C.c_double, vp]
+        L.sgzo_scope_stream_front_colours.restype = C.c_size_t
+        L.sgzo_scope_stream_front_colours.argtypes = [vp, C.c_uint32, C.c_int, vp]
+        L.sgzo_scope_wave_plot_ex.restype = C.c_size_t
+        L.sgzo_scope_wave_plot_ex.argtypes = [C.POINTER(ScopeView), C.c_int, C.c_int, vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double,
+                                              C.c_double, vp, vp, vp, C.c_size_t]
+        L.sgzo_nth_element_by_index.restype = None
+        L.sgzo_nth_element_by_index.argtypes = [vp, C.c_int, C.c_int]
+        L.sgzo_scope_fundamental.restype = None
+        L.sgzo_scope_fundamental.argtypes = [C.POINTER(SpectralState), vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                             C.c_double, C.c_double]
+        L.sgzo_scope_trigger_offset.restype = None
+        L.sgzo_scope_trigger_offset.argtypes = [C.POINTER(SpectralState), vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                                C.c_double]
+        L.sgzo_lr_design.restype = None
+        L.sgzo_lr_design.argtypes = [C.c_double, C.c_double, C.c_double, vp]
+        L.sgzo_lr_process.restype = None
+        L.sgzo_lr_process.argtypes = [vp, vp, C.c_float, vp]
+        L.sgzo_colour_smooth_pole.restype = C.c_float
+        L.sgzo_colour_smooth_pole.argtypes = [C.c_double, C.c_double]
+        L.sgzo_colour_accumulate.restype = None
+        L.sgzo_colour_accumulate.argtypes = [vp, vp, vp, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -368,7 +391,7 @@ def vector_audio_processing(f: VectorFilters, L, R, envelope_coeff, stereo_coeff
     return gain.value
 
 
-TRIG_NONE, TRIG_ZERO_CROSSING = 0, 4
+TRIG_NONE, TRIG_SPECTRAL, TRIG_ZERO_CROSSING = 0, 1, 4
 ENV_NONE, ENV_RMS, ENV_PEAK_DECAY = 0, 1, 2
 OSC_LEFT, OSC_RIGHT, OSC_MID, OSC_SIDE, OSC_SEPARATE, OSC_MIDSIDE = range(6)
 
@@ -426,6 +449,25 @@ class ScopeStream:
     def peak_filter(self, lanes: int, coeff: float) -> float:
         return lib().sgzo_scope_stream_peak_filter(self.h, lanes, coeff)
 
+    def enable_colours(self, band_colours, blend: float, smoothing_ms: float, keys):
+        """band_colours [3][3] float r,g,b of low / mid / high; keys [channels][4] RGBA8 (defaultKey per channel)"""
+        bc = np.ascontiguousarray(band_colours, np.float32).reshape(3, 3)
+        k = np.ascontiguousarray(keys, np.uint8).reshape(self.channels, 4)
+        lib().sgzo_scope_stream_enable_colours(self.h, _ptr(bc), float(blend), float(smoothing_ms), _ptr(k))
+
+    def front_colours(self, c: int, aux: bool = False):
+        """(raw colour ring memory [size] as RGBA8 words, cursor)"""
+        out = np.zeros(self.size, np.uint32)
+        cur = lib().sgzo_scope_stream_front_colours(self.h, c, int(aux), _ptr(out))
+        return out, int(cur)
+
+    def logical(self, c: int, size: int, colours=None) -> np.ndarray:
+        """the reference's Spectral-mode ring of the moment: the newest `size` samples, oldest first (a ring whose cursor is 0).
+        colours: None -> audio; False / True -> colourData / auxColourData"""
+        m, cur = self.front(c) if colours is None else self.front_colours(c, colours)
+        t = np.concatenate([m[cur:], m[:cur]])
+        return np.ascontiguousarray(t[len(t) - size:])
+
 
 def scope_wave_plot(view: ScopeView, trigger_mode: int, interpolation: int, mem_a: np.ndarray, mem_b: np.ndarray, eval_mode: int,
                     cursor: int, max_points: int = 1 << 22) -> np.ndarray:
@@ -436,6 +478,60 @@ def scope_wave_plot(view: ScopeView, trigger_mode: int, interpolation: int, mem_
     out = np.zeros((n, 3), np.float32)
     m = lib().sgzo_scope_wave_plot(C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, _ptr(out), n)
     assert m == n
+    return out
+
+
+def scope_wave_plot_ex(view: ScopeView, trigger_mode: int, interpolation: int, mem_a, mem_b, eval_mode: int, cursor: int,
+                       cycle_samples: float = 0.0, sample_offset: float = 0.0, colour_mem=None):
+    """drawWavePlot incl. Spectral triggering and per-vertex colours -> (vertices [n][3], rgba [n][4] or None)"""
+    a = np.ascontiguousarray(mem_a, np.float32)
+    b = np.ascontiguousarray(mem_b, np.float32)
+    cm = None if colour_mem is None else np.ascontiguousarray(colour_mem, np.uint32)
+    args = (C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, cycle_samples, sample_offset,
+            None if cm is None else _ptr(cm))
+    n = lib().sgzo_scope_wave_plot_ex(*args, None, None, 0)
+    out = np.zeros((n, 3), np.float32)
+    rgba = None if cm is None else np.zeros(n, np.uint32)
+    m = lib().sgzo_scope_wave_plot_ex(*args, _ptr(out), None if rgba is None else _ptr(rgba), n)
+    assert m == n
+    return out, (None if rgba is None else rgba.view(np.uint8).reshape(n, 4))
+
+
+class BinRecord(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("value", C.c_double), ("offset", C.c_double)]
+
+
+class SpectralState(C.Structure):
+    """triggerState + medianTriggerFilter / medianPos (Oscilloscope.h:176-196, :324-325)"""
+    _fields_ = [("median", BinRecord * 8), ("median_pos", C.c_uint64), ("record", BinRecord), ("fundamental", C.c_double),
+                ("cycle_samples", C.c_double), ("sample_offset", C.c_double), ("phase", C.c_double)]
+
+
+def scope_analyse(ts: SpectralState, mem_a, mem_b, eval_mode: int, cursor: int, window_size: float, sample_rate: float,
+                  threshold: float, hysteresis: float, phase_offset_degrees: float):
+    """calculateFundamentalPeriod + calculateTriggeringOffset (Spectral) on a ring; updates ts"""
+    a = np.ascontiguousarray(mem_a, np.float32)
+    b = np.ascontiguousarray(mem_b, np.float32)
+    lib().sgzo_scope_fundamental(C.byref(ts), _ptr(a), _ptr(b), eval_mode, a.size, cursor, window_size, sample_rate, threshold, hysteresis)
+    lib().sgzo_scope_trigger_offset(C.byref(ts), _ptr(a), _ptr(b), eval_mode, a.size, cursor, window_size, sample_rate, phase_offset_degrees)
+    return ts
+
+
+def nth_element_by_index(records: np.ndarray, nth: int) -> np.ndarray:
+    """records: structured [(index u8, value f8, offset f8)]; returns the array as std::nth_element leaves it"""
+    r = np.ascontiguousarray(records).copy()
+    lib().sgzo_nth_element_by_index(_ptr(r), r.shape[0], nth)
+    return r
+
+
+def lr_bands(x: np.ndarray, sample_rate: float, low=300.0, high=3000.0) -> np.ndarray:
+    """the 3-band Linkwitz-Riley split of a signal -> [n][3]"""
+    co = np.zeros(20, np.float32)
+    st = np.zeros(16, np.float32)
+    lib().sgzo_lr_design(low, high, sample_rate, _ptr(co))
+    out = np.zeros((x.size, 3), np.float32)
+    for i, v in enumerate(np.asarray(x, np.float32)):
+        lib().sgzo_lr_process(_ptr(st), _ptr(co), float(v), _ptr(out[i]))
     return out
 
 

@@ -9,7 +9,9 @@
  *   Source/Oscilloscope/OscilloscopeDSP.inl:427-710      StreamState::audioProcessing: RMS envelope (:520-585, :676-693), ring write (:696-697)
  *   Source/Oscilloscope/OscilloscopeDSP.inl:713-886      Oscilloscope::runPeakFilter, every OscChannels mode
  *   Source/Oscilloscope/OscilloscopeParameters.h:491-507 calculateTriggerIndices
- * The per-sample colours of audioProcessing (:487-674, LR4 crossover -> band energies -> RGB) are a separate row.
+ * The per-sample colours of audioProcessing (:445-517, :588-647: LR4 crossover -> band energies -> RGB) run through scope_spectral.c's
+ * restatement of the cpl filters when sgzo_scope_stream_enable_colours was called; they live in rings parallel to the audio rings
+ * (Channel::colourData / auxColourData, ChannelData.h:58-66) and are swapped with them (ChannelData.h:155-159).
  *
  * cpl::CLIFOStream<float> is restated as a ring of `size` elements with a write cursor (UNVERIFIED vs cpl, which is absent):
  *   createWriter().copyIntoHead(src, n)                      appends n samples at the cursor, wrapping at `size`;
@@ -23,7 +25,7 @@
 #include <string.h>
 
 enum { OSC_LEFT = 0, OSC_RIGHT = 1, OSC_MID = 2, OSC_SIDE = 3, OSC_SEPARATE = 4, OSC_MIDSIDE = 5 };
-enum { TRIG_NONE = 0, TRIG_ZERO_CROSSING = 4 };            /* OscilloscopeContent::TriggeringMode, OscilloscopeParameters.h:50-58 */
+enum { TRIG_NONE = 0, TRIG_SPECTRAL = 1, TRIG_ZERO_CROSSING = 4 };            /* OscilloscopeContent::TriggeringMode, OscilloscopeParameters.h:50-58 */
 enum { ENV_NONE = 0, ENV_RMS = 1, ENV_PEAK_DECAY = 2 };    /* EnvelopeModes, CommonSignalizer.h */
 
 typedef struct { float *buf; size_t size, cursor; } ring_t;
@@ -34,6 +36,28 @@ static void ring_write(ring_t *r, const float *src, size_t n)
     for (size_t i = 0; i < n; ++i) {
         r->buf[r->cursor] = src[i];
         if (++r->cursor == r->size) r->cursor = 0;
+    }
+}
+
+/* CLIFOStream<PixelType>: the same ring over RGBA8 pixels */
+typedef struct { uint32_t *buf; size_t size, cursor; } cring_t;
+static void cring_write(cring_t *r, const uint32_t *src, size_t n)
+{
+    if (r->size == 0) return;
+    for (size_t i = 0; i < n; ++i) {
+        r->buf[r->cursor] = src[i];
+        if (++r->cursor == r->size) r->cursor = 0;
+    }
+}
+static void cring_copy_head(cring_t *dst, const cring_t *src, size_t historySize, long offset)
+{
+    if (dst->size == 0 || src->size == 0) return;
+    long rd = ((long)src->cursor + offset) % (long)src->size;
+    if (rd < 0) rd += (long)src->size;
+    for (size_t i = 0; i < historySize; ++i) {
+        dst->buf[dst->cursor] = src->buf[rd];
+        if (++dst->cursor == dst->size) dst->cursor = 0;
+        if (++rd == (long)src->size) rd = 0;
     }
 }
 
@@ -79,10 +103,30 @@ struct sgzo_scope_stream {
     uint64_t crossOrigin, oldPeak, currentPeak, bufferedSamples, frontOrigin, steadyClock;
     queue_t peaks;
     uint64_t swaps;                                /* diagnostic: number of swapBuffers so far */
+    /* frequency colouring (audioProcessing :445-517, :588-647) */
+    int colours_on;
+    sgzo_lr_coeffs network_coeffs;                 /* channelData.networkCoeffs */
+    float smooth_pole;                             /* channelData.smoothFilterPole */
+    float band_colours[3][3];                      /* content->lowColour / midColour / highColour as float r, g, b */
+    float blend;                                   /* 1 - frequencyColouringBlend */
+    sgzo_lr_state *network;                        /* filterStates.channels[c].network */
+    float (*smooth)[3], (*aux_smooth)[3];          /* filterStates.channels[c].smoothFilters / auxSmoothFilter */
+    uint8_t (*keys)[4];                            /* filterStates.channels[c].defaultKey as RGBA8 */
+    cring_t *back_col, *back_aux, *front_col, *front_aux;
 };
 
-/* ChannelData::resizeAudioStorage (ChannelData.h:106-129), non-spectral modes: size = ceil(effectiveWindowSize + 1) */
-static size_t storage_size(double window) { return (size_t)ceil(window + 1); }
+/* ChannelData::resizeAudioStorage (ChannelData.h:106-129).  Non-spectral modes: size = ceil(effectiveWindowSize + 1).  Spectral: the
+ * reference resizes every frame to max((size_t)(0.5 + cycleSamples + ceil(window)), LookaheadSize); this stream keeps the largest
+ * such ring (cycleSamples <= sampleRate / 5, the 5 Hz floor of calculateFundamentalPeriod) and sgzo_scope_stream_logical() cuts the
+ * reference's ring of the moment out of it (the newest `size` samples, oldest first = a ring whose cursor is 0). */
+static size_t storage_size(double window, int trigger_mode, double sample_rate)
+{
+    if (trigger_mode == TRIG_SPECTRAL) {
+        const size_t n = (size_t)(0.5 + sample_rate / 5.0 + ceil(window));
+        return n > 8192 ? n : 8192;
+    }
+    return (size_t)ceil(window + 1);
+}
 
 sgzo_scope_stream *sgzo_scope_stream_create(uint32_t channels, double sample_rate, double window_size, int trigger_mode,
                                             double threshold, uint32_t osc_mode, double trigger_channel_1based,
@@ -93,7 +137,7 @@ sgzo_scope_stream *sgzo_scope_stream_create(uint32_t channels, double sample_rat
     s->sample_rate = sample_rate; s->envelope_window = envelope_window_s;
     s->back = (ring_t *)calloc(channels, sizeof(ring_t));
     s->front = (ring_t *)calloc(channels, sizeof(ring_t));
-    const size_t size = storage_size(window_size);
+    const size_t size = storage_size(window_size, trigger_mode, sample_rate);
     for (uint32_t c = 0; c < channels; ++c) {
         s->back[c].buf = (float *)calloc(size, sizeof(float)); s->back[c].size = size;
         s->front[c].buf = (float *)calloc(size, sizeof(float)); s->front[c].size = size;
@@ -114,7 +158,69 @@ void sgzo_scope_stream_destroy(sgzo_scope_stream *s)
 {
     if (!s) return;
     for (uint32_t c = 0; c < s->channels; ++c) { free(s->back[c].buf); free(s->front[c].buf); }
+    if (s->colours_on)
+        for (uint32_t c = 0; c < s->channels; ++c) {
+            free(s->back_col[c].buf); free(s->back_aux[c].buf); free(s->front_col[c].buf); free(s->front_aux[c].buf);
+        }
+    free(s->back_col); free(s->back_aux); free(s->front_col); free(s->front_aux);
+    free(s->network); free(s->smooth); free(s->aux_smooth); free(s->keys);
     free(s->back); free(s->front); free(s->envelope); free(s->peaks.v); free(s);
+}
+
+/* switches the per-sample colours on (state.colourChannelsByFrequency only decides whether the renderer reads them; the reference
+ * always computes them).  band_colours: low / mid / high as float r, g, b (ColourValue::getValue()); keys: RGBA8 per channel. */
+void sgzo_scope_stream_enable_colours(sgzo_scope_stream *s, const float band_colours[3][3], double frequency_colouring_blend,
+                                      double colour_smoothing_ms, const uint8_t (*keys)[4])
+{
+    const uint32_t C = s->channels;
+    s->colours_on = 1;
+    memcpy(s->band_colours, band_colours, sizeof(s->band_colours));
+    s->blend = 1 - (float)frequency_colouring_blend;                                       /* :515 */
+    s->smooth_pole = sgzo_colour_smooth_pole(colour_smoothing_ms, s->sample_rate);          /* tuneColourSmoothing, :439 */
+    sgzo_lr_design(300, 3000, s->sample_rate, &s->network_coeffs);                          /* tuneCrossOver(300, 3000, sampleRate), :440 */
+    s->network = (sgzo_lr_state *)calloc(C, sizeof(sgzo_lr_state));
+    s->smooth = calloc(C, sizeof(float[3])); s->aux_smooth = calloc(C, sizeof(float[3]));
+    s->keys = calloc(C, 4);
+    memcpy(s->keys, keys, (size_t)C * 4);
+    s->back_col = calloc(C, sizeof(cring_t)); s->back_aux = calloc(C, sizeof(cring_t));
+    s->front_col = calloc(C, sizeof(cring_t)); s->front_aux = calloc(C, sizeof(cring_t));
+    const size_t size = s->front[0].size;
+    for (uint32_t c = 0; c < C; ++c) {
+        cring_t *all[4] = {&s->back_col[c], &s->back_aux[c], &s->front_col[c], &s->front_aux[c]};
+        for (int k = 0; k < 4; ++k) { all[k]->buf = (uint32_t *)calloc(size, sizeof(uint32_t)); all[k]->size = size; }
+    }
+}
+
+static uint32_t pack_rgba(const uint8_t p[4]) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+/* the colour part of audioProcessing for numChannels >= 2 (:588-647): per channel pair, per sample */
+static void colour_processing(sgzo_scope_stream *s, const float *const *buffer, size_t numSamples, int into_back)
+{
+    uint32_t *cl = (uint32_t *)malloc(sizeof(uint32_t) * numSamples * 4), *cr = cl + numSamples, *cm = cr + numSamples, *cs = cm + numSamples;
+    for (uint32_t pair = 0; pair < s->channels; pair += 2) {
+        sgzo_lr_state *netLeft = &s->network[pair], *netRight = &s->network[pair + 1];
+        float *smLeft = s->smooth[pair], *smRight = s->smooth[pair + 1], *smMid = s->aux_smooth[pair], *smSide = s->aux_smooth[pair + 1];
+        const uint8_t *leftColour = s->keys[pair], *rightColour = s->keys[pair + 1];
+        for (size_t n = 0; n < numSamples; ++n) {
+            float leftBands[3], rightBands[3], mid[3], side[3];
+            uint8_t px[4];
+            sgzo_lr_process(netLeft, &s->network_coeffs, buffer[pair][n], leftBands);
+            sgzo_lr_process(netRight, &s->network_coeffs, buffer[pair + 1][n], rightBands);
+            sgzo_colour_filter_states(leftBands, smLeft, s->smooth_pole);
+            sgzo_colour_filter_states(rightBands, smRight, s->smooth_pole);
+            for (int i = 0; i < 3; ++i) { mid[i] = leftBands[i] + rightBands[i]; side[i] = leftBands[i] - rightBands[i]; }
+            sgzo_colour_filter_states(mid, smMid, s->smooth_pole);
+            sgzo_colour_filter_states(side, smSide, s->smooth_pole);
+            sgzo_colour_accumulate(smLeft, s->band_colours, leftColour, s->blend, px); cl[n] = pack_rgba(px);
+            sgzo_colour_accumulate(smRight, s->band_colours, rightColour, s->blend, px); cr[n] = pack_rgba(px);
+            sgzo_colour_accumulate(smMid, s->band_colours, leftColour, s->blend, px); cm[n] = pack_rgba(px);
+            sgzo_colour_accumulate(smSide, s->band_colours, rightColour, s->blend, px); cs[n] = pack_rgba(px);
+        }
+        cring_t *col = into_back ? s->back_col : s->front_col, *aux = into_back ? s->back_aux : s->front_aux;
+        cring_write(&col[pair], cl, numSamples); cring_write(&col[pair + 1], cr, numSamples);      /* cwLeft / cwRight */
+        cring_write(&aux[pair], cm, numSamples); cring_write(&aux[pair + 1], cs, numSamples);      /* cwMid / cwSide */
+    }
+    free(cl);
 }
 
 /* the part of StreamState::audioProcessing that is on this row: RMS envelope (:520-585, :676-693) and the ring write (:696-697) */
@@ -179,6 +285,7 @@ static void audio_processing(sgzo_scope_stream *s, const float *const *buffer, s
         s->envelope[0] = filterEnv[0];                                                 /* only Left and Right are stored back */
         s->envelope[1] = filterEnv[1];
     }
+    if (s->colours_on) colour_processing(s, buffer, numSamples, target == s->back);
     for (uint32_t c = 0; c < numChannels; ++c) ring_write(&target[c], buffer[c], numSamples);   /* :696-697 */
 }
 
@@ -282,7 +389,13 @@ static void process_mutating(sgzo_scope_stream *s, const float **localPointers, 
             const double amount = (isPeakOutsideOfWindow ? halfSize : (double)missingBufferSamples) + (double)neededPreSamples;
             const size_t cappedSize = (size_t)min_u64(s->bufferedSamples, (uint64_t)ceil(amount + 1));
             /* ChannelData::swapBuffers(cappedSize, -bufferedSamples), ChannelData.h:147-161 */
-            for (uint32_t c = 0; c < s->channels; ++c) ring_copy_head(&s->front[c], &s->back[c], cappedSize, -(long)s->bufferedSamples);
+            for (uint32_t c = 0; c < s->channels; ++c) {
+                ring_copy_head(&s->front[c], &s->back[c], cappedSize, -(long)s->bufferedSamples);
+                if (s->colours_on) {
+                    cring_copy_head(&s->front_col[c], &s->back_col[c], cappedSize, -(long)s->bufferedSamples);
+                    cring_copy_head(&s->front_aux[c], &s->back_aux[c], cappedSize, -(long)s->bufferedSamples);
+                }
+            }
             s->bufferedSamples -= min_u64(s->bufferedSamples, (uint64_t)cappedSize);
             s->frontOrigin += cappedSize;
             s->oldPeak = s->currentPeak;
@@ -321,6 +434,13 @@ size_t sgzo_scope_stream_front(const sgzo_scope_stream *s, uint32_t c, float *ou
 {
     memcpy(out, s->front[c].buf, sizeof(float) * s->front[c].size);
     return s->front[c].cursor;
+}
+/* front colour ring of channel c (aux = 0: colourData, 1: auxColourData): raw ring memory as RGBA8 words */
+size_t sgzo_scope_stream_front_colours(const sgzo_scope_stream *s, uint32_t c, int aux, uint32_t *out)
+{
+    const cring_t *r = aux ? &s->front_aux[c] : &s->front_col[c];
+    memcpy(out, r->buf, sizeof(uint32_t) * r->size);
+    return r->cursor;
 }
 size_t sgzo_scope_stream_size(const sgzo_scope_stream *s) { return s->front[0].size; }
 double sgzo_scope_stream_envelope_gain(const sgzo_scope_stream *s) { return s->envelope_gain; }

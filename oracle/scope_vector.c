@@ -232,28 +232,43 @@ static float wave_eval(const float *a, const float *b, int mode, long idx)
     return a[idx];
 }
 
-size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
-                            int eval_mode, size_t size, size_t cursor, float *xyz, size_t max_points)
+/* Spectral triggering adds triggerState.cycleSamples / sampleOffset (:598-612, :808-811); colour_mem != NULL is
+ * state.colourChannelsByFrequency: the evaluator's colour ring (colourData of the channel for Left / Right, auxColourData for Mid /
+ * Side, SampleColourEvaluators.h:64,183) read at the audio position, RGBA8 per vertex into rgba (Linear :664-677: the sample's
+ * colour; Lanczos :836-877: currentColour.lerp(nextColour, delta), the colours of the two newest kernel samples). */
+size_t sgzo_scope_wave_plot_ex(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                               int eval_mode, size_t size, size_t cursor, double cycle_samples, double sample_offset,
+                               const uint32_t *colour_mem, float *xyz, uint32_t *rgba, size_t max_points)
 {
     enum { KernelSize = 10, KernelBufferSize = 21 };
     if (size == 0) return 0;
     const double horizontalDelta = v->right - v->left;
     long roundedWindow = (long)ceil(v->window_size);                                   /* :563 */
+    long quantizedCycleSamples = 0;
     const double sizeMinusOne = fmax(1.0, v->window_size - 1);
     const double pixelsPerSample = v->rendering_scale * fabs(((double)v->width - 1) / (sizeMinusOne * horizontalDelta));
     if (pixelsPerSample < 1 && interpolation != 0) interpolation = 2;                  /* :575-578: Linear below one pixel per sample */
-    const double triggerSampleOffset = trigger_mode == 4 ? (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5 : 0.0;
+    const double triggerSampleOffset = trigger_mode == 4 ? (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5
+                                                         : (trigger_mode == 1 ? sample_offset : 0.0);
+    const double triggerCycleSamples = trigger_mode == 1 ? cycle_samples : 0.0;        /* calculateTriggeringOffset :241-248 */
     long bufferOffset;
     if (trigger_mode == 4) bufferOffset = (long)ceil(triggerSampleOffset);             /* :590-596 */
-    else bufferOffset = roundedWindow;                                                 /* :598-612, triggering off: no cycle samples */
+    else {                                                                             /* :598-612 */
+        const long cycleBuffers = interpolation == 3 ? 2 : 1;
+        if (trigger_mode != 0) quantizedCycleSamples = (long)ceil(triggerCycleSamples);
+        bufferOffset = roundedWindow + cycleBuffers * quantizedCycleSamples;
+    }
     roundedWindow = roundedWindow > 2 ? roundedWindow : 2;                             /* :615 */
     size_t n = 0;
     if (interpolation == 2) {                                                          /* Linear, :707-741 */
         long p = ((long)cursor - bufferOffset) % (long)size;                           /* eval.startFrom(-(bufferOffset + 0)) */
         if (p < 0) p += (long)size;
-        const float endCondition = (float)roundedWindow;
+        const float endCondition = (float)(roundedWindow + quantizedCycleSamples);     /* :631 */
         for (float i = 0; i < endCondition; i += 1) {
-            if (n < max_points) { xyz[n * 3] = i; xyz[n * 3 + 1] = wave_eval(memA, memB, eval_mode, p); xyz[n * 3 + 2] = 0; }
+            if (n < max_points) {
+                xyz[n * 3] = i; xyz[n * 3 + 1] = wave_eval(memA, memB, eval_mode, p); xyz[n * 3 + 2] = 0;
+                if (colour_mem && rgba) rgba[n] = colour_mem[p];
+            }
             ++n;
             if (++p == (long)size) p = 0;
         }
@@ -262,7 +277,8 @@ size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int inte
     /* Lanczos, :790-891 */
     double samplePos;
     if (trigger_mode == 4) samplePos = triggerSampleOffset;
-    else samplePos = ceil(0.0 * 2 + v->window_size - 0.0);                              /* :813, :817-821 */
+    else samplePos = triggerCycleSamples * 2 + v->window_size - (trigger_mode == 1 ? triggerSampleOffset : 0.0);   /* :810 */
+    if (trigger_mode == 0 || trigger_mode == 2) samplePos = ceil(samplePos);            /* :814-819 */
     const double inc = horizontalDelta / (v->rendering_scale * ((double)v->width - 1));
     double unitSpacePos = v->left;
     const double samplesPerPixel = 1.0 / pixelsPerSample;
@@ -271,7 +287,12 @@ size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int inte
     long p = ((long)cursor + (-(long)floor(samplePos) - KernelSize)) % (long)size;       /* eval.startFrom, :829 */
     if (p < 0) p += (long)size;
     float kernel[KernelBufferSize];
-    for (int i = 0; i < KernelBufferSize; ++i) { kernel[i] = wave_eval(memA, memB, eval_mode, p); if (++p == (long)size) p = 0; }
+    uint32_t currentColour = 0, nextColour = 0;                                         /* ColourT{} */
+    for (int i = 0; i < KernelBufferSize; ++i) {
+        kernel[i] = wave_eval(memA, memB, eval_mode, p);
+        currentColour = nextColour; if (colour_mem) nextColour = colour_mem[p];         /* get(), :836-843 */
+        if (++p == (long)size) p = 0;
+    }
     do {
         double delta = currentSample - samplePos;
         while (delta > 1) {
@@ -279,15 +300,30 @@ size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int inte
             delta -= 1;
             memmove(kernel, kernel + 1, sizeof(float) * (KernelBufferSize - 1));
             kernel[KernelBufferSize - 1] = wave_eval(memA, memB, eval_mode, p);
+            currentColour = nextColour; if (colour_mem) nextColour = colour_mem[p];
             if (++p == (long)size) p = 0;
         }
         const double y = sgzo_lanczos_filter_f64(kernel, KernelBufferSize, (double)KernelSize + delta, KernelSize);
-        if (n < max_points) { xyz[n * 3] = (float)unitSpacePos; xyz[n * 3 + 1] = (float)y; xyz[n * 3 + 2] = 0; }
+        if (n < max_points) {
+            xyz[n * 3] = (float)unitSpacePos; xyz[n * 3 + 1] = (float)y; xyz[n * 3 + 2] = 0;
+            if (colour_mem && rgba) {
+                uint8_t a[4], b[4], o[4];
+                memcpy(a, &currentColour, 4); memcpy(b, &nextColour, 4);
+                sgzo_colour_lerp_f64(a, b, delta, o);
+                memcpy(&rgba[n], o, 4);
+            }
+        }
         ++n;
         currentSample += samplesPerPixel;
         unitSpacePos += inc;
     } while (unitSpacePos < (v->right + inc));
     return n;
+}
+
+size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                            int eval_mode, size_t size, size_t cursor, float *xyz, size_t max_points)
+{
+    return sgzo_scope_wave_plot_ex(v, trigger_mode, interpolation, memA, memB, eval_mode, size, cursor, 0.0, 0.0, NULL, xyz, NULL, max_points);
 }
 
 /* drawPolarPlot (VectorscopeRendering.cpp:500-746) over an AudioBufferView of the history ring: memory memL / memR of `size` samples

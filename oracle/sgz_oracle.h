@@ -172,6 +172,34 @@ double sgzo_scope_stream_envelope_gain(const sgzo_scope_stream *s);
 void   sgzo_scope_stream_envelopes(const sgzo_scope_stream *s, float *out);
 void   sgzo_scope_stream_state(const sgzo_scope_stream *s, uint64_t out[8]);
 double sgzo_scope_stream_peak_filter(sgzo_scope_stream *s, uint32_t lanes, double coeff);   /* runPeakFilter, all channel modes */
+void   sgzo_scope_stream_enable_colours(sgzo_scope_stream *s, const float band_colours[3][3], double frequency_colouring_blend,
+                                        double colour_smoothing_ms, const uint8_t (*keys)[4]);
+size_t sgzo_scope_stream_front_colours(const sgzo_scope_stream *s, uint32_t c, int aux, uint32_t *out);
+size_t sgzo_scope_wave_plot_ex(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                               int eval_mode, size_t size, size_t cursor, double cycle_samples, double sample_offset,
+                               const uint32_t *colour_mem, float *xyz, uint32_t *rgba, size_t max_points);
+
+/* ---------------- Oscilloscope spectral trigger + frequency colouring (scope_spectral.c) ---------------- */
+typedef struct sgzo_bin_record { uint64_t index; double value, offset; } sgzo_bin_record;      /* Oscilloscope.h BinRecord */
+typedef struct sgzo_spectral_state {                                                           /* triggerState + the median filter */
+    sgzo_bin_record median[8];        /* medianTriggerFilter[i].record, value-initialised */
+    uint64_t median_pos;              /* medianPos */
+    sgzo_bin_record record;           /* triggerState.record */
+    double fundamental, cycle_samples, sample_offset, phase;
+} sgzo_spectral_state;
+void sgzo_nth_element_by_index(sgzo_bin_record *v, int n, int nth);
+void sgzo_scope_fundamental(sgzo_spectral_state *ts, const float *memA, const float *memB, int eval_mode, size_t size, size_t cursor,
+                            double window_size, double sample_rate, double threshold, double hysteresis);
+void sgzo_scope_trigger_offset(sgzo_spectral_state *ts, const float *memA, const float *memB, int eval_mode, size_t size, size_t cursor,
+                               double window_size, double sample_rate, double phase_offset_degrees);
+typedef struct sgzo_lr_coeffs { float lp1[5], hp1[5], lp2[5], hp2[5]; } sgzo_lr_coeffs;      /* b0 b1 b2 a1 a2 per section type */
+typedef struct sgzo_lr_state { float z[8][2]; } sgzo_lr_state;                               /* lp1 a,b  hp1 a,b  lp2 a,b  hp2 a,b */
+void  sgzo_lr_design(double low_hz, double high_hz, double sample_rate, sgzo_lr_coeffs *out);
+void  sgzo_lr_process(sgzo_lr_state *st, const sgzo_lr_coeffs *k, float x, float bands[3]);
+float sgzo_colour_smooth_pole(double milliseconds, double sample_rate);
+void  sgzo_colour_filter_states(const float bands[3], float states[3], float pole);
+void  sgzo_colour_accumulate(const float state[3], const float colours[3][3], const uint8_t key[4], float blend, uint8_t out[4]);
+void  sgzo_colour_lerp_f64(const uint8_t a[4], const uint8_t b[4], double t, uint8_t out[4]);
 
 /* ---------------- Vectorscope (a13, a14) ---------------- */
 void sgzo_vector_polar(const float *L, const float *R, size_t n, int fade, float *xyz /*n*3*/);
