@@ -48,7 +48,7 @@ enum { SGZ_WIN_SYMMETRIC = 0, SGZ_WIN_PERIODIC };
 /* OscChannels, Source/Common/CommonSignalizer.h:458-493 */
 enum { SGZ_OSC_LEFT = 0, SGZ_OSC_RIGHT, SGZ_OSC_MID, SGZ_OSC_SIDE, SGZ_OSC_SEPARATE, SGZ_OSC_MIDSIDE };
 
-/* OscilloscopeContent::TriggeringMode, Source/Oscilloscope/OscilloscopeParameters.h:50-58 (built: None, ZeroCrossing) */
+/* OscilloscopeContent::TriggeringMode, Source/Oscilloscope/OscilloscopeParameters.h:50-58 (built: None, Spectral, ZeroCrossing) */
 enum { SGZ_TRIG_NONE = 0, SGZ_TRIG_SPECTRAL, SGZ_TRIG_WINDOW, SGZ_TRIG_ENVELOPE_HOLD, SGZ_TRIG_ZERO_CROSSING };
 /* EnvelopeModes / SubSampleInterpolation, Source/Common/CommonSignalizer.h:72-85 */
 enum { SGZ_ENV_NONE = 0, SGZ_ENV_RMS, SGZ_ENV_PEAK_DECAY };
@@ -312,13 +312,15 @@ sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t cha
  * The trigger detector, TriggeringProcessor::processMutating's window selection (StreamPreprocessing.h:79-206), the back / front
  * rings (ChannelData.h) and the envelope all live in HBM; one push = one staged copy + one kernel launch, and push never waits for
  * the GPU (SGZ_BUSY instead).  One producer thread (push), one consumer thread (everything else).
- * Not built (SGZ_EUNSUPPORTED): trigger modes Spectral / Window / EnvelopeHold, per-sample frequency colouring,
- * interpolation None / Rectangular. */
+ * trigger mode Spectral (sgz_scope_analyse = calculateFundamentalPeriod + calculateTriggeringOffset,
+ * OscilloscopeDSP.inl:62-308, on the device ring) and the per-sample frequency colouring of audioProcessing (:445-647: 3-band
+ * Linkwitz-Riley split -> smoothed band energies -> RGB, kept in colour rings beside the audio rings and swapped with them).
+ * Not built (SGZ_EUNSUPPORTED): trigger modes Window / EnvelopeHold, interpolation None / Rectangular. */
 typedef struct sgz_scope_config {
     double   sample_rate;
     double   window_size;        /* state.effectiveWindowSize in samples (fractions allowed)                     */
     uint32_t num_channels;       /* even, 2..64                                                                  */
-    uint32_t trigger_mode;       /* SGZ_TRIG_NONE / SGZ_TRIG_ZERO_CROSSING                                       */
+    uint32_t trigger_mode;       /* SGZ_TRIG_NONE / SGZ_TRIG_SPECTRAL / SGZ_TRIG_ZERO_CROSSING                   */
     uint32_t channel_mode;       /* SGZ_OSC_* (OscChannels): trigger mix, envelope mix                           */
     uint32_t envelope_mode;      /* SGZ_ENV_*: RMS runs in push (audioProcessing), PEAK_DECAY in sgz_scope_peak_filter */
     uint32_t interpolation;      /* SGZ_SUBSAMPLE_LINEAR / SGZ_SUBSAMPLE_LANCZOS                                 */
@@ -327,7 +329,25 @@ typedef struct sgz_scope_config {
     double   trigger_channel;    /* content->triggeringChannel, 1-based (calculateTriggerIndices)                */
     double   envelope_window;    /* content->envelopeWindow normalised value = seconds             */
     uint8_t  colours[64][4];     /* per channel: filterStates.channels[c].defaultKey as RGBA8                    */
+    /* Spectral triggering (all ignored in the other modes) */
+    double   trigger_hysteresis;   /* content->triggerHysteresis, 0..1                                           */
+    double   trigger_phase_offset; /* content->triggerPhaseOffset in degrees                                     */
+    /* frequency colouring */
+    uint32_t colour_by_frequency;  /* state.colourChannelsByFrequency: colours computed in push, per-vertex colours from the rings */
+    float    frequency_colouring_blend;   /* content->frequencyColouringBlend, 0..1                              */
+    double   colour_smoothing_ms;  /* content->colourSmoothing (transformed value, milliseconds)                 */
+    float    band_colours[3][3];   /* content->lowColour / midColour / highColour as float r, g, b               */
 } sgz_scope_config;
+/* Oscilloscope::triggerState after analyseAndSetupState's first two steps (Oscilloscope.h:176-196) */
+typedef struct sgz_trigger_state {
+    uint64_t record_index;         /* triggerState.record: the winning bin, its magnitude and its fractional offset */
+    double   record_value, record_offset;
+    double   fundamental;          /* Hz, >= 5 */
+    double   cycle_samples;        /* sampleRate / fundamental (0 outside Spectral mode)                          */
+    double   sample_offset;        /* samples                                                                      */
+    double   phase;                /* radians, [0, tau)                                                            */
+    uint64_t ring_size;            /* ChannelData::resizeAudioStorage's size for this frame: the ring drawWavePlot wraps in */
+} sgz_trigger_state;
 typedef struct sgz_scope sgz_scope;
 sgz_status sgz_scope_create(const sgz_scope_config *cfg, sgz_scope **out);
 void       sgz_scope_destroy(sgz_scope *s);
@@ -340,6 +360,14 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain);
 /* envelopeGain of the RMS mode and the per-channel envelope states (either may be NULL) */
 sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes /*num_channels*/);
+/* Once per rendered frame, before sgz_scope_vertices: calculateFundamentalPeriod + calculateTriggeringOffset
+ * (OscilloscopeDSP.inl:62-308) for the trigger evaluator (evaluator / channel as in sgz_scope_vertices).  Spectral mode: one kernel
+ * (8192-point fp64 transform of the newest samples in LDS, the harmonic peak pick with hysteresis, the median of 8, the Goertzel
+ * phase) on the device ring; the state is read back (this call waits) and kept for the vertex calls.  Other modes: cycle_samples = 0
+ * and the mode's fixed sample_offset, no GPU work.  The Spectral ring keeps the most the reference can ask for
+ * ((size_t)(0.5 + sampleRate / 5 + ceil(window)) samples, the 5 Hz floor) and every read wraps in `ring_size`, the size
+ * resizeAudioStorage gives the reference's ring for this frame (ChannelData.h:107-128), counted back from the newest sample. */
+sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel, sgz_trigger_state *out);
 size_t     sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view);
 /* One evaluator's line strip.  evaluator: SGZ_OSC_LEFT / RIGHT (channel `channel` / `channel` + 1) or SGZ_OSC_MID / SIDE (0.5 (l +- r)
  * of the pair at `channel`); view->window_size is ignored (the stream's is used).  xyz: float3 per vertex, rgba: RGBA8 per vertex
@@ -350,6 +378,8 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
 /* parity hooks: front buffer memory of one channel (begin()) + its write cursor; TriggeringProcessor counters
  * {frontOrigin, bufferedSamples, oldPeak, currentPeak, steadyClock, peaks.size(), isWorkingOnPeak, swaps} */
 sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out /*size*/, uint32_t *size, uint32_t *cursor);
+/* the colour ring beside it: aux = 0 colourData, 1 auxColourData (Mid at even, Side at odd channels); RGBA8 words */
+sgz_status sgz_scope_front_colours(sgz_scope *s, uint32_t channel, uint32_t aux, uint8_t *out /*4*size*/);
 sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8]);
 
 /* ------------------------------------------------------------------------------------------------

@@ -66,7 +66,14 @@ class ScopeConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_double), ("window_size", C.c_double), ("num_channels", C.c_uint32), ("trigger_mode", C.c_uint32),
                 ("channel_mode", C.c_uint32), ("envelope_mode", C.c_uint32), ("interpolation", C.c_uint32), ("max_block", C.c_uint32),
                 ("trigger_threshold", C.c_double), ("trigger_channel", C.c_double), ("envelope_window", C.c_double),
-                ("colours", (C.c_uint8 * 4) * 64)]
+                ("colours", (C.c_uint8 * 4) * 64),
+                ("trigger_hysteresis", C.c_double), ("trigger_phase_offset", C.c_double), ("colour_by_frequency", C.c_uint32),
+                ("frequency_colouring_blend", C.c_float), ("colour_smoothing_ms", C.c_double), ("band_colours", (C.c_float * 3) * 3)]
+
+
+class TriggerState(C.Structure):
+    _fields_ = [("record_index", C.c_uint64), ("record_value", C.c_double), ("record_offset", C.c_double), ("fundamental", C.c_double),
+                ("cycle_samples", C.c_double), ("sample_offset", C.c_double), ("phase", C.c_double), ("ring_size", C.c_uint64)]
 
 
 class VectorFilters(C.Structure):
@@ -114,7 +121,8 @@ EXPORTS = [
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
     "sgz_spectrum_stats", "sgz_spectrum_history",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
-    "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state",
+    "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
+    "sgz_scope_front_colours",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
     "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
@@ -202,6 +210,8 @@ def lib() -> C.CDLL:
     L.sgz_scope_vertices.argtypes = [vp, C.POINTER(ScopeView), u32, u32, vp, vp, C.POINTER(u32)]
     L.sgz_scope_front.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_debug_state.argtypes = [vp, vp]
+    L.sgz_scope_analyse.argtypes = [vp, u32, u32, C.POINTER(TriggerState)]
+    L.sgz_scope_front_colours.argtypes = [vp, u32, u32, vp]
     L.sgz_vector_create.argtypes = [C.POINTER(VectorConfig), C.POINTER(vp)]
     L.sgz_vector_destroy.argtypes = [vp]
     L.sgz_vector_destroy.restype = None
@@ -415,12 +425,17 @@ class Scope:
     def __init__(self, **kw):
         self.cfg = ScopeConfig()
         colours = kw.pop("colours", None)
+        bands = kw.pop("band_colours", None)
         for k, v in kw.items():
             setattr(self.cfg, k, v)
         for c in range(64):
             col = colours[c] if colours is not None and c < len(colours) else (255, 255, 255, 255)
             for j in range(4):
                 self.cfg.colours[c][j] = int(col[j])
+        if bands is not None:
+            for i in range(3):
+                for j in range(3):
+                    self.cfg.band_colours[i][j] = float(bands[i][j])
         self.h = C.c_void_p()
         check(lib().sgz_scope_create(C.byref(self.cfg), C.byref(self.h)))
 
@@ -451,6 +466,19 @@ class Scope:
         out = np.zeros(size.value, np.float32)
         check(lib().sgz_scope_front(self.h, channel, _np_ptr(out), C.byref(size), C.byref(cur)))
         return out, int(cur.value)
+
+    def front_colours(self, channel: int, aux: bool = False) -> np.ndarray:
+        """colour ring memory beside front(channel): uint32 RGBA8 words [size]"""
+        size = C.c_uint32(0)
+        check(lib().sgz_scope_front(self.h, channel, None, C.byref(size), None))
+        out = np.zeros(size.value, np.uint32)
+        check(lib().sgz_scope_front_colours(self.h, channel, int(aux), _np_ptr(out)))
+        return out
+
+    def analyse(self, evaluator: int = 0, channel: int = 0) -> TriggerState:
+        ts = TriggerState()
+        check(lib().sgz_scope_analyse(self.h, evaluator, channel, C.byref(ts)))
+        return ts
 
     def state(self) -> dict:
         out = np.zeros(8, np.uint64)

@@ -26,6 +26,15 @@
 //   C  all threads execute the swaps in order into the front rings;
 //   D  the block is appended to the back rings;
 //   E  RMS envelope: one lane per recurrence, sequential fp32 (rounding order is the reference's).
+//   F  (colour_by_frequency) the per-sample colours of audioProcessing (:445-647) for the whole block, before C so that swaps can
+//      take them along: F1/F2 the 3-band Linkwitz-Riley tree as two passes of cascaded biquads (one lane per channel and branch,
+//      sequential in time), F3 the twelve band-energy smoothers of a channel pair (left / right / mid / side x 3 bands, one lane
+//      each), F4 accumulateColour for every (sample, signal) in parallel.  Colour rings sit beside the audio rings (colourData /
+//      auxColourData, ChannelData.h:58-66) and move with them (swapBuffers, ChannelData.h:155-159).
+//
+// Spectral triggering (sgz_scope_analyse -> scopeSpectralKernel, OscilloscopeDSP.inl:62-308): audio goes straight into the front ring
+// like TriggeringMode::None; once per rendered frame one workgroup transforms the newest 8192 samples in LDS (fp64), picks the
+// fundamental, runs the median of 8 and the Goertzel phase, and leaves cycleSamples / sampleOffset for the vertex kernels.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -43,9 +52,10 @@ using namespace sgz;
 namespace sgz {
 // scope_vector.hip: Lanczos / linear vertex kernels on a ring whose cursor lives in device memory
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
-                               const float *ringB, uint32_t evalMode, uint32_t size, const uint32_t *d_cursor, uint32_t rgba,
-                               float *d_xyz, uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream);
-size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation);
+                               const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
+                               double cycleSamples, double sampleOffset, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
+                               uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream);
+size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation, uint32_t triggerMode, double cycleSamples);
 }
 
 namespace {
@@ -73,6 +83,24 @@ struct ScopeDev {
     unsigned long long swaps, droppedPeaks;
 };
 
+// frequency colouring state: filterStates.channels[c].{network, smoothFilters, auxSmoothFilter} (ChannelData.h:68-80)
+struct ColourDev {
+    float z[kMaxCh][8][2];                    // biquad states: lp1 a, b; hp1 a, b; lp2 a, b; hp2 a, b (transposed direct form II)
+    float smooth[kMaxCh][3], aux[kMaxCh][3];
+};
+struct ColourParams {
+    ColourDev *st;
+    float lp1[5], hp1[5], lp2[5], hp2[5];     // b0 b1 b2 a1 a2 (Crossover::Coefficients::design, UNVERIFIED vs cpl: see oracle/scope_spectral.c)
+    float pole, blend;                        // channelData.smoothFilterPole; 1 - frequencyColouringBlend
+    float band[3][3];                         // low / mid / high colour
+    float *bands;                             // scratch [channels][4][maxBlock]: low, mid, high, rest
+    float *sm;                                // scratch [channels / 2 * 12][maxBlock]: smoothed band energies
+    uint32_t *block;                          // [2 channels][maxBlock] colours of the block: colourData planes, then auxColourData
+    uint32_t *front, *back;                   // [2 channels][size] / [2 channels][backCap]
+    uint32_t maxBlock;
+    uint32_t keys[kMaxCh];                    // defaultKey per channel, RGBA8
+};
+
 struct IngestParams {
     ScopeDev *st;
     unsigned long long *peaks;                // [kPeakCap]
@@ -84,7 +112,38 @@ struct IngestParams {
     uint32_t triggerMode, oscMode, envMode;
     uint32_t trigSeparate, trigPair;
     float envelopeCoeff;
+    uint32_t colours;                         // colour_by_frequency
 };
+
+__device__ __forceinline__ float biquadStep(const float *c, float &z0, float &z1, float x)
+{
+    const float y = c[0] * x + z0;
+    z0 = (c[1] * x - c[3] * y) + z1;
+    z1 = c[2] * x - c[4] * y;
+    return y;
+}
+// static_cast<uint8_t>(float) as the x86 build behaves (see oracle/scope_spectral.c to_u8)
+__device__ __forceinline__ uint32_t toU8(float v) { return (!(v > -1.0f) || !(v < 256.0f)) ? 0u : uint32_t(int(v)) & 255u; }
+// accumulateColour (OscilloscopeDSP.inl:472-497) + PixelType::lerp(key, blend)
+__device__ __forceinline__ uint32_t accumulateColour(const float st[3], const float band[3][3], uint32_t key, float blend)
+{
+    float red = 0.f, green = 0.f, blue = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        red += st[i] * band[i][0];
+        green += st[i] * band[i][1];
+        blue += st[i] * band[i][2];
+    }
+    const float invMax = 255.0f / fmaxf(red, fmaxf(blue, green));
+    const uint32_t ret[4] = {toU8(red * invMax), toU8(green * invMax), toU8(blue * invMax), 255u};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = float(ret[k]), b = float((key >> (8 * k)) & 255u);
+        out |= toU8(a + (b - a) * blend) << (8 * k);
+    }
+    return out;
+}
 
 __device__ __forceinline__ long long waveInclusiveMax(long long v)
 {
@@ -140,7 +199,7 @@ __device__ __forceinline__ double trigSample(uint32_t mode, const float *a, cons
 
 __device__ __forceinline__ unsigned long long minU64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
-__global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm)
+__global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams col)
 {
     __shared__ long long sScan[16];
     __shared__ unsigned int sSum[16];
@@ -310,7 +369,64 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     }
     __syncthreads();
 
-    // ---- C: swaps (ZeroCrossing) or the block itself (None: audioProcessing straight into the front buffer), in order
+    // ---- F: per-sample colours of the block (audioProcessing :445-517, :588-647).  Every sample passes through audioProcessing exactly
+    // once and in order, whatever the split into calls, so the filters run over the block as a whole.
+    if (prm.colours) {
+        const uint32_t MB = col.maxBlock;
+        ColourDev *cs = col.st;
+        if (uint32_t(tid) < 2 * C) {                                   // F1: low = LP4_f1(x), rest = HP4_f1(x)
+            const uint32_t c = uint32_t(tid) >> 1, hp = uint32_t(tid) & 1u;
+            const float *k = hp ? col.hp1 : col.lp1;
+            float k0[5]; for (int j = 0; j < 5; ++j) k0[j] = k[j];
+            float (*z)[2] = cs->z[c] + (hp ? 2 : 0);
+            float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
+            const float *x = prm.block + size_t(c) * n;
+            float *out = col.bands + (size_t(c) * 4 + (hp ? 3 : 0)) * MB;
+            for (uint32_t i = 0; i < n; ++i) out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, x[i]));
+            z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
+        }
+        __syncthreads();
+        if (uint32_t(tid) < 2 * C) {                                   // F2: mid = LP4_f2(rest), high = HP4_f2(rest)
+            const uint32_t c = uint32_t(tid) >> 1, hp = uint32_t(tid) & 1u;
+            const float *k = hp ? col.hp2 : col.lp2;
+            float k0[5]; for (int j = 0; j < 5; ++j) k0[j] = k[j];
+            float (*z)[2] = cs->z[c] + (hp ? 6 : 4);
+            float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
+            const float *x = col.bands + (size_t(c) * 4 + 3) * MB;
+            float *out = col.bands + (size_t(c) * 4 + (hp ? 2 : 1)) * MB;
+            for (uint32_t i = 0; i < n; ++i) out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, x[i]));
+            z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
+        }
+        __syncthreads();
+        if (uint32_t(tid) < 6 * C) {                                   // F3: filterStates (:460-468) of left, right, mid, side
+            const uint32_t pair = uint32_t(tid) / 12u, r = uint32_t(tid) % 12u, sig = r / 3u, band = r % 3u;
+            const float *l = col.bands + (size_t(2 * pair) * 4 + band) * MB, *rr = col.bands + (size_t(2 * pair + 1) * 4 + band) * MB;
+            float *stp = sig == 0 ? &cs->smooth[2 * pair][band] : sig == 1 ? &cs->smooth[2 * pair + 1][band]
+                       : sig == 2 ? &cs->aux[2 * pair][band] : &cs->aux[2 * pair + 1][band];
+            float y = *stp;
+            const float pole = col.pole;
+            float *out = col.sm + size_t(tid) * MB;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float v = sig == 0 ? l[i] : sig == 1 ? rr[i] : sig == 2 ? l[i] + rr[i] : l[i] - rr[i];
+                const float input = v * v;
+                y = input + pole * (y - input);
+                out[i] = y;
+            }
+            *stp = y;
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < 2 * C * n; e += T) {                // F4: accumulateColour per (signal, sample)
+            const uint32_t q = e / n, i = e - q * n, pair = q >> 2, sig = q & 3u;
+            const float *sp = col.sm + size_t(pair * 12 + sig * 3) * MB + i;
+            const float stv[3] = {sp[0], sp[MB], sp[2 * size_t(MB)]};
+            const uint32_t keyCh = 2 * pair + (sig & 1u);              // left / mid: the left key, right / side: the right key
+            const uint32_t plane = (sig < 2 ? 0u : C) + keyCh;         // cwLeft, cwRight -> colourData; cwMid, cwSide -> auxColourData
+            col.block[size_t(plane) * MB + i] = accumulateColour(stv, col.band, col.keys[keyCh], col.blend);
+        }
+        __syncthreads();
+    }
+
+    // ---- C: swaps (ZeroCrossing) or the block itself (None / Spectral: audioProcessing straight into the front buffer), in order
     const uint32_t size = prm.size;
     uint32_t cursor = sCursor0;
     const unsigned long long written0 = sWritten0;
@@ -327,6 +443,15 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             uint32_t d = cur0 + i; if (d >= size) d -= size;
             prm.front[size_t(c) * size + d] = v;
         }
+        if (prm.colours)
+            for (uint32_t e = tid; e < m * 2 * C; e += T) {
+                const uint32_t c = e / m, i = e - c * m;
+                const unsigned long long abs = src + skip + i;
+                const uint32_t v = abs >= written0 ? col.block[size_t(c) * col.maxBlock + uint32_t(abs - written0)]
+                                                   : col.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
+                uint32_t d = cur0 + i; if (d >= size) d -= size;
+                col.front[size_t(c) * size + d] = v;
+            }
         cursor = uint32_t((cursor + len) % size);
         __syncthreads();
     };
@@ -342,6 +467,11 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             const uint32_t c = e / keep, i = first + (e - c * keep);
             prm.back[size_t(c) * prm.backCap + uint32_t((written0 + i) & (prm.backCap - 1))] = prm.block[size_t(c) * n + i];
         }
+        if (prm.colours)
+            for (uint32_t e = tid; e < keep * 2 * C; e += T) {
+                const uint32_t c = e / keep, i = first + (e - c * keep);
+                col.back[size_t(c) * prm.backCap + uint32_t((written0 + i) & (prm.backCap - 1))] = col.block[size_t(c) * col.maxBlock + i];
+            }
     }
 
     // ---- E: RMS envelope (audioProcessing, OscilloscopeDSP.inl:520-585, :676-693); wave 0, lane c = recurrence c
@@ -406,13 +536,18 @@ struct PeakParams {
     ScopeDev *st;
     const float *front; uint32_t size, channels, mode, lanes;
     double coeff;
+    uint32_t len;       // Spectral: the reference's ring of the moment (the newest len samples, taken as memory order); else 0
 };
 __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
 {
     __shared__ float sL[kMaxCh][16], sR[16];
     const uint32_t C = prm.channels, size = prm.size;
     const uint32_t mode = C == 1 ? uint32_t(SGZ_OSC_LEFT) : prm.mode;
-    const uint32_t stop = size - (size & (prm.lanes - 1));
+    const uint32_t len = prm.len ? prm.len : size;
+    const uint32_t stop = len - (len & (prm.lanes - 1));
+    // memory index of slot i of the reference's ring: the ring itself, or (Spectral) the newest len samples of the larger ring
+    const uint32_t first = prm.len ? (prm.st->frontCursor + size - len) % size : 0u;
+    auto at = [&](uint32_t i) { uint32_t p = first + i; return p >= size ? p - size : p; };
     const int tid = threadIdx.x, wave = tid >> 6, waves = blockDim.x >> 6;
     auto blockMax = [&](float v, float *slot) {
         for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -421,7 +556,8 @@ __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
     const float *L = prm.front, *R = prm.front + (C > 1 ? size : 0);
     if (mode <= SGZ_OSC_SIDE) {
         float m = 0.f;
-        for (uint32_t i = tid; i < stop; i += blockDim.x) {
+        for (uint32_t j = tid; j < stop; j += blockDim.x) {
+            const uint32_t i = at(j);
             float v;
             if (mode == SGZ_OSC_LEFT) v = L[i];
             else if (mode == SGZ_OSC_RIGHT) v = R[i];
@@ -434,12 +570,13 @@ __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
         for (uint32_t c = 0; c < C; ++c) {
             float m = 0.f;
             const float *x = prm.front + size_t(c) * size;
-            for (uint32_t i = tid; i < stop; i += blockDim.x) m = fmaxf(fabsf(x[i]), m);
+            for (uint32_t j = tid; j < stop; j += blockDim.x) m = fmaxf(fabsf(x[at(j)]), m);
             blockMax(m, sL[c]);
         }
     } else {
         float ml = 0.f, mr = 0.f;
-        for (uint32_t i = tid; i < stop; i += blockDim.x) {
+        for (uint32_t j = tid; j < stop; j += blockDim.x) {
+            const uint32_t i = at(j);
             const float a = L[i] + R[i], b = L[i] - R[i];
             ml = fmaxf(fabsf(a * 0.5f), ml);
             mr = fmaxf(fabsf(b * 0.5f), mr);
@@ -474,6 +611,240 @@ __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
     st->autoGain = 1.0 / double(start);
 }
 
+
+// ---- Spectral triggering: Oscilloscope::calculateFundamentalPeriod + calculateTriggeringOffset (OscilloscopeDSP.inl:62-308)
+struct BinRec { unsigned long long index; double value, offset; };           // BinRecord, Oscilloscope.h
+struct SpectralDev {
+    BinRec median[8];                        // medianTriggerFilter[i].record (value-initialised)
+    unsigned long long medianPos;
+    BinRec record;                           // triggerState.record
+    double fundamental, cycleSamples, sampleOffset, phase;
+    unsigned long long ringSize;             // resizeAudioStorage's size (ChannelData.h:107-128): in = of the previous frame, out = of this one
+};
+struct SpectralParams {
+    SpectralDev *st;
+    const float *ringA, *ringB; uint32_t evalMode, cap;
+    const uint32_t *d_cursor;
+    double windowSize, sampleRate, threshold, hysteresis, phaseOffsetDeg, quarterSemitone;
+    const double2 *tw;                       // [4096] exp(-2 pi i k / 8192)
+};
+
+__device__ __forceinline__ double recOmega(const BinRec &r) { return double(r.index) + r.offset; }
+__device__ __forceinline__ uint32_t brev13(uint32_t i) { return __brev(i) >> 19; }
+__device__ __forceinline__ uint32_t logicalPhys(long rel, uint32_t cursor, uint32_t cap, uint32_t len)
+{
+    long q = rel % long(len);
+    if (q < 0) q += long(len);
+    return uint32_t((long(cursor) + long(cap - len) + q) % long(cap));
+}
+__device__ __forceinline__ double evalD(const float *a, const float *b, uint32_t mode, uint32_t idx)
+{
+    if (mode == 1u) return double(0.5f * (a[idx] + b[idx]));
+    if (mode == 2u) return double(0.5f * (a[idx] - b[idx]));
+    return double(a[idx]);
+}
+
+// libstdc++'s std::nth_element(v, v + 4, v + 8, by index) -- see oracle/scope_spectral.c for why the algorithm itself matters
+__device__ inline bool recLess(const BinRec &a, const BinRec &b) { return a.index < b.index; }
+__device__ inline void recSwap(BinRec &a, BinRec &b) { const BinRec t = a; a = b; b = t; }
+__device__ void nthElementByIndex(BinRec *v, int n, int nth)
+{
+    int first = 0, last = n;
+    int depth = 0;
+    for (int k = n; k > 1; k >>= 1) ++depth;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            for (int i = first; i <= nth; ++i)
+                for (int j = i + 1; j < last; ++j)
+                    if (recLess(v[j], v[i])) recSwap(v[i], v[j]);
+            return;
+        }
+        --depth;
+        const int mid = first + (last - first) / 2;
+        {   // __move_median_to_first(first, first + 1, mid, last - 1)
+            const int r = first, a = first + 1, b = mid, c = last - 1;
+            if (recLess(v[a], v[b])) {
+                if (recLess(v[b], v[c])) recSwap(v[r], v[b]);
+                else if (recLess(v[a], v[c])) recSwap(v[r], v[c]);
+                else recSwap(v[r], v[a]);
+            } else if (recLess(v[a], v[c])) recSwap(v[r], v[a]);
+            else if (recLess(v[b], v[c])) recSwap(v[r], v[c]);
+            else recSwap(v[r], v[b]);
+        }
+        int f = first + 1, l = last;                       // __unguarded_partition(first + 1, last, pivot = first)
+        for (;;) {
+            while (recLess(v[f], v[first])) ++f;
+            --l;
+            while (recLess(v[first], v[l])) --l;
+            if (!(f < l)) break;
+            recSwap(v[f], v[l]);
+            ++f;
+        }
+        if (f <= nth) first = f;
+        else last = f;
+    }
+    for (int i = first + 1; i < last; ++i) {               // __insertion_sort
+        const BinRec val = v[i];
+        if (recLess(val, v[first])) {
+            for (int j = i; j > first; --j) v[j] = v[j - 1];
+            v[first] = val;
+        } else {
+            int j = i;
+            while (recLess(val, v[j - 1])) { v[j] = v[j - 1]; --j; }
+            v[j] = val;
+        }
+    }
+}
+
+// One workgroup; dynamic LDS: re[8192], im[8192] doubles.  The transform is an in-place radix-2 DIF (bit-reversed output); natural bin
+// k sits at position brev13(k).  Only bins 0 .. 4096 are read afterwards, i.e. position 1 and the even positions, so |X[i]| of bin i
+// (1 <= i < 4096) is parked at re[brev13(i) + 1] -- the slot of bin i + 4096.
+__global__ void __launch_bounds__(1024) scopeSpectralKernel(const SpectralParams prm)
+{
+    extern __shared__ double spectralLds[];
+    double *re = spectralLds, *im = spectralLds + 8192;
+    __shared__ double sRed[2][16];
+    __shared__ double sRadians, sSampleDifference;
+    __shared__ long sOffset2;
+    const int tid = threadIdx.x;
+    SpectralDev *st = prm.st;
+    const uint32_t cursor = *prm.d_cursor, cap = prm.cap, len = uint32_t(st->ringSize);
+    constexpr uint32_t N = 8192;
+
+    {   // transformBuffer[i] = eval.evaluateSampleInc() from -max(ceil(effectiveWindowSize), LookaheadSize) (:92-99)
+        const long offset = long(fmax(ceil(prm.windowSize), double(N)));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = uint32_t(tid) + 1024u * j;
+            re[i] = evalD(prm.ringA, prm.ringB, prm.evalMode, logicalPhys(-offset + long(i), cursor, cap, len));
+            im[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    for (int s = 0; s < 13; ++s) {                         // DustFFT_fwdDa: forward DFT, fp64
+        const uint32_t half = 4096u >> s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = uint32_t(tid) + 1024u * j;
+            const uint32_t pos = b & (half - 1), i0 = ((b >> (12 - s)) << (13 - s)) + pos, i1 = i0 + half;
+            const double2 w = prm.tw[pos << s];
+            const double ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+            const double dr = ar - br, di = ai - bi;
+            re[i0] = ar + br; im[i0] = ai + bi;
+            re[i1] = dr * w.x - di * w.y; im[i1] = dr * w.y + di * w.x;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = uint32_t(tid) + 1024u * j;
+        if (i >= 1) { const uint32_t p = brev13(i); re[p + 1] = hypot(re[p], im[p]); }      // std::abs(complex<double>)
+    }
+    __syncthreads();
+
+    if (tid < 64) {                                        // the candidate scan (:134-181), 64 bins at a time
+        const int lane = tid;
+        auto mag = [&](uint32_t i) { return re[brev13(i) + 1]; };
+        auto quadDelta = [&](uint32_t w) -> double {       // :113-124
+            const uint32_t p0 = brev13(w), p1 = brev13(w + 1), pm = brev13(w == 0 ? 1 : w - 1);
+            const double dre = re[p0] * 2.0 - re[pm] - re[p1], dim = im[p0] * 2.0 - im[pm] - im[p1];
+            if ((dre + dim) == 0) return 0.0;
+            const double nre = re[pm] - re[p1], nim = im[pm] - im[p1];
+            return (nre * dre + nim * dim) / (dre * dre + dim * dim);
+        };
+        const double invHysteresis = 1 - prm.hysteresis, quarterSemitone = prm.quarterSemitone;
+        BinRec max;
+        max.index = 1;
+        max.value = fmax(prm.threshold * double(N) / 6.0, mag(1));
+        max.offset = quadDelta(1);
+        uint32_t start = 2;
+        while (start < (N >> 1)) {
+            const uint32_t i = start + uint32_t(lane);
+            const bool cand = i < (N >> 1) && invHysteresis * mag(i) > max.value * 2;      // candidate must be vastly better
+            const unsigned long long mask = __ballot(cand);
+            if (!mask) { start += 64; continue; }
+            const uint32_t k = start + uint32_t(__ffsll((long long)mask) - 1);
+            BinRec current{k, mag(k), 0.0};
+            if (recOmega(max) > 0) {
+                current.offset = quadDelta(k);
+                const double factor = recOmega(current) / recOmega(max);
+                const double sensivity = current.value / max.value;
+                if (invHysteresis * sensivity > 20) max = current;
+                else if (fabs(1 - factor) < invHysteresis * quarterSemitone) max = current;
+                else {
+                    const double multipleDeviation = fabs(factor - floor(factor + 0.5));
+                    if (invHysteresis * fabs(multipleDeviation) > quarterSemitone) max = current;
+                }
+            } else {
+                max = current;
+                max.offset = quadDelta(uint32_t(max.index));
+            }
+            start = k + 1;
+        }
+        if (lane == 0) {                                   // the median of 8 (:183-214)
+            BinRec localMedian[8];
+            for (int i = 0; i < 8; ++i) localMedian[i] = st->median[i];
+            st->median[st->medianPos] = max;
+            st->medianPos = (st->medianPos + 1) & 7ull;
+            nthElementByIndex(localMedian, 8, 4);
+            const BinRec oldMedianBin = localMedian[4];
+            if (oldMedianBin.index != ~0ull && fabs(recOmega(max) - recOmega(oldMedianBin)) > 0.5) max = oldMedianBin;
+            st->record = max;
+            double fundamental = prm.sampleRate * recOmega(max) / double(N);
+            st->fundamental = fundamental = fmax(5.0, fundamental);
+            const double cycleSamples = prm.sampleRate / fundamental;
+            st->cycleSamples = cycleSamples;
+            // calculateTriggeringOffset (:256-270)
+            const double tau = 6.283185307179586476925286766559;
+            const double radians = tau * recOmega(max) / double(N);
+            const double offsetReal = fmax(double(N), prm.windowSize + cycleSamples);
+            const unsigned long long offset = (unsigned long long)ceil(offsetReal);
+            sRadians = radians;
+            sSampleDifference = double(offset) - (prm.windowSize + cycleSamples);
+            sOffset2 = long(offset);
+        }
+    }
+    __syncthreads();
+    {   // cpl::dsp::goertzel: z = s[N-1] - exp(-i w) s[N-2] = sum_n x[n] exp(i w (N - 1 - n)) (oracle/scope_spectral.c); evaluated as the
+        // sum, all threads, fp64
+        const double radians = sRadians;
+        const long offset = sOffset2;
+        double zr = 0, zi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t n = uint32_t(tid) + 1024u * j;
+            const double x = evalD(prm.ringA, prm.ringB, prm.evalMode, logicalPhys(-offset + long(n), cursor, cap, len));
+            double sn, cs;
+            sincos(radians * double(N - 1 - n), &sn, &cs);
+            zr += x * cs; zi += x * sn;
+        }
+        for (int o = 32; o > 0; o >>= 1) { zr += __shfl_xor(zr, o); zi += __shfl_xor(zi, o); }
+        if ((tid & 63) == 0) { sRed[0][tid >> 6] = zr; sRed[1][tid >> 6] = zi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double zr = 0, zi = 0;
+        for (int w = 0; w < 16; ++w) { zr += sRed[0][w]; zi += sRed[1][w]; }
+        const double tau = 6.283185307179586476925286766559;
+        const double rotation = -sSampleDifference * sRadians;              // :272-278
+        const double cr = cos(rotation), ci = -sin(rotation);
+        const double wr = zr * cr - zi * ci, wi = zr * ci + zi * cr;
+        double phase = tau - atan2(wi, wr);
+        phase += st->record.offset * tau;
+        phase -= 1.5707963267948966192313216916398;
+        phase += tau * prm.phaseOffsetDeg / 360;
+        phase = fmod(phase, tau);
+        while (phase < 0) phase += tau;
+        st->phase = phase;
+        const double cycles = phase / tau;
+        st->sampleOffset = cycles * prm.sampleRate / st->fundamental - 1;
+        // resizeAudioStorage(Spectral) for this frame (ChannelData.h:113-117)
+        const unsigned long long need = (unsigned long long)(0.5 + st->cycleSamples + ceil(prm.windowSize));
+        st->ringSize = need > N ? need : N;
+    }
+}
+
 }  // namespace
 
 struct sgz_scope {
@@ -488,6 +859,12 @@ struct sgz_scope {
     uint32_t size = 0, backCap = 0;
     uint32_t trigSeparate = 0, trigPair = 0;
     float envelopeCoeff = 0.f;
+    // frequency colouring (colour_by_frequency)
+    ColourParams col{};
+    // Spectral triggering
+    SpectralDev *d_spectral = nullptr;
+    double2 *d_tw = nullptr;
+    sgz_trigger_state trig{};                             // triggerState as of the last sgz_scope_analyse (consumer thread)
     // vertex output (consumer side)
     float *d_xyz = nullptr; uint32_t *d_rgba = nullptr; size_t vertexCap = 0;
     void *h_out = nullptr; size_t hOutBytes = 0;          // pinned
@@ -500,7 +877,8 @@ static void scopeFree(sgz_scope *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->stage.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_peaks, (void *)s->d_swaps, (void *)s->d_front, (void *)s->d_back, (void *)s->d_xyz,
-                    (void *)s->d_rgba})
+                    (void *)s->d_rgba, (void *)s->col.st, (void *)s->col.bands, (void *)s->col.sm, (void *)s->col.block, (void *)s->col.front,
+                    (void *)s->col.back, (void *)s->d_spectral, (void *)s->d_tw})
         if (p) (void)hipFree(p);
     if (s->h_out) (void)hipHostFree(s->h_out);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -513,8 +891,19 @@ static sgz_status scopeValidate(const sgz_scope_config *c)
     if (!std::isfinite(c->window_size) || c->window_size < 0 || c->window_size > double(1u << 26)) return fail(SGZ_EINVAL, "window_size");
     if (c->num_channels < 2 || (c->num_channels & 1) || c->num_channels > kMaxCh)
         return fail(SGZ_EINVAL, "num_channels must be even, 2..64 (OscilloscopeDSP.inl:318)");
-    if (c->trigger_mode != SGZ_TRIG_NONE && c->trigger_mode != SGZ_TRIG_ZERO_CROSSING)
-        return fail(SGZ_EUNSUPPORTED, "trigger modes Spectral / Window / EnvelopeHold are not built (SURVEY 8(f) #3)");
+    if (c->trigger_mode != SGZ_TRIG_NONE && c->trigger_mode != SGZ_TRIG_ZERO_CROSSING && c->trigger_mode != SGZ_TRIG_SPECTRAL)
+        return fail(SGZ_EUNSUPPORTED, "trigger modes Window / EnvelopeHold are not built");
+    if (c->trigger_mode == SGZ_TRIG_SPECTRAL) {
+        if (!(c->trigger_hysteresis >= 0) || !(c->trigger_hysteresis <= 1)) return fail(SGZ_EINVAL, "trigger_hysteresis outside 0..1");
+        if (!std::isfinite(c->trigger_phase_offset)) return fail(SGZ_EINVAL, "trigger_phase_offset");
+        if (c->sample_rate / 5.0 + c->window_size > double(1u << 26)) return fail(SGZ_EINVAL, "ring too long");
+    }
+    if (c->colour_by_frequency) {
+        if (!(c->frequency_colouring_blend >= 0) || !(c->frequency_colouring_blend <= 1)) return fail(SGZ_EINVAL, "frequency_colouring_blend");
+        if (!(c->colour_smoothing_ms >= 0) || !std::isfinite(c->colour_smoothing_ms)) return fail(SGZ_EINVAL, "colour_smoothing_ms");
+        if (!(c->sample_rate > 2 * 3000.0)) return fail(SGZ_EINVAL, "frequency colouring needs a sample rate above 6 kHz (crossovers at 300 / 3000 Hz)");
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (!std::isfinite(c->band_colours[i][j])) return fail(SGZ_EINVAL, "band_colours");
+    }
     if (c->channel_mode > SGZ_OSC_MIDSIDE || c->envelope_mode > SGZ_ENV_PEAK_DECAY) return fail(SGZ_EINVAL, "enum value");
     if (c->interpolation != SGZ_SUBSAMPLE_LINEAR && c->interpolation != SGZ_SUBSAMPLE_LANCZOS)
         return fail(SGZ_EUNSUPPORTED, "sub-sample interpolation: Linear or Lanczos");
@@ -532,10 +921,16 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
     if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     SGZ_HIP(hipStreamSynchronize(s->stream));
     const uint32_t C = cfg->num_channels;
-    const uint32_t size = uint32_t(std::ceil(cfg->window_size + 1));                 // ChannelData.h:121
+    // ChannelData::resizeAudioStorage (ChannelData.h:107-128).  Spectral: the largest ring the reference can ask for (5 Hz floor of the
+    // fundamental); the reference's ring of the frame is cut out of it by the readers (sgz_trigger_state::ring_size)
+    uint32_t size = uint32_t(std::ceil(cfg->window_size + 1));                       // :121
+    if (cfg->trigger_mode == SGZ_TRIG_SPECTRAL)
+        size = uint32_t(std::max<size_t>(size_t(0.5 + cfg->sample_rate / 5.0 + std::ceil(cfg->window_size)), 8192));
     uint32_t backCap = 1; while (backCap < size) backCap <<= 1;
     const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
-    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock;
+    const bool colours = cfg->colour_by_frequency != 0;
+    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock ||
+                         colours != (s->cfg.colour_by_frequency != 0);
     ScopeDev h{};
     if (!fresh) SGZ_HIP(hipMemcpy(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost));
     if (realloc) {
@@ -551,6 +946,68 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_swaps), size_t(kMaxSwaps) * sizeof(Swap)));
         }
         h.frontCursor = 0; h.written = 0;
+        for (void **p : {(void **)&s->col.st, (void **)&s->col.bands, (void **)&s->col.sm, (void **)&s->col.block, (void **)&s->col.front,
+                         (void **)&s->col.back})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (colours) {
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.st), sizeof(ColourDev)));
+            SGZ_HIP(hipMemset(s->col.st, 0, sizeof(ColourDev)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.bands), size_t(C) * 4 * maxBlock * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.sm), size_t(C) * 6 * maxBlock * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.block), size_t(C) * 2 * maxBlock * sizeof(uint32_t)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.front), size_t(C) * 2 * size * sizeof(uint32_t)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->col.back), size_t(C) * 2 * backCap * sizeof(uint32_t)));
+            SGZ_HIP(hipMemset(s->col.front, 0, size_t(C) * 2 * size * sizeof(uint32_t)));
+            SGZ_HIP(hipMemset(s->col.back, 0, size_t(C) * 2 * backCap * sizeof(uint32_t)));
+        }
+        s->col.maxBlock = maxBlock;
+    }
+    if (colours) {
+        // tuneCrossOver(300, 3000, sampleRate), tuneColourSmoothing(ms, sampleRate) (ChannelData.h:163-171).  cpl's designs are not in the
+        // reference tree: the 3-band Linkwitz-Riley tree and the one-pole design are the published ones (oracle/scope_spectral.c)
+        auto butterworth = [](double fnorm, bool highpass, float *c) {
+            const double w0 = 6.283185307179586476925286766559 * fnorm;
+            const double cw = std::cos(w0), alpha = std::sin(w0) / (2.0 * 0.70710678118654752440);
+            const double a0 = 1 + alpha;
+            double b0, b1;
+            if (highpass) { b0 = (1 + cw) / 2; b1 = -(1 + cw); }
+            else { b0 = (1 - cw) / 2; b1 = 1 - cw; }
+            c[0] = float(b0 / a0); c[1] = float(b1 / a0); c[2] = float(b0 / a0);
+            c[3] = float(-2 * cw / a0); c[4] = float((1 - alpha) / a0);
+        };
+        const float f1 = float(300.0 / cfg->sample_rate), f2 = float(3000.0 / cfg->sample_rate);
+        butterworth(double(f1), false, s->col.lp1); butterworth(double(f1), true, s->col.hp1);
+        butterworth(double(f2), false, s->col.lp2); butterworth(double(f2), true, s->col.hp2);
+        s->col.pole = float(std::exp(-1.0 / (cfg->colour_smoothing_ms / 1000.0 * cfg->sample_rate)));
+        s->col.blend = 1 - cfg->frequency_colouring_blend;                               // OscilloscopeDSP.inl:515
+        std::memcpy(s->col.band, cfg->band_colours, sizeof(s->col.band));
+        for (uint32_t c = 0; c < C; ++c) std::memcpy(&s->col.keys[c], cfg->colours[c], 4);
+    }
+    if (cfg->trigger_mode == SGZ_TRIG_SPECTRAL) {
+        if (!s->d_tw) {
+            std::vector<double2> tw(4096);
+            for (int k = 0; k < 4096; ++k) {
+                const double a = -6.283185307179586476925286766559 * double(k) / 8192.0;
+                tw[k] = make_double2(std::cos(a), std::sin(a));
+            }
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_tw), sizeof(double2) * 4096));
+            SGZ_HIP(hipMemcpy(s->d_tw, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_spectral), sizeof(SpectralDev)));
+            SGZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scopeSpectralKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * 8192 * int(sizeof(double))));
+        }
+        if (realloc || s->cfg.trigger_mode != SGZ_TRIG_SPECTRAL) {
+            SpectralDev sd{};                                                             // Oscilloscope(): medianPos(), value-initialised filter
+            sd.ringSize = std::max<size_t>(size_t(0.5 + 0.0 + std::ceil(cfg->window_size)), 8192);
+            SGZ_HIP(hipMemcpy(s->d_spectral, &sd, sizeof(sd), hipMemcpyHostToDevice));
+            s->trig = sgz_trigger_state{};
+            s->trig.ring_size = sd.ringSize;
+        }
+    } else {
+        s->trig = sgz_trigger_state{};
+        s->trig.ring_size = size;
+        if (cfg->trigger_mode == SGZ_TRIG_ZERO_CROSSING)                                  // calculateTriggeringOffset :233-240
+            s->trig.sample_offset = (cfg->window_size * 0.5 - double(int(cfg->window_size * 0.5))) - 1.5;
     }
     // TriggeringProcessor::setSettings, StreamPreprocessing.h:46-53
     h.windowChanged = std::ceil(cfg->window_size) != std::ceil(h.windowSize) ? 1 : 0;
@@ -608,7 +1065,8 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     prm.front = s->d_front; prm.size = s->size; prm.back = s->d_back; prm.backCap = s->backCap;
     prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
     prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
-    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm);
+    prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
+    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->col);
     SGZ_HIP(hipGetLastError());
     return s->stage.commit(s->stream);
 }
@@ -617,9 +1075,11 @@ sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes
 {
     if (!s || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
     // coeff = pow(exp(-lanes / (envelopeWindow * sampleRate)), numSamples * dt), OscilloscopeDSP.inl:745-747
-    const double power = double(s->size) * delta_time;
+    const bool spectral = s->cfg.trigger_mode == SGZ_TRIG_SPECTRAL;
+    const uint32_t numSamples = spectral ? uint32_t(s->trig.ring_size) : s->size;          // audioData.getSize()
+    const double power = double(numSamples) * delta_time;
     const double coeff = std::pow(std::exp(-double(lanes) / (s->cfg.envelope_window * s->cfg.sample_rate)), power);
-    PeakParams prm{s->d_state, s->d_front, s->size, s->cfg.num_channels, s->cfg.channel_mode, lanes, coeff};
+    PeakParams prm{s->d_state, s->d_front, s->size, s->cfg.num_channels, s->cfg.channel_mode, lanes, coeff, spectral ? numSamples : 0u};
     hipLaunchKernelGGL(scopePeakKernel, dim3(1), dim3(1024), 0, s->stream, prm);
     SGZ_HIP(hipGetLastError());
     if (auto_gain) {
@@ -653,6 +1113,16 @@ sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out, uint32_t 
     return SGZ_OK;
 }
 
+sgz_status sgz_scope_front_colours(sgz_scope *s, uint32_t channel, uint32_t aux, uint8_t *out)
+{
+    if (!s || !out || channel >= s->cfg.num_channels || aux > 1) return fail(SGZ_EINVAL, "bad argument");
+    if (!s->cfg.colour_by_frequency) return fail(SGZ_EINVAL, "colour_by_frequency is off");
+    const size_t plane = size_t(aux ? s->cfg.num_channels : 0u) + channel;
+    SGZ_HIP(hipMemcpyAsync(out, s->col.front + plane * s->size, size_t(s->size) * 4, hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    return SGZ_OK;
+}
+
 sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8])
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
@@ -669,7 +1139,44 @@ size_t sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view)
     if (!s || !view || view->width < 2 || !(view->right > view->left)) return 0;
     sgz_scope_view v = *view;
     v.window_size = s->cfg.window_size;
-    return scopeVertexCount(v, s->cfg.interpolation);
+    return scopeVertexCount(v, s->cfg.interpolation, s->cfg.trigger_mode, s->trig.cycle_samples);
+}
+
+sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel, sgz_trigger_state *out)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (s->cfg.trigger_mode == SGZ_TRIG_SPECTRAL) {
+        const uint32_t C = s->cfg.num_channels;
+        uint32_t chA, chB, evalMode;
+        switch (evaluator) {
+        case SGZ_OSC_LEFT: chA = chB = channel; evalMode = 0; break;
+        case SGZ_OSC_RIGHT: chA = chB = channel + 1; evalMode = 0; break;
+        case SGZ_OSC_MID: chA = channel; chB = channel + 1; evalMode = 1; break;
+        case SGZ_OSC_SIDE: chA = channel; chB = channel + 1; evalMode = 2; break;
+        default: return fail(SGZ_EINVAL, "evaluator: SGZ_OSC_LEFT / RIGHT / MID / SIDE");
+        }
+        if (chA >= C || chB >= C) return fail(SGZ_EINVAL, "channel out of range");
+        SpectralParams prm{};
+        prm.st = s->d_spectral;
+        prm.ringA = s->d_front + size_t(chA) * s->size; prm.ringB = s->d_front + size_t(chB) * s->size;
+        prm.evalMode = evalMode; prm.cap = s->size;
+        prm.d_cursor = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor));
+        prm.windowSize = s->cfg.window_size; prm.sampleRate = s->cfg.sample_rate;
+        prm.threshold = s->cfg.trigger_threshold; prm.hysteresis = s->cfg.trigger_hysteresis;
+        prm.phaseOffsetDeg = s->cfg.trigger_phase_offset;
+        prm.quarterSemitone = std::pow(2, 0.25 / 12.0) - 1;                                  // OscilloscopeDSP.inl:126
+        prm.tw = s->d_tw;
+        hipLaunchKernelGGL(scopeSpectralKernel, dim3(1), dim3(1024), 2 * 8192 * sizeof(double), s->stream, prm);
+        SGZ_HIP(hipGetLastError());
+        SpectralDev h;
+        SGZ_HIP(hipMemcpyAsync(&h, s->d_spectral, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+        SGZ_HIP(hipStreamSynchronize(s->stream));
+        s->trig.record_index = h.record.index; s->trig.record_value = h.record.value; s->trig.record_offset = h.record.offset;
+        s->trig.fundamental = h.fundamental; s->trig.cycle_samples = h.cycleSamples; s->trig.sample_offset = h.sampleOffset;
+        s->trig.phase = h.phase; s->trig.ring_size = h.ringSize;
+    }
+    if (out) *out = s->trig;
+    return SGZ_OK;
 }
 
 sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz, uint8_t *rgba,
@@ -690,7 +1197,7 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     if (chA >= C || chB >= C) return fail(SGZ_EINVAL, "channel out of range");
     sgz_scope_view v = *view;
     v.window_size = s->cfg.window_size;                               // state.effectiveWindowSize is the stream's
-    const size_t need = scopeVertexCount(v, s->cfg.interpolation);
+    const size_t need = scopeVertexCount(v, s->cfg.interpolation, s->cfg.trigger_mode, s->trig.cycle_samples);
     if (need > *count) { *count = uint32_t(need); return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
     if (s->vertexCap < need) {
         if (s->d_xyz) (void)hipFree(s->d_xyz);
@@ -705,10 +1212,15 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     uint32_t key;
     std::memcpy(&key, s->cfg.colours[colourCh], 4);                    // evaluator.getDefaultKey()
     size_t points = 0;
+    // colourChannelsByFrequency: Left / Right read colourData of their channel, Mid / Side auxColourData (SampleColourEvaluators.h:64,183)
+    const uint32_t *colRing = nullptr;
+    if (s->cfg.colour_by_frequency && rgba)
+        colRing = s->col.front + size_t((evalMode == 0 ? 0u : C) + colourCh) * s->size;
     SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, s->d_front + size_t(chA) * s->size,
-                                s->d_front + size_t(chB) * s->size, evalMode, s->size,
+                                s->d_front + size_t(chB) * s->size, evalMode, uint32_t(s->trig.ring_size), s->size,
                                 reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
-                                key, s->d_xyz, rgba ? s->d_rgba : nullptr, need, &points, s->stream));
+                                s->trig.cycle_samples, s->trig.sample_offset, key, colRing, s->d_xyz, rgba ? s->d_rgba : nullptr, need,
+                                &points, s->stream));
     float *hx = static_cast<float *>(s->h_out);
     uint32_t *hc = reinterpret_cast<uint32_t *>(hx + need * 3);
     SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, points * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));

@@ -24,7 +24,8 @@ namespace {
 struct ScopeScalars { double samplePos0, inc, samplesPerPixel, unit0, right, pixelsPerSample; long cursor0; size_t points; };
 
 // triggerMode: OscilloscopeContent::TriggeringMode (0 None, 4 ZeroCrossing)
-ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMode = SGZ_TRIG_ZERO_CROSSING)
+ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMode = SGZ_TRIG_ZERO_CROSSING, double cycleSamples = 0.0,
+                         double sampleOffset = 0.0)
 {
     ScopeScalars s{};
     const double horizontalDelta = v.right - v.left;
@@ -34,6 +35,8 @@ ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMo
     double samplePos;
     if (triggerMode == SGZ_TRIG_ZERO_CROSSING)
         samplePos = (v.window_size * 0.5 - double(int(v.window_size * 0.5))) - 1.5;          // triggerState.sampleOffset, OscilloscopeDSP.inl:238
+    else if (triggerMode == SGZ_TRIG_SPECTRAL)
+        samplePos = cycleSamples * 2 + v.window_size - sampleOffset;                         // :810 (no ceil: :814-819 is None / Window only)
     else
         samplePos = std::ceil(0.0 * 2 + v.window_size - 0.0);                                // :806-816 (cycleSamples = sampleOffset = 0)
     s.inc = horizontalDelta / (v.rendering_scale * (double(v.width) - 1));                   // :822
@@ -134,19 +137,44 @@ __device__ __forceinline__ float evalSample(const float *a, const float *b, uint
     return a[idx];
 }
 
+// The reference's ring of `len` samples inside a physical ring of `cap` >= len (Spectral mode keeps the largest ring the reference can
+// ask for, see sgz.h): logical position q (counted from the write cursor = the oldest of the newest `len` samples) -> memory index.
+// cap == len (every other mode): (cursor + q) mod len, the ring itself.
+__device__ __forceinline__ uint32_t ringPhys(long rel, uint32_t cursor, uint32_t cap, uint32_t len)
+{
+    long q = rel % long(len);
+    if (q < 0) q += long(len);
+    return uint32_t((long(cursor) + long(cap - len) + q) % long(cap));
+}
+// UPixel::lerp(other, t) with a double t (currentColour.lerp(nextColour, delta), OscilloscopeRendering.cpp:876): per component
+// (uint8)(a + (b - a) t)
+__device__ __forceinline__ uint32_t lerpRgba(uint32_t a, uint32_t b, double t)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double x = double((a >> (8 * k)) & 255u), y = double((b >> (8 * k)) & 255u);
+        const double v = x + (y - x) * t;
+        const uint32_t c = (!(v > -1.0) || !(v < 256.0)) ? 0u : uint32_t(int(v)) & 255u;
+        out |= c << (8 * k);
+    }
+    return out;
+}
+
 __global__ void __launch_bounds__(256)
-scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, const uint32_t *d_cursor, size_t points,
-                       double samplePos0, double spp, double unit0, double inc, long cursor0, uint32_t key, float3 *xyz, uint32_t *rgba)
+scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, uint32_t cap, const uint32_t *d_cursor,
+                       size_t points, double samplePos0, double spp, double unit0, double inc, long cursor0, uint32_t key,
+                       const uint32_t *colRing, float3 *xyz, uint32_t *rgba)
 {
     const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= points) return;
-    const long base = long(*d_cursor);                      // cursorPosition(): the evaluator's offsets count from it
+    const uint32_t base = *d_cursor;                        // cursorPosition(): the evaluator's offsets count from it
     const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
     const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
     const double delta = D - shifts;
     const double x = 10.0 + delta;
     const long fl = long(floor(x));
-    const long cur = (base + cursor0 + long(shifts)) % long(len);
+    const long cur = cursor0 + long(shifts);                // logical position of kernel[0]
     const double kPi = 3.14159265358979323846;
     const long rn = long(rint(x));
     const double e = x - double(rn);
@@ -171,24 +199,25 @@ scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode
             const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
             wt = 10.0 * sa * sb / (pd * pd);
         }
-        long idx = (idx0 + t) % long(len); if (idx < 0) idx += long(len);
-        acc += double(evalSample(ringA, ringB, evalMode, uint32_t(idx))) * wt;
+        acc += double(evalSample(ringA, ringB, evalMode, ringPhys(idx0 + t, base, cap, len))) * wt;
     }
     xyz[p] = make_float3(float(unit0 + double(p) * inc), float(acc), 0.f);
-    if (rgba) rgba[p] = key;
+    if (rgba) {
+        // colourChannelsByFrequency: the colours of the two newest kernel samples, blended by delta (:836-843, :874-877)
+        rgba[p] = colRing ? lerpRgba(colRing[ringPhys(cur + 19, base, cap, len)], colRing[ringPhys(cur + 20, base, cap, len)], delta) : key;
+    }
 }
 
 // Linear: vertex i = (i, sample[cursor - bufferOffset + i], 0), i < endCondition (OscilloscopeRendering.cpp:707-741)
 __global__ void __launch_bounds__(256)
-scopeWaveLinearKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, const uint32_t *d_cursor, size_t points,
-                      long start0, uint32_t key, float3 *xyz, uint32_t *rgba)
+scopeWaveLinearKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, uint32_t cap, const uint32_t *d_cursor,
+                      size_t points, long start0, uint32_t key, const uint32_t *colRing, float3 *xyz, uint32_t *rgba)
 {
     const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= points) return;
-    long idx = (long(*d_cursor) + start0 + long(p)) % long(len);
-    if (idx < 0) idx += long(len);
-    xyz[p] = make_float3(float(p), evalSample(ringA, ringB, evalMode, uint32_t(idx)), 0.f);
-    if (rgba) rgba[p] = key;
+    const uint32_t idx = ringPhys(start0 + long(p), *d_cursor, cap, len);
+    xyz[p] = make_float3(float(p), evalSample(ringA, ringB, evalMode, idx), 0.f);
+    if (rgba) rgba[p] = colRing ? colRing[idx] : key;      // :664-677: drawer.addColour(data.second) per sample
 }
 
 // ------------------------------------------------------------------------------------------- K10
@@ -410,35 +439,43 @@ bool waveIsLanczos(const sgz_scope_view &v, uint32_t interpolation)
 
 namespace sgz {
 
-size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation)
+size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation, uint32_t triggerMode, double cycleSamples)
 {
     if (waveIsLanczos(view, interpolation)) return scopeDerive(view, 0).points;
-    return size_t(std::max<long>(2, long(std::ceil(view.window_size))));            // endCondition = roundedWindow (:614, :631)
+    // endCondition = roundedWindow + quantizedCycleSamples (:614, :631)
+    const long quantizedCycleSamples = triggerMode == SGZ_TRIG_SPECTRAL ? long(std::ceil(cycleSamples)) : 0;
+    return size_t(std::max<long>(2, long(std::ceil(view.window_size))) + quantizedCycleSamples);
 }
 
+// ringA / ringB / colRing: one channel's plane of the physical ring (`cap` elements); `size`: the reference's ring of the moment
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
-                               const float *ringB, uint32_t evalMode, uint32_t size, const uint32_t *d_cursor, uint32_t rgba,
-                               float *d_xyz, uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
+                               const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
+                               double cycleSamples, double sampleOffset, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
+                               uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
 {
     const int block = 256;
     if (waveIsLanczos(view, interpolation)) {
-        const ScopeScalars s = scopeDerive(view, size, triggerMode);
+        const ScopeScalars s = scopeDerive(view, size, triggerMode, cycleSamples, sampleOffset);
         if (s.points > capacity) return hipErrorInvalidValue;
         hipLaunchKernelGGL(scopeWaveLanczosKernel, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, ringA, ringB,
-                           evalMode, size, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0, rgba,
-                           reinterpret_cast<float3 *>(d_xyz), d_rgba);
+                           evalMode, size, cap, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0, rgba,
+                           colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba);
         *points = s.points;
     } else {
         const long roundedWindow = long(std::ceil(view.window_size));
-        long bufferOffset;
+        long bufferOffset, quantizedCycleSamples = 0;
         if (triggerMode == SGZ_TRIG_ZERO_CROSSING) {
             const double realOffset = (view.window_size * 0.5 - double(int(view.window_size * 0.5))) - 1.5;
             bufferOffset = long(std::ceil(realOffset));                                 // :593-594
-        } else bufferOffset = roundedWindow;                                            // :611 (no cycle buffers: triggering is off)
-        const size_t n = size_t(std::max<long>(2, roundedWindow));
+        } else {
+            // :598-612; this branch is never Lanczos, so cycleBuffers = 1
+            if (triggerMode != SGZ_TRIG_NONE) quantizedCycleSamples = long(std::ceil(cycleSamples));
+            bufferOffset = roundedWindow + quantizedCycleSamples;
+        }
+        const size_t n = size_t(std::max<long>(2, roundedWindow) + quantizedCycleSamples);
         if (n > capacity) return hipErrorInvalidValue;
         hipLaunchKernelGGL(scopeWaveLinearKernel, dim3(unsigned((n + block - 1) / block)), dim3(block), 0, stream, ringA, ringB, evalMode,
-                           size, d_cursor, n, -bufferOffset, rgba, reinterpret_cast<float3 *>(d_xyz), d_rgba);
+                           size, cap, d_cursor, n, -bufferOffset, rgba, colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba);
         *points = n;
     }
     return hipGetLastError();

@@ -184,6 +184,161 @@ def test_push_never_waits_and_rejects_bad_input(gpu):
     assert res.count(api.SGZ_OK) >= 8
     assert dt < 5.0
     with pytest.raises(api.SgzError):
-        api.Scope(**_cfg(trigger_mode=1))                              # Spectral: not built
+        api.Scope(**_cfg(trigger_mode=3))                              # EnvelopeHold: not built
     with pytest.raises(api.SgzError):
         api.Scope(**_cfg(num_channels=3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# frequency colouring and Spectral triggering
+
+BANDS = [(1.0, 0.25, 0.1), (0.2, 1.0, 0.3), (0.15, 0.35, 1.0)]
+KEYS = [(10, 20, 30, 255), (200, 100, 50, 255), (0, 255, 0, 128), (90, 90, 255, 255)]
+
+
+def _colour_signal(seed, n, channels, sr):
+    """tones in all three bands with slowly moving weights + noise: the band energies (hence the colours) keep changing"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    x = np.zeros((channels, n), np.float32)
+    for c in range(channels):
+        w = 0.5 + 0.5 * np.sin(2 * np.pi * (1.3 + c) * t[:, None] * np.array([0.7, 1.1, 1.9]) + c)
+        x[c] = (w[:, 0] * np.sin(2 * np.pi * 97.0 * t + c) + w[:, 1] * np.sin(2 * np.pi * 1130.0 * t) * (0.8 if c & 1 else 1.0)
+                + w[:, 2] * 0.7 * np.sin(2 * np.pi * 7900.0 * t + 0.3 * c) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("over", [
+    dict(trigger_mode=0, window_size=3000.0),                                      # straight into the front rings
+    dict(trigger_mode=4, window_size=1500.5, trigger_threshold=0.1),               # colours travel through the back rings and the swaps
+    dict(trigger_mode=4, window_size=700.0, num_channels=4, channel_mode=4, trigger_channel=3.0, frequency_colouring_blend=0.35),
+    dict(trigger_mode=0, window_size=900.0, sample_rate=44100.0, colour_smoothing_ms=0.5, frequency_colouring_blend=0.0),
+])
+def test_frequency_colouring_is_bit_exact(gpu, oracle, over):
+    """audioProcessing's colour path (OscilloscopeDSP.inl:445-517, :588-647): 3-band crossover, band-energy smoothers, accumulateColour,
+    for left / right (colourData) and mid / side (auxColourData), in rings that move with the audio rings -- every fp32 operation in the
+    oracle's order, so the RGBA8 rings must be identical"""
+    po = oracle
+    cfg = _cfg(colour_by_frequency=1, frequency_colouring_blend=0.8, colour_smoothing_ms=4.0, band_colours=BANDS, colours=KEYS)
+    cfg.update(over)
+    C = cfg["num_channels"]
+    sr = cfg["sample_rate"]
+    x = _colour_signal(2, 60000, C, sr)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(C, sr, cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"], cfg["channel_mode"],
+                         cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
+    ref.enable_colours(BANDS, cfg["frequency_colouring_blend"], cfg["colour_smoothing_ms"], (KEYS * 16)[:C])
+    rng = np.random.default_rng(8)
+    pos = 0
+    while pos < x.shape[1]:
+        n = int(rng.integers(1, 2500))
+        _push(dev, x[:, pos:pos + n]); ref.audio(x[:, pos:pos + n])
+        pos += n
+    assert dev.state() == ref.state()
+    distinct = 0
+    for c in range(C):
+        a, cur = dev.front(c)
+        b, wcur = ref.front(c)
+        assert cur == wcur and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for aux in (False, True):
+            got = dev.front_colours(c, aux)
+            want, _ = ref.front_colours(c, aux)
+            assert np.array_equal(got, want), (c, aux, int((got != want).sum()), got[:4], want[:4])
+            distinct += len(np.unique(got))
+    assert distinct > 50 * C                                                       # the colours really vary along the ring
+
+    # per-vertex colours of drawWavePlot (Linear: the sample's colour; Lanczos: lerp of the two newest kernel samples)
+    W = cfg["window_size"]
+    for interp, width in ((3, 4 * int(W) + 1), (2, 400)):
+        dev.configure(interpolation=interp)
+        for evaluator in range(4):
+            v = api.ScopeView(W, 0.1, 0.9, 1.0, width, 0)
+            vo = po.ScopeView(W, 0.1, 0.9, 1.0, width, 0)
+            m0, cur = ref.front(0)
+            m1, _ = ref.front(1)
+            if evaluator == 0: a, b, em, cm = m0, m0, 0, ref.front_colours(0, False)[0]
+            elif evaluator == 1: a, b, em, cm = m1, m1, 0, ref.front_colours(1, False)[0]
+            elif evaluator == 2: a, b, em, cm = m0, m1, 1, ref.front_colours(0, True)[0]
+            else: a, b, em, cm = m0, m1, 2, ref.front_colours(1, True)[0]
+            want, wcol = po.scope_wave_plot_ex(vo, cfg["trigger_mode"], interp, a, b, em, cur, 0.0, 0.0, cm)
+            got, gcol = dev.vertices(v, evaluator, 0)
+            assert got.shape == want.shape
+            assert np.abs(got[:, 1] - want[:, 1]).max() <= 2e-6
+            # the lerp weight is a difference of fp64 sums computed in closed form on the device: a component may land on the other
+            # side of an integer once in a long while
+            diff = np.abs(gcol.astype(int) - wcol.astype(int))
+            assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, (interp, evaluator, diff.max(), (diff != 0).mean())
+
+
+def _tone(n, sr, f0, seed, harmonics=(1.0, 0.5, 0.25)):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    x = sum(a * np.sin(2 * np.pi * f0 * (k + 1) * t + 0.7 * k) for k, a in enumerate(harmonics))
+    return np.stack([x + 0.01 * rng.standard_normal(n), 0.6 * x + 0.01 * rng.standard_normal(n)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("sr,window,f0,evaluator,hyst", [
+    (48000.0, 2000.0, 441.3, 0, 0.0), (48000.0, 12000.5, 97.0, 2, 0.3), (192000.0, 19200.0, 1234.5, 1, 0.1), (44100.0, 800.0, 60.0, 3, 0.0)])
+def test_spectral_trigger_against_the_oracle(gpu, oracle, sr, window, f0, evaluator, hyst):
+    """sgz_scope_analyse = calculateFundamentalPeriod + calculateTriggeringOffset on the device ring, frame after frame (the median of 8
+    makes it stateful), then drawWavePlot with cycleSamples / sampleOffset inside the reference's ring of the moment.
+    Integer decisions (winning bin, median record, ring size) identical; fp64 results to 1e-9 relative (the transform's butterfly
+    order and the Goertzel sum's order differ), sampleOffset to 1e-6 samples."""
+    po = oracle
+    cfg = _cfg(sample_rate=sr, window_size=window, trigger_mode=1, trigger_threshold=0.02, trigger_hysteresis=hyst,
+               trigger_phase_offset=30.0, interpolation=3, envelope_mode=2)
+    x = _tone(int(sr * 1.2), sr, f0, seed=4)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(2, sr, window, 1, 0.02, 0, 1.0, 2, 0.3)
+    ts = po.SpectralState()
+    sz = max(int(0.5 + 0.0 + np.ceil(window)), 8192)
+    em = {0: 0, 1: 0, 2: 1, 3: 2}[evaluator]
+    pos = 0
+    block = 1777
+    for frame in range(12):
+        for _ in range(6):
+            _push(dev, x[:, pos:pos + block]); ref.audio(x[:, pos:pos + block]); pos += block
+        mem = [ref.logical(c, sz) for c in (0, 1)]
+        a, b = (mem[1], mem[1]) if evaluator == 1 else (mem[0], mem[1]) if em else (mem[0], mem[0])
+        po.scope_analyse(ts, a, b, em, 0, window, sr, 0.02, hyst, 30.0)
+        got = dev.analyse(evaluator, 0)
+        assert got.record_index == ts.record.index, (frame, got.record_index, ts.record.index)
+        assert abs(got.record_value - ts.record.value) <= 1e-9 * max(1.0, ts.record.value)
+        assert abs(got.record_offset - ts.record.offset) <= 1e-8
+        assert abs(got.fundamental - ts.fundamental) <= 1e-8 * ts.fundamental
+        assert abs(got.cycle_samples - ts.cycle_samples) <= 1e-8 * ts.cycle_samples
+        assert abs(got.sample_offset - ts.sample_offset) <= 1e-6, (frame, got.sample_offset, ts.sample_offset)
+        sz = max(int(0.5 + ts.cycle_samples + np.ceil(window)), 8192)
+        assert got.ring_size == sz
+        if frame >= 5:
+            assert abs(got.fundamental - f0) < 0.02 * f0 + 0.5
+        if frame in (2, 7, 11):
+            # the vertices of this frame, both interpolations (the device call uses its own fp64 cycleSamples / sampleOffset)
+            mem = [ref.logical(c, sz) for c in (0, 1)]
+            a, b = (mem[1], mem[1]) if evaluator == 1 else (mem[0], mem[1]) if em else (mem[0], mem[0])
+            for interp, width in ((3, 2 * int(window) + 1), (2, 300)):
+                dev.configure(interpolation=interp)
+                v = api.ScopeView(window, 0.0, 1.0, 1.0, width, 0)
+                vo = po.ScopeView(window, 0.0, 1.0, 1.0, width, 0)
+                want, _ = po.scope_wave_plot_ex(vo, 1, interp, a, b, em, 0, got.cycle_samples, got.sample_offset)
+                g, _ = dev.vertices(v, evaluator, 0)
+                assert g.shape == want.shape, (g.shape, want.shape)
+                assert np.array_equal(g[:, 0], want[:, 0])
+                assert np.abs(g[:, 1] - want[:, 1]).max() <= (2e-6 if interp == 3 else 0.0)
+    # runPeakFilter over the reference's ring of the moment (the newest ring_size samples; envelopes start at 0 on both sides)
+    dt = 1 / 60
+    coeff = float(np.power(np.exp(-8.0 / (0.3 * sr)), sz * dt))
+    scratch = po.ScopeStream(2, sr, float(sz - 1), 0, 0.0, 0, 1.0, 2, 0.3)       # a ring of exactly sz samples, written once: cursor 0
+    assert scratch.size == sz
+    scratch.audio(np.stack([ref.logical(c, sz) for c in (0, 1)]))
+    assert dev.peak_filter(dt, 8) == scratch.peak_filter(8, coeff)
+    dev.close()
+
+
+def test_spectral_rejects_bad_config(gpu):
+    with pytest.raises(api.SgzError):
+        api.Scope(**_cfg(trigger_mode=1, trigger_hysteresis=1.5))
+    with pytest.raises(api.SgzError):
+        api.Scope(**_cfg(trigger_mode=2))                                          # Window: not built
+    with pytest.raises(api.SgzError):
+        api.Scope(**_cfg(colour_by_frequency=1, sample_rate=4000.0, band_colours=BANDS))
