@@ -252,6 +252,21 @@ sgz_status sgz_spectrum_configure(sgz_spectrum *s, const sgz_spectrum_config *cf
 sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
 /* frameQueue.popElement -> RGBA8 column of P pixels; SGZ_EMPTY when none is ready */
 sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint32_t *axis_points);
+/* Display hand-off without the host: instead of popping columns and uploading each with
+ * oglImage.updateSingleColumn (SpectrumRendering.cpp:696-721, :742-744), bind a device image of P rows x `columns` RGBA8 texels and
+ * let sgz_spectrum_flush_columns (consumer thread, in place of the pop loop) scatter every ready column into it at
+ * x = framePixelPosition, wrapping at `columns`; *first_column / *count name the texel columns written by this call (SGZ_EMPTY: none).
+ *   sgz_spectrum_bind_image     caller-owned DEVICE memory (any mapped interop resource); d_image = NULL unbinds
+ *   sgz_spectrum_create_image   the library allocates the image and exports it as a dma-buf fd (the caller closes it): an MI355X has
+ *                               no graphics engine, the GL / Vulkan context of the display GPU imports the fd
+ *                               (EXT_memory_object_fd, EGL_EXT_image_dma_buf_import); dmabuf_fd may be NULL
+ *   sgz_spectrum_bind_gl_buffer an OpenGL buffer object (e.g. a pixel-unpack buffer the texture is updated from) of a context that is
+ *                               current on this thread and lives on the same device: hipGraphicsGLRegisterBuffer + map
+ * A configure drops the binding (the image height is the axis size). */
+sgz_status sgz_spectrum_bind_image(sgz_spectrum *s, void *d_image, uint32_t columns, size_t pitch_bytes);
+sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d_image, size_t *pitch_bytes, int *dmabuf_fd);
+sgz_status sgz_spectrum_bind_gl_buffer(sgz_spectrum *s, unsigned int gl_buffer, uint32_t columns, size_t pitch_bytes);
+sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, uint32_t *count);
 /* lineGraphs[graph].getResults(P) for pair `pair`: float2 [P] (TransformPair.h:72-76) */
 sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t graph, float *out /*2*P*/);
 sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                                   /* clearAudioState, TransformPair.h:177-184 */

@@ -119,7 +119,8 @@ EXPORTS = [
     "sgz_spectrogram_render_sharded",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
-    "sgz_spectrum_stats", "sgz_spectrum_history",
+    "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
+    "sgz_spectrum_flush_columns",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours",
@@ -198,6 +199,10 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_set_mix.argtypes = [vp, u32, vp]
     L.sgz_spectrum_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sgz_spectrum_history.argtypes = [vp, u32, vp]
+    L.sgz_spectrum_bind_image.argtypes = [vp, vp, u32, sz]
+    L.sgz_spectrum_create_image.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]
+    L.sgz_spectrum_bind_gl_buffer.argtypes = [vp, C.c_uint, u32, sz]
+    L.sgz_spectrum_flush_columns.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_create.argtypes = [C.POINTER(ScopeConfig), C.POINTER(vp)]
     L.sgz_scope_destroy.argtypes = [vp]
     L.sgz_scope_destroy.restype = None

@@ -22,7 +22,17 @@
 // push never waits for the GPU: staging slots and column slots are checked with hipEventQuery / atomics, allocations and LDS
 // grants happen in create / configure (a warm-up render of the largest batch), and a push that finds the GPU too far behind
 // returns SGZ_BUSY without having consumed anything.
+//
+// Display hand-off without the host (replaces oglImage.updateSingleColumn per popped frame,
+// SpectrumRendering.cpp:696-721, :742-744).  The column queue also exists in HBM; sgz_spectrum_flush_columns (consumer thread)
+// scatters every ready column into a bound device image [P rows][pitch] at x = framePixelPosition -- exactly the texels
+// updateSingleColumn would upload.  The image is (a) caller-owned device memory (sgz_spectrum_bind_image: any mapped interop
+// resource), (b) allocated here and exported as a dma-buf fd (sgz_spectrum_create_image: the MI355X has no graphics engine, so the
+// GL / Vulkan context lives on the display GPU and imports the fd with EXT_memory_object_fd / EGL_EXT_image_dma_buf_import), or
+// (c) an OpenGL buffer object of a context on the same device, registered and mapped through HIP's GL interop
+// (sgz_spectrum_bind_gl_buffer).
 #include <hip/hip_runtime.h>
+#include <hip/hip_gl_interop.h>
 
 #include <atomic>
 #include <cstring>
@@ -55,6 +65,13 @@ ringIngestKernel(const float *src, uint32_t n, uint32_t numSrc, const uint8_t *m
     r[p] = v;
     r[p + cap] = v;
 }
+
+// texel (x, y) = column[y]: what updateSingleColumn(x, column) uploads into a P-row texture
+__global__ void __launch_bounds__(256) columnScatterKernel(const uint32_t *column, uint8_t *image, size_t pitch, uint32_t x, uint32_t P)
+{
+    const uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < P) *reinterpret_cast<uint32_t *>(image + size_t(y) * pitch + size_t(x) * 4) = column[y];
+}
 }  // namespace
 
 struct sgz_spectrum {
@@ -78,7 +95,25 @@ struct sgz_spectrum {
     // SPSC column queue: the producer fills slot tail % depth and bumps tail, the consumer reads slot head % depth and bumps head
     std::atomic<uint64_t> qHead{0}, qTail{0};
     std::atomic<uint64_t> dropped{0}, busy{0};
+    // display hand-off (consumer thread): device copy of the queue slots, the bound image, framePixelPosition
+    uint8_t *d_colsQ = nullptr;       // [kQueueDepth][P][4]
+    hipStream_t outStream = nullptr;
+    uint8_t *d_image = nullptr; size_t imgPitch = 0; uint32_t imgColumns = 0, imgX = 0;
+    bool imgOwned = false;
+    hipGraphicsResource *glResource = nullptr;
 };
+
+static void unbindImage(sgz_spectrum *s)
+{
+    if (s->outStream) (void)hipStreamSynchronize(s->outStream);
+    if (s->glResource) {
+        (void)hipGraphicsUnmapResources(1, &s->glResource, s->outStream);
+        (void)hipGraphicsUnregisterResource(s->glResource);
+        s->glResource = nullptr;
+    }
+    if (s->imgOwned && s->d_image) (void)hipFree(s->d_image);
+    s->d_image = nullptr; s->imgOwned = false; s->imgColumns = 0; s->imgPitch = 0; s->imgX = 0;
+}
 
 static void freeHandle(sgz_spectrum *s)
 {
@@ -87,6 +122,9 @@ static void freeHandle(sgz_spectrum *s)
     s->stage.release();
     for (float *p : {s->d_ring, s->d_mapped, s->d_state, s->d_lines, s->d_linesBatch, s->d_trackBins}) if (p) (void)hipFree(p);
     if (s->d_peak) (void)hipFree(s->d_peak);
+    unbindImage(s);
+    if (s->outStream) (void)hipStreamDestroy(s->outStream);
+    if (s->d_colsQ) (void)hipFree(s->d_colsQ);
     if (s->d_colsBatch) (void)hipFree(s->d_colsBatch);
     if (s->d_mix) (void)hipFree(s->d_mix);
     if (s->h_cols) (void)hipHostFree(s->h_cols);
@@ -129,6 +167,8 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     for (float **q : {&s->d_ring, &s->d_mapped, &s->d_state, &s->d_lines, &s->d_linesBatch, &s->d_trackBins}) if (*q) { (void)hipFree(*q); *q = nullptr; }
     if (s->d_colsBatch) { (void)hipFree(s->d_colsBatch); s->d_colsBatch = nullptr; }
     if (s->h_cols) { (void)hipHostFree(s->h_cols); s->h_cols = nullptr; }
+    if (s->d_colsQ) { (void)hipFree(s->d_colsQ); s->d_colsQ = nullptr; }
+    unbindImage(s);                                        // the image's height is the axis size: a new configuration needs a new binding
     // a piece's frames read windows that end inside the piece: the ring must hold W + one piece
     s->cap = (p.W + kPiece + 63u) & ~63u;
     s->maxFrames = kPiece / p.cfg.hop + 1;
@@ -145,6 +185,8 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     if (p.cfg.channel_mode != SGZ_CH_PHASE) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_trackBins), size_t(p.C) * (size_t(p.N) + 1) * sizeof(float)));
     if (!s->d_peak) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peak), sizeof(sgz_peak)));
     SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_cols), size_t(kQueueDepth) * p.P * 4, hipHostMallocDefault));
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsQ), size_t(kQueueDepth) * p.P * 4));
+    if (!s->outStream) SGZ_HIP(hipStreamCreateWithFlags(&s->outStream, hipStreamNonBlocking));
     for (auto &e : s->colEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s->qHead.store(0); s->qTail.store(0);
     if ((st = uploadMix(s, uint32_t(nch), nullptr)) != SGZ_OK) return st;
@@ -253,6 +295,8 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
                 const int slot = int(tail % kQueueDepth);
                 SGZ_HIP(hipMemcpyAsync(s->h_cols + size_t(slot) * p.P * 4, s->d_colsBatch + size_t(k) * p.P * 4, size_t(p.P) * 4,
                                        hipMemcpyDeviceToHost, s->stream));
+                SGZ_HIP(hipMemcpyAsync(s->d_colsQ + size_t(slot) * p.P * 4, s->d_colsBatch + size_t(k) * p.P * 4, size_t(p.P) * 4,
+                                       hipMemcpyDeviceToDevice, s->stream));
                 SGZ_HIP(hipEventRecord(s->colEvents[slot], s->stream));
                 s->qTail.store(tail + 1, std::memory_order_release);
             }
@@ -278,6 +322,88 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba, uint32_t *axi
     if (axis_points) *axis_points = p.P;
     s->qHead.store(head + 1, std::memory_order_release);
     return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_bind_image(sgz_spectrum *s, void *d_image, uint32_t columns, size_t pitch_bytes)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    unbindImage(s);
+    if (!d_image) return SGZ_OK;
+    if (columns == 0 || pitch_bytes < size_t(columns) * 4 || (pitch_bytes & 3) || (reinterpret_cast<uintptr_t>(d_image) & 3))
+        return fail(SGZ_EINVAL, "image: columns > 0, pitch >= 4 * columns, 4-byte aligned");
+    s->d_image = static_cast<uint8_t *>(d_image); s->imgColumns = columns; s->imgPitch = pitch_bytes; s->imgX = 0;
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d_image, size_t *pitch_bytes, int *dmabuf_fd)
+{
+    if (!s || columns == 0 || !pitch_bytes) return fail(SGZ_EINVAL, "bad argument");
+    unbindImage(s);
+    const Plan &p = *s->plan;
+    const size_t pitch = (size_t(columns) * 4 + 255) & ~size_t(255);
+    // dma-buf export works on whole pages of an allocation
+    const size_t bytes = (pitch * p.P + 4095) & ~size_t(4095);
+    uint8_t *img = nullptr;
+    SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&img), bytes));
+    hipError_t e = hipMemset(img, 0, bytes);
+    int fd = -1;
+    if (e == hipSuccess && dmabuf_fd) e = hipMemGetHandleForAddressRange(&fd, img, bytes, hipMemRangeHandleTypeDmaBufFd, 0);
+    if (e != hipSuccess) { (void)hipFree(img); return hipFail(e, "image allocation / dma-buf export"); }
+    s->d_image = img; s->imgOwned = true; s->imgColumns = columns; s->imgPitch = pitch; s->imgX = 0;
+    if (d_image) *d_image = img;
+    *pitch_bytes = pitch;
+    if (dmabuf_fd) *dmabuf_fd = fd;
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_bind_gl_buffer(sgz_spectrum *s, unsigned int gl_buffer, uint32_t columns, size_t pitch_bytes)
+{
+    if (!s || columns == 0 || pitch_bytes < size_t(columns) * 4 || (pitch_bytes & 3)) return fail(SGZ_EINVAL, "bad argument");
+    unbindImage(s);
+    const Plan &p = *s->plan;
+    hipGraphicsResource *res = nullptr;
+    hipError_t e = hipGraphicsGLRegisterBuffer(&res, gl_buffer, hipGraphicsRegisterFlagsWriteDiscard);
+    if (e != hipSuccess || !res) return hipFail(e != hipSuccess ? e : hipErrorInvalidValue, "hipGraphicsGLRegisterBuffer (needs a current OpenGL context on this device)");
+    void *ptr = nullptr; size_t size = 0;
+    e = hipGraphicsMapResources(1, &res, s->outStream);
+    if (e == hipSuccess) e = hipGraphicsResourceGetMappedPointer(&ptr, &size, res);
+    if (e != hipSuccess || size < pitch_bytes * p.P) {
+        (void)hipGraphicsUnmapResources(1, &res, s->outStream);
+        (void)hipGraphicsUnregisterResource(res);
+        return e != hipSuccess ? hipFail(e, "mapping the GL buffer") : fail(SGZ_EINVAL, "GL buffer smaller than pitch * axis_points");
+    }
+    s->glResource = res;
+    s->d_image = static_cast<uint8_t *>(ptr); s->imgColumns = columns; s->imgPitch = pitch_bytes; s->imgX = 0;
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, uint32_t *count)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (!s->d_image) return fail(SGZ_EINVAL, "no image bound");
+    const Plan &p = *s->plan;
+    uint32_t n = 0;
+    const uint32_t first = s->imgX;
+    uint64_t head = s->qHead.load(std::memory_order_relaxed);
+    // at most one lap of the image per call, so that `first` / `count` describe the dirty range unambiguously
+    while (n < s->imgColumns && head != s->qTail.load(std::memory_order_acquire)) {
+        const int slot = int(head % kQueueDepth);
+        const hipError_t q = hipEventQuery(s->colEvents[slot]);
+        if (q == hipErrorNotReady) break;
+        if (q != hipSuccess) return hipFail(q, "hipEventQuery");
+        hipLaunchKernelGGL(columnScatterKernel, dim3((p.P + 255) / 256), dim3(256), 0, s->outStream,
+                           reinterpret_cast<const uint32_t *>(s->d_colsQ + size_t(slot) * p.P * 4), s->d_image, s->imgPitch, s->imgX, p.P);
+        SGZ_HIP(hipGetLastError());
+        s->imgX = (s->imgX + 1) % s->imgColumns;           // framePixelPosition %= numSpectrumColumns (SpectrumRendering.cpp:712-718)
+        ++head; ++n;
+    }
+    if (n) {
+        SGZ_HIP(hipStreamSynchronize(s->outStream));        // the texels are in place before the slots go back to the producer
+        s->qHead.store(head, std::memory_order_release);
+    }
+    if (first_column) *first_column = first;
+    if (count) *count = n;
+    return n ? SGZ_OK : SGZ_EMPTY;
 }
 
 sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t graph, float *out)

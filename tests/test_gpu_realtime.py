@@ -180,3 +180,118 @@ def test_push_never_waits(gpu):
         assert refused.value == res.count(api.SGZ_BUSY)
     finally:
         api.lib().sgz_spectrum_destroy(h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the display hand-off without the host
+
+def _flush_all(h, want, timeout=10.0):
+    """(first, count) of every non-empty flush until `want` columns have been written"""
+    out, total = [], 0
+    t0 = time.time()
+    first, cnt = C.c_uint32(0), C.c_uint32(0)
+    while total < want and time.time() - t0 < timeout:
+        st = api.lib().sgz_spectrum_flush_columns(h, C.byref(first), C.byref(cnt))
+        if st == api.SGZ_OK:
+            out.append((first.value, cnt.value)); total += cnt.value
+        else:
+            assert st == api.SGZ_EMPTY
+            time.sleep(0.001)
+    return out, total
+
+
+@pytest.mark.parametrize("own_image", [False, True])
+def test_columns_land_in_a_device_image(gpu, own_image):
+    """sgz_spectrum_flush_columns writes texel (x, y) = column[y] at x = framePixelPosition, wrapping at the image width -- the texels
+    oglImage.updateSingleColumn would upload (SpectrumRendering.cpp:696-721) -- into caller-owned device memory (the mock of a mapped
+    interop resource) or into the library's own image, which is also exported as a dma-buf fd."""
+    import os
+    import torch
+    P, hop, W, columns = 200, 512, 4096, 7
+    cfg = config.spectrum_config(window_size=W, hop=hop, axis_points=P)
+    c = api.config_from_dict(cfg)
+    x = synth.gen(5, 48000, hop * 19, 2)
+    # reference columns: a second handle drained with pop_column
+    h2 = C.c_void_p()
+    api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h2)))
+    want = []
+    for pos in range(0, x.shape[1], hop):
+        _push_all(h2, x[:, pos:pos + hop], hop)
+        want += _pop_all(h2, P, 1)
+    api.lib().sgz_spectrum_destroy(h2)
+    want = np.stack(want).view(np.uint32)[:, :, 0]                                  # [frames][P]
+    assert want.shape[0] == 19
+
+    h = C.c_void_p()
+    api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)))
+    fd = -1
+    try:
+        assert api.lib().sgz_spectrum_flush_columns(h, None, None) == api.SGZ_EINVAL           # nothing bound
+        if own_image:
+            d_img, pitch, cfd = C.c_void_p(), C.c_size_t(0), C.c_int(-1)
+            api.check(api.lib().sgz_spectrum_create_image(h, columns, C.byref(d_img), C.byref(pitch), C.byref(cfd)))
+            fd = cfd.value
+            assert fd >= 0 and os.fstat(fd).st_size >= 0                                       # a live file descriptor (the dma-buf)
+            assert pitch.value >= 4 * columns and pitch.value % 256 == 0
+            pitch_b = pitch.value
+            img_t = None
+        else:
+            pitch_b = 4 * (columns + 3)                                                        # a pitch wider than the image
+            img_t = torch.full((P, pitch_b // 4), 0x01020304, dtype=torch.int32, device=gpu)
+            api.check(api.lib().sgz_spectrum_bind_image(h, img_t.data_ptr(), columns, pitch_b))
+
+            def read_image():
+                torch.cuda.synchronize()
+                return img_t.cpu().numpy().view(np.uint32)
+        written = 0
+        for pos in range(0, x.shape[1], hop * 3):                                              # three frames per push: several columns per flush
+            _push_all(h, x[:, pos:pos + hop * 3], hop * 3)
+            k = min(3, 19 - written)
+            ranges, total = _flush_all(h, k)
+            assert total == k
+            x0 = ranges[0][0]
+            assert x0 == written % columns
+            written += k
+        if own_image:
+            host = np.zeros((P, pitch_b // 4), np.uint32)
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), d_img, C.c_size_t(host.nbytes), 2) == 0       # hipMemcpyDeviceToHost
+            img = host
+        else:
+            img = read_image()
+            assert (img[:, columns:] == 0x01020304).all()                                      # texels beyond the image width are untouched
+        # column x holds the newest frame f with f % columns == x
+        for xcol in range(columns):
+            f = max(f for f in range(19) if f % columns == xcol)
+            assert np.array_equal(img[:, xcol], want[f]), (xcol, f)
+        # rebinding resets framePixelPosition; unbinding makes flush an error again
+        if not own_image:
+            api.check(api.lib().sgz_spectrum_bind_image(h, None, 0, 0))
+            assert api.lib().sgz_spectrum_flush_columns(h, None, None) == api.SGZ_EINVAL
+            assert api.lib().sgz_spectrum_bind_image(h, img_t.data_ptr(), columns, 4 * columns - 4) == api.SGZ_EINVAL
+    finally:
+        api.lib().sgz_spectrum_destroy(h)
+        if fd >= 0:
+            os.close(fd)
+
+
+def test_gl_buffer_binding_fails_cleanly_without_a_context(gpu):
+    """an MI355X has no graphics engine and this box no display: hipGraphicsGLRegisterBuffer cannot succeed, and the call must say so
+    with a status instead of taking the process down (run in a child so that a crash inside the GL loader shows up as a failure)"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C\n"
+        "from signalizer_amd import api, config\n"
+        "c = api.config_from_dict(config.spectrum_config(window_size=4096, hop=512, axis_points=64))\n"
+        "h = C.c_void_p()\n"
+        "api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)))\n"
+        "st = api.lib().sgz_spectrum_bind_gl_buffer(h, 1, 16, 64)\n"
+        "assert st < 0, st\n"
+        "assert api.lib().sgz_spectrum_flush_columns(h, None, None) == api.SGZ_EINVAL\n"
+        "api.lib().sgz_spectrum_destroy(h)\n"
+        "print('clean', st)\n")
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "clean" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
