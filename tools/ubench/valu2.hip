@@ -12,6 +12,10 @@ __global__ void k(float *out, long long *clk, float a, float b)
     float x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = float(threadIdx.x + i);
+    float2 y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = make_float2(float(threadIdx.x + i), float(i));
+    const float2 pa = make_float2(a, b), pb = make_float2(b, a);
     long long t0 = __builtin_readcyclecounter();
     if (OP == 0) BODY(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b)))
     if (OP == 1) BODY(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[j]) : "v"(a)))
@@ -34,8 +38,21 @@ __global__ void k(float *out, long long *clk, float a, float b)
     if (OP == 18) BODY(asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b)))
     if (OP == 19) BODY(asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[j]) : "v"(a)))
     if (OP == 20) BODY(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_fma_f32 %2, %2, %1, %1" : "+v"(x[j]), "+v"(a), "+v"(x[(j+1)&15]) : : "s20", "s21"))
+    if (OP == 21) BODY(asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[j & 7]) : "v"(pa), "v"(pb)))
+    if (OP == 22) BODY(asm volatile("v_pk_fma_f32 %0, %0, s[20:21], %1" : "+v"(y[j & 7]) : "v"(pb) : "s20", "s21"))
+    if (OP == 23) BODY(asm volatile("v_pk_mul_f32 %0, %0, s[20:21]" : "+v"(y[j & 7]) : : "s20", "s21"))
+    if (OP == 24) BODY(asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[j & 7]) : "v"(pa)))
+    if (OP == 25) BODY(asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[j & 7]) : "v"(pa)))
+    if (OP == 26) BODY(asm volatile("v_pk_fma_f32 %0, %0, s[20:21], %1 op_sel_hi:[1,0,1]" : "+v"(y[j & 7]) : "v"(pb) : "s20", "s21"))
+    if (OP == 27) BODY(asm volatile("v_fma_f32 %0, %0, s20, %1" : "+v"(x[j]) : "v"(b) : "s20"))
+    if (OP == 28) BODY(asm volatile("v_fmac_f32 %0, s20, %1" : "+v"(x[j]) : "v"(b) : "s20"))
+    if (OP == 29) BODY(asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[j])))
+    if (OP == 30) BODY(asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(x[j])))
+    if (OP == 31) BODY(asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x[j]) : "v"(a), "v"(b)))
     long long t1 = __builtin_readcyclecounter();
     float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += y[i].x + y[i].y;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += x[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
@@ -69,6 +86,10 @@ int main()
     run("v_add_f32 v,s", k<13>, 1); run("v_fma_f32 v,s,v", k<14>, 1); run("v_min_u32", k<15>, 1);
     run("v_mul_f32 inline const", k<16>, 1); run("v_mul_f32 literal", k<17>, 1); run("v_fmac_f32", k<18>, 1); run("v_add_u32", k<19>, 1);
     run("cndmask s + fma interleaved (per instr)", k<20>, 2);
+    run("v_pk_fma_f32 v,v,v", k<21>, 1); run("v_pk_fma_f32 v,s[2],v", k<22>, 1); run("v_pk_mul_f32 v,s[2]", k<23>, 1);
+    run("v_pk_mul_f32 v,v", k<24>, 1); run("v_pk_add_f32 v,v", k<25>, 1); run("v_pk_fma_f32 v,s[2],v op_sel_hi", k<26>, 1);
+    run("v_fma_f32 v,s20,v", k<27>, 1); run("v_fmac_f32 s20,v", k<28>, 1); run("v_sqrt_f32", k<29>, 1); run("v_lshlrev_b32", k<30>, 1);
+    run("v_add3_u32", k<31>, 1);
     }
     return 0;
 }
