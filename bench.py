@@ -123,6 +123,126 @@ class CAbiShard:
         self.api.lib().sgz_comm_destroy(self.comm)
 
 
+def views_workload(args, rank, world, dev) -> None:
+    """BASELINE configs[2] (Oscilloscope) / configs[3] (Vectorscope) through the real-time handles, the way the plugin would drive
+    them: per rendered frame (60 Hz) the audio thread's callbacks (512 samples each, host buffers in) and then the render thread's
+    calls (peak filter, vertices of every channel / pair, host buffers out).  The handles own their streams and `vertices` waits for
+    its result, so a step is timed on the host clock; the dominant kernel is timed separately through its stateless stage call on
+    the launch stream with HIP events (same view, same data volume) for the roofline object."""
+    import ctypes as C
+    import torch
+    from signalizer_amd import api, synth
+    L = api.lib()
+    scope = args.workload == "cfg3"
+    if scope:
+        sr, W, nch = 192000.0, 19200, 2
+        per_frame = int(sr / 60)
+        width = 8 * W + 1
+        h = api.Scope(sample_rate=sr, window_size=float(W), num_channels=nch, trigger_mode=4, channel_mode=0, envelope_mode=2,
+                      interpolation=3, max_block=512, trigger_threshold=0.05, trigger_channel=1.0, envelope_window=0.3)
+        view = api.ScopeView(float(W), 0.0, 1.0, 1.0, width, 0)
+    else:
+        sr, W, nch = 96000.0, 9600, 8
+        per_frame = int(sr / 60)
+        h = api.Vector(sample_rate=sr, num_channels=nch, window_size=W, envelope_mode=2, lanes=8, fade_history=1, max_block=512,
+                       envelope_window=0.3, stereo_window=0.1)
+    x = synth.gen(31 + rank, int(sr), per_frame * 64, nch)
+    refused = 0
+
+    def push(block):
+        nonlocal refused
+        while h.push(block) == api.SGZ_BUSY:                       # never waits; a refused block is offered again
+            refused += 1
+
+    frame = 0
+    units = 0
+
+    def step():
+        nonlocal frame, units
+        a = (frame % 64) * per_frame
+        for pos in range(a, a + per_frame, 512):
+            push(x[:, pos:min(pos + 512, a + per_frame)])
+        if scope:
+            h.peak_filter(1 / 60, 8)
+            n = 0
+            for ev in (0, 1):
+                xyz, _ = h.vertices(view, ev, 0)
+                n += xyz.shape[0]
+        else:
+            h.peak_filter(1 / 60)
+            n = 0
+            for p in range(nch // 2):
+                xyz, _ = h.vertices(p)
+                n += xyz.shape[0]
+        frame += 1
+        units = n
+
+    for _ in range(max(args.warmup, 70)):                          # at least one lap of the signal: rings full, triggers running
+        step()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the dominant kernel on its own: stage call on the launch stream, HIP events
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = HipEvents(2)
+    if scope:
+        ring = torch.from_numpy(synth.gen(3, int(sr), W, 2)).to(dev)
+        v = api.ScopeView(float(W), 0.0, 1.0, 1.0, width, 0)
+        npts = L.sgz_scope_num_points(C.byref(v))
+        verts = torch.zeros((2, npts, 2), dtype=torch.float32, device=dev)
+        call = lambda: api.check(L.sgz_scope_lanczos_device(C.byref(v), ring.data_ptr(), W, ring.stride(0), 2, verts.data_ptr(), stream))
+        alg = 2 * (W * 4 + npts * 8)
+        kname = "scopeLanczosKernel (both channels; the handle's scopeWaveLanczosKernel is the same arithmetic per channel)"
+    else:
+        xx = torch.from_numpy(synth.gen(4, int(sr), W, nch)).to(dev)
+        pol = torch.zeros((nch // 2, W, 3), dtype=torch.float32, device=dev)
+        call = lambda: api.check(L.sgz_vector_polar_device(xx.data_ptr(), xx.stride(0), nch // 2, W, 8, pol.data_ptr(), stream))
+        alg = (nch // 2) * (2 * W * 4 + W * 12)
+        kname = "vectorPolarKernel (4 pairs; the handle's vectorPolarViewKernel adds the colour stream)"
+    for _ in range(10):
+        call()
+    torch.cuda.synchronize()
+    ev.record(0, stream)
+    for _ in range(100):
+        call()
+    ev.record(1, stream)
+    torch.cuda.synchronize()
+    kern_ms = ev.elapsed_ms(0, 1) / 100
+    if rank == 0:
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": ("oscilloscope vertices/sec: Lanczos-10 8x resample + zero-crossing trigger, stereo 192 kHz, 100 ms window" if scope else
+                       "vectorscope vertices/sec: L/R -> polar + envelope decay, 8-channel 96 kHz, 100 ms window"),
+            "value": units * world * args.steps / dt, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 kernel weights)" if scope else "f32",
+            "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[2]: Oscilloscope, stereo 192 kHz, 19 200-sample window, zero-crossing trigger at 0.05, "
+                                    "Lanczos-10 at 8 points per sample (153 601 vertices per channel), peak-decay envelope" if scope else
+                                    "BASELINE.json configs[3]: Vectorscope, 8 channels (4 pairs) 96 kHz, 9 600-sample history, peak-decay envelope, fade colours"),
+                       "step": "one rendered frame at 60 Hz through the real-time handle: 1/60 s of audio in 512-sample callbacks from host buffers "
+                               "(one staged copy + one kernel each), then peak filter and the vertices of every channel / pair into host buffers",
+                       "parallelism": "replicas only" if world > 1 else "single device", "vertices_per_step": units,
+                       "realtime_factor": (1 / 60) / (dt / args.steps), "pushes_refused_busy": refused},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                         "note": "a few MB per launch: the kernel is bound by its launch latency and (scope) its fp64 weight arithmetic, not by HBM"},
+        }
+        print(json.dumps(out), flush=True)
+    h.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,10 +251,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the contract line (tail-free launch, step with state "
                                                               "outputs): tools/profile.sh, so that the profiled dispatches are the workload's only")
-    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "cfg5", "cfg3", "cfg4"), default="cfg2",
                     help="cfg2 (default): BASELINE.json's metric; with N GPUs every rank renders its own 60 s (weak scaling).  cfg5: the "
                          "64-channel 65536-pt job of BASELINE configs[4] -- ONE 60 s x 32-pair job split over the N ranks by time "
-                         "chunk (strong scaling, 7.5 s per rank at N = 8): the curve SURVEY 8(e) asks for")
+                         "chunk (strong scaling, 7.5 s per rank at N = 8): the curve SURVEY 8(e) asks for.  cfg3 / cfg4: the Oscilloscope / "
+                         "Vectorscope real-time handles on BASELINE configs[2] / configs[3] (one step = one rendered frame at 60 Hz: the audio "
+                         "callbacks of 1/60 s, then the render-thread calls); these paths do not shard: N ranks run N replicas")
     ap.add_argument("--shard-impl", choices=("c_abi", "torch"), default="c_abi",
                     help="N > 1: sgz_spectrogram_render_sharded on its own RCCL communicator (default), or signalizer_amd.sharding over "
                          "torch.distributed's nccl backend")
@@ -158,6 +280,11 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload in ("cfg3", "cfg4"):
+        views_workload(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     strong = args.workload == "cfg5"
     if strong:
         cfg = config.cfg5()
@@ -177,7 +304,19 @@ def main() -> None:
     plan = api.Plan(cfg).upload()
     x_dev = torch.from_numpy(x_host).to(dev)
     timer = sharding.TimeChunkRenderer(plan, x_dev, rank=rank, world=world, halo=args.halo)   # kernel / collective probes (and the torch path)
-    shard = timer if (world == 1 or args.shard_impl == "torch") else CAbiShard(plan, x_dev, rank, world, dev)
+    shard, shard_note = timer, ("single device" if world == 1 else "torch")
+    if world > 1 and args.shard_impl == "c_abi":
+        # every rank must take the same path: agree on whether the library's own RCCL communicator came up everywhere
+        try:
+            cand, err = CAbiShard(plan, x_dev, rank, world, dev), ""
+        except Exception as e:                                     # noqa: BLE001 -- any failure here means "use the torch path"
+            cand, err = None, f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if cand is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            shard, shard_note = cand, "c_abi"
+        else:
+            shard_note = "torch (sgz_comm_create failed on some rank" + (f": {err}" if err else "") + ")"
     frames_per_rank = shard.local_frames
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -271,7 +410,7 @@ def main() -> None:
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
                        "step": "K_A + K_B -> RGBA8 columns; line results and the decay end state are not requested in the timed step "
                                "(the image does not depend on them; ms_per_step_with_state times the step that writes them)",
-                       "shard_impl": "single device" if world == 1 else args.shard_impl,
+                       "shard_impl": shard_note,
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps, "single_shot_ms": single_shot_ms,
                        "collectives_ms_per_step": coll_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -155,8 +155,12 @@ long       sgz_num_frames(size_t nsamples, uint32_t window_size, uint32_t hop);
 sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, size_t channel_stride,
                                          size_t nsamples, uint8_t *d_rgba, float *d_lines,
                                          float *d_state, void *stream);
-/* Host-buffer convenience wrapper (H2D, render, D2H); `planar` are the reference's planar channel
- * pointers (AudioStream::Listener::onStreamAudio's float** buffer, Spectrum.h:370). */
+/* Host buffers in, host buffers out (H2D, render, D2H on a stream of the plan's own); `planar` are the reference's planar channel
+ * pointers (AudioStream::Listener::onStreamAudio's float** buffer, Spectrum.h:370).  The plan keeps the device copies between calls:
+ * repeated renders of the same shape allocate nothing and rebuild no tables.  sgz_spectrogram_render is the one-shot form (plan
+ * built and destroyed inside the call: the fp64 constant block costs more than the render itself). */
+sgz_status sgz_spectrogram_render_host(sgz_plan *plan, const float *const *planar, uint32_t num_channels, size_t nsamples,
+                                       uint8_t *rgba_out, float *lines_out, sgz_timing *timing);
 sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *const *planar,
                                   uint32_t num_channels, size_t nsamples, uint8_t *rgba_out,
                                   float *lines_out, sgz_timing *timing);

@@ -119,7 +119,7 @@ EXPORTS = [
     "sgz_spectrogram_render_sharded",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
-    "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
+    "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
     "sgz_spectrum_flush_columns",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
@@ -172,6 +172,7 @@ def lib() -> C.CDLL:
     L.sgz_num_frames.restype = C.c_long
     L.sgz_spectrogram_render_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.sgz_spectrogram_render.argtypes = [C.POINTER(SpectrumConfig), vp, u32, sz, vp, vp, C.POINTER(Timing)]
+    L.sgz_spectrogram_render_host.argtypes = [vp, vp, u32, sz, vp, vp, C.POINTER(Timing)]
     L.sgz_stage_bins.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgz_stage_mapped.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgz_stage_map_from_bins.argtypes = [vp, vp, sz, vp, vp]
@@ -414,6 +415,19 @@ def render_spectrogram(cfg: dict, planar: np.ndarray, want_lines: bool = False):
     t = Timing()
     check(lib().sgz_spectrogram_render(C.byref(c), ptrs, nch, S, _np_ptr(rgba),
                                        _np_ptr(lines) if want_lines else None, C.byref(t)))
+    return rgba, lines, {"h2d_ms": t.h2d_ms, "kernel_ms": t.kernel_ms, "d2h_ms": t.d2h_ms, "frames": t.frames}
+
+
+def render_spectrogram_host(plan, planar: np.ndarray, want_lines: bool = False):
+    """Host-buffer render on a plan the caller keeps (sgz_spectrogram_render_host): no table rebuild, no allocation after the first call."""
+    planar = np.ascontiguousarray(planar, np.float32)
+    nch, S = planar.shape
+    F = plan.num_frames(S)
+    rgba = np.zeros((F, plan.P, 4), np.uint8)
+    lines = np.zeros((F, plan.cfg.num_pairs, NUM_GRAPHS, plan.P, 2), np.float32) if want_lines else None
+    ptrs = (C.c_void_p * nch)(*[planar[i].ctypes.data for i in range(nch)])
+    t = Timing()
+    check(lib().sgz_spectrogram_render_host(plan.h, ptrs, nch, S, _np_ptr(rgba), _np_ptr(lines) if want_lines else None, C.byref(t)))
     return rgba, lines, {"h2d_ms": t.h2d_ms, "kernel_ms": t.kernel_ms, "d2h_ms": t.d2h_ms, "frames": t.frames}
 
 

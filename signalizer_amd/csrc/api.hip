@@ -39,6 +39,10 @@ Plan::~Plan()
                     d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyFlag, d_nyBest};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
+        if (p) (void)hipFree(p);
+    for (void *e : hostEv) if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    if (hostStream) (void)hipStreamDestroy(static_cast<hipStream_t>(hostStream));
 }
 
 template <typename T>
@@ -471,6 +475,55 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
     return runDecayColour(p, p.d_mapped, frames, d_rgba, d_lines, d_state, s);
 }
 
+// Host buffers in, host buffers out, on a plan the caller keeps: the constant block is built and uploaded once, the device buffers and
+// the stream live in the plan and only grow, so a second render of the same shape allocates nothing.
+sgz_status sgz_spectrogram_render_host(sgz_plan *plan, const float *const *planar, uint32_t num_channels, size_t nsamples,
+                                       uint8_t *rgba_out, float *lines_out, sgz_timing *timing)
+{
+    if (!plan || !planar || !rgba_out) return fail(SGZ_EINVAL, "null argument");
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    if (num_channels != 2 * p.C) return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72)");
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    if (frames <= 0) { if (timing) *timing = sgz_timing{}; return SGZ_SKIPPED_FRAME; }
+    if (!p.hostStream) {
+        hipStream_t ns = nullptr;
+        SGZ_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        p.hostStream = ns;
+        for (void *&e : p.hostEv) { hipEvent_t ne = nullptr; SGZ_HIP(hipEventCreate(&ne)); e = ne; }
+    }
+    hipStream_t s = static_cast<hipStream_t>(p.hostStream);
+    hipEvent_t ev[4];
+    for (int i = 0; i < 4; ++i) ev[i] = static_cast<hipEvent_t>(p.hostEv[i]);
+    const size_t stride = (nsamples + 63) & ~size_t(63);                    // 256-byte rows: the channel-split kernels want aligned rows
+    const size_t linesN = size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2;
+    if ((st = ensureCap(&p.d_hostAudio, &p.hostAudioCap, size_t(num_channels) * stride)) != SGZ_OK) return st;
+    if ((st = ensureCap(&p.d_hostRgba, &p.hostRgbaCap, (size_t(frames) * p.P * 4 + 3) / 4)) != SGZ_OK) return st;
+    if (lines_out && (st = ensureCap(&p.d_hostLines, &p.hostLinesCap, linesN)) != SGZ_OK) return st;
+    SGZ_HIP(hipEventRecord(ev[0], s));
+    for (uint32_t c = 0; c < num_channels; ++c)
+        SGZ_HIP(hipMemcpyAsync(p.d_hostAudio + size_t(c) * stride, planar[c], nsamples * sizeof(float), hipMemcpyHostToDevice, s));
+    SGZ_HIP(hipEventRecord(ev[1], s));
+    uint8_t *d_rgba = reinterpret_cast<uint8_t *>(p.d_hostRgba);
+    st = sgz_spectrogram_render_device(plan, p.d_hostAudio, stride, nsamples, d_rgba, lines_out ? p.d_hostLines : nullptr, nullptr, s);
+    if (st != SGZ_OK) return st;
+    SGZ_HIP(hipEventRecord(ev[2], s));
+    SGZ_HIP(hipMemcpyAsync(rgba_out, d_rgba, size_t(frames) * p.P * 4, hipMemcpyDeviceToHost, s));
+    if (lines_out) SGZ_HIP(hipMemcpyAsync(lines_out, p.d_hostLines, linesN * sizeof(float), hipMemcpyDeviceToHost, s));
+    SGZ_HIP(hipEventRecord(ev[3], s));
+    SGZ_HIP(hipStreamSynchronize(s));
+    if (timing) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+        timing->h2d_ms = a; timing->kernel_ms = b; timing->d2h_ms = c; timing->frames = uint64_t(frames);
+    }
+    return SGZ_OK;
+}
+
+// One-shot convenience: builds a plan for cfg, renders, destroys it.  Callers that render more than once keep the plan
+// (sgz_plan_create + sgz_spectrogram_render_host): the constant block (fp64 window design, pixel records) costs more than the render.
 sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *const *planar, uint32_t num_channels,
                                   size_t nsamples, uint8_t *rgba_out, float *lines_out, sgz_timing *timing)
 {
@@ -479,46 +532,9 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
     sgz_plan *plan = nullptr;
     sgz_status st = sgz_plan_create(cfg, &plan);
     if (st != SGZ_OK) return st;
-    st = sgz_plan_upload(plan);
-    if (st != SGZ_OK) { sgz_plan_destroy(plan); return st; }
-    Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
-    float *d_audio = nullptr, *d_lines = nullptr;
-    uint8_t *d_rgba = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    auto cleanup = [&]() {
-        if (d_audio) (void)hipFree(d_audio);
-        if (d_lines) (void)hipFree(d_lines);
-        if (d_rgba) (void)hipFree(d_rgba);
-        for (hipEvent_t e : {e0, e1, e2, e3}) if (e) (void)hipEventDestroy(e);
-        sgz_plan_destroy(plan);
-    };
-    if (frames <= 0) { cleanup(); if (timing) *timing = sgz_timing{}; return SGZ_SKIPPED_FRAME; }
-#define SGZ_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hipFail(_e, #call); } } while (0)
-    SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_audio), size_t(num_channels) * nsamples * sizeof(float)));
-    SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_rgba), size_t(frames) * p.P * 4));
-    if (lines_out) SGZ_HIP_C(hipMalloc(reinterpret_cast<void **>(&d_lines), size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float)));
-    SGZ_HIP_C(hipEventCreate(&e0)); SGZ_HIP_C(hipEventCreate(&e1)); SGZ_HIP_C(hipEventCreate(&e2)); SGZ_HIP_C(hipEventCreate(&e3));
-    SGZ_HIP_C(hipEventRecord(e0, nullptr));
-    for (uint32_t c = 0; c < num_channels; ++c)
-        SGZ_HIP_C(hipMemcpyAsync(d_audio + size_t(c) * nsamples, planar[c], nsamples * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    SGZ_HIP_C(hipEventRecord(e1, nullptr));
-    st = sgz_spectrogram_render_device(plan, d_audio, nsamples, nsamples, d_rgba, d_lines, nullptr, nullptr);
-    if (st != SGZ_OK) { cleanup(); return st; }
-    SGZ_HIP_C(hipEventRecord(e2, nullptr));
-    SGZ_HIP_C(hipMemcpyAsync(rgba_out, d_rgba, size_t(frames) * p.P * 4, hipMemcpyDeviceToHost, nullptr));
-    if (lines_out)
-        SGZ_HIP_C(hipMemcpyAsync(lines_out, d_lines, size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-    SGZ_HIP_C(hipEventRecord(e3, nullptr));
-    SGZ_HIP_C(hipStreamSynchronize(nullptr));
-    if (timing) {
-        float a = 0, b = 0, c = 0;
-        (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2); (void)hipEventElapsedTime(&c, e2, e3);
-        timing->h2d_ms = a; timing->kernel_ms = b; timing->d2h_ms = c; timing->frames = uint64_t(frames);
-    }
-#undef SGZ_HIP_C
-    cleanup();
-    return SGZ_OK;
+    st = sgz_spectrogram_render_host(plan, planar, num_channels, nsamples, rgba_out, lines_out, timing);
+    sgz_plan_destroy(plan);
+    return st;
 }
 
 sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,

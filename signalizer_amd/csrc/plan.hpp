@@ -97,6 +97,11 @@ struct Plan {
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
+    // sgz_spectrogram_render_host: device copies of the caller's host buffers, the stream they move on, timing events
+    float *d_hostAudio = nullptr, *d_hostRgba = nullptr, *d_hostLines = nullptr;
+    size_t hostAudioCap = 0, hostRgbaCap = 0, hostLinesCap = 0;
+    void *hostStream = nullptr;                           // hipStream_t / hipEvent_t (this header is also compiled as plain C++)
+    void *hostEv[4] = {nullptr, nullptr, nullptr, nullptr};
     float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr, *d_winPhaseT = nullptr;
     float *d_ny = nullptr; uint32_t *d_nyFlag = nullptr; float *d_nyBest = nullptr; size_t nyCap = 0; uint32_t nyEpoch = 0;   // channel-split path: Nyquist exchange of a frame's two workgroups
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs

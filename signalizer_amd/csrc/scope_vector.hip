@@ -330,16 +330,26 @@ peakKernel(const float *ch, size_t stride, size_t stop, float *peaks)
 // VectorscopeRendering.cpp:528-543,:592): sequential by construction, but it only depends on (n, lanes).  One small
 // kernel replays it -- one thread per lane, `iters` dependent adds -- into ramp[k][lane] = outFade of iteration k,
 // lane; the per-sample kernel then just looks its value up.
-__global__ void fadeRampKernel(size_t n, uint32_t lanes, long iters, float *ramp /*[iters][lanes]*/)
+__global__ void __launch_bounds__(256) fadeRampKernel(size_t n, uint32_t lanes, long iters, float *ramp /*[iters][lanes]*/)
 {
-    const uint32_t lane = threadIdx.x;
-    if (lane >= lanes) return;
+    // the chain itself is `iters` dependent adds per lane; it is written through LDS so that the (few) chain threads never wait for
+    // global stores (a lone wave has 64 stores in flight at most: 25 ns per iteration when it stored directly)
+    __shared__ float buf[8192];
+    const uint32_t tid = threadIdx.x;
     const float fadePerSample = 1.0f / float(n);
-    float f = fadePerSample * float(lane);
+    float f = fadePerSample * float(tid);
     const float incr = fadePerSample * float(lanes);
-    for (long k = 0; k < iters; ++k) {
-        ramp[size_t(k) * lanes + lane] = f - 1.0f;
-        f += incr;
+    const long chunk = long(8192 / lanes);
+    for (long k0 = 0; k0 < iters; k0 += chunk) {
+        const long m = iters - k0 < chunk ? iters - k0 : chunk;
+        if (tid < lanes)
+            for (long k = 0; k < m; ++k) {
+                buf[k * lanes + tid] = f - 1.0f;
+                f += incr;
+            }
+        __syncthreads();
+        for (long e = tid; e < m * long(lanes); e += 256) ramp[k0 * lanes + e] = buf[e];
+        __syncthreads();
     }
 }
 
@@ -571,7 +581,7 @@ sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_
     StreamScratch ramp(s);
     SGZ_HIP(ramp.get((size_t(iters) * lanes + 1) * sizeof(float)));
     float *d_ramp = reinterpret_cast<float *>(ramp.p);
-    if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(64), 0, s, n, lanes, iters, d_ramp);
+    if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(256), 0, s, n, lanes, iters, d_ramp);
     const int block = 256;
     dim3 grid(unsigned((n + block - 1) / block), pairs);
     hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, s, d_planar, stride, pairs, n, lanes, iters, d_ramp,

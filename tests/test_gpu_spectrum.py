@@ -177,6 +177,15 @@ def test_end_to_end_cfg2_8frames_and_host_wrapper(gpu, oracle):
     ref = np.stack([r["lines"].real, r["lines"].imag], axis=-1)
     ok = ref > -100                                                       # not the clip sentinel
     assert np.abs(lines - ref)[ok].max() <= 2e-4                          # normalised dB units (1.0 = 120 dB)
+    # the plan-keeping form: same bytes as the device render, call after call, on buffers of changing length and odd row lengths
+    plan = api.Plan(cfg).upload()
+    for n in (S, S - 8192 - 3, S):
+        xs = np.ascontiguousarray(x[:, :n])
+        got, glines, t = api.render_spectrogram_host(plan, xs, want_lines=True)
+        want = plan.render(_planar_cuda(xs, gpu)).cpu().numpy()
+        assert t["frames"] == want.shape[0] and np.array_equal(got, want)
+        assert np.isfinite(glines).all()
+    assert np.array_equal(got, rgba)
 
 
 def test_multi_pair_blend(gpu, oracle):
