@@ -35,7 +35,7 @@ sgz_status hipFail(hipError_t e, const char *what)
 Plan::~Plan()
 {
     // best effort; ignore errors on teardown
-    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
                     d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyFlag, d_nyBest};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -67,6 +67,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.slope, &p.d_slope)) != SGZ_OK) return st;
     if ((st = uploadVec(p.colourTables, &p.d_colourTables)) != SGZ_OK) return st;
     if ((st = uploadVec(p.weights, &p.d_weights)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.weights11, &p.d_weights11)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
@@ -125,7 +126,7 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.tw1odd = reinterpret_cast<const float2 *>(p.d_tw1odd);
     prm.dcPixels = p.d_dcPixels; prm.nDcPixels = uint32_t(p.dcPixels.size());
-    prm.recs = p.d_recs; prm.weights = p.d_weights;
+    prm.recs = p.d_recs; prm.weights = p.d_weights; prm.weights11 = p.d_weights11;
     prm.items = p.d_items; prm.nItems = uint32_t(p.items.size()); prm.nItemsLeft = p.nItemsLeft;
     prm.invSize = p.scalars.invSize;
     prm.roundSize = uint32_t(numCUs());

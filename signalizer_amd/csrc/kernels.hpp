@@ -30,6 +30,7 @@ struct StftParams {
     long taskBase;            // halves path: first (frame, pair) task of this launch (outputs are indexed from 0)
     const PixelRec *recs;     // [sides][P]
     const float *weights;
+    const float *weights11;   // fused kernel: kMaxTaps + 1 floats per record, zero where the tap window steps over an LDS pad slot
     const MaxItem *items;     // balanced arg-max work list (null: serial per-pixel scan)
     uint32_t nItems;
     uint32_t nItemsLeft;      // items [0, nItemsLeft) belong to left-side records (ascending k), the rest to the right side

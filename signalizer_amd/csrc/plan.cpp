@@ -509,6 +509,25 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     if (cfg.channel_mode == SGZ_CH_PHASE) buildPhaseRecords(p);
     else buildPixelRecords(p);
     p.weights.insert(p.weights.end(), size_t(kMaxTaps), 0.0f);    // padding: the kernel reads kMaxTaps weights unconditionally
+    // The fused kernel (N = R^3) reads a tap window as kMaxTaps + 1 CONTIGUOUS floats of its bank-padded csf array (one pad slot,
+    // holding 0, after every R entries; csf[0 .. 9] repeated behind csf[N] for the periodic indexing).  Its weights: the record's
+    // taps in order, +0 at the position of the pad slot the window steps over (if any), +0 behind the last tap.
+    p.weights11.clear();
+    {
+        const uint32_t R = p.N == 32768u ? 32u : (p.N == 4096u ? 16u : 0u);
+        if (R && cfg.channel_mode != SGZ_CH_PHASE) {
+            p.weights11.assign(p.recs.size() * size_t(kMaxTaps + 1), 0.0f);
+            for (size_t r = 0; r < p.recs.size(); ++r) {
+                const PixelRec &rec = p.recs[r];
+                if (rec.kind != 0) continue;
+                float *w = &p.weights11[r * size_t(kMaxTaps + 1)];
+                // taps i at csf index a + i; LDS offset from the first tap: i, +1 from the first i >= 1 with (a + i) % R == 0 on
+                const uint32_t rem = uint32_t(rec.a) % R;
+                const int cross = rem ? int(R - rem) : kMaxTaps + 1;       // first tap behind a pad slot (none if the window starts a block)
+                for (int i = 0; i < rec.b; ++i) w[i < cross ? i : i + 1] = p.weights[size_t(rec.c) + size_t(i)];
+            }
+        }
+    }
     // balanced arg-max work list: every kind-1 record cut at 16-aligned csf windows (see MaxItem)
     p.items.clear();
     p.nItemsLeft = 0;

@@ -58,6 +58,7 @@ struct Plan {
     std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
+    std::vector<float> weights11;       // N = R^3 (fused kernel): [record][kMaxTaps + 1], see WholeFrameIndex::kLinearTaps
     std::vector<uint32_t> phaseType, phaseNorm;   // Phase mode only (plan.cpp buildPhaseRecords), [P] each
     uint32_t phaseNormFinal = 0;
     std::vector<MaxItem> items;         // arg-max runs cut into <= 16-bin pieces (left-side records first)
@@ -83,7 +84,7 @@ struct Plan {
 
     // device mirrors (owned)
     bool uploaded = false;
-    float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr;
+    float *d_window = nullptr, *d_slope = nullptr, *d_colourTables = nullptr, *d_weights = nullptr, *d_weights11 = nullptr;
     float *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twN = nullptr, *d_tw1odd = nullptr;
     float *d_work0 = nullptr, *d_work1 = nullptr, *d_binsWork = nullptr; size_t workSlab = 0;
     uint32_t *d_dcPixels = nullptr; float *d_dcWork = nullptr; size_t dcSlab = 0;   // Complex mode: pixel list, csf[0] of a slab of tasks

@@ -112,7 +112,7 @@ mapSideKernel(const StftParams prm, const float *bins, const uint32_t N, float *
     };
     if (count <= 5 * NT) stage(std::integral_constant<int, 5>{});
     else stage(std::integral_constant<int, 17>{});
-    mapper.prefetchWeights(prm);
+    mapper.prefetchWeights(prm, tid, v.total);
     ldsBarrier();
     SGZ_CLK(7);
     mapper.run(prm, v, at, lds, win, tid, task);
@@ -168,7 +168,7 @@ template <int LR>
 static hipError_t launchHalves(const StftParams &prm, int grid, hipStream_t stream)
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
-    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
+    const size_t ldsBytes = (size_t(N) + (N >> LR) + 12 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
     const bool simple = prm.mode == SGZ_CH_SEPARATE || prm.mode == SGZ_CH_COMPLEX;
     const bool fullw = prm.W == uint32_t(2 * N);
     using Kern = void (*)(const StftParams);
@@ -196,7 +196,7 @@ template <int LR>
 static hipError_t launchStft(const StftParams &prm, int grid, hipStream_t stream)
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
-    const size_t baseBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
+    const size_t baseBytes = (size_t(N) + (N >> LR) + 12 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
     const size_t slotBytes = size_t(prm.nItems) * 4;
     StftParams p2 = prm;
     size_t ldsBytes = baseBytes;
@@ -220,7 +220,7 @@ template <int LR>
 static hipError_t launchComplex(const StftParams &prm, int grid, hipStream_t stream)
 {
     constexpr int R = 1 << LR, T = R * R, N = R * T;
-    const size_t ldsBytes = (size_t(N) + (N >> LR) + 4 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
+    const size_t ldsBytes = (size_t(N) + (N >> LR) + 12 + 2 * R + 4 + 2 * kSpecBins) * sizeof(float);
     const bool fullw = prm.W == uint32_t(N);
     using Kern = void (*)(const StftParams);
     static const Kern kerns[2] = {&stftComplexKernel<LR, false>, &stftComplexKernel<LR, true>};

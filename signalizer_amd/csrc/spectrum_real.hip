@@ -46,6 +46,7 @@ namespace sgz {
 struct ChannelIndex {
     int n, off;
     static constexpr bool kSkipEmpty = true;
+    static constexpr bool kLinearTaps = false;
     __device__ __forceinline__ int size() const { return n; }
     __device__ __forceinline__ int operator()(int k) const { const int i = k - off; return i + (i >> 5); }
     __device__ __forceinline__ bool holds(int k) const { return k >= off && k <= off + n / 2; }
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             put(M, 0.f);                                                    // csf[N/2]: settled late, can never win meanwhile (strict >)
         }
     }
-    if (nSide && prm.mapped) mapper.prefetchWeights(sp);
+    if (nSide && prm.mapped) mapper.prefetchWeights(sp, tid, nSide);
     ldsBarrier();
     RCLK(7);
     if (prm.binsOut) {                                                      // test hook: this side's half of csf, csf order

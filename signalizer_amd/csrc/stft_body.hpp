@@ -102,6 +102,10 @@ template <int LR>
 struct WholeFrameIndex {
     static constexpr int N = (1 << LR) * (1 << LR) * (1 << LR);
     static constexpr bool kSkipEmpty = false;        // both sides of a view fill the thread batches (measured: a skip gains nothing)
+    // the fused kernel's csf array can be read as kMaxTaps + 1 CONTIGUOUS floats from a tap window's first entry: its pad slots
+    // hold 0, csf[0 .. 9] is repeated behind csf[N] (the window's periodic indexing over N + 1 entries), and the plan's
+    // weights11 table carries a zero where a window steps over a pad slot -- no per-tap address arithmetic, no per-tap select
+    static constexpr bool kLinearTaps = true;
     __device__ __forceinline__ int size() const { return N; }
     __device__ __forceinline__ int operator()(int k) const { return k + (k >> LR); }
     __device__ __forceinline__ bool holds(int) const { return true; }
@@ -111,6 +115,7 @@ struct WholeFrameIndex {
 struct OneSideIndex {
     int n, off;
     static constexpr bool kSkipEmpty = true;         // one side's work list leaves whole waves of a batch slot empty: skip those
+    static constexpr bool kLinearTaps = false;
     __device__ __forceinline__ int size() const { return n; }
     __device__ __forceinline__ int operator()(int k) const
     {
@@ -150,9 +155,10 @@ struct MapPixelsBalanced {
     static constexpr int IB = 4;                                         // items per thread per batch (register budget)
     static constexpr int RB = 2;                                         // records per thread per batch (register budget)
     static constexpr int PB = 10;                                        // piece entries fetched per batch in (c)
+    static constexpr int NW = Index::kLinearTaps ? kMaxTaps + 1 : kMaxTaps;   // weights (and taps) fetched per record
     uint32_t iw0[IB];
     PixelRec rec0[RB];
-    float w0[RB][kMaxTaps];
+    float w0[RB][NW];
 
     __device__ __forceinline__ void loadItems(const MapView &v, uint32_t base, int tid, uint32_t (&iw)[IB]) const
     {
@@ -171,13 +177,21 @@ struct MapPixelsBalanced {
         }
     }
     // tap weights: unconditional, independent loads (the weight table is padded by kMaxTaps zeros)
-    __device__ __forceinline__ void loadWeights(const StftParams &prm, const PixelRec (&rec)[RB], float (&w)[RB][kMaxTaps]) const
+    __device__ __forceinline__ void loadWeights(const StftParams &prm, const PixelRec (&rec)[RB], float (&w)[RB][NW], int base, int tid,
+                                                int total) const
     {
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const int wbase = rec[b].kind == 0 ? rec[b].c : 0;
+            if (Index::kLinearTaps) {                                    // fixed 11 floats per record, indexed by the record
+                const int idx = base + b * NT + tid;
+                const float *src = prm.weights11 + size_t(idx < total ? idx : 0) * NW;
 #pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) w[b][i] = prm.weights[wbase + i];
+                for (int i = 0; i < NW; ++i) w[b][i] = src[i];
+            } else {
+                const int wbase = rec[b].kind == 0 ? rec[b].c : 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) w[b][i] = prm.weights[wbase + i];
+            }
         }
     }
     __device__ __forceinline__ void prefetchTables(const MapView &v, int tid)
@@ -185,7 +199,7 @@ struct MapPixelsBalanced {
         loadItems(v, 0u, tid, iw0);
         loadRecs(v, 0, tid, rec0);
     }
-    __device__ __forceinline__ void prefetchWeights(const StftParams &prm) { loadWeights(prm, rec0, w0); }
+    __device__ __forceinline__ void prefetchWeights(const StftParams &prm, int tid, int total) { loadWeights(prm, rec0, w0, 0, tid, total); }
 
 __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, const Index at, const float *lds, float *win, int tid,
                                     long task)
@@ -239,26 +253,32 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
     const bool oneBatch = total <= NT * RB;                              // then the records stay in registers across the barrier
     PixelRec rec[RB];
     for (int base = 0; base < total; base += NT * RB) {
-        float w[RB][kMaxTaps], mv[RB][kMaxTaps];
+        float w[RB][NW], mv[RB][NW];
         if (base == 0) {
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
                 rec[b] = rec0[b];
 #pragma unroll
-                for (int i = 0; i < kMaxTaps; ++i) w[b][i] = w0[b][i];
+                for (int i = 0; i < NW; ++i) w[b][i] = w0[b][i];
             }
         } else {
             loadRecs(v, base, tid, rec);
-            loadWeights(prm, rec, w);
+            loadWeights(prm, rec, w, base, tid, total);
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             if (Index::kSkipEmpty && base + b * NT + (tid & ~63) >= total) continue;
             int k = rec[b].kind == 0 ? rec[b].a : 0;
+            if (Index::kLinearTaps) {
+                const float *src = lds + at(k);                         // one address, immediate offsets
 #pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) {
-                mv[b][i] = lds[at(k)];
-                k = (k == N) ? 0 : k + 1;
+                for (int i = 0; i < NW; ++i) mv[b][i] = src[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    mv[b][i] = lds[at(k)];
+                    k = (k == N) ? 0 : k + 1;
+                }
             }
         }
 #pragma unroll
@@ -267,9 +287,13 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
             const int idx = base + b * NT + tid;
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < kMaxTaps; ++i) {
+            for (int i = 0; i < NW; ++i) {
                 const float prod = mv[b][i] * w[b][i];
-                acc = (i < rec[b].b) ? acc + prod : acc;               // taps accumulate in order (lanczosFilter restatement)
+                // taps accumulate in order (lanczosFilter restatement).  Linear form: entries that are not taps carry weight +0 and read
+                // a finite value (a zeroed pad slot, or a bin of a frame that is finite wherever this pixel is), so they add +-0 to a
+                // sum that is never -0: the same sum, bit for bit
+                if (Index::kLinearTaps) acc = acc + prod;
+                else acc = (i < rec[b].b) ? acc + prod : acc;
             }
             if (rec[b].kind == 0) out[idx] = finishPixel<LR>(prm.invSize * acc);
         }
@@ -373,7 +397,8 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
     constexpr int T = R * R;
     constexpr int N = R * T;
     constexpr int PADSTRIDE = T + (T >> LR);          // padded distance between k and k + T
-    constexpr int SCRATCH = N + (N >> LR) + 4;        // float index of column 0's 2R-float scratch
+    constexpr int WRAP = N + (N >> LR) + 1;           // csf[0 .. 9] again, behind csf[N] (WholeFrameIndex::kLinearTaps)
+    constexpr int SCRATCH = N + (N >> LR) + 12;       // float index of column 0's 2R-float scratch
     constexpr int SPEC = SCRATCH + 2 * R + 4;         // float index of the kSpecBins csf entries that stay complex (complex_dc.hpp)
     constexpr int SLOTS = SPEC + 2 * kSpecBins;       // float index (even) of the arg-max piece winners (nItems uint2)
     constexpr int TILE = R * (R + 1);
@@ -686,6 +711,10 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                                                                        // done for exchange 1, costs 7 % on a tail-free launch)
 #pragma unroll
         for (int m3 = 0; m3 < R; ++m3) lds[base + m3 * PADSTRIDE] = mag[brev(m3, LR)];
+        if (HALF < 0) {                                             // WholeFrameIndex::kLinearTaps: see the index policy
+            lds[(tid + 1) * (R + 1) - 1] = 0.f;                     // the T = N / R pad slots
+            if (kc >= 1 && kc <= 9) lds[WRAP + kc] = mag[brev(0, LR)];
+        }
         // Column 0 (k = T m3, all held by thread 0) mirrors onto itself and DC / Nyquist are special: redone from thread 0's
         // scratch copy by lanes of the SAME wave, after that wave's own stores above (one wave's LDS operations execute in
         // order), so no extra workgroup barrier is needed.
@@ -707,22 +736,26 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
                 if (split) {
                     lds[N + (N >> LR)] = dcIm * 0.5f;                // csf[N]   = Im(csf[0]) * 0.5   (TransformDSP.inl:861)
                     lds[0] = dcRe * 0.5f;                            // csf[0]   = Re(csf[0]) * 0.5   (:862)
+                    lds[WRAP] = dcRe * 0.5f;
                     lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // :863
                 } else {
                     lds[N + (N >> LR)] = 0.f;
                     lds[0] = 0.5f * __builtin_amdgcn_sqrtf(dcRe * dcRe + dcIm * dcIm);
+                    lds[WRAP] = lds[0];
                     if (mode != SGZ_CH_COMPLEX)
                         lds[N / 2 + ((N / 2) >> LR)] = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
                 }
             }
         }
-        if (doMap) mapper.prefetchWeights(prm);
+        if (doMap) mapper.prefetchWeights(prm, tid, int(prm.sides * prm.P));
         ldsBarrier();
     } else {
         // test path (sgz_stage_map_from_bins): csf magnitudes come from HBM
         const float *src = prm.binsIn + size_t(task) * (N + 1);
-        if (doMap) { mapper.prefetchTables(wholeView(prm, task), tid); mapper.prefetchWeights(prm); }
+        if (doMap) { mapper.prefetchTables(wholeView(prm, task), tid); mapper.prefetchWeights(prm, tid, int(prm.sides * prm.P)); }
         for (int k = tid; k <= N; k += T) lds[k + (k >> LR)] = src[k];
+        lds[(tid + 1) * (R + 1) - 1] = 0.f;
+        if (tid < 10) lds[WRAP + tid] = src[tid];
         ldsBarrier();
     }
     SGZ_CLK(7);
