@@ -115,6 +115,30 @@ struct IngestParams {
     uint32_t colours;                         // colour_by_frequency
 };
 
+// A lane that walks a block sequentially (a recurrence) must not wait a memory round trip per sample: the samples come in batches of
+// 16 independent loads, the next batch in flight while the current one is consumed.  load(i) -> float, step(i, v).
+template <typename Load, typename Step>
+__device__ __forceinline__ void walkSequential(uint32_t n, Load load, Step step)
+{
+    constexpr uint32_t B = 16;
+    const uint32_t full = n & ~(B - 1);                      // whole batches: straight-line code, no per-sample predicate
+    if (full) {
+        float cur[B], nxt[B];
+#pragma unroll
+        for (uint32_t j = 0; j < B; ++j) cur[j] = load(j);
+        for (uint32_t i0 = 0; i0 < full; i0 += B) {
+            const uint32_t in = i0 + B < full ? i0 + B : i0;  // (the last batch reloads itself: uniform code)
+#pragma unroll
+            for (uint32_t j = 0; j < B; ++j) nxt[j] = load(in + j);
+#pragma unroll
+            for (uint32_t j = 0; j < B; ++j) step(i0 + j, cur[j]);
+#pragma unroll
+            for (uint32_t j = 0; j < B; ++j) cur[j] = nxt[j];
+        }
+    }
+    for (uint32_t i = full; i < n; ++i) step(i, load(i));     // < 16 samples
+}
+
 __device__ __forceinline__ float biquadStep(const float *c, float &z0, float &z1, float x)
 {
     const float y = c[0] * x + z0;
@@ -382,7 +406,8 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
             const float *x = prm.block + size_t(c) * n;
             float *out = col.bands + (size_t(c) * 4 + (hp ? 3 : 0)) * MB;
-            for (uint32_t i = 0; i < n; ++i) out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, x[i]));
+            walkSequential(n, [&](uint32_t i) { return x[i]; },
+                           [&](uint32_t i, float v) { out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, v)); });
             z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
         }
         __syncthreads();
@@ -394,7 +419,8 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
             const float *x = col.bands + (size_t(c) * 4 + 3) * MB;
             float *out = col.bands + (size_t(c) * 4 + (hp ? 2 : 1)) * MB;
-            for (uint32_t i = 0; i < n; ++i) out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, x[i]));
+            walkSequential(n, [&](uint32_t i) { return x[i]; },
+                           [&](uint32_t i, float v) { out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, v)); });
             z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
         }
         __syncthreads();
@@ -406,12 +432,12 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             float y = *stp;
             const float pole = col.pole;
             float *out = col.sm + size_t(tid) * MB;
-            for (uint32_t i = 0; i < n; ++i) {
-                const float v = sig == 0 ? l[i] : sig == 1 ? rr[i] : sig == 2 ? l[i] + rr[i] : l[i] - rr[i];
-                const float input = v * v;
-                y = input + pole * (y - input);
-                out[i] = y;
-            }
+            walkSequential(n, [&](uint32_t i) { return sig == 0 ? l[i] : sig == 1 ? rr[i] : sig == 2 ? l[i] + rr[i] : l[i] - rr[i]; },
+                           [&](uint32_t i, float v) {
+                               const float input = v * v;
+                               y = input + pole * (y - input);
+                               out[i] = y;
+                           });
             *stp = y;
         }
         __syncthreads();
@@ -488,27 +514,22 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         bool own = false;
         if (mode == SGZ_OSC_SEPARATE) {
             own = true;
-            if (active) for (uint32_t i = from; i < to; ++i) { const float s = bc[i] * bc[i]; y = s + k * (y - s); }
+            if (active) walkSequential(to - from, [&](uint32_t i) { return bc[from + i]; }, [&](uint32_t, float v) { const float s = v * v; y = s + k * (y - s); });
         } else if (mode == SGZ_OSC_MIDSIDE) {
             if (tid < 2) {
                 own = true;
-                for (uint32_t i = 0; i < to; ++i) {
-                    const float l = b0[i], r = b1[i];
-                    const float s = tid == 0 ? 0.5f * ((l + r) * (l + r)) : 0.5f * ((l - r) * (l - r));
-                    y = s + k * (y - s);
-                }
+                // the mix itself is exact in either order of evaluation: (l +- r) once, squared, halved
+                walkSequential(to, [&](uint32_t i) { return tid == 0 ? b0[i] + b1[i] : b0[i] - b1[i]; },
+                               [&](uint32_t, float v) { const float s = 0.5f * (v * v); y = s + k * (y - s); });
             }
         } else if (tid == 0) {
             own = true;
             const float *src = mode == SGZ_OSC_RIGHT ? b1 : b0;
-            for (uint32_t i = 0; i < to; ++i) {
-                float v;
-                if (mode == SGZ_OSC_MID) v = 0.5f * (b0[i] + b1[i]);
-                else if (mode == SGZ_OSC_SIDE) v = 0.5f * (b0[i] - b1[i]);
-                else v = src[i];
-                const float s = v * v;
-                y = s + k * (y - s);
-            }
+            // (one walk per mode: a branch inside the load would keep the batch of loads from being issued together)
+            auto rms = [&](uint32_t, float v) { const float s = v * v; y = s + k * (y - s); };
+            if (mode == SGZ_OSC_MID) walkSequential(to, [&](uint32_t i) { return 0.5f * (b0[i] + b1[i]); }, rms);
+            else if (mode == SGZ_OSC_SIDE) walkSequential(to, [&](uint32_t i) { return 0.5f * (b0[i] - b1[i]); }, rms);
+            else walkSequential(to, [&](uint32_t i) { return src[i]; }, rms);
         }
         // filterEnv[c] of the last call: copies of channel 0 (mono modes) / channel 1 (MidSide) where the channel has no recurrence
         const float y0 = __shfl(y, 0), y1 = __shfl(y, 1);
