@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -296,6 +297,11 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         sgz_status stw = ensureCap(&p.d_phaseWork, &p.phaseWorkCap, size_t(frames) * p.C * p.P);
         if (stw != SGZ_OK) return stw;
         SGZ_HIP(launchDecayPhase(prm, p.d_phaseWork, stream));
+        return SGZ_OK;
+    }
+    static const bool noFused = std::getenv("SGZ_KB_FUSED") && std::getenv("SGZ_KB_FUSED")[0] == '0';   // A/B switch for measurements
+    if (!noFused && decayColourFusedApplies(prm)) {
+        SGZ_HIP(launchDecayColourFused(prm, stream));
         return SGZ_OK;
     }
     if (prm.numChunks > 1) {

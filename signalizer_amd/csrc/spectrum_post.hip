@@ -180,6 +180,87 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
     }
 }
 
+// The whole of K_B as ONE launch for the commonest request: the colour column only (no line results, no state out), one pair, at
+// most kFusedChunks time chunks.  A workgroup of 1024 threads owns PX = 4 pixels for the whole time axis:
+//   1. threads (chunk, px) < 64 x 4 load their chunk's magnitudes (side 0), park them in LDS and scan the chunk from a zero carry;
+//   2. 4 threads fold the chunk-end states with the same sequential multiplies as decayCarryKernel;
+//   3. ALL threads share the frames x 4 emissions (replay <= 8 steps from the LDS magnitudes on the folded carry-in, dB map, colour).
+// Nothing goes through HBM between the steps and there is one launch instead of two.
+template <int PX>
+__global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams prm)
+{
+    __shared__ float aggS[kFusedChunks][PX];                    // chunk-end states of the zero-carry scans
+    __shared__ float carryS[kFusedChunks][PX];                  // exact state at the end of chunk d (after the fold)
+    __shared__ float magS[kFusedChunks * kMaxChunk][PX];
+    const uint32_t tid = threadIdx.x;
+    const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
+    const float pole = prm.sc.pole[0];
+    // 1a. every thread fetches its share of the frames x PX magnitudes (side 0 of the pair)
+    const uint32_t items = uint32_t(prm.frames) * PX;
+    for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX; e += 1024) {
+        const uint32_t px = e % PX, f = e / PX;
+        const uint32_t pixel = blockIdx.x * PX + px;
+        magS[f][px] = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] : 0.f;
+    }
+    __syncthreads();
+    // 1b. zero-carry scan of every chunk
+    if (tid < kFusedChunks * PX) {
+        const uint32_t px = tid % PX, chunk = tid / PX;
+        const uint32_t pixel = blockIdx.x * PX + px;
+        const long f0 = long(chunk) * kMaxChunk;
+        const int len = chunk < prm.numChunks ? int(min(long(kMaxChunk), prm.frames - f0)) : 0;
+        float a = (pixel < prm.P && chunk == 0 && prm.stateIn) ? prm.stateIn[size_t(pixel) * 2] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kMaxChunk; ++t)
+            if (t < len) {
+                const float m = magS[chunk * kMaxChunk + t][px];
+                a = a * pole;                                   // states[i] *= pole, TransformDSP.inl:1336,:1370
+                if (m > a) a = m;                               // :1338-1341
+            }
+        aggS[chunk][px] = a;
+    }
+    __syncthreads();
+    // 2. the fold: sequential by nature (8 dependent multiplies per chunk); the aggregates are read 16 at a time so that the chain
+    //    never waits for LDS
+    if (tid < PX) {
+        float c = aggS[0][tid];
+        carryS[0][tid] = c;
+        for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = aggS[min(d0 + j, uint32_t(kFusedChunks - 1))][tid];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (d0 + j < prm.numChunks) {
+#pragma unroll
+                    for (int i = 0; i < kMaxChunk; ++i) c = c * pole;  // every chunk before the last is full
+                    if (v[j] > c) c = v[j];
+                    carryS[d0 + j][tid] = c;
+                }
+        }
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < items; e += 1024) {
+        const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
+        const uint32_t pixel = blockIdx.x * PX + px;
+        if (pixel >= prm.P) continue;
+        float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[size_t(pixel) * 2] : 0.f;
+        float cr = chunk > 0 ? carryS[chunk - 1][px] : 0.f;    // exact state at the end of the previous chunk
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i)
+            if (uint32_t(i) <= t) {
+                const float m = magS[chunk * kMaxChunk + i][px];
+                a = a * pole;
+                if (m > a) a = m;
+                cr = cr * pole;
+            }
+        const float st = a > cr ? a : cr;
+        float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
+        blendColour(cb, dbMap(prm.slope[pixel], st, prm.sc), prm.colourTables, prm.sc);
+        reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+    }
+}
+
 // K_B2 (after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels, so the GPU sees frames*P
 // threads (the fp64 log of dbMap is ~200 instructions; with one thread per (chunk, pixel) a wave would issue eight of them
 // back to back on an otherwise empty SIMD).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) only
@@ -425,6 +506,17 @@ hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
         hipLaunchKernelGGL(decayCarryKernel<uint32_t>, dim3(grid), dim3(block), 0, stream, prm);
     else
         hipLaunchKernelGGL(decayCarryKernel<size_t>, dim3(grid), dim3(block), 0, stream, prm);
+    return hipGetLastError();
+}
+
+bool decayColourFusedApplies(const DecayParams &prm)
+{
+    return prm.rgba && !prm.lines && !prm.state && prm.C == 1 && prm.numChunks <= uint32_t(kFusedChunks);
+}
+hipError_t launchDecayColourFused(const DecayParams &prm, hipStream_t stream)
+{
+    constexpr int PX = 4;
+    hipLaunchKernelGGL(decayColourFusedKernel<PX>, dim3((prm.P + PX - 1) / PX), dim3(1024), 0, stream, prm);
     return hipGetLastError();
 }
 
