@@ -165,6 +165,12 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
                                   uint32_t num_channels, size_t nsamples, uint8_t *rgba_out,
                                   float *lines_out, sgz_timing *timing);
 
+/* Device memory for the display hand-off: `bytes` rounded up to whole pages, exported as a dma-buf file descriptor
+ * (dmabuf_fd may be NULL: plain allocation) that the GL / Vulkan context of the display GPU imports (EXT_memory_object_fd) -- an MI355X
+ * has no graphics engine of its own.  The caller closes the fd and frees the memory with sgz_export_free. */
+sgz_status sgz_export_alloc(size_t bytes, void **d_ptr, size_t *allocated, int *dmabuf_fd);
+void       sgz_export_free(void *d_ptr);
+
 /* Stage entry points (parity tests call these through the ABI; all DEVICE pointers, async on stream):
  *  bins:   per (frame,pair) the post-split magnitude array csf[0..N] of mapToLinearSpace
  *          (TransformDSP.inl:858-869 for Separate/MidSide; :553-560 mono modes) as float [N+1];
@@ -394,6 +400,10 @@ size_t     sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view
  * falls back to Linear like the reference (OscilloscopeRendering.cpp:575-578): x is then the sample index (sample space). */
 sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz,
                               uint8_t *rgba, uint32_t *count);
+/* The same stream into DEVICE buffers -- a mapped vertex buffer object, or memory from sgz_export_alloc that the display GPU's GL /
+ * Vulkan imported -- without the D2H copy.  In place when the call returns. */
+sgz_status sgz_scope_vertices_device(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
+                                     uint8_t *d_rgba, uint32_t *count);
 /* parity hooks: front buffer memory of one channel (begin()) + its write cursor; TriggeringProcessor counters
  * {frontOrigin, bufferedSamples, oldPeak, currentPeak, steadyClock, peaks.size(), isWorkingOnPeak, swaps} */
 sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out /*size*/, uint32_t *size, uint32_t *cursor);
@@ -440,6 +450,7 @@ sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, do
 /* xyz: float3 [window_size], rgb: float3 [window_size] or NULL; *count: in = capacity in vertices, out = window_size.  Vertex
  * order = the reference's: the older section of the ring ([cursor, size)) first, then [0, cursor). */
 sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count);
+sgz_status sgz_vector_vertices_device(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb, uint32_t *count);   /* DEVICE buffers */
 /* parity hook: history ring memory of one channel + the write cursor */
 sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out /*window_size*/, uint32_t *size, uint32_t *cursor);
 

@@ -123,7 +123,7 @@ EXPORTS = [
     "sgz_spectrum_flush_columns",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
-    "sgz_scope_front_colours",
+    "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
     "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
@@ -218,6 +218,11 @@ def lib() -> C.CDLL:
     L.sgz_scope_debug_state.argtypes = [vp, vp]
     L.sgz_scope_analyse.argtypes = [vp, u32, u32, C.POINTER(TriggerState)]
     L.sgz_scope_front_colours.argtypes = [vp, u32, u32, vp]
+    L.sgz_scope_vertices_device.argtypes = [vp, C.POINTER(ScopeView), u32, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_vector_vertices_device.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_export_alloc.argtypes = [sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]
+    L.sgz_export_free.argtypes = [vp]
+    L.sgz_export_free.restype = None
     L.sgz_vector_create.argtypes = [C.POINTER(VectorConfig), C.POINTER(vp)]
     L.sgz_vector_destroy.argtypes = [vp]
     L.sgz_vector_destroy.restype = None

@@ -544,6 +544,26 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
     return st;
 }
 
+// Device memory another API can import: allocated here, exported as a dma-buf fd (whole pages).  For the vertex / image hand-off to a
+// GL or Vulkan context on the display GPU (an MI355X has no graphics engine): glImportMemoryFdEXT + glNamedBufferStorageMemEXT.
+sgz_status sgz_export_alloc(size_t bytes, void **d_ptr, size_t *allocated, int *dmabuf_fd)
+{
+    if (!bytes || !d_ptr) return fail(SGZ_EINVAL, "bad argument");
+    const size_t rounded = (bytes + 4095) & ~size_t(4095);
+    void *p = nullptr;
+    SGZ_HIP(hipMalloc(&p, rounded));
+    int fd = -1;
+    if (dmabuf_fd) {
+        const hipError_t e = hipMemGetHandleForAddressRange(&fd, p, rounded, hipMemRangeHandleTypeDmaBufFd, 0);
+        if (e != hipSuccess) { (void)hipFree(p); return hipFail(e, "hipMemGetHandleForAddressRange (dma-buf export)"); }
+        *dmabuf_fd = fd;
+    }
+    *d_ptr = p;
+    if (allocated) *allocated = rounded;
+    return SGZ_OK;
+}
+void sgz_export_free(void *d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }
+
 sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
                           float *d_bins, void *stream)
 {

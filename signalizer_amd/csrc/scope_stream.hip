@@ -1200,11 +1200,10 @@ sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel,
     return SGZ_OK;
 }
 
-sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz, uint8_t *rgba,
-                              uint32_t *count)
+// one evaluator's vertex stream into DEVICE buffers (the handle's own, or the caller's mapped VBO); *points = vertices written
+static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
+                                    uint32_t *d_rgba, size_t capacity, size_t *points)
 {
-    if (!s || !view || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
-    if (view->width < 2 || !(view->right > view->left)) return fail(SGZ_EINVAL, "bad view");
     const uint32_t C = s->cfg.num_channels;
     // SampleColourEvaluator<OscChannels::...>, SampleColourEvaluators.h: Left / Right read one channel, Mid / Side 0.5 (l +- r)
     uint32_t chA, chB, evalMode, colourCh;
@@ -1218,6 +1217,26 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     if (chA >= C || chB >= C) return fail(SGZ_EINVAL, "channel out of range");
     sgz_scope_view v = *view;
     v.window_size = s->cfg.window_size;                               // state.effectiveWindowSize is the stream's
+    uint32_t key;
+    std::memcpy(&key, s->cfg.colours[colourCh], 4);                    // evaluator.getDefaultKey()
+    // colourChannelsByFrequency: Left / Right read colourData of their channel, Mid / Side auxColourData (SampleColourEvaluators.h:64,183)
+    const uint32_t *colRing = nullptr;
+    if (s->cfg.colour_by_frequency && d_rgba)
+        colRing = s->col.front + size_t((evalMode == 0 ? 0u : C) + colourCh) * s->size;
+    SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, s->d_front + size_t(chA) * s->size,
+                                s->d_front + size_t(chB) * s->size, evalMode, uint32_t(s->trig.ring_size), s->size,
+                                reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
+                                s->trig.cycle_samples, s->trig.sample_offset, key, colRing, d_xyz, d_rgba, capacity, points, s->stream));
+    return SGZ_OK;
+}
+
+sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz, uint8_t *rgba,
+                              uint32_t *count)
+{
+    if (!s || !view || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
+    if (view->width < 2 || !(view->right > view->left)) return fail(SGZ_EINVAL, "bad view");
+    sgz_scope_view v = *view;
+    v.window_size = s->cfg.window_size;
     const size_t need = scopeVertexCount(v, s->cfg.interpolation, s->cfg.trigger_mode, s->trig.cycle_samples);
     if (need > *count) { *count = uint32_t(need); return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
     if (s->vertexCap < need) {
@@ -1230,18 +1249,9 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
         SGZ_HIP(hipHostMalloc(&s->h_out, need * 16, hipHostMallocDefault));
         s->vertexCap = need;
     }
-    uint32_t key;
-    std::memcpy(&key, s->cfg.colours[colourCh], 4);                    // evaluator.getDefaultKey()
     size_t points = 0;
-    // colourChannelsByFrequency: Left / Right read colourData of their channel, Mid / Side auxColourData (SampleColourEvaluators.h:64,183)
-    const uint32_t *colRing = nullptr;
-    if (s->cfg.colour_by_frequency && rgba)
-        colRing = s->col.front + size_t((evalMode == 0 ? 0u : C) + colourCh) * s->size;
-    SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, s->d_front + size_t(chA) * s->size,
-                                s->d_front + size_t(chB) * s->size, evalMode, uint32_t(s->trig.ring_size), s->size,
-                                reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
-                                s->trig.cycle_samples, s->trig.sample_offset, key, colRing, s->d_xyz, rgba ? s->d_rgba : nullptr, need,
-                                &points, s->stream));
+    const sgz_status st = scopeVerticesInto(s, view, evaluator, channel, s->d_xyz, rgba ? s->d_rgba : nullptr, need, &points);
+    if (st != SGZ_OK) return st;
     float *hx = static_cast<float *>(s->h_out);
     uint32_t *hc = reinterpret_cast<uint32_t *>(hx + need * 3);
     SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, points * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -1249,6 +1259,24 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     SGZ_HIP(hipStreamSynchronize(s->stream));
     std::memcpy(xyz, hx, points * 3 * sizeof(float));
     if (rgba) std::memcpy(rgba, hc, points * 4);
+    *count = uint32_t(points);
+    return SGZ_OK;
+}
+
+sgz_status sgz_scope_vertices_device(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
+                                     uint8_t *d_rgba, uint32_t *count)
+{
+    if (!s || !view || !d_xyz || !count) return fail(SGZ_EINVAL, "null argument");
+    if (view->width < 2 || !(view->right > view->left)) return fail(SGZ_EINVAL, "bad view");
+    if ((reinterpret_cast<uintptr_t>(d_xyz) & 3) || (reinterpret_cast<uintptr_t>(d_rgba) & 3)) return fail(SGZ_EINVAL, "4-byte aligned buffers");
+    sgz_scope_view v = *view;
+    v.window_size = s->cfg.window_size;
+    const size_t need = scopeVertexCount(v, s->cfg.interpolation, s->cfg.trigger_mode, s->trig.cycle_samples);
+    if (need > *count) { *count = uint32_t(need); return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
+    size_t points = 0;
+    const sgz_status st = scopeVerticesInto(s, view, evaluator, channel, d_xyz, reinterpret_cast<uint32_t *>(d_rgba), need, &points);
+    if (st != SGZ_OK) return st;
+    SGZ_HIP(hipStreamSynchronize(s->stream));                 // the vertices are in place when the call returns
     *count = uint32_t(points);
     return SGZ_OK;
 }

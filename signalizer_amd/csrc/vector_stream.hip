@@ -372,21 +372,30 @@ sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint3
     return SGZ_OK;
 }
 
+// the kernels of one pair's vertex stream into DEVICE buffers (the handle's own, or the caller's mapped VBO)
+static sgz_status vectorVerticesInto(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb)
+{
+    const uint32_t size = s->size;
+    hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
+    PolarParams prm{};
+    prm.st = s->d_state; prm.ring = s->d_ring; prm.size = size; prm.lanes = s->cfg.lanes; prm.fade = s->cfg.fade_history ? 1u : 0u;
+    prm.ramp = s->d_ramp; prm.tail = s->d_tail;
+    prm.xyz = reinterpret_cast<float3 *>(d_xyz); prm.rgb = reinterpret_cast<float3 *>(d_rgb);
+    for (int k = 0; k < 3; ++k) prm.colour[k] = s->cfg.colours[pair][k];
+    prm.pair = pair;
+    hipLaunchKernelGGL(vectorPolarViewKernel, dim3((size + 255) / 256), dim3(256), 0, s->stream, prm);
+    SGZ_HIP(hipGetLastError());
+    return SGZ_OK;
+}
+
 sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count)
 {
     if (!s || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
     if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
     const uint32_t size = s->size;
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
-    hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
-    PolarParams prm{};
-    prm.st = s->d_state; prm.ring = s->d_ring; prm.size = size; prm.lanes = s->cfg.lanes; prm.fade = s->cfg.fade_history ? 1u : 0u;
-    prm.ramp = s->d_ramp; prm.tail = s->d_tail;
-    prm.xyz = reinterpret_cast<float3 *>(s->d_xyz); prm.rgb = rgb ? reinterpret_cast<float3 *>(s->d_rgb) : nullptr;
-    for (int k = 0; k < 3; ++k) prm.colour[k] = s->cfg.colours[pair][k];
-    prm.pair = pair;
-    hipLaunchKernelGGL(vectorPolarViewKernel, dim3((size + 255) / 256), dim3(256), 0, s->stream, prm);
-    SGZ_HIP(hipGetLastError());
+    const sgz_status st = vectorVerticesInto(s, pair, s->d_xyz, rgb ? s->d_rgb : nullptr);
+    if (st != SGZ_OK) return st;
     float *hx = static_cast<float *>(s->h_out);
     SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     if (rgb) SGZ_HIP(hipMemcpyAsync(hx + size_t(size) * 3, s->d_rgb, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -394,6 +403,18 @@ sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *
     std::memcpy(xyz, hx, size_t(size) * 3 * sizeof(float));
     if (rgb) std::memcpy(rgb, hx + size_t(size) * 3, size_t(size) * 3 * sizeof(float));
     *count = size;
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_vertices_device(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb, uint32_t *count)
+{
+    if (!s || !d_xyz || !count) return fail(SGZ_EINVAL, "null argument");
+    if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
+    if (*count < s->size) { *count = s->size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
+    const sgz_status st = vectorVerticesInto(s, pair, d_xyz, d_rgb);
+    if (st != SGZ_OK) return st;
+    SGZ_HIP(hipStreamSynchronize(s->stream));                 // the vertices are in place when the call returns
+    *count = s->size;
     return SGZ_OK;
 }
 

@@ -345,3 +345,60 @@ def test_spectral_rejects_bad_config(gpu):
         api.Scope(**_cfg(trigger_mode=2))                                          # Window: not built
     with pytest.raises(api.SgzError):
         api.Scope(**_cfg(colour_by_frequency=1, sample_rate=4000.0, band_colours=BANDS))
+
+
+def test_vertices_into_device_buffers(gpu):
+    """SURVEY 8(f) #1, vertex side: sgz_scope_vertices_device / sgz_vector_vertices_device write the streams the host calls return into
+    caller-owned DEVICE memory (a mapped vertex buffer, or sgz_export_alloc memory exported as a dma-buf) without the D2H copy"""
+    import ctypes as C
+    import os
+    import torch
+    L = api.lib()
+    cfg = _cfg(window_size=3000.0, colours=[(10, 20, 30, 255), (200, 100, 50, 255)], colour_by_frequency=1, frequency_colouring_blend=0.7,
+               colour_smoothing_ms=3.0, band_colours=BANDS)
+    dev = api.Scope(**cfg)
+    x = _colour_signal(9, 20000, 2, SR)
+    for pos in range(0, x.shape[1], 1000):
+        _push(dev, x[:, pos:pos + 1000])
+    v = api.ScopeView(3000.0, 0.0, 1.0, 1.0, 6001, 0)
+    for evaluator in (0, 3):
+        want_xyz, want_rgba = dev.vertices(v, evaluator, 0)
+        n = want_xyz.shape[0]
+        # exported memory: one allocation for vertices + colours
+        d_ptr, got_bytes, fd = C.c_void_p(), C.c_size_t(0), C.c_int(-1)
+        api.check(L.sgz_export_alloc(n * 16, C.byref(d_ptr), C.byref(got_bytes), C.byref(fd)))
+        try:
+            assert fd.value >= 0 and got_bytes.value >= n * 16 and got_bytes.value % 4096 == 0
+            os.fstat(fd.value)
+            cnt = C.c_uint32(n)
+            api.check(L.sgz_scope_vertices_device(dev.h, C.byref(v), evaluator, 0, d_ptr, C.c_void_p(d_ptr.value + n * 12), C.byref(cnt)))
+            assert cnt.value == n
+            host = np.zeros(n * 16, np.uint8)
+            hip = C.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), d_ptr, C.c_size_t(host.nbytes), 2) == 0
+            assert np.array_equal(host[:n * 12].view(np.float32).reshape(n, 3), want_xyz)
+            assert np.array_equal(host[n * 12:].reshape(n, 4), want_rgba)
+            cnt = C.c_uint32(n - 1)
+            assert L.sgz_scope_vertices_device(dev.h, C.byref(v), evaluator, 0, d_ptr, None, C.byref(cnt)) == api.SGZ_EINVAL and cnt.value == n
+        finally:
+            os.close(fd.value)
+            L.sgz_export_free(d_ptr)
+    dev.close()
+
+    vec = api.Vector(sample_rate=96000.0, num_channels=4, window_size=2000, envelope_mode=2, lanes=8, fade_history=1, max_block=512,
+                     envelope_window=0.3, stereo_window=0.1, colours=[(1.0, 0.5, 0.25), (0.2, 0.9, 0.4)])
+    y = _colour_signal(4, 5000, 4, 96000.0)
+    for pos in range(0, y.shape[1], 500):
+        while vec.push(y[:, pos:pos + 500]) == api.SGZ_BUSY:
+            pass
+    for pair in (0, 1):
+        want_xyz, want_rgb = vec.vertices(pair)
+        n = want_xyz.shape[0]
+        t_xyz = torch.zeros((n, 3), dtype=torch.float32, device=gpu)
+        t_rgb = torch.zeros((n, 3), dtype=torch.float32, device=gpu)
+        cnt = C.c_uint32(n)
+        api.check(L.sgz_vector_vertices_device(vec.h, pair, t_xyz.data_ptr(), t_rgb.data_ptr(), C.byref(cnt)))
+        torch.cuda.synchronize()
+        assert cnt.value == n
+        assert np.array_equal(t_xyz.cpu().numpy(), want_xyz) and np.array_equal(t_rgb.cpu().numpy(), want_rgb)
+    vec.close()
