@@ -547,7 +547,6 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             if (!right) { lo = k & 15; n = std::min<long>(16 - lo, oEnd - o); hi = lo + n - 1; }
             else { hi = k & 15; n = std::min<long>(hi + 1, oEnd - o); lo = hi - n + 1; }
             MaxItem it;
-            it.slot = uint32_t(r);
             it.win = uint32_t(w) | (uint32_t(lo) << 16) | (uint32_t(hi) << 20);
             p.items.push_back(it);
             ++pieces;

@@ -27,8 +27,7 @@ struct PixelRec {
 // Pieces of a run are listed in the reference's scan order (ascending offset: ascending k on the left side,
 // descending k on the right side, where k = N - offset).
 struct MaxItem {
-    uint32_t slot;      // side * P + pixel (informational)
-    uint32_t win;       // w | lo << 16 | hi << 20
+    uint32_t win;       // w | lo << 16 | hi << 20   (one word per piece: every workgroup of a launch reads the whole list)
 };
 
 // Scalars the kernels need (all derived on the host exactly as the reference derives them).

@@ -184,7 +184,8 @@ struct MapPixelsBalanced {
         for (int b = 0; b < RB; ++b) {
             if (Index::kLinearTaps) {                                    // fixed 11 floats per record, indexed by the record
                 const int idx = base + b * NT + tid;
-                const float *src = prm.weights11 + size_t(idx < total ? idx : 0) * NW;
+                // (arg-max records carry no weights: they all read record 0's slot -- one broadcast line instead of 44 bytes each)
+                const float *src = prm.weights11 + size_t(idx < total && rec[b].kind == 0 ? idx : 0) * NW;
 #pragma unroll
                 for (int i = 0; i < NW; ++i) w[b][i] = src[i];
             } else {
