@@ -402,3 +402,47 @@ def test_vertices_into_device_buffers(gpu):
         assert cnt.value == n
         assert np.array_equal(t_xyz.cpu().numpy(), want_xyz) and np.array_equal(t_rgb.cpu().numpy(), want_rgb)
     vec.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scope_configurations(gpu, oracle, seed):
+    """seeded sweep over the handle's configuration space (channels, trigger / channel / envelope modes, window, threshold, colouring,
+    sample rate) and block schedules (1 .. 3000 samples, incl. blocks shorter than one prefetch batch): trigger bookkeeping, rings, colour
+    rings, envelopes -- everything bit for bit"""
+    po = oracle
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.choice([2, 2, 4, 6]))
+    sr = float(rng.choice([44100.0, 48000.0, 96000.0, 192000.0]))
+    colours = bool(rng.integers(0, 2))
+    cfg = _cfg(sample_rate=sr, window_size=float(np.round(rng.uniform(40, 4000), int(rng.integers(0, 3)))), num_channels=C,
+               trigger_mode=int(rng.choice([0, 4, 4])), channel_mode=int(rng.integers(0, 6)), envelope_mode=int(rng.integers(0, 3)),
+               trigger_threshold=float(rng.choice([0.0, 0.05, 0.3, 2.0])), trigger_channel=float(rng.integers(1, C + 1)),
+               envelope_window=float(rng.uniform(0.01, 0.5)), colour_by_frequency=int(colours),
+               frequency_colouring_blend=float(rng.choice([0.0, 0.25, 1.0])), colour_smoothing_ms=float(rng.uniform(0.2, 20.0)),
+               band_colours=BANDS, colours=(KEYS * 16)[:C])
+    n = int(rng.integers(8000, 40000))
+    x = _colour_signal(seed, n, C, sr) * np.float32(rng.uniform(0.1, 1.5))
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(C, sr, cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"], cfg["channel_mode"], cfg["trigger_channel"],
+                         cfg["envelope_mode"], cfg["envelope_window"])
+    if colours:
+        ref.enable_colours(BANDS, cfg["frequency_colouring_blend"], cfg["colour_smoothing_ms"], (KEYS * 16)[:C])
+    pos = 0
+    while pos < n:
+        m = int(rng.choice([rng.integers(1, 16), rng.integers(16, 600), rng.integers(600, 3000)]))
+        _push(dev, x[:, pos:pos + m]); ref.audio(x[:, pos:pos + m])
+        pos += m
+    assert dev.state() == ref.state(), cfg
+    for c in range(C):
+        a, cur = dev.front(c)
+        b, wcur = ref.front(c)
+        assert cur == wcur and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (cfg, c)
+        if colours:
+            for aux in (False, True):
+                assert np.array_equal(dev.front_colours(c, aux), ref.front_colours(c, aux)[0]), (cfg, c, aux)
+    gain, env = dev.gains()
+    if cfg["envelope_mode"] == 1:
+        assert gain == ref.envelope_gain and np.array_equal(env[:2].view(np.uint32), ref.envelopes()[:2].view(np.uint32)), cfg
+    if cfg["envelope_mode"] == 2:
+        coeff = float(np.power(np.exp(-8.0 / (cfg["envelope_window"] * sr)), ref.size / 60))
+        assert dev.peak_filter(1 / 60, 8) == ref.peak_filter(8, coeff), cfg
