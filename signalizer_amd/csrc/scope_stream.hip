@@ -456,35 +456,48 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     const uint32_t size = prm.size;
     uint32_t cursor = sCursor0;
     const unsigned long long written0 = sWritten0;
-    auto appendFront = [&](unsigned long long src, uint32_t len) {
+    // `later`: samples that swaps after this one (same block) will append.  The ring holds `size` samples, so whatever this swap writes
+    // survives only where fewer than `size` samples follow: a noisy signal fires a dozen triggers per block, each swap copies a
+    // window's worth, and only the last one or two are still there when the block is done -- the others just move the cursor.
+    auto appendFront = [&](unsigned long long src, uint32_t len, unsigned long long later) {
         // only the last `size` samples of a longer run survive in the ring
-        const uint32_t skip = len > size ? len - size : 0;
+        uint32_t skip = len > size ? len - size : 0;
         const uint32_t cur0 = uint32_t((cursor + skip) % size);
-        const uint32_t m = len - skip;
-        for (uint32_t e = tid; e < m * C; e += T) {
-            const uint32_t c = e / m, i = e - c * m;
-            const unsigned long long abs = src + skip + i;
-            const float v = abs >= written0 ? prm.block[size_t(c) * n + uint32_t(abs - written0)]
-                                            : prm.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
-            uint32_t d = cur0 + i; if (d >= size) d -= size;
-            prm.front[size_t(c) * size + d] = v;
-        }
-        if (prm.colours)
-            for (uint32_t e = tid; e < m * 2 * C; e += T) {
-                const uint32_t c = e / m, i = e - c * m;
-                const unsigned long long abs = src + skip + i;
-                const uint32_t v = abs >= written0 ? col.block[size_t(c) * col.maxBlock + uint32_t(abs - written0)]
-                                                   : col.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
-                uint32_t d = cur0 + i; if (d >= size) d -= size;
-                col.front[size_t(c) * size + d] = v;
+        // of the remaining m samples the first `dead` are overwritten by the later swaps
+        const uint32_t m0 = len - skip;
+        const unsigned long long room = later >= size ? 0ull : size - later;          // newest samples of this swap that stay visible
+        const uint32_t dead = m0 > room ? uint32_t(m0 - room) : 0u;
+        const uint32_t m = m0 - dead;
+        for (uint32_t c = 0; c < C; ++c)
+            for (uint32_t i = tid; i < m; i += T) {
+                const unsigned long long abs = src + skip + dead + i;
+                const float v = abs >= written0 ? prm.block[size_t(c) * n + uint32_t(abs - written0)]
+                                                : prm.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
+                uint32_t d = (cur0 + dead + i) % size;
+                prm.front[size_t(c) * size + d] = v;
             }
+        if (prm.colours)
+            for (uint32_t c = 0; c < 2 * C; ++c)
+                for (uint32_t i = tid; i < m; i += T) {
+                    const unsigned long long abs = src + skip + dead + i;
+                    const uint32_t v = abs >= written0 ? col.block[size_t(c) * col.maxBlock + uint32_t(abs - written0)]
+                                                       : col.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
+                    uint32_t d = (cur0 + dead + i) % size;
+                    col.front[size_t(c) * size + d] = v;
+                }
         cursor = uint32_t((cursor + len) % size);
         __syncthreads();
     };
     if (prm.triggerMode == 4u) {
         const uint32_t ns = sNumSwaps;
-        for (uint32_t k = 0; k < ns; ++k) appendFront(prm.swapList[k].src, prm.swapList[k].len);
-    } else appendFront(written0, n);
+        // suffix sums of the swap lengths: thread-private walk from the back (the list is short)
+        unsigned long long later = 0;
+        for (uint32_t k = 0; k < ns; ++k) later += prm.swapList[k].len;
+        for (uint32_t k = 0; k < ns; ++k) {
+            later -= prm.swapList[k].len;
+            appendFront(prm.swapList[k].src, prm.swapList[k].len, later);
+        }
+    } else appendFront(written0, n, 0ull);
 
     // ---- D: the block goes into the back rings (ZeroCrossing only; absolute index mod backCap)
     if (prm.triggerMode == 4u) {
