@@ -943,6 +943,7 @@ static sgz_status scopeValidate(const sgz_scope_config *c)
         return fail(SGZ_EUNSUPPORTED, "sub-sample interpolation: Linear or Lanczos");
     if (!std::isfinite(c->trigger_threshold) || !std::isfinite(c->trigger_channel) || !(c->trigger_channel >= 1)) return fail(SGZ_EINVAL, "trigger");
     if (!std::isfinite(c->envelope_window) || c->envelope_window < 0) return fail(SGZ_EINVAL, "envelope_window");
+    if (c->max_block > (1u << 17)) return fail(SGZ_EINVAL, "max_block above 131072 samples");
     return SGZ_OK;
 }
 

@@ -254,6 +254,7 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
     if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     SGZ_HIP(hipStreamSynchronize(s->stream));
     const uint32_t C = cfg->num_channels, size = cfg->window_size;
+    if (cfg->max_block > (1u << 17)) return fail(SGZ_EINVAL, "max_block above 131072 samples");
     const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
     const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock;
     if (realloc) {
