@@ -122,7 +122,7 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
 #define SGZ_PATH_FUSED    1u
 #define SGZ_PATH_HALVES   2u
 #define SGZ_PATH_SIDE_MAP 4u
-#define SGZ_PATH_CHANNEL_SPLIT 8u   /* Separate mode, N = 32768 / 65536, W == N, even hop: one workgroup per (frame, pair, channel) with a
+#define SGZ_PATH_CHANNEL_SPLIT 8u   /* Separate mode, N = 16384 / 32768 / 65536, W == N, even hop: one workgroup per (frame, pair, channel) with a
                                        real-input FFT (spectrum_real.hip) takes the place of the kernels above for device buffers whose
                                        rows are 8-byte aligned */
 uint32_t   sgz_plan_path(const sgz_plan *plan);

@@ -189,7 +189,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.mapped = d_mapped; rp.binsOut = d_binsOut;
         rp.ny = p.d_ny; rp.nyFlag = p.d_nyFlag; rp.nyBest = p.d_nyBest; rp.epoch = p.nyEpoch;
         rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
-        rp.roundSize = uint32_t(numCUs()) * (p.N == 32768 ? 2u : 1u);
+        rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
 #endif

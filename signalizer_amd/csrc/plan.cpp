@@ -610,7 +610,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         }
     }
     // channel-split path (spectrum_real.hip): eligibility and tables
-    p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
+    p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
                   p.dcPixels.empty() && !p.items.empty();
     if (p.realSplit) {
         const long N = long(p.N), M = N / 2;
@@ -641,7 +641,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         }
         const size_t nLeft = p.nItemsLeft, nRight = p.items.size() - p.nItemsLeft;
         const size_t ldsFloats = size_t(M + 1) + size_t((M + 1) >> 5) + 2;
-        const size_t budget = (p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
+        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
         if (std::max(nLeft, nRight) * 4 > budget) p.realSplit = false;
     }
     // Which eligible plans take it.  Measured on MI355X (tools/ka_time.py): at N = 65536 the fused channel workgroups beat the half-frame
@@ -649,7 +649,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // tasks still trail the whole-frame kernel (53.7 us against 47.4 us at 348 frames), so that size stays on stftMapKernel unless asked
     // for.  SGZ_CHANNEL_SPLIT=1 / 0 forces the choice for every eligible plan (A/B runs, and the tests of the N = 32768 variant).
     if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
-    else if (p.N != 65536) p.realSplit = false;
+    else if (p.N == 32768) p.realSplit = false;
     if (p.realSplit) {
         const double kTwoPi = 6.28318530717958647692;
         const uint32_t M = p.N / 2, R1 = M / 1024, T = R1 * 32;
@@ -670,6 +670,17 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                     const double ang = kTwoPi * double(2 * c + e) / double(p.N);
                     p.winPhase[size_t(c) * 4 + 2 * e + 0] = float(std::cos(ang));
                     p.winPhase[size_t(c) * 4 + 2 * e + 1] = float(std::sin(ang));
+                }
+        }
+        if (p.tw2.empty()) {                                   // N = 16384 has no R^3 tables of its own: the channel transform's passes 2 / 3 are radix 32
+            const int R = 32, rows2 = 3 + R / 4 - 1;
+            p.tw2.resize(size_t(rows2) * R * 2);
+            for (int row = 0; row < rows2; ++row)
+                for (int t2 = 0; t2 < R; ++t2) {
+                    const uint32_t m = uint32_t(t2 * mult(row)) % 1024u;
+                    const double ang = -kTwoPi * double(m) / 1024.0;
+                    p.tw2[(size_t(row) * R + t2) * 2 + 0] = float(std::cos(ang));
+                    p.tw2[(size_t(row) * R + t2) * 2 + 1] = float(std::sin(ang));
                 }
         }
         p.twRealPost.resize(size_t(T) * 2);

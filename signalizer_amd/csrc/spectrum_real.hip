@@ -64,6 +64,16 @@ __device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
     return 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
 }
 
+// the R1-point DIFs of a thread's U = R / R1 columns (registers [u R1, (u + 1) R1))
+template <int R, int R1, int U, int u = 0>
+__device__ __forceinline__ void pass1Columns(v2 (&c)[R])
+{
+    if constexpr (u < U) {
+        difPacked<R, R1, u * R1>(c);
+        pass1Columns<R, R1, U, u + 1>(c);
+    }
+}
+
 template <int LR1, bool WCOS>
 __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams prm)
 {
@@ -164,9 +174,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     __builtin_amdgcn_sched_barrier(0);
     RCLK(13);
     // -------------------------------------------------------------------------- pass 1: radix R1 per column, times W_M^{c q1}
+    pass1Columns<R, R1, U>(c);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (u == 0) difPacked<R, R1, 0>(c); else difPacked<R, R1, (U > 1 ? R1 : 0)>(c);
         constexpr int NB = R1 / 4 - 1;
         float2 a[3], b[NB];
         const int col = tid + T * u;
@@ -386,7 +396,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
     const uint32_t maxSide = std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
     const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4;
-    static size_t granted[4][64] = {};
+    static size_t granted[6][64] = {};
     const bool wcos = prm.winPhase != nullptr;
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
         if (ldsBytes > limit) return hipErrorInvalidValue;
@@ -396,6 +406,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     };
     hipError_t e;
     if (N == 32768) e = wcos ? go(&stftRealKernel<4, true>, 0, 512, 80 * 1024) : go(&stftRealKernel<4, false>, 1, 512, 80 * 1024);
+    else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true>, 4, 256, 40 * 1024) : go(&stftRealKernel<3, false>, 5, 256, 40 * 1024);
     else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true>, 2, 1024, 160 * 1024) : go(&stftRealKernel<5, false>, 3, 1024, 160 * 1024);
     else return hipErrorNotSupported;
     if (e != hipSuccess) return e;

@@ -391,14 +391,14 @@ def test_unsupported_and_errors(gpu):
         api.Plan(config.spectrum_config(axis_points=1))
 
 
-@pytest.mark.parametrize("N,pairs,frames", [(32768, 1, 5), (32768, 3, 4), (65536, 2, 3)])
+@pytest.mark.parametrize("N,pairs,frames", [(32768, 1, 5), (32768, 3, 4), (65536, 2, 3), (16384, 1, 9), (16384, 2, 6)])
 def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, pairs, frames):
-    """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 65536, forced here at N = 32768
-    too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including
+    """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 16384 and 65536, forced here at
+    N = 32768 too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including
     csf[0], csf[N], csf[N/2 - 1] (quirk Q3) and csf[N/2], the one entry that needs both channels and is settled by whichever
     workgroup finishes second -- and identical pixels given identical bins."""
     from parity_chain import check_render
-    sr = 48000.0 if N == 32768 else 96000.0          # (the 10 Hz view start must keep the Lanczos taps above bin 0: eligibility)
+    sr = {16384: 24000.0, 32768: 48000.0, 65536: 96000.0}[N]   # (the 10 Hz view start must keep the Lanczos taps above bin 0: eligibility)
     cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs)
     S = N + (frames - 1) * (N // 4)
     x = synth.gen(23, int(sr), S, 2 * pairs)
