@@ -36,7 +36,7 @@ sgz_status hipFail(hipError_t e, const char *what)
 Plan::~Plan()
 {
     // best effort; ignore errors on teardown
-    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
+    void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
                     d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyFlag, d_nyBest};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -69,6 +69,8 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.colourTables, &p.d_colourTables)) != SGZ_OK) return st;
     if ((st = uploadVec(p.weights, &p.d_weights)) != SGZ_OK) return st;
     if ((st = uploadVec(p.weights11, &p.d_weights11)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.recsReal, &p.d_recsReal)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.realLowPixels, &p.d_realLowPixels)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw1, &p.d_tw1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2, &p.d_tw2)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twN, &p.d_twN)) != SGZ_OK) return st;
@@ -167,6 +169,8 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyBest), units * 64 * sizeof(float)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyFlag), units * sizeof(uint32_t)));
+            if (p.d_low) { (void)hipFree(p.d_low); p.d_low = nullptr; }
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float)));
             SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * sizeof(uint32_t), stream));
             p.nyCap = units;
             p.nyEpoch = 0;
@@ -183,7 +187,8 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
         rp.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
         rp.twPost = reinterpret_cast<const float2 *>(p.d_twRealPost);
-        rp.recs = p.d_recs; rp.weights = p.d_weights; rp.items = p.d_items;
+        rp.recs = p.d_recsReal ? p.d_recsReal : p.d_recs; rp.recsFull = p.d_recs; rp.weights = p.d_weights; rp.items = p.d_items;
+        rp.low = p.d_low; rp.lowPixels = p.d_realLowPixels; rp.lowCount[0] = p.realLowCount[0]; rp.lowCount[1] = p.realLowCount[1];
         rp.nItems = uint32_t(p.items.size()); rp.nItemsLeft = p.nItemsLeft;
         rp.invSize = p.scalars.invSize;
         rp.mapped = d_mapped; rp.binsOut = d_binsOut;

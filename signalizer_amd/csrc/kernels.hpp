@@ -66,9 +66,18 @@ struct RealParams {
     // of the two channels finishes second finds the other's flag set and settles those pixels for both sides.
     float *ny; uint32_t *nyFlag; float *nyBest; uint32_t epoch;
     uint32_t fixFrom[2];      // per side: pixels [fixFrom, P) have runs that end on csf[N/2]
+    // Interpolated pixels whose tap window reaches over bin 0 into the OTHER channel's half of csf (the window's periodic indexing:
+    // ..., csf[N-1], csf[N], csf[0], csf[1], ...).  Settled like csf[N/2]: both channels publish their kLowBins lowest csf entries
+    // (low, [unit][kLowBins]: left csf[j], right csf[N - j]), map with those pixels switched off (recs = the plan's channel-split copy),
+    // and the later workgroup evaluates the listed pixels of both sides from the published entries (recsFull / weights).
+    float *low;
+    const PixelRec *recsFull; // the unmodified records
+    const uint32_t *lowPixels; // [lowCount[0] + lowCount[1]] pixel indices, left side's first
+    uint32_t lowCount[2];
     unsigned long long *phaseClock; uint32_t clkUnit;   // -DSGZ_DEBUG builds: shader clocks of workgroup `clkUnit` at the phase boundaries
     uint32_t roundSize;       // workgroups that run concurrently, for the XCD-aware order
 };
+constexpr int kLowBins = 24;
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream);
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);

@@ -612,6 +612,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // channel-split path (spectrum_real.hip): eligibility and tables
     p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
                   p.dcPixels.empty() && !p.items.empty();
+    std::vector<uint32_t> lowFix[2];
     if (p.realSplit) {
         const long N = long(p.N), M = N / 2;
         for (size_t r = 0; r < p.recs.size() && p.realSplit; ++r) {
@@ -619,9 +620,23 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             const bool right = r >= size_t(p.P);
             auto inside = [&](long k) { return right ? (k >= M && k <= N) : (k >= 0 && k <= M); };
             if (rec.kind == 0) {
-                // interpolation taps must stay on their side and clear of csf[N/2], the one entry that needs both channels
+                // interpolation taps stay clear of csf[N/2] (the entry that needs both channels) and either on their own side, or -- a
+                // window that reaches over bin 0: ..., csf[N-1], csf[N], csf[0], csf[1], ... -- inside the kLowBins lowest entries of
+                // the two channels (left csf[j], right csf[N - j], j < kLowBins), which the channels publish: such a pixel is settled
+                // by the later workgroup (spectrum_real.hip) and switched off in the kernels' own mapping (recsReal)
+                constexpr long kLow = 24;                                // = kLowBins (kernels.hpp)
                 long k = rec.a;
-                for (int i = 0; i < rec.b; ++i) { p.realSplit = p.realSplit && inside(k) && k != M && !(i + 1 < rec.b && k == N); k = (k == N) ? 0 : k + 1; }
+                bool foreign = false, nearZero = true;
+                for (int i = 0; i < rec.b; ++i) {
+                    p.realSplit = p.realSplit && k != M;
+                    if (!inside(k)) foreign = true;
+                    if (!(k < kLow || k > N - kLow)) nearZero = false;
+                    k = (k == N) ? 0 : k + 1;
+                }
+                if (foreign) {
+                    if (nearZero) lowFix[right ? 1 : 0].push_back(uint32_t(r - (right ? size_t(p.P) : 0)));
+                    else p.realSplit = false;
+                }
             } else if (rec.kind & 1) {
                 for (long o = rec.a; o < long(rec.a) + rec.b; ++o) p.realSplit = p.realSplit && inside(right ? N - o : o);
             }
@@ -650,6 +665,18 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // for.  SGZ_CHANNEL_SPLIT=1 / 0 forces the choice for every eligible plan (A/B runs, and the tests of the N = 32768 variant).
     if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
     else if (p.N == 32768) p.realSplit = false;
+    p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0;
+    if (p.realSplit && lowFix[0].size() + lowFix[1].size() > 128) p.realSplit = false;      // (one thread settles them)
+    if (p.realSplit && !(lowFix[0].empty() && lowFix[1].empty())) {
+        p.recsReal = p.recs;
+        for (int side = 0; side < 2; ++side) {
+            p.realLowCount[side] = uint32_t(lowFix[side].size());
+            for (uint32_t x : lowFix[side]) {
+                p.realLowPixels.push_back(x);
+                p.recsReal[size_t(side) * p.P + x] = PixelRec{2, 0, 0, 0};               // neither interpolated nor arg-max: nothing is written
+            }
+        }
+    }
     if (p.realSplit) {
         const double kTwoPi = 6.28318530717958647692;
         const uint32_t M = p.N / 2, R1 = M / 1024, T = R1 * 32;

@@ -57,6 +57,9 @@ struct Plan {
     std::vector<float> colourTables;    // C * 6 * 3 (generateSpectrogramColourRotation per pair)
     std::vector<PixelRec> recs;         // sides * P
     std::vector<float> weights;         // packed tap weights
+    std::vector<PixelRec> recsReal;     // channel-split kernels: recs with the pixels of realLowPixels switched off (empty: recs itself)
+    std::vector<uint32_t> realLowPixels; // pixels whose taps reach over bin 0 into the other channel's entries: left side's, then right side's
+    uint32_t realLowCount[2] = {0, 0};
     std::vector<float> weights11;       // N = R^3 (fused kernel): [record][kMaxTaps + 1], see WholeFrameIndex::kLinearTaps
     std::vector<uint32_t> phaseType, phaseNorm;   // Phase mode only (plan.cpp buildPhaseRecords), [P] each
     uint32_t phaseNormFinal = 0;
@@ -96,6 +99,7 @@ struct Plan {
     float *d_agg = nullptr; size_t aggCap = 0;            // decay chunk aggregates
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
+    PixelRec *d_recsReal = nullptr; uint32_t *d_realLowPixels = nullptr; float *d_low = nullptr;
     float *d_scratch = nullptr; size_t scratchCap = 0;    // per-workgroup bin scratch (N > 32768)
     // sgz_spectrogram_render_host: device copies of the caller's host buffers, the stream they move on, timing events
     float *d_hostAudio = nullptr, *d_hostRgba = nullptr, *d_hostLines = nullptr;

@@ -347,30 +347,65 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
         for (int i = tid; i <= M; i += T) dst[i] = lds[i + (i >> 5)];
     }
+    if (prm.lowCount[0] + prm.lowCount[1]) {                                // this side's lowest csf entries, for the pixels that reach over bin 0
+        if (tid < kLowBins) {
+            const int k = side ? N - tid : tid;
+            __hip_atomic_store(prm.low + size_t(self) * kLowBins + tid, lds[at(k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
     RCLK(9);
     // ---- csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) and the pixels whose arg-max run ends on it (it is the last offset of
     // either side's scan, compared with a strict >).  Store own flag, then look at the partner's (both sequentially consistent): at
     // least the later of the two workgroups sees the other's flag and settles both sides; if both do, they write identical values.
+    __shared__ int sSettle;
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(prm.nyFlag + self, prm.epoch, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_load(prm.nyFlag + partner, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch) {
+        sSettle = __hip_atomic_load(prm.nyFlag + partner, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sSettle) return;
+    // This workgroup is (one of) the later of the pair: both channels' published values are visible (the flag was read with acquire
+    // semantics before the barrier; the values themselves are read with agent-scope atomics).  Threads [0, 128): the pixels whose run
+    // ends on csf[N/2], both sides; threads [128, 256): the pixels whose tap window reaches over bin 0.
+    {
 #pragma clang fp contract(off)
-            const float nyRe = __hip_atomic_load(prm.ny + (task << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float nyIm = __hip_atomic_load(prm.ny + (task << 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float vM = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
-            const float sqM = vM * vM + 0.f;                                // Math::square(csf[offset]) with imag == 0
-            if (prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
-            if (prm.mapped) {
-                for (int s = 0; s < 2; ++s) {
-                    const float *best = prm.nyBest + (size_t(task) * 2 + s) * 64;
-                    float *out = prm.mapped + (size_t(task) * 2 + s) * prm.P;
-                    for (uint32_t x = prm.fixFrom[s]; x < prm.P; ++x) {
-                        const float b = __hip_atomic_load(best + (x - prm.fixFrom[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (sqM > b) out[x] = finishPixel<5>(prm.invSize * vM);
-                    }
+        const float nyRe = __hip_atomic_load(prm.ny + (task << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nyIm = __hip_atomic_load(prm.ny + (task << 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float vM = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
+        const float sqM = vM * vM + 0.f;                                    // Math::square(csf[offset]) with imag == 0
+        if (tid == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
+        if (prm.mapped && tid < 128) {
+            const int s = tid >> 6;
+            const uint32_t x = prm.fixFrom[s] + uint32_t(tid & 63);
+            if (x < prm.P) {
+                const float b = __hip_atomic_load(prm.nyBest + (size_t(task) * 2 + s) * 64 + (tid & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sqM > b) prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = finishPixel<5>(prm.invSize * vM);
+            }
+        }
+        if (prm.mapped && tid >= 128 && tid < 256) {
+            const uint32_t li = uint32_t(tid - 128);
+            if (li < prm.lowCount[0] + prm.lowCount[1]) {
+                const int s = li < prm.lowCount[0] ? 0 : 1;
+                const uint32_t x = prm.lowPixels[li];
+                const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
+                const float *lowL = prm.low + size_t(task << 1) * kLowBins, *lowR = lowL + kLowBins;
+                float v[kMaxTaps], w[kMaxTaps];
+                int k = rec.a;
+#pragma unroll
+                for (int i = 0; i < kMaxTaps; ++i) {                          // independent loads first
+                    const bool on = i < rec.b;
+                    const float *src = k < kLowBins ? lowL + k : lowR + (N - k);
+                    v[i] = on ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    w[i] = on ? prm.weights[rec.c + i] : 0.f;
+                    if (on) k = (k == N) ? 0 : k + 1;
                 }
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < kMaxTaps; ++i)
+                    if (i < rec.b) acc = acc + v[i] * w[i];                   // taps in order (lanczosFilter restatement)
+                prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
             }
         }
     }

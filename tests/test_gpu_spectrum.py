@@ -391,15 +391,19 @@ def test_unsupported_and_errors(gpu):
         api.Plan(config.spectrum_config(axis_points=1))
 
 
-@pytest.mark.parametrize("N,pairs,frames", [(32768, 1, 5), (32768, 3, 4), (65536, 2, 3), (16384, 1, 9), (16384, 2, 6)])
-def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, pairs, frames):
+@pytest.mark.parametrize("N,sr,pairs,frames,over", [
+    (32768, 48000.0, 1, 5, {}), (32768, 48000.0, 3, 4, {}), (65536, 96000.0, 2, 3, {}), (16384, 24000.0, 1, 9, {}), (16384, 24000.0, 2, 6, {}),
+    # tap windows that reach over bin 0 into the other channel's entries (settled by the later workgroup): the reference's default view
+    # at N = 16384 / 48 kHz, linear views from 0 Hz, linear interpolation
+    (16384, 48000.0, 1, 9, {}), (16384, 44100.0, 2, 5, {}), (32768, 48000.0, 2, 4, dict(view_scaling=0)),
+    (32768, 48000.0, 1, 4, dict(view_scaling=0, bin_interp=1)), (65536, 96000.0, 1, 3, dict(view_scaling=0))])
+def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr, pairs, frames, over):
     """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 16384 and 65536, forced here at
     N = 32768 too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including
     csf[0], csf[N], csf[N/2 - 1] (quirk Q3) and csf[N/2], the one entry that needs both channels and is settled by whichever
     workgroup finishes second -- and identical pixels given identical bins."""
     from parity_chain import check_render
-    sr = {16384: 24000.0, 32768: 48000.0, 65536: 96000.0}[N]   # (the 10 Hz view start must keep the Lanczos taps above bin 0: eligibility)
-    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs)
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs, **over)
     S = N + (frames - 1) * (N // 4)
     x = synth.gen(23, int(sr), S, 2 * pairs)
     monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "1")

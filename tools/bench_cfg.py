@@ -25,7 +25,6 @@ run("N=32768 stereo, Phase mode", config.spectrum_config(window_size=32768, hop=
 run("N=65536, 4 pairs 96 kHz (cfg5 sizes), 10 s", config.cfg5(pairs=4), 10, 96000)
 run("N=65536, 32 pairs 96 kHz (cfg5, one GPU's 20 s chunk)", config.cfg5(pairs=32), 20, 96000)
 run("N=8192 stereo, 60 s", config.spectrum_config(window_size=8192, hop=2048), 60, 48000)
-run("N=16384 stereo (generic passes), 60 s", config.spectrum_config(window_size=16384, hop=4096), 60, 48000)
-run("N=16384 stereo, view from 30 Hz (channel-split kernel), 60 s", config.spectrum_config(window_size=16384, hop=4096, min_log_freq=30.0), 60, 48000)
+run("N=16384 stereo, 60 s", config.spectrum_config(window_size=16384, hop=4096), 60, 48000)
 run("N=2048 stereo (generic passes), 60 s", config.spectrum_config(window_size=2048, hop=512), 60, 48000)
 run("N=1024 stereo (generic passes), 60 s", config.spectrum_config(window_size=1024, hop=256), 60, 48000)
