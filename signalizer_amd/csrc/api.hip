@@ -166,11 +166,12 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             if (p.d_nyFlag) { (void)hipFree(p.d_nyFlag); p.d_nyFlag = nullptr; }
             if (p.d_nyBest) { (void)hipFree(p.d_nyBest); p.d_nyBest = nullptr; }
             p.nyCap = 0;
-            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyBest), units * 64 * sizeof(float)));
-            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float)));
-            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyFlag), units * sizeof(uint32_t)));
+            // the pair exchange of the channel workgroups: fine-grained (coherent across the XCDs' L2s), see spectrum_real.hip
+            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyBest), units * 128 * sizeof(float), hipDeviceMallocFinegrained));
+            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float), hipDeviceMallocFinegrained));
+            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyFlag), units * sizeof(uint32_t), hipDeviceMallocFinegrained));
             if (p.d_low) { (void)hipFree(p.d_low); p.d_low = nullptr; }
-            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float)));
+            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float), hipDeviceMallocFinegrained));
             SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * sizeof(uint32_t), stream));
             p.nyCap = units;
             p.nyEpoch = 0;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
     const MapView view{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
                        side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * 2 + side) * prm.P : nullptr,
-                       prm.nyBest + size_t(self) * 64, int(prm.fixFrom[side])};
+                       prm.nyBest + size_t(self) * 128, int(prm.fixFrom[side])};
     const ChannelIndex at{N, side ? M : 0};
     float *win = lds + XFLOATS;
     MapPixelsBalanced<5, T, ChannelIndex> mapper;
@@ -344,8 +344,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ldsBarrier();
     RCLK(7);
     if (prm.binsOut) {                                                      // test hook: this side's half of csf, csf order
+        // (csf[N/2] -- the left side's last entry, the right side's first -- is written by the settling workgroup alone)
         float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
-        for (int i = tid; i <= M; i += T) dst[i] = lds[i + (i >> 5)];
+        for (int i = tid; i <= M; i += T)
+            if (i != (side ? 0 : M)) dst[i] = lds[i + (i >> 5)];
     }
     if (prm.lowCount[0] + prm.lowCount[1]) {                                // this side's lowest csf entries, for the pixels that reach over bin 0
         if (tid < kLowBins) {
@@ -356,13 +358,24 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
     RCLK(9);
     // ---- csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) and the pixels whose arg-max run ends on it (it is the last offset of
-    // either side's scan, compared with a strict >).  Store own flag, then look at the partner's (both sequentially consistent): at
-    // least the later of the two workgroups sees the other's flag and settles both sides; if both do, they write identical values.
+    // either side's scan, compared with a strict >), and the pixels whose tap window reaches over bin 0: they need both channels.
+    // Nobody waits.  Every workgroup PUBLISHES what the other side needs -- Nyquist bin, low bins, and for its own late pixels the
+    // winning square and the value it would have written -- and raises its flag; it then looks at the partner's flag: at least the later
+    // of the two sees the other's and settles the late pixels of BOTH sides (if both do, they write identical values).  Late pixels are
+    // written by settlers only, so no two writers ever disagree about a byte.
+    // The exchange costs no cache maintenance: the published arrays are fine-grained (coherent across the XCDs' L2s) and accessed with
+    // relaxed agent-scope atomics only; order comes from the hardware's completion counters -- the barrier's workgroup-scope release waits
+    // for every thread's stores to be acknowledged before thread 0 raises the flag, and thread 0 waits for the flag's own
+    // acknowledgement before it reads the partner's (a sequentially consistent agent-scope store / load pair would write back and
+    // invalidate the XCD's whole L2 here: 19 % of the kernel at N = 65536, 23 % at N = 32768).
     __shared__ int sSettle;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this thread's published values are acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_store(prm.nyFlag + self, prm.epoch, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
-        sSettle = __hip_atomic_load(prm.nyFlag + partner, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+        __hip_atomic_store(prm.nyFlag + self, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the flag is at the coherence point before the partner's is read
+        sSettle = __hip_atomic_load(prm.nyFlag + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
     }
     __syncthreads();
     if (!sSettle) return;
@@ -380,8 +393,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const int s = tid >> 6;
             const uint32_t x = prm.fixFrom[s] + uint32_t(tid & 63);
             if (x < prm.P) {
-                const float b = __hip_atomic_load(prm.nyBest + (size_t(task) * 2 + s) * 64 + (tid & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sqM > b) prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = finishPixel<5>(prm.invSize * vM);
+                const float *pub = prm.nyBest + (size_t(task) * 2 + s) * 128 + (tid & 63);
+                const float b = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float own = __hip_atomic_load(pub + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = sqM > b ? finishPixel<5>(prm.invSize * vM) : own;
             }
         }
         if (prm.mapped && tid >= 128 && tid < 256) {
