@@ -417,14 +417,15 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/traffic_latest.json (committed rocprofv3 --pmc pass of this "
                                                                         "workload, gfx950 correction applied; not collected in this run)",
-                         "kernel": "stftMapKernel<5, 0, true, true>" if not strong else "stftRealKernel<5, true> (one K_A pass)",
+                         "kernel": ("stftRealKernel<4, true>" if plan.path & 8 else "stftMapKernel<5, 0, true, true>") if not strong else
+                                   ("stftRealKernel<5, true> (one K_A pass)" if plan.path & 8 else "stftHalfKernel + mapSideKernel (one K_A pass)"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": frames_per_rank * pairs * bytes_per_frame},
         }
         if "no_tail" in extra:
             nt = extra["no_tail"]
             out["roofline"]["frac_no_tail"] = nt["achieved"] / HBM_PEAK_GBPS
             out["roofline"]["no_tail"] = {"tasks": nt["tasks"], "kernel_ms": nt["kernel_ms"], "achieved": nt["achieved"],
-                                          "note": "same kernel, 8 stereo pairs of the cfg2 buffer: no partial second round of workgroups"}
+                                          "note": "8 stereo pairs of the cfg2 buffer: many rounds of workgroups, so the partial last round does not count; at this task count the library runs the whole-frame kernel stftMapKernel<5, 0, true, true> (the channel-split form is for launches of few rounds)"}
         if "ms_per_step_with_state" in extra:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
         if not args.no_cpu_baseline and world == 1 and not strong:

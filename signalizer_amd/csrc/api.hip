@@ -158,7 +158,12 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
-    if (p.realSplit && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
+    // N = 32768 has both forms.  A launch is as long as its slowest CU's queue of frames: with few rounds of workgroups the channel-split
+    // form wins (half-size workgroups, two per CU: 348 frames 38.2 us against 44.0 us), on long launches the whole-frame kernel's
+    // throughput does (0.385 against 0.365 of the roofline at 2784 frames): the task count decides.  SGZ_CHANNEL_SPLIT=1 pins the former.
+    const bool pinSplit = std::getenv("SGZ_CHANNEL_SPLIT") && std::getenv("SGZ_CHANNEL_SPLIT")[0] == '1';
+    const bool splitPays = p.N != 32768 || tasks <= 1024 || pinSplit;
+    if (p.realSplit && splitPays && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
         // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
         const size_t units = size_t(tasks) * 2;
         if (p.nyCap < units) {
@@ -169,15 +174,15 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
             // the pair exchange of the channel workgroups: fine-grained (coherent across the XCDs' L2s), see spectrum_real.hip
             SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyBest), units * 128 * sizeof(float), hipDeviceMallocFinegrained));
             SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float), hipDeviceMallocFinegrained));
-            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyFlag), units * sizeof(uint32_t), hipDeviceMallocFinegrained));
+            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyFlag), units * 2 * sizeof(uint32_t), hipDeviceMallocFinegrained));
             if (p.d_low) { (void)hipFree(p.d_low); p.d_low = nullptr; }
             SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float), hipDeviceMallocFinegrained));
-            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * sizeof(uint32_t), stream));
+            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * 2 * sizeof(uint32_t), stream));
             p.nyCap = units;
             p.nyEpoch = 0;
         }
         if (++p.nyEpoch == 0) {                                          // the epoch wrapped: start over from clean flags
-            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, p.nyCap * sizeof(uint32_t), stream));
+            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, p.nyCap * 2 * sizeof(uint32_t), stream));
             p.nyEpoch = 1;
         }
         RealParams rp{};
@@ -195,6 +200,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.mapped = d_mapped; rp.binsOut = d_binsOut;
         rp.ny = p.d_ny; rp.nyFlag = p.d_nyFlag; rp.nyBest = p.d_nyBest; rp.epoch = p.nyEpoch;
         rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
+        { const char *e = std::getenv("SGZ_PAIR_TEST"); rp.pairTest = e ? uint32_t(std::atoi(e)) : 0u; }
         rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;

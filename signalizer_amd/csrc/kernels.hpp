@@ -74,6 +74,10 @@ struct RealParams {
     const PixelRec *recsFull; // the unmodified records
     const uint32_t *lowPixels; // [lowCount[0] + lowCount[1]] pixel indices, left side's first
     uint32_t lowCount[2];
+    // test hook for the rare paths of the pair exchange (tests/test_gpu_spectrum.py, env SGZ_PAIR_TEST): 0 = off; 1 = every workgroup's first
+    // look at the partner's flag1 says "not published" (fallback: publish own state, raise flag2, look again); 2 = the left channel
+    // gives up unconditionally and the right channel waits for its flag2 and settles both sides
+    uint32_t pairTest;
     unsigned long long *phaseClock; uint32_t clkUnit;   // -DSGZ_DEBUG builds: shader clocks of workgroup `clkUnit` at the phase boundaries
     uint32_t roundSize;       // workgroups that run concurrently, for the XCD-aware order
 };

@@ -659,12 +659,11 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
         if (std::max(nLeft, nRight) * 4 > budget) p.realSplit = false;
     }
-    // Which eligible plans take it.  Measured on MI355X (tools/ka_time.py): at N = 65536 the fused channel workgroups beat the half-frame
-    // kernels + map kernel by 30 % (cfg5, 32 pairs: 842 us against 1199 us per K_A pass); at N = 32768 two co-resident 512-thread
-    // tasks still trail the whole-frame kernel (53.7 us against 47.4 us at 348 frames), so that size stays on stftMapKernel unless asked
-    // for.  SGZ_CHANNEL_SPLIT=1 / 0 forces the choice for every eligible plan (A/B runs, and the tests of the N = 32768 variant).
+    // Every eligible plan takes it.  Measured on MI355X (tools/ka_time.py, tools/hybrid_probe.py), since the pair exchange stopped costing
+    // cache maintenance: N = 65536 (cfg5, 32 pairs) 693 us per K_A pass against 1199 us for the half-frame kernels + map kernel;
+    // N = 32768 (cfg2, 348 frames = 696 channel workgroups, two per CU) 38.2 us against 44.0 us for the whole-frame kernel; N = 16384
+    // 6.9 M against 2.9 M transforms/s for the generic passes.  SGZ_CHANNEL_SPLIT=0 keeps a plan off it (A/B runs).
     if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
-    else if (p.N == 32768) p.realSplit = false;
     p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0;
     if (p.realSplit && lowFix[0].size() + lowFix[1].size() > 128) p.realSplit = false;      // (one thread settles them)
     if (p.realSplit && !(lowFix[0].empty() && lowFix[1].empty())) {

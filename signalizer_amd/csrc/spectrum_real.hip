@@ -107,11 +107,13 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     const long partner = (task << 1) | (side ^ 1);      // ny / flag / best slots are indexed by task * 2 + side
     const long self = (task << 1) | side;
 
+    __shared__ float sLate[128];                                            // own late pixels: winning squares [0, 64), pixel values [64, 128)
+    __shared__ float sNyOwn;
     // map tables of this side
     const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
     const MapView view{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
                        side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * 2 + side) * prm.P : nullptr,
-                       prm.nyBest + size_t(self) * 128, int(prm.fixFrom[side])};
+                       sLate, int(prm.fixFrom[side])};
     const ChannelIndex at{N, side ? M : 0};
     float *win = lds + XFLOATS;
     MapPixelsBalanced<5, T, ChannelIndex> mapper;
@@ -268,7 +270,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             lds[SCRATCH + 2 * m3 + 1] = c[brev(m3, LR)].y;
         }
         // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] is settled by whichever channel finishes second (below)
-        __hip_atomic_store(prm.ny + self, c[0].x - c[0].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sNyOwn = c[0].x - c[0].y;
+        __hip_atomic_store(prm.ny + self, sNyOwn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // Column 0 (k = T m3, all in thread 0) pairs m3 with R - m3 inside one thread and holds DC / Nyquist: lanes 0 .. R/2 of wave 0 redo it
     // from thread 0's scratch copy right away (the scratch is not part of the tiles), keep the values and store them after the
@@ -349,78 +352,111 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         for (int i = tid; i <= M; i += T)
             if (i != (side ? 0 : M)) dst[i] = lds[i + (i >> 5)];
     }
-    if (prm.lowCount[0] + prm.lowCount[1]) {                                // this side's lowest csf entries, for the pixels that reach over bin 0
-        if (tid < kLowBins) {
-            const int k = side ? N - tid : tid;
-            __hip_atomic_store(prm.low + size_t(self) * kLowBins + tid, lds[at(k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- The pair exchange.  csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) with the pixels whose arg-max run ends on it (the
+    // last offset of either side's scan, compared with a strict >), and the pixels whose tap window reaches over bin 0, need BOTH channels.
+    // Nobody waits and nobody maintains caches: the exchanged arrays are fine-grained (coherent across the XCDs' L2s), accessed with
+    // relaxed agent-scope atomics only, and ordered by the hardware's completion counters (a sequentially consistent agent-scope store /
+    // load pair writes back and invalidates the XCD's whole L2: it cost 19 % of this kernel at N = 65536, 23 % at N = 32768).
+    //   early  (here, before the mapping): wave 0 publishes this channel's Nyquist bin and lowest bins and, once those stores are
+    //          acknowledged, raises flag1.
+    //   end    if the partner's flag1 is up -- the usual case: the two workgroups run side by side -- this workgroup settles ITS OWN late
+    //          pixels from the partner's published bins and is done.
+    //          If not, it publishes the state of its late pixels, raises flag2 ("mine are unsettled"), waits for that store's
+    //          acknowledgement and looks at flag1 once more: up now -> it settles itself after all; still down -> the partner, whose
+    //          flag1 store then completes after this look, will find flag2 up at its own end (it waits for its flag1's acknowledgement
+    //          before looking) and settles this side too.  Both may do it: identical values.  Late pixels have no other writer.
+    if (tid < 64) {
+        if (prm.lowCount[0] + prm.lowCount[1]) {
+            if (tid < kLowBins) {
+                const int k = side ? N - tid : tid;
+                __hip_atomic_store(prm.low + size_t(self) * kLowBins + tid, lds[at(k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // wave 0 wrote ny and the low bins: acknowledged
+        if (tid == 0) __hip_atomic_store(prm.nyFlag + 2 * self, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
     RCLK(9);
-    // ---- csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) and the pixels whose arg-max run ends on it (it is the last offset of
-    // either side's scan, compared with a strict >), and the pixels whose tap window reaches over bin 0: they need both channels.
-    // Nobody waits.  Every workgroup PUBLISHES what the other side needs -- Nyquist bin, low bins, and for its own late pixels the
-    // winning square and the value it would have written -- and raises its flag; it then looks at the partner's flag: at least the later
-    // of the two sees the other's and settles the late pixels of BOTH sides (if both do, they write identical values).  Late pixels are
-    // written by settlers only, so no two writers ever disagree about a byte.
-    // The exchange costs no cache maintenance: the published arrays are fine-grained (coherent across the XCDs' L2s) and accessed with
-    // relaxed agent-scope atomics only; order comes from the hardware's completion counters -- the barrier's workgroup-scope release waits
-    // for every thread's stores to be acknowledged before thread 0 raises the flag, and thread 0 waits for the flag's own
-    // acknowledgement before it reads the partner's (a sequentially consistent agent-scope store / load pair would write back and
-    // invalidate the XCD's whole L2 here: 19 % of the kernel at N = 65536, 23 % at N = 32768).
-    __shared__ int sSettle;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this thread's published values are acknowledged
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
+    __shared__ int sHave, sPartnerGaveUp;
+    __syncthreads();                                                        // sLate is complete
     if (tid == 0) {
-        __hip_atomic_store(prm.nyFlag + self, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the flag is at the coherence point before the partner's is read
-        sSettle = __hip_atomic_load(prm.nyFlag + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // flag1's store is at the coherence point (see above)
+        sHave = __hip_atomic_load(prm.nyFlag + 2 * partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+        if (prm.pairTest == 2u && side == 1) {                              // (test hook: the left channel, dispatched first, is giving up)
+            while (__hip_atomic_load(prm.nyFlag + 2 * partner + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != prm.epoch) __builtin_amdgcn_s_sleep(8);
+            sHave = 1;
+        }
+        sPartnerGaveUp = __hip_atomic_load(prm.nyFlag + 2 * partner + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+        if (prm.pairTest == 1u || (prm.pairTest == 2u && side == 0)) sHave = 0;
     }
     __syncthreads();
-    if (!sSettle) return;
-    // This workgroup is (one of) the later of the pair: both channels' published values are visible (the flag was read with acquire
-    // semantics before the barrier; the values themselves are read with agent-scope atomics).  Threads [0, 128): the pixels whose run
-    // ends on csf[N/2], both sides; threads [128, 256): the pixels whose tap window reaches over bin 0.
+    if (!sHave) {
+        // the partner has not published yet: leave a note and look again
+        if (tid < 128) __hip_atomic_store(prm.nyBest + size_t(self) * 128 + tid, sLate[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(prm.nyFlag + 2 * self + 1, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sHave = __hip_atomic_load(prm.nyFlag + 2 * partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
+            sPartnerGaveUp = 0;                                              // (a partner that has not even published cannot have given up)
+            if (prm.pairTest == 2u) sHave = 0;
+        }
+        __syncthreads();
+        if (!sHave) return;                                                  // the partner settles both sides at its end
+    }
+    // settle: s = 0 this side (own late state in LDS, own low bins in LDS), s = 1 the partner's side if it gave up (its state from the
+    // published arrays).  Threads [0, 64): the pixels whose run ends on csf[N/2]; [128, 256): the pixels that reach over bin 0.
     {
 #pragma clang fp contract(off)
-        const float nyRe = __hip_atomic_load(prm.ny + (task << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float nyIm = __hip_atomic_load(prm.ny + (task << 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nyP = __hip_atomic_load(prm.ny + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nyRe = side ? nyP : sNyOwn, nyIm = side ? sNyOwn : nyP;     // left channel's is the real part
         const float vM = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
         const float sqM = vM * vM + 0.f;                                    // Math::square(csf[offset]) with imag == 0
         if (tid == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
-        if (prm.mapped && tid < 128) {
-            const int s = tid >> 6;
-            const uint32_t x = prm.fixFrom[s] + uint32_t(tid & 63);
-            if (x < prm.P) {
-                const float *pub = prm.nyBest + (size_t(task) * 2 + s) * 128 + (tid & 63);
-                const float b = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float own = __hip_atomic_load(pub + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = sqM > b ? finishPixel<5>(prm.invSize * vM) : own;
-            }
-        }
-        if (prm.mapped && tid >= 128 && tid < 256) {
-            const uint32_t li = uint32_t(tid - 128);
-            if (li < prm.lowCount[0] + prm.lowCount[1]) {
-                const int s = li < prm.lowCount[0] ? 0 : 1;
-                const uint32_t x = prm.lowPixels[li];
-                const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
-                const float *lowL = prm.low + size_t(task << 1) * kLowBins, *lowR = lowL + kLowBins;
-                float v[kMaxTaps], w[kMaxTaps];
-                int k = rec.a;
-#pragma unroll
-                for (int i = 0; i < kMaxTaps; ++i) {                          // independent loads first
-                    const bool on = i < rec.b;
-                    const float *src = k < kLowBins ? lowL + k : lowR + (N - k);
-                    v[i] = on ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    w[i] = on ? prm.weights[rec.c + i] : 0.f;
-                    if (on) k = (k == N) ? 0 : k + 1;
+        const float *lowP = prm.low + size_t(partner) * kLowBins;
+        for (int who = 0; who < (sPartnerGaveUp ? 2 : 1); ++who) {
+            const int s = who ? (side ^ 1) : side;                           // the side being settled
+            const long u = (task << 1) | s;
+            if (prm.mapped && tid < 64) {
+                const uint32_t x = prm.fixFrom[s] + uint32_t(tid);
+                if (x < prm.P) {
+                    float b, own;
+                    if (!who) { b = sLate[tid]; own = sLate[64 + tid]; }
+                    else {
+                        b = __hip_atomic_load(prm.nyBest + size_t(u) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        own = __hip_atomic_load(prm.nyBest + size_t(u) * 128 + 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    prm.mapped[size_t(u) * prm.P + x] = sqM > b ? finishPixel<5>(prm.invSize * vM) : own;
                 }
-                float acc = 0.f;
+            }
+            if (prm.mapped && tid >= 128 && tid < 256) {
+                const uint32_t n = uint32_t(tid - 128);
+                if (n < prm.lowCount[s]) {
+                    const uint32_t x = prm.lowPixels[(s ? prm.lowCount[0] : 0u) + n];
+                    const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
+                    float v[kMaxTaps], w[kMaxTaps];
+                    int k = rec.a;
 #pragma unroll
-                for (int i = 0; i < kMaxTaps; ++i)
-                    if (i < rec.b) acc = acc + v[i] * w[i];                   // taps in order (lanczosFilter restatement)
-                prm.mapped[(size_t(task) * 2 + s) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
+                    for (int i = 0; i < kMaxTaps; ++i) {                      // independent loads first
+                        const bool on = i < rec.b;
+                        // csf[k]: k < kLowBins is the left channel's bin k, k > N - kLowBins the right channel's bin N - k; this
+                        // workgroup's own bins are in its LDS, the partner's in its published array
+                        const bool left = k < kLowBins;
+                        const int j = left ? k : N - k;
+                        const bool mine = (side == 0) == left;
+                        float val = 0.f;
+                        if (on) val = mine ? lds[at(k)] : __hip_atomic_load(lowP + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[i] = val;
+                        w[i] = on ? prm.weights[rec.c + i] : 0.f;
+                        if (on) k = (k == N) ? 0 : k + 1;
+                    }
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < kMaxTaps; ++i)
+                        if (i < rec.b) acc = acc + v[i] * w[i];               // taps in order (lanczosFilter restatement)
+                    prm.mapped[size_t(u) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
+                }
             }
         }
     }

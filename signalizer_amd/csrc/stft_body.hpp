@@ -141,7 +141,7 @@ struct MapView {
     int total;                // records in this view
     int rightFrom;            // records [rightFrom, total) are right-side records (k = N - offset)
     float *out;               // [total]
-    float *bestOut = nullptr; // optional: the winning SQUARE of the arg-max records [bestFrom, total) -> bestOut[idx - bestFrom], their pixel values -> bestOut[64 + ...], INSTEAD of out[]
+    float *bestOut = nullptr; // optional (LDS): the winning SQUARE of the arg-max records [bestFrom, total) -> bestOut[idx - bestFrom], their pixel values -> bestOut[64 + ...], INSTEAD of out[]
     int bestFrom = 0;         // (spectrum_real.hip: the pixels whose run ends on csf[N/2] are settled after both channels are done)
 };
 __device__ __forceinline__ MapView wholeView(const StftParams &prm, long task)
@@ -359,10 +359,10 @@ __device__ __forceinline__ void run(const StftParams &prm, const MapView &v, con
             }
             const float pix = finishPixel<LR>(prm.invSize * val);
             if (v.bestOut && idx >= v.bestFrom) {
-                // spectrum_real.hip: settled by the later workgroup of the pair, which is the only writer of these pixels -- published
-                // (winning square, pixel value) with agent-scope stores, not written
-                __hip_atomic_store(v.bestOut + (idx - v.bestFrom), bestSq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(v.bestOut + 64 + (idx - v.bestFrom), pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // spectrum_real.hip: these pixels also depend on the other channel and are written once that is known -- (winning square,
+                // pixel value) go to the workgroup's LDS, nothing is written here
+                v.bestOut[idx - v.bestFrom] = bestSq;
+                v.bestOut[64 + (idx - v.bestFrom)] = pix;
             } else out[idx] = pix;
         }
     }

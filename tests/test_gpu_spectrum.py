@@ -426,3 +426,27 @@ def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr
     if pairs > 1:
         problems, stats = check_render(oracle, split, cfg, x, gpu)
         assert not problems, (problems[:5], stats)
+
+
+@pytest.mark.parametrize("N,sr", [(16384, 48000.0), (32768, 48000.0), (65536, 96000.0)])
+def test_pair_exchange_rare_paths(gpu, monkeypatch, N, sr):
+    """the channel workgroups' exchange (spectrum_real.hip): the usual path (the partner has published: every workgroup settles its own late
+    pixels), the fallback (SGZ_PAIR_TEST=1: publish own state, raise flag2, look again) and the hand-over (SGZ_PAIR_TEST=2: the left
+    channel gives up, the right channel settles both sides from the published state) must write the same bytes"""
+    monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "1")
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=3)
+    x = _planar_cuda(synth.gen(41, int(sr), N + 37 * (N // 4), 6), gpu)
+    plan = api.Plan(cfg).upload()
+    assert plan.path & 8
+    out = {}
+    for mode in ("0", "1", "2", "0"):
+        monkeypatch.setenv("SGZ_PAIR_TEST", mode)
+        m = plan.stage_mapped(x).cpu().numpy()
+        b = plan.stage_bins(x).cpu().numpy()
+        if mode in out:
+            assert np.array_equal(out[mode][0].view(np.uint32), m.view(np.uint32))
+        out[mode] = (m, b)
+    for mode in ("1", "2"):
+        assert np.array_equal(out[mode][0].view(np.uint32), out["0"][0].view(np.uint32)), (mode, int((out[mode][0] != out["0"][0]).sum()))
+        assert np.array_equal(out[mode][1].view(np.uint32), out["0"][1].view(np.uint32)), mode
+    monkeypatch.delenv("SGZ_PAIR_TEST")
