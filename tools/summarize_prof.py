@@ -39,19 +39,23 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 # FETCH_SIZE (KiB) under-reports coalesced reads by 2x -> doubled; WRITE_SIZE (KiB) taken as reported.
 import json
 raw = {}
+kname = None
 for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in find("*counter_collection.csv"):
         if tag not in f:
             continue
-        tot, n = 0.0, 0
+        per = {}
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                if r.get("Counter_Name") == counter and "stftMapKernel" in r.get("Kernel_Name", ""):
-                    tot += float(r.get("Counter_Value", 0)); n += 1
-        if n:
-            raw[counter] = tot / n
+                k = r.get("Kernel_Name", "")
+                if r.get("Counter_Name") == counter and ("stftMapKernel" in k or "stftRealKernel" in k):   # K_A, whichever form the plan runs
+                    a = per.setdefault(k, [0.0, 0]); a[0] += float(r.get("Counter_Value", 0)); a[1] += 1
+        if per:
+            k = max(per, key=lambda q: per[q][1])
+            kname = k.split("(")[0].replace("void sgz::", "")
+            raw[counter] = per[k][0] / per[k][1]
 if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
-    traffic = {"kernel": "stftMapKernel<5, 0>", "fetch_size_kib_per_launch": raw["FETCH_SIZE"], "write_size_kib_per_launch": raw["WRITE_SIZE"],
+    traffic = {"kernel": kname, "fetch_size_kib_per_launch": raw["FETCH_SIZE"], "write_size_kib_per_launch": raw["WRITE_SIZE"],
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE counts 128-B requests as 64 B)",
                "traffic_bytes_per_launch": int((2 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024)}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
