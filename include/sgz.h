@@ -122,9 +122,10 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
 #define SGZ_PATH_FUSED    1u
 #define SGZ_PATH_HALVES   2u
 #define SGZ_PATH_SIDE_MAP 4u
-#define SGZ_PATH_CHANNEL_SPLIT 8u   /* Separate mode, N = 16384 / 32768 / 65536, W == N, even hop: one workgroup per (frame, pair, channel) with a
-                                       real-input FFT (spectrum_real.hip) takes the place of the kernels above for device buffers whose
-                                       rows are 8-byte aligned */
+#define SGZ_PATH_CHANNEL_SPLIT 8u   /* N = 16384 / 32768 / 65536, W == N, even hop: the real-input kernel (spectrum_real.hip) -- Separate: one
+                                       workgroup per (frame, pair, channel); Left / Right / Merge / Side: one per (frame, pair) on the mixed
+                                       signal -- takes the place of the kernels above for device buffers whose rows are 8-byte aligned
+                                       (at N = 32768 in Separate mode: for launches of up to 1024 tasks) */
 uint32_t   sgz_plan_path(const sgz_plan *plan);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

@@ -163,7 +163,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     // throughput does (0.385 against 0.365 of the roofline at 2784 frames): the task count decides.  SGZ_CHANNEL_SPLIT=1 pins the former.
     const bool pinSplit = std::getenv("SGZ_CHANNEL_SPLIT") && std::getenv("SGZ_CHANNEL_SPLIT")[0] == '1';
     const bool splitPays = p.N != 32768 || tasks <= 1024 || pinSplit;
-    if (p.realSplit && splitPays && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
+    if ((p.realMono || (p.realSplit && splitPays)) && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
         // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
         const size_t units = size_t(tasks) * 2;
         if (p.nyCap < units) {
@@ -187,7 +187,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         }
         RealParams rp{};
         rp.planar = d_planar; rp.chStride = chStride; rp.frames = frames;
-        rp.hop = p.cfg.hop; rp.C = p.C; rp.P = p.P;
+        rp.hop = p.cfg.hop; rp.C = p.C; rp.P = p.P; rp.mode = p.cfg.channel_mode;
         rp.window = p.d_window;
         rp.winPhase = reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = p.winP0; rp.winP1 = p.winP1;
         rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
@@ -415,7 +415,7 @@ uint32_t sgz_plan_path(const sgz_plan *plan)
 {
     if (!plan) return SGZ_PATH_GENERIC;
     const Plan &p = plan->impl;
-    const uint32_t real = p.realSplit ? SGZ_PATH_CHANNEL_SPLIT : 0u;
+    const uint32_t real = (p.realSplit || p.realMono) ? SGZ_PATH_CHANNEL_SPLIT : 0u;
     if (p.fused) return SGZ_PATH_FUSED | real;
     return (p.halves ? SGZ_PATH_HALVES : SGZ_PATH_GENERIC) | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u) | real;
 }

@@ -48,6 +48,7 @@ struct RealParams {
     size_t chStride;
     long frames;
     uint32_t hop, C, P;
+    uint32_t mode;            // SGZ_CH_SEPARATE (two channel workgroups per task), or Left / Right / Merge / Side (one workgroup: the mixed signal)
     const float *window;      // [N]
     // Hann / Hamming, periodic: w[n] = p0 + p1 cos(2 pi n / N) is evaluated in the kernel instead of fetched (a third of the kernel's
     // L2 -> L1 traffic is the window, the same 4 N bytes for every workgroup): winPhase[c] = (cos, sin) of 2 pi (2c) / N and of

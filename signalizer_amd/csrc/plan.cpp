@@ -664,6 +664,28 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // N = 32768 (cfg2, 348 frames = 696 channel workgroups, two per CU) 38.2 us against 44.0 us for the whole-frame kernel; N = 16384
     // 6.9 M against 2.9 M transforms/s for the generic passes.  SGZ_CHANNEL_SPLIT=0 keeps a plan off it (A/B runs).
     if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
+    // The mono modes transform ONE real signal per task: the same kernel, one workgroup per (frame, pair), no pair exchange.  Eligible
+    // when every pixel stays inside csf[0 .. N/2] without wrapping (csf[N/2] = X[N/2] / 2 is real for a real signal: arg-max runs may
+    // end on it, tap windows may not touch it -- it is signed; everything above N/2 is the raw mirror half, which this kernel does not hold)
+    p.realMono = (cfg.channel_mode == SGZ_CH_LEFT || cfg.channel_mode == SGZ_CH_RIGHT || cfg.channel_mode == SGZ_CH_MERGE ||
+                  cfg.channel_mode == SGZ_CH_SIDE) &&
+                 (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u && !p.items.empty();
+    if (p.realMono) {
+        const long N = long(p.N), M = N / 2;
+        for (size_t r = 0; r < p.recs.size() && p.realMono; ++r) {
+            const PixelRec &rec = p.recs[r];
+            if (rec.kind == 0) {
+                long k = rec.a;
+                for (int i = 0; i < rec.b; ++i) { p.realMono = p.realMono && k >= 0 && k < M; ++k; }     // (no wrap: k + 1 <= M < N)
+            } else if (rec.kind & 1) {
+                p.realMono = p.realMono && rec.a >= 0 && long(rec.a) + rec.b - 1 <= M && rec.c <= M;
+            }
+        }
+        const size_t ldsFloats = size_t(M + 1) + size_t((M + 1) >> 5) + 2;
+        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
+        if (p.items.size() * 4 > budget) p.realMono = false;
+        if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realMono = false; }
+    }
     p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0;
     if (p.realSplit && lowFix[0].size() + lowFix[1].size() > 128) p.realSplit = false;      // (one thread settles them)
     if (p.realSplit && !(lowFix[0].empty() && lowFix[1].empty())) {
@@ -676,7 +698,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             }
         }
     }
-    if (p.realSplit) {
+    if (p.realSplit || p.realMono) {
         const double kTwoPi = 6.28318530717958647692;
         const uint32_t M = p.N / 2, R1 = M / 1024, T = R1 * 32;
         const int rows = 3 + int(R1) / 4 - 1;

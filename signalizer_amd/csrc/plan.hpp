@@ -77,6 +77,7 @@ struct Plan {
     // workgroup: a real-input FFT of N/2 complex points, that channel's csf side and that side's pixels.  Eligible when every record
     // of a side stays inside that side's half of csf (no wrap-around taps) and a side's arg-max pieces fit beside |X| in LDS.
     bool realSplit = false;
+    bool realMono = false;              // Left / Right / Merge / Side on the real-input kernel, one workgroup per (frame, pair)
     std::vector<float> twReal1;         // pass-1 twiddles W_{N/2}^{c q}, factorised rows [3 + R1/4 - 1][1024] (re, im)
     uint32_t realFixFrom[2] = {0, 0};   // per side: first pixel whose arg-max run ends on csf[N/2] (the one cross-channel entry); [from, P) are settled late
     std::vector<float> winPhaseT;       // fused whole-frame kernel, same idea: (cos, sin) of 2 pi t / N, t < R^2

@@ -74,7 +74,10 @@ __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
     }
 }
 
-template <int LR1, bool WCOS>
+// MONO: SpectrumChannels Left / Right / Merge / Side -- ONE real signal per (frame, pair) (the reference transforms it as a complex frame
+// with a zero imaginary part, TransformDSP.inl:59-135): one workgroup per task, no pair exchange.  csf[0] = |X[0]| / 2 and
+// csf[N/2] = X[N/2] / 2 (:547-552; the latter stays signed: the reference leaves it complex, and X[N/2] of a real signal is real).
+template <int LR1, bool WCOS, bool MONO = false>
 __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams prm)
 {
     constexpr int LR = 5, R = 32, R1 = 1 << LR1, T = R1 * R, RR = R * R, M = R1 * RR, N = 2 * M, U = R / R1;
@@ -89,7 +92,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     const int ix = half ? R - 1 - l : l;                // c_lo in pass 2, q2 in pass 3
 
     // ---- work list: unit = (frame, pair, channel); XCD-aware order as in stft_body.hpp (a speed assumption only)
-    const long units = prm.frames * long(prm.C) * 2;
+    const long units = prm.frames * long(prm.C) * (MONO ? 1 : 2);
     long unit = blockIdx.x;
     if (units >= 64 && prm.roundSize >= 8 && prm.roundSize % 8 == 0) {
         const long nb = gridDim.x, bid = blockIdx.x;
@@ -99,8 +102,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         const long per = nbr / 8, extra = nbr % 8;
         unit = base + x * per + (x < extra ? x : extra) + i;
     }
-    const int side = int(unit & 1);
-    long task = unit >> 1;                              // (frame, pair)
+    const int side = MONO ? 0 : int(unit & 1);
+    long task = MONO ? unit : unit >> 1;                // (frame, pair)
     if (prm.C > 1) { const long pr = task / prm.frames, fr = task - pr * prm.frames; task = fr * prm.C + pr; }
     const long frame = task / prm.C;
     const int pair = int(task - frame * prm.C);
@@ -110,10 +113,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     __shared__ float sLate[128];                                            // own late pixels: winning squares [0, 64), pixel values [64, 128)
     __shared__ float sNyOwn;
     // map tables of this side
-    const uint32_t nLeft = prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
+    const uint32_t nLeft = MONO ? prm.nItems : prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
     const MapView view{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
-                       side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * 2 + side) * prm.P : nullptr,
-                       sLate, int(prm.fixFrom[side])};
+                       side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * (MONO ? 1 : 2) + side) * prm.P : nullptr,
+                       MONO ? nullptr : sLate, int(prm.fixFrom[side])};
     const ChannelIndex at{N, side ? M : 0};
     float *win = lds + XFLOATS;
     MapPixelsBalanced<5, T, ChannelIndex> mapper;
@@ -129,11 +132,26 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
         // 8-byte loads, R of them per thread, in batches of B with the next batch in flight while this one is multiplied (the
         // scheduling barriers keep instruction selection from hoisting all 2R loads to the top: 128 registers of raw samples)
-        const float *X = prm.planar + size_t(2 * pair + side) * prm.chStride + size_t(frame) * prm.hop;
+        const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : side;
+        const float *X = prm.planar + size_t(2 * pair + firstCh) * prm.chStride + size_t(frame) * prm.hop;
         // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
         auto offOf = [&](int e) { const int u = e / R1, j = e % R1; return uint32_t(tid + T * u + RR * j) * 8u; };
 #pragma unroll
         for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X), offOf(i)); c[i] = v2{xv.x, xv.y}; }
+        if (MONO && (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE)) {
+            // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
+            const float *Y = X + prm.chStride;
+            const float sgn = prm.mode == SGZ_CH_SIDE ? -1.f : 1.f;
+#pragma unroll
+            for (int b0 = 0; b0 < R; b0 += 8) {
+                float2 y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = ldg(reinterpret_cast<const float2 *>(Y), offOf(b0 + i));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[b0 + i] = v2{c[b0 + i].x + sgn * y[i].x, c[b0 + i].y + sgn * y[i].y};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         if (WCOS) {
             // w[n] = p0 + p1 cos(theta_n), theta_n = 2 pi n / N, n = 2 (col + R^2 j) + e: theta = phi(col, e) + 2 pi j / R1 -- the phase of the
             // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
@@ -172,6 +190,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                 for (int i = 0; i < B; ++i) { c[b0 + B + i] = v2{c[b0 + B + i].x * wb[i].x, c[b0 + B + i].y * wb[i].y}; asm volatile("" : "+v"(c[b0 + B + i])); }
             }
         }
+    }
+    if (MONO && (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE)) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) c[i] = v2{c[i].x * 0.5f, c[i].y * 0.5f};
     }
     __builtin_amdgcn_sched_barrier(0);
     RCLK(13);
@@ -271,7 +293,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         }
         // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] is settled by whichever channel finishes second (below)
         sNyOwn = c[0].x - c[0].y;
-        __hip_atomic_store(prm.ny + self, sNyOwn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!MONO) __hip_atomic_store(prm.ny + self, sNyOwn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // Column 0 (k = T m3, all in thread 0) pairs m3 with R - m3 inside one thread and holds DC / Nyquist: lanes 0 .. R/2 of wave 0 redo it
     // from thread 0's scratch copy right away (the scratch is not part of the tiles), keep the values and store them after the
@@ -290,6 +312,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             fixB = realBinMag(b, a, v2{-cs, -sn});                          // W_{2R}^{R - m3} = (-cos, -sin)
         } else {
             fixA = 0.5f * (lds[SCRATCH] + lds[SCRATCH + 1]);                // csf[0] = Re(csf[0]) * 0.5 / csf[N] = Im(csf[0]) * 0.5 (:861-862): X_c[0] / 2, signed
+            if (MONO) { fixA = __builtin_fabsf(fixA); fixB = 0.5f * (lds[SCRATCH] - lds[SCRATCH + 1]); }   // |X[0]| / 2 and X[N/2] / 2 (:547-552)
         }
     }
     // ---- recombination.  a = Z[k] (own register m3 < R/2), b = Z[M - k] (lane L ^ R, register R-1-m3):
@@ -322,7 +345,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     RCLK(6);
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
-    if (side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
+    if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
     if (nSide) mapper.prefetchTables(view, tid);
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
@@ -340,7 +363,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             if (tid != R / 2) put(T * (R - tid), fixB);
         } else {
             put(0, fixA);
-            put(M, 0.f);                                                    // csf[N/2]: settled late, can never win meanwhile (strict >)
+            put(M, MONO ? fixB : 0.f);                                      // pairs: csf[N/2] is settled late, 0 can never win meanwhile (strict >)
         }
     }
     if (nSide && prm.mapped) mapper.prefetchWeights(sp, tid, nSide);
@@ -350,7 +373,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // (csf[N/2] -- the left side's last entry, the right side's first -- is written by the settling workgroup alone)
         float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
         for (int i = tid; i <= M; i += T)
-            if (i != (side ? 0 : M)) dst[i] = lds[i + (i >> 5)];
+            if (MONO || i != (side ? 0 : M)) dst[i] = lds[i + (i >> 5)];
     }
     // ---- The pair exchange.  csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) with the pixels whose arg-max run ends on it (the
     // last offset of either side's scan, compared with a strict >), and the pixels whose tap window reaches over bin 0, need BOTH channels.
@@ -365,7 +388,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     //          acknowledgement and looks at flag1 once more: up now -> it settles itself after all; still down -> the partner, whose
     //          flag1 store then completes after this look, will find flag2 up at its own end (it waits for its flag1's acknowledgement
     //          before looking) and settles this side too.  Both may do it: identical values.  Late pixels have no other writer.
-    if (tid < 64) {
+    if (!MONO && tid < 64) {
         if (prm.lowCount[0] + prm.lowCount[1]) {
             if (tid < kLowBins) {
                 const int k = side ? N - tid : tid;
@@ -377,6 +400,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
     RCLK(9);
+    if (MONO) return;
     __shared__ int sHave, sPartnerGaveUp;
     __syncthreads();                                                        // sLate is complete
     if (tid == 0) {
@@ -476,13 +500,14 @@ static hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64
 
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
 {
-    const long units = prm.frames * long(prm.C) * 2;
+    const bool mono = prm.mode != SGZ_CH_SEPARATE;
+    const long units = prm.frames * long(prm.C) * (mono ? 1 : 2);
     if (units <= 0) return hipSuccess;
     const uint32_t M = N / 2;
     const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
-    const uint32_t maxSide = std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
+    const uint32_t maxSide = mono ? prm.nItems : std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
     const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4;
-    static size_t granted[6][64] = {};
+    static size_t granted[12][64] = {};
     const bool wcos = prm.winPhase != nullptr;
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
         if (ldsBytes > limit) return hipErrorInvalidValue;
@@ -491,6 +516,14 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
         return hipSuccess;
     };
     hipError_t e;
+    if (mono) {
+        if (N == 32768) e = wcos ? go(&stftRealKernel<4, true, true>, 6, 512, 80 * 1024) : go(&stftRealKernel<4, false, true>, 7, 512, 80 * 1024);
+        else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true, true>, 8, 256, 40 * 1024) : go(&stftRealKernel<3, false, true>, 9, 256, 40 * 1024);
+        else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true, true>, 10, 1024, 160 * 1024) : go(&stftRealKernel<5, false, true>, 11, 1024, 160 * 1024);
+        else return hipErrorNotSupported;
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     if (N == 32768) e = wcos ? go(&stftRealKernel<4, true>, 0, 512, 80 * 1024) : go(&stftRealKernel<4, false>, 1, 512, 80 * 1024);
     else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true>, 4, 256, 40 * 1024) : go(&stftRealKernel<3, false>, 5, 256, 40 * 1024);
     else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true>, 2, 1024, 160 * 1024) : go(&stftRealKernel<5, false>, 3, 1024, 160 * 1024);

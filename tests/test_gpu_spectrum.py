@@ -450,3 +450,32 @@ def test_pair_exchange_rare_paths(gpu, monkeypatch, N, sr):
         assert np.array_equal(out[mode][0].view(np.uint32), out["0"][0].view(np.uint32)), (mode, int((out[mode][0] != out["0"][0]).sum()))
         assert np.array_equal(out[mode][1].view(np.uint32), out["0"][1].view(np.uint32)), mode
     monkeypatch.delenv("SGZ_PAIR_TEST")
+
+
+@pytest.mark.parametrize("N,sr,mode,pairs,over", [
+    (32768, 48000.0, config.CH_LEFT, 1, {}), (32768, 48000.0, config.CH_RIGHT, 2, {}), (32768, 48000.0, config.CH_MERGE, 1, {}),
+    (32768, 48000.0, config.CH_SIDE, 3, {}), (65536, 96000.0, config.CH_MERGE, 2, {}), (65536, 96000.0, config.CH_LEFT, 1, {}),
+    (16384, 24000.0, config.CH_SIDE, 1, {}), (16384, 24000.0, config.CH_RIGHT, 2, {}),
+    (32768, 48000.0, config.CH_MERGE, 1, dict(bin_interp=1)), (32768, 44100.0, config.CH_LEFT, 1, dict(window_type=2))])
+def test_mono_modes_on_the_real_input_kernel(gpu, oracle, monkeypatch, N, sr, mode, pairs, over):
+    """Left / Right / Merge / Side transform one real signal per frame: spectrum_real.hip's MONO form (one workgroup per (frame, pair)) against
+    the oracle through the parity chain, and bin for bin (csf[0 .. N/2], incl. the halved csf[0] and the signed csf[N/2]) against the
+    complex whole-frame / halves / generic kernels"""
+    from parity_chain import check_render
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs, channel_mode=mode, **over)
+    frames = 6
+    x = synth.gen(29, int(sr), N + (frames - 1) * (N // 4), 2 * pairs)
+    real = api.Plan(cfg).upload()
+    monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "0")
+    other = api.Plan(cfg).upload()
+    monkeypatch.delenv("SGZ_CHANNEL_SPLIT")
+    assert real.path & 8 and not other.path & 8
+    xg = _planar_cuda(x, gpu)
+    a, b = real.stage_bins(xg).cpu().numpy()[..., :N // 2 + 1], other.stage_bins(xg).cpu().numpy()[..., :N // 2 + 1]
+    # the complex kernels leave csf[N/2] complex; as a real number it is +- its magnitude
+    assert np.abs(a[..., :N // 2] - b[..., :N // 2]).max() <= BIN_TOL * np.abs(b).max()
+    assert np.abs(np.abs(a[..., N // 2]) - np.abs(b[..., N // 2])).max() <= BIN_TOL * np.abs(b).max()
+    problems, stats = check_render(oracle, real, cfg, x, gpu, want_lines=True)
+    assert not problems, (problems[:5], stats)
+    m1, m2 = real.stage_mapped(xg).cpu().numpy(), other.stage_mapped(xg).cpu().numpy()
+    assert np.abs(m1 - m2).max() <= 4e-6 * np.abs(b).max() * real.window_scale / (N * 0.5) * 4

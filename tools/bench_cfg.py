@@ -21,6 +21,10 @@ def run(name, cfg, seconds, sr):
                       "transforms_per_s": F * cfg["num_pairs"] / dt}))
 run("N=4096 stereo (cfg1 sizes), 60 s", config.spectrum_config(window_size=4096, hop=1024), 60, 48000)
 run("N=32768 stereo cfg2", config.cfg2(), 60, 48000)
+run("N=32768 stereo, Merge mode (one real signal per frame)", config.spectrum_config(window_size=32768, hop=8192, channel_mode=config.CH_MERGE), 60, 48000)
+run("N=32768 stereo, Left mode", config.spectrum_config(window_size=32768, hop=8192, channel_mode=config.CH_LEFT), 60, 48000)
+run("N=65536, 32 pairs 96 kHz, Merge mode", dict(config.cfg5(pairs=32), channel_mode=config.CH_MERGE), 20, 96000)
+run("N=16384 stereo, Side mode, 60 s", config.spectrum_config(window_size=16384, hop=4096, channel_mode=config.CH_SIDE), 60, 48000)
 run("N=32768 stereo, Phase mode", config.spectrum_config(window_size=32768, hop=8192, channel_mode=config.CH_PHASE), 60, 48000)
 run("N=65536, 4 pairs 96 kHz (cfg5 sizes), 10 s", config.cfg5(pairs=4), 10, 96000)
 run("N=65536, 32 pairs 96 kHz (cfg5, one GPU's 20 s chunk)", config.cfg5(pairs=32), 20, 96000)

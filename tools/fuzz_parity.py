@@ -37,7 +37,11 @@ def main():
         ok = not problems
         if ok and it % 8 == 0:
             rgba2, _, _ = api.render_spectrogram(cfg, x)              # the host-buffer entry point renders the same bytes
-            ok = np.array_equal(rgba2, plan.render(torch.from_numpy(x).cuda()).cpu().numpy())
+            # (it copies the channels into rows of a 64-sample multiple; the same layout here, so that both renders take the same
+            # kernels -- the real-input kernels want 8-byte aligned rows and a plan falls back to the complex ones otherwise)
+            xt = torch.zeros((x.shape[0], (x.shape[1] + 63) // 64 * 64), dtype=torch.float32, device="cuda")
+            xt[:, :x.shape[1]] = torch.from_numpy(x).cuda()
+            ok = np.array_equal(rgba2, plan.render(xt[:, :x.shape[1]]).cpu().numpy())
             if not ok: problems = ["host-buffer entry point differs from the device render"]
         print(it, "ok " if ok else "BAD", "N", plan.N, "path", plan.path, "mode", cfg["channel_mode"], "interp", cfg["bin_interp"], "view",
               cfg["view_scaling"], "P", cfg["axis_points"], "pairs", cfg["num_pairs"], "frames", frames, stats)
