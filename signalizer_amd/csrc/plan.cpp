@@ -610,7 +610,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         }
     }
     // channel-split path (spectrum_real.hip): eligibility and tables
-    p.realSplit = cfg.channel_mode == SGZ_CH_SEPARATE && (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
+    p.realSplit = (cfg.channel_mode == SGZ_CH_SEPARATE || cfg.channel_mode == SGZ_CH_MIDSIDE) && (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u &&
                   p.dcPixels.empty() && !p.items.empty();
     std::vector<uint32_t> lowFix[2];
     if (p.realSplit) {

@@ -132,16 +132,19 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
         // 8-byte loads, R of them per thread, in batches of B with the next batch in flight while this one is multiplied (the
         // scheduling barriers keep instruction selection from hoisting all 2R loads to the top: 128 registers of raw samples)
-        const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : side;
+        // which input channels feed this workgroup's signal: Separate: channel `side`; MidSide: (l + r) / 2 on side 0, (l - r) / 2 on side 1
+        // (prepareTransform's MidSide case, then the same split as Separate); mono: l, r, (l + r) / 2 or (l - r) / 2
+        const bool mixed = MONO ? (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE) : prm.mode == SGZ_CH_MIDSIDE;
+        const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : (mixed ? 0 : side);
         const float *X = prm.planar + size_t(2 * pair + firstCh) * prm.chStride + size_t(frame) * prm.hop;
         // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
         auto offOf = [&](int e) { const int u = e / R1, j = e % R1; return uint32_t(tid + T * u + RR * j) * 8u; };
 #pragma unroll
         for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X), offOf(i)); c[i] = v2{xv.x, xv.y}; }
-        if (MONO && (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE)) {
+        if (mixed) {
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
-            const float sgn = prm.mode == SGZ_CH_SIDE ? -1.f : 1.f;
+            const float sgn = (MONO ? prm.mode == SGZ_CH_SIDE : side == 1) ? -1.f : 1.f;
 #pragma unroll
             for (int b0 = 0; b0 < R; b0 += 8) {
                 float2 y[8];
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             }
         }
     }
-    if (MONO && (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE)) {
+    if (MONO ? (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE) : prm.mode == SGZ_CH_MIDSIDE) {
 #pragma unroll
         for (int i = 0; i < R; ++i) c[i] = v2{c[i].x * 0.5f, c[i].y * 0.5f};
     }
@@ -500,7 +503,7 @@ static hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64
 
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
 {
-    const bool mono = prm.mode != SGZ_CH_SEPARATE;
+    const bool mono = prm.mode != SGZ_CH_SEPARATE && prm.mode != SGZ_CH_MIDSIDE;
     const long units = prm.frames * long(prm.C) * (mono ? 1 : 2);
     if (units <= 0) return hipSuccess;
     const uint32_t M = N / 2;

@@ -396,7 +396,10 @@ def test_unsupported_and_errors(gpu):
     # tap windows that reach over bin 0 into the other channel's entries (settled by the later workgroup): the reference's default view
     # at N = 16384 / 48 kHz, linear views from 0 Hz, linear interpolation
     (16384, 48000.0, 1, 9, {}), (16384, 44100.0, 2, 5, {}), (32768, 48000.0, 2, 4, dict(view_scaling=0)),
-    (32768, 48000.0, 1, 4, dict(view_scaling=0, bin_interp=1)), (65536, 96000.0, 1, 3, dict(view_scaling=0))])
+    (32768, 48000.0, 1, 4, dict(view_scaling=0, bin_interp=1)), (65536, 96000.0, 1, 3, dict(view_scaling=0)),
+    # MidSide: the same two workgroups on (l + r) / 2 and (l - r) / 2
+    (32768, 48000.0, 2, 5, dict(channel_mode=config.CH_MIDSIDE)), (65536, 96000.0, 1, 3, dict(channel_mode=config.CH_MIDSIDE)),
+    (16384, 48000.0, 1, 7, dict(channel_mode=config.CH_MIDSIDE))])
 def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr, pairs, frames, over):
     """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 16384 and 65536, forced here at
     N = 32768 too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including

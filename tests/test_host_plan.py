@@ -79,7 +79,7 @@ def test_path_selection():
     """which K_A implementation a configuration selects"""
     P = lambda **kw: api.Plan(config.spectrum_config(**kw)).path
     assert P(window_size=4096, hop=1024) == 1 and P(window_size=32768, hop=8192) == 1 | 8   # cfg2: channel-split workgroups (whole-frame kernel behind them)
-    assert P(window_size=32768, hop=8192, channel_mode=config.CH_MIDSIDE) == 1
+    assert P(window_size=32768, hop=8192, channel_mode=config.CH_MIDSIDE) == 1 | 8 and P(window_size=32768, hop=8192, channel_mode=config.CH_COMPLEX) == 1
     assert P(window_size=3000, hop=750) == 1                                  # zero-padded to 4096
     assert P(window_size=65536, hop=16384, sample_rate=96000.0) == 2 | 4 | 8    # cfg5: channel-split workgroups (halves + per-side LDS map behind them)
     assert P(window_size=8192, hop=2048, channel_mode=config.CH_MERGE) == 2 | 4
