@@ -417,8 +417,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": None if traffic is None else "profiles/traffic_latest.json (committed rocprofv3 --pmc pass of this "
                                                                         "workload, gfx950 correction applied; not collected in this run)",
-                         "kernel": ("stftRealKernel<4, true>" if plan.path & 8 else "stftMapKernel<5, 0, true, true>") if not strong else
-                                   ("stftRealKernel<5, true> (one K_A pass)" if plan.path & 8 else "stftHalfKernel + mapSideKernel (one K_A pass)"),
+                         "kernel": ("stftRealKernel<4, true, 0>" if plan.path & 8 else "stftMapKernel<5, 0, true, true>") if not strong else
+                                   ("stftRealKernel<5, true, 0> (one K_A pass)" if plan.path & 8 else "stftHalfKernel + mapSideKernel (one K_A pass)"),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": frames_per_rank * pairs * bytes_per_frame},
         }
         if "no_tail" in extra:

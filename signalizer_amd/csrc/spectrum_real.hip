@@ -77,10 +77,12 @@ __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
 // MONO: SpectrumChannels Left / Right / Merge / Side -- ONE real signal per (frame, pair) (the reference transforms it as a complex frame
 // with a zero imaginary part, TransformDSP.inl:59-135): one workgroup per task, no pair exchange.  csf[0] = |X[0]| / 2 and
 // csf[N/2] = X[N/2] / 2 (:547-552; the latter stays signed: the reference leaves it complex, and X[N/2] of a real signal is real).
-template <int LR1, bool WCOS, bool MONO = false>
+template <int LR1, bool WCOS, int MIX = 0>                 // MIX: 0 Separate (two channel workgroups), 1 mono Left / Right, 2 MidSide (two workgroups on mid and side), 3 mono Merge / Side
 __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams prm)
 {
     constexpr int LR = 5, R = 32, R1 = 1 << LR1, T = R1 * R, RR = R * R, M = R1 * RR, N = 2 * M, U = R / R1;
+    constexpr bool MONO = MIX == 1 || MIX == 3;
+    constexpr bool mixed = MIX >= 2;                    // the signal is (l +- r) / 2: compile-time, the second channel's loads cost registers
     constexpr int PADSTRIDE = T + (T >> 5);             // padded distance between k and k + T
     constexpr int TILE = R * (R + 1);
     constexpr int XFLOATS = ((M + 1) + ((M + 1) >> 5) + 2) & ~1;      // this side's |X| array (padded) -- the winners follow it
@@ -134,7 +136,6 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // scheduling barriers keep instruction selection from hoisting all 2R loads to the top: 128 registers of raw samples)
         // which input channels feed this workgroup's signal: Separate: channel `side`; MidSide: (l + r) / 2 on side 0, (l - r) / 2 on side 1
         // (prepareTransform's MidSide case, then the same split as Separate); mono: l, r, (l + r) / 2 or (l - r) / 2
-        const bool mixed = MONO ? (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE) : prm.mode == SGZ_CH_MIDSIDE;
         const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : (mixed ? 0 : side);
         const float *X = prm.planar + size_t(2 * pair + firstCh) * prm.chStride + size_t(frame) * prm.hop;
         // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
@@ -145,13 +146,14 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
             const float sgn = (MONO ? prm.mode == SGZ_CH_SIDE : side == 1) ? -1.f : 1.f;
+            constexpr int YB = LR1 == 5 ? 4 : 8;        // 1024 threads: 128 registers, 64 of them hold the left channel
 #pragma unroll
-            for (int b0 = 0; b0 < R; b0 += 8) {
-                float2 y[8];
+            for (int b0 = 0; b0 < R; b0 += YB) {
+                float2 y[YB];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = ldg(reinterpret_cast<const float2 *>(Y), offOf(b0 + i));
+                for (int i = 0; i < YB; ++i) y[i] = ldg(reinterpret_cast<const float2 *>(Y), offOf(b0 + i));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) c[b0 + i] = v2{c[b0 + i].x + sgn * y[i].x, c[b0 + i].y + sgn * y[i].y};
+                for (int i = 0; i < YB; ++i) c[b0 + i] = v2{c[b0 + i].x + sgn * y[i].x, c[b0 + i].y + sgn * y[i].y};
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             }
         } else {
             // the window in batches of B pairs, two batches in flight
-            constexpr int B = 8;
+            constexpr int B = LR1 >= 4 ? 4 : 8;
             float2 wa[B], wb[B];
 #pragma unroll
             for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(i));
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             }
         }
     }
-    if (MONO ? (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE) : prm.mode == SGZ_CH_MIDSIDE) {
+    if (mixed) {
 #pragma unroll
         for (int i = 0; i < R; ++i) c[i] = v2{c[i].x * 0.5f, c[i].y * 0.5f};
     }
@@ -510,7 +512,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
     const uint32_t maxSide = mono ? prm.nItems : std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
     const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4;
-    static size_t granted[12][64] = {};
+    static size_t granted[24][64] = {};
     const bool wcos = prm.winPhase != nullptr;
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
         if (ldsBytes > limit) return hipErrorInvalidValue;
@@ -519,10 +521,26 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
         return hipSuccess;
     };
     hipError_t e;
+    if (mono && (prm.mode == SGZ_CH_MERGE || prm.mode == SGZ_CH_SIDE)) {
+        if (N == 32768) e = wcos ? go(&stftRealKernel<4, true, 3>, 18, 512, 80 * 1024) : go(&stftRealKernel<4, false, 3>, 19, 512, 80 * 1024);
+        else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true, 3>, 20, 256, 40 * 1024) : go(&stftRealKernel<3, false, 3>, 21, 256, 40 * 1024);
+        else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true, 3>, 22, 1024, 160 * 1024) : go(&stftRealKernel<5, false, 3>, 23, 1024, 160 * 1024);
+        else return hipErrorNotSupported;
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     if (mono) {
-        if (N == 32768) e = wcos ? go(&stftRealKernel<4, true, true>, 6, 512, 80 * 1024) : go(&stftRealKernel<4, false, true>, 7, 512, 80 * 1024);
-        else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true, true>, 8, 256, 40 * 1024) : go(&stftRealKernel<3, false, true>, 9, 256, 40 * 1024);
-        else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true, true>, 10, 1024, 160 * 1024) : go(&stftRealKernel<5, false, true>, 11, 1024, 160 * 1024);
+        if (N == 32768) e = wcos ? go(&stftRealKernel<4, true, 1>, 6, 512, 80 * 1024) : go(&stftRealKernel<4, false, 1>, 7, 512, 80 * 1024);
+        else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true, 1>, 8, 256, 40 * 1024) : go(&stftRealKernel<3, false, 1>, 9, 256, 40 * 1024);
+        else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true, 1>, 10, 1024, 160 * 1024) : go(&stftRealKernel<5, false, 1>, 11, 1024, 160 * 1024);
+        else return hipErrorNotSupported;
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
+    if (prm.mode == SGZ_CH_MIDSIDE) {
+        if (N == 32768) e = wcos ? go(&stftRealKernel<4, true, 2>, 12, 512, 80 * 1024) : go(&stftRealKernel<4, false, 2>, 13, 512, 80 * 1024);
+        else if (N == 16384) e = wcos ? go(&stftRealKernel<3, true, 2>, 14, 256, 40 * 1024) : go(&stftRealKernel<3, false, 2>, 15, 256, 40 * 1024);
+        else if (N == 65536) e = wcos ? go(&stftRealKernel<5, true, 2>, 16, 1024, 160 * 1024) : go(&stftRealKernel<5, false, 2>, 17, 1024, 160 * 1024);
         else return hipErrorNotSupported;
         if (e != hipSuccess) return e;
         return hipGetLastError();
