@@ -136,7 +136,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = LIB_PATH
+    path = os.environ.get("SGZ_LIB", LIB_PATH)          # (SGZ_LIB: another build of the library, for A/B timing on one box: tools/ab.sh)
     if not os.path.exists(path):
         _build.build()
     # PyTorch-ROCm bundles its own HIP/HSA runtime: if torch is going to share this process it must be

@@ -139,9 +139,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : (mixed ? 0 : side);
         const float *X = prm.planar + size_t(2 * pair + firstCh) * prm.chStride + size_t(frame) * prm.hop;
         // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
-        auto offOf = [&](int e) { const int u = e / R1, j = e % R1; return uint32_t(tid + T * u + RR * j) * 8u; };
+        // (element = compile-time part + tid.  Pinning the compile-time part to scalar base registers -- `global_load v, v_lane, s[base]`, no
+        // vector address arithmetic per load -- was measured on one box against this form: cfg2 -1 %, cfg5 +1.3 %: not kept)
+        auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return T * u + RR * j; };
+        const uint32_t lane8 = uint32_t(tid) * 8u;
 #pragma unroll
-        for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X), offOf(i)); c[i] = v2{xv.x, xv.y}; }
+        for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X) + elemOf(i), lane8); c[i] = v2{xv.x, xv.y}; }
         if (mixed) {
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             for (int b0 = 0; b0 < R; b0 += YB) {
                 float2 y[YB];
 #pragma unroll
-                for (int i = 0; i < YB; ++i) y[i] = ldg(reinterpret_cast<const float2 *>(Y), offOf(b0 + i));
+                for (int i = 0; i < YB; ++i) y[i] = ldg(reinterpret_cast<const float2 *>(Y) + elemOf(b0 + i), lane8);
 #pragma unroll
                 for (int i = 0; i < YB; ++i) c[b0 + i] = v2{c[b0 + i].x + sgn * y[i].x, c[b0 + i].y + sgn * y[i].y};
                 __builtin_amdgcn_sched_barrier(0);
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 ph = ldg(prm.winPhase, uint32_t(tid + T * u) * 16u);
+                const float4 ph = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);
 #pragma unroll
                 for (int j = 0; j < R1; ++j) {
                     constexpr int S32 = 32 / R1;
@@ -178,17 +181,17 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             constexpr int B = LR1 >= 4 ? 4 : 8;
             float2 wa[B], wb[B];
 #pragma unroll
-            for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(i));
+            for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window) + elemOf(i), lane8);
 #pragma unroll
             for (int b0 = 0; b0 < R; b0 += 2 * B) {
 #pragma unroll
-                for (int i = 0; i < B; ++i) wb[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(b0 + B + i));
+                for (int i = 0; i < B; ++i) wb[i] = ldg(reinterpret_cast<const float2 *>(prm.window) + elemOf(b0 + B + i), lane8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < B; ++i) { c[b0 + i] = v2{c[b0 + i].x * wa[i].x, c[b0 + i].y * wa[i].y}; asm volatile("" : "+v"(c[b0 + i])); }
                 if (b0 + 2 * B < R) {
 #pragma unroll
-                    for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window), offOf(b0 + 2 * B + i));
+                    for (int i = 0; i < B; ++i) wa[i] = ldg(reinterpret_cast<const float2 *>(prm.window) + elemOf(b0 + 2 * B + i), lane8);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -210,9 +213,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         float2 a[3], b[NB];
         const int col = tid + T * u;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[i] = ldg(prm.tw1, uint32_t(col + i * RR) * 8u);
+        for (int i = 0; i < 3; ++i) a[i] = ldg(prm.tw1 + (T * u + i * RR), uint32_t(tid) * 8u);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) b[i] = ldg(prm.tw1, uint32_t(col + (3 + i) * RR) * 8u);
+        for (int i = 0; i < NB; ++i) b[i] = ldg(prm.tw1 + (T * u + (3 + i) * RR), uint32_t(tid) * 8u);
 #pragma unroll
         for (int q = 1; q < R1; ++q) {
             const int qa = q >> 2, qb = q & 3;
@@ -355,11 +358,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
+        // (two base addresses and compile-time offsets: a run-time stride costs a 64-bit multiply-add per store)
         const int up = kc + (kc >> 5), down = (M - kc) + ((M - kc) >> 5);
-        float *pa = lds + (side ? down : up), *pb = lds + (side ? up : down);
-        const int sa = side ? -PADSTRIDE : PADSTRIDE;
+        int lowest = down - (R / 2 - 1) * PADSTRIDE;
+        asm volatile("" : "+v"(lowest));                                    // (opaque: or the offsets are folded back into subtractions from `down`)
+        float *pu = lds + up, *pd = lds + lowest;
+        if (side == 0) {
 #pragma unroll
-        for (int m3 = 0; m3 < R / 2; ++m3) { pa[m3 * sa] = magA[m3]; pb[-m3 * sa] = magB[m3]; }
+            for (int m3 = 0; m3 < R / 2; ++m3) { pu[m3 * PADSTRIDE] = magA[m3]; pd[(R / 2 - 1 - m3) * PADSTRIDE] = magB[m3]; }
+        } else {
+#pragma unroll
+            for (int m3 = 0; m3 < R / 2; ++m3) { pd[(R / 2 - 1 - m3) * PADSTRIDE] = magA[m3]; pu[m3 * PADSTRIDE] = magB[m3]; }
+        }
     }
     if (tid <= R / 2) {                                                     // column 0, after this wave's own stores (one wave's LDS operations execute in order)
         auto put = [&](int k, float v) { const int i = side ? M - k : k; lds[i + (i >> 5)] = v; };
