@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 
@@ -228,6 +229,10 @@ struct sgz_vector {
     float *d_ramp = nullptr, *d_tail = nullptr, *d_xyz = nullptr, *d_rgb = nullptr;
     void *h_out = nullptr;
     uint64_t busy = 0;
+    // the fade ramp is a function of (size, cursor, lanes): one replay serves every pair of a rendered frame -- it is redone when a block
+    // has been accepted since (pushes counts them; ~0 = never computed / reconfigured)
+    std::atomic<uint64_t> pushes{0};
+    uint64_t rampAt = ~0ull;
 };
 
 static void vectorFree(sgz_vector *s)
@@ -253,6 +258,7 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         return fail(SGZ_EINVAL, "window times");
     if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     SGZ_HIP(hipStreamSynchronize(s->stream));
+    s->rampAt = ~0ull;
     const uint32_t C = cfg->num_channels, size = cfg->window_size;
     if (cfg->max_block > (1u << 17)) return fail(SGZ_EINVAL, "max_block above 131072 samples");
     const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
@@ -329,6 +335,7 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
                   s->envelopeCoeff, s->stereoCoeff, s->pole1};
     hipLaunchKernelGGL(vectorIngestKernel, dim3(1), dim3(256), 0, s->stream, prm);
     SGZ_HIP(hipGetLastError());
+    s->pushes.fetch_add(1, std::memory_order_release);
     return s->stage.commit(s->stream);
 }
 
@@ -377,7 +384,11 @@ sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint3
 static sgz_status vectorVerticesInto(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb)
 {
     const uint32_t size = s->size;
-    hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
+    const uint64_t now = s->pushes.load(std::memory_order_acquire);
+    if (s->rampAt != now) {                                    // (1 200 dependent additions at cfg4: 36 us, once per rendered frame instead of once per pair)
+        hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
+        s->rampAt = now;
+    }
     PolarParams prm{};
     prm.st = s->d_state; prm.ring = s->d_ring; prm.size = size; prm.lanes = s->cfg.lanes; prm.fade = s->cfg.fade_history ? 1u : 0u;
     prm.ramp = s->d_ramp; prm.tail = s->d_tail;
