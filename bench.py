@@ -382,6 +382,28 @@ def main() -> None:
             state.zero_(); plan.render(view, rgba=rgba, lines=lines, state=state)
         torch.cuda.synchronize()
         extra["ms_per_step_with_state"] = (time.perf_counter() - ts) / 50 * 1e3
+        # (iii) two buffers in flight: independent renders (two plans -- a plan owns its scratch --, two streams) alternate, so that one
+        #       buffer's K_B and the partly filled last round of its K_A overlap the other buffer's K_A.  What a job of many buffers gets;
+        #       NOT the contract line's value (steps there run one after the other on one stream), and a kernel's own duration grows under it.
+        plan_b = api.Plan(cfg).upload()
+        x_b = torch.from_numpy(synth.gen(config.CFG2_SEED + 7, sr, S, 2 * pairs)).to(dev)
+        rg = [torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        st = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        job = [(plan, view, rg[0], st[0].cuda_stream), (plan_b, x_b, rg[1], st[1].cuda_stream)]
+        for i in range(10):
+            pl, xx, out_, s_ = job[i & 1]
+            pl.render(xx, rgba=out_, stream=s_)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        n2 = 2 * max(50, args.steps // 2)
+        for i in range(n2):
+            pl, xx, out_, s_ = job[i & 1]
+            pl.render(xx, rgba=out_, stream=s_)
+        torch.cuda.synchronize()
+        two = (time.perf_counter() - ts) / n2
+        extra["two_in_flight"] = {"ms_per_step": two * 1e3, "value": F * pairs / two,
+                                  "note": "two independent buffers alternate on two streams (two plans); steps of the contract line do not overlap"}
+        del plan_b, x_b
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -428,6 +450,8 @@ def main() -> None:
                                           "note": "8 stereo pairs of the cfg2 buffer: many rounds of workgroups, so the partial last round does not count; at this task count the library runs the whole-frame kernel stftMapKernel<5, 0, true, true> (the channel-split form is for launches of few rounds)"}
         if "ms_per_step_with_state" in extra:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
+        if "two_in_flight" in extra:
+            out["config"]["two_in_flight"] = extra["two_in_flight"]
         if not args.no_cpu_baseline and world == 1 and not strong:
             out["cpu_baseline"] = cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)
