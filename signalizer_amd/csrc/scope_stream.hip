@@ -1158,6 +1158,18 @@ sgz_status sgz_scope_front_colours(sgz_scope *s, uint32_t channel, uint32_t aux,
     return SGZ_OK;
 }
 
+#ifdef SGZ_DEBUG
+// (debug builds: the spectral trigger's median ring, 8 x (index, value, offset) as doubles)
+sgz_status sgz_scope_debug_median(sgz_scope *s, double out[24])
+{
+    SpectralDev h;
+    SGZ_HIP(hipMemcpyAsync(&h, s->d_spectral, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < 8; ++i) { out[3 * i] = double(h.median[i].index); out[3 * i + 1] = h.median[i].value; out[3 * i + 2] = h.median[i].offset; }
+    return SGZ_OK;
+}
+#endif
+
 sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8])
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");

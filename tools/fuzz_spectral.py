@@ -1,5 +1,12 @@
 """random sweep of sgz_scope_analyse (Spectral triggering) against the oracle: sample rates, windows, fundamentals, harmonic mixes, noise,
-hysteresis, evaluators, block schedules.  usage: fuzz_spectral.py [cases] [seed]"""
+hysteresis, evaluators, block schedules.  usage: fuzz_spectral.py [cases] [seed]
+
+A case that reports a different winning BIN is not automatically a disagreement: the candidate test compares omega(current) / omega(max)
+with the nearest integer at a quarter-semitone bar (OscilloscopeDSP.inl:155-175), and while max is still the seeded bin 1 its omega is
+1 + quadDelta(1) -- a ratio of differences of leakage-level bins 0, 1, 2 that can come out near -1 (omega 0.06).  The ratio is then
+amplified 16 x 2767-fold and the two transforms' rounding (1e-9 of the offset) decides the test: seed 77 case 72 is such a frame
+(tools/debug_spectral_case.py 77 72 prints both median rings: the device keeps (1, 409.6, -0.937457) where the oracle takes bin 2767; the
+oracle run on the device's ring memory takes 2767 too).  Conditioning of the reference's own rule, 1 case in 300 of this sweep."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
