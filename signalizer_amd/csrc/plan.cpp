@@ -664,9 +664,13 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // N = 32768 (cfg2, 348 frames = 696 channel workgroups, two per CU) 38.2 us against 44.0 us for the whole-frame kernel; N = 16384
     // 6.9 M against 2.9 M transforms/s for the generic passes.  SGZ_CHANNEL_SPLIT=0 keeps a plan off it (A/B runs).
     if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
-    // The mono modes transform ONE real signal per task: the same kernel, one workgroup per (frame, pair), no pair exchange.  Eligible
-    // when every pixel stays inside csf[0 .. N/2] without wrapping (csf[N/2] = X[N/2] / 2 is real for a real signal: arg-max runs may
-    // end on it, tap windows may not touch it -- it is signed; everything above N/2 is the raw mirror half, which this kernel does not hold)
+    // The mono modes transform ONE real signal per task: the same kernel, one workgroup per (frame, pair), no pair exchange.  It holds
+    // csf[0 .. N/2] as magnitudes (csf[N/2] = X[N/2] / 2 is real for a real signal: arg-max runs may end on it) and the kSpecBins entries
+    // of complex_dc.hpp the reference leaves complex (csf[N-8 .. N-1] = conj X[8 .. 1], csf[N/2 .. N/2+7]); csf[N] is 0 in these modes.
+    // Eligible when every arg-max run stays inside csf[0 .. N/2] and every tap window inside those entries; the pixels whose taps leave the
+    // magnitudes (windows that wrap below bin 0 -- the lowest pixels of a view from 0 Hz or of the default view at N = 16384 -- or sit at
+    // Nyquist) are redone by complexDcPixel from the complex entries, like the whole-frame kernel does (monoFix).
+    std::vector<uint32_t> monoFix;
     p.realMono = (cfg.channel_mode == SGZ_CH_LEFT || cfg.channel_mode == SGZ_CH_RIGHT || cfg.channel_mode == SGZ_CH_MERGE ||
                   cfg.channel_mode == SGZ_CH_SIDE) &&
                  (p.N == 16384 || p.N == 32768 || p.N == 65536) && p.W == p.N && (cfg.hop % 2u) == 0u && !p.items.empty();
@@ -676,18 +680,35 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             const PixelRec &rec = p.recs[r];
             if (rec.kind == 0) {
                 long k = rec.a;
-                for (int i = 0; i < rec.b; ++i) { p.realMono = p.realMono && k >= 0 && k < M; ++k; }     // (no wrap: k + 1 <= M < N)
+                bool special = false;
+                for (int i = 0; i < rec.b; ++i) {
+                    const bool plain = k >= 0 && k < M;
+                    const bool held = k == N || (k >= N - 8 && k < N) || (k >= M && k < M + 8);      // complex_dc.hpp specSlot (mono modes)
+                    p.realMono = p.realMono && (plain || held);
+                    special = special || !plain;
+                    k = (k == N) ? 0 : k + 1;                                               // periodic over the N + 1 entries
+                }
+                if (special) monoFix.push_back(uint32_t(r));
             } else if (rec.kind & 1) {
                 p.realMono = p.realMono && rec.a >= 0 && long(rec.a) + rec.b - 1 <= M && rec.c <= M;
             }
         }
+        if (monoFix.size() > 256) p.realMono = false;
         const size_t ldsFloats = size_t(M + 1) + size_t((M + 1) >> 5) + 2;
-        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
+        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16 - 2 * 16 * 4;     // (2 x kSpecBins floats of complex entries)
         if (p.items.size() * 4 > budget) p.realMono = false;
         if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realMono = false; }
     }
     p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0;
     if (p.realSplit && lowFix[0].size() + lowFix[1].size() > 128) p.realSplit = false;      // (one thread settles them)
+    if (p.realMono && !monoFix.empty()) {                                                   // (mono: the same fields carry the redone pixels)
+        p.recsReal = p.recs;
+        p.realLowCount[0] = uint32_t(monoFix.size());
+        for (uint32_t x : monoFix) {
+            p.realLowPixels.push_back(x);
+            p.recsReal[x] = PixelRec{2, 0, 0, 0};
+        }
+    }
     if (p.realSplit && !(lowFix[0].empty() && lowFix[1].empty())) {
         p.recsReal = p.recs;
         for (int side = 0; side < 2; ++side) {

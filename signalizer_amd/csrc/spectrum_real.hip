@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                        MONO ? nullptr : sLate, int(prm.fixFrom[side])};
     const ChannelIndex at{N, side ? M : 0};
     float *win = lds + XFLOATS;
+    // mono modes: the kSpecBins csf entries the reference leaves complex (complex_dc.hpp), behind the winners; written during the
+    // recombination (nothing else uses the area), read by the pixels of prm.lowPixels after the mapping
+    float *spec = win + (prm.nItems > 72u ? prm.nItems : 72u);
     MapPixelsBalanced<5, T, ChannelIndex> mapper;
     StftParams sp{};
     sp.weights = prm.weights; sp.invSize = prm.invSize;
@@ -349,6 +352,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const float pr = ex + ox, pi = ey + oy, mr = ex - ox, mi = ey - oy;
             magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
             magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(mr * mr + mi * mi);
+            if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
+                // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
+                // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
+                spec[2 * (8 - kc)] = 0.5f * pr; spec[2 * (8 - kc) + 1] = -0.5f * pi;
+                if (kc < 8) { spec[2 * (8 + kc)] = 0.5f * mr; spec[2 * (8 + kc) + 1] = 0.5f * mi; }
+            }
         }
     }
     RCLK(6);
@@ -378,6 +387,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             if (tid != R / 2) put(T * (R - tid), fixB);
         } else {
             put(0, fixA);
+            if (MONO) { spec[16] = fixB; spec[17] = 0.f; }                   // csf[N/2] = Z[N/2] / 2 among the complex entries (slot 8)
             put(M, MONO ? fixB : 0.f);                                      // pairs: csf[N/2] is settled late, 0 can never win meanwhile (strict >)
         }
     }
@@ -415,7 +425,20 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
     RCLK(9);
-    if (MONO) return;
+    if (MONO) {
+        // the pixels whose tap windows leave the magnitudes (wrap below bin 0: csf[N - j] = conj X[j], csf[N] = 0; or reach csf[N/2 ..]):
+        // complex sums in the reference's order (complex_dc.hpp), from entries written before the last barrier; the mapping skipped them
+        if (prm.mapped && prm.lowCount[0]) {
+            float *out = prm.mapped + size_t(task) * prm.P;
+            for (uint32_t i = tid; i < prm.lowCount[0]; i += T) {
+                const uint32_t x = prm.lowPixels[i];
+                out[x] = complexDcPixel(prm.recsFull[x], prm.weights, prm.invSize, N, prm.mode,
+                                        [&](int k) { return k >= N ? 0.f : lds[k + (k >> 5)]; },
+                                        [&](int sl) { return make_float2(spec[2 * sl], spec[2 * sl + 1]); });
+            }
+        }
+        return;
+    }
     __shared__ int sHave, sPartnerGaveUp;
     __syncthreads();                                                        // sLate is complete
     if (tid == 0) {
@@ -521,7 +544,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     const uint32_t M = N / 2;
     const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
     const uint32_t maxSide = mono ? prm.nItems : std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
-    const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4;
+    const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4 + (mono ? 2 * kSpecBins * 4 : 0);
     static size_t granted[24][64] = {};
     const bool wcos = prm.winPhase != nullptr;
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {

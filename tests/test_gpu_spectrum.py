@@ -459,7 +459,13 @@ def test_pair_exchange_rare_paths(gpu, monkeypatch, N, sr):
     (32768, 48000.0, config.CH_LEFT, 1, {}), (32768, 48000.0, config.CH_RIGHT, 2, {}), (32768, 48000.0, config.CH_MERGE, 1, {}),
     (32768, 48000.0, config.CH_SIDE, 3, {}), (65536, 96000.0, config.CH_MERGE, 2, {}), (65536, 96000.0, config.CH_LEFT, 1, {}),
     (16384, 24000.0, config.CH_SIDE, 1, {}), (16384, 24000.0, config.CH_RIGHT, 2, {}),
-    (32768, 48000.0, config.CH_MERGE, 1, dict(bin_interp=1)), (32768, 44100.0, config.CH_LEFT, 1, dict(window_type=2))])
+    (32768, 48000.0, config.CH_MERGE, 1, dict(bin_interp=1)), (32768, 44100.0, config.CH_LEFT, 1, dict(window_type=2)),
+    # tap windows that wrap below bin 0 (csf[N - j] = conj X[j] stays complex in the mono modes, csf[N] = 0) or reach csf[N/2 ..]:
+    # redone from the kernel's complex entries (complex_dc.hpp)
+    (16384, 48000.0, config.CH_SIDE, 1, {}), (16384, 48000.0, config.CH_MERGE, 2, dict(bin_interp=1)),
+    (32768, 48000.0, config.CH_LEFT, 1, dict(view_scaling=0, view_left=0.0, view_right=1.0)),
+    (32768, 48000.0, config.CH_MERGE, 1, dict(view_scaling=0, view_left=0.0, view_right=0.01, bin_interp=1)),
+    (65536, 96000.0, config.CH_RIGHT, 1, dict(min_log_freq=2.0)), (16384, 48000.0, config.CH_LEFT, 1, dict(view_scaling=0, view_left=0.9, view_right=1.0))])
 def test_mono_modes_on_the_real_input_kernel(gpu, oracle, monkeypatch, N, sr, mode, pairs, over):
     """Left / Right / Merge / Side transform one real signal per frame: spectrum_real.hip's MONO form (one workgroup per (frame, pair)) against
     the oracle through the parity chain, and bin for bin (csf[0 .. N/2], incl. the halved csf[0] and the signed csf[N/2]) against the
