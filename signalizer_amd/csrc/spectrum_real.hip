@@ -215,10 +215,15 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         constexpr int NB = R1 / 4 - 1;
         float2 a[3], b[NB];
         const int col = tid + T * u;
+        // W^c and W^{4c} from the table, the other rows as their powers (two loads per column instead of 3 + NB: the table is 8 KB per
+        // row and workgroup, and what a workgroup fetches costs as much as what it computes)
+        auto sq = [](float2 w) { return float2{w.x * w.x - w.y * w.y, 2.f * w.x * w.y}; };
+        auto mul = [](float2 p, float2 q) { return float2{p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x}; };
+        a[0] = ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
+        if (NB > 0) b[0] = ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
+        a[1] = sq(a[0]); a[2] = mul(a[1], a[0]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[i] = ldg(prm.tw1 + (T * u + i * RR), uint32_t(tid) * 8u);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) b[i] = ldg(prm.tw1 + (T * u + (3 + i) * RR), uint32_t(tid) * 8u);
+        for (int i = 1; i < NB; ++i) b[i] = (i & 1) ? sq(b[i / 2]) : mul(b[i - 1], b[0]);
 #pragma unroll
         for (int q = 1; q < R1; ++q) {
             const int qa = q >> 2, qb = q & 3;
