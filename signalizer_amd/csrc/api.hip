@@ -287,6 +287,7 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
     prm.sc = p.scalars;
     prm.state = d_state; prm.stateIn = d_state; prm.rgba = d_rgba; prm.lines = d_lines;
     prm.colourOnly = (!d_state && !d_lines && d_rgba) ? 1u : 0u;
+    prm.magScale = p.cfg.channel_mode == SGZ_CH_PHASE ? 0.5f : 1.0f;
     if (d_state && frames > 1) {
         // frame 0's threads read the carry-in while the last frame's threads write the new state: snapshot it
         const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
@@ -305,13 +306,19 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     DecayParams prm;
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
+    static const bool noFused = std::getenv("SGZ_KB_FUSED") && std::getenv("SGZ_KB_FUSED")[0] == '0';   // A/B switch for measurements
     if (p.cfg.channel_mode == SGZ_CH_PHASE) {
+        // colour column only: the image reads the main graph's magnitude state alone (decayPhaseColourKernel), a plain peak decay of
+        // plane 0 x 0.5 -- the chunked exact scan of the fused kernel instead of the sequential walk the phase smoother needs
+        if (!noFused && decayColourFusedApplies(prm)) {
+            SGZ_HIP(launchDecayColourFused(prm, stream));
+            return SGZ_OK;
+        }
         sgz_status stw = ensureCap(&p.d_phaseWork, &p.phaseWorkCap, size_t(frames) * p.C * p.P);
         if (stw != SGZ_OK) return stw;
         SGZ_HIP(launchDecayPhase(prm, p.d_phaseWork, stream));
         return SGZ_OK;
     }
-    static const bool noFused = std::getenv("SGZ_KB_FUSED") && std::getenv("SGZ_KB_FUSED")[0] == '0';   // A/B switch for measurements
     if (!noFused && decayColourFusedApplies(prm)) {
         SGZ_HIP(launchDecayColourFused(prm, stream));
         return SGZ_OK;
@@ -343,6 +350,7 @@ sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, co
     prm.colourTables = p.d_colourTables;
     prm.sc = p.scalars;
     prm.state = d_stateOut; prm.stateIn = d_carry; prm.rgba = d_rgba; prm.lines = d_lines;
+    prm.magScale = 1.0f;
     if (prm.numChunks > 1) {
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
         if (!p.d_agg || p.aggCap < need) return fail(SGZ_EINVAL, "sgz_stage_decay_emit without a preceding sgz_stage_decay_scan of the same frames");

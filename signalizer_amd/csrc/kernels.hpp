@@ -126,6 +126,7 @@ struct DecayParams {
     float *state;             // [C][G][P][2] (float2: left/right) out: state after the last frame, may be null
     uint8_t *rgba;            // [frames][P][4] or null
     float *lines;             // [frames][C][G][P][2] or null
+    float magScale;           // factor on the mapped magnitudes before the decay: 1, or 0.5 in Phase mode (mag *= consts::half, TransformDSP.inl:1407) -- fused kernel only
     uint32_t colourOnly;      // neither lines nor state are wanted: only (side 0, LineMain) of every pair feeds the colour column, the scans skip the rest
 };
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream);   // local + carry, one launch when the chunks fit a workgroup

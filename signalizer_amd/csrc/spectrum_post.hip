@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX; e += 1024) {
         const uint32_t px = e % PX, f = e / PX;
         const uint32_t pixel = blockIdx.x * PX + px;
-        magS[f][px] = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] : 0.f;
+        magS[f][px] = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] * prm.magScale : 0.f;   // (x 1 is exact)
     }
     __syncthreads();
     // 1b. zero-carry scan of every chunk

@@ -114,6 +114,26 @@ def test_phase_end_to_end(gpu, oracle, interp):
     assert not problems, (problems[:5], stats)
 
 
+@pytest.mark.parametrize("frames", [1, 9, 70])
+def test_phase_colour_only_render(gpu, oracle, frames):
+    """the image alone (no line results, no state): the main graph's magnitude state is a plain peak decay of plane 0 x 0.5, so the
+    request runs the one-launch chunked K_B instead of the sequential walk the phase smoother needs -- same bytes as that walk and as the
+    oracle given the mapped planes"""
+    import torch
+    po = oracle
+    cfg = _cfg(config.INTERP_LANCZOS, P=400)
+    x = synth.gen(15, 48000, 4096 + (frames - 1) * 1024, 2)
+    plan = api.Plan(cfg).upload()
+    xg = torch.from_numpy(x).to(gpu)
+    fused = plan.render(xg).cpu().numpy()
+    lines = torch.empty((fused.shape[0], plan.C, 2, plan.P, 2), dtype=torch.float32, device=gpu)
+    walked = plan.render(xg, lines=lines).cpu().numpy()               # (lines requested: the sequential kernels)
+    assert np.array_equal(fused, walked)
+    from parity_chain import check_render
+    problems, stats = check_render(po, plan, cfg, x, gpu, want_lines=False)
+    assert not problems, (problems[:5], stats)
+
+
 def test_phase_has_no_carry_fold(gpu):
     """the cancellation smoother is a linear recurrence: the exact multi-GPU carry fold does not apply"""
     import torch
