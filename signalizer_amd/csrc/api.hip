@@ -293,8 +293,13 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
         const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
         sgz_status st0 = ensureCap(&p.d_stateCopy, &p.stateCopyCap, stateN);
         if (st0 != SGZ_OK) return st0;
-        SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        prm.stateIn = p.d_stateCopy;
+        if (prm.numChunks > 1 && p.cfg.channel_mode != SGZ_CH_PHASE) {
+            // two launches: the scan launch reads the live state and stashes what it read, the emit launch reads the stash (no copy launch)
+            prm.stateStash = p.d_stateCopy;
+        } else {
+            SGZ_HIP(hipMemcpyAsync(p.d_stateCopy, d_state, stateN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            prm.stateIn = p.d_stateCopy;
+        }
     }
     return SGZ_OK;
 }
@@ -329,6 +334,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         if (st != SGZ_OK) return st;
         prm.agg = p.d_agg;
         SGZ_HIP(launchDecayLocalCarry(prm, stream));
+        if (prm.stateStash) { prm.stateIn = prm.stateStash; prm.stateStash = nullptr; }
     }
     SGZ_HIP(launchDecayEmit(prm, stream));
     return SGZ_OK;

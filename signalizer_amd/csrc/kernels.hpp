@@ -123,6 +123,7 @@ struct DecayParams {
     DeviceScalars sc;
     float *agg;               // [numChunks][C][sides][G][P] chunk-end aggregates (zero carry-in, chunk 0 uses state)
     const float *stateIn;     // [C][G][P][2] carry-in (a private copy when numChunks > 1), may be null
+    float *stateStash;        // scan launches: copy of every carry-in entry they read (the emit launch reads it from there while the last frame's threads write state), or null
     float *state;             // [C][G][P][2] (float2: left/right) out: state after the last frame, may be null
     uint8_t *rgba;            // [frames][P][4] or null
     float *lines;             // [frames][C][G][P][2] or null

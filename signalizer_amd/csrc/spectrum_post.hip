@@ -34,8 +34,11 @@ __global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
 
     float a[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k)
-        a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+    for (int k = 0; k < G; ++k) {
+        const size_t si = ((size_t(pair) * G + k) * prm.P + pixel) * 2 + side;
+        a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[si] : 0.f;
+        if (chunk == 0 && prm.stateStash) prm.stateStash[si] = a[k];   // the carry-in as the emit launch must see it (it overwrites state)
+    }
     const long f0 = long(chunk) * kMaxChunk;
     const int len = int(min(long(kMaxChunk), prm.frames - f0));
     float mag[kMaxChunk];
@@ -137,8 +140,11 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
     if (live) {
         float a[G];
 #pragma unroll
-        for (int k = 0; k < G; ++k)
-            a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f;
+        for (int k = 0; k < G; ++k) {
+            const size_t si = ((size_t(pair) * G + k) * prm.P + pixel) * 2 + side;
+            a[k] = (chunk == 0 && prm.stateIn) ? prm.stateIn[si] : 0.f;
+            if (chunk == 0 && prm.stateStash) prm.stateStash[si] = a[k];   // the carry-in as the emit launch must see it (it overwrites state)
+        }
         const long f0 = long(chunk) * kMaxChunk;
         const int len = int(min(long(kMaxChunk), prm.frames - f0));
         float mag[kMaxChunk];
