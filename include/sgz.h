@@ -124,7 +124,7 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
 #define SGZ_PATH_SIDE_MAP 4u
 #define SGZ_PATH_CHANNEL_SPLIT 8u   /* N = 16384 / 32768 / 65536, W == N, even hop: the real-input kernel (spectrum_real.hip) -- Separate: one
                                        workgroup per (frame, pair, channel); Left / Right / Merge / Side: one per (frame, pair) on the mixed
-                                       signal -- takes the place of the kernels above for device buffers whose rows are 8-byte aligned
+                                       signal -- takes the place of the kernels above, whatever the row layout
                                        (at N = 32768 in Separate mode: for launches of up to 1024 tasks) */
 uint32_t   sgz_plan_path(const sgz_plan *plan);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2

@@ -163,7 +163,9 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     // throughput does (0.385 against 0.365 of the roofline at 2784 frames): the task count decides.  SGZ_CHANNEL_SPLIT=1 pins the former.
     const bool pinSplit = std::getenv("SGZ_CHANNEL_SPLIT") && std::getenv("SGZ_CHANNEL_SPLIT")[0] == '1';
     const bool splitPays = p.N != 32768 || tasks <= 1024 || pinSplit;
-    if ((p.realMono || (p.realSplit && splitPays)) && d_binsIn == nullptr && (chStride % 2) == 0 && (reinterpret_cast<uintptr_t>(d_planar) % 8) == 0) {
+    // (rows need no more than their natural 4-byte alignment: gfx950's global_load_dwordx2 takes dword-aligned addresses, measured
+    // bit-identical and within 2 % of 8-byte aligned rows, tools/unaligned_probe.py -- so the choice of kernel never depends on the layout)
+    if ((p.realMono || (p.realSplit && splitPays)) && d_binsIn == nullptr) {
         // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
         const size_t units = size_t(tasks) * 2;
         if (p.nyCap < units) {
@@ -529,7 +531,7 @@ sgz_status sgz_spectrogram_render_host(sgz_plan *plan, const float *const *plana
     hipStream_t s = static_cast<hipStream_t>(p.hostStream);
     hipEvent_t ev[4];
     for (int i = 0; i < 4; ++i) ev[i] = static_cast<hipEvent_t>(p.hostEv[i]);
-    const size_t stride = (nsamples + 63) & ~size_t(63);                    // 256-byte rows: the channel-split kernels want aligned rows
+    const size_t stride = (nsamples + 63) & ~size_t(63);                    // 256-byte rows
     const size_t linesN = size_t(frames) * p.C * SGZ_NUM_GRAPHS * p.P * 2;
     if ((st = ensureCap(&p.d_hostAudio, &p.hostAudioCap, size_t(num_channels) * stride)) != SGZ_OK) return st;
     if ((st = ensureCap(&p.d_hostRgba, &p.hostRgbaCap, (size_t(frames) * p.P * 4 + 3) / 4)) != SGZ_OK) return st;

@@ -38,7 +38,7 @@ def main():
         if ok and it % 8 == 0:
             rgba2, _, _ = api.render_spectrogram(cfg, x)              # the host-buffer entry point renders the same bytes
             # (it copies the channels into rows of a 64-sample multiple; the same layout here, so that both renders take the same
-            # kernels -- the real-input kernels want 8-byte aligned rows and a plan falls back to the complex ones otherwise)
+            # kernels -- before the real-input kernels took dword-aligned rows a plan fell back to the complex ones on odd strides)
             xt = torch.zeros((x.shape[0], (x.shape[1] + 63) // 64 * 64), dtype=torch.float32, device="cuda")
             xt[:, :x.shape[1]] = torch.from_numpy(x).cuda()
             ok = np.array_equal(rgba2, plan.render(xt[:, :x.shape[1]]).cpu().numpy())

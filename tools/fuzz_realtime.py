@@ -57,8 +57,8 @@ def main():
         # the per-block path must reproduce the batch render of [W zeros ++ audio] byte for byte (same kernels, decay state carried
         # exactly); the batch render itself is held against the oracle by the parity chain (tests/parity_chain.py)
         padded = np.ascontiguousarray(padded)
-        # rows of a 64-sample multiple, like the handle's ring: the real-input kernels want 8-byte aligned rows and a plan falls back to the
-        # complex ones otherwise -- another rounding, and "byte for byte" compares one kernel with itself
+        # rows of a 64-sample multiple, like the handle's ring (before the real-input kernels took dword-aligned rows a plan fell back to
+        # the complex ones on odd strides -- another rounding, while "byte for byte" must compare one kernel with itself)
         def aligned(a):
             t = torch.zeros((a.shape[0], (a.shape[1] + 63) // 64 * 64), dtype=torch.float32, device="cuda")
             t[:, :a.shape[1]] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
