@@ -488,3 +488,23 @@ def test_mono_modes_on_the_real_input_kernel(gpu, oracle, monkeypatch, N, sr, mo
     assert not problems, (problems[:5], stats)
     m1, m2 = real.stage_mapped(xg).cpu().numpy(), other.stage_mapped(xg).cpu().numpy()
     assert np.abs(m1 - m2).max() <= 4e-6 * np.abs(b).max() * real.window_scale / (N * 0.5) * 4
+
+
+@pytest.mark.parametrize("N,sr,mode", [(32768, 48000.0, config.CH_SEPARATE), (16384, 48000.0, config.CH_MERGE), (65536, 96000.0, config.CH_MIDSIDE)])
+def test_result_does_not_depend_on_the_row_layout(gpu, N, sr, mode):
+    """rows at their natural 4-byte alignment (odd row stride, base shifted by one sample) run the same real-input kernels as aligned rows:
+    identical bits, whatever buffer the caller hands over"""
+    import torch
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, channel_mode=mode)
+    plan = api.Plan(cfg).upload()
+    assert plan.path & 8
+    S = N + 5 * (N // 4)
+    x = torch.from_numpy(synth.gen(41, int(sr), S, 2)).to(gpu)
+    even = torch.zeros((2, S + 2), dtype=torch.float32, device=gpu)
+    odd = torch.zeros((2, S + 3), dtype=torch.float32, device=gpu)
+    even[:, :S] = x
+    odd[:, 1:S + 1] = x                                                # odd stride AND a base one sample past an aligned address
+    a = plan.stage_mapped(even[:, :S]).cpu().numpy()
+    b = plan.stage_mapped(odd[:, 1:S + 1]).cpu().numpy()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(plan.render(even[:, :S]).cpu().numpy(), plan.render(odd[:, 1:S + 1]).cpu().numpy())

@@ -140,3 +140,16 @@ def test_no_cpu_fallback_compute_fails_loudly_without_gpu():
     h = C.c_void_p()
     c = api.config_from_dict(config.cfg1())
     assert api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)) == api.SGZ_EHIP
+
+
+def test_mono_views_on_the_real_input_kernel():
+    """which mono views the real-input kernel takes (plan.cpp realMono): tap windows may wrap below bin 0 or reach csf[N/2 .. N/2+7] -- the
+    kernel keeps those 16 complex entries --, arg-max runs must stay inside csf[0 .. N/2]"""
+    P = lambda **kw: api.Plan(config.spectrum_config(**kw)).path
+    mono = dict(window_size=32768, hop=8192, channel_mode=config.CH_MERGE)
+    assert P(**mono) & 8                                                                   # default log view
+    assert P(**mono, view_scaling=0, view_left=0.0, view_right=1.0) & 8                    # linear from 0 Hz to Nyquist
+    assert P(**mono, view_scaling=0, view_left=0.0, view_right=0.001, bin_interp=2) & 8    # deep zoom at 0 Hz: every window wraps
+    assert P(window_size=16384, hop=4096, channel_mode=config.CH_LEFT) & 8                 # default view at N = 16384: its lowest windows wrap
+    assert not P(window_size=30000, hop=7500, channel_mode=config.CH_MERGE) & 8            # zero-padded window
+    assert not P(window_size=8192, hop=2048, channel_mode=config.CH_MERGE) & 8             # no real-input kernel at this size
