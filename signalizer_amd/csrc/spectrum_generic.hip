@@ -315,7 +315,22 @@ genericMapPhase(const float2 *csfAll, uint32_t N, uint32_t P, const PixelRec *re
         int maxBin = 0x7fffffff;
         for (int i = lane; i < rec.b; i += kMapLanes) {
             const int off = rec.a + i;
-            const float2 l = normalised(off, ph.normFinal), r = normalised(int(N) - off, ph.normFinal);
+            float2 l, r;
+            if (FROMZ != 0 && off > 0 && off < int(N / 2) - 1) {
+                // csf[off] = X1[off] and csf[N - off] = X2[off] come from the same two transform values: load them once (the general
+                // path below fetches Z[off] and Z[N - off] for either entry), same expressions as phaseCsfEntry
+                const float2 za = FROMZ == 2 ? make_float2(zf[off], zf[N + off]) : csf[off];
+                const float2 zb = FROMZ == 2 ? make_float2(zf[N - off], zf[N + (N - off)]) : csf[N - off];
+                l = make_float2((za.x + zb.x) * 0.5f, (za.y - zb.y) * 0.5f);
+                r = make_float2((za.y + zb.y) * 0.5f, (zb.x - za.x) * 0.5f);
+                if (uint32_t(off) < ph.normFinal) {                     // (off < N - off: the one condition covers both entries)
+                    l = make_float2(cabsHypot(l), 0.f);
+                    r = make_float2(cabsHypot(r), 0.f);
+                }
+            } else {
+                l = normalised(off, ph.normFinal);
+                r = normalised(int(N) - off, ph.normFinal);
+            }
             const float a = l.x * l.x + l.y * l.y, b = r.x * r.x + r.y * r.y;     // Math::square(complex) = |z|^2
             const float newMag = a < b ? b : a;                        // std::max
             if (newMag > maxValue) { maxValue = newMag; maxBin = off; }
