@@ -218,6 +218,9 @@ sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t fr
 /* std::log(float) as the dB map evaluates it (TransformDSP.inl:1345): glibc's logf algorithm, bit-identical to libm over every
  * positive finite float (tests/test_gpu_spectrum.py checks all 2^31 of them).  d_x > 0; DEVICE pointers. */
 sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream);
+/* the last step of every K_A pixel, magnitude = sqrt(re*re + im*im) with im == 0 (TransformDSP.inl:1331): evaluated as |x| where the
+ * square is a normal float (the two are bit-identical there), as the correctly rounded root elsewhere */
+sgz_status sgz_stage_finish_pixel(const float *d_x, float *d_y, size_t n, void *stream);
 
 /* Multi-GPU time-chunk sharding (collective A2).  Rank q renders its frames with a zero
  * carry-in and publishes its end state A_q (the d_state output above).  Because fl(x*pole) is monotone,

@@ -37,7 +37,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyFlag, d_nyBest};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -79,6 +79,10 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.twRealPost, &p.d_twRealPost)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhase, &p.d_winPhase)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhaseT, &p.d_winPhaseT)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.chunkEnds, &p.d_chunkEnds)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.chunkReBase, &p.d_chunkReBase)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.chunkRec, &p.d_chunkRec)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.weights12, &p.d_weights12)) != SGZ_OK) return st;
     if ((st = uploadVec(p.dcPixels, &p.d_dcPixels)) != SGZ_OK) return st;
     if ((st = uploadVec(p.recs, &p.d_recs)) != SGZ_OK) return st;
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
@@ -165,27 +169,17 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const bool splitPays = p.N != 32768 || tasks <= 1024 || pinSplit;
     // (rows need no more than their natural 4-byte alignment: gfx950's global_load_dwordx2 takes dword-aligned addresses, measured
     // bit-identical and within 2 % of 8-byte aligned rows, tools/unaligned_probe.py -- so the choice of kernel never depends on the layout)
-    if ((p.realMono || (p.realSplit && splitPays)) && d_binsIn == nullptr) {
+    if ((p.realMono && d_binsIn == nullptr) || (p.realSplit && splitPays)) {
         // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
         const size_t units = size_t(tasks) * 2;
         if (p.nyCap < units) {
-            if (p.d_ny) { (void)hipFree(p.d_ny); p.d_ny = nullptr; }
-            if (p.d_nyFlag) { (void)hipFree(p.d_nyFlag); p.d_nyFlag = nullptr; }
-            if (p.d_nyBest) { (void)hipFree(p.d_nyBest); p.d_nyBest = nullptr; }
+            for (float **b : {&p.d_ny, &p.d_nyBest, &p.d_low}) if (*b) { (void)hipFree(*b); *b = nullptr; }
             p.nyCap = 0;
-            // the pair exchange of the channel workgroups: fine-grained (coherent across the XCDs' L2s), see spectrum_real.hip
-            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyBest), units * 128 * sizeof(float), hipDeviceMallocFinegrained));
-            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float), hipDeviceMallocFinegrained));
-            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_nyFlag), units * 2 * sizeof(uint32_t), hipDeviceMallocFinegrained));
-            if (p.d_low) { (void)hipFree(p.d_low); p.d_low = nullptr; }
-            SGZ_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float), hipDeviceMallocFinegrained));
-            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, units * 2 * sizeof(uint32_t), stream));
+            // what the channel workgroups leave for realLateKernel (spectrum_real.hip): Nyquist bins, winning squares of the top pixels, lowest bins
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_nyBest), units * 64 * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_ny), units * sizeof(float)));
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_low), units * kLowBins * sizeof(float)));
             p.nyCap = units;
-            p.nyEpoch = 0;
-        }
-        if (++p.nyEpoch == 0) {                                          // the epoch wrapped: start over from clean flags
-            SGZ_HIP(hipMemsetAsync(p.d_nyFlag, 0, p.nyCap * 2 * sizeof(uint32_t), stream));
-            p.nyEpoch = 1;
         }
         RealParams rp{};
         rp.planar = d_planar; rp.chStride = chStride; rp.frames = frames;
@@ -195,14 +189,14 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
         rp.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
         rp.twPost = reinterpret_cast<const float2 *>(p.d_twRealPost);
-        rp.recs = p.d_recsReal ? p.d_recsReal : p.d_recs; rp.recsFull = p.d_recs; rp.weights = p.d_weights; rp.items = p.d_items;
+        rp.recs = p.d_recsReal ? p.d_recsReal : p.d_recs; rp.recsFull = p.d_recs; rp.weights = p.d_weights;
+        rp.chunkEnds = p.d_chunkEnds; rp.chunkReBase = p.d_chunkReBase; rp.chunkRec = p.d_chunkRec; rp.weights12 = p.d_weights12;
+        rp.chunkSlots[0] = p.chunkSlots[0]; rp.chunkSlots[1] = p.chunkSlots[1];
         rp.low = p.d_low; rp.lowPixels = p.d_realLowPixels; rp.lowCount[0] = p.realLowCount[0]; rp.lowCount[1] = p.realLowCount[1];
-        rp.nItems = uint32_t(p.items.size()); rp.nItemsLeft = p.nItemsLeft;
         rp.invSize = p.scalars.invSize;
-        rp.mapped = d_mapped; rp.binsOut = d_binsOut;
-        rp.ny = p.d_ny; rp.nyFlag = p.d_nyFlag; rp.nyBest = p.d_nyBest; rp.epoch = p.nyEpoch;
+        rp.mapped = d_mapped; rp.binsOut = d_binsOut; rp.binsIn = d_binsIn;
+        rp.ny = p.d_ny; rp.nyBest = p.d_nyBest;
         rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
-        { const char *e = std::getenv("SGZ_PAIR_TEST"); rp.pairTest = e ? uint32_t(std::atoi(e)) : 0u; }
         rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
@@ -654,6 +648,13 @@ sgz_status sgz_stage_logf(const float *d_x, float *d_y, size_t n, void *stream)
 {
     if (!d_x || !d_y) return fail(SGZ_EINVAL, "null buffer");
     SGZ_HIP(launchLogf(d_x, d_y, n, reinterpret_cast<hipStream_t>(stream)));
+    return SGZ_OK;
+}
+
+sgz_status sgz_stage_finish_pixel(const float *d_x, float *d_y, size_t n, void *stream)
+{
+    if (!d_x || !d_y) return fail(SGZ_EINVAL, "null buffer");
+    SGZ_HIP(launchFinishPixel(d_x, d_y, n, reinterpret_cast<hipStream_t>(stream)));
     return SGZ_OK;
 }
 

@@ -1,0 +1,83 @@
+// fft_scalar.hpp -- in-register radix-2 butterflies in the form the gfx950 VALU runs fastest: plain (not packed) fp32 FMAs.
+//
+// What the instructions cost on this chip (tools/ubench/valu*.hip, dit.hip): a wave64 v_add / v_mul / v_fmac / v_fmamk / v_fma occupies
+// its SIMD for 2.2-2.4 clocks when every register source is a VGPR or the constant is a LITERAL (VOP2 forms: v_fmamk_f32, v_fmac_f32,
+// v_mul_f32 take a 32-bit literal) or an inline constant; a v_pk_*_f32 costs 4.4 (exactly two plain ones), and any SGPR source
+// halves the rate.  So the cheapest butterfly is the one with the fewest plain operations, constants as literals:
+//     decimation in time,  p = a + w b,  q = a - w b = 2 a - p:
+//         p.re = fma(b.im, s, fma(b.re, c, a.re))    p.im = fma(b.re, -s, fma(b.im, c, a.im))    q = fma(2, a, -p)
+//     = 6 operations for a general twiddle (the decimation-in-frequency form, (a - b) w, needs 4 + 4), 4 for w = 1 and w = -i.
+// A 32-point transform is 46 trivial and 34 general butterflies = 388 operations against 456 for the packed DIF (228 packed).
+// hipcc selects v_fmamk / v_fmac with literal twiddles for exactly this source (checked in the ISA); trivial butterflies written on
+// (re, im) pairs become v_pk_add_f32, which costs the same as the two adds it replaces.
+//
+// Register convention (the same as difPacked in fft_common.hpp, so the kernels' exchanges do not change): input x[j] in c[BASE + j],
+// output X[k] in c[BASE + brev(k)].  DIT wants its input in bit-reversed order and delivers natural order; here the array is simply
+// read through brev() (compile-time indices of a fully unrolled loop: the permutation is free).
+#pragma once
+#include "fft_common.hpp"
+
+namespace sgz {
+
+// c * w for a per-lane w = (w.x, w.y): 4 plain operations
+__device__ __forceinline__ v2 cmulScalar(v2 c, float2 w)
+{
+    const float t0 = c.x * w.x, t1 = c.x * w.y;
+    return v2{__builtin_fmaf(-c.y, w.y, t0), __builtin_fmaf(c.y, w.x, t1)};
+}
+__device__ __forceinline__ float2 cmulScalar(float2 c, float2 w)
+{
+    const float t0 = c.x * w.x, t1 = c.x * w.y;
+    return float2{__builtin_fmaf(-c.y, w.y, t0), __builtin_fmaf(c.y, w.x, t1)};
+}
+// w * w: 3 operations
+__device__ __forceinline__ float2 csqScalar(float2 w)
+{
+    const float d = w.x * w.x;
+    return float2{__builtin_fmaf(-w.y, w.y, d), (w.x + w.x) * w.y};
+}
+
+// one DIT stage: butterflies of span 2^S / 2 on the logical array y[i] = c[BASE + brev(i)], twiddles W_{2^S}^j = W_32^{j 32 / 2^S}
+template <int LR, int S, int BASE, int NREG>
+__device__ __forceinline__ void ditStage(v2 (&c)[NREG])
+{
+    constexpr int n = 1 << LR, m = 1 << S, h = m / 2;
+#pragma unroll
+    for (int k0 = 0; k0 < n; k0 += m) {
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const int ia = BASE + brev(k0 + j, LR), ib = BASE + brev(k0 + j + h, LR);
+            const v2 a = c[ia], b = c[ib];
+            const int tw = j * (32 / m);                                // W_32^tw, tw in [0, 16)
+            if (tw == 0) { c[ia] = a + b; c[ib] = a - b; }
+            else if (tw == 8) { c[ia] = v2{a.x + b.y, a.y - b.x}; c[ib] = v2{a.x - b.y, a.y + b.x}; }      // w b = -i b
+            else if (tw < 8) {
+                const float cs = cos32(tw), sn = sin32(tw);             // w b = (cs b.re + sn b.im, cs b.im - sn b.re)
+                const float pr = __builtin_fmaf(b.y, sn, __builtin_fmaf(b.x, cs, a.x));
+                const float pi = __builtin_fmaf(b.x, -sn, __builtin_fmaf(b.y, cs, a.y));
+                c[ia] = v2{pr, pi};
+                c[ib] = v2{__builtin_fmaf(2.f, a.x, -pr), __builtin_fmaf(2.f, a.y, -pi)};
+            } else {
+                const float cs = cos32(tw - 8), sn = sin32(tw - 8);     // w = -i w', w' b = (tr, ti):  w b = (ti, -tr)
+                const float pr = __builtin_fmaf(b.x, -sn, __builtin_fmaf(b.y, cs, a.x));
+                const float pi = __builtin_fmaf(b.y, -sn, __builtin_fmaf(b.x, -cs, a.y));
+                c[ia] = v2{pr, pi};
+                c[ib] = v2{__builtin_fmaf(2.f, a.x, -pr), __builtin_fmaf(2.f, a.y, -pi)};
+            }
+        }
+    }
+}
+
+// 2^LR-point transform of c[BASE .. BASE + 2^LR): x[j] in c[BASE + j] -> X[k] in c[BASE + brev(k, LR)].  FIRST: the first stage to run
+// (a caller that has already combined the pairs (j, j + n/2) -- the window-fused load of spectrum_real.hip -- starts at 2)
+template <int LR, int BASE, int NREG, int FIRST = 1>
+__device__ __forceinline__ void ditScalar(v2 (&c)[NREG])
+{
+    if constexpr (FIRST <= 1) ditStage<LR, 1, BASE>(c);
+    if constexpr (FIRST <= 2 && LR >= 2) ditStage<LR, 2, BASE>(c);
+    if constexpr (LR >= 3) ditStage<LR, 3, BASE>(c);
+    if constexpr (LR >= 4) ditStage<LR, 4, BASE>(c);
+    if constexpr (LR >= 5) ditStage<LR, 5, BASE>(c);
+}
+
+}  // namespace sgz

@@ -57,15 +57,19 @@ struct RealParams {
     const float2 *tw1;        // [3 + R1/4 - 1][1024]  pass-1 twiddles W_{N/2}^{c q}
     const float2 *tw2;        // [10][32]  (the whole-frame kernels' pass-2 table)
     const float2 *twPost;     // [R1 * 32]  W_N^{kc}
-    const PixelRec *recs; const float *weights; const MaxItem *items;
-    uint32_t nItems, nItemsLeft;
+    const PixelRec *recs; const float *weights;
+    // the chunk-scan pixel map (chunk_map.hpp; plan.cpp buildChunkMap): per side, [T] end bits, [T] slot bases, [P] records
+    const uint32_t *chunkEnds; const uint32_t *chunkReBase; const uint32_t *chunkRec; const float *weights12;
+    uint32_t chunkSlots[2];
     float invSize;
     float *mapped;            // [frames][C][2][P] or null
     float *binsOut;           // test hook: [frames][C][N+1] csf magnitudes, or null
-    // csf[N/2] = |X_L[M] + i X_R[M]| / 2 needs both channels.  Nobody waits for it: a workgroup maps with 0 there, publishes its Nyquist bin
-    // (ny), the winning squares of the pixels whose arg-max run ends on csf[N/2] (nyBest, [unit][64]) and then its epoch flag; whichever
-    // of the two channels finishes second finds the other's flag set and settles those pixels for both sides.
-    float *ny; uint32_t *nyFlag; float *nyBest; uint32_t epoch;
+    const float *binsIn;      // test hook (pairs only): skip the transform, map from these csf magnitudes [frames][C][N+1]
+    // csf[N/2] = |X_L[M] + i X_R[M]| / 2 needs both channels.  Nobody waits for it: a workgroup maps with 0 there and leaves its Nyquist bin
+    // (ny, [unit]) and the winning squares of the pixels whose arg-max run ends on csf[N/2] (nyBest, [unit][64]) in HBM; realLateKernel,
+    // launched behind the channel workgroups, settles those pixels for both sides.
+    float *ny; float *nyBest;
+    uint32_t lateInNext;      // 1: the caller's next kernel applies the late pixels itself (no realLateKernel launch)
     uint32_t fixFrom[2];      // per side: pixels [fixFrom, P) have runs that end on csf[N/2]
     // Interpolated pixels whose tap window reaches over bin 0 into the OTHER channel's half of csf (the window's periodic indexing:
     // ..., csf[N-1], csf[N], csf[0], csf[1], ...).  Settled like csf[N/2]: both channels publish their kLowBins lowest csf entries
@@ -75,10 +79,6 @@ struct RealParams {
     const PixelRec *recsFull; // the unmodified records
     const uint32_t *lowPixels; // [lowCount[0] + lowCount[1]] pixel indices, left side's first
     uint32_t lowCount[2];
-    // test hook for the rare paths of the pair exchange (tests/test_gpu_spectrum.py, env SGZ_PAIR_TEST): 0 = off; 1 = every workgroup's first
-    // look at the partner's flag1 says "not published" (fallback: publish own state, raise flag2, look again); 2 = the left channel
-    // gives up unconditionally and the right channel waits for its flag2 and settles both sides
-    uint32_t pairTest;
     unsigned long long *phaseClock; uint32_t clkUnit;   // -DSGZ_DEBUG builds: shader clocks of workgroup `clkUnit` at the phase boundaries
     uint32_t roundSize;       // workgroups that run concurrently, for the XCD-aware order
 };
@@ -142,7 +142,8 @@ hipError_t launchDecayApplyCarry(const DecayParams &prm, const float *carry, hip
 // SpectrumChannels::Phase: sequential-in-time K_B (the cancellation smoother is a linear recurrence: no exact chunk fold);
 // work: [frames][C][P] floats for the main graph's dB values
 hipError_t launchDecayPhase(const DecayParams &prm, float *work, hipStream_t stream);
-hipError_t launchLogf(const float *x, float *y, size_t n, hipStream_t stream);   // y = std::log(x) as K_B's dB map computes it (x > 0)
+hipError_t launchLogf(const float *x, float *y, size_t n, hipStream_t stream);
+hipError_t launchFinishPixel(const float *x, float *y, size_t n, hipStream_t stream);   // y = sqrt(x * x + 0) as K_A's pixels compute it   // y = std::log(x) as K_B's dB map computes it (x > 0)
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
 

@@ -396,6 +396,76 @@ static void buildTwiddles(Plan &p)
         }
 }
 
+// Tables of the chunk-scan pixel map (chunk_map.hpp) for the channel-split kernels: `recs` = the records those kernels map
+// (recsReal when some pixels are settled elsewhere), nSides = 2 (pairs) or 1 (mono).  Returns false when the map does not apply
+// (overlapping runs, a tap window that does not fit kTapFloats: neither occurs with the reference's mapping, but the kernel must not
+// be handed tables it would misread).
+static bool buildChunkMap(Plan &p, const std::vector<PixelRec> &recs, int nSides)
+{
+    const long N = long(p.N), M = N / 2;
+    const uint32_t T = uint32_t(M / 32);
+    p.chunkEnds.assign(size_t(nSides) * T, 0u);
+    p.chunkReBase.assign(size_t(nSides) * T, 0u);
+    p.chunkRec.assign(size_t(nSides) * p.P * 2, 0u);
+    p.weights12.assign(size_t(kTapFloats), 0.0f);                      // row 0: what the pixels without taps read
+    for (int side = 0; side < nSides; ++side) {
+        const long off = side ? M : 0;
+        std::vector<uint8_t> end(size_t(M), 0), owned(size_t(M), 0);
+        struct Tile { long lo, hi; uint32_t x; };
+        std::vector<Tile> tiles;
+        for (uint32_t x = 0; x < p.P; ++x) {
+            const PixelRec &rec = recs[size_t(side) * p.P + x];
+            uint32_t *cr = &p.chunkRec[(size_t(side) * p.P + x) * 2];
+            if (rec.kind == 0) {
+                const long i0 = long(rec.a) - off;
+                if (i0 < 0 || i0 + rec.b - 1 > M || rec.b > kMaxTaps) return false;
+                cr[0] = uint32_t(p.weights12.size() / kTapFloats);
+                cr[1] = uint32_t(chunkPos(int(i0)));
+                p.weights12.insert(p.weights12.end(), size_t(kTapFloats), 0.0f);
+                float *w = &p.weights12[p.weights12.size() - kTapFloats];
+                for (int t = 0; t < rec.b; ++t) {
+                    const int d = chunkPos(int(i0 + t)) - chunkPos(int(i0));
+                    if (d < 0 || d >= kTapFloats) return false;
+                    w[d] = p.weights[size_t(rec.c) + size_t(t)];
+                }
+            } else if (rec.kind & 1) {
+                // offsets [a, a + b): csf index = offset (left) or N - offset (right); side-local entry i = index - off
+                long lo = side ? M - (long(rec.a) + rec.b - 1) : long(rec.a);
+                long hi = side ? M - long(rec.a) : long(rec.a) + rec.b - 1;
+                if (lo < 0 || hi > M) return false;
+                uint32_t flags = 0;
+                if (hi == M) { flags |= kChunkPlusM; hi = M - 1; }
+                if (lo > hi) { cr[0] = 0; cr[1] = flags | kChunkNoScan; }
+                else if (lo == hi) { cr[0] = uint32_t(chunkPos(int(lo))); cr[1] = flags | kChunkDirect; }
+                else {
+                    for (long i = lo; i <= hi; ++i) { if (owned[size_t(i)]) return false; owned[size_t(i)] = 1; }
+                    tiles.push_back(Tile{lo, hi, x});
+                    cr[1] = flags;                                       // completed below
+                }
+            }
+        }
+        for (const Tile &t : tiles) {
+            end[size_t(t.hi)] = 1;
+            if (t.lo >= 1 && !owned[size_t(t.lo - 1)]) end[size_t(t.lo - 1)] = 1;      // an unowned entry right before a tile: restart the maximum behind it
+        }
+        std::vector<uint32_t> rank(size_t(M) + 1, 0);
+        for (long i = 0; i < M; ++i) rank[size_t(i) + 1] = rank[size_t(i)] + end[size_t(i)];
+        if (rank[size_t(M)] > 0xFFFFu) return false;
+        p.chunkSlots[side] = rank[size_t(M)];
+        for (uint32_t t = 0; t < T; ++t) p.chunkReBase[size_t(side) * T + t] = rank[size_t(t) * 32];
+        for (long i = 0; i < M; ++i)
+            if (end[size_t(i)]) p.chunkEnds[size_t(side) * T + size_t(i >> 5)] |= 1u << (i & 31);
+        for (const Tile &t : tiles) {
+            uint32_t *cr = &p.chunkRec[(size_t(side) * p.P + t.x) * 2];
+            const uint32_t c0 = uint32_t(t.lo >> 5), nC = uint32_t(t.hi >> 5) - c0;
+            if (nC > 0xFFFFu) return false;
+            cr[0] = rank[size_t(t.hi)] | (c0 << 16);
+            cr[1] |= nC;
+        }
+    }
+    return true;
+}
+
 sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
 {
     if (cfg.window_size < 1 || cfg.axis_points < 2 || cfg.num_pairs < 1 || cfg.hop < 1 || !(cfg.sample_rate >= 1)) {
@@ -718,6 +788,16 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                 p.recsReal[size_t(side) * p.P + x] = PixelRec{2, 0, 0, 0};               // neither interpolated nor arg-max: nothing is written
             }
         }
+    }
+    p.chunkEnds.clear(); p.chunkReBase.clear(); p.chunkRec.clear(); p.weights12.clear(); p.chunkSlots[0] = p.chunkSlots[1] = 0;
+    if (p.realSplit || p.realMono) {
+        // the pixel map of these kernels (chunk_map.hpp) and its LDS budget: magnitudes + max(pass-2 twiddle table, tile and chunk maxima)
+        const bool ok = buildChunkMap(p, p.recsReal.empty() ? p.recs : p.recsReal, p.realSplit ? 2 : 1);
+        const size_t Mh = p.N / 2, Tt = Mh / 32;
+        const size_t sFloats = size_t(chunkPos(int(Mh))) + 32;
+        const size_t extra = std::max<size_t>(size_t(std::max(p.chunkSlots[0], p.chunkSlots[1])) + 1 + Tt, p.N >= 32768 ? 2048 : 0);
+        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - 1024;    // (1 KB of static LDS)
+        if (!ok || (sFloats + extra + (p.realMono ? 2 * 16 : 0)) * 4 > budget) { p.realSplit = false; p.realMono = false; p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0; }
     }
     if (p.realSplit || p.realMono) {
         const double kTwoPi = 6.28318530717958647692;

@@ -30,6 +30,19 @@ struct MaxItem {
     uint32_t win;       // w | lo << 16 | hi << 20   (one word per piece: every workgroup of a launch reads the whole list)
 };
 
+// Chunk-scan pixel map (chunk_map.hpp; tables from plan.cpp buildChunkMap).  A side's magnitudes S[i], i = 0 .. M (left: csf[i],
+// right: csf[M + i]) live in LDS at float position chunkPos(i): two pad floats after every 32 entries, so that a thread's chunk of 32
+// is 8-byte aligned (ds_read_b64) and both the strided stores of the transform and the chunk reads are free of bank conflicts.
+constexpr int chunkPos(int i) { return i + ((i >> 5) << 1); }
+constexpr int kTapFloats = kMaxTaps + 2;          // a tap window as contiguous floats: <= 10 taps + the 2 pad slots it may step over
+// ChunkRec = two words per (side, pixel):
+//   interpolated pixel:  [0] = row of its weights in weights12,  [1] = float position of its first tap
+//   arg-max pixel:       [1] = chunks before the last one that its run covers | flags << 16;
+//                        [0] = index of the run's tile maximum | first of those chunks << 16   (kChunkDirect: float position of the run's one entry)
+constexpr uint32_t kChunkDirect = 1u << 16;       // the run has one entry inside the chunks: read it
+constexpr uint32_t kChunkPlusM = 1u << 17;        // the run includes entry M (csf[N/2] of the left side / a mono signal), which no chunk holds
+constexpr uint32_t kChunkNoScan = 1u << 18;       // the run has no entry inside the chunks
+
 // Scalars the kernels need (all derived on the host exactly as the reference derives them).
 struct DeviceScalars {
     float invSize;        // windowKernelScale / (W/2), TransformDSP.inl:540
@@ -83,6 +96,14 @@ struct Plan {
     std::vector<float> winPhaseT;       // fused whole-frame kernel, same idea: (cos, sin) of 2 pi t / N, t < R^2
     std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
     std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
+    // Chunk-scan pixel map of the channel-split kernels (chunk_map.hpp, built by buildChunkMap): a side's M magnitudes are cut into
+    // T chunks of 32 consecutive entries, one per thread; the arg-max runs of >= 2 entries ("tiles") are segments of a segmented
+    // running maximum inside the chunks.
+    std::vector<uint32_t> chunkEnds;    // [side][T]: bit j = the thread's chunk element j is the last entry of a tile (or sits right before one)
+    std::vector<uint32_t> chunkReBase;  // [side][T]: number of such entries below the thread's chunk = index of its first tile maximum
+    std::vector<uint32_t> chunkRec;     // [side][P][2]: per pixel, see ChunkRec in chunk_map.hpp
+    std::vector<float> weights12;       // [interpolated pixel][12]: its taps as 12 contiguous floats of the padded array (0 on pad slots and behind the last tap)
+    uint32_t chunkSlots[2] = {0, 0};    // tile maxima per side
     DeviceScalars scalars{};
 
     // device mirrors (owned)
@@ -108,7 +129,8 @@ struct Plan {
     void *hostStream = nullptr;                           // hipStream_t / hipEvent_t (this header is also compiled as plain C++)
     void *hostEv[4] = {nullptr, nullptr, nullptr, nullptr};
     float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr, *d_winPhaseT = nullptr;
-    float *d_ny = nullptr; uint32_t *d_nyFlag = nullptr; float *d_nyBest = nullptr; size_t nyCap = 0; uint32_t nyEpoch = 0;   // channel-split path: Nyquist exchange of a frame's two workgroups
+    uint32_t *d_chunkEnds = nullptr, *d_chunkReBase = nullptr, *d_chunkRec = nullptr; float *d_weights12 = nullptr;
+    float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;
 

@@ -22,14 +22,16 @@
 //   map     MapPixelsBalanced (stft_body.hpp) on this side's records and arg-max pieces.
 // csf[N/2] is the one entry that mixes the channels: the reference halves the PACKED bin there, |X_L[M] + i X_R[M]| / 2
 // (TransformDSP.inl:863).  It is the last offset of either side's arg-max scan and is compared with a strict >, so nobody waits for
-// it: a workgroup maps with 0 in its place, publishes its own Nyquist bin and the winning squares of the (top) pixels whose run ends
-// there, then raises its epoch flag; the channel that finishes second sees the other's flag and settles those pixels for both
-// sides (store own flag, load the partner's, both sequentially consistent: at least one of the two sees the other).
+// it: a workgroup maps with 0 in its place and leaves its own Nyquist bin and the winning squares of the (top) pixels whose run ends
+// there in HBM; realLateKernel, behind the launch, settles those pixels for both sides.
 // Everything else the path needs (mono modes, Complex, Phase, zero-padded windows, views whose filter taps wrap around csf) stays
 // on the whole-frame kernels; plan.cpp decides (Plan::realSplit).
 #include <algorithm>
 
-#include "stft_body.hpp"
+#include "chunk_map.hpp"
+#ifndef SGZ_ABL
+#define SGZ_ABL 0      // (ablation builds for measurements only: tools/ablate_builds.sh)
+#endif
 
 #ifdef SGZ_DEBUG
 #define RCLK(slot)                                                                                                     \
@@ -42,15 +44,17 @@
 
 namespace sgz {
 
-// csf index -> LDS float index of this side's array: left holds csf[0 .. M], right csf[M .. N], both at positions 0 .. M
+// csf index -> LDS float index of this side's array: left holds csf[0 .. M], right csf[M .. N], both as entries 0 .. M at chunkPos()
 struct ChannelIndex {
     int n, off;
-    static constexpr bool kSkipEmpty = true;
-    static constexpr bool kLinearTaps = false;
     __device__ __forceinline__ int size() const { return n; }
-    __device__ __forceinline__ int operator()(int k) const { const int i = k - off; return i + (i >> 5); }
+    __device__ __forceinline__ int operator()(int k) const { return chunkPos(k - off); }
     __device__ __forceinline__ bool holds(int k) const { return k >= off && k <= off + n / 2; }
 };
+
+// floats of a side's magnitude array: entries 0 .. M at chunkPos(), then 16 zeroed floats (a tap window is read as kTapFloats
+// contiguous floats from its first entry)
+constexpr int realXFloats(int M) { return (chunkPos(M) + 1 + 16 + 1) & ~1; }
 
 // |X[k]| of the real-input transform from a = Z[k], b = Z[M - k] and w = W_N^k = (cos, -sin):
 //   2 X = (a + conj b) - i w (a - conj b)
@@ -74,6 +78,52 @@ __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
     }
 }
 
+// Everything behind the barrier that completes a side's magnitudes in LDS: the test hook that writes them out, the pair exchange,
+// the pixel map (chunk_map.hpp) and the settlement of the pixels that need both channels.  Shared by the transform kernel and by
+// realMapFromBinsKernel (sgz_stage_map_from_bins: the same code maps injected bins, so "the mapping is bit-exact given the bins"
+// is tested on the very functions the bench kernel runs).
+template <int LR1, int MIX>
+__device__ __forceinline__ void realMapSettle(const RealParams &prm, float *lds, const int tid, const int side, const long task, const long self,
+                                              const ChunkTables &tb, ChunkMap<(1 << (LR1 + 5))> &mapper, float *re, float *ce, float *spec)
+{
+    constexpr int R = 32, R1 = 1 << LR1, T = R1 * R, M = R1 * R * R, N = 2 * M;
+    constexpr bool MONO = MIX == 1 || MIX == 3;
+    const ChannelIndex at{N, side ? M : 0};
+    [[maybe_unused]] const long unit = MONO ? task : self;                   // (debug clocks)
+    if (prm.binsOut) {                                                      // test hook: this side's half of csf, csf order
+        // (csf[N/2] -- the left side's last entry, the right side's first -- is written by the settling workgroup alone)
+        float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
+        for (int i = tid; i <= M; i += T)
+            if (MONO || i != (side ? 0 : M)) dst[i] = lds[chunkPos(i)];
+    }
+    // ---- What needs BOTH channels is left to realLateKernel (below), which runs behind this launch: csf[N/2] = |X_L[M] + i X_R[M]| / 2
+    // (TransformDSP.inl:863) with the pixels whose arg-max run ends on it, and the pixels whose tap window reaches over bin 0.  This
+    // workgroup only leaves what that kernel needs in HBM -- its Nyquist bin (ny, stored by the transform), its lowest bins, and (from the
+    // map) the winning squares of its top pixels, whose values so far ignore csf[N/2] (0 in its place can never win: strict >).
+    // (Until round 3 the two channel workgroups of a frame settled these pixels between themselves with flags in fine-grained memory:
+    // three dependent memory round trips at the end of every workgroup, 1.5 us of a 37 us launch, tools/ablate_builds.sh.)
+    if (!MONO && (prm.lowCount[0] + prm.lowCount[1]) && tid < kLowBins) prm.low[size_t(self) * kLowBins + tid] = lds[at(side ? N - tid : tid)];
+    RCLK(8);
+#if SGZ_ABL != 5
+    mapper.run(tb, at, lds, re, ce, prm.invSize, tid);
+#endif
+    RCLK(9);
+    if (MONO) {
+        // the pixels whose tap windows leave the magnitudes (wrap below bin 0: csf[N - j] = conj X[j], csf[N] = 0; or reach csf[N/2 ..]):
+        // complex sums in the reference's order (complex_dc.hpp), from entries written before the last barrier; the mapping skipped them
+        if (prm.mapped && prm.lowCount[0]) {
+            float *out = prm.mapped + size_t(task) * prm.P;
+            for (uint32_t i = tid; i < prm.lowCount[0]; i += T) {
+                const uint32_t x = prm.lowPixels[i];
+                out[x] = complexDcPixel(prm.recsFull[x], prm.weights, prm.invSize, N, prm.mode,
+                                        [&](int k) { return k >= N ? 0.f : lds[chunkPos(k)]; },
+                                        [&](int sl) { return make_float2(spec[2 * sl], spec[2 * sl + 1]); });
+            }
+        }
+        return;
+    }
+}
+
 // MONO: SpectrumChannels Left / Right / Merge / Side -- ONE real signal per (frame, pair) (the reference transforms it as a complex frame
 // with a zero imaginary part, TransformDSP.inl:59-135): one workgroup per task, no pair exchange.  csf[0] = |X[0]| / 2 and
 // csf[N/2] = X[N/2] / 2 (:547-552; the latter stays signed: the reference leaves it complex, and X[N/2] of a real signal is real).
@@ -83,10 +133,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     constexpr int LR = 5, R = 32, R1 = 1 << LR1, T = R1 * R, RR = R * R, M = R1 * RR, N = 2 * M, U = R / R1;
     constexpr bool MONO = MIX == 1 || MIX == 3;
     constexpr bool mixed = MIX >= 2;                    // the signal is (l +- r) / 2: compile-time, the second channel's loads cost registers
-    constexpr int PADSTRIDE = T + (T >> 5);             // padded distance between k and k + T
+    constexpr int PADSTRIDE = chunkPos(T);              // padded distance between k and k + T
     constexpr int TILE = R * (R + 1);
-    constexpr int XFLOATS = ((M + 1) + ((M + 1) >> 5) + 2) & ~1;      // this side's |X| array (padded) -- the winners follow it
-    constexpr int SCRATCH = XFLOATS;                    // column 0's 2R floats live where the winners will be written later
+    constexpr int XFLOATS = realXFloats(M);             // this side's |X| array (padded) -- the map's tile and chunk maxima follow it
+    constexpr int SCRATCH = XFLOATS;                    // column 0's 2R floats live where the tile maxima will be written later
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
@@ -109,27 +159,25 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     if (prm.C > 1) { const long pr = task / prm.frames, fr = task - pr * prm.frames; task = fr * prm.C + pr; }
     const long frame = task / prm.C;
     const int pair = int(task - frame * prm.C);
-    const long partner = (task << 1) | (side ^ 1);      // ny / flag / best slots are indexed by task * 2 + side
-    const long self = (task << 1) | side;
+    const long self = (task << 1) | side;               // ny / low / nyBest slots are indexed by task * 2 + side
 
-    __shared__ float sLate[128];                                            // own late pixels: winning squares [0, 64), pixel values [64, 128)
-    __shared__ float sNyOwn;
-    // map tables of this side
-    const uint32_t nLeft = MONO ? prm.nItems : prm.nItemsLeft, nSide = side ? prm.nItems - nLeft : nLeft;
-    const MapView view{prm.items + (side ? nLeft : 0u), nSide, side ? 0u : nSide, side ? nLeft : 0u, prm.recs + side * prm.P, int(prm.P),
-                       side ? 0 : int(prm.P), prm.mapped ? prm.mapped + (size_t(task) * (MONO ? 1 : 2) + side) * prm.P : nullptr,
-                       MONO ? nullptr : sLate, int(prm.fixFrom[side])};
-    const ChannelIndex at{N, side ? M : 0};
-    float *win = lds + XFLOATS;
-    // mono modes: the kSpecBins csf entries the reference leaves complex (complex_dc.hpp), behind the winners; written during the
-    // recombination (nothing else uses the area), read by the pixels of prm.lowPixels after the mapping
-    float *spec = win + (prm.nItems > 72u ? prm.nItems : 72u);
-    MapPixelsBalanced<5, T, ChannelIndex> mapper;
-    StftParams sp{};
-    sp.weights = prm.weights; sp.invSize = prm.invSize;
+    // map tables of this side (chunk_map.hpp)
+    const uint32_t maxSlots = prm.chunkSlots[0] > prm.chunkSlots[1] ? prm.chunkSlots[0] : prm.chunkSlots[1];
+    const ChunkTables tb{prm.chunkEnds + side * T, prm.chunkReBase + side * T,
+                         reinterpret_cast<const uint2 *>(prm.chunkRec) + size_t(side) * prm.P, prm.recs + size_t(side) * prm.P, prm.weights12,
+                         prm.mapped ? prm.mapped + (size_t(task) * (MONO ? 1 : 2) + side) * prm.P : nullptr,
+                         MONO ? nullptr : prm.nyBest + size_t(self) * 64, int(prm.fixFrom[side]), int(prm.P), side != 0,
 #ifdef SGZ_DEBUG
-    sp.phaseClock = prm.phaseClock; sp.ablate = prm.clkUnit << 16;
+                         (prm.phaseClock && unit == long(prm.clkUnit)) ? prm.phaseClock : nullptr};
+#else
+                         nullptr};
 #endif
+    const ChannelIndex at{N, side ? M : 0};
+    float *re = lds + XFLOATS, *ce = re + maxSlots + 1;
+    // mono modes: the kSpecBins csf entries the reference leaves complex (complex_dc.hpp), behind the maxima; written during the
+    // recombination (nothing else uses the area), read by the pixels of prm.lowPixels after the mapping
+    float *spec = ce + T;
+    ChunkMap<T> mapper;
 
     RCLK(0);
     v2 c[R];
@@ -163,7 +211,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (WCOS) {
+        if (WCOS && SGZ_ABL != 3) {
             // w[n] = p0 + p1 cos(theta_n), theta_n = 2 pi n / N, n = 2 (col + R^2 j) + e: theta = phi(col, e) + 2 pi j / R1 -- the phase of the
             // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
 #pragma unroll
@@ -179,7 +227,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                     c[i] = v2{c[i].x * (prm.winP0 + prm.winP1 * ce), c[i].y * (prm.winP0 + prm.winP1 * co)};
                 }
             }
-        } else {
+        } else if (SGZ_ABL != 3) {
             // the window in batches of B pairs, two batches in flight
             constexpr int B = LR1 >= 4 ? 4 : 8;
             float2 wa[B], wb[B];
@@ -209,7 +257,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     __builtin_amdgcn_sched_barrier(0);
     RCLK(13);
     // -------------------------------------------------------------------------- pass 1: radix R1 per column, times W_M^{c q1}
+#if SGZ_ABL != 7
     pass1Columns<R, R1, U>(c);
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         constexpr int NB = R1 / 4 - 1;
@@ -237,7 +287,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     RCLK(1);
     // -------------------------------------------------------------------------- exchange 1: two rounds of R1 x 512 complex values
-    {
+    if (SGZ_ABL != 9) {
         v2 *lds2 = reinterpret_cast<v2 *>(lds);
         auto writeRound = [&](int r) {
 #pragma unroll
@@ -267,15 +317,19 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ldsBarrier();                                                        // every wave has read exchange 1: the tiles may overwrite it
     RCLK(2);
     // -------------------------------------------------------------------------- pass 2 (c_lo = ix): radix R over c_hi
+#if SGZ_ABL != 8
     difPacked<R, R, 0>(c);
+#endif
     {
         TwFactors<LR> tw;
         tw.load(prm.tw2, ix, R);
+#if SGZ_ABL != 2
         tw.apply(c);
+#endif
     }
     RCLK(3);
     // -------------------------------------------------------------------------- exchange 2: wave-local R x R transposes
-    {
+    if (SGZ_ABL != 6) {
         const int tile = group * TILE;
 #pragma unroll
         for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].x;
@@ -297,7 +351,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(4);
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
     const float2 wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
+#if SGZ_ABL != 1
     difPacked<R, R, 0>(c);
+#endif
     RCLK(5);
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
     const int kc = q1 + R1 * ix;
@@ -307,9 +363,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             lds[SCRATCH + 2 * m3] = c[brev(m3, LR)].x;
             lds[SCRATCH + 2 * m3 + 1] = c[brev(m3, LR)].y;
         }
-        // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] is settled by whichever channel finishes second (below)
-        sNyOwn = c[0].x - c[0].y;
-        if (!MONO) __hip_atomic_store(prm.ny + self, sNyOwn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] needs both channels' (realLateKernel)
+        if (!MONO) prm.ny[self] = c[0].x - c[0].y;
     }
     // Column 0 (k = T m3, all in thread 0) pairs m3 with R - m3 inside one thread and holds DC / Nyquist: lanes 0 .. R/2 of wave 0 redo it
     // from thread 0's scratch copy right away (the scratch is not part of the tiles), keep the values and store them after the
@@ -355,8 +410,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const float ex = a.x + b.x, ey = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
             const float ox = w.x * dy + w.y * dx, oy = w.y * dy - w.x * dx;      // -i w (dx + i dy)
             const float pr = ex + ox, pi = ey + oy, mr = ex - ox, mi = ey - oy;
+#if SGZ_ABL == 4
+            magA[m3] = a.x + b.x; magB[m3] = a.y + b.y + w.x;
+#else
             magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
             magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(mr * mr + mi * mi);
+#endif
             if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
                 // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
                 // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
@@ -368,12 +427,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(6);
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
     if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
-    if (nSide) mapper.prefetchTables(view, tid);
+    mapper.prefetch(tb, tid);
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
         // (two base addresses and compile-time offsets: a run-time stride costs a 64-bit multiply-add per store)
-        const int up = kc + (kc >> 5), down = (M - kc) + ((M - kc) >> 5);
+        const int up = chunkPos(kc), down = chunkPos(M - kc);
         int lowest = down - (R / 2 - 1) * PADSTRIDE;
         asm volatile("" : "+v"(lowest));                                    // (opaque: or the offsets are folded back into subtractions from `down`)
         float *pu = lds + up, *pd = lds + lowest;
@@ -386,7 +445,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         }
     }
     if (tid <= R / 2) {                                                     // column 0, after this wave's own stores (one wave's LDS operations execute in order)
-        auto put = [&](int k, float v) { const int i = side ? M - k : k; lds[i + (i >> 5)] = v; };
+        auto put = [&](int k, float v) { const int i = side ? M - k : k; lds[chunkPos(i)] = v; };
         if (tid >= 1) {
             put(T * tid, fixA);
             if (tid != R / 2) put(T * (R - tid), fixB);
@@ -396,137 +455,98 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             put(M, MONO ? fixB : 0.f);                                      // pairs: csf[N/2] is settled late, 0 can never win meanwhile (strict >)
         }
     }
-    if (nSide && prm.mapped) mapper.prefetchWeights(sp, tid, nSide);
+    // the two pad floats behind this thread's chunk and the floats behind entry M: tap windows read over them with weight 0
+    *reinterpret_cast<float2 *>(lds + chunkPos(32 * tid) + 32) = float2{0.f, 0.f};
+    if (tid < 16) lds[chunkPos(M) + 1 + tid] = 0.f;
     ldsBarrier();
     RCLK(7);
-    if (prm.binsOut) {                                                      // test hook: this side's half of csf, csf order
-        // (csf[N/2] -- the left side's last entry, the right side's first -- is written by the settling workgroup alone)
-        float *dst = prm.binsOut + size_t(task) * (N + 1) + (side ? M : 0);
-        for (int i = tid; i <= M; i += T)
-            if (MONO || i != (side ? 0 : M)) dst[i] = lds[i + (i >> 5)];
-    }
-    // ---- The pair exchange.  csf[N/2] = | X_L[M] + i X_R[M] | / 2 (TransformDSP.inl:863) with the pixels whose arg-max run ends on it (the
-    // last offset of either side's scan, compared with a strict >), and the pixels whose tap window reaches over bin 0, need BOTH channels.
-    // Nobody waits and nobody maintains caches: the exchanged arrays are fine-grained (coherent across the XCDs' L2s), accessed with
-    // relaxed agent-scope atomics only, and ordered by the hardware's completion counters (a sequentially consistent agent-scope store /
-    // load pair writes back and invalidates the XCD's whole L2: it cost 19 % of this kernel at N = 65536, 23 % at N = 32768).
-    //   early  (here, before the mapping): wave 0 publishes this channel's Nyquist bin and lowest bins and, once those stores are
-    //          acknowledged, raises flag1.
-    //   end    if the partner's flag1 is up -- the usual case: the two workgroups run side by side -- this workgroup settles ITS OWN late
-    //          pixels from the partner's published bins and is done.
-    //          If not, it publishes the state of its late pixels, raises flag2 ("mine are unsettled"), waits for that store's
-    //          acknowledgement and looks at flag1 once more: up now -> it settles itself after all; still down -> the partner, whose
-    //          flag1 store then completes after this look, will find flag2 up at its own end (it waits for its flag1's acknowledgement
-    //          before looking) and settles this side too.  Both may do it: identical values.  Late pixels have no other writer.
-    if (!MONO && tid < 64) {
-        if (prm.lowCount[0] + prm.lowCount[1]) {
-            if (tid < kLowBins) {
-                const int k = side ? N - tid : tid;
-                __hip_atomic_store(prm.low + size_t(self) * kLowBins + tid, lds[at(k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // wave 0 wrote ny and the low bins: acknowledged
-        if (tid == 0) __hip_atomic_store(prm.nyFlag + 2 * self, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (prm.mapped && nSide) mapper.run(sp, view, at, lds, win, tid, unit);
-    RCLK(9);
-    if (MONO) {
-        // the pixels whose tap windows leave the magnitudes (wrap below bin 0: csf[N - j] = conj X[j], csf[N] = 0; or reach csf[N/2 ..]):
-        // complex sums in the reference's order (complex_dc.hpp), from entries written before the last barrier; the mapping skipped them
-        if (prm.mapped && prm.lowCount[0]) {
-            float *out = prm.mapped + size_t(task) * prm.P;
-            for (uint32_t i = tid; i < prm.lowCount[0]; i += T) {
-                const uint32_t x = prm.lowPixels[i];
-                out[x] = complexDcPixel(prm.recsFull[x], prm.weights, prm.invSize, N, prm.mode,
-                                        [&](int k) { return k >= N ? 0.f : lds[k + (k >> 5)]; },
-                                        [&](int sl) { return make_float2(spec[2 * sl], spec[2 * sl + 1]); });
-            }
-        }
-        return;
-    }
-    __shared__ int sHave, sPartnerGaveUp;
-    __syncthreads();                                                        // sLate is complete
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // flag1's store is at the coherence point (see above)
-        sHave = __hip_atomic_load(prm.nyFlag + 2 * partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
-        if (prm.pairTest == 2u && side == 1) {                              // (test hook: the left channel, dispatched first, is giving up)
-            while (__hip_atomic_load(prm.nyFlag + 2 * partner + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != prm.epoch) __builtin_amdgcn_s_sleep(8);
-            sHave = 1;
-        }
-        sPartnerGaveUp = __hip_atomic_load(prm.nyFlag + 2 * partner + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
-        if (prm.pairTest == 1u || (prm.pairTest == 2u && side == 0)) sHave = 0;
-    }
+    realMapSettle<LR1, MIX>(prm, lds, tid, side, task, self, tb, mapper, re, ce, spec);
+}
+
+// Test hook (sgz_stage_map_from_bins on a channel-split plan): csf magnitudes [task][N + 1] come from HBM instead of the transform;
+// everything behind them -- pair exchange, chunk-scan map, late-pixel settlement -- is realMapSettle, the code the transform kernel runs.
+// csf[N/2] (the left side's last entry, the right side's first) is published as this channel's "Nyquist bin" and taken as it is by
+// realLateKernel (prm.binsIn != null switches the |X_L[M] + i X_R[M]| / 2 evaluation off there).  Pairs only.
+template <int LR1>
+__global__ void __launch_bounds__(1 << (LR1 + 5)) realMapFromBinsKernel(const RealParams prm)
+{
+    constexpr int R = 32, R1 = 1 << LR1, T = R1 * R, M = R1 * R * R, N = 2 * M;
+    constexpr int XFLOATS = realXFloats(M);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const long unit = blockIdx.x;
+    const int side = int(unit & 1);
+    const long task = unit >> 1;
+    const long self = (task << 1) | side;
+    const uint32_t maxSlots = prm.chunkSlots[0] > prm.chunkSlots[1] ? prm.chunkSlots[0] : prm.chunkSlots[1];
+    const ChunkTables tb{prm.chunkEnds + side * T, prm.chunkReBase + side * T,
+                         reinterpret_cast<const uint2 *>(prm.chunkRec) + size_t(side) * prm.P, prm.recs + size_t(side) * prm.P, prm.weights12,
+                         prm.mapped ? prm.mapped + (size_t(task) * 2 + side) * prm.P : nullptr, prm.nyBest + size_t(self) * 64, int(prm.fixFrom[side]), int(prm.P), side != 0, nullptr};
+    float *re = lds + XFLOATS, *ce = re + maxSlots + 1;
+    ChunkMap<T> mapper;
+    mapper.prefetch(tb, tid);
+    const float *src = prm.binsIn + size_t(task) * (N + 1) + (side ? M : 0);
+    for (int i = tid; i <= M; i += T) lds[chunkPos(i)] = (i == (side ? 0 : M)) ? 0.f : src[i];   // pairs: csf[N/2] is settled late, 0 can never win meanwhile
+    *reinterpret_cast<float2 *>(lds + chunkPos(32 * tid) + 32) = float2{0.f, 0.f};
+    if (tid < 16) lds[chunkPos(M) + 1 + tid] = 0.f;
+    if (tid == 0) prm.ny[self] = src[side ? 0 : M];
     __syncthreads();
-    if (!sHave) {
-        // the partner has not published yet: leave a note and look again
-        if (tid < 128) __hip_atomic_store(prm.nyBest + size_t(self) * 128 + tid, sLate[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(prm.nyFlag + 2 * self + 1, prm.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            sHave = __hip_atomic_load(prm.nyFlag + 2 * partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == prm.epoch ? 1 : 0;
-            sPartnerGaveUp = 0;                                              // (a partner that has not even published cannot have given up)
-            if (prm.pairTest == 2u) sHave = 0;
-        }
-        __syncthreads();
-        if (!sHave) return;                                                  // the partner settles both sides at its end
-    }
-    // settle: s = 0 this side (own late state in LDS, own low bins in LDS), s = 1 the partner's side if it gave up (its state from the
-    // published arrays).  Threads [0, 64): the pixels whose run ends on csf[N/2]; [128, 256): the pixels that reach over bin 0.
-    {
+    realMapSettle<LR1, 0>(prm, lds, tid, side, task, self, tb, mapper, re, ce, lds);
+}
+
+// The pixels of a frame that need both channels, behind the launch whose workgroups each saw one:
+//   * csf[N/2] = |X_L[M] + i X_R[M]| / 2 (TransformDSP.inl:863) is the LAST offset of the arg-max scans of either side's top pixels
+//     (fixFrom .. P), compared with a strict >: it wins exactly when its square exceeds the winning square the channel's workgroup
+//     left in nyBest; the pixel then shows csf[N/2] itself;
+//   * the interpolated pixels whose tap window reaches over bin 0 (..., csf[N-1], csf[N], csf[0], csf[1], ...: the other channel's
+//     lowest bins): evaluated here from the kLowBins lowest entries both channels left in `low`, taps in order.
+// One workgroup per (frame, pair): threads [0, 128) the top pixels of the two sides, [128, 256) the low pixels.
+__global__ void __launch_bounds__(256) realLateKernel(const RealParams prm, const int N)
+{
 #pragma clang fp contract(off)
-        const float nyP = __hip_atomic_load(prm.ny + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float nyRe = side ? nyP : sNyOwn, nyIm = side ? sNyOwn : nyP;     // left channel's is the real part
-        const float vM = 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
-        const float sqM = vM * vM + 0.f;                                    // Math::square(csf[offset]) with imag == 0
-        if (tid == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
-        const float *lowP = prm.low + size_t(partner) * kLowBins;
-        for (int who = 0; who < (sPartnerGaveUp ? 2 : 1); ++who) {
-            const int s = who ? (side ^ 1) : side;                           // the side being settled
-            const long u = (task << 1) | s;
-            if (prm.mapped && tid < 64) {
-                const uint32_t x = prm.fixFrom[s] + uint32_t(tid);
-                if (x < prm.P) {
-                    float b, own;
-                    if (!who) { b = sLate[tid]; own = sLate[64 + tid]; }
-                    else {
-                        b = __hip_atomic_load(prm.nyBest + size_t(u) * 128 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        own = __hip_atomic_load(prm.nyBest + size_t(u) * 128 + 64 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    prm.mapped[size_t(u) * prm.P + x] = sqM > b ? finishPixel<5>(prm.invSize * vM) : own;
-                }
+    const long task = blockIdx.x;
+    const int tid = threadIdx.x, M = N / 2;
+    const float nyRe = prm.ny[2 * task], nyIm = prm.ny[2 * task + 1];           // the left channel's is the real part
+    const float vM = prm.binsIn ? nyRe : 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // (bins injected: the left channel stored csf[N/2] itself)
+    const float sqM = vM * vM + 0.f;                                        // Math::square(csf[offset]) with imag == 0
+    if (tid == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
+    if (!prm.mapped) return;
+    if (tid < 128) {
+        const int s = tid >> 6, j = tid & 63;
+        const uint32_t x = prm.fixFrom[s] + uint32_t(j);
+        const long u = 2 * task + s;
+        if (x < prm.P && sqM > prm.nyBest[size_t(u) * 64 + j]) prm.mapped[size_t(u) * prm.P + x] = finishPixel<5>(prm.invSize * vM);
+    } else {
+        const uint32_t n = uint32_t(tid - 128);
+        if (n < prm.lowCount[0] + prm.lowCount[1]) {
+            const int s = n < prm.lowCount[0] ? 0 : 1;
+            const uint32_t x = prm.lowPixels[n];
+            const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
+            const float *lowL = prm.low + size_t(2 * task) * kLowBins, *lowR = lowL + kLowBins;
+            float acc = 0.f;
+            int k = rec.a;
+            for (int i = 0; i < rec.b; ++i) {                                // taps in order (lanczosFilter restatement)
+                // csf[k]: k < kLowBins is the left channel's bin k, k > N - kLowBins the right channel's bin N - k
+                const float v = k < kLowBins ? lowL[k] : lowR[N - k];
+                acc = acc + v * prm.weights[rec.c + i];
+                k = (k == N) ? 0 : k + 1;
             }
-            if (prm.mapped && tid >= 128 && tid < 256) {
-                const uint32_t n = uint32_t(tid - 128);
-                if (n < prm.lowCount[s]) {
-                    const uint32_t x = prm.lowPixels[(s ? prm.lowCount[0] : 0u) + n];
-                    const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
-                    float v[kMaxTaps], w[kMaxTaps];
-                    int k = rec.a;
-#pragma unroll
-                    for (int i = 0; i < kMaxTaps; ++i) {                      // independent loads first
-                        const bool on = i < rec.b;
-                        // csf[k]: k < kLowBins is the left channel's bin k, k > N - kLowBins the right channel's bin N - k; this
-                        // workgroup's own bins are in its LDS, the partner's in its published array
-                        const bool left = k < kLowBins;
-                        const int j = left ? k : N - k;
-                        const bool mine = (side == 0) == left;
-                        float val = 0.f;
-                        if (on) val = mine ? lds[at(k)] : __hip_atomic_load(lowP + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[i] = val;
-                        w[i] = on ? prm.weights[rec.c + i] : 0.f;
-                        if (on) k = (k == N) ? 0 : k + 1;
-                    }
-                    float acc = 0.f;
-#pragma unroll
-                    for (int i = 0; i < kMaxTaps; ++i)
-                        if (i < rec.b) acc = acc + v[i] * w[i];               // taps in order (lanczosFilter restatement)
-                    prm.mapped[size_t(u) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
-                }
-            }
+            prm.mapped[(size_t(2 * task + s)) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
         }
     }
+}
+
+// test hook: y = finishPixel(x), the last step of every K_A pixel (stft_body.hpp)
+__global__ void __launch_bounds__(256) finishPixelKernel(const float *x, float *y, size_t n)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = finishPixel<5>(x[i]);
+}
+hipError_t launchFinishPixel(const float *x, float *y, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(finishPixelKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+    return hipGetLastError();
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
@@ -546,16 +566,31 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     const bool mono = prm.mode != SGZ_CH_SEPARATE && prm.mode != SGZ_CH_MIDSIDE;
     const long units = prm.frames * long(prm.C) * (mono ? 1 : 2);
     if (units <= 0) return hipSuccess;
-    const uint32_t M = N / 2;
-    const size_t xFloats = size_t(((M + 1) + ((M + 1) >> 5) + 2) & ~1u);
-    const uint32_t maxSide = mono ? prm.nItems : std::max(prm.nItemsLeft, prm.nItems - prm.nItemsLeft);
-    const size_t ldsBytes = xFloats * 4 + size_t(std::max(maxSide, 72u)) * 4 + (mono ? 2 * kSpecBins * 4 : 0);
-    static size_t granted[24][64] = {};
+    const uint32_t M = N / 2, T = M / 32;
+    const uint32_t maxSlots = std::max(prm.chunkSlots[0], prm.chunkSlots[1]);
+    // magnitudes, then the map's tile / chunk maxima (the same floats hold column 0's scratch during the recombination), then (mono) the complex entries
+    const size_t ldsBytes = (size_t(realXFloats(int(M))) + std::max<size_t>(size_t(maxSlots) + 1 + T, 64) + (mono ? 2 * kSpecBins : 0)) * 4;
+    static size_t granted[27][64] = {};
     const bool wcos = prm.winPhase != nullptr;
+    if (prm.binsIn) {
+        if (mono) return hipErrorNotSupported;
+        auto inject = [&](auto kern, int slot, unsigned threads) -> hipError_t {
+            if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
+            hipLaunchKernelGGL(realLateKernel, dim3(unsigned(units / 2)), dim3(256), 0, stream, prm, int(N));
+            return hipGetLastError();
+        };
+        if (N == 32768) return inject(&realMapFromBinsKernel<4>, 24, 512);
+        if (N == 16384) return inject(&realMapFromBinsKernel<3>, 25, 256);
+        if (N == 65536) return inject(&realMapFromBinsKernel<5>, 26, 1024);
+        return hipErrorNotSupported;
+    }
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
         if (ldsBytes > limit) return hipErrorInvalidValue;
         if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
+        // the pixels that need both channels (skipped when the caller's next kernel overlays them itself: prm.lateInNext)
+        if (!mono && !prm.lateInNext) hipLaunchKernelGGL(realLateKernel, dim3(unsigned(units / 2)), dim3(256), 0, stream, prm, int(N));
         return hipSuccess;
     };
     hipError_t e;

@@ -45,7 +45,12 @@ template <int LR>
 __device__ __forceinline__ float finishPixel(float val)
 {
 #pragma clang fp contract(off)
-    // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365)
+    // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365).
+    // In binary floating point with round-to-nearest, sqrt(fl(x^2)) == |x| whenever x^2 neither underflows nor overflows (the square
+    // keeps |x| to half an ulp of the square, i.e. a quarter ulp of |x| after the root): the correctly rounded root -- a ~20-instruction
+    // sequence on this chip -- is needed outside [2^-62, 2^63] only.  tests/test_gpu_spectrum.py checks the identity over every float.
+    const float a = __builtin_fabsf(val);
+    if (a >= 0x1p-62f && a <= 0x1p63f) return a;
     const float sq = val * val + 0.f;
     return __builtin_sqrtf(sq);                                        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
 }

@@ -153,6 +153,25 @@ def test_logf_equals_libm_over_every_positive_float(gpu, oracle):
     assert np.isposinf(y[:1].cpu().numpy()[0])
 
 
+def test_finish_pixel_equals_sqrt_of_square_over_every_float(gpu):
+    """K_A's last step per pixel, sqrt(x * x + 0) (TransformDSP.inl:1331 with im == 0), is evaluated as |x| where the square is a normal
+    float: bit-identical to the correctly rounded root of the rounded square for EVERY float (both signs, denormals, inf; NaN stays NaN)."""
+    import torch
+    step = 1 << 26
+    y = torch.empty(step, dtype=torch.float32, device=gpu)
+    for lo in range(0, 1 << 32, step):
+        bits = torch.arange(lo, lo + step, dtype=torch.int64, device=gpu).to(torch.int32)      # wraps into the negative patterns
+        x = bits.view(torch.float32)
+        api.check(api.lib().sgz_stage_finish_pixel(x.data_ptr(), y.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream))
+        got = y.cpu().numpy()
+        xc = x.cpu().numpy()
+        with np.errstate(over="ignore", invalid="ignore", under="ignore"):
+            want = np.sqrt((xc * xc + np.float32(0)).astype(np.float32))
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan), lo
+        assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), lo
+
+
 def test_end_to_end_cfg1(gpu, oracle):
     po = oracle
     cfg = config.cfg1()
@@ -431,28 +450,43 @@ def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr
         assert not problems, (problems[:5], stats)
 
 
-@pytest.mark.parametrize("N,sr", [(16384, 48000.0), (32768, 48000.0), (65536, 96000.0)])
-def test_pair_exchange_rare_paths(gpu, monkeypatch, N, sr):
-    """the channel workgroups' exchange (spectrum_real.hip): the usual path (the partner has published: every workgroup settles its own late
-    pixels), the fallback (SGZ_PAIR_TEST=1: publish own state, raise flag2, look again) and the hand-over (SGZ_PAIR_TEST=2: the left
-    channel gives up, the right channel settles both sides from the published state) must write the same bytes"""
+@pytest.mark.parametrize("N,sr,over", [
+    (16384, 48000.0, {}), (32768, 48000.0, {}), (65536, 96000.0, {}),
+    (32768, 48000.0, dict(channel_mode=config.CH_MIDSIDE, bin_interp=config.INTERP_LINEAR)),
+    # a linear view from 0 Hz: the first pixels' tap windows reach over bin 0 into the other channel's bins (realLateKernel's low pixels)
+    (32768, 48000.0, dict(view_scaling=config.VIEW_LINEAR, view_left=0.0, view_right=0.02, axis_points=777)),
+    (16384, 48000.0, dict(bin_interp=config.INTERP_NONE, axis_points=2500)),       # more pixels than two per thread: the map's further rounds
+    (65536, 96000.0, dict(axis_points=300, min_log_freq=40.0))])                   # long runs: many chunks per pixel
+def test_channel_split_mapping_bit_exact_given_bins(gpu, oracle, monkeypatch, N, sr, over):
+    """Chain link 2 on the kernels the bench runs: sgz_stage_map_from_bins on a channel-split plan feeds the oracle's csf magnitudes to
+    realMapFromBinsKernel -- the chunk-scan map, the late-pixel bookkeeping and realLateKernel are the very functions stftRealKernel
+    runs behind its transform (spectrum_real.hip realMapSettle) -- and every pixel, incl. the top pixels that csf[N/2] can win and
+    the pixels whose taps reach over bin 0, must equal the oracle's mapToLinearSpace (TransformDSP.inl:871-985) bit for bit."""
+    import torch
+    po = oracle
     monkeypatch.setenv("SGZ_CHANNEL_SPLIT", "1")
-    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=3)
-    x = _planar_cuda(synth.gen(41, int(sr), N + 37 * (N // 4), 6), gpu)
+    cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, **over)
+    p = po.params_from_dict(cfg)
+    frames = 3
+    x = synth.gen(23, int(sr), N + (frames - 1) * (N // 4), 2)
+    x[0, 1::2] -= 0.4                                   # energy at Nyquist in the left channel: csf[N/2] wins the top pixels
+    x[0, 0::2] += 0.4
     plan = api.Plan(cfg).upload()
     assert plan.path & 8
-    out = {}
-    for mode in ("0", "1", "2", "0"):
-        monkeypatch.setenv("SGZ_PAIR_TEST", mode)
-        m = plan.stage_mapped(x).cpu().numpy()
-        b = plan.stage_bins(x).cpu().numpy()
-        if mode in out:
-            assert np.array_equal(out[mode][0].view(np.uint32), m.view(np.uint32))
-        out[mode] = (m, b)
-    for mode in ("1", "2"):
-        assert np.array_equal(out[mode][0].view(np.uint32), out["0"][0].view(np.uint32)), (mode, int((out[mode][0] != out["0"][0]).sum()))
-        assert np.array_equal(out[mode][1].view(np.uint32), out["0"][1].view(np.uint32)), mode
-    monkeypatch.delenv("SGZ_PAIR_TEST")
+    csfs = np.zeros((frames, 1, plan.N + 1), np.float32)
+    want = np.zeros((frames, 1, 2, plan.P), np.float32)
+    for f in range(frames):
+        o = f * (N // 4)
+        raw, csf, csp = po.frame_bins(p, x[0, o:o + N], x[1, o:o + N])
+        csfs[f, 0] = csf.real
+        v = csp.reshape(2, plan.P)
+        want[f, 0] = np.sqrt((v.real * v.real + v.imag * v.imag).astype(np.float32)).astype(np.float32)
+    got = plan.stage_map_from_bins(torch.from_numpy(csfs).to(gpu)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (int((got != want).sum()), np.nonzero(got != want)[-1][:8])
+    # and the transform kernel itself, through the chain (its own bins within the FFT's tolerance, colours given its pixels byte for byte)
+    from parity_chain import check_render
+    problems, _ = check_render(po, plan, cfg, x, gpu)
+    assert not problems, problems
 
 
 @pytest.mark.parametrize("N,sr,mode,pairs,over", [
