@@ -186,6 +186,12 @@ sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channe
                             float *d_mapped /*[frames][pairs][2][P]*/, void *stream);
 sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t frames,
                                    float *d_mapped, void *stream);
+/* K_A's dominant launch ALONE, for timing it with events on `stream` (bench.py's roofline line): on a channel-split plan the pixels
+ * that need both channels (the top pixels csf[N/2] can win, taps that reach over bin 0) hold the values of the channel's own bins
+ * only -- sgz_stage_mapped / the render calls complete them (a small follow-up launch, or K_B's fused kernel as it reads them);
+ * on every other plan this is sgz_stage_mapped. */
+sgz_status sgz_stage_mapped_dominant(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                                     float *d_mapped /*[frames][pairs][2][P]*/, void *stream);
 /* d_rgba and d_lines may both be NULL: a state-only pass that just advances d_state over `frames` frames (what the
  * multi-GPU carry exchange below needs from every rank before the real pass). */
 sgz_status sgz_stage_decay_colour(sgz_plan *plan, const float *d_mapped, size_t frames,

@@ -114,7 +114,7 @@ EXPORTS = [
     "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_path", "sgz_plan_dc_pixels", "sgz_plan_get_window",
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
-    "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped",
+    "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant",
     "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout",
     "sgz_spectrogram_render_sharded",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
@@ -175,6 +175,7 @@ def lib() -> C.CDLL:
     L.sgz_spectrogram_render_host.argtypes = [vp, vp, u32, sz, vp, vp, C.POINTER(Timing)]
     L.sgz_stage_bins.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgz_stage_mapped.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgz_stage_mapped_dominant.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgz_stage_map_from_bins.argtypes = [vp, vp, sz, vp, vp]
     L.sgz_stage_decay_colour.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.sgz_decay_fold_carry.argtypes = [vp, vp, vp, u32, u32, vp, vp]

@@ -154,9 +154,22 @@ static sgz_status ensureDcWork(Plan &p, size_t slab)
     return SGZ_OK;
 }
 
-sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
-                          float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock)
+// the channel-split launch's late-pixel fields alone (realLateKernel as a launch of its own, runDecayColour's fallback)
+static RealParams fillRealLate(Plan &p, long frames, float *d_mapped)
 {
+    RealParams rp{};
+    rp.frames = frames; rp.C = p.C; rp.P = p.P; rp.mode = p.cfg.channel_mode;
+    rp.recsFull = p.d_recs; rp.weights = p.d_weights;
+    rp.low = p.d_low; rp.lowPixels = p.d_realLowPixels; rp.lowCount[0] = p.realLowCount[0]; rp.lowCount[1] = p.realLowCount[1];
+    rp.invSize = p.scalars.invSize; rp.mapped = d_mapped;
+    rp.ny = p.d_ny; rp.nyBest = p.d_nyBest; rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
+    return rp;
+}
+
+sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
+                          float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock, bool deferLate)
+{
+    p.lateDeferred = nullptr;
     const bool phase = p.cfg.channel_mode == SGZ_CH_PHASE;
     StftParams prm = fillStftParams(p, d_planar, chStride, frames, d_mapped, d_binsOut, d_binsIn, d_phaseClock);
     const long tasks = frames * long(p.C);
@@ -197,6 +210,9 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.mapped = d_mapped; rp.binsOut = d_binsOut; rp.binsIn = d_binsIn;
         rp.ny = p.d_ny; rp.nyBest = p.d_nyBest;
         rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
+        // the pixels that need both channels: realLateKernel behind the channel workgroups, or -- an image-only render, no low pixels --
+        // K_B's fused kernel while it loads the magnitudes (then the step stays at two launches)
+        if (deferLate && !p.realMono && d_mapped && !d_binsOut && p.realLowCount[0] + p.realLowCount[1] == 0) { rp.lateInNext = 1u; p.lateDeferred = d_mapped; }
         rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
@@ -308,6 +324,20 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
     static const bool noFused = std::getenv("SGZ_KB_FUSED") && std::getenv("SGZ_KB_FUSED")[0] == '0';   // A/B switch for measurements
+    if (p.lateDeferred) {
+        // the channel-split K_A in front of this call left its late pixels to whoever reads its magnitudes next (runStft, deferLate)
+        float *pending = const_cast<float *>(p.lateDeferred);
+        p.lateDeferred = nullptr;
+        if (d_mapped == pending && !noFused && p.cfg.channel_mode != SGZ_CH_PHASE && decayColourFusedApplies(prm)) {
+            // the fused colour kernel completes those pixels as it loads the magnitudes (spectrum_post.hip): the step stays at two
+            // launches.  (Tried for the scan / emit kernels as well: the extra loads sit on their critical path, +3 us each,
+            // against 2-5 us for realLateKernel as a launch of its own.)
+            prm.late = LateFix{p.d_ny, p.d_nyBest, p.realFixFrom[0], p.realFixFrom[1], p.P, p.scalars.invSize, 0u};
+            prm.hasLate = 1u;
+        } else {
+            SGZ_HIP(launchRealLate(fillRealLate(p, frames, pending), p.N, stream));
+        }
+    }
     if (p.cfg.channel_mode == SGZ_CH_PHASE) {
         // colour column only: the image reads the main graph's magnitude state alone (decayPhaseColourKernel), a plain peak decay of
         // plane 0 x 0.5 -- the chunked exact scan of the fused kernel instead of the sequential walk the phase smoother needs
@@ -500,7 +530,7 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P);
     if (st != SGZ_OK) return st;
-    if ((st = runStft(p, d_planar, channel_stride, frames, p.d_mapped, nullptr, nullptr, s)) != SGZ_OK) return st;
+    if ((st = runStft(p, d_planar, channel_stride, frames, p.d_mapped, nullptr, nullptr, s, nullptr, /*deferLate=*/true)) != SGZ_OK) return st;
     return runDecayColour(p, p.d_mapped, frames, d_rgba, d_lines, d_state, s);
 }
 
@@ -604,6 +634,18 @@ sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channe
     Plan &p = plan->impl;
     const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
     return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+sgz_status sgz_stage_mapped_dominant(sgz_plan *plan, const float *d_planar, size_t channel_stride, size_t nsamples,
+                                     float *d_mapped, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    Plan &p = plan->impl;
+    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    st = runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), nullptr, /*deferLate=*/true);
+    p.lateDeferred = nullptr;                        // (nobody completes them: see sgz.h)
+    return st;
 }
 
 sgz_status sgz_stage_map_from_bins(sgz_plan *plan, const float *d_bins, size_t frames, float *d_mapped, void *stream)

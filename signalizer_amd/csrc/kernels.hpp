@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "plan.hpp"
+#include "late_fix.hpp"
 
 namespace sgz {
 
@@ -84,6 +85,8 @@ struct RealParams {
 };
 constexpr int kLowBins = 24;
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream);
+// the late pixels of a launch that ran with lateInNext = 1 (pairs), as a launch of its own
+hipError_t launchRealLate(const RealParams &prm, uint32_t N, hipStream_t stream);
 constexpr int kDecayChunk = 8;    // frames per time chunk of K_B
 hipError_t launchStftMap(const StftParams &prm, uint32_t N, int grid, hipStream_t stream);
 // the fused kernel's load + three passes only: raw transform Z of every task -> prm.zOut (N = 4096, 32768; Phase mode)
@@ -129,6 +132,7 @@ struct DecayParams {
     float *lines;             // [frames][C][G][P][2] or null
     float magScale;           // factor on the mapped magnitudes before the decay: 1, or 0.5 in Phase mode (mag *= consts::half, TransformDSP.inl:1407) -- fused kernel only
     uint32_t colourOnly;      // neither lines nor state are wanted: only (side 0, LineMain) of every pair feeds the colour column, the scans skip the rest
+    LateFix late; uint32_t hasLate;   // fused colour kernel: `mapped` comes from channel workgroups whose late pixels (late_fix.hpp) are applied while it is read
 };
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream);   // local + carry, one launch when the chunks fit a workgroup
 hipError_t launchDecayLocal(const DecayParams &prm, hipStream_t stream);

@@ -192,10 +192,10 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     if ((st = uploadMix(s, uint32_t(nch), nullptr)) != SGZ_OK) return st;
     // warm-up: the largest batch a push can produce, on the silent ring -- every lazy allocation and LDS grant of the kernels
     // happens here, not on the audio thread.  The state it leaves is cleared again.
-    st = runStft(p, s->d_ring, size_t(2) * s->cap, long(s->maxFrames), s->d_mapped, nullptr, nullptr, s->stream);
+    st = runStft(p, s->d_ring, size_t(2) * s->cap, long(s->maxFrames), s->d_mapped, nullptr, nullptr, s->stream, nullptr, /*deferLate=*/true);
     if (st == SGZ_OK) st = runDecayColour(p, s->d_mapped, long(s->maxFrames), s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
     if (st == SGZ_OK && s->maxFrames > 1) {
-        st = runStft(p, s->d_ring, size_t(2) * s->cap, 1, s->d_mapped, nullptr, nullptr, s->stream);
+        st = runStft(p, s->d_ring, size_t(2) * s->cap, 1, s->d_mapped, nullptr, nullptr, s->stream, nullptr, /*deferLate=*/true);
         if (st == SGZ_OK) st = runDecayColour(p, s->d_mapped, 1, s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
     }
     if (st != SGZ_OK) return st;
@@ -283,7 +283,7 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
             // frame k's window ends `first + k hop` samples into the piece; in the mirrored ring it starts at q + k hop, contiguous
             const uint32_t end0 = (s->head.load(std::memory_order_relaxed) + first) % s->cap;
             const uint32_t q = (end0 + s->cap - (W % s->cap)) % s->cap;
-            st = runStft(p, s->d_ring + q, size_t(2) * s->cap, long(frames), s->d_mapped, nullptr, nullptr, s->stream);
+            st = runStft(p, s->d_ring + q, size_t(2) * s->cap, long(frames), s->d_mapped, nullptr, nullptr, s->stream, nullptr, /*deferLate=*/true);
             if (st != SGZ_OK) return st;
             st = runDecayColour(p, s->d_mapped, long(frames), s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
             if (st != SGZ_OK) return st;

@@ -206,7 +206,10 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX; e += 1024) {
         const uint32_t px = e % PX, f = e / PX;
         const uint32_t pixel = blockIdx.x * PX + px;
-        magS[f][px] = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] * prm.magScale : 0.f;   // (x 1 is exact)
+        float m = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] * prm.magScale : 0.f;   // (x 1 is exact)
+        if (prm.hasLate && e < items && pixel >= prm.late.fixFrom0 && pixel < prm.P)                            // (late_fix.hpp)
+            m = lateNyquistPixel(prm.late, lateNyquistBin(prm.late, long(f)), lateBestSquare(prm.late, long(f), 0, pixel), m);
+        magS[f][px] = m;
     }
     __syncthreads();
     // 1b. zero-carry scan of every chunk

@@ -500,40 +500,63 @@ __global__ void __launch_bounds__(1 << (LR1 + 5)) realMapFromBinsKernel(const Re
 //     left in nyBest; the pixel then shows csf[N/2] itself;
 //   * the interpolated pixels whose tap window reaches over bin 0 (..., csf[N-1], csf[N], csf[0], csf[1], ...: the other channel's
 //     lowest bins): evaluated here from the kLowBins lowest entries both channels left in `low`, taps in order.
-// One workgroup per (frame, pair): threads [0, 128) the top pixels of the two sides, [128, 256) the low pixels.
-__global__ void __launch_bounds__(256) realLateKernel(const RealParams prm, const int N)
+// One thread per pixel: items [0, tasks * 2 * nTop) are the top pixels (task, side, j), the rest the low pixels (task, n) -- a few
+// hundred threads at cfg2, so that the launch costs little more than its boundary.
+__host__ __device__ LateFix lateFixOf(const RealParams &prm)
+{
+    return LateFix{prm.ny, prm.nyBest, prm.fixFrom[0], prm.fixFrom[1], prm.P, prm.invSize, prm.binsIn ? 1u : 0u};
+}
+__global__ void __launch_bounds__(256) realLateKernel(const RealParams prm, const int N, const uint32_t nTop)
 {
 #pragma clang fp contract(off)
-    const long task = blockIdx.x;
-    const int tid = threadIdx.x, M = N / 2;
-    const float nyRe = prm.ny[2 * task], nyIm = prm.ny[2 * task + 1];           // the left channel's is the real part
-    const float vM = prm.binsIn ? nyRe : 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);   // (bins injected: the left channel stored csf[N/2] itself)
-    const float sqM = vM * vM + 0.f;                                        // Math::square(csf[offset]) with imag == 0
-    if (tid == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + M] = vM;
-    if (!prm.mapped) return;
-    if (tid < 128) {
-        const int s = tid >> 6, j = tid & 63;
-        const uint32_t x = prm.fixFrom[s] + uint32_t(j);
-        const long u = 2 * task + s;
-        if (x < prm.P && sqM > prm.nyBest[size_t(u) * 64 + j]) prm.mapped[size_t(u) * prm.P + x] = finishPixel<5>(prm.invSize * vM);
-    } else {
-        const uint32_t n = uint32_t(tid - 128);
-        if (n < prm.lowCount[0] + prm.lowCount[1]) {
-            const int s = n < prm.lowCount[0] ? 0 : 1;
-            const uint32_t x = prm.lowPixels[n];
-            const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
-            const float *lowL = prm.low + size_t(2 * task) * kLowBins, *lowR = lowL + kLowBins;
-            float acc = 0.f;
-            int k = rec.a;
-            for (int i = 0; i < rec.b; ++i) {                                // taps in order (lanczosFilter restatement)
-                // csf[k]: k < kLowBins is the left channel's bin k, k > N - kLowBins the right channel's bin N - k
-                const float v = k < kLowBins ? lowL[k] : lowR[N - k];
-                acc = acc + v * prm.weights[rec.c + i];
-                k = (k == N) ? 0 : k + 1;
-            }
-            prm.mapped[(size_t(2 * task + s)) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
+    const long tasks = prm.frames * long(prm.C);
+    const long item = long(blockIdx.x) * 256 + threadIdx.x;
+    const long tops = tasks * 2 * nTop;
+    const uint32_t nLow = prm.lowCount[0] + prm.lowCount[1];
+    if (item < tops) {
+        const long task = item / (2 * nTop);
+        const int s = int((item / nTop) & 1);
+        const uint32_t j = uint32_t(item % nTop);
+        const LateFix lf = lateFixOf(prm);
+        const uint32_t x = lf.fixFrom(s) + j;
+        const bool top = x < prm.P && prm.mapped;
+        // every load goes out before anything is looked at: one memory round trip
+        float *px = prm.mapped + size_t(2 * task + s) * prm.P + (top ? x : 0u);
+        const float own = top ? *px : 0.f;
+        const float best = top ? lateBestSquare(lf, task, s, x) : 0.f;
+        const float vM = lateNyquistBin(lf, task);
+        if (s == 0 && j == 0 && prm.binsOut) prm.binsOut[size_t(task) * (N + 1) + N / 2] = vM;
+        if (top) {
+            const float v = lateNyquistPixel(lf, vM, best, own);
+            if (v != own || !(own == own)) *px = v;
         }
+    } else if (item < tops + tasks * nLow && prm.mapped) {
+        const long task = (item - tops) / nLow;
+        const uint32_t n = uint32_t((item - tops) % nLow);
+        const int s = n < prm.lowCount[0] ? 0 : 1;
+        const uint32_t x = prm.lowPixels[n];
+        const PixelRec rec = prm.recsFull[size_t(s) * prm.P + x];
+        const float *lowL = prm.low + size_t(2 * task) * kLowBins, *lowR = lowL + kLowBins;
+        float acc = 0.f;
+        int k = rec.a;
+        for (int i = 0; i < rec.b; ++i) {                                    // taps in order (lanczosFilter restatement)
+            // csf[k]: k < kLowBins is the left channel's bin k, k > N - kLowBins the right channel's bin N - k
+            const float v = k < kLowBins ? lowL[k] : lowR[N - k];
+            acc = acc + v * prm.weights[rec.c + i];
+            k = (k == N) ? 0 : k + 1;
+        }
+        prm.mapped[(size_t(2 * task + s)) * prm.P + x] = finishPixel<5>(prm.invSize * acc);
     }
+}
+hipError_t launchRealLate(const RealParams &prm, uint32_t N, hipStream_t stream)
+{
+    const long tasks = prm.frames * long(prm.C);
+    if (tasks <= 0) return hipSuccess;
+    uint32_t nTop = 1;                                                       // (>= 1: item (task, 0, 0) also writes binsOut[N/2])
+    for (int s = 0; s < 2; ++s) nTop = std::max(nTop, std::min(64u, prm.P - std::min(prm.P, prm.fixFrom[s])));
+    const long items = tasks * 2 * nTop + tasks * long(prm.lowCount[0] + prm.lowCount[1]);
+    hipLaunchKernelGGL(realLateKernel, dim3(unsigned((items + 255) / 256)), dim3(256), 0, stream, prm, int(N), nTop);
+    return hipGetLastError();
 }
 
 // test hook: y = finishPixel(x), the last step of every K_A pixel (stft_body.hpp)
@@ -577,8 +600,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
         auto inject = [&](auto kern, int slot, unsigned threads) -> hipError_t {
             if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
-            hipLaunchKernelGGL(realLateKernel, dim3(unsigned(units / 2)), dim3(256), 0, stream, prm, int(N));
-            return hipGetLastError();
+            return launchRealLate(prm, N, stream);
         };
         if (N == 32768) return inject(&realMapFromBinsKernel<4>, 24, 512);
         if (N == 16384) return inject(&realMapFromBinsKernel<3>, 25, 256);
@@ -590,7 +612,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
         if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
         // the pixels that need both channels (skipped when the caller's next kernel overlays them itself: prm.lateInNext)
-        if (!mono && !prm.lateInNext) hipLaunchKernelGGL(realLateKernel, dim3(unsigned(units / 2)), dim3(256), 0, stream, prm, int(N));
+        if (!mono && !prm.lateInNext) return launchRealLate(prm, N, stream);
         return hipSuccess;
     };
     hipError_t e;

@@ -9,6 +9,7 @@
 #include "complex_dc.hpp"
 #include "fft_common.hpp"
 #include "kernels.hpp"
+#include "late_fix.hpp"
 
 namespace sgz {
 
@@ -42,18 +43,7 @@ namespace sgz {
 // key (bits(|X|^2) << 32 | ~offset): larger square wins, equal squares -> smaller scan offset wins, which is
 // exactly "first strictly greater".  Key 0 (no square > 0) falls back to `bin` like the reference's initial value.
 template <int LR>
-__device__ __forceinline__ float finishPixel(float val)
-{
-#pragma clang fp contract(off)
-    // mapAndTransformDFTFilters: magnitude = sqrt(re*re + im*im), im == 0 (TransformDSP.inl:1331,:1365).
-    // In binary floating point with round-to-nearest, sqrt(fl(x^2)) == |x| whenever x^2 neither underflows nor overflows (the square
-    // keeps |x| to half an ulp of the square, i.e. a quarter ulp of |x| after the root): the correctly rounded root -- a ~20-instruction
-    // sequence on this chip -- is needed outside [2^-62, 2^63] only.  tests/test_gpu_spectrum.py checks the identity over every float.
-    const float a = __builtin_fabsf(val);
-    if (a >= 0x1p-62f && a <= 0x1p63f) return a;
-    const float sq = val * val + 0.f;
-    return __builtin_sqrtf(sq);                                        // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
-}
+__device__ __forceinline__ float finishPixel(float val) { return finishMagnitude(val); }   // (late_fix.hpp)
 
 template <int LR, int NT>
 __device__ __forceinline__ void mapPixelsSerial(const StftParams &prm, const float *lds, int tid, long task)

@@ -207,7 +207,7 @@ class TimeChunkRenderer:
         stream = torch.cuda.current_stream().cuda_stream
         e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
         hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
-        call = lambda: api.check(api.lib().sgz_stage_mapped(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1],
+        call = lambda: api.check(api.lib().sgz_stage_mapped_dominant(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1],
                                                            mapped.data_ptr(), stream))
         for _ in range(5):
             call()

@@ -31,7 +31,7 @@ def main():
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
-        ka = lambda: api.check(api.lib().sgz_stage_mapped(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), stream))
+        ka = lambda: api.check(api.lib().sgz_stage_mapped_dominant(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), stream))
         rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device="cuda")
         full = lambda: plan.render(x, rgba=rgba)
         m, mn = timeit(ka, iters)

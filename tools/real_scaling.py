@@ -13,7 +13,7 @@ hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
 for F in (32, 64, 128, 192, 256, 320, 384, 512, 768, 1024):
     S = 32768 + 8192 * (F - 1)
     mapped = torch.empty((F, 1, 2, 1024), dtype=torch.float32, device="cuda")
-    fn = lambda: api.check(api.lib().sgz_stage_mapped(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), stream))
+    fn = lambda: api.check(api.lib().sgz_stage_mapped_dominant(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), stream))
     for _ in range(5): fn()
     t = []
     for _ in range(30):
