@@ -448,7 +448,7 @@ def main() -> None:
             nt = extra["no_tail"]
             out["roofline"]["frac_no_tail"] = nt["achieved"] / HBM_PEAK_GBPS
             out["roofline"]["no_tail"] = {"tasks": nt["tasks"], "kernel_ms": nt["kernel_ms"], "achieved": nt["achieved"],
-                                          "note": "8 stereo pairs of the cfg2 buffer: many rounds of workgroups, so the partial last round does not count; at this task count the library runs the whole-frame kernel stftMapKernel<5, 0, true, true> (the channel-split form is for launches of few rounds)"}
+                                          "note": "8 stereo pairs of the cfg2 buffer: many rounds of workgroups, so the partial last round does not count (the same channel-split kernel as the headline launch)"}
         if "ms_per_step_with_state" in extra:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
         if "two_in_flight" in extra:

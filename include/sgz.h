@@ -127,6 +127,15 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
                                        signal -- takes the place of the kernels above, whatever the row layout
                                        (at N = 32768 in Separate mode: for launches of up to 1024 tasks) */
 uint32_t   sgz_plan_path(const sgz_plan *plan);
+/* Per-plan switches (all default to what is fastest; the parity tests and measurements flip them):
+ *   SGZ_OPT_CHANNEL_SPLIT  1 (default): eligible plans run the real-input channel-split kernels (SGZ_PATH_CHANNEL_SPLIT); 0: never
+ *   SGZ_OPT_FUSED_COLOUR   1 (default): an image-only K_B of one pair runs as the single fused launch; 0: scan + emit launches
+ *   SGZ_OPT_FETCH_WINDOW   0 (default): Hann / Hamming periodic windows at W == N are evaluated inside K_A; 1: fetched from the table
+ * Call between sgz_plan_create and the first compute call on the plan (same threading rule as every other plan call). */
+#define SGZ_OPT_CHANNEL_SPLIT 1u
+#define SGZ_OPT_FUSED_COLOUR  2u
+#define SGZ_OPT_FETCH_WINDOW  3u
+sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or
  * sit at Nyquist -- redone as complex sums after the magnitude-only mapping.  Returns their count; writes at most `cap`. */

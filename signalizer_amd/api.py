@@ -114,7 +114,7 @@ EXPORTS = [
     "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_path", "sgz_plan_dc_pixels", "sgz_plan_get_window",
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
-    "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant",
+    "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant", "sgz_plan_set_option",
     "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout",
     "sgz_spectrogram_render_sharded",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
@@ -180,6 +180,7 @@ def lib() -> C.CDLL:
     L.sgz_stage_decay_colour.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.sgz_decay_fold_carry.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     L.sgz_stage_logf.argtypes = [vp, vp, sz, vp]
+    L.sgz_plan_set_option.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.sgz_stage_finish_pixel.argtypes = [vp, vp, sz, vp]
     L.sgz_stage_track_peak.argtypes = [vp, vp, C.c_double, C.POINTER(Peak), vp]
     L.sgz_spectrum_track_peak.argtypes = [vp, u32, C.c_double, C.POINTER(Peak)]
@@ -257,6 +258,9 @@ def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW = 1, 2, 3
+
+
 class Plan:
     """The Spectrum constant block (TransformConstant mirror). Host tables need no GPU."""
 
@@ -279,6 +283,11 @@ class Plan:
 
     def upload(self):
         check(lib().sgz_plan_upload(self.h))
+        return self
+
+    def set_option(self, option: int, value: int):
+        """sgz_plan_set_option: OPT_CHANNEL_SPLIT / OPT_FUSED_COLOUR / OPT_FETCH_WINDOW"""
+        check(lib().sgz_plan_set_option(self.h, option, value))
         return self
 
     @property

@@ -37,7 +37,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -77,6 +77,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.tw1odd, &p.d_tw1odd)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twReal1, &p.d_twReal1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twRealPost, &p.d_twRealPost)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.tw2Full, &p.d_tw2Full)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhase, &p.d_winPhase)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhaseT, &p.d_winPhaseT)) != SGZ_OK) return st;
     if ((st = uploadVec(p.chunkEnds, &p.d_chunkEnds)) != SGZ_OK) return st;
@@ -128,7 +129,7 @@ static StftParams fillStftParams(Plan &p, const float *d_planar, size_t chStride
     prm.hop = p.cfg.hop; prm.W = p.W; prm.P = p.P; prm.C = p.C;
     prm.sides = uint32_t(p.sides); prm.mode = p.cfg.channel_mode;
     prm.window = p.d_window;
-    prm.winPhase = reinterpret_cast<const float2 *>(p.d_winPhaseT); prm.winP0 = p.winP0; prm.winP1 = p.winP1;
+    prm.winPhase = p.optFetchWindow ? nullptr : reinterpret_cast<const float2 *>(p.d_winPhaseT); prm.winP0 = p.winP0; prm.winP1 = p.winP1;
     prm.tw1 = reinterpret_cast<const float2 *>(p.d_tw1);
     prm.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
     prm.tw1odd = reinterpret_cast<const float2 *>(p.d_tw1odd);
@@ -175,14 +176,12 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
     const long tasks = frames * long(p.C);
     if (tasks <= 0) return SGZ_OK;
     if (tasks > 0x7fffffffL) return fail(SGZ_EINVAL, "too many (frame, pair) tasks for one launch");
-    // N = 32768 has both forms.  A launch is as long as its slowest CU's queue of frames: with few rounds of workgroups the channel-split
-    // form wins (half-size workgroups, two per CU: 348 frames 38.2 us against 44.0 us), on long launches the whole-frame kernel's
-    // throughput does (0.385 against 0.365 of the roofline at 2784 frames): the task count decides.  SGZ_CHANNEL_SPLIT=1 pins the former.
-    const bool pinSplit = std::getenv("SGZ_CHANNEL_SPLIT") && std::getenv("SGZ_CHANNEL_SPLIT")[0] == '1';
-    const bool splitPays = p.N != 32768 || tasks <= 1024 || pinSplit;
+    // Every eligible plan runs the channel-split form (spectrum_real.hip).  Since the chunk-scan map and the late-pixel pass replaced
+    // the piece list and the in-kernel pair exchange it wins at every launch size on MI355X (N = 32768: 348 frames 36 us against 44 us
+    // for the whole-frame kernel, 2784 frame-pairs 212 us against 238 us); sgz_plan_set_option(SGZ_OPT_CHANNEL_SPLIT, 0) keeps a plan off it.
     // (rows need no more than their natural 4-byte alignment: gfx950's global_load_dwordx2 takes dword-aligned addresses, measured
     // bit-identical and within 2 % of 8-byte aligned rows, tools/unaligned_probe.py -- so the choice of kernel never depends on the layout)
-    if ((p.realMono && d_binsIn == nullptr) || (p.realSplit && splitPays)) {
+    if (p.optChannelSplit && ((p.realMono && d_binsIn == nullptr) || p.realSplit)) {
         // Separate mode, N = 32768 / 65536, full window: one workgroup per (frame, pair, channel) (spectrum_real.hip)
         const size_t units = size_t(tasks) * 2;
         if (p.nyCap < units) {
@@ -198,10 +197,11 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.planar = d_planar; rp.chStride = chStride; rp.frames = frames;
         rp.hop = p.cfg.hop; rp.C = p.C; rp.P = p.P; rp.mode = p.cfg.channel_mode;
         rp.window = p.d_window;
-        rp.winPhase = reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = p.winP0; rp.winP1 = p.winP1;
+        rp.winPhase = p.optFetchWindow ? nullptr : reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = p.winP0; rp.winP1 = p.winP1;
         rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
         rp.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
         rp.twPost = reinterpret_cast<const float2 *>(p.d_twRealPost);
+        rp.tw2Full = reinterpret_cast<const float4 *>(p.d_tw2Full);
         rp.recs = p.d_recsReal ? p.d_recsReal : p.d_recs; rp.recsFull = p.d_recs; rp.weights = p.d_weights;
         rp.chunkEnds = p.d_chunkEnds; rp.chunkReBase = p.d_chunkReBase; rp.chunkRec = p.d_chunkRec; rp.weights12 = p.d_weights12;
         rp.chunkSlots[0] = p.chunkSlots[0]; rp.chunkSlots[1] = p.chunkSlots[1];
@@ -323,7 +323,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     DecayParams prm;
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
-    static const bool noFused = std::getenv("SGZ_KB_FUSED") && std::getenv("SGZ_KB_FUSED")[0] == '0';   // A/B switch for measurements
+    const bool noFused = !p.optFusedColour;                                  // (sgz_plan_set_option: A/B switch for measurements)
     if (p.lateDeferred) {
         // the channel-split K_A in front of this call left its late pixels to whoever reads its magnitudes next (runStft, deferLate)
         float *pending = const_cast<float *>(p.lateDeferred);
@@ -451,11 +451,23 @@ sgz_status sgz_plan_upload(sgz_plan *plan)
 uint32_t sgz_plan_transform_size(const sgz_plan *plan) { return plan ? plan->impl.N : 0; }
 double sgz_plan_window_scale(const sgz_plan *plan) { return plan ? plan->impl.windowScale : 0.0; }
 uint32_t sgz_plan_break_pixel(const sgz_plan *plan) { return plan ? plan->impl.breakPixel : 0; }
+sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
+{
+    if (!plan) return fail(SGZ_EINVAL, "null plan");
+    Plan &p = plan->impl;
+    switch (option) {
+    case SGZ_OPT_CHANNEL_SPLIT: p.optChannelSplit = value != 0; return SGZ_OK;
+    case SGZ_OPT_FUSED_COLOUR: p.optFusedColour = value != 0; return SGZ_OK;
+    case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
+    default: return fail(SGZ_EINVAL, "unknown plan option");
+    }
+}
+
 uint32_t sgz_plan_path(const sgz_plan *plan)
 {
     if (!plan) return SGZ_PATH_GENERIC;
     const Plan &p = plan->impl;
-    const uint32_t real = (p.realSplit || p.realMono) ? SGZ_PATH_CHANNEL_SPLIT : 0u;
+    const uint32_t real = (p.optChannelSplit && (p.realSplit || p.realMono)) ? SGZ_PATH_CHANNEL_SPLIT : 0u;
     if (p.fused) return SGZ_PATH_FUSED | real;
     return (p.halves ? SGZ_PATH_HALVES : SGZ_PATH_GENERIC) | (p.sideMapOk ? SGZ_PATH_SIDE_MAP : 0u) | real;
 }

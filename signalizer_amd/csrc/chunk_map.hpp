@@ -21,9 +21,6 @@
 // workgroup's 34.6 k clocks, tools/phase_clocks.py.)
 #pragma once
 #include "stft_body.hpp"
-#ifndef SGZ_ABL
-#define SGZ_ABL 0
-#endif
 
 namespace sgz {
 
@@ -146,7 +143,7 @@ struct ChunkMap {
         uint32_t slotAddr = (slotBase << 2) + uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)re));   // LDS byte address of the chunk's first tile slot
         uint64_t prev = 0;
 #pragma unroll
-        for (int j = 0; j < (SGZ_ABL == 16 ? 0 : 32); ++j) {
+        for (int j = 0; j < 32; ++j) {
             const uint64_t e = __builtin_amdgcn_uicmp(endBits & (1u << j), 0u, 33 /* ICMP_NE */);
             if (j > 0)
                 asm volatile("s_andn2_b64 exec, exec, %2\n\tv_max_f32 %0, %0, %1\n\ts_mov_b64 exec, -1"
@@ -160,7 +157,7 @@ struct ChunkMap {
         SGZ_MAPCLK(10);
         // ---- interpolated pixels of the first round
 #pragma unroll
-        for (int b = 0; b < (SGZ_ABL == 14 ? 0 : RB); ++b) {
+        for (int b = 0; b < RB; ++b) {
             const float acc = taps(lds, rec[b].kind == 0 ? cr[b].y : 0u, wq[b]);
             if (rec[b].kind == 0 && tb.out) tb.out[tid + b * T] = finishPixel<5>(invSize * acc);
         }
@@ -170,7 +167,7 @@ struct ChunkMap {
         SGZ_MAPCLK(12);
         // ---- one thread per arg-max pixel
 #pragma unroll
-        for (int b = 0; b < (SGZ_ABL == 15 ? 0 : RB); ++b) resolve(tb, at, lds, re, ce, invSize, rec[b], cr[b], tid + b * T);
+        for (int b = 0; b < RB; ++b) resolve(tb, at, lds, re, ce, invSize, rec[b], cr[b], tid + b * T);
         // ---- further rounds (more than RB T pixels per side)
         for (int base = RB * T; base < tb.P; base += T) {
             const int x = base + tid;

@@ -80,4 +80,69 @@ __device__ __forceinline__ void ditScalar(v2 (&c)[NREG])
     if constexpr (LR >= 5) ditStage<LR, 5, BASE>(c);
 }
 
+// ---- the same decimation-in-time butterflies on packed (re, im) pairs: 3 packed operations for a general twiddle instead of the 4 of
+// the decimation-in-frequency form in fft_common.hpp (difPacked), 2 for w = 1 and w = -i:
+//     t = a + c b                          v_pk_fma_f32  b, (c, s), a      op_sel_hi:[1,0,1]                       (both halves times c)
+//     p = t + s (b.im, -b.re)              v_pk_fma_f32  b, (c, s), t      op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]
+//     q = 2 a - p                          v_pk_fma_f32  a, 2.0, p         neg_lo / neg_hi on p
+// and for w = -i w':  t = a + c (b.im, -b.re),  p = t - s b.  Measured with realistic register traffic (tools/ubench/valu4.hip,
+// banks.hip) a packed operation costs ~4.8-5.5 clocks against ~2.9-3.1 for each of the two plain ones it replaces, and half the
+// issue slots -- which is what a workgroup alone on its CU is short of.  A 32-point transform: 46 x 2 + 34 x 3 = 194 packed
+// operations (difPacked: 228).
+// twiddle constants travel as an SGPR pair k = (cos, sin)
+__device__ __forceinline__ void bflyPackedLow(v2 &a, v2 &b, v2 k)            // w = k.x - i k.y,  0 < angle < pi/2
+{
+    v2 t, p, q;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(k), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(p) : "v"(b), "s"(k), "v"(t));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(q) : "v"(a), "v"(p));
+    a = p; b = q;
+}
+__device__ __forceinline__ void bflyPackedHigh(v2 &a, v2 &b, v2 k)           // w = -i (k.x - i k.y)
+{
+    v2 t, p, q;
+    // t = (a.x + c b.y, a.y - c b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(t) : "v"(b), "s"(k), "v"(a));
+    // p = (t.x - s b.x, t.y - s b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(p) : "v"(b), "s"(k), "v"(t));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(q) : "v"(a), "v"(p));
+    a = p; b = q;
+}
+// p = a - i b, q = a + i b   (w = -i)
+__device__ __forceinline__ void bflyPackedRot(v2 &a, v2 &b)
+{
+    v2 p, q;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(b));      // (a.x + b.y, a.y - b.x)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(q) : "v"(a), "v"(b));      // (a.x - b.y, a.y + b.x)
+    a = p; b = q;
+}
+
+template <int LR, int S, int BASE, int NREG>
+__device__ __forceinline__ void ditStagePacked(v2 (&c)[NREG])
+{
+    constexpr int n = 1 << LR, m = 1 << S, h = m / 2;
+#pragma unroll
+    for (int k0 = 0; k0 < n; k0 += m) {
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const int ia = BASE + brev(k0 + j, LR), ib = BASE + brev(k0 + j + h, LR);
+            const int tw = j * (32 / m);                                // W_32^tw, tw in [0, 16)
+            if (tw == 0) { const v2 a = c[ia], b = c[ib]; c[ia] = a + b; c[ib] = a - b; }
+            else if (tw == 8) bflyPackedRot(c[ia], c[ib]);
+            else if (tw < 8) bflyPackedLow(c[ia], c[ib], v2{cos32(tw), sin32(tw)});
+            else bflyPackedHigh(c[ia], c[ib], v2{cos32(tw - 8), sin32(tw - 8)});
+        }
+    }
+}
+// 2^LR-point transform of c[BASE .. BASE + 2^LR): x[j] in c[BASE + j] -> X[k] in c[BASE + brev(k, LR)] (difPacked's convention)
+template <int LR, int BASE, int NREG, int FIRST = 1>
+__device__ __forceinline__ void ditPacked(v2 (&c)[NREG])
+{
+    if constexpr (FIRST <= 1) ditStagePacked<LR, 1, BASE>(c);
+    if constexpr (FIRST <= 2 && LR >= 2) ditStagePacked<LR, 2, BASE>(c);
+    if constexpr (LR >= 3) ditStagePacked<LR, 3, BASE>(c);
+    if constexpr (LR >= 4) ditStagePacked<LR, 4, BASE>(c);
+    if constexpr (LR >= 5) ditStagePacked<LR, 5, BASE>(c);
+}
+
 }  // namespace sgz

@@ -56,7 +56,8 @@ struct RealParams {
     // 2 pi (2c + 1) / N for the 1024 columns; the step to a column's next sample pair is a compile-time rotation.  Null: fetch.
     const float4 *winPhase; float winP0, winP1;
     const float2 *tw1;        // [3 + R1/4 - 1][1024]  pass-1 twiddles W_{N/2}^{c q}
-    const float2 *tw2;        // [10][32]  (the whole-frame kernels' pass-2 table)
+    const float2 *tw2;        // [10][32]  (the whole-frame kernels' pass-2 table: N = 16384 builds the other rows as products)
+    const float4 *tw2Full;    // N >= 32768: all 32 rows [32][32] float2, copied to LDS by every workgroup (one twiddle = one ds_read_b64)
     const float2 *twPost;     // [R1 * 32]  W_N^{kc}
     const PixelRec *recs; const float *weights;
     // the chunk-scan pixel map (chunk_map.hpp; plan.cpp buildChunkMap): per side, [T] end bits, [T] slot bases, [P] records

@@ -665,7 +665,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     }
     // the window evaluated inside the kernels (Hann / Hamming, periodic, W == N): w[n] = a0 - a1 cos(2 pi n / N)
     const bool cosWindow = (cfg.window_type == SGZ_WIN_HANN || cfg.window_type == SGZ_WIN_HAMMING) && cfg.window_symmetry == SGZ_WIN_PERIODIC &&
-                           p.W == p.N && !std::getenv("SGZ_FETCH_WINDOW");
+                           p.W == p.N;
     if (cosWindow) {
         p.winP0 = cfg.window_type == SGZ_WIN_HANN ? 0.5f : 0.54f;
         p.winP1 = cfg.window_type == SGZ_WIN_HANN ? -0.5f : -0.46f;
@@ -732,8 +732,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
     // Every eligible plan takes it.  Measured on MI355X (tools/ka_time.py, tools/hybrid_probe.py), since the pair exchange stopped costing
     // cache maintenance: N = 65536 (cfg5, 32 pairs) 693 us per K_A pass against 1199 us for the half-frame kernels + map kernel;
     // N = 32768 (cfg2, 348 frames = 696 channel workgroups, two per CU) 38.2 us against 44.0 us for the whole-frame kernel; N = 16384
-    // 6.9 M against 2.9 M transforms/s for the generic passes.  SGZ_CHANNEL_SPLIT=0 keeps a plan off it (A/B runs).
-    if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realSplit = false; }
+    // 6.9 M against 2.9 M transforms/s for the generic passes.  sgz_plan_set_option(SGZ_OPT_CHANNEL_SPLIT, 0) keeps a plan off it (A/B runs, parity tests against the other kernels).
     // The mono modes transform ONE real signal per task: the same kernel, one workgroup per (frame, pair), no pair exchange.  It holds
     // csf[0 .. N/2] as magnitudes (csf[N/2] = X[N/2] / 2 is real for a real signal: arg-max runs may end on it) and the kSpecBins entries
     // of complex_dc.hpp the reference leaves complex (csf[N-8 .. N-1] = conj X[8 .. 1], csf[N/2 .. N/2+7]); csf[N] is 0 in these modes.
@@ -767,7 +766,6 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         const size_t ldsFloats = size_t(M + 1) + size_t((M + 1) >> 5) + 2;
         const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16 - 2 * 16 * 4;     // (2 x kSpecBins floats of complex entries)
         if (p.items.size() * 4 > budget) p.realMono = false;
-        if (const char *e = std::getenv("SGZ_CHANNEL_SPLIT")) { if (e[0] == '0') p.realMono = false; }
     }
     p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0;
     if (p.realSplit && lowFix[0].size() + lowFix[1].size() > 128) p.realSplit = false;      // (one thread settles them)
@@ -795,8 +793,8 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         const bool ok = buildChunkMap(p, p.recsReal.empty() ? p.recs : p.recsReal, p.realSplit ? 2 : 1);
         const size_t Mh = p.N / 2, Tt = Mh / 32;
         const size_t sFloats = size_t(chunkPos(int(Mh))) + 32;
-        const size_t extra = std::max<size_t>(size_t(std::max(p.chunkSlots[0], p.chunkSlots[1])) + 1 + Tt, p.N >= 32768 ? 2048 : 0);
-        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - 1024;    // (1 KB of static LDS)
+        const size_t extra = std::max<size_t>(size_t(std::max(p.chunkSlots[0], p.chunkSlots[1])) + 1 + Tt, p.N >= 32768 ? 2048 : 0) + 64;   // (+ column 0's scratch)
+        const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024;    // (the kernels have no static LDS)
         if (!ok || (sFloats + extra + (p.realMono ? 2 * 16 : 0)) * 4 > budget) { p.realSplit = false; p.realMono = false; p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0; }
     }
     if (p.realSplit || p.realMono) {
@@ -830,6 +828,16 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                     const double ang = -kTwoPi * double(m) / 1024.0;
                     p.tw2[(size_t(row) * R + t2) * 2 + 0] = float(std::cos(ang));
                     p.tw2[(size_t(row) * R + t2) * 2 + 1] = float(std::sin(ang));
+                }
+        }
+        p.tw2Full.clear();
+        if (p.N >= 32768) {
+            p.tw2Full.resize(size_t(32) * 32 * 2);
+            for (uint32_t q = 0; q < 32; ++q)
+                for (uint32_t c = 0; c < 32; ++c) {
+                    const double ang = -kTwoPi * double((q * c) % 1024u) / 1024.0;
+                    p.tw2Full[(size_t(q) * 32 + c) * 2 + 0] = float(std::cos(ang));
+                    p.tw2Full[(size_t(q) * 32 + c) * 2 + 1] = float(std::sin(ang));
                 }
         }
         p.twRealPost.resize(size_t(T) * 2);

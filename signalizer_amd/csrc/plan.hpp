@@ -96,6 +96,7 @@ struct Plan {
     std::vector<float> winPhaseT;       // fused whole-frame kernel, same idea: (cos, sin) of 2 pi t / N, t < R^2
     std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
     std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
+    std::vector<float> tw2Full;         // channel-split kernels, N >= 32768: the whole pass-2 table W_1024^{c q}, [q < 32][c < 32] (re, im), staged in LDS
     // Chunk-scan pixel map of the channel-split kernels (chunk_map.hpp, built by buildChunkMap): a side's M magnitudes are cut into
     // T chunks of 32 consecutive entries, one per thread; the arg-max runs of >= 2 entries ("tiles") are segments of a segmented
     // running maximum inside the chunks.
@@ -105,6 +106,8 @@ struct Plan {
     std::vector<float> weights12;       // [interpolated pixel][12]: its taps as 12 contiguous floats of the padded array (0 on pad slots and behind the last tap)
     uint32_t chunkSlots[2] = {0, 0};    // tile maxima per side
     DeviceScalars scalars{};
+    // sgz_plan_set_option
+    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false;
 
     // device mirrors (owned)
     bool uploaded = false;
@@ -128,6 +131,7 @@ struct Plan {
     size_t hostAudioCap = 0, hostRgbaCap = 0, hostLinesCap = 0;
     void *hostStream = nullptr;                           // hipStream_t / hipEvent_t (this header is also compiled as plain C++)
     void *hostEv[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *d_tw2Full = nullptr;
     float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr, *d_winPhaseT = nullptr;
     uint32_t *d_chunkEnds = nullptr, *d_chunkReBase = nullptr, *d_chunkRec = nullptr; float *d_weights12 = nullptr;
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel

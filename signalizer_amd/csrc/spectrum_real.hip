@@ -29,9 +29,8 @@
 #include <algorithm>
 
 #include "chunk_map.hpp"
-#ifndef SGZ_ABL
-#define SGZ_ABL 0      // (ablation builds for measurements only: tools/ablate_builds.sh)
-#endif
+#include "fft_scalar.hpp"
+#include "fft_scalar.hpp"
 
 #ifdef SGZ_DEBUG
 #define RCLK(slot)                                                                                                     \
@@ -56,6 +55,14 @@ struct ChannelIndex {
 // contiguous floats from its first entry)
 constexpr int realXFloats(int M) { return (chunkPos(M) + 1 + 16 + 1) & ~1; }
 
+// floats behind the magnitudes that change hands during a workgroup's life: the pass-2 twiddle table (N >= 32768: 32 x 32 float2),
+// later the map's tile maxima (slots + 1) and chunk maxima (T)
+constexpr size_t realExtraFloats(uint32_t maxSlots, uint32_t T, bool tw2InLds)
+{
+    const size_t a = size_t(maxSlots) + 1 + T, b = tw2InLds ? 2048 : 0;
+    return a > b ? a : b;
+}
+
 // |X[k]| of the real-input transform from a = Z[k], b = Z[M - k] and w = W_N^k = (cos, -sin):
 //   2 X = (a + conj b) - i w (a - conj b)
 __device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
@@ -69,12 +76,12 @@ __device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
 }
 
 // the R1-point DIFs of a thread's U = R / R1 columns (registers [u R1, (u + 1) R1))
-template <int R, int R1, int U, int u = 0>
+template <int R, int R1, int U, int LR1, int u = 0>
 __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
 {
     if constexpr (u < U) {
-        difPacked<R, R1, u * R1>(c);
-        pass1Columns<R, R1, U, u + 1>(c);
+        ditPacked<LR1, u * R1>(c);
+        pass1Columns<R, R1, U, LR1, u + 1>(c);
     }
 }
 
@@ -101,12 +108,10 @@ __device__ __forceinline__ void realMapSettle(const RealParams &prm, float *lds,
     // workgroup only leaves what that kernel needs in HBM -- its Nyquist bin (ny, stored by the transform), its lowest bins, and (from the
     // map) the winning squares of its top pixels, whose values so far ignore csf[N/2] (0 in its place can never win: strict >).
     // (Until round 3 the two channel workgroups of a frame settled these pixels between themselves with flags in fine-grained memory:
-    // three dependent memory round trips at the end of every workgroup, 1.5 us of a 37 us launch, tools/ablate_builds.sh.)
+    // three dependent memory round trips at the end of every workgroup: 1.5 us of a 37 us launch in an ablation build.)
     if (!MONO && (prm.lowCount[0] + prm.lowCount[1]) && tid < kLowBins) prm.low[size_t(self) * kLowBins + tid] = lds[at(side ? N - tid : tid)];
     RCLK(8);
-#if SGZ_ABL != 5
     mapper.run(tb, at, lds, re, ce, prm.invSize, tid);
-#endif
     RCLK(9);
     if (MONO) {
         // the pixels whose tap windows leave the magnitudes (wrap below bin 0: csf[N - j] = conj X[j], csf[N] = 0; or reach csf[N/2 ..]):
@@ -136,7 +141,6 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     constexpr int PADSTRIDE = chunkPos(T);              // padded distance between k and k + T
     constexpr int TILE = R * (R + 1);
     constexpr int XFLOATS = realXFloats(M);             // this side's |X| array (padded) -- the map's tile and chunk maxima follow it
-    constexpr int SCRATCH = XFLOATS;                    // column 0's 2R floats live where the tile maxima will be written later
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
@@ -176,10 +180,17 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     float *re = lds + XFLOATS, *ce = re + maxSlots + 1;
     // mono modes: the kSpecBins csf entries the reference leaves complex (complex_dc.hpp), behind the maxima; written during the
     // recombination (nothing else uses the area), read by the pixels of prm.lowPixels after the mapping
-    float *spec = ce + T;
+    // behind them (and behind the pass-2 twiddle table, which shares their place but is still being read by slow waves when fast ones
+    // are past pass 3): column 0's 2R floats of scratch, then the mono modes' complex entries
+    const int SCRATCH = XFLOATS + int(realExtraFloats(maxSlots, T, LR1 >= 4));
+    float *spec = lds + SCRATCH + 2 * R;
     ChunkMap<T> mapper;
 
     RCLK(0);
+    if constexpr (LR1 >= 4) {
+        // the pass-2 twiddle table -> LDS (8 KB behind the exchange areas; the map's maxima take the place later)
+        if (tid < 512) reinterpret_cast<float4 *>(lds + XFLOATS)[tid] = prm.tw2Full[tid];
+    }
     v2 c[R];
     {
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (WCOS && SGZ_ABL != 3) {
+        if (WCOS) {
             // w[n] = p0 + p1 cos(theta_n), theta_n = 2 pi n / N, n = 2 (col + R^2 j) + e: theta = phi(col, e) + 2 pi j / R1 -- the phase of the
             // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
 #pragma unroll
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
                     c[i] = v2{c[i].x * (prm.winP0 + prm.winP1 * ce), c[i].y * (prm.winP0 + prm.winP1 * co)};
                 }
             }
-        } else if (SGZ_ABL != 3) {
+        } else {
             // the window in batches of B pairs, two batches in flight
             constexpr int B = LR1 >= 4 ? 4 : 8;
             float2 wa[B], wb[B];
@@ -257,9 +268,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     __builtin_amdgcn_sched_barrier(0);
     RCLK(13);
     // -------------------------------------------------------------------------- pass 1: radix R1 per column, times W_M^{c q1}
-#if SGZ_ABL != 7
-    pass1Columns<R, R1, U>(c);
-#endif
+    pass1Columns<R, R1, U, LR1>(c);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         constexpr int NB = R1 / 4 - 1;
@@ -287,7 +296,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     RCLK(1);
     // -------------------------------------------------------------------------- exchange 1: two rounds of R1 x 512 complex values
-    if (SGZ_ABL != 9) {
+    {
         v2 *lds2 = reinterpret_cast<v2 *>(lds);
         auto writeRound = [&](int r) {
 #pragma unroll
@@ -317,19 +326,21 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ldsBarrier();                                                        // every wave has read exchange 1: the tiles may overwrite it
     RCLK(2);
     // -------------------------------------------------------------------------- pass 2 (c_lo = ix): radix R over c_hi
-#if SGZ_ABL != 8
-    difPacked<R, R, 0>(c);
-#endif
-    {
+    ditPacked<LR, 0>(c);
+    if constexpr (LR1 >= 4) {
+        // times W_1024^{c_lo q2}: the whole table sits in LDS behind the exchange areas (copied at the start of the kernel) -- one
+        // ds_read_b64 and one complex product per value, instead of 10 fetched rows and 21 products to build the other 21
+        const v2 *tab = reinterpret_cast<const v2 *>(lds + XFLOATS) + ix;
+#pragma unroll
+        for (int q = 1; q < R; ++q) c[brev(q, LR)] = cmul(c[brev(q, LR)], tab[q * R]);
+    } else {
         TwFactors<LR> tw;
         tw.load(prm.tw2, ix, R);
-#if SGZ_ABL != 2
         tw.apply(c);
-#endif
     }
     RCLK(3);
     // -------------------------------------------------------------------------- exchange 2: wave-local R x R transposes
-    if (SGZ_ABL != 6) {
+    {
         const int tile = group * TILE;
 #pragma unroll
         for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].x;
@@ -351,9 +362,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(4);
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
     const float2 wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
-#if SGZ_ABL != 1
-    difPacked<R, R, 0>(c);
-#endif
+    ditPacked<LR, 0>(c);
     RCLK(5);
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
     const int kc = q1 + R1 * ix;
@@ -410,12 +419,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const float ex = a.x + b.x, ey = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
             const float ox = w.x * dy + w.y * dx, oy = w.y * dy - w.x * dx;      // -i w (dx + i dy)
             const float pr = ex + ox, pi = ey + oy, mr = ex - ox, mi = ey - oy;
-#if SGZ_ABL == 4
-            magA[m3] = a.x + b.x; magB[m3] = a.y + b.y + w.x;
-#else
             magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
             magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(mr * mr + mi * mi);
-#endif
             if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
                 // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
                 // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
@@ -592,7 +597,7 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     const uint32_t M = N / 2, T = M / 32;
     const uint32_t maxSlots = std::max(prm.chunkSlots[0], prm.chunkSlots[1]);
     // magnitudes, then the map's tile / chunk maxima (the same floats hold column 0's scratch during the recombination), then (mono) the complex entries
-    const size_t ldsBytes = (size_t(realXFloats(int(M))) + std::max<size_t>(size_t(maxSlots) + 1 + T, 64) + (mono ? 2 * kSpecBins : 0)) * 4;
+    const size_t ldsBytes = (size_t(realXFloats(int(M))) + realExtraFloats(maxSlots, T, N >= 32768) + 64 + (mono ? 2 * kSpecBins : 0)) * 4;
     static size_t granted[27][64] = {};
     const bool wcos = prm.winPhase != nullptr;
     if (prm.binsIn) {

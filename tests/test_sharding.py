@@ -30,6 +30,27 @@ def test_partition_covers_every_global_frame_once(world, S, W, hop):
     assert sps[-1].halo == 0
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("S,W,hop", [(2880000, 32768, 8192), (5760000, 65536, 16384), (1920000, 65536, 16384), (10000, 4096, 1000), (4096, 4096, 4096)])
+def test_c_abi_shard_layout_equals_shard_plan(world, S, W, hop):
+    """sgz_shard_layout (csrc/sharded.hip: the partition sgz_spectrogram_render_sharded runs on) against ShardPlan (the Python twin the
+    gloo test and bench.py's torch path run on), over the same sweep: frames, first frame, halo in / out of every rank.  Host arithmetic
+    only -- no GPU."""
+    import ctypes as C
+    from signalizer_amd import api
+    cfg = config.spectrum_config(window_size=W, hop=hop, sample_rate=96000.0)
+    plan = api.Plan(cfg)
+    halos = [ShardPlan(r, world, S, W, hop).halo for r in range(world)]
+    for r in range(world):
+        sp = ShardPlan(r, world, S, W, hop)
+        vals = [C.c_uint64() for _ in range(4)]
+        api.check(api.lib().sgz_shard_layout(plan.h, r, world, S, *[C.byref(v) for v in vals]))
+        local, first, halo_in, halo_out = [int(v.value) for v in vals]
+        assert (local, first) == (sp.local_frames, sp.first_frame(r)), (r, local, first)
+        assert halo_in == sp.halo, (r, halo_in, sp.halo)
+        assert halo_out == (halos[r - 1] if r > 0 else 0), (r, halo_out)
+
+
 def test_bench_workload_partition():
     sp = [ShardPlan(r, 8, 2880000, 32768, 8192) for r in range(8)]
     assert [s.local_frames for s in sp] == [352, 352, 351, 352, 351, 352, 351, 348]

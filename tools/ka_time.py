@@ -1,6 +1,6 @@
 """K_A timing loop for kernel work: average launch duration (HIP events on the launch stream) of sgz_stage_mapped at
 cfg2 (348 frames, 2 rounds on 256 CUs) and at a tail-free size (8 pairs x 348 = 2784 tasks), plus the whole step.
-usage: [SGZ_CHANNEL_SPLIT=0|1] ka_time.py [iters]     (the variable forces / forbids the channel-split kernel where eligible)"""
+usage: [SGZ_WHOLE_FRAME=1] ka_time.py [iters]     (SGZ_WHOLE_FRAME=1: plan option SGZ_OPT_CHANNEL_SPLIT = 0, the whole-frame / halves kernels)"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,7 +27,9 @@ def main():
         sr = int(cfg["sample_rate"])
         S = int(config.CFG2_SECONDS * 48000) if name != "cfg5_20s" else 20 * sr
         x = torch.from_numpy(synth.gen(2, sr, S, 2 * pairs)).cuda()
-        plan = api.Plan(cfg).upload()
+        plan = api.Plan(cfg)
+        if os.environ.get('SGZ_WHOLE_FRAME') == '1': plan.set_option(api.OPT_CHANNEL_SPLIT, 0)
+        plan.upload()
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream

@@ -2,6 +2,7 @@
 // with and without the inter-pass twiddles.  512-thread workgroups, two per CU, time of the whole launch / iterations.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <vector>
 #include "../../signalizer_amd/csrc/fft_common.hpp"
 #include "../../signalizer_amd/csrc/fft_scalar.hpp"
@@ -23,6 +24,7 @@ __global__ void __launch_bounds__(512, 4) k(float *out, const float *in, int ite
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) difPacked<R, R, 0>(c);
         if (MODE == 1) ditScalar<5, 0>(c);
+        if (MODE == 4) ditPacked<5, 0>(c);
         if (MODE == 2) { difPacked<R, R, 0>(c); tw.apply(c); }
         if (MODE == 3) {
             ditScalar<5, 0>(c);
@@ -70,5 +72,16 @@ int main()
     run<1>("ditScalar<5>", out, in);
     run<2>("difPacked + TwFactors", out, in);
     run<3>("ditScalar + 31 cmul (LDS)", out, in);
+    run<4>("ditPacked<5>", out, in);
+    // numerics: the three forms on the same input
+    {
+        std::vector<float> a(512 * 512), b(512 * 512), c2(512 * 512);
+        hipLaunchKernelGGL(k<0>, dim3(512), dim3(512), 0, 0, out, in, 1); hipMemcpy(a.data(), out, a.size() * 4, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k<1>, dim3(512), dim3(512), 0, 0, out, in, 1); hipMemcpy(b.data(), out, b.size() * 4, hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k<4>, dim3(512), dim3(512), 0, 0, out, in, 1); hipMemcpy(c2.data(), out, c2.size() * 4, hipMemcpyDeviceToHost);
+        double d1 = 0, d2 = 0, mx = 0;
+        for (size_t i = 0; i < a.size(); ++i) { d1 = fmax(d1, fabs(a[i] - b[i])); d2 = fmax(d2, fabs(a[i] - c2[i])); mx = fmax(mx, fabs(a[i])); }
+        printf("checksum differences vs difPacked: scalar DIT %.3g, packed DIT %.3g (max |sum| %.3g)\n", d1, d2, mx);
+    }
     return 0;
 }
