@@ -84,6 +84,37 @@ def cpu_baseline(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
             "sample": f"first {nfr} of 348 frames of the same 60 s stereo buffer, oracle/libsgz_oracle.so (gcc -O3, strict fp), 1 thread of {os.cpu_count()}"}
 
 
+def cpu_baseline_pairs(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
+    """cfg5's CPU baseline: the reference parallelises across stereo pairs only (SpectrumDSP.cpp:83), so the
+    oracle runs one thread per pair, min(pairs, cores) at a time (ctypes releases the GIL around the C calls), each on its own pair's
+    two channels; the cross-pair colour blend (SpectrumDSP.cpp:177-180, a few operations per pixel) is left out of the timed sample."""
+    import concurrent.futures as cf
+    from oracle import pyoracle as po
+    pairs = cfg["num_pairs"]
+    cores = os.cpu_count() or 1
+    threads = max(1, min(pairs, cores))
+    one = dict(cfg, num_pairs=1)
+    p = po.params_from_dict(one)
+    W, hop = cfg["window_size"], cfg["hop"]
+    total = (x.shape[1] - W) // hop + 1
+
+    def job(pair, nfr):
+        po.spectrogram_range(p, np.ascontiguousarray(x[2 * pair:2 * pair + 2]), 0, nfr)
+
+    t0 = time.perf_counter()
+    job(0, 2)
+    per = (time.perf_counter() - t0) / 2                        # seconds per (frame, pair) on one thread
+    rounds = -(-pairs // threads)
+    nfr = int(max(2, min(total, budget_s / max(per * rounds, 1e-6))))
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda pr: job(pr, nfr), range(pairs)))
+    dt = time.perf_counter() - t0
+    return {"value": nfr / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"first {nfr} of {total} frames of all {pairs} pairs of the same 60 s buffer, oracle/libsgz_oracle.so (gcc -O3, strict fp), "
+                      f"one thread per pair, {threads} at a time, of {cores} cores; the cross-pair colour blend is not in the sample"}
+
+
 class CAbiShard:
     """this rank's share of the job through sgz_spectrogram_render_sharded on an RCCL communicator of its own (the ids travel over
     torch.distributed, which is only the launcher's rendezvous here)"""
@@ -123,7 +154,7 @@ class CAbiShard:
         self.api.lib().sgz_comm_destroy(self.comm)
 
 
-def views_workload(args, rank, world, dev) -> None:
+def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True):
     """BASELINE configs[2] (Oscilloscope) / configs[3] (Vectorscope) through the real-time handles, the way the plugin would drive
     them: per rendered frame (60 Hz) the audio thread's callbacks (512 samples each, host buffers in) and then the render thread's
     calls (peak filter, vertices of every channel / pair, host buffers out).  The handles own their streams and `vertices` waits for
@@ -133,7 +164,8 @@ def views_workload(args, rank, world, dev) -> None:
     import torch
     from signalizer_amd import api, synth
     L = api.lib()
-    scope = args.workload == "cfg3"
+    scope = (workload or args.workload) == "cfg3"
+    nsteps = steps or args.steps
     if scope:
         sr, W, nch = 192000.0, 19200, 2
         per_frame = int(sr / 60)
@@ -184,7 +216,7 @@ def views_workload(args, rank, world, dev) -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(nsteps):
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -225,8 +257,8 @@ def views_workload(args, rank, world, dev) -> None:
         out = {
             "metric": ("oscilloscope vertices/sec: Lanczos-10 8x resample + zero-crossing trigger, stereo 192 kHz, 100 ms window" if scope else
                        "vectorscope vertices/sec: L/R -> polar + envelope decay, 8-channel 96 kHz, 100 ms window"),
-            "value": units * world * args.steps / dt, "unit": "vertices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 kernel weights)" if scope else "f32",
+            "value": units * world * nsteps / dt, "unit": "vertices/s", "n_gpus": world, "steps": nsteps, "warmup": args.warmup,
+            "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 kernel weights)" if scope else "f32",
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: Oscilloscope, stereo 192 kHz, 19 200-sample window, zero-crossing trigger at 0.05, "
                                     "Lanczos-10 at 8 points per sample (153 601 vertices per channel), peak-decay envelope" if scope else
@@ -234,13 +266,17 @@ def views_workload(args, rank, world, dev) -> None:
                        "step": "one rendered frame at 60 Hz through the real-time handle: 1/60 s of audio in 512-sample callbacks from host buffers "
                                "(one staged copy + one kernel each), then peak filter and the vertices of every channel / pair into host buffers",
                        "parallelism": "replicas only" if world > 1 else "single device", "vertices_per_step": units,
-                       "realtime_factor": (1 / 60) / (dt / args.steps), "pushes_refused_busy": refused},
+                       "realtime_factor": (1 / 60) / (dt / nsteps), "pushes_refused_busy": refused},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
                          "note": "a few MB per launch: the kernel is bound by its launch latency and (scope) its fp64 weight arithmetic, not by HBM"},
         }
-        print(json.dumps(out), flush=True)
+        if emit:
+            print(json.dumps(out), flush=True)
+    else:
+        out = None
     h.close()
+    return out
 
 
 def main() -> None:
@@ -453,8 +489,18 @@ def main() -> None:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
         if "two_in_flight" in extra:
             out["config"]["two_in_flight"] = extra["two_in_flight"]
-        if not args.no_cpu_baseline and world == 1 and not strong:
-            out["cpu_baseline"] = cpu_baseline(cfg, x_host)
+        if world == 1 and not strong and not args.no_extras:
+            # BASELINE configs[2] / configs[3] on the same box, so that the driver's record of this run holds them too (their own lines:
+            # --workload cfg3 / cfg4)
+            out["extras"] = {}
+            for w in ("cfg3", "cfg4"):
+                v = views_workload(args, 0, 1, dev, workload=w, steps=120, emit=False)
+                out["extras"][w] = {"metric": v["metric"], "value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"],
+                                    "vertices_per_step": v["config"]["vertices_per_step"], "realtime_factor": v["config"]["realtime_factor"],
+                                    "pushes_refused_busy": v["config"]["pushes_refused_busy"], "kernel": v["roofline"]["kernel"],
+                                    "kernel_ms": v["roofline"]["kernel_ms"], "roofline_frac": v["roofline"]["frac"]}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_pairs(cfg, x_host) if strong else cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)
     if world > 1:
         if shard is not timer:

@@ -262,6 +262,24 @@ sgz_status sgz_shard_layout(const sgz_plan *plan, uint32_t rank, uint32_t world,
 sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint32_t rank, uint32_t world, float *d_chunk,
                                           size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
                                           void *stream);
+/* The same render on the caller's own transport: the three collectives of the protocol as plain functions (counts in floats, device
+ * pointers, 0 = success).  Each is ordered on `stream` the way ncclSend / ncclRecv / ncclAllGather are -- work queued on the stream
+ * before the call is visible to it, work queued after it sees its result; an implementation may simply synchronise the stream and
+ * move the data on the host.  Between group_begin and group_end (both optional) the send and the recv of one exchange are issued
+ * back to back and must not deadlock on each other; abort (optional) is called when this rank fails while its peers may already be
+ * waiting in a collective (ncclCommAbort on RCCL).  sgz_spectrogram_render_sharded is this call on RCCL. */
+typedef struct sgz_transport {
+    void *ctx;
+    int (*send)(void *ctx, const float *d_buf, size_t count, uint32_t peer, void *stream);
+    int (*recv)(void *ctx, float *d_buf, size_t count, uint32_t peer, void *stream);
+    int (*allgather)(void *ctx, const float *d_send, float *d_recv /*[world][count]*/, size_t count, void *stream);
+    int (*group_begin)(void *ctx);
+    int (*group_end)(void *ctx);
+    void (*abort)(void *ctx);
+} sgz_transport;
+sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport *transport, uint32_t rank, uint32_t world, float *d_chunk,
+                                             size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
+                                             void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Real-time per-block path: replaces Spectrum::ProcessorShell::onStreamAudio (SpectrumDSP.cpp:210-216)

@@ -43,6 +43,8 @@ Plan::~Plan()
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
         if (p) (void)hipFree(p);
     for (void *e : hostEv) if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    for (void *e : shardEv) if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    if (shardStream) (void)hipStreamDestroy(static_cast<hipStream_t>(shardStream));
     if (hostStream) (void)hipStreamDestroy(static_cast<hipStream_t>(hostStream));
 }
 

@@ -136,6 +136,7 @@ struct Plan {
     uint32_t *d_chunkEnds = nullptr, *d_chunkReBase = nullptr, *d_chunkRec = nullptr; float *d_weights12 = nullptr;
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
+    void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;
 

@@ -2,17 +2,23 @@
 // of the stream and every frame whose first sample lies in it.  The same protocol as signalizer_amd/sharding.py, on the host's own
 // RCCL communicator, so that a C++ host needs neither torch nor Python:
 //   A1  halo: ncclSend of this rank's leading samples to rank - 1 / ncclRecv of rank + 1's (exactly the samples the last frames
-//       reach into the next chunk: W - hop when hop divides the chunk), one grouped pair -- each transfer rides one xGMI link;
-//   K_A over the local frames; K_B scan from a zero carry-in -> this rank's end state;
+//       reach into the next chunk: W - hop when hop divides the chunk), one grouped pair -- each transfer rides one xGMI link.
+//       It runs on a stream of its own WHILE K_A transforms the frames that lie inside the chunk (all but the last
+//       ceil((W - hop) / hop) = 3 at 75 % overlap); only those last frames wait for it;
+//   K_A over the local frames (two launches: inside the chunk / reaching into the halo); K_B scan from a zero carry-in -> end state;
 //   A2  ncclAllGather of the end states (pairs x graphs x P x 2 floats per rank) -> exact carry fold (decayFoldKernel);
 //   K_B emit with the carry folded into the kept aggregates.
+// The three collectives go through a small table of functions (sgz_transport, sgz.h): RCCL's by default, the caller's own otherwise --
+// which is also how the tests run this very code with 2-4 ranks sharing one GPU (RCCL refuses that; a host-memory shim does not).
 // RCCL is bound at run time (dlopen): libsgz.so has no link-time dependency on it, and inside a PyTorch process the RCCL that
 // torch already loaded is the one used.  The real-time per-block path stays single-GPU ("replicas only").
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "runtime.hpp"
 
@@ -30,6 +36,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -51,7 +58,7 @@ Rccl *rccl()
         Rccl r;
         r.lib = h;
 #define SGZ_SYM(field, name) *reinterpret_cast<void **>(&r.field) = dlsym(h, name)
-        SGZ_SYM(GetUniqueId, "ncclGetUniqueId"); SGZ_SYM(CommInitRank, "ncclCommInitRank"); SGZ_SYM(CommDestroy, "ncclCommDestroy");
+        SGZ_SYM(GetUniqueId, "ncclGetUniqueId"); SGZ_SYM(CommInitRank, "ncclCommInitRank"); SGZ_SYM(CommDestroy, "ncclCommDestroy"); SGZ_SYM(CommAbort, "ncclCommAbort");
         SGZ_SYM(AllGather, "ncclAllGather"); SGZ_SYM(Send, "ncclSend"); SGZ_SYM(Recv, "ncclRecv");
         SGZ_SYM(GroupStart, "ncclGroupStart"); SGZ_SYM(GroupEnd, "ncclGroupEnd"); SGZ_SYM(GetErrorString, "ncclGetErrorString");
 #undef SGZ_SYM
@@ -133,19 +140,43 @@ sgz_status sgz_shard_layout(const sgz_plan *plan, uint32_t rank, uint32_t world,
     return SGZ_OK;
 }
 
+// ---- RCCL as an sgz_transport
+static int rcclSend(void *ctx, const float *d, size_t n, uint32_t peer, void *stream)
+{
+    return rccl()->Send(d, n, kNcclFloat, int(peer), static_cast<ncclComm_t>(ctx), reinterpret_cast<hipStream_t>(stream));
+}
+static int rcclRecv(void *ctx, float *d, size_t n, uint32_t peer, void *stream)
+{
+    return rccl()->Recv(d, n, kNcclFloat, int(peer), static_cast<ncclComm_t>(ctx), reinterpret_cast<hipStream_t>(stream));
+}
+static int rcclAllGather(void *ctx, const float *d_send, float *d_recv, size_t nPerRank, void *stream)
+{
+    return rccl()->AllGather(d_send, d_recv, nPerRank, kNcclFloat, static_cast<ncclComm_t>(ctx), reinterpret_cast<hipStream_t>(stream));
+}
+static int rcclGroupBegin(void *) { return rccl()->GroupStart(); }
+static int rcclGroupEnd(void *) { return rccl()->GroupEnd(); }
+static void rcclAbort(void *ctx) { if (rccl()->CommAbort) (void)rccl()->CommAbort(static_cast<ncclComm_t>(ctx)); }
+
 sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint32_t rank, uint32_t world, float *d_chunk,
                                           size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
                                           void *stream)
 {
-    if (!plan || !d_chunk || !d_rgba || rank >= world || world == 0 || world > 64) return fail(SGZ_EINVAL, "bad argument");
+    if (!nccl_comm || !rccl()) return fail(SGZ_EHIP, "no RCCL communicator");
+    const sgz_transport t{nccl_comm, rcclSend, rcclRecv, rcclAllGather, rcclGroupBegin, rcclGroupEnd, rcclAbort};
+    return sgz_spectrogram_render_sharded_on(plan, &t, rank, world, d_chunk, channel_stride, chunk_samples, d_rgba, local_frames, stream);
+}
+
+sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport *t, uint32_t rank, uint32_t world, float *d_chunk,
+                                             size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
+                                             void *stream)
+{
+    if (!plan || !t || !t->send || !t->recv || !t->allgather || !d_chunk || !d_rgba || rank >= world || world == 0 || world > 64)
+        return fail(SGZ_EINVAL, "bad argument");
     Plan &p = plan->impl;
     if (!p.uploaded) { std::string err; sgz_status st = uploadPlan(p, err); if (st != SGZ_OK) return fail(st, err); }
     if (p.cfg.channel_mode == SGZ_CH_PHASE)
         return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
-    Rccl *r = rccl();
-    if (!nccl_comm || !r) return fail(SGZ_EHIP, "no RCCL communicator");
-    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Shard sh{chunk_samples, p.W, p.cfg.hop, world};
     const uint64_t frames = sh.framesOf(rank), haloIn = sh.halo(rank), haloOut = rank ? sh.halo(rank - 1) : 0;
@@ -153,35 +184,63 @@ sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint3
     if (channel_stride < chunk_samples + haloIn) return fail(SGZ_EINVAL, "channel_stride must leave room for the halo behind the chunk");
     const uint32_t nch = 2 * p.C;
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+    // a failure on this rank alone, once the peers may be inside a collective: they must fail too, not wait for ever
+    auto bail = [&](sgz_status st) { if (world > 1 && t->abort) t->abort(t->ctx); return st; };
+    auto coll = [&](int e, const char *what) { return e == 0 ? SGZ_OK : bail(fail(SGZ_EHIP, std::string(what) + " failed (transport error " + std::to_string(e) + ")")); };
     // work buffer: [end state][carry][world x end states][halo send][halo recv]
     const size_t need = stateN * (2 + world) + size_t(nch) * (haloOut + haloIn);
     sgz_status st = ensureCap(&p.d_shard, &p.shardCap, need);
-    if (st != SGZ_OK) return st;
+    if (st != SGZ_OK) return bail(st);
     float *d_end = p.d_shard, *d_carry = d_end + stateN, *d_all = d_carry + stateN;
     float *d_send = d_all + stateN * world, *d_recv = d_send + size_t(nch) * haloOut;
-    // A1: neighbour halo
-    if (haloOut) SGZ_HIP(hipMemcpy2DAsync(d_send, haloOut * sizeof(float), d_chunk, channel_stride * sizeof(float), haloOut * sizeof(float),
-                                          nch, hipMemcpyDeviceToDevice, s));
-    if (haloOut || (haloIn && rank + 1 < world)) {
-        SGZ_NCCL(r->GroupStart());
-        if (haloOut) SGZ_NCCL(r->Send(d_send, size_t(nch) * haloOut, kNcclFloat, int(rank) - 1, comm, s));
-        if (haloIn && rank + 1 < world) SGZ_NCCL(r->Recv(d_recv, size_t(nch) * haloIn, kNcclFloat, int(rank) + 1, comm, s));
-        SGZ_NCCL(r->GroupEnd());
+    // the halo's own stream and the two events that tie it to the caller's
+    if (!p.shardStream) {
+        hipStream_t cs; hipEvent_t e0, e1;
+        SGZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        SGZ_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        SGZ_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        p.shardStream = cs; p.shardEv[0] = e0; p.shardEv[1] = e1;
     }
-    if (haloIn && rank + 1 < world)
-        SGZ_HIP(hipMemcpy2DAsync(d_chunk + chunk_samples, channel_stride * sizeof(float), d_recv, haloIn * sizeof(float),
-                                 haloIn * sizeof(float), nch, hipMemcpyDeviceToDevice, s));
-    // K_A + zero-carry scan
+    hipStream_t cs = static_cast<hipStream_t>(p.shardStream);
+    hipEvent_t evFork = static_cast<hipEvent_t>(p.shardEv[0]), evJoin = static_cast<hipEvent_t>(p.shardEv[1]);
+    const bool wantRecv = haloIn && rank + 1 < world;
+    // A1 on the halo stream: pack -> send / recv (one group) -> unpack behind the chunk
+    const bool exchange = haloOut || wantRecv;
+    if (exchange) {
+        if (hipError_t e = hipEventRecord(evFork, s); e != hipSuccess) return bail(hipFail(e, "hipEventRecord"));      // (the chunk is ready when the caller's stream gets here)
+        if (hipError_t e = hipStreamWaitEvent(cs, evFork, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
+        if (haloOut)
+            if (hipError_t e = hipMemcpy2DAsync(d_send, haloOut * sizeof(float), d_chunk, channel_stride * sizeof(float), haloOut * sizeof(float),
+                                                nch, hipMemcpyDeviceToDevice, cs); e != hipSuccess) return bail(hipFail(e, "hipMemcpy2DAsync (halo pack)"));
+        int eb = t->group_begin ? t->group_begin(t->ctx) : 0, es = 0, er = 0;
+        if (eb == 0 && haloOut) es = t->send(t->ctx, d_send, size_t(nch) * haloOut, rank - 1, cs);
+        if (eb == 0 && es == 0 && wantRecv) er = t->recv(t->ctx, d_recv, size_t(nch) * haloIn, rank + 1, cs);
+        const int ee = (eb == 0 && t->group_end) ? t->group_end(t->ctx) : 0;      // (a group that was opened is always closed)
+        if ((st = coll(eb ? eb : es ? es : er ? er : ee, "halo exchange")) != SGZ_OK) return st;
+        if (wantRecv)
+            if (hipError_t e = hipMemcpy2DAsync(d_chunk + chunk_samples, channel_stride * sizeof(float), d_recv, haloIn * sizeof(float),
+                                                haloIn * sizeof(float), nch, hipMemcpyDeviceToDevice, cs); e != hipSuccess) return bail(hipFail(e, "hipMemcpy2DAsync (halo unpack)"));
+        if (hipError_t e = hipEventRecord(evJoin, cs); e != hipSuccess) return bail(hipFail(e, "hipEventRecord"));
+    }
+    // K_A: the frames inside the chunk first (they overlap the exchange), then -- behind the halo -- the frames that reach into it
     if (frames) {
-        st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P);
-        if (st != SGZ_OK) return st;
-        st = runStft(p, d_chunk + sh.localOffset(rank), channel_stride, long(frames), p.d_mapped, nullptr, nullptr, s);
-        if (st != SGZ_OK) return st;
+        if ((st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P)) != SGZ_OK) return bail(st);
+        const uint64_t off = sh.localOffset(rank);
+        uint64_t early = frames;
+        if (wantRecv) early = chunk_samples >= off + p.W ? std::min<uint64_t>(frames, (chunk_samples - off - p.W) / p.cfg.hop + 1) : 0;
+        const size_t perFrame = size_t(p.C) * p.sides * p.P;
+        if (early && (st = runStft(p, d_chunk + off, channel_stride, long(early), p.d_mapped, nullptr, nullptr, s)) != SGZ_OK) return bail(st);
+        if (exchange)
+            if (hipError_t e = hipStreamWaitEvent(s, evJoin, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
+        if (early < frames && (st = runStft(p, d_chunk + off + early * p.cfg.hop, channel_stride, long(frames - early),
+                                            p.d_mapped + early * perFrame, nullptr, nullptr, s)) != SGZ_OK) return bail(st);
+    } else if (exchange) {
+        if (hipError_t e = hipStreamWaitEvent(s, evJoin, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
     }
-    SGZ_HIP(hipMemsetAsync(d_end, 0, stateN * sizeof(float), s));
-    if (frames && (st = runDecayColour(p, p.d_mapped, long(frames), nullptr, nullptr, d_end, s)) != SGZ_OK) return st;
+    if (hipError_t e = hipMemsetAsync(d_end, 0, stateN * sizeof(float), s); e != hipSuccess) return bail(hipFail(e, "hipMemsetAsync"));
+    if (frames && (st = runDecayColour(p, p.d_mapped, long(frames), nullptr, nullptr, d_end, s)) != SGZ_OK) return bail(st);
     // A2: end states of every rank, exact fold of the predecessors
-    SGZ_NCCL(r->AllGather(d_end, d_all, stateN, kNcclFloat, comm, s));
+    if ((st = coll(t->allgather(t->ctx, d_end, d_all, stateN, s), "end-state all-gather")) != SGZ_OK) return st;
     const float *carry = nullptr;
     if (rank > 0) {
         long long fr[64];

