@@ -202,10 +202,8 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                 n += xyz.shape[0]
         else:
             h.peak_filter(1 / 60)
-            n = 0
-            for p in range(nch // 2):
-                xyz, _ = h.vertices(p)
-                n += xyz.shape[0]
+            xyz, _ = h.vertices_all()                              # every pair's vertex stream, one wait for the GPU
+            n = xyz.shape[0] * xyz.shape[1]
         frame += 1
         units = n
 
@@ -264,7 +262,8 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                                     "Lanczos-10 at 8 points per sample (153 601 vertices per channel), peak-decay envelope" if scope else
                                     "BASELINE.json configs[3]: Vectorscope, 8 channels (4 pairs) 96 kHz, 9 600-sample history, peak-decay envelope, fade colours"),
                        "step": "one rendered frame at 60 Hz through the real-time handle: 1/60 s of audio in 512-sample callbacks from host buffers "
-                               "(one staged copy + one kernel each), then peak filter and the vertices of every channel / pair into host buffers",
+                               "(one staged copy + one kernel each), then peak filter and the vertices of every channel / pair into host buffers "
+                               "(vectorscope: sgz_vector_vertices_all, one wait for the four pairs)",
                        "parallelism": "replicas only" if world > 1 else "single device", "vertices_per_step": units,
                        "realtime_factor": (1 / 60) / (dt / nsteps), "pushes_refused_busy": refused},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

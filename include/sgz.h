@@ -488,6 +488,9 @@ sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, do
  * order = the reference's: the older section of the ring ([cursor, size)) first, then [0, cursor). */
 sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *rgb, uint32_t *count);
 sgz_status sgz_vector_vertices_device(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb, uint32_t *count);   /* DEVICE buffers */
+/* every pair's stream with ONE wait for the GPU (the render thread draws all pairs of a frame, VectorscopeRendering.cpp:253-276):
+ * xyz / rgb: float3 [num_channels / 2][window_size]; *count: in = capacity PER PAIR, out = window_size */
+sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32_t *count);
 /* parity hook: history ring memory of one channel + the write cursor */
 sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out /*window_size*/, uint32_t *size, uint32_t *cursor);
 

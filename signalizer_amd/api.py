@@ -125,7 +125,7 @@ EXPORTS = [
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
-    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_history",
+    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
     "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
 ]
@@ -234,6 +234,7 @@ def lib() -> C.CDLL:
     L.sgz_vector_peak_filter.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
     L.sgz_vector_filters_get.argtypes = [vp, C.POINTER(VectorFilters), C.POINTER(C.c_double)]
     L.sgz_vector_vertices.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_vector_vertices_all.argtypes = [vp, vp, vp, C.POINTER(u32)]
     L.sgz_vector_history.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_num_points.argtypes = [C.POINTER(ScopeView)]
     L.sgz_scope_num_points.restype = sz
@@ -588,6 +589,14 @@ class Vector:
         g = C.c_double(0)
         check(lib().sgz_vector_peak_filter(self.h, delta_time, C.byref(g)))
         return g.value
+
+    def vertices_all(self, want_colours: bool = True):
+        n, pairs = self.cfg.window_size, self.cfg.num_channels // 2
+        xyz = np.zeros((pairs, n, 3), np.float32)
+        rgb = np.zeros((pairs, n, 3), np.float32) if want_colours else None
+        cnt = C.c_uint32(n)
+        check(lib().sgz_vector_vertices_all(self.h, _np_ptr(xyz), _np_ptr(rgb) if want_colours else None, C.byref(cnt)))
+        return xyz, rgb
 
     def vertices(self, pair: int = 0, want_colours: bool = True):
         n = self.cfg.window_size

@@ -10,6 +10,8 @@
 // One push = one staged copy + one launch (ring append + the eight one-pole recurrences + the RMS epilogue); push never waits.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 #include <atomic>
@@ -85,7 +87,16 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
             if (lane < 8) {
                 const float *src = sel == 0 ? sL : (sel == 1 ? sR : sP);
                 const int cnt = int(min(64u, np - base));
-                for (int k = 0; k < cnt; ++k) { const float x = src[k]; y = x + a * (y - x); }   // :327-342
+                // (sixteen inputs at a time into registers, then the dependent steps: one LDS round trip per sixteen instead of one per step,
+                // which is what the 22 us of this kernel were)
+                for (int k0 = 0; k0 < cnt; k0 += 16) {
+                    float xs[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xs[j] = src[(k0 + j) & 63];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (k0 + j < cnt) { const float x = xs[j]; y = x + a * (y - x); }                    // :327-342
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -150,12 +161,21 @@ __global__ void __launch_bounds__(256) vectorRampKernel(const VecDev *st, uint32
         const long body = n - V > 0 ? ((n - V + V - 1) / V) * V : 0;        // samples the SIMD loop (i < n - V; i += V) covers
         for (long i0 = 0; i0 < body; i0 += chunk) {
             const long m = body - i0 < chunk ? body - i0 : chunk;
-            if (lane < lanes)
-                for (long i = 0; i < m; i += V) {
-                    buf[i + lane] = f;
-                    lastOut = f - 1.0f;
-                    f += incr;
+            if (lane < lanes) {
+                // (the chain itself -- one dependent fp32 addition per SIMD iteration, 1 200 at cfg4 -- is the reference's; what made this
+                // kernel 37 us was 64-bit index arithmetic and a rolled loop around it: 32-bit indices, unrolled by sixteen)
+                const int steps = int(m / V), stride = int(V);
+                float *dst = buf + lane;
+                int k = 0;
+                float prev = f;
+                for (; k + 16 <= steps; k += 16) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { dst[u * stride] = f; prev = f; f += incr; }
+                    dst += 16 * stride;
                 }
+                for (; k < steps; ++k) { *dst = f; prev = f; f += incr; dst += stride; }
+                if (steps > 0) lastOut = prev - 1.0f;
+            }
             __syncthreads();
             for (long e = lane; e < m; e += 256) ramp[base + size_t(i0 + e)] = buf[e];
             __syncthreads();
@@ -269,9 +289,11 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ring), size_t(C) * size * sizeof(float)));
         SGZ_HIP(hipMemset(s->d_ring, 0, size_t(C) * size * sizeof(float)));
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ramp), size_t(size) * sizeof(float)));
-        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_xyz), size_t(size) * 3 * sizeof(float)));
-        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rgb), size_t(size) * 3 * sizeof(float)));
-        SGZ_HIP(hipHostMalloc(&s->h_out, size_t(size) * 6 * sizeof(float), hipHostMallocDefault));
+        // (room for every pair's stream: sgz_vector_vertices_all renders them with one wait)
+        const size_t pairsCap = std::max<size_t>(1, C / 2);
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_xyz), pairsCap * size * 3 * sizeof(float)));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rgb), pairsCap * size * 3 * sizeof(float)));
+        SGZ_HIP(hipHostMalloc(&s->h_out, pairsCap * size * 6 * sizeof(float), hipHostMallocDefault));
         sgz_status st = s->stage.init(C, maxBlock);
         if (st != SGZ_OK) return st;
         if (!s->d_state) {
@@ -414,6 +436,26 @@ sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *
     SGZ_HIP(hipStreamSynchronize(s->stream));
     std::memcpy(xyz, hx, size_t(size) * 3 * sizeof(float));
     if (rgb) std::memcpy(rgb, hx + size_t(size) * 3, size_t(size) * 3 * sizeof(float));
+    *count = size;
+    return SGZ_OK;
+}
+
+sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32_t *count)
+{
+    if (!s || !xyz || !count) return fail(SGZ_EINVAL, "null argument");
+    const uint32_t size = s->size, pairs = s->cfg.num_channels / 2;
+    if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size per pair)"); }
+    const size_t per = size_t(size) * 3;
+    for (uint32_t p = 0; p < pairs; ++p) {
+        const sgz_status st = vectorVerticesInto(s, p, s->d_xyz + p * per, rgb ? s->d_rgb + p * per : nullptr);
+        if (st != SGZ_OK) return st;
+    }
+    float *hx = static_cast<float *>(s->h_out);
+    SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, pairs * per * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    if (rgb) SGZ_HIP(hipMemcpyAsync(hx + pairs * per, s->d_rgb, pairs * per * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    std::memcpy(xyz, hx, pairs * per * sizeof(float));
+    if (rgb) std::memcpy(rgb, hx + pairs * per, pairs * per * sizeof(float));
     *count = size;
     return SGZ_OK;
 }

@@ -120,3 +120,22 @@ def test_vector_push_rejects_bad_input(gpu):
         dev.push(np.zeros((2, 65), np.float32))
     with pytest.raises(api.SgzError):
         dev.push(np.zeros((4, 8), np.float32))
+
+
+def test_vertices_all_equals_per_pair_calls(gpu):
+    """sgz_vector_vertices_all (every pair's stream, one wait) writes the same floats as one sgz_vector_vertices call per pair"""
+    from signalizer_amd import api
+    sr, W, nch = 96000.0, 2400, 6
+    h = api.Vector(sample_rate=sr, num_channels=nch, window_size=W, envelope_mode=2, lanes=8, fade_history=1, max_block=512,
+                   envelope_window=0.3, stereo_window=0.1, colours=[(1.0, 0.5, 0.25), (0.2, 0.9, 0.4), (0.3, 0.3, 1.0)])
+    x = synth.gen(77, int(sr), 512 * 9 + 100, nch)
+    for pos in range(0, x.shape[1], 512):
+        while h.push(x[:, pos:pos + 512]) == api.SGZ_BUSY:
+            pass
+    h.peak_filter(1 / 60)
+    all_xyz, all_rgb = h.vertices_all()
+    for p in range(nch // 2):
+        xyz, rgb = h.vertices(p)
+        assert np.array_equal(all_xyz[p].view(np.uint32), xyz.view(np.uint32)), p
+        assert np.array_equal(all_rgb[p].view(np.uint32), rgb.view(np.uint32)), p
+    h.close()
