@@ -323,6 +323,17 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                           
 sgz_status sgz_spectrum_set_mix(sgz_spectrum *s, uint32_t num_sources, const uint8_t *matrix /*[2*num_pairs][num_sources]*/);
 /* columns dropped because the queue was full (SpectrumDSP.cpp:185-186) and pushes refused with SGZ_BUSY, since create */
 sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes);
+/* push never waits and never leaves a hole in the stream: a block the GPU is not ready for (all 8 staging slots in flight) waits in a
+ * host FIFO -- one second of audio deep, like the reference's cpl::AudioStream in front of its listeners (PluginProcessor.cpp:195-198,
+ * MixGraphListener.cpp:336-387) -- and is enqueued, in order, by the next push that finds a slot free.  SGZ_BUSY is returned only when
+ * that FIFO is full (or a reconfiguration holds the handle).  deferred_blocks: blocks that ever waited there; waiting_now: its depth.
+ * The same FIFO sits in front of sgz_scope_push and sgz_vector_push. */
+sgz_status sgz_spectrum_backlog(sgz_spectrum *s, uint64_t *deferred_blocks, uint32_t *waiting_now);
+/* enqueue whatever still waits in that FIFO (a stream that ended, a test): may wait for the GPU, so NOT for the audio thread -- and
+ * not while the audio thread pushes (a push that finds the handle held is refused) */
+sgz_status sgz_spectrum_flush(sgz_spectrum *s);
+/* the hipStream_t the handle enqueues its work on (so that a host can order its own device work behind the handle's) */
+void      *sgz_spectrum_stream(sgz_spectrum *s);
 /* the frequency tracker on the newest window of pair `pair` (consumer thread): transforms the device ring's current window and runs
  * sgz_stage_track_peak's search on it */
 sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_fraction, sgz_peak *out);
@@ -417,6 +428,7 @@ void       sgz_scope_destroy(sgz_scope *s);
 sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg);
 /* onStreamAudio(ctx, float** buffer, numChannels, numSamples); the steady clock is the running count of pushed samples */
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
+sgz_status sgz_scope_flush(sgz_scope *s);      /* as sgz_spectrum_flush */
 /* runPeakFilter once per rendered frame: delta_time = openGLDeltaTime(), lanes = the SIMD width whose tail the reference drops
  * (8 = AVX); *auto_gain = state.autoGain (optional; reading it waits for the kernel) */
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain);
@@ -482,6 +494,7 @@ sgz_status sgz_vector_create(const sgz_vector_config *cfg, sgz_vector **out);
 void       sgz_vector_destroy(sgz_vector *s);
 sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg);
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
+sgz_status sgz_vector_flush(sgz_vector *s);    /* as sgz_spectrum_flush */
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain /*optional: reading it waits*/);
 sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain);
 /* xyz: float3 [window_size], rgb: float3 [window_size] or NULL; *count: in = capacity in vertices, out = window_size.  Vertex

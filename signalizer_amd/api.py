@@ -125,7 +125,7 @@ EXPORTS = [
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
-    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_vector_history",
+    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_spectrum_backlog", "sgz_spectrum_stream", "sgz_spectrum_flush", "sgz_scope_flush", "sgz_vector_flush", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
     "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
 ]
@@ -496,7 +496,12 @@ class Scope:
         ptrs = (C.c_void_p * b.shape[0])(*[b[c].ctypes.data for c in range(b.shape[0])])
         return check(lib().sgz_scope_push(self.h, ptrs, b.shape[0], b.shape[1]))
 
+    def flush(self):
+        """blocks that waited for a staging slot are enqueued now (sgz_scope_flush): readers of results call it first"""
+        check(lib().sgz_scope_flush(self.h))
+
     def front(self, channel: int):
+        self.flush()
         size, cur = C.c_uint32(0), C.c_uint32(0)
         check(lib().sgz_scope_front(self.h, channel, None, C.byref(size), C.byref(cur)))
         out = np.zeros(size.value, np.float32)
@@ -504,6 +509,7 @@ class Scope:
         return out, int(cur.value)
 
     def front_colours(self, channel: int, aux: bool = False) -> np.ndarray:
+        self.flush()
         """colour ring memory beside front(channel): uint32 RGBA8 words [size]"""
         size = C.c_uint32(0)
         check(lib().sgz_scope_front(self.h, channel, None, C.byref(size), None))
@@ -512,28 +518,33 @@ class Scope:
         return out
 
     def analyse(self, evaluator: int = 0, channel: int = 0) -> TriggerState:
+        self.flush()
         ts = TriggerState()
         check(lib().sgz_scope_analyse(self.h, evaluator, channel, C.byref(ts)))
         return ts
 
     def state(self) -> dict:
+        self.flush()
         out = np.zeros(8, np.uint64)
         check(lib().sgz_scope_debug_state(self.h, _np_ptr(out)))
         keys = ("frontOrigin", "bufferedSamples", "oldPeak", "currentPeak", "steadyClock", "peaks", "isWorkingOnPeak", "swaps")
         return {k: int(v) for k, v in zip(keys, out)}
 
     def gains(self):
+        self.flush()
         g = C.c_double(0)
         env = np.zeros(self.cfg.num_channels, np.float32)
         check(lib().sgz_scope_gains(self.h, C.byref(g), _np_ptr(env)))
         return g.value, env
 
     def peak_filter(self, delta_time: float, lanes: int = 8) -> float:
+        self.flush()
         g = C.c_double(0)
         check(lib().sgz_scope_peak_filter(self.h, delta_time, lanes, C.byref(g)))
         return g.value
 
     def vertices(self, view: ScopeView, evaluator: int, channel: int = 0, want_colours: bool = True):
+        self.flush()
         n = lib().sgz_scope_vertex_count(self.h, C.byref(view))
         xyz = np.zeros((n, 3), np.float32)
         rgba = np.zeros((n, 4), np.uint8) if want_colours else None
@@ -574,23 +585,31 @@ class Vector:
         ptrs = (C.c_void_p * b.shape[0])(*[b[c].ctypes.data for c in range(b.shape[0])])
         return check(lib().sgz_vector_push(self.h, ptrs, b.shape[0], b.shape[1]))
 
+    def flush(self):
+        """blocks that waited for a staging slot are enqueued now (sgz_vector_flush): readers of results call it first"""
+        check(lib().sgz_vector_flush(self.h))
+
     def history(self, channel: int):
+        self.flush()
         size, cur = C.c_uint32(0), C.c_uint32(0)
         out = np.zeros(self.cfg.window_size, np.float32)
         check(lib().sgz_vector_history(self.h, channel, _np_ptr(out), C.byref(size), C.byref(cur)))
         return out, int(cur.value)
 
     def filters(self):
+        self.flush()
         f, g = VectorFilters(), C.c_double(0)
         check(lib().sgz_vector_filters_get(self.h, C.byref(f), C.byref(g)))
         return f, g.value
 
     def peak_filter(self, delta_time: float) -> float:
+        self.flush()
         g = C.c_double(0)
         check(lib().sgz_vector_peak_filter(self.h, delta_time, C.byref(g)))
         return g.value
 
     def vertices_all(self, want_colours: bool = True):
+        self.flush()
         n, pairs = self.cfg.window_size, self.cfg.num_channels // 2
         xyz = np.zeros((pairs, n, 3), np.float32)
         rgb = np.zeros((pairs, n, 3), np.float32) if want_colours else None
@@ -599,6 +618,7 @@ class Vector:
         return xyz, rgb
 
     def vertices(self, pair: int = 0, want_colours: bool = True):
+        self.flush()
         n = self.cfg.window_size
         xyz = np.zeros((n, 3), np.float32)
         rgb = np.zeros((n, 3), np.float32) if want_colours else None

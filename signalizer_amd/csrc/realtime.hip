@@ -32,6 +32,8 @@
 // (c) an OpenGL buffer object of a context on the same device, registered and mapped through HIP's GL interop
 // (sgz_spectrum_bind_gl_buffer).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <hip/hip_gl_interop.h>
 
 #include <atomic>
@@ -76,9 +78,12 @@ __global__ void __launch_bounds__(256) columnScatterKernel(const uint32_t *colum
 
 struct sgz_spectrum {
     Plan *plan = nullptr;
+    Plan *trackPlan = nullptr;                 // the frequency tracker's own constant block + launch scratch: sgz_spectrum_track_peak runs on the consumer
+                                               // thread while push launches K_A from the producer's -- they must not share a Plan's per-launch buffers
     std::mutex cfgMu;                 // configure (consumer thread) against push (producer, try_lock only)
     hipStream_t stream = nullptr;
     StageRing stage;
+    Backlog backlog;                           // blocks waiting for a staging slot (rt_common.hpp)
     // mirrored rings [2C][2 cap]
     float *d_ring = nullptr;
     uint32_t cap = 0;
@@ -120,6 +125,7 @@ static void freeHandle(sgz_spectrum *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->stage.release();
+    s->backlog.release();
     for (float *p : {s->d_ring, s->d_mapped, s->d_state, s->d_lines, s->d_linesBatch, s->d_trackBins}) if (p) (void)hipFree(p);
     if (s->d_peak) (void)hipFree(s->d_peak);
     unbindImage(s);
@@ -131,6 +137,7 @@ static void freeHandle(sgz_spectrum *s)
     for (auto &e : s->colEvents) if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s->plan;
+    delete s->trackPlan;
     delete s;
 }
 
@@ -144,6 +151,8 @@ static sgz_status uploadMix(sgz_spectrum *s, uint32_t numSources, const uint8_t 
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mix), m.size()));
     SGZ_HIP(hipMemcpy(s->d_mix, m.data(), m.size(), hipMemcpyHostToDevice));
     s->numSources = numSources;
+    // one second of audio may wait for the GPU (at least 32 staging pieces)
+    if (sgz_status st = s->backlog.init(size_t(numSources) * std::max<size_t>(size_t(s->plan->cfg.sample_rate), size_t(32) * kPiece)); st != SGZ_OK) return st;
     return s->stage.init(numSources, kPiece);
 }
 
@@ -158,10 +167,18 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     catch (const std::bad_alloc &) { st = SGZ_ENOMEM; err = "out of memory building the plan tables"; }
     if (st == SGZ_OK) st = uploadPlan(*pl, err);
     if (st != SGZ_OK) { delete pl; return fail(st, err); }
+    Plan *tp = new (std::nothrow) Plan();
+    if (!tp) { delete pl; return fail(SGZ_ENOMEM, "out of memory"); }
+    try { st = buildPlan(*cfg, *tp, err); }
+    catch (const std::bad_alloc &) { st = SGZ_ENOMEM; err = "out of memory building the plan tables"; }
+    if (st == SGZ_OK) st = uploadPlan(*tp, err);
+    if (st != SGZ_OK) { delete pl; delete tp; return fail(st, err); }
     if (!s->stream) SGZ_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     (void)hipStreamSynchronize(s->stream);
     delete s->plan;
     s->plan = pl;
+    delete s->trackPlan;
+    s->trackPlan = tp;
     Plan &p = *pl;
     const size_t nch = size_t(2) * p.C;
     for (float **q : {&s->d_ring, &s->d_mapped, &s->d_state, &s->d_lines, &s->d_linesBatch, &s->d_trackBins}) if (*q) { (void)hipFree(*q); *q = nullptr; }
@@ -247,31 +264,26 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s)
     return SGZ_OK;
 }
 
-sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
+// one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
+static sgz_status spectrumPushNow(sgz_spectrum *s, const float *const *blk, uint32_t nch, uint32_t n)
 {
-    if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
-    std::unique_lock<std::mutex> lk(s->cfgMu, std::try_to_lock);     // never waits: a reconfiguration in progress refuses the block
-    if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
     Plan &p = *s->plan;
-    if (num_channels != s->numSources)
-        return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72), or the source count of sgz_spectrum_set_mix");
-    const uint32_t pieces = (nsamples + kPiece - 1) / kPiece;
-    if (pieces > uint32_t(StageRing::kSlots)) return fail(SGZ_EINVAL, "push takes at most 131072 samples per call");
+    const uint32_t pieces = (n + kPiece - 1) / kPiece;
     // all or nothing: every piece's staging slot must be free now
     for (uint32_t k = 0; k < pieces; ++k) {
         const int slot = int((s->stage.seq + k) % StageRing::kSlots);
-        if (s->stage.used[slot] && hipEventQuery(s->stage.ev[slot]) == hipErrorNotReady) { s->busy++; return SGZ_BUSY; }
+        if (s->stage.used[slot] && hipEventQuery(s->stage.ev[slot]) == hipErrorNotReady) return SGZ_BUSY;
     }
     const uint32_t numDst = 2 * p.C, W = p.W, hop = p.cfg.hop;
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     const float *ptrs[kMaxSources];
-    for (uint32_t done = 0; done < nsamples;) {
-        const uint32_t m = std::min(nsamples - done, kPiece);
-        for (uint32_t c = 0; c < num_channels; ++c) ptrs[c] = planar[c] + done;
+    for (uint32_t done = 0; done < n;) {
+        const uint32_t m = std::min(n - done, kPiece);
+        for (uint32_t c = 0; c < nch; ++c) ptrs[c] = blk[c] + done;
         sgz_status st;
         const float *d_block = s->stage.stage(ptrs, m, s->stream, &st);
         if (!d_block) return st;
-        hipLaunchKernelGGL(ringIngestKernel, dim3((m + 255) / 256, numDst), dim3(256), 0, s->stream, d_block, m, num_channels, s->d_mix,
+        hipLaunchKernelGGL(ringIngestKernel, dim3((m + 255) / 256, numDst), dim3(256), 0, s->stream, d_block, m, nch, s->d_mix,
                            s->d_ring, s->cap, numDst, s->head.load(std::memory_order_relaxed));
         SGZ_HIP(hipGetLastError());
         if ((st = s->stage.commit(s->stream)) != SGZ_OK) return st;
@@ -304,6 +316,38 @@ sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32
         } else s->sinceLast += m;
         s->head.store((s->head.load(std::memory_order_relaxed) + m) % s->cap, std::memory_order_release);
         done += m;
+    }
+    return SGZ_OK;
+}
+
+sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
+{
+    if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
+    std::unique_lock<std::mutex> lk(s->cfgMu, std::try_to_lock);     // never waits: a reconfiguration in progress refuses the block
+    if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
+    Plan &p = *s->plan;
+    if (num_channels != s->numSources)
+        return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72), or the source count of sgz_spectrum_set_mix");
+    if ((nsamples + kPiece - 1) / kPiece > uint32_t(StageRing::kSlots)) return fail(SGZ_EINVAL, "push takes at most 131072 samples per call");
+    auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return spectrumPushNow(s, blk, nch, n); };
+    // never waits: a block the GPU is not ready for queues up behind the earlier ones (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
+    const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
+    if (st == SGZ_BUSY) s->busy++;
+    return st;
+}
+
+sgz_status sgz_spectrum_flush(sgz_spectrum *s)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->cfgMu);
+    const float *ptrs[64];
+    while (s->backlog.count) {
+        const Backlog::Entry e = s->backlog.front();
+        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
+        const sgz_status st = spectrumPushNow(s, ptrs, e.channels, e.n);
+        if (st == SGZ_BUSY) { SGZ_HIP(hipStreamSynchronize(s->stream)); continue; }      // this call may wait: it is not the audio thread's
+        s->backlog.pop();
+        if (st != SGZ_OK) return st;
     }
     return SGZ_OK;
 }
@@ -417,6 +461,17 @@ sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t gr
     return SGZ_OK;
 }
 
+void *sgz_spectrum_stream(sgz_spectrum *s) { return s ? s->stream : nullptr; }
+
+sgz_status sgz_spectrum_backlog(sgz_spectrum *s, uint64_t *deferred_blocks, uint32_t *waiting_now)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->cfgMu);                 // (the FIFO belongs to the producer: looked at under the push lock)
+    if (deferred_blocks) *deferred_blocks = s->backlog.deferred;
+    if (waiting_now) *waiting_now = s->backlog.count;
+    return SGZ_OK;
+}
+
 sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
@@ -428,7 +483,7 @@ sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64
 sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_fraction, sgz_peak *out)
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
-    Plan &p = *s->plan;
+    Plan &p = *s->trackPlan;                                  // (not the producer's plan: see sgz_spectrum::trackPlan)
     if (pair >= p.C) return fail(SGZ_EINVAL, "pair out of range");
     if (!s->d_trackBins) return fail(SGZ_EUNSUPPORTED, "frequency tracker: magnitude modes only");
     // the window a frame firing now would transform (work already enqueued by push precedes this on the stream)

@@ -1,9 +1,12 @@
 // rt_common.hpp -- what the three real-time handles (sgz_spectrum / sgz_scope / sgz_vector) share: a ring of pinned staging slots
-// for the audio thread's blocks.  push() never waits for the GPU (SURVEY.md 8(b) "must never block"): a slot whose previous
-// upload has not completed is detected with hipEventQuery and the block is refused (SGZ_BUSY) instead of waited for.
+// for the audio thread's blocks, and a host FIFO in front of it.  push() never waits for the GPU (SURVEY.md 8(b) "must never
+// block"): a slot whose previous upload has not completed is detected with hipEventQuery, and the block then WAITS ITS TURN in the
+// FIFO (Backlog below) -- the stream the kernels see has no holes, as the reference's cpl::AudioStream FIFO guarantees short of its own
+// overflow (PluginProcessor.cpp:195-198, MixGraphListener.cpp:336-387).  Only a full FIFO refuses a block (SGZ_BUSY).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "runtime.hpp"
@@ -68,5 +71,75 @@ struct StageRing {
         return SGZ_OK;
     }
 };
+
+// Blocks the GPU was not ready for, in arrival order.  Touched by the producer thread only (under the handle's push lock); storage is
+// allocated when the handle is configured, never on the audio thread.  Capacity: `seconds` of audio at the handle's rate (and at
+// least 32 blocks of the largest push) -- with the 8 staging slots that is how far the GPU may fall behind before audio is lost; the
+// reference's stream FIFO has the same kind of bound (its `bufferSize`).
+struct Backlog {
+    static constexpr int kEntries = 256;
+    struct Entry { uint32_t n, channels; size_t off; };
+    float *buf = nullptr;
+    size_t cap = 0, head = 0, tail = 0, used = 0;       // floats; [head, tail) circular, `used` counts the padding skipped at the wrap too
+    Entry ent[kEntries];
+    uint32_t eh = 0, count = 0;
+    uint64_t deferred = 0;                              // blocks that ever waited here
+
+    sgz_status init(size_t floats)
+    {
+        release();
+        buf = static_cast<float *>(std::malloc(floats * sizeof(float)));
+        if (!buf) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
+        cap = floats; head = tail = used = 0; eh = count = 0;
+        return SGZ_OK;
+    }
+    void release() { std::free(buf); buf = nullptr; cap = 0; head = tail = used = 0; eh = count = 0; }
+    void clear() { head = tail = used = 0; eh = count = 0; }
+    bool push(const float *const *planar, uint32_t channels, uint32_t n)
+    {
+        const size_t need = size_t(channels) * n;
+        if (count == kEntries || need > cap) return false;
+        size_t at = tail, pad = 0;
+        if (tail + need > cap) { pad = cap - tail; at = 0; }                    // does not fit behind the tail: start over at the front
+        if (used + pad + need > cap) return false;
+        for (uint32_t c = 0; c < channels; ++c) std::memcpy(buf + at + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
+        ent[(eh + count) % kEntries] = Entry{n, channels, at};
+        ++count; ++deferred;
+        tail = at + need; used += pad + need;
+        return true;
+    }
+    const Entry &front() const { return ent[eh]; }
+    void pop()
+    {
+        const Entry &e = ent[eh];
+        const size_t need = size_t(e.channels) * e.n;
+        const size_t pad = e.off >= head ? e.off - head : cap - head + e.off;   // (the padding skipped when this entry wrapped)
+        head = e.off + need; used -= pad + need;
+        eh = (eh + 1) % kEntries; --count;
+        if (!count) { head = tail = used = 0; }
+    }
+};
+
+// push with the FIFO in front: drain what waited (in order) while the GPU takes it, then the new block -- directly if nothing is waiting
+// and a slot is free, behind the others otherwise.  pushNow(planar, channels, n) is the handle's own enqueue (SGZ_BUSY = no slot free,
+// nothing consumed).
+template <typename PushNow>
+sgz_status pushThroughBacklog(Backlog &bl, const float *const *planar, uint32_t channels, uint32_t n, PushNow pushNow)
+{
+    const float *ptrs[64];
+    while (bl.count) {
+        const Backlog::Entry e = bl.front();
+        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = bl.buf + e.off + size_t(c) * e.n;
+        const sgz_status st = pushNow(ptrs, e.channels, e.n);
+        if (st == SGZ_BUSY) break;
+        bl.pop();
+        if (st != SGZ_OK) return st;
+    }
+    if (!bl.count) {
+        const sgz_status st = pushNow(planar, channels, n);
+        if (st != SGZ_BUSY) return st;
+    }
+    return bl.push(planar, channels, n) ? SGZ_OK : SGZ_BUSY;
+}
 
 }  // namespace sgz

@@ -37,6 +37,8 @@
 // fundamental, runs the median of 8 and the Goertzel phase, and leaves cycleSamples / sampleOffset for the vertex kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -886,6 +888,7 @@ struct sgz_scope {
     std::mutex mu;                    // configure (consumer thread) against push (producer: try_lock only, never waits)
     hipStream_t stream = nullptr;
     StageRing stage;
+    Backlog backlog;                           // blocks waiting for a staging slot (rt_common.hpp)
     ScopeDev *d_state = nullptr;
     unsigned long long *d_peaks = nullptr;
     Swap *d_swaps = nullptr;
@@ -910,6 +913,7 @@ static void scopeFree(sgz_scope *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->stage.release();
+    s->backlog.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_peaks, (void *)s->d_swaps, (void *)s->d_front, (void *)s->d_back, (void *)s->d_xyz,
                     (void *)s->d_rgba, (void *)s->col.st, (void *)s->col.bands, (void *)s->col.sm, (void *)s->col.block, (void *)s->col.front,
                     (void *)s->col.back, (void *)s->d_spectral, (void *)s->d_tw})
@@ -975,6 +979,8 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
         SGZ_HIP(hipMemset(s->d_front, 0, size_t(C) * size * sizeof(float)));
         SGZ_HIP(hipMemset(s->d_back, 0, size_t(C) * backCap * sizeof(float)));
         if ((st = s->stage.init(C, maxBlock)) != SGZ_OK) return st;
+        // one second of audio may wait for the GPU (at least 32 blocks)
+        if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(ScopeDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peaks), size_t(kPeakCap) * sizeof(unsigned long long)));
@@ -1083,6 +1089,24 @@ sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg)
     return scopeSetup(s, cfg, false);
 }
 
+// one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
+static sgz_status scopePushNow(sgz_scope *s, const float *const *blk, uint32_t nch, uint32_t n)
+{
+    sgz_status st;
+    const float *d_block = s->stage.stage(blk, n, s->stream, &st);
+    if (!d_block) return st;
+    IngestParams prm{};
+    prm.st = s->d_state; prm.peaks = s->d_peaks; prm.swapList = s->d_swaps;
+    prm.block = d_block; prm.n = n; prm.channels = nch;
+    prm.front = s->d_front; prm.size = s->size; prm.back = s->d_back; prm.backCap = s->backCap;
+    prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
+    prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
+    prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
+    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->col);
+    SGZ_HIP(hipGetLastError());
+    return s->stage.commit(s->stream);
+}
+
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
 {
     if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
@@ -1091,19 +1115,27 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     if (num_channels != s->cfg.num_channels) return fail(SGZ_EINVAL, "num_channels differs from the configuration");
     if (nsamples == 0) return SGZ_OK;                              // audioEntryPoint returns at once (:403-404)
     if (nsamples > s->stage.maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_scope_config::max_block");
-    sgz_status st;
-    const float *d_block = s->stage.stage(planar, nsamples, s->stream, &st);
-    if (!d_block) { if (st == SGZ_BUSY) s->busy++; return st; }
-    IngestParams prm{};
-    prm.st = s->d_state; prm.peaks = s->d_peaks; prm.swapList = s->d_swaps;
-    prm.block = d_block; prm.n = nsamples; prm.channels = num_channels;
-    prm.front = s->d_front; prm.size = s->size; prm.back = s->d_back; prm.backCap = s->backCap;
-    prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
-    prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
-    prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
-    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->col);
-    SGZ_HIP(hipGetLastError());
-    return s->stage.commit(s->stream);
+    auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return scopePushNow(s, blk, nch, n); };
+    // never waits: a block the GPU is not ready for queues up behind the earlier ones (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
+    const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
+    if (st == SGZ_BUSY) s->busy++;
+    return st;
+}
+
+sgz_status sgz_scope_flush(sgz_scope *s)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    const float *ptrs[64];
+    while (s->backlog.count) {
+        const Backlog::Entry e = s->backlog.front();
+        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
+        const sgz_status st = scopePushNow(s, ptrs, e.channels, e.n);
+        if (st == SGZ_BUSY) { SGZ_HIP(hipStreamSynchronize(s->stream)); continue; }      // this call may wait: it is not the audio thread's
+        s->backlog.pop();
+        if (st != SGZ_OK) return st;
+    }
+    return SGZ_OK;
 }
 
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain)

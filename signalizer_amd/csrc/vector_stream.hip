@@ -242,6 +242,7 @@ struct sgz_vector {
     std::mutex mu;
     hipStream_t stream = nullptr;
     StageRing stage;
+    Backlog backlog;                           // blocks waiting for a staging slot (rt_common.hpp)
     VecDev *d_state = nullptr;
     float *d_ring = nullptr;
     uint32_t size = 0;
@@ -260,6 +261,7 @@ static void vectorFree(sgz_vector *s)
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->stage.release();
+    s->backlog.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_ring, (void *)s->d_ramp, (void *)s->d_tail, (void *)s->d_xyz, (void *)s->d_rgb})
         if (p) (void)hipFree(p);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -296,6 +298,8 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         SGZ_HIP(hipHostMalloc(&s->h_out, pairsCap * size * 6 * sizeof(float), hipHostMallocDefault));
         sgz_status st = s->stage.init(C, maxBlock);
         if (st != SGZ_OK) return st;
+        // one second of audio may wait for the GPU (at least 32 blocks)
+        if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(VecDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_tail), 2 * sizeof(float)));
@@ -342,6 +346,20 @@ sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg)
     return vectorSetup(s, cfg, false);
 }
 
+// one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
+static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t nch, uint32_t n)
+{
+    sgz_status st;
+    const float *d_block = s->stage.stage(blk, n, s->stream, &st);
+    if (!d_block) return st;
+    VecIngest prm{s->d_state, d_block, n, nch, s->d_ring, s->size, s->cfg.lanes, s->cfg.envelope_mode,
+                  s->envelopeCoeff, s->stereoCoeff, s->pole1};
+    hipLaunchKernelGGL(vectorIngestKernel, dim3(1), dim3(256), 0, s->stream, prm);
+    SGZ_HIP(hipGetLastError());
+    s->pushes.fetch_add(1, std::memory_order_release);
+    return s->stage.commit(s->stream);
+}
+
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
 {
     if (!s || !planar) return fail(SGZ_EINVAL, "null argument");
@@ -350,15 +368,27 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     if (num_channels != s->cfg.num_channels) return fail(SGZ_EINVAL, "num_channels differs from the configuration");
     if (nsamples == 0) return SGZ_OK;
     if (nsamples > s->stage.maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_vector_config::max_block");
-    sgz_status st;
-    const float *d_block = s->stage.stage(planar, nsamples, s->stream, &st);
-    if (!d_block) { if (st == SGZ_BUSY) s->busy++; return st; }
-    VecIngest prm{s->d_state, d_block, nsamples, num_channels, s->d_ring, s->size, s->cfg.lanes, s->cfg.envelope_mode,
-                  s->envelopeCoeff, s->stereoCoeff, s->pole1};
-    hipLaunchKernelGGL(vectorIngestKernel, dim3(1), dim3(256), 0, s->stream, prm);
-    SGZ_HIP(hipGetLastError());
-    s->pushes.fetch_add(1, std::memory_order_release);
-    return s->stage.commit(s->stream);
+    auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return vectorPushNow(s, blk, nch, n); };
+    // never waits: a block the GPU is not ready for queues up behind the earlier ones (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
+    const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
+    if (st == SGZ_BUSY) s->busy++;
+    return st;
+}
+
+sgz_status sgz_vector_flush(sgz_vector *s)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    const float *ptrs[64];
+    while (s->backlog.count) {
+        const Backlog::Entry e = s->backlog.front();
+        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
+        const sgz_status st = vectorPushNow(s, ptrs, e.channels, e.n);
+        if (st == SGZ_BUSY) { SGZ_HIP(hipStreamSynchronize(s->stream)); continue; }      // this call may wait: it is not the audio thread's
+        s->backlog.pop();
+        if (st != SGZ_OK) return st;
+    }
+    return SGZ_OK;
 }
 
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain)

@@ -15,6 +15,11 @@ def _pop_all(h, P, want, timeout=10.0):
     t0 = time.time()
     buf = np.zeros((P, 4), np.uint8)
     ap = C.c_uint32(0)
+    if timeout > 0:
+        # the producer is idle while a test waits for columns: blocks that queued up behind busy staging slots are enqueued now
+        # (on a live stream the next push does that)
+        api.lib().sgz_spectrum_flush.argtypes = [C.c_void_p]
+        api.check(api.lib().sgz_spectrum_flush(h))
     while len(cols) < want and time.time() - t0 < timeout:
         st = api.lib().sgz_spectrum_pop_column(h, buf.ctypes.data_as(C.c_void_p), C.byref(ap))
         if st == api.SGZ_OK:
@@ -71,6 +76,60 @@ def test_push_pop_matches_offline(gpu, oracle, block, mode, W):
         api.lib().sgz_spectrum_destroy(h)
 
 
+def test_stalled_gpu_delays_blocks_instead_of_dropping_them(gpu):
+    """push never waits, and a late GPU must not punch holes into the stream.  The handle's stream is stalled
+    (it waits for an event behind a 0.3 s spin kernel on another stream) while 40 blocks arrive back to back -- 8 fit the staging slots, the
+    rest wait in the host FIFO (rt_common.hpp Backlog) and are enqueued in order once the stream moves again.  The column stream must
+    be the batch render's, byte for byte, and no push may have been refused."""
+    import torch
+    cfg = config.spectrum_config(window_size=4096, hop=4096, axis_points=200)
+    W, hop, P, block, nblocks = 4096, 4096, 200, 512, 48
+    x = synth.gen(18, 48000, nblocks * block, 2)
+    c = api.config_from_dict(cfg)
+    h = C.c_void_p()
+    L = api.lib()
+    api.check(L.sgz_spectrum_create(C.byref(c), C.byref(h)))
+    L.sgz_spectrum_stream.restype = C.c_void_p
+    L.sgz_spectrum_stream.argtypes = [C.c_void_p]
+    L.sgz_spectrum_backlog.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    try:
+        side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(int(0.3 * 2.0e9))                         # ~0.3 s of spinning
+            ev.record(side)
+        assert hip.hipStreamWaitEvent(L.sgz_spectrum_stream(h), C.c_void_p(ev.cuda_event), 0) == 0
+        for b in range(nblocks - 8):
+            blk = np.ascontiguousarray(x[:, b * block:(b + 1) * block])
+            ptrs = (C.c_void_p * 2)(blk[0].ctypes.data, blk[1].ctypes.data)
+            assert L.sgz_spectrum_push(h, ptrs, 2, block) == api.SGZ_OK      # accepted, every one of them, without waiting
+        deferred, waiting = C.c_uint64(0), C.c_uint32(0)
+        api.check(L.sgz_spectrum_backlog(h, C.byref(deferred), C.byref(waiting)))
+        assert deferred.value >= nblocks - 8 - 8 - 1 and waiting.value > 0, (deferred.value, waiting.value)   # the stream really was stalled
+        torch.cuda.synchronize()                                         # the spin kernel is over
+        cols = []
+        for b in range(nblocks - 8, nblocks):                            # the next pushes drain the FIFO, in order, then take their own blocks
+            blk = np.ascontiguousarray(x[:, b * block:(b + 1) * block])
+            ptrs = (C.c_void_p * 2)(blk[0].ctypes.data, blk[1].ctypes.data)
+            assert L.sgz_spectrum_push(h, ptrs, 2, block) == api.SGZ_OK
+            cols += _pop_all(h, P, 1, timeout=0.0)
+        frames = nblocks * block // hop
+        cols += _pop_all(h, P, frames - len(cols))
+        api.check(L.sgz_spectrum_backlog(h, C.byref(deferred), C.byref(waiting)))
+        assert waiting.value == 0
+        dropped, refused = C.c_uint64(0), C.c_uint64(0)
+        api.check(L.sgz_spectrum_stats(h, C.byref(dropped), C.byref(refused)))
+        assert dropped.value == 0 and refused.value == 0
+        padded = np.concatenate([np.zeros((2, W), np.float32), x], axis=1)[:, hop:]
+        plan = api.Plan(cfg).upload()
+        batch = plan.render(torch.from_numpy(np.ascontiguousarray(padded)).to(gpu)).cpu().numpy()[:frames]
+        assert len(cols) == frames and np.array_equal(np.stack(cols), batch)
+    finally:
+        L.sgz_spectrum_destroy(h)
+
+
 def test_queue_depth_drops_like_frame_queue(gpu):
     """frameQueue(10): if the consumer never pops, at most 10 columns are retained (SpectrumDSP.cpp:47,:185-186)."""
     cfg = config.spectrum_config(window_size=4096, hop=256, axis_points=64)
@@ -96,6 +155,9 @@ def _push_all(h, x, block):
             if st != api.SGZ_BUSY:
                 break
         api.check(st)
+    # (blocks that queued up behind busy staging slots: enqueued now, the caller looks at the ring / the columns next)
+    api.lib().sgz_spectrum_flush.argtypes = [C.c_void_p]
+    api.check(api.lib().sgz_spectrum_flush(h))
 
 
 def test_device_ring_history_across_wrap_around(gpu):

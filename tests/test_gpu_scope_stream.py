@@ -396,6 +396,7 @@ def test_vertices_into_device_buffers(gpu):
         n = want_xyz.shape[0]
         t_xyz = torch.zeros((n, 3), dtype=torch.float32, device=gpu)
         t_rgb = torch.zeros((n, 3), dtype=torch.float32, device=gpu)
+        torch.cuda.synchronize()                                       # (the fills run on torch's stream, the handle's kernels on its own)
         cnt = C.c_uint32(n)
         api.check(L.sgz_vector_vertices_device(vec.h, pair, t_xyz.data_ptr(), t_rgb.data_ptr(), C.byref(cnt)))
         torch.cuda.synchronize()
