@@ -175,9 +175,12 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
                                   uint32_t num_channels, size_t nsamples, uint8_t *rgba_out,
                                   float *lines_out, sgz_timing *timing);
 
-/* Device memory for the display hand-off: `bytes` rounded up to whole pages, exported as a dma-buf file descriptor
- * (dmabuf_fd may be NULL: plain allocation) that the GL / Vulkan context of the display GPU imports (EXT_memory_object_fd) -- an MI355X
- * has no graphics engine of its own.  The caller closes the fd and frees the memory with sgz_export_free. */
+/* Device memory for the display hand-off: `bytes` rounded up to whole 2 MiB blocks (*allocated), exported as a dma-buf
+ * file descriptor (dmabuf_fd may be NULL: plain allocation) that the GL / Vulkan context of the display GPU -- an MI355X has no graphics
+ * engine of its own -- or any other process imports (EXT_memory_object_fd, EGL_EXT_image_dma_buf_import, hipImportExternalMemory with
+ * hipExternalMemoryHandleTypeOpaqueFd and size = *allocated).  Whole blocks because a dma-buf is a whole buffer object and the runtime
+ * packs smaller allocations into shared ones: the importer sees the memory from offset 0 (tests/test_gpu_realtime.py imports the fd in
+ * a second process and compares the texels).  The caller closes the fd and frees the memory with sgz_export_free. */
 sgz_status sgz_export_alloc(size_t bytes, void **d_ptr, size_t *allocated, int *dmabuf_fd);
 void       sgz_export_free(void *d_ptr);
 
@@ -304,11 +307,14 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint3
  * let sgz_spectrum_flush_columns (consumer thread, in place of the pop loop) scatter every ready column into it at
  * x = framePixelPosition, wrapping at `columns`; *first_column / *count name the texel columns written by this call (SGZ_EMPTY: none).
  *   sgz_spectrum_bind_image     caller-owned DEVICE memory (any mapped interop resource); d_image = NULL unbinds
- *   sgz_spectrum_create_image   the library allocates the image and exports it as a dma-buf fd (the caller closes it): an MI355X has
- *                               no graphics engine, the GL / Vulkan context of the display GPU imports the fd
- *                               (EXT_memory_object_fd, EGL_EXT_image_dma_buf_import); dmabuf_fd may be NULL
+ *   sgz_spectrum_create_image   the library allocates the image (whole 2 MiB blocks, see sgz_export_alloc) and exports it as a dma-buf
+ *                               fd (the caller closes it): an MI355X has no graphics engine, the GL / Vulkan context of the display
+ *                               GPU imports the fd (EXT_memory_object_fd, EGL_EXT_image_dma_buf_import; import size = pitch * P
+ *                               rounded up to 2 MiB); dmabuf_fd may be NULL
  *   sgz_spectrum_bind_gl_buffer an OpenGL buffer object (e.g. a pixel-unpack buffer the texture is updated from) of a context that is
- *                               current on this thread and lives on the same device: hipGraphicsGLRegisterBuffer + map
+ *                               current on this thread and lives on the same device: hipGraphicsGLRegisterBuffer; flush_columns maps
+ *                               and unmaps it around its writes.  UNTESTED beyond "fails with a status": the MI355X boxes this library
+ *                               is developed on have no GL context to offer (no display engine, no render node for EGL)
  * A configure drops the binding (the image height is the axis size). */
 sgz_status sgz_spectrum_bind_image(sgz_spectrum *s, void *d_image, uint32_t columns, size_t pitch_bytes);
 sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d_image, size_t *pitch_bytes, int *dmabuf_fd);

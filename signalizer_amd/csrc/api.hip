@@ -322,6 +322,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
                                  float *d_state, hipStream_t stream)
 {
     if (frames <= 0) return SGZ_OK;
+    p.aggMapped = nullptr;                                   // whatever d_agg held is about to be overwritten (or left stale by a fused launch)
     DecayParams prm;
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
@@ -362,6 +363,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
         if (st != SGZ_OK) return st;
         prm.agg = p.d_agg;
         SGZ_HIP(launchDecayLocalCarry(prm, stream));
+        p.aggMapped = d_mapped; p.aggFrames = frames;        // d_agg now holds the chunk aggregates of exactly this scan
         if (prm.stateStash) { prm.stateIn = prm.stateStash; prm.stateStash = nullptr; }
     }
     SGZ_HIP(launchDecayEmit(prm, stream));
@@ -387,9 +389,10 @@ sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, co
     prm.magScale = 1.0f;
     if (prm.numChunks > 1) {
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
-        if (!p.d_agg || p.aggCap < need) return fail(SGZ_EINVAL, "sgz_stage_decay_emit without a preceding sgz_stage_decay_scan of the same frames");
+        if (!p.d_agg || p.aggCap < need || p.aggMapped != d_mapped || p.aggFrames != frames)
+            return fail(SGZ_EINVAL, "sgz_stage_decay_emit without a preceding sgz_stage_decay_scan of the same (mapped, frames) -- another K_B call on the plan in between invalidates the kept aggregates");
         prm.agg = p.d_agg;
-        if (d_carry) SGZ_HIP(launchDecayApplyCarry(prm, d_carry, stream));
+        if (d_carry) { SGZ_HIP(launchDecayApplyCarry(prm, d_carry, stream)); p.aggMapped = nullptr; }   // (the carry is folded INTO the aggregates: one emit per scan)
     }
     if (!d_rgba && !d_lines && !d_stateOut) return SGZ_OK;
     SGZ_HIP(launchDecayEmit(prm, stream));
@@ -615,7 +618,10 @@ sgz_status sgz_spectrogram_render(const sgz_spectrum_config *cfg, const float *c
 sgz_status sgz_export_alloc(size_t bytes, void **d_ptr, size_t *allocated, int *dmabuf_fd)
 {
     if (!bytes || !d_ptr) return fail(SGZ_EINVAL, "bad argument");
-    const size_t rounded = (bytes + 4095) & ~size_t(4095);
+    // A dma-buf is a whole buffer object.  The HSA runtime carves allocations below 2 MiB out of shared 2 MiB blocks, and an importer of
+    // such an fd sees the BLOCK from its start, not the allocation (measured: another process read the neighbouring tables through
+    // the fd of a 52 KB image).  Exported memory is therefore allocated in whole 2 MiB blocks, which get a buffer object of their own.
+    const size_t rounded = (bytes + kExportGranule - 1) & ~(kExportGranule - 1);
     void *p = nullptr;
     SGZ_HIP(hipMalloc(&p, rounded));
     int fd = -1;

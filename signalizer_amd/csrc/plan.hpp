@@ -122,6 +122,7 @@ struct Plan {
     // work buffers (grown on demand)
     float *d_mapped = nullptr; size_t mappedCap = 0;      // [frames][pairs][2][P]
     float *d_agg = nullptr; size_t aggCap = 0;            // decay chunk aggregates
+    const float *aggMapped = nullptr; long aggFrames = 0; // whose zero-carry scan d_agg holds (sgz_stage_decay_emit checks it), null: nobody's
     float *d_stateCopy = nullptr; size_t stateCopyCap = 0;  // carry-in snapshot (decayEmit reads it while writing state)
     float *d_phaseWork = nullptr; size_t phaseWorkCap = 0;   // Phase mode: main-graph dB values [frames][C][P]
     PixelRec *d_recsReal = nullptr; uint32_t *d_realLowPixels = nullptr; float *d_low = nullptr;

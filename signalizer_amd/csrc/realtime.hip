@@ -112,8 +112,7 @@ static void unbindImage(sgz_spectrum *s)
 {
     if (s->outStream) (void)hipStreamSynchronize(s->outStream);
     if (s->glResource) {
-        (void)hipGraphicsUnmapResources(1, &s->glResource, s->outStream);
-        (void)hipGraphicsUnregisterResource(s->glResource);
+        (void)hipGraphicsUnregisterResource(s->glResource);          // (never left mapped: flush_columns maps and unmaps around its writes)
         s->glResource = nullptr;
     }
     if (s->imgOwned && s->d_image) (void)hipFree(s->d_image);
@@ -385,8 +384,9 @@ sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d
     unbindImage(s);
     const Plan &p = *s->plan;
     const size_t pitch = (size_t(columns) * 4 + 255) & ~size_t(255);
-    // dma-buf export works on whole pages of an allocation
-    const size_t bytes = (pitch * p.P + 4095) & ~size_t(4095);
+    // a dma-buf is a whole buffer object: allocated in whole 2 MiB blocks so that the fd describes the image and nothing else (api.hip
+    // sgz_export_alloc has the measurement)
+    const size_t bytes = (pitch * p.P + kExportGranule - 1) & ~(kExportGranule - 1);
     uint8_t *img = nullptr;
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&img), bytes));
     hipError_t e = hipMemset(img, 0, bytes);
@@ -411,21 +411,33 @@ sgz_status sgz_spectrum_bind_gl_buffer(sgz_spectrum *s, unsigned int gl_buffer, 
     void *ptr = nullptr; size_t size = 0;
     e = hipGraphicsMapResources(1, &res, s->outStream);
     if (e == hipSuccess) e = hipGraphicsResourceGetMappedPointer(&ptr, &size, res);
-    if (e != hipSuccess || size < pitch_bytes * p.P) {
-        (void)hipGraphicsUnmapResources(1, &res, s->outStream);
+    // (mapped here only to check its size: GL may touch the buffer whenever HIP does not hold it mapped, so flush_columns maps and
+    // unmaps it around its own writes -- the interop contract)
+    const hipError_t eu = hipGraphicsUnmapResources(1, &res, s->outStream);
+    if (e != hipSuccess || eu != hipSuccess || size < pitch_bytes * p.P) {
         (void)hipGraphicsUnregisterResource(res);
-        return e != hipSuccess ? hipFail(e, "mapping the GL buffer") : fail(SGZ_EINVAL, "GL buffer smaller than pitch * axis_points");
+        return e != hipSuccess ? hipFail(e, "mapping the GL buffer") : eu != hipSuccess ? hipFail(eu, "unmapping the GL buffer")
+                                                                     : fail(SGZ_EINVAL, "GL buffer smaller than pitch * axis_points");
     }
     s->glResource = res;
-    s->d_image = static_cast<uint8_t *>(ptr); s->imgColumns = columns; s->imgPitch = pitch_bytes; s->imgX = 0;
+    s->d_image = nullptr; s->imgColumns = columns; s->imgPitch = pitch_bytes; s->imgX = 0;
     return SGZ_OK;
 }
 
 sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, uint32_t *count)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
-    if (!s->d_image) return fail(SGZ_EINVAL, "no image bound");
+    if (!s->d_image && !s->glResource) return fail(SGZ_EINVAL, "no image bound");
     const Plan &p = *s->plan;
+    uint8_t *image = s->d_image;
+    hipGraphicsResource *gl = static_cast<hipGraphicsResource *>(s->glResource);
+    if (gl) {                                                  // a GL buffer is HIP's only between map and unmap
+        void *ptr = nullptr; size_t size = 0;
+        SGZ_HIP(hipGraphicsMapResources(1, &gl, s->outStream));
+        const hipError_t e = hipGraphicsResourceGetMappedPointer(&ptr, &size, gl);
+        if (e != hipSuccess) { (void)hipGraphicsUnmapResources(1, &gl, s->outStream); return hipFail(e, "hipGraphicsResourceGetMappedPointer"); }
+        image = static_cast<uint8_t *>(ptr);
+    }
     uint32_t n = 0;
     const uint32_t first = s->imgX;
     uint64_t head = s->qHead.load(std::memory_order_relaxed);
@@ -436,7 +448,7 @@ sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, u
         if (q == hipErrorNotReady) break;
         if (q != hipSuccess) return hipFail(q, "hipEventQuery");
         hipLaunchKernelGGL(columnScatterKernel, dim3((p.P + 255) / 256), dim3(256), 0, s->outStream,
-                           reinterpret_cast<const uint32_t *>(s->d_colsQ + size_t(slot) * p.P * 4), s->d_image, s->imgPitch, s->imgX, p.P);
+                           reinterpret_cast<const uint32_t *>(s->d_colsQ + size_t(slot) * p.P * 4), image, s->imgPitch, s->imgX, p.P);
         SGZ_HIP(hipGetLastError());
         s->imgX = (s->imgX + 1) % s->imgColumns;           // framePixelPosition %= numSpectrumColumns (SpectrumRendering.cpp:712-718)
         ++head; ++n;
@@ -445,6 +457,7 @@ sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, u
         SGZ_HIP(hipStreamSynchronize(s->outStream));        // the texels are in place before the slots go back to the producer
         s->qHead.store(head, std::memory_order_release);
     }
+    if (gl) SGZ_HIP(hipGraphicsUnmapResources(1, &gl, s->outStream));
     if (first_column) *first_column = first;
     if (count) *count = n;
     return n ? SGZ_OK : SGZ_EMPTY;

@@ -17,6 +17,7 @@ sgz_status hipFail(hipError_t e, const char *what);
         if (_e != hipSuccess) return ::sgz::hipFail(_e, #call); \
     } while (0)
 
+constexpr size_t kExportGranule = size_t(2) << 20;      // allocations that are exported as dma-buf fds: whole 2 MiB blocks (sgz_export_alloc)
 sgz_status ensureCap(float **buf, size_t *cap, size_t need);
 int numCUs();
 // K_A over `frames` frames (ideal STFT framing from d_planar); any of mapped/binsOut may be null

@@ -262,8 +262,37 @@ def _flush_all(h, want, timeout=10.0):
     return out, total
 
 
+_IMPORTER = r"""
+# second process of test_columns_land_in_a_device_image: import the exported dma-buf fd as HIP external memory, read the image back
+import ctypes as C, sys
+import numpy as np
+fd, nbytes, alloc, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+hip = C.CDLL("libamdhip64.so")
+class Handle(C.Union):
+    _fields_ = [("fd", C.c_int), ("win32", C.c_void_p * 2), ("nvSciBufObject", C.c_void_p)]
+class HandleDesc(C.Structure):
+    _fields_ = [("type", C.c_int), ("handle", Handle), ("size", C.c_ulonglong), ("flags", C.c_uint), ("reserved", C.c_uint * 16)]
+class BufferDesc(C.Structure):
+    _fields_ = [("offset", C.c_ulonglong), ("size", C.c_ulonglong), ("flags", C.c_uint), ("reserved", C.c_uint * 16)]
+assert hip.hipSetDevice(0) == 0
+hd = HandleDesc(); hd.type = 1; hd.handle.fd = fd; hd.size = alloc          # hipExternalMemoryHandleTypeOpaqueFd
+ext = C.c_void_p()
+e = hip.hipImportExternalMemory(C.byref(ext), C.byref(hd))
+assert e == 0, ("hipImportExternalMemory", e)
+bd = BufferDesc(); bd.offset = 0; bd.size = alloc
+ptr = C.c_void_p()
+e = hip.hipExternalMemoryGetMappedBuffer(C.byref(ptr), ext, C.byref(bd))
+assert e == 0, ("hipExternalMemoryGetMappedBuffer", e)
+host = np.zeros(nbytes, np.uint8)
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+assert hip.hipMemcpy(host.ctypes.data, ptr, nbytes, 2) == 0
+np.save(out, host)
+print("imported", nbytes)
+"""
+
+
 @pytest.mark.parametrize("own_image", [False, True])
-def test_columns_land_in_a_device_image(gpu, own_image):
+def test_columns_land_in_a_device_image(gpu, oracle, own_image):
     """sgz_spectrum_flush_columns writes texel (x, y) = column[y] at x = framePixelPosition, wrapping at the image width -- the texels
     oglImage.updateSingleColumn would upload (SpectrumRendering.cpp:696-721) -- into caller-owned device memory (the mock of a mapped
     interop resource) or into the library's own image, which is also exported as a dma-buf fd."""
@@ -283,6 +312,15 @@ def test_columns_land_in_a_device_image(gpu, own_image):
     api.lib().sgz_spectrum_destroy(h2)
     want = np.stack(want).view(np.uint32)[:, :, 0]                                  # [frames][P]
     assert want.shape[0] == 19
+    # ... and those columns are the ORACLE's, through the parity chain: the batch render of the same stream (history = W zeros) gives the
+    # same bytes, and the batch render is held to the oracle link by link (tests/parity_chain.py)
+    from parity_chain import check_render
+    padded = np.ascontiguousarray(np.concatenate([np.zeros((2, W), np.float32), x], axis=1)[:, hop:])
+    plan = api.Plan(cfg).upload()
+    batch = plan.render(torch.from_numpy(padded).to(gpu)).cpu().numpy()[:19]
+    assert np.array_equal(batch.view(np.uint32)[:, :, 0], want)
+    problems, _ = check_render(oracle, plan, cfg, padded, gpu)
+    assert not problems, problems
 
     h = C.c_void_p()
     api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)))
@@ -319,6 +357,17 @@ def test_columns_land_in_a_device_image(gpu, own_image):
             hip = C.CDLL("libamdhip64.so")
             assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), d_img, C.c_size_t(host.nbytes), 2) == 0       # hipMemcpyDeviceToHost
             img = host
+            # the consumer side of the hand-off: ANOTHER PROCESS imports the dma-buf fd (HIP external memory, the path a Vulkan / GL
+            # interop or a compositor takes) and must read the same texels
+            import subprocess, sys, tempfile
+            alloc = (host.nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)        # the library exports whole 2 MiB blocks (sgz.h)
+            with tempfile.TemporaryDirectory() as td:
+                outp = os.path.join(td, "img.npy")
+                r = subprocess.run([sys.executable, "-c", _IMPORTER, str(fd), str(host.nbytes), str(alloc), outp], pass_fds=(fd,),
+                                   capture_output=True, text=True, timeout=300)
+                assert r.returncode == 0 and "imported" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+                other = np.load(outp).view(np.uint32).reshape(host.shape)
+            assert np.array_equal(other, host)
         else:
             img = read_image()
             assert (img[:, columns:] == 0x01020304).all()                                      # texels beyond the image width are untouched
