@@ -1,15 +1,13 @@
-// fft_scalar.hpp -- in-register radix-2 butterflies in the form the gfx950 VALU runs fastest: plain (not packed) fp32 FMAs.
+// fft_scalar.hpp -- in-register radix-2 butterflies in decimation-in-time form, p = a + w b, q = 2 a - p, which costs three
+// fused operations per general twiddle instead of the four (subtract, then a complex multiply) of decimation in frequency.
 //
-// What the instructions cost on this chip (tools/ubench/valu*.hip, dit.hip): a wave64 v_add / v_mul / v_fmac / v_fmamk / v_fma occupies
-// its SIMD for 2.2-2.4 clocks when every register source is a VGPR or the constant is a LITERAL (VOP2 forms: v_fmamk_f32, v_fmac_f32,
-// v_mul_f32 take a 32-bit literal) or an inline constant; a v_pk_*_f32 costs 4.4 (exactly two plain ones), and any SGPR source
-// halves the rate.  So the cheapest butterfly is the one with the fewest plain operations, constants as literals:
-//     decimation in time,  p = a + w b,  q = a - w b = 2 a - p:
-//         p.re = fma(b.im, s, fma(b.re, c, a.re))    p.im = fma(b.re, -s, fma(b.im, c, a.im))    q = fma(2, a, -p)
-//     = 6 operations for a general twiddle (the decimation-in-frequency form, (a - b) w, needs 4 + 4), 4 for w = 1 and w = -i.
-// A 32-point transform is 46 trivial and 34 general butterflies = 388 operations against 456 for the packed DIF (228 packed).
-// hipcc selects v_fmamk / v_fmac with literal twiddles for exactly this source (checked in the ISA); trivial butterflies written on
-// (re, im) pairs become v_pk_add_f32, which costs the same as the two adds it replaces.
+// What the instructions cost on this chip with the register traffic of a real butterfly network (tools/ubench/valu4.hip, banks.hip,
+// dit.hip; NOTES.md "VALU rates"): a wave64 plain fp32 v_add / v_mul / v_fmac / v_fmamk occupies its SIMD for ~2.8-3.1 clocks
+// (2.2 only in a dependent chain on one register), a three-source v_fma 3.1-3.7 (5.5 when two sources share a VGPR bank), a
+// v_pk_*_f32 4.8-5.5: per flop the packed form is ~10 % cheaper and it halves the issue slots.  Whole 32-point transforms on 8 waves
+// of one CU: difPacked 1153 clocks, the scalar DIT below 1427, the packed DIT (ditPacked, at the end of this file) 998 -- the kernels
+// use ditPacked; the scalar form stays for the microbenchmark and as the readable statement of the arithmetic.
+//     p.re = fma(b.im, s, fma(b.re, c, a.re))    p.im = fma(b.re, -s, fma(b.im, c, a.im))    q = fma(2, a, -p)
 //
 // Register convention (the same as difPacked in fft_common.hpp, so the kernels' exchanges do not change): input x[j] in c[BASE + j],
 // output X[k] in c[BASE + brev(k)].  DIT wants its input in bit-reversed order and delivers natural order; here the array is simply

@@ -35,8 +35,6 @@ class RefVector:
         self.sc = float(np.float32(np.exp(-1.0 / (stereo_window * SR))))
 
     def audio(self, blk):
-        for i in range(blk.shape[1]):
-            pass
         n = blk.shape[1]
         idx = (self.cursor + np.arange(n)) % self.size
         self.mem[:, idx] = blk                      # later samples overwrite earlier ones where a long block laps the ring
