@@ -36,6 +36,11 @@ typedef enum sgz_status {
 /* SpectrumChannels, Source/Common/CommonSignalizer.h:495-539 */
 enum { SGZ_CH_LEFT = 0, SGZ_CH_RIGHT, SGZ_CH_MERGE, SGZ_CH_SIDE, SGZ_CH_PHASE, SGZ_CH_SEPARATE,
        SGZ_CH_MIDSIDE, SGZ_CH_COMPLEX };
+/* SpectrumContent::TransformAlgorithm, Source/Spectrum/SpectrumParameters.h:66-69.  RSNT ("Resonator"): a bank of complex
+ * one-pole resonators, one per axis point, advanced by every sample (TransformPair::resonatingDispatch, TransformDSP.inl:1213-1295);
+ * a frame is the windowed resonator state every `hop` samples (audioEntryPoint :1172-1201, mapToLinearSpace :1103-1133).  The
+ * resonator itself is cpl::dsp::CComplexResonator (absent submodule): restated from its published mathematics, see resonator.hip. */
+enum { SGZ_ALGO_FFT = 0, SGZ_ALGO_RSNT = 1 };
 /* SpectrumContent::BinInterpolation */
 enum { SGZ_INTERP_NONE = 0, SGZ_INTERP_LINEAR, SGZ_INTERP_LANCZOS };
 /* SpectrumContent::ViewScaling */
@@ -80,6 +85,8 @@ typedef struct sgz_spectrum_config {
     uint8_t  colours[SGZ_NUM_SPEC_COLOURS + 1][3];    /* [0] background, [1..5] gradient stops (RGB8) */
     uint8_t  _pad[2];
     double   ratios[SGZ_NUM_SPEC_COLOURS];            /* content->specRatios (normalised values)      */
+    uint32_t algorithm;          /* SGZ_ALGO_*: constant.algo, Spectrum.cpp:367                                  */
+    uint32_t free_q;             /* RSNT: content->freeQ (Spectrum.cpp:593): bandwidths not bounded by the window */
 } sgz_spectrum_config;
 
 typedef struct sgz_timing {         /* filled by the batch entry points when non-NULL */
@@ -127,6 +134,17 @@ uint32_t   sgz_plan_break_pixel(const sgz_plan *plan);                         /
                                        signal -- takes the place of the kernels above, whatever the row layout
                                        (at N = 32768 in Separate mode: for launches of up to 1024 tasks) */
 uint32_t   sgz_plan_path(const sgz_plan *plan);
+/* frames an offline render / stage call produces from `nsamples` samples per channel: FFT: sgz_num_frames(nsamples, W, hop);
+ * RSNT: nsamples / hop (a frame after every hop samples, no window history) */
+uint64_t   sgz_plan_num_frames(const sgz_plan *plan, size_t nsamples);
+/* RSNT plans: the resonator bank CComplexResonator::Constant::mapSystemHz builds (TransformConstant.h:120-123) -- `vectors` detuned
+ * resonators per axis point: coeff [vectors][P] (re, im) pole positions, gain [P], weights [vectors] of the frequency-domain window.
+ * Any output may be NULL; returns SGZ_EINVAL on an FFT plan. */
+sgz_status sgz_plan_get_resonator(const sgz_plan *plan, uint32_t *vectors, float *coeff, float *gain, float *weights);
+/* RSNT plans carry the resonator state between calls (the reference's TransformPair::cresonator).  sgz_stage_mapped and renders without
+ * a carried decay state (d_state == NULL) start from rest by themselves; a render WITH d_state continues the stream, resonators
+ * included.  This call puts them to rest explicitly (TransformPair.h:183 resetState); no-op on FFT plans. */
+sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 /* Per-plan switches (all default to what is fastest; the parity tests and measurements flip them):
  *   SGZ_OPT_CHANNEL_SPLIT  1 (default): eligible plans run the real-input channel-split kernels (SGZ_PATH_CHANNEL_SPLIT); 0: never
  *   SGZ_OPT_FUSED_COLOUR   1 (default): an image-only K_B of one pair runs as the single fused launch; 0: scan + emit launches

@@ -51,6 +51,8 @@ class SpectrumParams(C.Structure):
         ("colours", (C.c_uint8 * 3) * (NUM_SPEC_COLOURS + 1)),
         ("_pad", C.c_uint8 * 2),
         ("ratios", C.c_double * NUM_SPEC_COLOURS),
+        ("algorithm", C.c_uint32),
+        ("free_q", C.c_uint32),
     ]
 
 
@@ -70,7 +72,7 @@ class VectorFilters(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "sgz_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "scope_spectral.c", "resonator.c", "sgz_oracle.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -114,6 +116,17 @@ def lib() -> C.CDLL:
         L.sgzo_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_spectrogram_range.restype = C.c_long
         L.sgzo_spectrogram_range.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, C.c_long, C.c_long, vp]
+        L.sgzo_window_cosine_terms.restype = C.c_int
+        L.sgzo_window_cosine_terms.argtypes = [C.c_uint32, vp]
+        L.sgzo_resonator_map.argtypes = [C.POINTER(SpectrumParams), vp, vp, vp, vp, C.POINTER(C.c_int)]
+        L.sgzo_resonate_real.argtypes = [vp, C.c_uint32, C.c_int, vp, vp, C.c_int, C.c_size_t]
+        L.sgzo_resonator_dispatch.restype = C.c_int
+        L.sgzo_resonator_dispatch.argtypes = [C.c_uint32, vp, vp, C.c_size_t, vp, vp]
+        L.sgzo_resonator_windowed_state.argtypes = [C.POINTER(SpectrumParams), vp, vp, vp, C.c_int, C.c_int, vp]
+        L.sgzo_resonator_num_frames.restype = C.c_long
+        L.sgzo_resonator_num_frames.argtypes = [C.c_size_t, C.c_uint32]
+        L.sgzo_resonator_spectrogram.restype = C.c_long
+        L.sgzo_resonator_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_track_peak.argtypes = [C.POINTER(SpectrumParams), vp, C.c_uint32, vp, C.c_double, C.c_double, vp]
         L.sgzo_decay_colour.restype = C.c_long
         L.sgzo_decay_colour.argtypes = [C.POINTER(SpectrumParams), vp, C.c_long, vp, vp]
@@ -309,6 +322,38 @@ def spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False,
     ptrs = (C.c_void_p * nch)(*[planar[c].ctypes.data for c in range(nch)])
     n = lib().sgzo_spectrogram(C.byref(p), ptrs, S, _ptr(rgba),
                                _ptr(lines) if want_lines else None, _ptr(mapped) if want_mapped else None)
+    assert n == F, (n, F)
+    return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F}
+
+
+RES_MAX_TERMS = 5
+
+
+def resonator_map(p: SpectrumParams):
+    """mapSystemHz restated: (coeff [V][P] complex64, gain [P], weights [V]) for the plan's mapped frequencies."""
+    P = p.axis_points
+    mf = remap_frequencies(p)
+    coeff = np.zeros((2 * RES_MAX_TERMS - 1, P), np.complex64)
+    gain = np.zeros(P, np.float32)
+    weights = np.zeros(2 * RES_MAX_TERMS - 1, np.float32)
+    V = C.c_int(0)
+    lib().sgzo_resonator_map(C.byref(p), _ptr(mf), _ptr(coeff), _ptr(gain), _ptr(weights), C.byref(V))
+    return coeff[:V.value].copy(), gain, weights[:V.value].copy()
+
+
+def resonator_spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False, want_mapped: bool = False):
+    """RSNT offline job: one frame per hop samples, resonators from rest.  Same result dict as spectrogram()."""
+    planar = np.ascontiguousarray(planar, np.float32)
+    nch, S = planar.shape
+    assert nch == 2 * p.num_pairs
+    F = lib().sgzo_resonator_num_frames(S, p.hop)
+    P = p.axis_points
+    rgba = np.zeros((F, P, 4), np.uint8)
+    lines = np.zeros((F, p.num_pairs, NUM_GRAPHS, P), np.complex64) if want_lines else None
+    mapped = np.zeros((F, p.num_pairs, 2 * P), np.complex64) if want_mapped else None
+    ptrs = (C.c_void_p * nch)(*[planar[c].ctypes.data for c in range(nch)])
+    n = lib().sgzo_resonator_spectrogram(C.byref(p), ptrs, S, _ptr(rgba), _ptr(lines) if want_lines else None,
+                                         _ptr(mapped) if want_mapped else None)
     assert n == F, (n, F)
     return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F}
 

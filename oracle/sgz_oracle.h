@@ -73,7 +73,11 @@ typedef struct sgzo_spectrum_params {
     uint8_t  colours[SGZO_NUM_SPEC_COLOURS + 1][3]; /* [0]=background, 1..5 gradient, RGB8    */
     uint8_t  _pad[2];
     double   ratios[SGZO_NUM_SPEC_COLOURS];         /* content->specRatios normalised values  */
+    uint32_t algorithm;          /* SGZO_ALGO_*: SpectrumContent::TransformAlgorithm (SpectrumParameters.h:66-69) */
+    uint32_t free_q;             /* content->freeQ (Spectrum.cpp:593): RSNT bandwidths not bounded by the window  */
 } sgzo_spectrum_params;
+enum { SGZO_ALGO_FFT = 0, SGZO_ALGO_RSNT = 1 };
+#define SGZO_RES_MAX_TERMS 5     /* cosine-sum terms of the widest window (flat top): 2 * 5 - 1 = 9 vectors */
 
 /* ---------------- primitives (cpl restatements, UNVERIFIED vs cpl) ---------------- */
 double   sgzo_window(uint32_t type, uint32_t symmetry, double alpha, double beta,
@@ -214,6 +218,19 @@ typedef struct sgzo_vector_filters {          /* Source/Vectorscope/Vectorscope.
 void sgzo_vector_audio_processing(sgzo_vector_filters *f, const float *L, const float *R, size_t n,
                                   uint32_t lanes, float envelope_coeff, float stereo_coeff,
                                   float second_speed, int env_mode /*0 none,1 rms*/, float *gain_out);
+
+/* ---------------- RSNT: the resonator algorithm (resonator.c; cpl::dsp::CComplexResonator restated, UNVERIFIED vs cpl) ---------------- */
+int  sgzo_window_cosine_terms(uint32_t window_type, double a[SGZO_RES_MAX_TERMS]);
+void sgzo_resonator_map(const sgzo_spectrum_params *p, const float *mapped, sgzo_cf *coeff /*[V][P]*/, float *gain /*[P]*/,
+                        float *weights /*[V]*/, int *vectors);
+void sgzo_resonate_real(const sgzo_cf *coeff, uint32_t P, int V, sgzo_cf *state /*[signals][V][P]*/, const float *const *work,
+                        int signals, size_t n);
+int  sgzo_resonator_dispatch(uint32_t mode, const float *L, const float *R, size_t n, float *work0, float *work1);
+void sgzo_resonator_windowed_state(const sgzo_spectrum_params *p, const sgzo_cf *state, const float *gain, const float *weights,
+                                   int V, int signals, sgzo_cf *csp /*[2P]*/);
+long sgzo_resonator_num_frames(size_t nsamples, uint32_t hop);
+long sgzo_resonator_spectrogram(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                                uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out);
 
 #ifdef __cplusplus
 }

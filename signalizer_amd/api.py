@@ -38,6 +38,7 @@ class SpectrumConfig(C.Structure):
         ("clip_db", C.c_double), ("slope_a", C.c_double), ("slope_b", C.c_double),
         ("pole", C.c_float * NUM_GRAPHS), ("colours", (C.c_uint8 * 3) * (NUM_SPEC_COLOURS + 1)),
         ("_pad", C.c_uint8 * 2), ("ratios", C.c_double * NUM_SPEC_COLOURS),
+        ("algorithm", C.c_uint32), ("free_q", C.c_uint32),
     ]
 
 
@@ -113,7 +114,7 @@ EXPORTS = [
     "sgz_plan_create", "sgz_plan_destroy", "sgz_plan_upload", "sgz_plan_transform_size",
     "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_path", "sgz_plan_dc_pixels", "sgz_plan_get_window",
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
-    "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames",
+    "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames", "sgz_plan_num_frames", "sgz_plan_get_resonator", "sgz_plan_reset_resonator",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant", "sgz_plan_set_option",
     "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout", "sgz_spectrogram_render_sharded_on",
     "sgz_spectrogram_render_sharded",
@@ -170,6 +171,10 @@ def lib() -> C.CDLL:
     L.sgz_rotate_hue_rgb8.restype = None
     L.sgz_num_frames.argtypes = [sz, u32, u32]
     L.sgz_num_frames.restype = C.c_long
+    L.sgz_plan_num_frames.argtypes = [vp, sz]
+    L.sgz_plan_num_frames.restype = C.c_uint64
+    L.sgz_plan_get_resonator.argtypes = [vp, vp, vp, vp, vp]
+    L.sgz_plan_reset_resonator.argtypes = [vp, vp]
     L.sgz_spectrogram_render_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.sgz_spectrogram_render.argtypes = [C.POINTER(SpectrumConfig), vp, u32, sz, vp, vp, C.POINTER(Timing)]
     L.sgz_spectrogram_render_host.argtypes = [vp, vp, u32, sz, vp, vp, C.POINTER(Timing)]
@@ -352,7 +357,21 @@ class Plan:
         return out
 
     def num_frames(self, nsamples: int) -> int:
-        return lib().sgz_num_frames(nsamples, self.cfg.window_size, self.cfg.hop)
+        return int(lib().sgz_plan_num_frames(self.h, nsamples))
+
+    def resonator(self):
+        """RSNT plans: (coeff [V][P] complex64, gain [P], weights [V]) of the resonator bank."""
+        V = C.c_uint32(0)
+        check(lib().sgz_plan_get_resonator(self.h, C.byref(V), None, None, None))
+        coeff = np.zeros((V.value, self.P), np.complex64)
+        gain = np.zeros(self.P, np.float32)
+        weights = np.zeros(V.value, np.float32)
+        check(lib().sgz_plan_get_resonator(self.h, None, _np_ptr(coeff), _np_ptr(gain), _np_ptr(weights)))
+        return coeff, gain, weights
+
+    def reset_resonator(self, stream=None):
+        import torch
+        check(lib().sgz_plan_reset_resonator(self.h, stream if stream is not None else torch.cuda.current_stream().cuda_stream))
 
     # ---- device entry points (torch tensors on the GPU) -------------------------------------------
     def render(self, planar, rgba=None, lines=None, state=None, stream=None):
@@ -425,7 +444,7 @@ def render_spectrogram(cfg: dict, planar: np.ndarray, want_lines: bool = False):
     c = config_from_dict(cfg)
     planar = np.ascontiguousarray(planar, np.float32)
     nch, S = planar.shape
-    F = lib().sgz_num_frames(S, c.window_size, c.hop)
+    F = S // c.hop if c.algorithm == 1 else lib().sgz_num_frames(S, c.window_size, c.hop)
     rgba = np.zeros((F, c.axis_points, 4), np.uint8)
     lines = np.zeros((F, c.num_pairs, NUM_GRAPHS, c.axis_points, 2), np.float32) if want_lines else None
     ptrs = (C.c_void_p * nch)(*[planar[i].ctypes.data for i in range(nch)])

@@ -37,7 +37,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resGain, d_resState, d_resLocal};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -91,6 +91,15 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.items, &p.d_items)) != SGZ_OK) return st;
     if ((st = uploadVec(p.phaseType, &p.d_phaseType)) != SGZ_OK) return st;
     if ((st = uploadVec(p.phaseNorm, &p.d_phaseNorm)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resCoeff, &p.d_resCoeff)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resPow, &p.d_resPow)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resGain, &p.d_resGain)) != SGZ_OK) return st;
+    if (isResonator(p)) {                                  // the resonators start from rest (TransformPair.h:183 resetState)
+        if (p.d_resState) { (void)hipFree(p.d_resState); p.d_resState = nullptr; }
+        const size_t n = size_t(p.C) * 2 * size_t(p.resV) * p.P * 2 * sizeof(float);
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&p.d_resState), n));
+        SGZ_HIP(hipMemset(p.d_resState, 0, n));
+    }
     (void)hipGetDevice(&p.device);
     p.uploaded = true;
     return SGZ_OK;
@@ -169,10 +178,43 @@ static RealParams fillRealLate(Plan &p, long frames, float *d_mapped)
     return rp;
 }
 
+// RSNT: the resonators advance over frames x hop samples starting at d_planar, continuing from the state the plan carries
+sgz_status resetResonator(Plan &p, hipStream_t stream)
+{
+    if (!isResonator(p) || !p.d_resState) return SGZ_OK;
+    SGZ_HIP(hipMemsetAsync(p.d_resState, 0, size_t(p.C) * 2 * size_t(p.resV) * p.P * 2 * sizeof(float), stream));
+    return SGZ_OK;
+}
+
+static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
+{
+    if (frames <= 0) return SGZ_OK;
+    if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
+    ResParams r{};
+    r.planar = d_planar; r.chStride = chStride; r.frames = frames;
+    r.hop = p.cfg.hop; r.C = p.C; r.P = p.P; r.mode = p.cfg.channel_mode;
+    r.V = p.resV; r.signals = p.stateChannels; r.sides = p.sides; r.firstContinues = true;
+    r.coeff = reinterpret_cast<const float2 *>(p.d_resCoeff);
+    r.cpow = reinterpret_cast<const float2 *>(p.d_resPow);
+    r.gain = p.d_resGain;
+    for (int v = 0; v < 9; ++v) r.weights[v] = p.resWeights[v];
+    r.state = reinterpret_cast<float2 *>(p.d_resState);
+    sgz_status st = ensureCap(&p.d_resLocal, &p.resLocalCap, size_t(frames) * p.C * size_t(r.signals) * size_t(r.V) * p.P * 2);
+    if (st != SGZ_OK) return st;
+    r.local = reinterpret_cast<float2 *>(p.d_resLocal);
+    r.mapped = d_mapped;
+    SGZ_HIP(launchResonator(r, stream));
+    return SGZ_OK;
+}
+
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                           float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock, bool deferLate)
 {
     p.lateDeferred = nullptr;
+    if (isResonator(p)) {
+        if (d_binsOut || d_binsIn) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins");
+        return runResonator(p, d_planar, chStride, frames, d_mapped, stream);
+    }
     const bool phase = p.cfg.channel_mode == SGZ_CH_PHASE;
     StftParams prm = fillStftParams(p, d_planar, chStride, frames, d_mapped, d_binsOut, d_binsIn, d_phaseClock);
     const long tasks = frames * long(p.C);
@@ -484,6 +526,34 @@ uint32_t sgz_plan_dc_pixels(const sgz_plan *plan, uint32_t *out, uint32_t cap)
     return uint32_t(v.size());
 }
 
+static sgz_status checkReady(sgz_plan *plan);
+
+uint64_t sgz_plan_num_frames(const sgz_plan *plan, size_t nsamples)
+{
+    if (!plan) return 0;
+    const long f = planFrames(plan->impl, nsamples);
+    return f > 0 ? uint64_t(f) : 0;
+}
+
+sgz_status sgz_plan_get_resonator(const sgz_plan *plan, uint32_t *vectors, float *coeff, float *gain, float *weights)
+{
+    if (!plan) return fail(SGZ_EINVAL, "null plan");
+    const Plan &p = plan->impl;
+    if (!isResonator(p)) return fail(SGZ_EINVAL, "not an RSNT plan");
+    if (vectors) *vectors = uint32_t(p.resV);
+    if (coeff) std::memcpy(coeff, p.resCoeff.data(), p.resCoeff.size() * sizeof(float));
+    if (gain) std::memcpy(gain, p.resGain.data(), p.resGain.size() * sizeof(float));
+    if (weights) std::memcpy(weights, p.resWeights, size_t(p.resV) * sizeof(float));
+    return SGZ_OK;
+}
+
+sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream)
+{
+    sgz_status st = checkReady(plan);
+    if (st != SGZ_OK) return st;
+    return resetResonator(plan->impl, reinterpret_cast<hipStream_t>(stream));
+}
+
 sgz_status sgz_plan_get_window(const sgz_plan *plan, float *out)
 {
     if (!plan || !out) return fail(SGZ_EINVAL, "null argument");
@@ -541,12 +611,15 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
     if (frames <= 0) return SGZ_SKIPPED_FRAME;      // less than one window: prepareTransform returns false (TransformDSP.inl:45-46)
     if (!d_planar || (!d_rgba && !d_lines)) return fail(SGZ_EINVAL, "null buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P);
     if (st != SGZ_OK) return st;
+    // RSNT: a render without a carried decay state is a job of its own -- the resonators start from rest too (TransformPair.h:183);
+    // with d_state the caller continues a stream and the resonators (kept in the plan) continue with it
+    if (!d_state && (st = resetResonator(p, s)) != SGZ_OK) return st;
     if ((st = runStft(p, d_planar, channel_stride, frames, p.d_mapped, nullptr, nullptr, s, nullptr, /*deferLate=*/true)) != SGZ_OK) return st;
     return runDecayColour(p, p.d_mapped, frames, d_rgba, d_lines, d_state, s);
 }
@@ -561,7 +634,7 @@ sgz_status sgz_spectrogram_render_host(sgz_plan *plan, const float *const *plana
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
     if (num_channels != 2 * p.C) return fail(SGZ_EINVAL, "num_channels must equal 2*num_pairs (SpectrumDSP.cpp:65-72)");
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
     if (frames <= 0) { if (timing) *timing = sgz_timing{}; return SGZ_SKIPPED_FRAME; }
     if (!p.hostStream) {
         hipStream_t ns = nullptr;
@@ -642,7 +715,7 @@ sgz_status sgz_stage_bins(sgz_plan *plan, const float *d_planar, size_t channel_
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
     return runStft(p, d_planar, channel_stride, frames, nullptr, d_bins, nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -652,7 +725,8 @@ sgz_status sgz_stage_mapped(sgz_plan *plan, const float *d_planar, size_t channe
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
+    if ((st = resetResonator(p, reinterpret_cast<hipStream_t>(stream))) != SGZ_OK) return st;     // RSNT: a stage call starts from rest
     return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -662,7 +736,8 @@ sgz_status sgz_stage_mapped_dominant(sgz_plan *plan, const float *d_planar, size
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
+    if ((st = resetResonator(p, reinterpret_cast<hipStream_t>(stream))) != SGZ_OK) return st;
     st = runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), nullptr, /*deferLate=*/true);
     p.lateDeferred = nullptr;                        // (nobody completes them: see sgz.h)
     return st;
@@ -731,7 +806,7 @@ sgz_status sgz_debug_phase_clocks(sgz_plan *plan, const float *d_planar, size_t 
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
-    const long frames = sgz_num_frames(nsamples, p.W, p.cfg.hop);
+    const long frames = planFrames(p, nsamples);
     return runStft(p, d_planar, channel_stride, frames, d_mapped, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), d_clocks);
 }
 #endif

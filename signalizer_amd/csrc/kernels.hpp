@@ -152,4 +152,19 @@ hipError_t launchFinishPixel(const float *x, float *y, size_t n, hipStream_t str
 hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, uint32_t world, uint32_t rank, size_t perRank,
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
 
+// RSNT (resonator.hip): the resonator bank over `frames` frames of `hop` samples each, starting at planar; state carried in `state`
+struct ResParams {
+    const float *planar; size_t chStride; long frames;
+    uint32_t hop, C, P, mode;
+    int V, signals, sides;
+    bool firstContinues;              // frame 0 of this launch continues from `state` (always, except inside a long render's later slabs)
+    const float2 *coeff, *cpow;       // [V][P]
+    const float *gain;                // [P]
+    float weights[9];                 // [V]
+    float2 *state;                    // [C][2][V][P]
+    float2 *local;                    // [frames][C][signals][V][P]
+    float *mapped;                    // [frames][C][sides][P]
+};
+hipError_t launchResonator(const ResParams &prm, hipStream_t stream);
+
 }  // namespace sgz

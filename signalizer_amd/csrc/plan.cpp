@@ -466,6 +466,72 @@ static bool buildChunkMap(Plan &p, const std::vector<PixelRec> &recs, int nSides
     return true;
 }
 
+// ---- RSNT: CComplexResonator::Constant::mapSystemHz(mappedFrequencies, size, numVectors, sampleRate, freeQ, 8, windowSize)
+// (TransformConstant.h:120-123; numVectors = cpl::dsp::windowCoefficients(window).second, Spectrum.cpp:593).  cpl is absent: restated
+// from the mathematics it implements (UNVERIFIED vs cpl; oracle/resonator.c states the same choices and is the checker):
+//   - filter i sits on mappedFrequencies[i]; its bandwidth B_i is the spacing to the next axis point (the last reuses the one before);
+//     unless Q is free the equivalent window length fs / B_i is bounded by the window size;  pole radius r = exp(-pi B / fs);
+//   - a K-term cosine-sum window  w[n] = sum (-1)^m a_m cos(2 pi m n / N)  becomes the frequency-domain kernel
+//     a_0 X[k] - a_1/2 (X[k-1] + X[k+1]) + a_2/2 (...) - ...  on resonators detuned by m B_i: V = 2K - 1 "vectors";
+//   - gain 1 - r: a full-scale sine on the centre reads 1/2 unwindowed (the two-sided convention of the FFT branch).
+static int windowCosineTerms(uint32_t type, double a[5])
+{
+    for (int i = 0; i < 5; ++i) a[i] = 0.0;
+    switch (type) {
+    case SGZ_WIN_HANN: a[0] = 0.5; a[1] = 0.5; return 2;
+    case SGZ_WIN_HAMMING: a[0] = 0.54; a[1] = 0.46; return 2;
+    case SGZ_WIN_BLACKMAN: a[0] = 0.42; a[1] = 0.5; a[2] = 0.08; return 3;
+    case SGZ_WIN_EXACT_BLACKMAN: a[0] = 7938.0 / 18608.0; a[1] = 9240.0 / 18608.0; a[2] = 1430.0 / 18608.0; return 3;
+    case SGZ_WIN_NUTTALL: a[0] = 0.355768; a[1] = 0.487396; a[2] = 0.144232; a[3] = 0.012604; return 4;
+    case SGZ_WIN_BLACKMAN_NUTTALL: a[0] = 0.3635819; a[1] = 0.4891775; a[2] = 0.1365995; a[3] = 0.0106411; return 4;
+    case SGZ_WIN_BLACKMAN_HARRIS: a[0] = 0.35875; a[1] = 0.48829; a[2] = 0.14128; a[3] = 0.01168; return 4;
+    case SGZ_WIN_FLATTOP: a[0] = 0.21557895; a[1] = 0.41663158; a[2] = 0.277263158; a[3] = 0.083578947; a[4] = 0.006947368; return 5;
+    default: a[0] = 1.0; return 1;       // no cosine-sum form: unwindowed
+    }
+}
+
+static void buildResonator(Plan &p)
+{
+    const sgz_spectrum_config &cfg = p.cfg;
+    double a[5];
+    const int K = windowCosineTerms(cfg.window_type, a), V = 2 * K - 1;
+    const uint32_t P = p.P;
+    const double fs = double(cfg.sample_rate);
+    p.resV = V;
+    for (int v = 0; v < V; ++v) {
+        const int m = v - (K - 1), am = m < 0 ? -m : m;
+        p.resWeights[v] = float(am == 0 ? a[0] : ((am & 1) ? -0.5 : 0.5) * a[am]);
+    }
+    p.resCoeff.assign(size_t(V) * P * 2, 0.f);
+    p.resPow.assign(size_t(V) * P * 2, 0.f);
+    p.resGain.assign(P, 0.f);
+    for (uint32_t i = 0; i < P; ++i) {
+        const uint32_t k = i + 1 >= P ? P - 2 : i;
+        const double hDiff = std::fabs(double(p.mapped[k + 1]) - double(p.mapped[k]));
+        double length = hDiff > 0 ? fs / hDiff : double(cfg.window_size);
+        if (!cfg.free_q && length > double(cfg.window_size)) length = double(cfg.window_size);
+        if (length < 2.0) length = 2.0;
+        const double B = fs / length;
+        const double r = std::exp(-3.14159265358979323846 * B / fs);
+        p.resGain[i] = float(1.0 - r);
+        for (int v = 0; v < V; ++v) {
+            const double omega = 2.0 * 3.14159265358979323846 * (double(p.mapped[i]) + double(v - (K - 1)) * B) / fs;
+            const float cr = float(r * std::cos(omega)), ci = float(r * std::sin(omega));
+            p.resCoeff[(size_t(v) * P + i) * 2] = cr;
+            p.resCoeff[(size_t(v) * P + i) * 2 + 1] = ci;
+            // (the fp32 pole)^hop in double by repeated squaring: what `hop` steps of the fp32 recurrence multiply an old state by, up
+            // to the recurrence's own rounding -- the rounding of the pole itself (6e-8 x hop) must NOT be left out of the power
+            double br = cr, bi = ci, pr = 1.0, pi = 0.0;
+            for (uint32_t e = cfg.hop; e; e >>= 1) {
+                if (e & 1u) { const double t = pr * br - pi * bi; pi = pr * bi + pi * br; pr = t; }
+                const double t = br * br - bi * bi; bi = 2.0 * br * bi; br = t;
+            }
+            p.resPow[(size_t(v) * P + i) * 2] = float(pr);
+            p.resPow[(size_t(v) * P + i) * 2 + 1] = float(pi);
+        }
+    }
+}
+
 sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
 {
     if (cfg.window_size < 1 || cfg.axis_points < 2 || cfg.num_pairs < 1 || cfg.hop < 1 || !(cfg.sample_rate >= 1)) {
@@ -497,6 +563,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         return SGZ_EINVAL;
     }
     if (!(cfg.high_db > cfg.low_db)) { err = "high_db must exceed low_db"; return SGZ_EINVAL; }
+    if (cfg.algorithm > SGZ_ALGO_RSNT) { err = "algorithm must be SGZ_ALGO_FFT or SGZ_ALGO_RSNT"; return SGZ_EINVAL; }
     p.cfg = cfg;
     p.W = cfg.window_size;
     p.N = transformSizeFor(p.W);
@@ -576,6 +643,11 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             for (int c = 0; c < 3; ++c)
                 p.colourTables[(size_t(pair) * (SGZ_NUM_SPEC_COLOURS + 1) + i) * 3 + c] = float(rgb[c]) / 255.0f;
         }
+    if (cfg.algorithm == SGZ_ALGO_RSNT) {
+        // no transform tables: the axis points ARE the filters (mapToLinearSpace's RSNT branch copies the resonator state, :1103-1133)
+        buildResonator(p);
+        return SGZ_OK;
+    }
     if (cfg.channel_mode == SGZ_CH_PHASE) buildPhaseRecords(p);
     else buildPixelRecords(p);
     p.weights.insert(p.weights.end(), size_t(kMaxTaps), 0.0f);    // padding: the kernel reads kMaxTaps weights unconditionally

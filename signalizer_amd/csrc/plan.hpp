@@ -105,6 +105,12 @@ struct Plan {
     std::vector<uint32_t> chunkRec;     // [side][P][2]: per pixel, see ChunkRec in chunk_map.hpp
     std::vector<float> weights12;       // [interpolated pixel][12]: its taps as 12 contiguous floats of the padded array (0 on pad slots and behind the last tap)
     uint32_t chunkSlots[2] = {0, 0};    // tile maxima per side
+    // RSNT (resonator.hip; CComplexResonator::Constant restated): V = 2K - 1 detuned resonators per axis point for a K-term cosine-sum window
+    int resV = 0;
+    std::vector<float> resCoeff;        // [V][P] (re, im): pole r e^{j w}
+    std::vector<float> resPow;          // [V][P] (re, im): (the fp32 pole)^hop, evaluated in double -- the carry of a whole frame
+    std::vector<float> resGain;         // [P]
+    float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
     // sgz_plan_set_option
     bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false;
@@ -138,11 +144,20 @@ struct Plan {
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
     void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
+    float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resGain = nullptr;
+    float *d_resState = nullptr;                          // [C][2][V][P] (re, im): the resonators between calls
+    float *d_resLocal = nullptr; size_t resLocalCap = 0;  // [frames][C][signals][V][P] (re, im): per-frame sums from rest
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs
     int device = 0;
 
     ~Plan();
 };
+
+inline bool isResonator(const Plan &p) { return p.cfg.algorithm == SGZ_ALGO_RSNT; }
+inline long planFrames(const Plan &p, size_t nsamples)
+{
+    return isResonator(p) ? long(nsamples / p.cfg.hop) : long(sgz_num_frames(nsamples, p.W, p.cfg.hop));
+}
 
 // Builds every host table; returns SGZ_OK or an error (message in `err`).
 sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &plan, std::string &err);

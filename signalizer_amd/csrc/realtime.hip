@@ -185,8 +185,9 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     if (s->h_cols) { (void)hipHostFree(s->h_cols); s->h_cols = nullptr; }
     if (s->d_colsQ) { (void)hipFree(s->d_colsQ); s->d_colsQ = nullptr; }
     unbindImage(s);                                        // the image's height is the axis size: a new configuration needs a new binding
-    // a piece's frames read windows that end inside the piece: the ring must hold W + one piece
-    s->cap = (p.W + kPiece + 63u) & ~63u;
+    // a piece's frames read windows that end inside the piece: the ring must hold W + one piece (RSNT: a frame consumes the `hop`
+    // samples that end with it)
+    s->cap = ((isResonator(p) ? p.cfg.hop : p.W) + kPiece + 63u) & ~63u;
     s->maxFrames = kPiece / p.cfg.hop + 1;
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_ring), nch * 2 * s->cap * sizeof(float)));
     SGZ_HIP(hipMemsetAsync(s->d_ring, 0, nch * 2 * s->cap * sizeof(float), s->stream));    // history starts as silence
@@ -198,7 +199,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_lines), stateN * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_linesBatch), size_t(s->maxFrames) * stateN * sizeof(float)));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsBatch), size_t(s->maxFrames) * p.P * 4));
-    if (p.cfg.channel_mode != SGZ_CH_PHASE) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_trackBins), size_t(p.C) * (size_t(p.N) + 1) * sizeof(float)));
+    if (p.cfg.channel_mode != SGZ_CH_PHASE && !isResonator(p)) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_trackBins), size_t(p.C) * (size_t(p.N) + 1) * sizeof(float)));
     if (!s->d_peak) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peak), sizeof(sgz_peak)));
     SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_cols), size_t(kQueueDepth) * p.P * 4, hipHostMallocDefault));
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsQ), size_t(kQueueDepth) * p.P * 4));
@@ -215,6 +216,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
         if (st == SGZ_OK) st = runDecayColour(p, s->d_mapped, 1, s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
     }
     if (st != SGZ_OK) return st;
+    if ((st = resetResonator(p, s->stream)) != SGZ_OK) return st;
     SGZ_HIP(hipMemsetAsync(s->d_state, 0, stateN * sizeof(float), s->stream));
     SGZ_HIP(hipMemsetAsync(s->d_lines, 0, stateN * sizeof(float), s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -260,7 +262,7 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s)
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     SGZ_HIP(hipMemsetAsync(s->d_state, 0, stateN * sizeof(float), s->stream));
     SGZ_HIP(hipMemsetAsync(s->d_lines, 0, stateN * sizeof(float), s->stream));
-    return SGZ_OK;
+    return resetResonator(p, s->stream);                      // RSNT: TransformPair::clearAudioState -> cresonator.resetState (TransformPair.h:183)
 }
 
 // one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
@@ -293,7 +295,9 @@ static sgz_status spectrumPushNow(sgz_spectrum *s, const float *const *blk, uint
         if (frames) {
             // frame k's window ends `first + k hop` samples into the piece; in the mirrored ring it starts at q + k hop, contiguous
             const uint32_t end0 = (s->head.load(std::memory_order_relaxed) + first) % s->cap;
-            const uint32_t q = (end0 + s->cap - (W % s->cap)) % s->cap;
+            // (RSNT: the frames' hop-sample segments tile the stream -- frame k consumes [end_k - hop, end_k))
+            const uint32_t span = isResonator(p) ? hop : W;
+            const uint32_t q = (end0 + s->cap - (span % s->cap)) % s->cap;
             st = runStft(p, s->d_ring + q, size_t(2) * s->cap, long(frames), s->d_mapped, nullptr, nullptr, s->stream, nullptr, /*deferLate=*/true);
             if (st != SGZ_OK) return st;
             st = runDecayColour(p, s->d_mapped, long(frames), s->d_colsBatch, s->d_linesBatch, s->d_state, s->stream);
@@ -498,7 +502,7 @@ sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
     Plan &p = *s->trackPlan;                                  // (not the producer's plan: see sgz_spectrum::trackPlan)
     if (pair >= p.C) return fail(SGZ_EINVAL, "pair out of range");
-    if (!s->d_trackBins) return fail(SGZ_EUNSUPPORTED, "frequency tracker: magnitude modes only");
+    if (!s->d_trackBins) return fail(SGZ_EUNSUPPORTED, "frequency tracker: magnitude modes of the FFT algorithm only");
     // the window a frame firing now would transform (work already enqueued by push precedes this on the stream)
     const uint32_t q = (s->head.load(std::memory_order_acquire) + s->cap - (p.W % s->cap)) % s->cap;
     sgz_status st = runStft(p, s->d_ring + q, size_t(2) * s->cap, 1, nullptr, s->d_trackBins, nullptr, s->stream);

@@ -131,6 +131,7 @@ sgz_status sgz_shard_layout(const sgz_plan *plan, uint32_t rank, uint32_t world,
 {
     if (!plan || rank >= world || world == 0) return fail(SGZ_EINVAL, "bad argument");
     const Plan &p = plan->impl;
+    if (isResonator(p)) return fail(SGZ_EUNSUPPORTED, "RSNT renders are single device");
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
     const Shard sh{chunk_samples, p.W, p.cfg.hop, world};
     if (local_frames) *local_frames = sh.framesOf(rank);
@@ -176,6 +177,8 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
     if (!p.uploaded) { std::string err; sgz_status st = uploadPlan(p, err); if (st != SGZ_OK) return fail(st, err); }
     if (p.cfg.channel_mode == SGZ_CH_PHASE)
         return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
+    if (isResonator(p))
+        return fail(SGZ_EUNSUPPORTED, "RSNT: a rank's resonators would need every earlier rank's end state (an IIR carry); single device only");
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Shard sh{chunk_samples, p.W, p.cfg.hop, world};

@@ -122,7 +122,7 @@ def test_library_exports_every_symbol_the_header_declares():
 
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the C layout (the parity tests pass these structs across the ABI)"""
-    assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4   # incl. tail/align padding
+    assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4 + 8   # incl. align padding; algorithm, free_q
     assert api.SpectrumConfig.ratios.offset % 8 == 0 and api.SpectrumConfig.window_alpha.offset == 40
     assert C.sizeof(api.ScopeView) == 40 and C.sizeof(api.ZeroCrossingState) == 48 and C.sizeof(api.VectorFilters) == 32
 

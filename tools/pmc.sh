@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ/LDS counters for the bench kernels: tools/pmc.sh <tag>
 TAG=${1:-x}
+EXTRA=${2:-}          # e.g. "--workload cfg5"
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 export TMPDIR=/tmp
@@ -11,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $set | cut -d' ' -f1)
-  rocprofv3 -f csv --pmc $set --kernel-trace -d "$OUT/$name" -o c -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/$name.log" 2>&1
+  rocprofv3 -f csv --pmc $set --kernel-trace -d "$OUT/$name" -o c -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras $EXTRA > "$OUT/$name.log" 2>&1
 done
 cd "$ROOT"
 python - "$OUT" <<'PY'
