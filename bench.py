@@ -278,6 +278,33 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
     return out
 
 
+def rsnt_extra(dev, x_host) -> dict:
+    """the Spectrum view's other transform algorithm (RSNT, the resonator bank: resonator.hip) on the same 60 s buffer: one render =
+    351 frames (one per hop), 2 signals x 3 vectors x 1024 resonators advanced by every sample"""
+    import torch
+    from signalizer_amd import api, config
+    cfg = config.spectrum_config(algorithm=config.ALGO_RSNT)
+    xs = torch.from_numpy(x_host[:2]).to(dev)
+    plan = api.Plan(cfg).upload()
+    F = plan.num_frames(xs.shape[1])
+    rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
+    V = plan.resonator()[0].shape[0]
+    plan.render(xs, rgba=rgba)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); plan.render(xs, rgba=rgba); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    flops = 8.0 * F * cfg["hop"] * 2 * V * plan.P
+    return {"metric": "RSNT (resonator bank) spectrogram frames/sec, stereo 48 kHz, 1024 axis points, Hann (3 vectors), one frame per 8192 samples",
+            "value": F / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames": F, "realtime_factor": 60.0 / (ms * 1e-3),
+            "kernel": "resonateKernel<3> + resonatorFoldKernel<3> + K_B", "fp32_tflops": flops / (ms * 1e-3) / 1e12,
+            "note": "VALU-bound: 8 fp32 flops per sample, resonator, vector and signal (complex multiply-add, contraction off); "
+                    "157.3 TFLOP/s is the fp32 vector peak with packed FMAs"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,6 +525,7 @@ def main() -> None:
                                     "vertices_per_step": v["config"]["vertices_per_step"], "realtime_factor": v["config"]["realtime_factor"],
                                     "pushes_refused_busy": v["config"]["pushes_refused_busy"], "kernel": v["roofline"]["kernel"],
                                     "kernel_ms": v["roofline"]["kernel_ms"], "roofline_frac": v["roofline"]["frac"]}
+            out["extras"]["rsnt"] = rsnt_extra(dev, x_host)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_pairs(cfg, x_host) if strong else cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)
