@@ -887,8 +887,9 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             for (uint32_t c = 0; c < 1024; ++c)
                 for (int e = 0; e < 2; ++e) {
                     const double ang = kTwoPi * double(2 * c + e) / double(p.N);
-                    p.winPhase[size_t(c) * 4 + 2 * e + 0] = float(std::cos(ang));
-                    p.winPhase[size_t(c) * 4 + 2 * e + 1] = float(std::sin(ang));
+                    // p1 x (cos even, cos odd, sin even, sin odd): two aligned pairs, the window's cosine coefficient folded in
+                    p.winPhase[size_t(c) * 4 + e] = float(double(p.winP1) * std::cos(ang));
+                    p.winPhase[size_t(c) * 4 + 2 + e] = float(double(p.winP1) * std::sin(ang));
                 }
         }
         if (p.tw2.empty()) {                                   // N = 16384 has no R^3 tables of its own: the channel transform's passes 2 / 3 are radix 32

@@ -15,7 +15,7 @@
 // workgroup and are staged through LDS 256 at a time (one coalesced load + channel mix per thread, then broadcast reads).
 // Against the sequential fp32 recurrence the chained result differs by the rounding of one complex product per frame: ~1e-7 of the
 // state.  Bytes: 8 hop per (frame, pair) in, 8 V P per (frame, signal) through HBM between the two kernels: the path is
-// VALU-bound (7 V fp32 operations per sample and axis point with contraction off).
+// VALU-bound (per sample and axis point 7 V fp32 operations without contraction in the continuing frame, 4 V fused ones in the others).
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -39,10 +39,57 @@ __device__ __forceinline__ float resMix(uint32_t mode, int signal, float l, floa
     }
 }
 
+// one sample into the V chains of a thread.  EXACT: the reference's recurrence operation by operation (no contraction) -- the frame that
+// continues the carried state; otherwise fused multiply-adds (4 operations instead of 7): the frames that start from rest are chained
+// with c^hop afterwards and are held to a tolerance, not to the sequential recurrence's bits
+template <int V, bool EXACT>
+__device__ __forceinline__ void resStep(float (&re)[V], float (&im)[V], const float (&cr)[V], const float (&ci)[V], float x)
+{
+    if constexpr (EXACT) {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float nre = (re[v] * cr[v] - im[v] * ci[v]) + x;
+            const float nim = re[v] * ci[v] + im[v] * cr[v];
+            re[v] = nre; im[v] = nim;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float nre = __builtin_fmaf(re[v], cr[v], __builtin_fmaf(-im[v], ci[v], x));
+            const float nim = __builtin_fmaf(re[v], ci[v], im[v] * cr[v]);
+            re[v] = nre; im[v] = nim;
+        }
+    }
+}
+
+template <int V, bool EXACT>
+__device__ __forceinline__ void resRun(const ResParams &prm, float *xs, const float *L, const float *R, int signal, int tid,
+                                       float (&re)[V], float (&im)[V], const float (&cr)[V], const float (&ci)[V])
+{
+    for (uint32_t t0 = 0; t0 < prm.hop; t0 += kResBlock) {
+        const uint32_t n = min(uint32_t(kResBlock), prm.hop - t0);
+        __syncthreads();
+        xs[tid] = uint32_t(tid) < n ? resMix(prm.mode, signal, L[t0 + tid], R[t0 + tid]) : 0.f;
+        __syncthreads();
+        if (n == uint32_t(kResBlock)) {
+#pragma unroll 2
+            for (int j = 0; j < kResBlock; j += 4) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(xs + j);
+                resStep<V, EXACT>(re, im, cr, ci, x4.x);
+                resStep<V, EXACT>(re, im, cr, ci, x4.y);
+                resStep<V, EXACT>(re, im, cr, ci, x4.z);
+                resStep<V, EXACT>(re, im, cr, ci, x4.w);
+            }
+        } else {
+            for (uint32_t j = 0; j < n; ++j) resStep<V, EXACT>(re, im, cr, ci, xs[j]);
+        }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
 {
-#pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float xs[kResBlock];
     const int tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kResBlock + tid;
@@ -53,6 +100,7 @@ __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
     const long frame = long(unit / (uint32_t(prm.signals) * prm.C));
     const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
     const float *R = L + prm.chStride;
+    const bool continues = frame == 0 && prm.firstContinues;       // uniform per workgroup
 
     float cr[V], ci[V], re[V], im[V];
     const size_t stateAt = (size_t(pair) * 2 + size_t(signal)) * V * prm.P + i;
@@ -60,41 +108,11 @@ __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
     for (int v = 0; v < V; ++v) {
         const float2 c = live ? prm.coeff[size_t(v) * prm.P + i] : float2{0.f, 0.f};
         cr[v] = c.x; ci[v] = c.y;
-        const float2 s0 = (live && frame == 0 && prm.firstContinues) ? prm.state[stateAt + size_t(v) * prm.P] : float2{0.f, 0.f};
+        const float2 s0 = (live && continues) ? prm.state[stateAt + size_t(v) * prm.P] : float2{0.f, 0.f};
         re[v] = s0.x; im[v] = s0.y;
     }
-    for (uint32_t t0 = 0; t0 < prm.hop; t0 += kResBlock) {
-        const uint32_t n = min(uint32_t(kResBlock), prm.hop - t0);
-        __syncthreads();
-        xs[tid] = uint32_t(tid) < n ? resMix(prm.mode, signal, L[t0 + tid], R[t0 + tid]) : 0.f;
-        __syncthreads();
-        if (n == uint32_t(kResBlock)) {
-#pragma unroll 2
-            for (int j = 0; j < kResBlock; j += 4) {
-                const float4 x4 = *reinterpret_cast<const float4 *>(xs + j);
-                const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const float nre = (re[v] * cr[v] - im[v] * ci[v]) + x[k];
-                        const float nim = re[v] * ci[v] + im[v] * cr[v];
-                        re[v] = nre; im[v] = nim;
-                    }
-                }
-            }
-        } else {
-            for (uint32_t j = 0; j < n; ++j) {
-                const float x = xs[j];
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const float nre = (re[v] * cr[v] - im[v] * ci[v]) + x;
-                    const float nim = re[v] * ci[v] + im[v] * cr[v];
-                    re[v] = nre; im[v] = nim;
-                }
-            }
-        }
-    }
+    if (continues) resRun<V, true>(prm, xs, L, R, signal, tid, re, im, cr, ci);
+    else resRun<V, false>(prm, xs, L, R, signal, tid, re, im, cr, ci);
     if (live) {
         float2 *out = prm.local + ((size_t(frame) * prm.C + pair) * size_t(prm.signals) + size_t(signal)) * V * prm.P + i;
 #pragma unroll

@@ -224,18 +224,39 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         }
         if (WCOS) {
             // w[n] = p0 + p1 cos(theta_n), theta_n = 2 pi n / N, n = 2 (col + R^2 j) + e: theta = phi(col, e) + 2 pi j / R1 -- the phase of the
-            // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle
+            // column's first pair comes from a 16 KB table, the step to the next pair is a rotation by a compile-time angle.  Evaluated on
+            // (even, odd) sample pairs with packed operations, and only for j < R1 / 2: j + R1 / 2 is half a turn further, its cosine the
+            // negative -- w[j] = p0 + t, w[j + R1/2] = p0 - t with t = p1 cos(theta_j) (p1 is folded into the table).
+            const v2 p0 = v2{prm.winP0, prm.winP0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 ph = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);
+                const float4 ph = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
+                const v2 pc = v2{ph.x, ph.y}, ps = v2{ph.z, ph.w};
 #pragma unroll
-                for (int j = 0; j < R1; ++j) {
+                for (int j = 0; j < R1 / 2; ++j) {
                     constexpr int S32 = 32 / R1;
-                    const float cj = cos32((j * S32) % 32 <= 16 ? (j * S32) % 32 : 32 - (j * S32) % 32);
-                    const float sj = (j * S32) % 32 <= 16 ? sin32((j * S32) % 32) : -sin32(32 - (j * S32) % 32);
-                    const float ce = ph.x * cj - ph.y * sj, co = ph.z * cj - ph.w * sj;
-                    const int i = u * R1 + j;
-                    c[i] = v2{c[i].x * (prm.winP0 + prm.winP1 * ce), c[i].y * (prm.winP0 + prm.winP1 * co)};
+                    const int a32 = j * S32;                                    // angle in 32nds of a turn, < 16
+                    const int i = u * R1 + j, i2 = i + R1 / 2;
+                    if constexpr (LR1 == 3) {
+                        // (the 256-thread kernel runs at the 128-register limit with four columns' phases in flight: scalar form, same symmetry)
+                        const float cj = cos32(a32), sj = sin32(a32);
+                        const float te = a32 == 0 ? ph.x : ph.x * cj - ph.z * sj, to = a32 == 0 ? ph.y : ph.y * cj - ph.w * sj;
+                        c[i] = v2{c[i].x * (prm.winP0 + te), c[i].y * (prm.winP0 + to)};
+                        c[i2] = v2{c[i2].x * (prm.winP0 - te), c[i2].y * (prm.winP0 - to)};
+                        continue;
+                    }
+                    v2 t = pc;
+                    if (a32 != 0) {
+                        const v2 k = v2{cos32(a32), sin32(a32)};
+                        v2 m;
+                        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(m) : "v"(ps), "s"(k));                   // ps sin
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(pc), "s"(k), "v"(m));   // pc cos - ps sin
+                    }
+                    v2 wa, wb;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(wa) : "v"(t), "s"(p0));
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0]" : "=v"(wb) : "v"(t), "s"(p0));
+                    c[i] = c[i] * wa;
+                    c[i2] = c[i2] * wb;
                 }
             }
         } else {
@@ -416,11 +437,21 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const v2 a = c[i];
             const v2 b = v2{partnerOf(c[ip].x), partnerOf(c[ip].y)};
             const v2 w = m3 == 0 ? v2{wk.x, wk.y} : cmulConjK(v2{wk.x, wk.y}, v2{cos64(m3), sin64(m3)});
-            const float ex = a.x + b.x, ey = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
-            const float ox = w.x * dy + w.y * dx, oy = w.y * dy - w.x * dx;      // -i w (dx + i dy)
-            const float pr = ex + ox, pi = ey + oy, mr = ex - ox, mi = ey - oy;
-            magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(pr * pr + pi * pi);
-            magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(mr * mr + mi * mi);
+            // on (re, im) pairs: E = a + conj b, D = a - conj b, O = -i w D = (w.x D.y + w.y D.x, w.y D.y - w.x D.x); then the real parts
+            // (E.x + O.x, E.x - O.x) of 2 X[k], 2 X[M - k] in one pair and the imaginary parts (E.y + O.y, E.y - O.y) in another: both
+            // squared magnitudes come out of one packed multiply and one packed multiply-add
+            v2 E, D, t, O, re2, im2, sq;
+            asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E) : "v"(a), "v"(b));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(D) : "v"(a), "v"(b));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(w), "v"(D));                                   // (w.x D.y, w.y D.y)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(O) : "v"(w), "v"(D), "v"(t));     // (+ w.y D.x, - w.x D.x)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(re2) : "v"(E), "v"(O));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(im2) : "v"(E), "v"(O));
+            sq = re2 * re2;
+            asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(sq) : "v"(im2), "v"(sq));
+            const float pr = re2.x, mr = re2.y, pi = im2.x, mi = im2.y;
+            magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(sq.x);
+            magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(sq.y);
             if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
                 // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
                 // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
