@@ -376,9 +376,19 @@ def main() -> None:
         ok = torch.tensor([1 if cand is not None else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
+            # ... and on whether one render goes through everywhere (a rank that fails aborts its communicator, so its peers fail
+            # instead of waiting: sharded.hip)
+            try:
+                cand.render()
+                torch.cuda.synchronize()
+            except Exception as e:                                 # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             shard, shard_note = cand, "c_abi"
         else:
-            shard_note = "torch (sgz_comm_create failed on some rank" + (f": {err}" if err else "") + ")"
+            shard_note = "torch (the library's own RCCL path failed on some rank" + (f": {err}" if err else "") + ")"
     frames_per_rank = shard.local_frames
     stream = torch.cuda.current_stream().cuda_stream
 
