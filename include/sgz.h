@@ -53,7 +53,7 @@ enum { SGZ_WIN_SYMMETRIC = 0, SGZ_WIN_PERIODIC };
 /* OscChannels, Source/Common/CommonSignalizer.h:458-493 */
 enum { SGZ_OSC_LEFT = 0, SGZ_OSC_RIGHT, SGZ_OSC_MID, SGZ_OSC_SIDE, SGZ_OSC_SEPARATE, SGZ_OSC_MIDSIDE };
 
-/* OscilloscopeContent::TriggeringMode, Source/Oscilloscope/OscilloscopeParameters.h:50-58 (built: None, Spectral, ZeroCrossing) */
+/* OscilloscopeContent::TriggeringMode, Source/Oscilloscope/OscilloscopeParameters.h:50-58 */
 enum { SGZ_TRIG_NONE = 0, SGZ_TRIG_SPECTRAL, SGZ_TRIG_WINDOW, SGZ_TRIG_ENVELOPE_HOLD, SGZ_TRIG_ZERO_CROSSING };
 /* EnvelopeModes / SubSampleInterpolation, Source/Common/CommonSignalizer.h:72-85 */
 enum { SGZ_ENV_NONE = 0, SGZ_ENV_RMS, SGZ_ENV_PEAK_DECAY };
@@ -417,10 +417,11 @@ typedef struct sgz_scope_config {
     double   sample_rate;
     double   window_size;        /* state.effectiveWindowSize in samples (fractions allowed)                     */
     uint32_t num_channels;       /* even, 2..64                                                                  */
-    uint32_t trigger_mode;       /* SGZ_TRIG_NONE / SGZ_TRIG_SPECTRAL / SGZ_TRIG_ZERO_CROSSING                   */
+    uint32_t trigger_mode;       /* SGZ_TRIG_* (Window: see sgz_scope_set_transport)                             */
     uint32_t channel_mode;       /* SGZ_OSC_* (OscChannels): trigger mix, envelope mix                           */
     uint32_t envelope_mode;      /* SGZ_ENV_*: RMS runs in push (audioProcessing), PEAK_DECAY in sgz_scope_peak_filter */
-    uint32_t interpolation;      /* SGZ_SUBSAMPLE_LINEAR / SGZ_SUBSAMPLE_LANCZOS                                 */
+    uint32_t interpolation;      /* SGZ_SUBSAMPLE_*: None = the Linear vertex list, drawn as GL_POINTS (dotSamples,
+                                    OscilloscopeRendering.cpp:652-700); Rectangular = two vertices per sample (:746-789) */
     uint32_t max_block;          /* longest block push will be given (0: 8192)                                   */
     double   trigger_threshold;  /* content->triggerThreshold                                                    */
     double   trigger_channel;    /* content->triggeringChannel, 1-based (calculateTriggerIndices)                */
@@ -434,6 +435,9 @@ typedef struct sgz_scope_config {
     float    frequency_colouring_blend;   /* content->frequencyColouringBlend, 0..1                              */
     double   colour_smoothing_ms;  /* content->colourSmoothing (transformed value, milliseconds)                 */
     float    band_colours[3][3];   /* content->lowColour / midColour / highColour as float r, g, b               */
+    /* Spectral triggering on a frequency the user names (state.customTrigger / customTriggerFrequency, OscilloscopeDSP.inl:71-81) */
+    uint32_t custom_trigger;
+    double   custom_trigger_frequency;    /* Hz, in (0, sample_rate / 2)                                          */
 } sgz_scope_config;
 /* Oscilloscope::triggerState after analyseAndSetupState's first two steps (Oscilloscope.h:176-196) */
 typedef struct sgz_trigger_state {
@@ -453,6 +457,10 @@ sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg);
 /* onStreamAudio(ctx, float** buffer, numChannels, numSamples); the steady clock is the running count of pushed samples */
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
 sgz_status sgz_scope_flush(sgz_scope *s);      /* as sgz_spectrum_flush */
+/* TriggeringMode::Window draws the window at the host transport's phase: position_in_samples = cs.transportPosition =
+ * playhead.getPositionInSamples() + numSamples of the newest block (OscilloscopeDSP.inl:706; OscilloscopeRendering.cpp:588-592,
+ * :798-801).  Any thread, any time (one atomic store); ignored by the other modes. */
+sgz_status sgz_scope_set_transport(sgz_scope *s, int64_t position_in_samples);
 /* runPeakFilter once per rendered frame: delta_time = openGLDeltaTime(), lanes = the SIMD width whose tail the reference drops
  * (8 = AVX); *auto_gain = state.autoGain (optional; reading it waits for the kernel) */
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain);

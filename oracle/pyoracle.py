@@ -166,6 +166,10 @@ def lib() -> C.CDLL:
         L.sgzo_scope_stream_enable_colours.argtypes = [vp, vp, C.c_double, C.c_double, vp]
         L.sgzo_scope_stream_front_colours.restype = C.c_size_t
         L.sgzo_scope_stream_front_colours.argtypes = [vp, C.c_uint32, C.c_int, vp]
+        L.sgzo_scope_wave_plot_ex2.restype = C.c_size_t
+        L.sgzo_scope_wave_plot_ex2.argtypes = [C.POINTER(ScopeView), C.c_int, C.c_int, vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double,
+                                               C.c_double, C.c_int64, C.c_uint32, vp, vp, vp, C.c_size_t]
+        L.sgzo_scope_stream_set_hysteresis.argtypes = [vp, C.c_double]
         L.sgzo_scope_wave_plot_ex.restype = C.c_size_t
         L.sgzo_scope_wave_plot_ex.argtypes = [C.POINTER(ScopeView), C.c_int, C.c_int, vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double,
                                               C.c_double, vp, vp, vp, C.c_size_t]
@@ -174,6 +178,8 @@ def lib() -> C.CDLL:
         L.sgzo_scope_fundamental.restype = None
         L.sgzo_scope_fundamental.argtypes = [C.POINTER(SpectralState), vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                              C.c_double, C.c_double]
+        L.sgzo_scope_fundamental_custom.restype = None
+        L.sgzo_scope_fundamental_custom.argtypes = [C.POINTER(SpectralState), C.c_double, C.c_double]
         L.sgzo_scope_trigger_offset.restype = None
         L.sgzo_scope_trigger_offset.argtypes = [C.POINTER(SpectralState), vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                                 C.c_double]
@@ -456,6 +462,9 @@ class ScopeStream:
         except Exception:
             pass
 
+    def set_hysteresis(self, hysteresis: float):
+        lib().sgzo_scope_stream_set_hysteresis(self.h, hysteresis)
+
     def audio(self, block: np.ndarray):
         b = np.ascontiguousarray(block, np.float32)
         assert b.shape[0] == self.channels
@@ -542,6 +551,24 @@ def scope_wave_plot_ex(view: ScopeView, trigger_mode: int, interpolation: int, m
     return out, (None if rgba is None else rgba.view(np.uint8).reshape(n, 4))
 
 
+def scope_wave_plot_ex2(view: ScopeView, trigger_mode: int, interpolation: int, mem_a, mem_b, eval_mode: int, cursor: int,
+                        cycle_samples: float = 0.0, sample_offset: float = 0.0, transport_position: int = 0, key: int = 0xFFFFFFFF,
+                        colour_mem=None):
+    """drawWavePlot with every trigger mode (Window: transport_position) and interpolation (None / Rectangular / Linear / Lanczos)
+    -> (vertices [n][3], rgba [n][4])"""
+    a = np.ascontiguousarray(mem_a, np.float32)
+    b = np.ascontiguousarray(mem_b, np.float32)
+    cm = None if colour_mem is None else np.ascontiguousarray(colour_mem, np.uint32)
+    args = (C.byref(view), trigger_mode, interpolation, _ptr(a), _ptr(b), eval_mode, a.size, cursor, cycle_samples, sample_offset,
+            int(transport_position), int(key), None if cm is None else _ptr(cm))
+    n = lib().sgzo_scope_wave_plot_ex2(*args, None, None, 0)
+    out = np.zeros((n, 3), np.float32)
+    rgba = np.zeros(n, np.uint32)
+    m = lib().sgzo_scope_wave_plot_ex2(*args, _ptr(out), _ptr(rgba), n)
+    assert m == n
+    return out, rgba.view(np.uint8).reshape(n, 4)
+
+
 class BinRecord(C.Structure):
     _fields_ = [("index", C.c_uint64), ("value", C.c_double), ("offset", C.c_double)]
 
@@ -553,11 +580,14 @@ class SpectralState(C.Structure):
 
 
 def scope_analyse(ts: SpectralState, mem_a, mem_b, eval_mode: int, cursor: int, window_size: float, sample_rate: float,
-                  threshold: float, hysteresis: float, phase_offset_degrees: float):
-    """calculateFundamentalPeriod + calculateTriggeringOffset (Spectral) on a ring; updates ts"""
+                  threshold: float, hysteresis: float, phase_offset_degrees: float, custom_frequency: float = 0.0):
+    """calculateFundamentalPeriod + calculateTriggeringOffset (Spectral) on a ring; updates ts.  custom_frequency > 0: state.customTrigger"""
     a = np.ascontiguousarray(mem_a, np.float32)
     b = np.ascontiguousarray(mem_b, np.float32)
-    lib().sgzo_scope_fundamental(C.byref(ts), _ptr(a), _ptr(b), eval_mode, a.size, cursor, window_size, sample_rate, threshold, hysteresis)
+    if custom_frequency > 0:
+        lib().sgzo_scope_fundamental_custom(C.byref(ts), custom_frequency, sample_rate)
+    else:
+        lib().sgzo_scope_fundamental(C.byref(ts), _ptr(a), _ptr(b), eval_mode, a.size, cursor, window_size, sample_rate, threshold, hysteresis)
     lib().sgzo_scope_trigger_offset(C.byref(ts), _ptr(a), _ptr(b), eval_mode, a.size, cursor, window_size, sample_rate, phase_offset_degrees)
     return ts
 

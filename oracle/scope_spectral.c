@@ -177,6 +177,16 @@ void sgzo_scope_fundamental(sgzo_spectral_state *ts, const float *memA, const fl
     ts->cycle_samples = sample_rate / fundamental;
 }
 
+/* calculateFundamentalPeriod with state.customTrigger (OscilloscopeDSP.inl:71-81): the user names the frequency; no transform, the
+ * median filter is not touched.  sgzo_scope_trigger_offset follows as usual. */
+void sgzo_scope_fundamental_custom(sgzo_spectral_state *ts, double custom_frequency, double sample_rate)
+{
+    const double normalizedFrequency = custom_frequency / sample_rate;
+    ts->record.index = 0; ts->record.value = 1; ts->record.offset = normalizedFrequency * (double)LOOKAHEAD;
+    ts->fundamental = custom_frequency;
+    ts->cycle_samples = sample_rate / custom_frequency;
+}
+
 /* calculateTriggeringOffset, Spectral branch */
 void sgzo_scope_trigger_offset(sgzo_spectral_state *ts, const float *memA, const float *memB, int eval_mode, size_t size, size_t cursor,
                                double window_size, double sample_rate, double phase_offset_degrees)

@@ -25,7 +25,7 @@
 #include <string.h>
 
 enum { OSC_LEFT = 0, OSC_RIGHT = 1, OSC_MID = 2, OSC_SIDE = 3, OSC_SEPARATE = 4, OSC_MIDSIDE = 5 };
-enum { TRIG_NONE = 0, TRIG_SPECTRAL = 1, TRIG_ZERO_CROSSING = 4 };            /* OscilloscopeContent::TriggeringMode, OscilloscopeParameters.h:50-58 */
+enum { TRIG_NONE = 0, TRIG_SPECTRAL = 1, TRIG_WINDOW = 2, TRIG_ENVELOPE_HOLD = 3, TRIG_ZERO_CROSSING = 4 };            /* OscilloscopeContent::TriggeringMode, OscilloscopeParameters.h:50-58 */
 enum { ENV_NONE = 0, ENV_RMS = 1, ENV_PEAK_DECAY = 2 };    /* EnvelopeModes, CommonSignalizer.h */
 
 typedef struct { float *buf; size_t size, cursor; } ring_t;
@@ -153,6 +153,9 @@ sgzo_scope_stream *sgzo_scope_stream_create(uint32_t channels, double sample_rat
     s->threshold = threshold;
     return s;
 }
+
+/* TriggeringProcessor::setSettings' hysteresis (StreamPreprocessing.h:46-53, Oscilloscope.cpp:310): only the envelope-hold detector reads it */
+void sgzo_scope_stream_set_hysteresis(sgzo_scope_stream *s, double hysteresis) { s->hysteresis = hysteresis; }
 
 void sgzo_scope_stream_destroy(sgzo_scope_stream *s)
 {
@@ -289,7 +292,7 @@ static void audio_processing(sgzo_scope_stream *s, const float *const *buffer, s
     for (uint32_t c = 0; c < numChannels; ++c) ring_write(&target[c], buffer[c], numSamples);   /* :696-697 */
 }
 
-/* executeSamplingWindows<ZeroCrossingProcessor>, OscilloscopeDSP.inl:311-385 + StreamPreprocessing.h:315-349 */
+/* executeSamplingWindows<ZeroCrossingProcessor | PeakHoldProcessor>, OscilloscopeDSP.inl:311-385 + StreamPreprocessing.h:270-349 */
 static void pre_analyse(sgzo_scope_stream *s, const float *const *buffer, size_t numSamples)
 {
     if (s->channels < 2) return;
@@ -309,6 +312,24 @@ static void pre_analyse(sgzo_scope_stream *s, const float *const *buffer, size_t
         if (localMode == OSC_MID) sample = (double)(0.5f * (a[n] + b[n]));
         else if (localMode == OSC_SIDE) sample = (double)(0.5f * (a[n] - b[n]));
         else sample = (double)a[n];
+        if (s->trigger_mode == TRIG_ENVELOPE_HOLD) {                                    /* PeakHoldProcessor::process, :282-310 */
+            sample *= sample;
+            const double delta = sample - s->state;
+            if (delta < 0) {
+                s->state *= 0.9999;
+                s->state = fmax(s->threshold * s->threshold, s->state);
+                if (s->isPeakHold) {
+                    /* minus one since this is the first sample that doesn't qualify as a (rising) peak */
+                    q_push(&s->peaks, s->playhead + count - 1);
+                    s->isPeakHold = 0;
+                }
+            } else {
+                if (delta > s->hysteresis * s->state) s->isPeakHold = 1;
+                s->state = sample;
+            }
+            count++;
+            continue;
+        }
         if (sample > 0 && s->state < 0) { s->isPeakHold = 1; s->crossOrigin = s->playhead + count; }
         if (s->isPeakHold && sample > s->threshold) { s->isPeakHold = 0; q_push(&s->peaks, s->crossOrigin); }
         s->state = sample;
@@ -423,8 +444,9 @@ void sgzo_scope_stream_audio(sgzo_scope_stream *s, const float *const *planar, s
         s->frontOrigin = s->playhead;
         s->isWorkingOnPeak = 0;
     }
-    if (s->trigger_mode == TRIG_ZERO_CROSSING) pre_analyse(s, local, n);                /* preAnalyseAudio, :387-399 */
-    if (s->trigger_mode != TRIG_ZERO_CROSSING) audio_processing(s, local, n, s->front); /* :415-418 */
+    const int hold = s->trigger_mode == TRIG_ZERO_CROSSING || s->trigger_mode == TRIG_ENVELOPE_HOLD;
+    if (hold) pre_analyse(s, local, n);                                                 /* preAnalyseAudio, :387-399 */
+    if (!hold) audio_processing(s, local, n, s->front);                                 /* :415-418 */
     else process_mutating(s, local, n);                                                 /* :420-422 */
     s->playhead += n;
 }

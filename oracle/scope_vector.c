@@ -240,6 +240,20 @@ size_t sgzo_scope_wave_plot_ex(const sgzo_scope_view *v, int trigger_mode, int i
                                int eval_mode, size_t size, size_t cursor, double cycle_samples, double sample_offset,
                                const uint32_t *colour_mem, float *xyz, uint32_t *rgba, size_t max_points)
 {
+    return sgzo_scope_wave_plot_ex2(v, trigger_mode, interpolation, memA, memB, eval_mode, size, cursor, cycle_samples, sample_offset, 0,
+                                    0xffffffffu, colour_mem, xyz, rgba, max_points);
+}
+
+/* ... plus the remaining branches of drawWavePlot: TriggeringMode::Window (2) places the window by the host transport
+ * (cs.transportPosition = playhead.getPositionInSamples() + numSamples, OscilloscopeDSP.inl:706; :588-592, :798-801), EnvelopeHold (3)
+ * draws like ZeroCrossing (:593-597, :802-805); SubSampleInterpolation::None (0) draws the Linear vertex list as GL_POINTS
+ * (dotSamples, :652-700, and no case in the switch), Rectangular (1) two vertices per sample with the previous and the current
+ * sample's colour (:746-789; `key` = evaluator.getDefaultKey() when colours do not follow the frequency). */
+size_t sgzo_scope_wave_plot_ex2(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                                int eval_mode, size_t size, size_t cursor, double cycle_samples, double sample_offset,
+                                int64_t transport_position, uint32_t key, const uint32_t *colour_mem, float *xyz, uint32_t *rgba,
+                                size_t max_points)
+{
     enum { KernelSize = 10, KernelBufferSize = 21 };
     if (size == 0) return 0;
     const double horizontalDelta = v->right - v->left;
@@ -248,11 +262,13 @@ size_t sgzo_scope_wave_plot_ex(const sgzo_scope_view *v, int trigger_mode, int i
     const double sizeMinusOne = fmax(1.0, v->window_size - 1);
     const double pixelsPerSample = v->rendering_scale * fabs(((double)v->width - 1) / (sizeMinusOne * horizontalDelta));
     if (pixelsPerSample < 1 && interpolation != 0) interpolation = 2;                  /* :575-578: Linear below one pixel per sample */
-    const double triggerSampleOffset = trigger_mode == 4 ? (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5
-                                                         : (trigger_mode == 1 ? sample_offset : 0.0);
+    const int hold = trigger_mode == 4 || trigger_mode == 3;                           /* ZeroCrossing, EnvelopeHold */
+    const double triggerSampleOffset = hold ? (v->window_size * 0.5 - (double)(int)(v->window_size * 0.5)) - 1.5
+                                            : (trigger_mode == 1 ? sample_offset : 0.0);
     const double triggerCycleSamples = trigger_mode == 1 ? cycle_samples : 0.0;        /* calculateTriggeringOffset :241-248 */
     long bufferOffset;
-    if (trigger_mode == 4) bufferOffset = (long)ceil(triggerSampleOffset);             /* :590-596 */
+    if (trigger_mode == 2) bufferOffset = (long)ceil(fmod((double)transport_position, v->window_size));   /* :588-592 */
+    else if (hold) bufferOffset = (long)ceil(triggerSampleOffset);                     /* :593-597 */
     else {                                                                             /* :598-612 */
         const long cycleBuffers = interpolation == 3 ? 2 : 1;
         if (trigger_mode != 0) quantizedCycleSamples = (long)ceil(triggerCycleSamples);
@@ -260,23 +276,43 @@ size_t sgzo_scope_wave_plot_ex(const sgzo_scope_view *v, int trigger_mode, int i
     }
     roundedWindow = roundedWindow > 2 ? roundedWindow : 2;                             /* :615 */
     size_t n = 0;
-    if (interpolation == 2) {                                                          /* Linear, :707-741 */
+    if (interpolation == 2 || interpolation == 0) {                                    /* Linear, :707-741; None: the same list as points, :652-700 */
         long p = ((long)cursor - bufferOffset) % (long)size;                           /* eval.startFrom(-(bufferOffset + 0)) */
         if (p < 0) p += (long)size;
         const float endCondition = (float)(roundedWindow + quantizedCycleSamples);     /* :631 */
         for (float i = 0; i < endCondition; i += 1) {
             if (n < max_points) {
                 xyz[n * 3] = i; xyz[n * 3 + 1] = wave_eval(memA, memB, eval_mode, p); xyz[n * 3 + 2] = 0;
-                if (colour_mem && rgba) rgba[n] = colour_mem[p];
+                if (rgba) rgba[n] = colour_mem ? colour_mem[p] : key;
             }
             ++n;
             if (++p == (long)size) p = 0;
         }
         return n;
     }
+    if (interpolation == 1) {                                                          /* Rectangular, :746-789 */
+        long p = ((long)cursor - bufferOffset) % (long)size;
+        if (p < 0) p += (long)size;
+        const float endCondition = (float)(roundedWindow + quantizedCycleSamples);
+        uint32_t oldColour = colour_mem ? colour_mem[p] : key;                         /* evaluator.evaluateColour() before the loop */
+        for (float i = 0; i < endCondition; i += 1) {
+            const float y = wave_eval(memA, memB, eval_mode, p);
+            const uint32_t col = colour_mem ? colour_mem[p] : key;
+            if (n + 1 < max_points) {
+                xyz[n * 3] = i; xyz[n * 3 + 1] = y; xyz[n * 3 + 2] = 0;
+                xyz[n * 3 + 3] = i + 1; xyz[n * 3 + 4] = y; xyz[n * 3 + 5] = 0;
+                if (rgba) { rgba[n] = oldColour; rgba[n + 1] = col; }
+            }
+            oldColour = col;
+            n += 2;
+            if (++p == (long)size) p = 0;
+        }
+        return n;
+    }
     /* Lanczos, :790-891 */
     double samplePos;
-    if (trigger_mode == 4) samplePos = triggerSampleOffset;
+    if (trigger_mode == 2) samplePos = fmod((double)transport_position, v->window_size) - 1;   /* :798-801 */
+    else if (hold) samplePos = triggerSampleOffset;                                     /* :802-805 */
     else samplePos = triggerCycleSamples * 2 + v->window_size - (trigger_mode == 1 ? triggerSampleOffset : 0.0);   /* :810 */
     if (trigger_mode == 0 || trigger_mode == 2) samplePos = ceil(samplePos);            /* :814-819 */
     const double inc = horizontalDelta / (v->rendering_scale * ((double)v->width - 1));

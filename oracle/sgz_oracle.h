@@ -154,6 +154,10 @@ size_t sgzo_scope_lanczos(const sgzo_scope_view *v, const float *ring, size_t le
 size_t sgzo_scope_num_points(const sgzo_scope_view *v);
 
 /* drawWavePlot for one evaluator on front-buffer memory + cursor (trigger_mode 0 None / 4 ZeroCrossing; interpolation 2 Linear / 3 Lanczos) */
+size_t sgzo_scope_wave_plot_ex2(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
+                                int eval_mode, size_t size, size_t cursor, double cycle_samples, double sample_offset,
+                                int64_t transport_position, uint32_t key, const uint32_t *colour_mem, float *xyz, uint32_t *rgba,
+                                size_t max_points);
 size_t sgzo_scope_wave_plot(const sgzo_scope_view *v, int trigger_mode, int interpolation, const float *memA, const float *memB,
                             int eval_mode, size_t size, size_t cursor, float *xyz, size_t max_points);
 
@@ -169,6 +173,7 @@ sgzo_scope_stream *sgzo_scope_stream_create(uint32_t channels, double sample_rat
                                             double threshold, uint32_t osc_mode, double trigger_channel_1based,
                                             uint32_t env_mode, double envelope_window_s);
 void   sgzo_scope_stream_destroy(sgzo_scope_stream *s);
+void   sgzo_scope_stream_set_hysteresis(sgzo_scope_stream *s, double hysteresis);
 void   sgzo_scope_stream_audio(sgzo_scope_stream *s, const float *const *planar, size_t n);
 size_t sgzo_scope_stream_size(const sgzo_scope_stream *s);                          /* front buffer size = ceil(window + 1) */
 size_t sgzo_scope_stream_front(const sgzo_scope_stream *s, uint32_t c, float *out); /* raw ring memory; returns the cursor */
@@ -194,6 +199,7 @@ typedef struct sgzo_spectral_state {                                            
 void sgzo_nth_element_by_index(sgzo_bin_record *v, int n, int nth);
 void sgzo_scope_fundamental(sgzo_spectral_state *ts, const float *memA, const float *memB, int eval_mode, size_t size, size_t cursor,
                             double window_size, double sample_rate, double threshold, double hysteresis);
+void sgzo_scope_fundamental_custom(sgzo_spectral_state *ts, double custom_frequency, double sample_rate);
 void sgzo_scope_trigger_offset(sgzo_spectral_state *ts, const float *memA, const float *memB, int eval_mode, size_t size, size_t cursor,
                                double window_size, double sample_rate, double phase_offset_degrees);
 typedef struct sgzo_lr_coeffs { float lp1[5], hp1[5], lp2[5], hp2[5]; } sgzo_lr_coeffs;      /* b0 b1 b2 a1 a2 per section type */

@@ -69,7 +69,8 @@ class ScopeConfig(C.Structure):
                 ("trigger_threshold", C.c_double), ("trigger_channel", C.c_double), ("envelope_window", C.c_double),
                 ("colours", (C.c_uint8 * 4) * 64),
                 ("trigger_hysteresis", C.c_double), ("trigger_phase_offset", C.c_double), ("colour_by_frequency", C.c_uint32),
-                ("frequency_colouring_blend", C.c_float), ("colour_smoothing_ms", C.c_double), ("band_colours", (C.c_float * 3) * 3)]
+                ("frequency_colouring_blend", C.c_float), ("colour_smoothing_ms", C.c_double), ("band_colours", (C.c_float * 3) * 3),
+                ("custom_trigger", C.c_uint32), ("custom_trigger_frequency", C.c_double)]
 
 
 class TriggerState(C.Structure):
@@ -126,7 +127,7 @@ EXPORTS = [
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
-    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_spectrum_backlog", "sgz_spectrum_stream", "sgz_spectrum_flush", "sgz_scope_flush", "sgz_vector_flush", "sgz_vector_history",
+    "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_spectrum_backlog", "sgz_spectrum_stream", "sgz_spectrum_flush", "sgz_scope_flush", "sgz_scope_set_transport", "sgz_vector_flush", "sgz_vector_history",
     "sgz_scope_num_points", "sgz_scope_lanczos_device", "sgz_scope_zero_crossing_device",
     "sgz_peak_filter_device", "sgz_vector_polar_device", "sgz_vector_audio_processing_device",
 ]
@@ -175,6 +176,7 @@ def lib() -> C.CDLL:
     L.sgz_plan_num_frames.restype = C.c_uint64
     L.sgz_plan_get_resonator.argtypes = [vp, vp, vp, vp, vp]
     L.sgz_plan_reset_resonator.argtypes = [vp, vp]
+    L.sgz_scope_set_transport.argtypes = [vp, C.c_int64]
     L.sgz_spectrogram_render_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.sgz_spectrogram_render.argtypes = [C.POINTER(SpectrumConfig), vp, u32, sz, vp, vp, C.POINTER(Timing)]
     L.sgz_spectrogram_render_host.argtypes = [vp, vp, u32, sz, vp, vp, C.POINTER(Timing)]
@@ -518,6 +520,10 @@ class Scope:
     def flush(self):
         """blocks that waited for a staging slot are enqueued now (sgz_scope_flush): readers of results call it first"""
         check(lib().sgz_scope_flush(self.h))
+
+    def set_transport(self, position_in_samples: int):
+        """cs.transportPosition (TriggeringMode::Window)"""
+        check(lib().sgz_scope_set_transport(self.h, C.c_int64(int(position_in_samples))))
 
     def front(self, channel: int):
         self.flush()

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include <cmath>
 #include <cstring>
@@ -55,7 +56,7 @@ namespace sgz {
 // scope_vector.hip: Lanczos / linear vertex kernels on a ring whose cursor lives in device memory
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
                                const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
-                               double cycleSamples, double sampleOffset, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
+                               double cycleSamples, double sampleOffset, long long transport, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
                                uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream);
 size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation, uint32_t triggerMode, double cycleSamples);
 }
@@ -70,7 +71,7 @@ struct Swap { unsigned long long src; unsigned int len; unsigned int pad; };
 
 struct ScopeDev {
     // TriggeringProcessor (StreamPreprocessing.h:210-226)
-    double threshold, windowSize, state;
+    double threshold, windowSize, state, hysteresis;
     int windowChanged, isPeakHold, isWorkingOnPeak, pad0;
     unsigned long long crossOrigin, oldPeak, currentPeak, bufferedSamples, frontOrigin, steadyClock;
     unsigned long long playhead;              // ctx.getPlayhead().getSteadyClock(): samples delivered so far
@@ -250,6 +251,45 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     }
     __syncthreads();
 
+    const bool hold = prm.triggerMode == 4u || prm.triggerMode == 3u;      // ZeroCrossing, EnvelopeHold: detector -> processMutating
+    // ---- A': PeakHoldProcessor over the block (StreamPreprocessing.h:270-313): an envelope follower whose every step depends on the
+    // last one's branch -- one lane walks the block (a few microseconds per 512 samples; the triggers it finds are rare)
+    if (prm.triggerMode == 3u && C >= 2) {
+        if (tid == 0) {
+            uint32_t localMode = prm.oscMode, pair = prm.trigPair;
+            if (localMode == SGZ_OSC_MIDSIDE) { localMode = SGZ_OSC_MID; pair = prm.trigSeparate & ~1u; }     // :340-352
+            const float *a, *b;
+            if (localMode == SGZ_OSC_RIGHT) a = b = prm.block + size_t(pair + 1) * n;
+            else if (localMode == SGZ_OSC_LEFT) a = b = prm.block + size_t(pair) * n;
+            else if (localMode == SGZ_OSC_SEPARATE) a = b = prm.block + size_t(prm.trigSeparate) * n;
+            else { a = prm.block + size_t(pair) * n; b = a + n; }
+            double state = st->state;
+            const double thr2 = st->threshold * st->threshold, hysteresis = st->hysteresis;
+            int holding = st->isPeakHold;
+            unsigned int qc = st->qCount;
+            const unsigned int q0 = st->qHead;
+            unsigned long long dropped = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                double sample = trigSample(localMode, a, b, i);
+                sample *= sample;
+                const double delta = sample - state;
+                if (delta < 0) {
+                    state *= 0.9999;
+                    state = fmax(thr2, state);
+                    if (holding) {
+                        if (qc < kPeakCap) { prm.peaks[(q0 + qc) % kPeakCap] = playhead + (unsigned long long)i - 1ull; ++qc; }
+                        else ++dropped;
+                        holding = 0;
+                    }
+                } else {
+                    if (delta > hysteresis * state) holding = 1;
+                    state = sample;
+                }
+            }
+            st->state = state; st->isPeakHold = holding; st->qCount = qc; st->droppedPeaks += dropped;
+        }
+        __syncthreads();
+    }
     // ---- A: ZeroCrossingProcessor over the block (executeSamplingWindows, OscilloscopeDSP.inl:311-385)
     if (prm.triggerMode == 4u && C >= 2) {
         uint32_t localMode = prm.oscMode, pair = prm.trigPair;
@@ -317,7 +357,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         unsigned int numSwaps = 0, lastStart = 0, lastLen = n;
         sCursor0 = st->frontCursor;
         sWritten0 = st->written;
-        if (prm.triggerMode == 4u) {
+        if (hold) {
             unsigned long long bufferedSamples = st->bufferedSamples, frontOrigin = st->frontOrigin, steadyClock = st->steadyClock;
             unsigned long long oldPeak = st->oldPeak, currentPeak = st->currentPeak;
             unsigned int qHead = st->qHead, qCount = st->qCount;
@@ -490,7 +530,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         cursor = uint32_t((cursor + len) % size);
         __syncthreads();
     };
-    if (prm.triggerMode == 4u) {
+    if (hold) {
         const uint32_t ns = sNumSwaps;
         // suffix sums of the swap lengths: thread-private walk from the back (the list is short)
         unsigned long long later = 0;
@@ -501,8 +541,8 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         }
     } else appendFront(written0, n, 0ull);
 
-    // ---- D: the block goes into the back rings (ZeroCrossing only; absolute index mod backCap)
-    if (prm.triggerMode == 4u) {
+    // ---- D: the block goes into the back rings (ZeroCrossing / EnvelopeHold only; absolute index mod backCap)
+    if (hold) {
         const uint32_t keep = n > prm.backCap ? prm.backCap : n, first = n - keep;
         for (uint32_t e = tid; e < keep * C; e += T) {
             const uint32_t c = e / keep, i = first + (e - c * keep);
@@ -562,7 +602,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     __syncthreads();
     if (tid == 0) {
         st->frontCursor = cursor;
-        if (prm.triggerMode == 4u) st->written = written0 + n;
+        if (hold) st->written = written0 + n;
         st->playhead = playhead + n;
     }
 }
@@ -662,6 +702,7 @@ struct SpectralParams {
     const float *ringA, *ringB; uint32_t evalMode, cap;
     const uint32_t *d_cursor;
     double windowSize, sampleRate, threshold, hysteresis, phaseOffsetDeg, quarterSemitone;
+    double customFrequency;                  // state.customTrigger ? state.customTriggerFrequency : 0
     const double2 *tw;                       // [4096] exp(-2 pi i k / 8192)
 };
 
@@ -748,6 +789,27 @@ __global__ void __launch_bounds__(1024) scopeSpectralKernel(const SpectralParams
     const uint32_t cursor = *prm.d_cursor, cap = prm.cap, len = uint32_t(st->ringSize);
     constexpr uint32_t N = 8192;
 
+    // what calculateFundamentalPeriod leaves behind and what calculateTriggeringOffset derives from it first (:256-270)
+    auto settle = [&](const BinRec &rec, double fundamental) {
+        st->record = rec;
+        st->fundamental = fundamental;
+        const double cycleSamples = prm.sampleRate / fundamental;
+        st->cycleSamples = cycleSamples;
+        const double tau = 6.283185307179586476925286766559;
+        const double radians = tau * recOmega(rec) / double(N);
+        const double offsetReal = fmax(double(N), prm.windowSize + cycleSamples);
+        const unsigned long long offset = (unsigned long long)ceil(offsetReal);
+        sRadians = radians;
+        sSampleDifference = double(offset) - (prm.windowSize + cycleSamples);
+        sOffset2 = long(offset);
+    };
+    if (prm.customFrequency > 0) {
+        // state.customTrigger (:71-81): the user names the frequency -- no transform, no median filter; the Goertzel phase below runs on it
+        if (tid == 0) {
+            BinRec rec; rec.index = 0; rec.value = 1; rec.offset = prm.customFrequency / prm.sampleRate * double(N);
+            settle(rec, prm.customFrequency);
+        }
+    } else {
     {   // transformBuffer[i] = eval.evaluateSampleInc() from -max(ceil(effectiveWindowSize), LookaheadSize) (:92-99)
         const long offset = long(fmax(ceil(prm.windowSize), double(N)));
 #pragma unroll
@@ -826,20 +888,10 @@ __global__ void __launch_bounds__(1024) scopeSpectralKernel(const SpectralParams
             nthElementByIndex(localMedian, 8, 4);
             const BinRec oldMedianBin = localMedian[4];
             if (oldMedianBin.index != ~0ull && fabs(recOmega(max) - recOmega(oldMedianBin)) > 0.5) max = oldMedianBin;
-            st->record = max;
             double fundamental = prm.sampleRate * recOmega(max) / double(N);
-            st->fundamental = fundamental = fmax(5.0, fundamental);
-            const double cycleSamples = prm.sampleRate / fundamental;
-            st->cycleSamples = cycleSamples;
-            // calculateTriggeringOffset (:256-270)
-            const double tau = 6.283185307179586476925286766559;
-            const double radians = tau * recOmega(max) / double(N);
-            const double offsetReal = fmax(double(N), prm.windowSize + cycleSamples);
-            const unsigned long long offset = (unsigned long long)ceil(offsetReal);
-            sRadians = radians;
-            sSampleDifference = double(offset) - (prm.windowSize + cycleSamples);
-            sOffset2 = long(offset);
+            settle(max, fmax(5.0, fundamental));
         }
+    }
     }
     __syncthreads();
     {   // cpl::dsp::goertzel: z = s[N-1] - exp(-i w) s[N-2] = sum_n x[n] exp(i w (N - 1 - n)) (oracle/scope_spectral.c); evaluated as the
@@ -901,6 +953,7 @@ struct sgz_scope {
     // Spectral triggering
     SpectralDev *d_spectral = nullptr;
     double2 *d_tw = nullptr;
+    std::atomic<long long> transport{0};                 // cs.transportPosition (OscilloscopeDSP.inl:706): TriggeringMode::Window places the window by it
     sgz_trigger_state trig{};                             // triggerState as of the last sgz_scope_analyse (consumer thread)
     // vertex output (consumer side)
     float *d_xyz = nullptr; uint32_t *d_rgba = nullptr; size_t vertexCap = 0;
@@ -929,11 +982,14 @@ static sgz_status scopeValidate(const sgz_scope_config *c)
     if (!std::isfinite(c->window_size) || c->window_size < 0 || c->window_size > double(1u << 26)) return fail(SGZ_EINVAL, "window_size");
     if (c->num_channels < 2 || (c->num_channels & 1) || c->num_channels > kMaxCh)
         return fail(SGZ_EINVAL, "num_channels must be even, 2..64 (OscilloscopeDSP.inl:318)");
-    if (c->trigger_mode != SGZ_TRIG_NONE && c->trigger_mode != SGZ_TRIG_ZERO_CROSSING && c->trigger_mode != SGZ_TRIG_SPECTRAL)
-        return fail(SGZ_EUNSUPPORTED, "trigger modes Window / EnvelopeHold are not built");
+    if (c->trigger_mode > SGZ_TRIG_ZERO_CROSSING) return fail(SGZ_EINVAL, "trigger_mode");
+    if (c->trigger_mode == SGZ_TRIG_ENVELOPE_HOLD && (!(c->trigger_hysteresis >= 0) || !std::isfinite(c->trigger_hysteresis)))
+        return fail(SGZ_EINVAL, "trigger_hysteresis");
     if (c->trigger_mode == SGZ_TRIG_SPECTRAL) {
         if (!(c->trigger_hysteresis >= 0) || !(c->trigger_hysteresis <= 1)) return fail(SGZ_EINVAL, "trigger_hysteresis outside 0..1");
         if (!std::isfinite(c->trigger_phase_offset)) return fail(SGZ_EINVAL, "trigger_phase_offset");
+        if (c->custom_trigger && (!(c->custom_trigger_frequency > 0) || !(c->custom_trigger_frequency < c->sample_rate * 0.5)))
+            return fail(SGZ_EINVAL, "custom_trigger_frequency must lie in (0, sample_rate / 2)");
         if (c->sample_rate / 5.0 + c->window_size > double(1u << 26)) return fail(SGZ_EINVAL, "ring too long");
     }
     if (c->colour_by_frequency) {
@@ -943,8 +999,7 @@ static sgz_status scopeValidate(const sgz_scope_config *c)
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (!std::isfinite(c->band_colours[i][j])) return fail(SGZ_EINVAL, "band_colours");
     }
     if (c->channel_mode > SGZ_OSC_MIDSIDE || c->envelope_mode > SGZ_ENV_PEAK_DECAY) return fail(SGZ_EINVAL, "enum value");
-    if (c->interpolation != SGZ_SUBSAMPLE_LINEAR && c->interpolation != SGZ_SUBSAMPLE_LANCZOS)
-        return fail(SGZ_EUNSUPPORTED, "sub-sample interpolation: Linear or Lanczos");
+    if (c->interpolation > SGZ_SUBSAMPLE_LANCZOS) return fail(SGZ_EINVAL, "interpolation");
     if (!std::isfinite(c->trigger_threshold) || !std::isfinite(c->trigger_channel) || !(c->trigger_channel >= 1)) return fail(SGZ_EINVAL, "trigger");
     if (!std::isfinite(c->envelope_window) || c->envelope_window < 0) return fail(SGZ_EINVAL, "envelope_window");
     if (c->max_block > (1u << 17)) return fail(SGZ_EINVAL, "max_block above 131072 samples");
@@ -1047,13 +1102,14 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
     } else {
         s->trig = sgz_trigger_state{};
         s->trig.ring_size = size;
-        if (cfg->trigger_mode == SGZ_TRIG_ZERO_CROSSING)                                  // calculateTriggeringOffset :233-240
+        if (cfg->trigger_mode == SGZ_TRIG_ZERO_CROSSING || cfg->trigger_mode == SGZ_TRIG_ENVELOPE_HOLD)   // calculateTriggeringOffset :233-240
             s->trig.sample_offset = (cfg->window_size * 0.5 - double(int(cfg->window_size * 0.5))) - 1.5;
     }
     // TriggeringProcessor::setSettings, StreamPreprocessing.h:46-53
     h.windowChanged = std::ceil(cfg->window_size) != std::ceil(h.windowSize) ? 1 : 0;
     h.windowSize = cfg->window_size;
     h.threshold = cfg->trigger_threshold;
+    h.hysteresis = cfg->trigger_hysteresis;
     SGZ_HIP(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
     s->size = size; s->backCap = backCap;
     // calculateTriggerIndices, OscilloscopeParameters.h:491-507
@@ -1213,6 +1269,13 @@ sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8])
     return SGZ_OK;
 }
 
+sgz_status sgz_scope_set_transport(sgz_scope *s, int64_t position_in_samples)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    s->transport.store(position_in_samples, std::memory_order_relaxed);
+    return SGZ_OK;
+}
+
 size_t sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view)
 {
     if (!s || !view || view->width < 2 || !(view->right > view->left)) return 0;
@@ -1242,6 +1305,7 @@ sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel,
         prm.d_cursor = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor));
         prm.windowSize = s->cfg.window_size; prm.sampleRate = s->cfg.sample_rate;
         prm.threshold = s->cfg.trigger_threshold; prm.hysteresis = s->cfg.trigger_hysteresis;
+        prm.customFrequency = s->cfg.custom_trigger ? s->cfg.custom_trigger_frequency : 0.0;
         prm.phaseOffsetDeg = s->cfg.trigger_phase_offset;
         prm.quarterSemitone = std::pow(2, 0.25 / 12.0) - 1;                                  // OscilloscopeDSP.inl:126
         prm.tw = s->d_tw;
@@ -1284,7 +1348,8 @@ static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, ui
     SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, s->d_front + size_t(chA) * s->size,
                                 s->d_front + size_t(chB) * s->size, evalMode, uint32_t(s->trig.ring_size), s->size,
                                 reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
-                                s->trig.cycle_samples, s->trig.sample_offset, key, colRing, d_xyz, d_rgba, capacity, points, s->stream));
+                                s->trig.cycle_samples, s->trig.sample_offset, s->transport.load(std::memory_order_relaxed), key, colRing, d_xyz,
+                                d_rgba, capacity, points, s->stream));
     return SGZ_OK;
 }
 

@@ -25,7 +25,7 @@ struct ScopeScalars { double samplePos0, inc, samplesPerPixel, unit0, right, pix
 
 // triggerMode: OscilloscopeContent::TriggeringMode (0 None, 4 ZeroCrossing)
 ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMode = SGZ_TRIG_ZERO_CROSSING, double cycleSamples = 0.0,
-                         double sampleOffset = 0.0)
+                         double sampleOffset = 0.0, long long transport = 0)
 {
     ScopeScalars s{};
     const double horizontalDelta = v.right - v.left;
@@ -33,7 +33,9 @@ ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMo
     const double pixelsPerSample = v.rendering_scale * std::fabs((double(v.width) - 1) / (sizeMinusOne * horizontalDelta));   // :572
     s.pixelsPerSample = pixelsPerSample;
     double samplePos;
-    if (triggerMode == SGZ_TRIG_ZERO_CROSSING)
+    if (triggerMode == SGZ_TRIG_WINDOW)
+        samplePos = std::ceil(std::fmod(double(transport), v.window_size) - 1);             // :798-801, :814-819
+    else if (triggerMode == SGZ_TRIG_ZERO_CROSSING || triggerMode == SGZ_TRIG_ENVELOPE_HOLD)
         samplePos = (v.window_size * 0.5 - double(int(v.window_size * 0.5))) - 1.5;          // triggerState.sampleOffset, OscilloscopeDSP.inl:238
     else if (triggerMode == SGZ_TRIG_SPECTRAL)
         samplePos = cycleSamples * 2 + v.window_size - sampleOffset;                         // :810 (no ceil: :814-819 is None / Window only)
@@ -218,6 +220,25 @@ scopeWaveLinearKernel(const float *ringA, const float *ringB, uint32_t evalMode,
     const uint32_t idx = ringPhys(start0 + long(p), *d_cursor, cap, len);
     xyz[p] = make_float3(float(p), evalSample(ringA, ringB, evalMode, idx), 0.f);
     if (rgba) rgba[p] = colRing ? colRing[idx] : key;      // :664-677: drawer.addColour(data.second) per sample
+}
+
+// Rectangular (:746-789): sample i becomes the two vertices (i, y), (i + 1, y), coloured with the previous sample's colour (the first:
+// its own, evaluator.evaluateColour() before the loop) and its own
+__global__ void __launch_bounds__(256)
+scopeWaveRectKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, uint32_t cap, const uint32_t *d_cursor,
+                    size_t samples, long start0, uint32_t key, const uint32_t *colRing, float3 *xyz, uint32_t *rgba)
+{
+    const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= samples) return;
+    const uint32_t idx = ringPhys(start0 + long(p), *d_cursor, cap, len);
+    const float y = evalSample(ringA, ringB, evalMode, idx);
+    xyz[2 * p] = make_float3(float(p), y, 0.f);
+    xyz[2 * p + 1] = make_float3(float(p) + 1.f, y, 0.f);
+    if (rgba) {
+        const uint32_t prev = p ? ringPhys(start0 + long(p) - 1, *d_cursor, cap, len) : idx;
+        rgba[2 * p] = colRing ? colRing[prev] : key;
+        rgba[2 * p + 1] = colRing ? colRing[idx] : key;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- K10
@@ -445,6 +466,15 @@ bool waveIsLanczos(const sgz_scope_view &v, uint32_t interpolation)
     return !(pps < 1);
 }
 
+// Rectangular falls back to Linear below one pixel per sample like Lanczos does; None never does (:575-578)
+bool waveIsRect(const sgz_scope_view &v, uint32_t interpolation)
+{
+    if (interpolation != SGZ_SUBSAMPLE_RECTANGULAR) return false;
+    const double sizeMinusOne = std::max(1.0, v.window_size - 1);
+    const double pps = v.rendering_scale * std::fabs((double(v.width) - 1) / (sizeMinusOne * (v.right - v.left)));
+    return !(pps < 1);
+}
+
 }  // namespace
 
 namespace sgz {
@@ -454,18 +484,19 @@ size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation, uint
     if (waveIsLanczos(view, interpolation)) return scopeDerive(view, 0).points;
     // endCondition = roundedWindow + quantizedCycleSamples (:614, :631)
     const long quantizedCycleSamples = triggerMode == SGZ_TRIG_SPECTRAL ? long(std::ceil(cycleSamples)) : 0;
-    return size_t(std::max<long>(2, long(std::ceil(view.window_size))) + quantizedCycleSamples);
+    const size_t samples = size_t(std::max<long>(2, long(std::ceil(view.window_size))) + quantizedCycleSamples);
+    return waveIsRect(view, interpolation) ? 2 * samples : samples;
 }
 
 // ringA / ringB / colRing: one channel's plane of the physical ring (`cap` elements); `size`: the reference's ring of the moment
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
                                const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
-                               double cycleSamples, double sampleOffset, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
-                               uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
+                               double cycleSamples, double sampleOffset, long long transport, uint32_t rgba, const uint32_t *colRing,
+                               float *d_xyz, uint32_t *d_rgba, size_t capacity, size_t *points, hipStream_t stream)
 {
     const int block = 256;
     if (waveIsLanczos(view, interpolation)) {
-        const ScopeScalars s = scopeDerive(view, size, triggerMode, cycleSamples, sampleOffset);
+        const ScopeScalars s = scopeDerive(view, size, triggerMode, cycleSamples, sampleOffset, transport);
         if (s.points > capacity) return hipErrorInvalidValue;
         hipLaunchKernelGGL(scopeWaveLanczosKernel, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, ringA, ringB,
                            evalMode, size, cap, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0, rgba,
@@ -474,15 +505,24 @@ hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode,
     } else {
         const long roundedWindow = long(std::ceil(view.window_size));
         long bufferOffset, quantizedCycleSamples = 0;
-        if (triggerMode == SGZ_TRIG_ZERO_CROSSING) {
+        if (triggerMode == SGZ_TRIG_WINDOW) {
+            bufferOffset = long(std::ceil(std::fmod(double(transport), view.window_size)));   // :588-592
+        } else if (triggerMode == SGZ_TRIG_ZERO_CROSSING || triggerMode == SGZ_TRIG_ENVELOPE_HOLD) {
             const double realOffset = (view.window_size * 0.5 - double(int(view.window_size * 0.5))) - 1.5;
             bufferOffset = long(std::ceil(realOffset));                                 // :593-594
         } else {
             // :598-612; this branch is never Lanczos, so cycleBuffers = 1
-            if (triggerMode != SGZ_TRIG_NONE) quantizedCycleSamples = long(std::ceil(cycleSamples));
+            if (triggerMode == SGZ_TRIG_SPECTRAL) quantizedCycleSamples = long(std::ceil(cycleSamples));
             bufferOffset = roundedWindow + quantizedCycleSamples;
         }
         const size_t n = size_t(std::max<long>(2, roundedWindow) + quantizedCycleSamples);
+        if (waveIsRect(view, interpolation)) {
+            if (2 * n > capacity) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(scopeWaveRectKernel, dim3(unsigned((n + block - 1) / block)), dim3(block), 0, stream, ringA, ringB, evalMode,
+                               size, cap, d_cursor, n, -bufferOffset, rgba, colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba);
+            *points = 2 * n;
+            return hipGetLastError();
+        }
         if (n > capacity) return hipErrorInvalidValue;
         hipLaunchKernelGGL(scopeWaveLinearKernel, dim3(unsigned((n + block - 1) / block)), dim3(block), 0, stream, ringA, ringB, evalMode,
                            size, cap, d_cursor, n, -bufferOffset, rgba, colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba);

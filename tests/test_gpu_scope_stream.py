@@ -184,7 +184,9 @@ def test_push_never_waits_and_rejects_bad_input(gpu):
     assert res.count(api.SGZ_OK) >= 8
     assert dt < 5.0
     with pytest.raises(api.SgzError):
-        api.Scope(**_cfg(trigger_mode=3))                              # EnvelopeHold: not built
+        api.Scope(**_cfg(trigger_mode=7))                              # no such TriggeringMode
+    with pytest.raises(api.SgzError):
+        api.Scope(**_cfg(interpolation=9))
     with pytest.raises(api.SgzError):
         api.Scope(**_cfg(num_channels=3))
 
@@ -342,7 +344,7 @@ def test_spectral_rejects_bad_config(gpu):
     with pytest.raises(api.SgzError):
         api.Scope(**_cfg(trigger_mode=1, trigger_hysteresis=1.5))
     with pytest.raises(api.SgzError):
-        api.Scope(**_cfg(trigger_mode=2))                                          # Window: not built
+        api.Scope(**_cfg(trigger_mode=1, custom_trigger=1, custom_trigger_frequency=0.0))
     with pytest.raises(api.SgzError):
         api.Scope(**_cfg(colour_by_frequency=1, sample_rate=4000.0, band_colours=BANDS))
 
@@ -447,3 +449,134 @@ def test_random_scope_configurations(gpu, oracle, seed):
     if cfg["envelope_mode"] == 2:
         coeff = float(np.power(np.exp(-8.0 / (cfg["envelope_window"] * sr)), ref.size / 60))
         assert dev.peak_filter(1 / 60, 8) == ref.peak_filter(8, coeff), cfg
+
+
+# ---- the remaining trigger modes and interpolations (outside SURVEY 8's rows; VERDICT r2 "missing" #4) ---------------------------------
+
+def _bursts(seed, n, channels):
+    """decaying tone bursts: what an envelope-hold trigger is for"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / SR
+    env = np.exp(-((t * 37.0) % 1.0) * 6.0)
+    x = np.zeros((channels, n), np.float32)
+    for c in range(channels):
+        x[c] = (env * np.sin(2 * np.pi * 523.0 * (1 + 0.2 * c) * t) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("over", [dict(window_size=3000.0, trigger_hysteresis=0.1, trigger_threshold=0.05),
+                                  dict(window_size=480.3, trigger_hysteresis=0.0, trigger_threshold=0.0, channel_mode=2),
+                                  dict(window_size=2048.0, trigger_hysteresis=0.5, trigger_threshold=0.3, channel_mode=4, num_channels=4,
+                                       trigger_channel=3.0, envelope_mode=1)])
+def test_envelope_hold_trigger_is_bit_exact(gpu, oracle, over):
+    """TriggeringMode::EnvelopeHold: PeakHoldProcessor (StreamPreprocessing.h:270-313) feeds the same processMutating automaton"""
+    po = oracle
+    cfg = _cfg(trigger_mode=3, **over)
+    x = _bursts(5, 150000, cfg["num_channels"])
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(cfg["num_channels"], cfg["sample_rate"], cfg["window_size"], 3, cfg["trigger_threshold"], cfg["channel_mode"],
+                         cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
+    ref.set_hysteresis(cfg["trigger_hysteresis"])
+    rng = np.random.default_rng(21)
+    pos = 0
+    while pos < x.shape[1]:
+        n = int(rng.integers(1, 3000))
+        blk = x[:, pos:pos + n]
+        _push(dev, blk); ref.audio(blk)
+        pos += blk.shape[1]
+        if rng.random() < 0.1:
+            assert dev.state() == ref.state()
+    assert dev.state() == ref.state() and ref.state()["swaps"] > 5
+    for c in range(cfg["num_channels"]):
+        got, gcur = dev.front(c)
+        want, wcur = ref.front(c)
+        assert gcur == wcur and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # drawn like ZeroCrossing (OscilloscopeRendering.cpp:593-597, :802-805)
+    m0, cur = ref.front(0)
+    for interp in (3, 2):
+        dev.configure(interpolation=interp)
+        v = api.ScopeView(cfg["window_size"], 0.0, 1.0, 1.0, 1600, 0)
+        vo = po.ScopeView(cfg["window_size"], 0.0, 1.0, 1.0, 1600, 0)
+        want, _ = po.scope_wave_plot_ex2(vo, 3, interp, m0, m0, 0, cur)
+        got, _ = dev.vertices(v, 0, 0)
+        assert got.shape == want.shape and np.array_equal(got[:, 0], want[:, 0])
+        assert np.abs(got[:, 1] - want[:, 1]).max() <= (2e-6 if interp == 3 else 0.0)
+
+
+@pytest.mark.parametrize("interp,window,width", [(0, 777.0, 1920), (1, 777.0, 1920), (1, 300.5, 4000), (1, 19200.0, 1920), (0, 19200.0, 1920)])
+def test_none_and_rectangular_interpolation(gpu, oracle, interp, window, width):
+    """SubSampleInterpolation::None = the Linear vertex list (drawn as points), Rectangular = two vertices per sample with the previous
+    and the current sample's colour; Rectangular (not None) falls back to Linear below one pixel per sample (:575-578)"""
+    po = oracle
+    cols = [(10, 20, 30, 255), (200, 100, 50, 255)]
+    for by_freq in (0, 1):
+        cfg = _cfg(window_size=window, trigger_mode=0, interpolation=interp, colours=cols, colour_by_frequency=by_freq,
+                   frequency_colouring_blend=0.3, colour_smoothing_ms=5.0,
+                   band_colours=[(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)])
+        x = _signal(9, 60000, 2)
+        dev = api.Scope(**cfg)
+        ref = po.ScopeStream(2, SR, window, 0, 0.05, 0, 1.0, 0, 0.3)
+        if by_freq:
+            ref.enable_colours([(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)], 0.3, 5.0, cols)
+        for pos in range(0, x.shape[1], 2500):
+            _push(dev, x[:, pos:pos + 2500]); ref.audio(x[:, pos:pos + 2500])
+        m1, cur = ref.front(1)
+        cm = ref.front_colours(1, False)[0] if by_freq else None
+        key = int(np.array(cols[1], np.uint8).view(np.uint32)[0])
+        for left, right in ((0.0, 1.0), (0.3, 0.35)):
+            v = api.ScopeView(window, left, right, 1.0, width, 0)
+            vo = po.ScopeView(window, left, right, 1.0, width, 0)
+            want, wcol = po.scope_wave_plot_ex2(vo, 0, interp, m1, m1, 0, cur, key=key, colour_mem=cm)
+            got, gcol = dev.vertices(v, 1, 0)
+            assert got.shape == want.shape, (got.shape, want.shape)
+            assert np.array_equal(got, want)
+            assert np.array_equal(gcol, wcol)
+        n_lin = max(2, int(np.ceil(window)))
+        pps = abs((width - 1) / (max(1.0, window - 1) * (right - left)))            # of the last (zoomed) view
+        assert got.shape[0] == (2 * n_lin if interp == 1 and pps >= 1 else n_lin)
+
+
+@pytest.mark.parametrize("interp,window", [(2, 1000.0), (3, 1000.0), (3, 480.3), (1, 777.0)])
+def test_window_trigger_follows_the_transport(gpu, oracle, interp, window):
+    """TriggeringMode::Window: audio thread as None, the drawn window starts at fmod(transportPosition, window) (:588-592, :798-801)"""
+    po = oracle
+    cfg = _cfg(window_size=window, trigger_mode=2, interpolation=interp)
+    x = _signal(13, 40000, 2)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(2, SR, window, 2, 0.05, 0, 1.0, 0, 0.3)
+    for pos in range(0, x.shape[1], 1999):
+        _push(dev, x[:, pos:pos + 1999]); ref.audio(x[:, pos:pos + 1999])
+    m0, cur = ref.front(0)
+    for transport in (0, 40000, 123456789, 40000 + 317):
+        dev.set_transport(transport)
+        v = api.ScopeView(window, 0.0, 1.0, 1.0, 2400, 0)
+        vo = po.ScopeView(window, 0.0, 1.0, 1.0, 2400, 0)
+        want, _ = po.scope_wave_plot_ex2(vo, 2, interp, m0, m0, 0, cur, transport_position=transport)
+        got, _ = dev.vertices(v, 0, 0)
+        assert got.shape == want.shape and np.array_equal(got[:, 0], want[:, 0]), (transport, got.shape, want.shape)
+        assert np.abs(got[:, 1] - want[:, 1]).max() <= (2e-6 if interp == 3 else 0.0)
+
+
+def test_custom_trigger_frequency(gpu, oracle):
+    """state.customTrigger (OscilloscopeDSP.inl:71-81): Spectral triggering on a named frequency -- no transform, no median filter"""
+    po = oracle
+    sr, window, f0 = 48000.0, 2000.0, 330.0
+    cfg = _cfg(sample_rate=sr, window_size=window, trigger_mode=1, trigger_threshold=0.02, trigger_hysteresis=0.1, trigger_phase_offset=15.0,
+               interpolation=3, custom_trigger=1, custom_trigger_frequency=f0)
+    t = np.arange(int(sr * 0.8)) / sr
+    x = np.stack([np.sin(2 * np.pi * f0 * t + 0.3), 0.5 * np.sin(2 * np.pi * 2 * f0 * t)]).astype(np.float32)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(2, sr, window, 1, 0.02, 0, 1.0, 0, 0.3)
+    ts = po.SpectralState()
+    pos, block, sz = 0, 1500, 8192
+    for frame in range(6):
+        for _ in range(4):
+            _push(dev, x[:, pos:pos + block]); ref.audio(x[:, pos:pos + block]); pos += block
+        mem = ref.logical(0, sz)
+        po.scope_analyse(ts, mem, mem, 0, 0, window, sr, 0.02, 0.1, 15.0, custom_frequency=f0)
+        got = dev.analyse(0, 0)
+        assert got.record_index == 0 and got.record_value == 1.0 and got.fundamental == f0
+        assert abs(got.record_offset - ts.record.offset) <= 1e-12 and got.cycle_samples == ts.cycle_samples
+        assert abs(got.sample_offset - ts.sample_offset) <= 1e-6, (frame, got.sample_offset, ts.sample_offset)
+        sz = max(int(0.5 + ts.cycle_samples + np.ceil(window)), 8192)
+        assert got.ring_size == sz

@@ -86,3 +86,36 @@ def test_rms_envelope_known_answer(oracle, mode):
     _feed(s, x)
     expect = {0: 0.5, 1: 0.25, 2: 0.375, 3: 0.125, 4: 0.5, 5: np.sqrt(0.5 * 0.75 ** 2)}[mode]
     assert abs(1.0 / s.envelope_gain - expect) < 1e-4
+
+
+def test_envelope_hold_fires_one_sample_after_a_rising_run_ends(oracle):
+    """PeakHoldProcessor (StreamPreprocessing.h:282-310) on squares: a run of rising squares arms, the first sample that falls fires a
+    trigger at the previous sample; the held level decays by 0.9999 per sample and never below threshold^2"""
+    po = oracle
+    sr, window = 48000.0, 64.0
+    s = po.ScopeStream(2, sr, window, 3, 0.1, 0, 1.0, 0, 0.3)
+    s.set_hysteresis(0.0)
+    x = np.zeros((2, 4000), np.float32)
+    x[0, 1000:1011] = np.linspace(0.2, 1.0, 11)            # rising to a peak at sample 1010, then silence
+    x[0, 3000:3006] = np.linspace(0.3, 1.5, 6)             # a second burst above the held (slowly decaying) level, peak at 3005
+    s.audio(x)
+    st = s.state()
+    assert st["swaps"] == 2                                # one window per burst ...
+    assert st["currentPeak"] == 3005 and st["oldPeak"] == 3005   # ... placed on the last rising sample
+
+
+def test_rectangular_and_none_vertex_lists(oracle):
+    po = oracle
+    mem = np.arange(10, dtype=np.float32) / 10
+    v = po.ScopeView(8.0, 0.0, 1.0, 1.0, 800, 0)
+    lin, _ = po.scope_wave_plot_ex2(v, 0, 2, mem, mem, 0, 3)
+    dots, _ = po.scope_wave_plot_ex2(v, 0, 0, mem, mem, 0, 3)
+    rect, col = po.scope_wave_plot_ex2(v, 0, 1, mem, mem, 0, 3, key=0x11223344)
+    assert np.array_equal(lin, dots) and lin.shape[0] == 8
+    assert rect.shape[0] == 16 and np.array_equal(rect[0::2, 1], lin[:, 1]) and np.array_equal(rect[1::2, 1], lin[:, 1])
+    assert np.array_equal(rect[0::2, 0], lin[:, 0]) and np.array_equal(rect[1::2, 0], lin[:, 0] + 1)
+    assert (col.view(np.uint32) == 0x11223344).all()
+    # Window mode: the drawn window starts ceil(fmod(transport, window)) samples back
+    a, _ = po.scope_wave_plot_ex2(v, 2, 2, mem, mem, 0, 3, transport_position=8 * 5 + 3)
+    b, _ = po.scope_wave_plot_ex2(v, 2, 2, mem, mem, 0, 3, transport_position=3)
+    assert np.array_equal(a, b) and a[0, 1] == mem[(3 - 3) % 10]
