@@ -15,7 +15,8 @@
 // workgroup and are staged through LDS 256 at a time (one coalesced load + channel mix per thread, then broadcast reads).
 // Against the sequential fp32 recurrence the chained result differs by the rounding of one complex product per frame: ~1e-7 of the
 // state.  Bytes: 8 hop per (frame, pair) in, 8 V P per (frame, signal) through HBM between the two kernels: the path is
-// VALU-bound (per sample and axis point 7 V fp32 operations without contraction in the continuing frame, 4 V fused ones in the others).
+// VALU-bound (per sample and axis point 7 V fp32 operations without contraction in the continuing frame, ~2.4 V fused ones in the
+// others, which take the samples eight at a time against the pole's powers).
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -63,23 +64,66 @@ __device__ __forceinline__ void resStep(float (&re)[V], float (&im)[V], const fl
     }
 }
 
+// samples per block step of the frames that start from rest: B consecutive steps of the recurrence collapse into
+//     s' = c^B s + sum_b c^(B-1-b) x[b]                (4 + 2 (B - 1) + 1 fused operations per B samples instead of 4 B),
+// the powers c^1 .. c^B living in registers (2 B per vector: B = 8 up to five vectors, 4 beyond)
+template <int V> struct ResBlock { static constexpr int B = V <= 5 ? 8 : 4; };
+
 template <int V, bool EXACT>
 __device__ __forceinline__ void resRun(const ResParams &prm, float *xs, const float *L, const float *R, int signal, int tid,
                                        float (&re)[V], float (&im)[V], const float (&cr)[V], const float (&ci)[V])
 {
+    constexpr int B = ResBlock<V>::B;
+    [[maybe_unused]] float pr[V][B], pi[V][B];                    // pr[v][k] + i pi[v][k] = c_v^(k+1)
+    if constexpr (!EXACT) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            pr[v][0] = cr[v]; pi[v][0] = ci[v];
+#pragma unroll
+            for (int k = 1; k < B; ++k) {
+                pr[v][k] = __builtin_fmaf(pr[v][k - 1], cr[v], -pi[v][k - 1] * ci[v]);
+                pi[v][k] = __builtin_fmaf(pr[v][k - 1], ci[v], pi[v][k - 1] * cr[v]);
+            }
+        }
+    }
     for (uint32_t t0 = 0; t0 < prm.hop; t0 += kResBlock) {
         const uint32_t n = min(uint32_t(kResBlock), prm.hop - t0);
         __syncthreads();
         xs[tid] = uint32_t(tid) < n ? resMix(prm.mode, signal, L[t0 + tid], R[t0 + tid]) : 0.f;
         __syncthreads();
         if (n == uint32_t(kResBlock)) {
+            if constexpr (EXACT) {
 #pragma unroll 2
-            for (int j = 0; j < kResBlock; j += 4) {
-                const float4 x4 = *reinterpret_cast<const float4 *>(xs + j);
-                resStep<V, EXACT>(re, im, cr, ci, x4.x);
-                resStep<V, EXACT>(re, im, cr, ci, x4.y);
-                resStep<V, EXACT>(re, im, cr, ci, x4.z);
-                resStep<V, EXACT>(re, im, cr, ci, x4.w);
+                for (int j = 0; j < kResBlock; j += 4) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(xs + j);
+                    resStep<V, true>(re, im, cr, ci, x4.x);
+                    resStep<V, true>(re, im, cr, ci, x4.y);
+                    resStep<V, true>(re, im, cr, ci, x4.z);
+                    resStep<V, true>(re, im, cr, ci, x4.w);
+                }
+            } else {
+                for (int j = 0; j < kResBlock; j += B) {
+                    float x[B];
+#pragma unroll
+                    for (int k = 0; k < B; k += 4) {
+                        const float4 x4 = *reinterpret_cast<const float4 *>(xs + j + k);
+                        x[k] = x4.x; x[k + 1] = x4.y; x[k + 2] = x4.z; x[k + 3] = x4.w;
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        // c^B s
+                        float nre = __builtin_fmaf(re[v], pr[v][B - 1], -im[v] * pi[v][B - 1]);
+                        float nim = __builtin_fmaf(re[v], pi[v][B - 1], im[v] * pr[v][B - 1]);
+                        // + sum_b c^(B-1-b) x[b]   (x is real; c^0 = 1)
+#pragma unroll
+                        for (int b = 0; b < B - 1; ++b) {
+                            nre = __builtin_fmaf(x[b], pr[v][B - 2 - b], nre);
+                            nim = __builtin_fmaf(x[b], pi[v][B - 2 - b], nim);
+                        }
+                        re[v] = nre + x[B - 1];
+                        im[v] = nim;
+                    }
+                }
             }
         } else {
             for (uint32_t j = 0; j < n; ++j) resStep<V, EXACT>(re, im, cr, ci, xs[j]);
