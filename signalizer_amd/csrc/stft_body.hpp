@@ -8,6 +8,7 @@
 
 #include "complex_dc.hpp"
 #include "fft_common.hpp"
+#include "fft_scalar.hpp"
 #include "kernels.hpp"
 #include "late_fix.hpp"
 
@@ -554,7 +555,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         __builtin_amdgcn_sched_barrier(0);          // keep the twiddle loads below the 3R sample loads (128-VGPR budget)
         SGZ_CLK(13);
         // ---------------------------------------------------------------------- pass 1
-        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(1u)) ditPacked<LR, 0>(c);
         SGZ_CLK(14);
         if (!SGZ_ABLATED(32u)) {
             TwFactors<LR, HALF == 1> tw;
@@ -597,7 +598,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         ldsBarrier();
         SGZ_CLK(2);
         // ---------------------------------------------------------------------- pass 2 (t2 = ix)
-        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(1u)) ditPacked<LR, 0>(c);
         if (!SGZ_ABLATED(32u)) {
             TwFactors<LR> tw;
             tw.load(prm.tw2, ix, R);
@@ -626,7 +627,7 @@ __device__ __forceinline__ void stftMapBody(const StftParams &prm, float *lds, c
         }
         SGZ_CLK(4);
         // ---------------------------------------------------------------------- pass 3 (q2 = ix)
-        if (!SGZ_ABLATED(1u)) difPacked<R, R, 0>(c);
+        if (!SGZ_ABLATED(1u)) ditPacked<LR, 0>(c);
         SGZ_CLK(5);
         SGZ_WCLK(1);
         if (ZOUT) {
