@@ -30,7 +30,7 @@ typedef enum sgz_status {
     SGZ_EINVAL = -1,
     SGZ_EHIP = -2,          /* a HIP runtime call failed / no gfx950 device                     */
     SGZ_ENOMEM = -3,
-    SGZ_EUNSUPPORTED = -4   /* e.g. the multi-GPU carry fold in SpectrumChannels::Phase            */
+    SGZ_EUNSUPPORTED = -4   /* e.g. line results from a folded carry in SpectrumChannels::Phase     */
 } sgz_status;
 
 /* SpectrumChannels, Source/Common/CommonSignalizer.h:495-539 */
@@ -246,7 +246,10 @@ sgz_status sgz_stage_track_peak(sgz_plan *plan, const float *d_bins, double mous
  * ZERO carry-in; writes that zero-carry end state (what a rank publishes) to d_end_state [pairs][graphs][P][2] and keeps the chunk
  * aggregates inside the plan.  emit: folds the true carry-in d_carry (NULL = zero) into the kept aggregates -- one pass over the
  * aggregates, no second scan of the magnitudes -- and renders; d_state_out (optional) receives the state after the last frame.
- * Result == sgz_stage_decay_colour(..., d_state = carry) bit for bit. */
+ * Result == sgz_stage_decay_colour(..., d_state = carry) bit for bit.
+ * SGZ_CH_PHASE: the magnitude half of the state -- a peak decay, and all the image is coloured from (SpectrumDSP.cpp:123) -- folds
+ * the same way; the cancellation smoother (:1409-1412) is a linear fp32 recurrence without an exact fold, so emit renders the image
+ * only (d_lines / d_state_out: SGZ_EUNSUPPORTED) and the phase halves of the scan's end state are not meaningful. */
 sgz_status sgz_stage_decay_scan(sgz_plan *plan, const float *d_mapped, size_t frames, float *d_end_state, void *stream);
 sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t frames, const float *d_carry, uint8_t *d_rgba,
                                 float *d_lines, float *d_state_out, void *stream);

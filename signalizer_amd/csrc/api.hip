@@ -361,7 +361,7 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
 }
 
 sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
-                                 float *d_state, hipStream_t stream)
+                                 float *d_state, hipStream_t stream, bool magnitudeOnly)
 {
     if (frames <= 0) return SGZ_OK;
     p.aggMapped = nullptr;                                   // whatever d_agg held is about to be overwritten (or left stale by a fused launch)
@@ -383,7 +383,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
             SGZ_HIP(launchRealLate(fillRealLate(p, frames, pending), p.N, stream));
         }
     }
-    if (p.cfg.channel_mode == SGZ_CH_PHASE) {
+    if (p.cfg.channel_mode == SGZ_CH_PHASE && !magnitudeOnly) {
         // colour column only: the image reads the main graph's magnitude state alone (decayPhaseColourKernel), a plain peak decay of
         // plane 0 x 0.5 -- the chunked exact scan of the fused kernel instead of the sequential walk the phase smoother needs
         if (!noFused && decayColourFusedApplies(prm)) {
@@ -428,7 +428,7 @@ sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, co
     prm.colourTables = p.d_colourTables;
     prm.sc = p.scalars;
     prm.state = d_stateOut; prm.stateIn = d_carry; prm.rgba = d_rgba; prm.lines = d_lines;
-    prm.magScale = 1.0f;
+    prm.magScale = p.cfg.channel_mode == SGZ_CH_PHASE ? 0.5f : 1.0f;
     if (prm.numChunks > 1) {
         const size_t need = size_t(prm.numChunks) * p.C * p.sides * SGZ_NUM_GRAPHS * p.P;
         if (!p.d_agg || p.aggCap < need || p.aggMapped != d_mapped || p.aggFrames != frames)
@@ -764,11 +764,12 @@ sgz_status sgz_stage_decay_scan(sgz_plan *plan, const float *d_mapped, size_t fr
     if (st != SGZ_OK) return st;
     Plan &p = plan->impl;
     if (!d_mapped || !d_end_state) return fail(SGZ_EINVAL, "null buffer");
-    if (p.cfg.channel_mode == SGZ_CH_PHASE)
-        return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
+    // Phase mode: the MAGNITUDE half of the state (what the image is coloured from, SpectrumDSP.cpp:123) is the same peak decay and
+    // folds exactly; the cancellation smoother (a linear recurrence: no exact fold) is not carried -- sgz_stage_decay_emit then
+    // renders the image only
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     SGZ_HIP(hipMemsetAsync(d_end_state, 0, size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2 * sizeof(float), s));
-    return runDecayColour(p, d_mapped, long(frames), nullptr, nullptr, d_end_state, s);     // scans + state-only emit of the last chunk
+    return runDecayColour(p, d_mapped, long(frames), nullptr, nullptr, d_end_state, s, /*magnitudeOnly=*/true);     // scans + state-only emit of the last chunk
 }
 
 sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t frames, const float *d_carry, uint8_t *d_rgba,
@@ -777,7 +778,8 @@ sgz_status sgz_stage_decay_emit(sgz_plan *plan, const float *d_mapped, size_t fr
     sgz_status st = checkReady(plan);
     if (st != SGZ_OK) return st;
     if (!d_mapped) return fail(SGZ_EINVAL, "null buffer");
-    if (plan->impl.cfg.channel_mode == SGZ_CH_PHASE) return fail(SGZ_EUNSUPPORTED, "Phase mode has no carry fold");
+    if (plan->impl.cfg.channel_mode == SGZ_CH_PHASE && (d_lines || d_state_out))
+        return fail(SGZ_EUNSUPPORTED, "Phase mode: only the image can be rendered from a folded carry (the cancellation smoother is a linear recurrence without an exact fold)");
     return runDecayEmitWithCarry(plan->impl, d_mapped, long(frames), d_carry, d_rgba, d_lines, d_state_out, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -818,9 +820,7 @@ sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64
     if (st != SGZ_OK) return st;
     if (!d_aggs || !frames_per_rank || !d_carry || rank >= world || world > 64) return fail(SGZ_EINVAL, "bad argument");
     Plan &p = plan->impl;
-    if (p.cfg.channel_mode == SGZ_CH_PHASE)
-        return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
-    long long fr[64];
+    long long fr[64];                                        // (Phase: the magnitude halves fold exactly; see sgz_stage_decay_scan)
     for (uint32_t q = 0; q < world; ++q) fr[q] = frames_per_rank[q];
     const size_t perRank = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     SGZ_HIP(launchDecayFold(d_aggs, fr, world, rank, perRank, p.P, p.scalars, d_carry, reinterpret_cast<hipStream_t>(stream)));

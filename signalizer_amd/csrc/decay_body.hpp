@@ -122,7 +122,7 @@ __device__ __forceinline__ void emitPixel(const DecayParams &prm, uint32_t chunk
             } else {
 #pragma unroll
                 for (int i = 0; i < kMaxChunk; ++i)             // independent loads first
-                    mag[i] = i <= t ? prm.mapped[size_t(f0 + i) * perFrame + size_t(ps) * prm.P + pixel] : 0.f;
+                    mag[i] = i <= t ? prm.mapped[size_t(f0 + i) * perFrame + size_t(ps) * prm.P + pixel] * prm.magScale : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < G; ++k) {

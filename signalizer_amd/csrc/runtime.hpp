@@ -32,7 +32,7 @@ extern uint32_t g_ablate;   // debug only (tools/ablate.py)
 #endif
 // K_B: decay recurrence + dB map + colour blend
 sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
-                          float *d_state, hipStream_t stream);
+                          float *d_state, hipStream_t stream, bool magnitudeOnly = false);
 sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, const float *d_carry, uint8_t *d_rgba, float *d_lines,
                                  float *d_stateOut, hipStream_t stream);
 // frequency tracker (tracker.hip): peak search + parabolic fit on one (frame, pair)'s csf magnitudes; d_out: DEVICE sgz_peak

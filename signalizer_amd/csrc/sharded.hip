@@ -175,8 +175,6 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
         return fail(SGZ_EINVAL, "bad argument");
     Plan &p = plan->impl;
     if (!p.uploaded) { std::string err; sgz_status st = uploadPlan(p, err); if (st != SGZ_OK) return fail(st, err); }
-    if (p.cfg.channel_mode == SGZ_CH_PHASE)
-        return fail(SGZ_EUNSUPPORTED, "Phase mode: the cancellation smoother is a linear recurrence, there is no exact carry fold");
     if (isResonator(p))
         return fail(SGZ_EUNSUPPORTED, "RSNT: a rank's resonators would need every earlier rank's end state (an IIR carry); single device only");
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
@@ -241,7 +239,7 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
         if (hipError_t e = hipStreamWaitEvent(s, evJoin, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
     }
     if (hipError_t e = hipMemsetAsync(d_end, 0, stateN * sizeof(float), s); e != hipSuccess) return bail(hipFail(e, "hipMemsetAsync"));
-    if (frames && (st = runDecayColour(p, p.d_mapped, long(frames), nullptr, nullptr, d_end, s)) != SGZ_OK) return bail(st);
+    if (frames && (st = runDecayColour(p, p.d_mapped, long(frames), nullptr, nullptr, d_end, s, /*magnitudeOnly=*/true)) != SGZ_OK) return bail(st);
     // A2: end states of every rank, exact fold of the predecessors
     if ((st = coll(t->allgather(t->ctx, d_end, d_all, stateN, s), "end-state all-gather")) != SGZ_OK) return st;
     const float *carry = nullptr;

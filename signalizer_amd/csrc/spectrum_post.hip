@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) decayLocalKernel(const DecayParams prm)
     float mag[kMaxChunk];
 #pragma unroll
     for (int t = 0; t < kMaxChunk; ++t)                         // independent loads first
-        mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem];
+        mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem] * prm.magScale;    // (x 1 is exact; 0.5: Phase, :1407)
 #pragma unroll
     for (int t = 0; t < kMaxChunk; ++t) {
         if (t < len) {
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
         const int len = int(min(long(kMaxChunk), prm.frames - f0));
         float mag[kMaxChunk];
 #pragma unroll
-        for (int t = 0; t < kMaxChunk; ++t) mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem];
+        for (int t = 0; t < kMaxChunk; ++t) mag[t] = prm.mapped[size_t(f0 + (t < len ? t : 0)) * perChunk + rem] * prm.magScale;
 #pragma unroll
         for (int t = 0; t < kMaxChunk; ++t) {
             if (t < len) {

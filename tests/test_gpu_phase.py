@@ -134,12 +134,18 @@ def test_phase_colour_only_render(gpu, oracle, frames):
     assert not problems, (problems[:5], stats)
 
 
-def test_phase_has_no_carry_fold(gpu):
-    """the cancellation smoother is a linear recurrence: the exact multi-GPU carry fold does not apply"""
+def test_phase_carry_fold_covers_the_image_only(gpu):
+    """the magnitude half of the Phase state is a peak decay and folds exactly (the image is coloured from it alone); the cancellation
+    smoother is a linear recurrence without an exact fold: line results / end state from a folded carry are refused"""
     import torch
     plan = api.Plan(_cfg(config.INTERP_LINEAR, P=64)).upload()
     aggs = torch.zeros((2, 1, 2, 64, 2), dtype=torch.float32, device=gpu)
     carry = torch.zeros((1, 2, 64, 2), dtype=torch.float32, device=gpu)
-    with pytest.raises(api.SgzError) as e:
-        plan.fold_carry(aggs, [4, 4], 1, carry)
-    assert e.value.status == api.SGZ_EUNSUPPORTED
+    plan.fold_carry(aggs, [4, 4], 1, carry)
+    mapped = torch.rand((4, 1, 2, 64), dtype=torch.float32, device=gpu)
+    end = torch.zeros((1, 2, 64, 2), dtype=torch.float32, device=gpu)
+    lines = torch.zeros((4, 1, 2, 64, 2), dtype=torch.float32, device=gpu)
+    s = torch.cuda.current_stream().cuda_stream
+    api.check(api.lib().sgz_stage_decay_scan(plan.h, mapped.data_ptr(), 4, end.data_ptr(), s))
+    st = api.lib().sgz_stage_decay_emit(plan.h, mapped.data_ptr(), 4, carry.data_ptr(), None, lines.data_ptr(), None, s)
+    assert st == api.SGZ_EUNSUPPORTED

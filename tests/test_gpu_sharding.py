@@ -41,7 +41,8 @@ def _worker(rank, world, port, cfg, S, q):
     (8192, 2048, 2, 8192 * 4 + 77, 3, config.CH_SEPARATE),            # halves path, three ranks
     (2048, 700, 1, 2048 * 6 + 5, 2, config.CH_MERGE),                # generic path, a mono mode, hop not dividing the chunk
     (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE),              # four ranks, three pairs
-    (65536, 16384, 4, 65536 * 3 + 999, 2, config.CH_SEPARATE)])       # cfg5's transform (N = 65536, halves path), sharded
+    (65536, 16384, 4, 65536 * 3 + 999, 2, config.CH_SEPARATE),        # cfg5's transform (N = 65536, halves path), sharded
+    (4096, 1024, 2, 4096 * 4 + 17, 3, config.CH_PHASE)])              # Phase: the image needs the magnitude half of the state only, which folds exactly
 def test_sharded_render_equals_single_device(gpu, window, hop, pairs, S, world, mode):
     import torch
     import torch.multiprocessing as mp
@@ -181,7 +182,8 @@ def _c_abi_worker(rank, world, port, cfg, S, q):
     (32768, 8192, 1, 32768 * 4, 3, config.CH_SEPARATE),               # hop divides the chunk: halo = W - hop, three frames behind it
     (65536, 16384, 4, 65536 * 3 + 999, 2, config.CH_SEPARATE),        # cfg5's transform, four pairs
     (4096, 1024, 3, 4096 * 3 + 1, 4, config.CH_MIDSIDE),              # four ranks, three pairs, whole-frame kernel
-    (2048, 700, 1, 2048 * 6 + 5, 3, config.CH_MERGE)])                # generic path, a mono mode
+    (2048, 700, 1, 2048 * 6 + 5, 3, config.CH_MERGE),                 # generic path, a mono mode
+    (4096, 1024, 1, 4096 * 5 + 300, 2, config.CH_PHASE)])             # Phase mode: image from the exactly folded magnitude states
 def test_c_abi_sharded_render_multi_rank_equals_single_device(gpu, window, hop, pairs, S, world, mode):
     """the C-ABI sharded path with 2-4 ranks (send / recv between distinct peers, the halo overlapped with the
     first K_A launch, decayFold inside the C path): bit-identical to a single-device render of the concatenated stream."""
