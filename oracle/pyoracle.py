@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
         L.sgzo_resonator_windowed_state.argtypes = [C.POINTER(SpectrumParams), vp, vp, vp, C.c_int, C.c_int, vp]
         L.sgzo_resonator_num_frames.restype = C.c_long
         L.sgzo_resonator_num_frames.argtypes = [C.c_size_t, C.c_uint32]
+        L.sgzo_resonator_spectrogram_scaled.restype = C.c_long
+        L.sgzo_resonator_spectrogram_scaled.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp, vp]
         L.sgzo_resonator_spectrogram.restype = C.c_long
         L.sgzo_resonator_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_track_peak.argtypes = [C.POINTER(SpectrumParams), vp, C.c_uint32, vp, C.c_double, C.c_double, vp]
@@ -347,8 +349,9 @@ def resonator_map(p: SpectrumParams):
     return coeff[:V.value].copy(), gain, weights[:V.value].copy()
 
 
-def resonator_spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False, want_mapped: bool = False):
-    """RSNT offline job: one frame per hop samples, resonators from rest.  Same result dict as spectrogram()."""
+def resonator_spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: bool = False, want_mapped: bool = False, want_scale: bool = False):
+    """RSNT offline job: one frame per hop samples, resonators from rest.  Same result dict as spectrogram(); want_scale adds
+    "scale" [F][C][2][P]: gain * sum_v |w_v| |s_v| per signal -- the size of the terms the window kernel sums (the tests' error bar)"""
     planar = np.ascontiguousarray(planar, np.float32)
     nch, S = planar.shape
     assert nch == 2 * p.num_pairs
@@ -358,10 +361,11 @@ def resonator_spectrogram(p: SpectrumParams, planar: np.ndarray, want_lines: boo
     lines = np.zeros((F, p.num_pairs, NUM_GRAPHS, P), np.complex64) if want_lines else None
     mapped = np.zeros((F, p.num_pairs, 2 * P), np.complex64) if want_mapped else None
     ptrs = (C.c_void_p * nch)(*[planar[c].ctypes.data for c in range(nch)])
-    n = lib().sgzo_resonator_spectrogram(C.byref(p), ptrs, S, _ptr(rgba), _ptr(lines) if want_lines else None,
-                                         _ptr(mapped) if want_mapped else None)
+    scale = np.zeros((F, p.num_pairs, 2, P), np.float32) if want_scale else None
+    n = lib().sgzo_resonator_spectrogram_scaled(C.byref(p), ptrs, S, _ptr(rgba), _ptr(lines) if want_lines else None,
+                                                _ptr(mapped) if want_mapped else None, _ptr(scale) if want_scale else None)
     assert n == F, (n, F)
-    return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F}
+    return {"rgba": rgba, "lines": lines, "mapped": mapped, "frames": F, "scale": scale}
 
 
 def decay_colour(p: SpectrumParams, mapped: np.ndarray, want_lines: bool = False):

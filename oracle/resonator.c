@@ -167,6 +167,15 @@ long sgzo_resonator_num_frames(size_t nsamples, uint32_t hop) { return hop ? (lo
 long sgzo_resonator_spectrogram(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
                                 uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out)
 {
+    return sgzo_resonator_spectrogram_scaled(p, planar, nsamples, rgba_out, line_out, mapped_out, NULL);
+}
+
+/* ... and, for the tests' error bars, the size of what the window kernel sums: scale_out [F][C][2][P] = gain sum_v |w_v| |s_v| per signal.
+ * The windowed value is a difference of nearly equal terms when the bandwidth is small against the detuning (long resonators, free
+ * Q): two correct fp32 evaluations of the recurrence differ by a few eps of THIS quantity, not of the result. */
+long sgzo_resonator_spectrogram_scaled(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                                       uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out, float *scale_out)
+{
     const uint32_t P = p->axis_points, C = p->num_pairs, hop = p->hop;
     const long F = sgzo_resonator_num_frames(nsamples, hop);
     if (F <= 0 || P < 2) return 0;
@@ -196,6 +205,17 @@ long sgzo_resonator_spectrogram(const sgzo_spectrum_params *p, const float *cons
             memset(csp, 0, sizeof(sgzo_cf) * (size_t)P * 2);
             sgzo_resonator_windowed_state(p, st, gain, weights, V, signals, csp);
             if (mapped_out) memcpy(mapped_out + ((size_t)f * C + pr) * 2 * P, csp, sizeof(sgzo_cf) * (size_t)P * sc);
+            if (scale_out)
+                for (int sg = 0; sg < 2; ++sg)
+                    for (uint32_t i = 0; i < P; ++i) {
+                        double acc = 0;
+                        if (sg < signals)
+                            for (int v = 0; v < V; ++v) {
+                                const sgzo_cf z = st[((size_t)sg * V + v) * P + i];
+                                acc += fabs((double)weights[v]) * hypot((double)z.re, (double)z.im);
+                            }
+                        scale_out[(((size_t)f * C + pr) * 2 + sg) * P + i] = (float)(acc * (double)gain[i]);
+                    }
             sgzo_cf *fs = states + (size_t)pr * SGZO_NUM_GRAPHS * P, *rs = results + (size_t)pr * SGZO_NUM_GRAPHS * P;
             sgzo_map_and_transform_filters(p, slope, csp, fs, rs);
             memcpy(frames + (size_t)pr * P, rs, sizeof(sgzo_cf) * P);

@@ -237,6 +237,8 @@ void sgzo_resonator_windowed_state(const sgzo_spectrum_params *p, const sgzo_cf 
 long sgzo_resonator_num_frames(size_t nsamples, uint32_t hop);
 long sgzo_resonator_spectrogram(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
                                 uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out);
+long sgzo_resonator_spectrogram_scaled(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                                       uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out, float *scale_out /*[F][C][2][P]*/);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resGain, d_resState, d_resLocal};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resPowB, d_resPowBLo, d_resGain, d_resState, d_resLocal};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -93,6 +93,8 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.phaseNorm, &p.d_phaseNorm)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resCoeff, &p.d_resCoeff)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resPow, &p.d_resPow)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resPowB, &p.d_resPowB)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resPowBLo, &p.d_resPowBLo)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resGain, &p.d_resGain)) != SGZ_OK) return st;
     if (isResonator(p)) {                                  // the resonators start from rest (TransformPair.h:183 resetState)
         if (p.d_resState) { (void)hipFree(p.d_resState); p.d_resState = nullptr; }
@@ -195,7 +197,9 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     r.hop = p.cfg.hop; r.C = p.C; r.P = p.P; r.mode = p.cfg.channel_mode;
     r.V = p.resV; r.signals = p.stateChannels; r.sides = p.sides; r.firstContinues = true;
     r.coeff = reinterpret_cast<const float2 *>(p.d_resCoeff);
-    r.cpow = reinterpret_cast<const float2 *>(p.d_resPow);
+    r.cpow = reinterpret_cast<const float4 *>(p.d_resPow);
+    r.cpowB = reinterpret_cast<const float2 *>(p.d_resPowB);
+    r.cpowBLo = reinterpret_cast<const float2 *>(p.d_resPowBLo);
     r.gain = p.d_resGain;
     for (int v = 0; v < 9; ++v) r.weights[v] = p.resWeights[v];
     r.state = reinterpret_cast<float2 *>(p.d_resState);

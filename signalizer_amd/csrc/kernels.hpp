@@ -158,7 +158,10 @@ struct ResParams {
     uint32_t hop, C, P, mode;
     int V, signals, sides;
     bool firstContinues;              // frame 0 of this launch continues from `state` (always, except inside a long render's later slabs)
-    const float2 *coeff, *cpow;       // [V][P]
+    const float2 *coeff;              // [V][P]
+    const float4 *cpow;               // [V][P]: pole^hop as (re, im, re_lo, im_lo)
+    const float2 *cpowB;              // [V][P][8]: pole^1 .. pole^8
+    const float2 *cpowBLo;            // [V][P][2]: low words of pole^4, pole^8
     const float *gain;                // [P]
     float weights[9];                 // [V]
     float2 *state;                    // [C][2][V][P]

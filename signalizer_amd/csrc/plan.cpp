@@ -503,7 +503,9 @@ static void buildResonator(Plan &p)
         p.resWeights[v] = float(am == 0 ? a[0] : ((am & 1) ? -0.5 : 0.5) * a[am]);
     }
     p.resCoeff.assign(size_t(V) * P * 2, 0.f);
-    p.resPow.assign(size_t(V) * P * 2, 0.f);
+    p.resPow.assign(size_t(V) * P * 4, 0.f);
+    p.resPowB.assign(size_t(V) * P * 8 * 2, 0.f);
+    p.resPowBLo.assign(size_t(V) * P * 2 * 2, 0.f);
     p.resGain.assign(P, 0.f);
     for (uint32_t i = 0; i < P; ++i) {
         const uint32_t k = i + 1 >= P ? P - 2 : i;
@@ -526,8 +528,24 @@ static void buildResonator(Plan &p)
                 if (e & 1u) { const double t = pr * br - pi * bi; pi = pr * bi + pi * br; pr = t; }
                 const double t = br * br - bi * bi; bi = 2.0 * br * bi; br = t;
             }
-            p.resPow[(size_t(v) * P + i) * 2] = float(pr);
-            p.resPow[(size_t(v) * P + i) * 2 + 1] = float(pi);
+            // (hi, lo) pairs: a power rounded to fp32 is a slightly different pole -- the same relative 3e-8 at EVERY step of the chain, which
+            // a resonator that remembers 1e5 samples turns into 1e-4 of its state; the low words take that systematic part out
+            p.resPow[(size_t(v) * P + i) * 4] = float(pr);
+            p.resPow[(size_t(v) * P + i) * 4 + 1] = float(pi);
+            p.resPow[(size_t(v) * P + i) * 4 + 2] = float(pr - double(float(pr)));
+            p.resPow[(size_t(v) * P + i) * 4 + 3] = float(pi - double(float(pi)));
+            // (the fp32 pole)^1 .. ^8, each rounded once from double: what the block steps of the frames from rest multiply by -- powers
+            // built up in fp32 would be a slightly different pole, and a resonator that remembers 1e5 samples notices 1e-7 of that
+            double qr = cr, qi = ci;
+            for (int k = 0; k < 8; ++k) {
+                p.resPowB[((size_t(v) * P + i) * 8 + k) * 2] = float(qr);
+                p.resPowB[((size_t(v) * P + i) * 8 + k) * 2 + 1] = float(qi);
+                if (k == 3 || k == 7) {                       // the block lengths in use (4, 8): low words of pole^B
+                    p.resPowBLo[((size_t(v) * P + i) * 2 + (k == 7 ? 1 : 0)) * 2] = float(qr - double(float(qr)));
+                    p.resPowBLo[((size_t(v) * P + i) * 2 + (k == 7 ? 1 : 0)) * 2 + 1] = float(qi - double(float(qi)));
+                }
+                const double t = qr * double(cr) - qi * double(ci); qi = qr * double(ci) + qi * double(cr); qr = t;
+            }
         }
     }
 }

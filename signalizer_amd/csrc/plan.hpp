@@ -108,7 +108,9 @@ struct Plan {
     // RSNT (resonator.hip; CComplexResonator::Constant restated): V = 2K - 1 detuned resonators per axis point for a K-term cosine-sum window
     int resV = 0;
     std::vector<float> resCoeff;        // [V][P] (re, im): pole r e^{j w}
-    std::vector<float> resPow;          // [V][P] (re, im): (the fp32 pole)^hop, evaluated in double -- the carry of a whole frame
+    std::vector<float> resPow;          // [V][P] (re, im, re_lo, im_lo): (the fp32 pole)^hop, evaluated in double, as hi + lo fp32 words -- the carry of a whole frame
+    std::vector<float> resPowB;         // [V][P][8] (re, im): (the fp32 pole)^1 .. ^8, rounded once each -- the block steps of resonateKernel
+    std::vector<float> resPowBLo;       // [V][P][2] (re, im): low words of pole^4 and pole^8
     std::vector<float> resGain;         // [P]
     float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
@@ -144,7 +146,7 @@ struct Plan {
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
     void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
-    float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resGain = nullptr;
+    float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resPowB = nullptr, *d_resPowBLo = nullptr, *d_resGain = nullptr;
     float *d_resState = nullptr;                          // [C][2][V][P] (re, im): the resonators between calls
     float *d_resLocal = nullptr; size_t resLocalCap = 0;  // [frames][C][signals][V][P] (re, im): per-frame sums from rest
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs

@@ -70,19 +70,22 @@ __device__ __forceinline__ void resStep(float (&re)[V], float (&im)[V], const fl
 template <int V> struct ResBlock { static constexpr int B = V <= 5 ? 8 : 4; };
 
 template <int V, bool EXACT>
-__device__ __forceinline__ void resRun(const ResParams &prm, float *xs, const float *L, const float *R, int signal, int tid,
+__device__ __forceinline__ void resRun(const ResParams &prm, float *xs, const float *L, const float *R, int signal, int tid, uint32_t i, bool live,
                                        float (&re)[V], float (&im)[V], const float (&cr)[V], const float (&ci)[V])
 {
     constexpr int B = ResBlock<V>::B;
-    [[maybe_unused]] float pr[V][B], pi[V][B];                    // pr[v][k] + i pi[v][k] = c_v^(k+1)
+    [[maybe_unused]] float pr[V][B], pi[V][B];                    // pr[v][k] + i pi[v][k] = c_v^(k+1), from the plan (rounded once each)
+    [[maybe_unused]] float lr[V], li[V];                          // low words of c_v^B: the state is multiplied by hi + lo
     if constexpr (!EXACT) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            pr[v][0] = cr[v]; pi[v][0] = ci[v];
+            const float2 lo = prm.cpowBLo[(size_t(v) * prm.P + (live ? i : 0u)) * 2 + (B == 8 ? 1 : 0)];
+            lr[v] = lo.x; li[v] = lo.y;
+            const float4 *q = reinterpret_cast<const float4 *>(prm.cpowB + (size_t(v) * prm.P + (live ? i : 0u)) * 8);
 #pragma unroll
-            for (int k = 1; k < B; ++k) {
-                pr[v][k] = __builtin_fmaf(pr[v][k - 1], cr[v], -pi[v][k - 1] * ci[v]);
-                pi[v][k] = __builtin_fmaf(pr[v][k - 1], ci[v], pi[v][k - 1] * cr[v]);
+            for (int k = 0; k < B; k += 2) {
+                const float4 t = q[k / 2];
+                pr[v][k] = t.x; pi[v][k] = t.y; pr[v][k + 1] = t.z; pi[v][k + 1] = t.w;
             }
         }
     }
@@ -111,9 +114,9 @@ __device__ __forceinline__ void resRun(const ResParams &prm, float *xs, const fl
                     }
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        // c^B s
-                        float nre = __builtin_fmaf(re[v], pr[v][B - 1], -im[v] * pi[v][B - 1]);
-                        float nim = __builtin_fmaf(re[v], pi[v][B - 1], im[v] * pr[v][B - 1]);
+                        // c^B s, c^B = hi + lo
+                        float nre = __builtin_fmaf(re[v], pr[v][B - 1], __builtin_fmaf(-im[v], pi[v][B - 1], __builtin_fmaf(re[v], lr[v], -im[v] * li[v])));
+                        float nim = __builtin_fmaf(re[v], pi[v][B - 1], __builtin_fmaf(im[v], pr[v][B - 1], __builtin_fmaf(re[v], li[v], im[v] * lr[v])));
                         // + sum_b c^(B-1-b) x[b]   (x is real; c^0 = 1)
 #pragma unroll
                         for (int b = 0; b < B - 1; ++b) {
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
         const float2 s0 = (live && continues) ? prm.state[stateAt + size_t(v) * prm.P] : float2{0.f, 0.f};
         re[v] = s0.x; im[v] = s0.y;
     }
-    if (continues) resRun<V, true>(prm, xs, L, R, signal, tid, re, im, cr, ci);
-    else resRun<V, false>(prm, xs, L, R, signal, tid, re, im, cr, ci);
+    if (continues) resRun<V, true>(prm, xs, L, R, signal, tid, i, live, re, im, cr, ci);
+    else resRun<V, false>(prm, xs, L, R, signal, tid, i, live, re, im, cr, ci);
     if (live) {
         float2 *out = prm.local + ((size_t(frame) * prm.C + pair) * size_t(prm.signals) + size_t(signal)) * V * prm.P + i;
 #pragma unroll
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(kResBlock) void resonatorFoldKernel(ResParams prm)
     const uint32_t pair = blockIdx.y;
     constexpr int K = (V + 1) / 2;
     const int S = prm.signals;
-    float pr[V], pi[V], w[V];
+    float pr[V], pi[V], qr[V], qi[V], w[V];
     float sre[2][V], sim[2][V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const float2 c = prm.cpow[size_t(v) * prm.P + i];
-        pr[v] = c.x; pi[v] = c.y; w[v] = prm.weights[v];
+        const float4 c = prm.cpow[size_t(v) * prm.P + i];
+        pr[v] = c.x; pi[v] = c.y; qr[v] = c.z; qi[v] = c.w; w[v] = prm.weights[v];
 #pragma unroll
         for (int s = 0; s < 2; ++s) { sre[s][v] = 0.f; sim[s][v] = 0.f; }
     }
@@ -197,8 +200,9 @@ __global__ __launch_bounds__(kResBlock) void resonatorFoldKernel(ResParams prm)
                 const float2 l = loc[size_t(v) * prm.P];
                 if (f == 0) { sre[s][v] = l.x; sim[s][v] = l.y; }            // frame 0 already continued from the carried state
                 else {
-                    const float nre = (sre[s][v] * pr[v] - sim[s][v] * pi[v]) + l.x;
-                    const float nim = (sre[s][v] * pi[v] + sim[s][v] * pr[v]) + l.y;
+                    // c^hop = hi + lo (plan.cpp): the low word keeps the chain from drifting off the sample-by-sample recurrence
+                    const float nre = __builtin_fmaf(sre[s][v], pr[v], __builtin_fmaf(-sim[s][v], pi[v], __builtin_fmaf(sre[s][v], qr[v], -sim[s][v] * qi[v]))) + l.x;
+                    const float nim = __builtin_fmaf(sre[s][v], pi[v], __builtin_fmaf(sim[s][v], pr[v], __builtin_fmaf(sre[s][v], qi[v], sim[s][v] * qr[v]))) + l.y;
                     sre[s][v] = nre; sim[s][v] = nim;
                 }
             }

@@ -3,8 +3,8 @@
 Bars:
   * a one-frame launch continues the carried state sample by sample: the windowed magnitudes are BIT-EXACT against the oracle's
     sequential fp32 recurrence (this is the real-time case: one frame per audio block);
-  * a multi-frame launch chains the frames with c^hop (resonator.hip): magnitudes within 2e-5 of the frame's largest
-    (measured ~3e-7: one complex product's rounding per frame);
+  * a multi-frame launch chains the frames with c^hop (resonator.hip): magnitudes within 2e-5 of the frame's largest (measured ~3e-7)
+    plus 4 eps sqrt(1 / (1 - r)) of the size of the terms the window kernel sums (long resonators: see check_planes);
   * decay -> dB -> colour -> RGBA8 and line results BIT-EXACT given the HIP path's own magnitudes (the same K_B as the FFT branch).
 cpl's CComplexResonator is absent: the oracle restates it (UNVERIFIED vs cpl), parity is against that restatement."""
 import ctypes as C
@@ -17,7 +17,41 @@ from signalizer_amd import api, config as cf, synth
 
 pytestmark = pytest.mark.gpu
 
-CHAIN_TOL = 2e-5
+CHAIN_TOL = 2e-5          # of the frame's largest value: well-conditioned configurations (measured ~3e-7)
+STATE_K = 4.0             # x eps x sqrt(1 / (1 - r)) of gain * sum_v |w_v| |s_v|, the terms the window kernel sums: a resonator remembers
+                          # ~1 / (1 - r) samples, its fp32 recurrence accumulates ~sqrt(that) roundings, and long resonators (free Q: up to
+                          # 1e5 samples) make the windowed value a small difference of large states -- two correct fp32 evaluations
+                          # (sequential, chained) differ by that much of THOSE, not of the result
+EPS = 2.0 ** -24
+
+
+def check_planes(got, ref, scale, mode, gain):
+    """got / ref: [F][C][planes][P] as K_A hands them to K_B; scale: the oracle's [F][C][2][P] (resonator_spectrogram(want_scale=True)).
+    gain [P] = 1 - r of the axis point (resonator_map).  Returns (list of problems, largest |error| / bar).  Bar per value: CHAIN_TOL x
+    the frame's largest + STATE_K eps sqrt(1 / (1 - r)) x the state scale;
+    Phase's cancellation plane 1 - |L + R| / (|L| + |R|): the same bar divided by the magnitude plane's value (first-order error of
+    the ratio), at least 2e-3 ... where the magnitude itself is above the bar (below it the ratio is noise in both)."""
+    problems, worst = [], 0.0
+    F, Cn, planes, P = ref.shape
+    state_tol = STATE_K * EPS * np.sqrt(1.0 / np.maximum(gain.astype(np.float64), 1e-12))
+    for f in range(F):
+        for c in range(Cn):
+            top = max(float(np.max(np.abs(ref[f, c, 0 if mode == cf.CH_PHASE else slice(None)]))), 1e-30)
+            for s in range(planes):
+                sc = scale[f, c, 0] + scale[f, c, 1] if mode == cf.CH_PHASE else scale[f, c, s]
+                bar = CHAIN_TOL * top + state_tol * sc
+                err = np.abs(got[f, c, s] - ref[f, c, s])
+                if mode == cf.CH_PHASE and s == 1:
+                    mid = ref[f, c, 0]
+                    keep = mid > 50 * bar
+                    rel = np.where(keep, 4 * bar / np.maximum(mid, 1e-30), np.inf) + 2e-6
+                    ratio = float(np.max(np.where(keep, err / rel, 0.0))) if keep.any() else 0.0
+                else:
+                    ratio = float(np.max(err / np.maximum(bar, 1e-37)))
+                worst = max(worst, ratio)
+                if ratio > 1.0:
+                    problems.append((f, c, s, ratio))
+    return problems, worst
 
 
 def _cfg(**over):
@@ -66,15 +100,11 @@ def test_render_chain_against_the_oracle(gpu, oracle, over):
     assert plan.num_frames(x.shape[1]) == F
     xs = _cuda(x, gpu)
     got = plan.stage_mapped(xs).cpu().numpy()
-    r = oracle.resonator_spectrogram(p, x, want_lines=True, want_mapped=True)
+    r = oracle.resonator_spectrogram(p, x, want_lines=True, want_mapped=True, want_scale=True)
     ref = _planes(r["mapped"], mode, P)
-    # link 1: the windowed state, frame by frame (Phase's cancellation plane is a ratio in [0, 1]: absolute)
-    for f in range(F):
-        for c in range(Cn):
-            for s in range(ref.shape[2]):
-                scale = 1.0 if (mode == cf.CH_PHASE and s == 1) else max(float(np.max(np.abs(ref[f, c]))), 1e-30)
-                err = float(np.max(np.abs(got[f, c, s] - ref[f, c, s])))
-                assert err <= (2e-3 if (mode == cf.CH_PHASE and s == 1) else CHAIN_TOL) * scale, (f, c, s, err, scale)
+    # link 1: the windowed state, frame by frame
+    problems, worst = check_planes(got, ref, r["scale"], mode, oracle.resonator_map(p)[1])
+    assert not problems, (problems[:5], worst)
     assert np.array_equal(got[0], ref[0])                                     # frame 0 ran from rest, sample by sample
     # link 2: decay, dB, colour and lines byte for byte given the HIP path's own magnitudes
     import torch
