@@ -36,7 +36,7 @@ def test_random_configurations_match_the_oracle(gpu, oracle, seed, wild):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("tool,count", [("fuzz_stages.py", 40), ("fuzz_realtime.py", 30), ("fuzz_scope.py", 30)])
+@pytest.mark.parametrize("tool,count", [("fuzz_stages.py", 40), ("fuzz_realtime.py", 30), ("fuzz_scope.py", 30), ("fuzz_rsnt.py", 40)])
 def test_stage_realtime_and_scope_sweeps(gpu, tool, count):
     """the other seeded sweeps (tools/): bit-exact stages, the per-block path and split renders, the Oscilloscope / Vectorscope
     kernels -- each prints one line per case and exits non-zero on any mismatch"""
@@ -45,5 +45,5 @@ def test_stage_realtime_and_scope_sweeps(gpu, tool, count):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(count), "1"], capture_output=True, text=True, timeout=900)
-    bad = [l for l in r.stdout.splitlines() if " BAD " in l]
+    bad = [l for l in r.stdout.splitlines() if " BAD " in l or l.startswith("BAD") or l.startswith("EXC")]
     assert r.returncode == 0 and not bad, (bad[:5], r.stderr[-500:])

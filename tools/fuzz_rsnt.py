@@ -59,3 +59,4 @@ for case in range(cases):
         bad += 1
         print("BAD", case, d)
 print(f"bad: {bad} of {cases}   (largest |error| / bar: {worst:.3f})")
+sys.exit(1 if bad else 0)
