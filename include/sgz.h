@@ -19,7 +19,9 @@
 extern "C" {
 #endif
 
-#define SGZ_ABI_VERSION 1
+/* 3: sgz_spectrum_config grew algorithm / free_q, sgz_scope_config custom_trigger / custom_trigger_frequency (round 3);
+ * a binding compares sgz_abi_version() with the header it was compiled against */
+#define SGZ_ABI_VERSION 3
 
 typedef enum sgz_status {
     SGZ_OK = 0,

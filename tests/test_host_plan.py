@@ -117,7 +117,7 @@ def test_library_exports_every_symbol_the_header_declares():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(api.EXPORTS) == declared
-    assert L.sgz_abi_version() == 1
+    assert L.sgz_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
