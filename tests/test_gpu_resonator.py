@@ -180,3 +180,76 @@ def test_unsupported_combinations_say_so(gpu):
     bins = torch.empty((4, 1, plan.N + 1), dtype=torch.float32, device=gpu)
     assert api.lib().sgz_stage_bins(plan.h, x.data_ptr(), x.stride(0), 4096, bins.data_ptr(), None) == api.SGZ_EUNSUPPORTED
     assert api.lib().sgz_shard_layout(plan.h, 0, 2, 8192, None, None, None, None) == api.SGZ_EUNSUPPORTED
+
+
+def _pop(h, P, want, timeout=10.0):
+    api.lib().sgz_spectrum_flush.argtypes = [C.c_void_p]
+    api.check(api.lib().sgz_spectrum_flush(h))
+    cols, buf, ap, t0 = [], np.zeros((P, 4), np.uint8), C.c_uint32(0), time.time()
+    while len(cols) < want and time.time() - t0 < timeout:
+        if api.lib().sgz_spectrum_pop_column(h, buf.ctypes.data_as(C.c_void_p), C.byref(ap)) == api.SGZ_OK:
+            cols.append(buf.copy())
+        else:
+            time.sleep(0.001)
+    return cols
+
+
+def test_real_time_handle_long_blocks_reconfiguration_and_clear(gpu, oracle):
+    """blocks longer than a hop (several frames per push: the chained path inside the handle), a switch FFT -> RSNT -> FFT by
+    sgz_spectrum_configure, and sgz_spectrum_clear_state putting the resonators to rest"""
+    hop, P = 512, 128
+    d = _cfg(hop=hop, axis_points=P, window_size=2048, channel_mode=cf.CH_MIDSIDE)
+    x = synth.gen(21, 48000, 8 * 2048, 2)
+    fft = dict(d, algorithm=cf.ALGO_FFT)
+    h = C.c_void_p()
+    c0 = api.config_from_dict(fft)
+    api.check(api.lib().sgz_spectrum_create(C.byref(c0), C.byref(h)))
+    try:
+        push = lambda blk: api.check(api.lib().sgz_spectrum_push(h, (C.c_void_p * 2)(blk[0].ctypes.data, blk[1].ctypes.data), 2, blk.shape[1]))
+        push(np.ascontiguousarray(x[:, :2048]))
+        assert len(_pop(h, P, 4)) == 4                                        # FFT columns (their bytes are test_gpu_realtime's business)
+        c1 = api.config_from_dict(d)
+        api.check(api.lib().sgz_spectrum_configure(h, C.byref(c1)))           # -> RSNT: resonators at rest, decay state cleared
+        cols = []
+        for b in range(4):
+            push(np.ascontiguousarray(x[:, b * 2048:(b + 1) * 2048]))         # 4 frames per push
+            cols += _pop(h, P, 4)                                             # (the column queue holds 10: SpectrumDSP.cpp:185-186 drops beyond)
+        got = np.stack(cols)
+        want = oracle.resonator_spectrogram(oracle.params_from_dict(d), x[:, :16 * hop])["rgba"]
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert got.shape == want.shape and diff.max() <= 1 and (diff > 0).mean() < 0.01, (int(diff.max()), float((diff > 0).mean()))
+        assert np.array_equal(got[0], want[0])                                # the first frame continued a state at rest, sample by sample
+        # clear_state: the next frames are those of a fresh stream
+        api.check(api.lib().sgz_spectrum_clear_state(h))
+        for b in range(8):
+            push(np.ascontiguousarray(x[:, b * hop:(b + 1) * hop]))           # one frame per push: bit-exact again
+        got2 = np.stack(_pop(h, P, 8))
+        want2 = oracle.resonator_spectrogram(oracle.params_from_dict(d), x[:, :8 * hop])["rgba"]
+        assert np.array_equal(got2, want2), int((got2 != want2).sum())
+        api.check(api.lib().sgz_spectrum_configure(h, C.byref(c0)))           # and back to the FFT
+        push(np.ascontiguousarray(x[:, :2048]))
+        assert len(_pop(h, P, 4)) == 4
+    finally:
+        api.lib().sgz_spectrum_destroy(h)
+
+
+def test_real_time_handle_mix_matrix_feeds_the_resonators(gpu, oracle):
+    """MixGraphListener's routing in front of the resonators: three sources summed into the two channels of the pair"""
+    hop, P = 256, 100
+    d = _cfg(hop=hop, axis_points=P, channel_mode=cf.CH_SEPARATE)
+    src = synth.gen(31, 48000, 6 * hop, 3)
+    mixed = np.stack([src[0] + src[2], src[1]]).astype(np.float32)
+    h = C.c_void_p()
+    c = api.config_from_dict(d)
+    api.check(api.lib().sgz_spectrum_create(C.byref(c), C.byref(h)))
+    try:
+        m = np.array([[1, 0, 1], [0, 1, 0]], np.uint8)                         # [destination channel][source]
+        api.check(api.lib().sgz_spectrum_set_mix(h, 3, m.ctypes.data_as(C.c_void_p)))
+        for b in range(6):
+            blk = np.ascontiguousarray(src[:, b * hop:(b + 1) * hop])
+            api.check(api.lib().sgz_spectrum_push(h, (C.c_void_p * 3)(*[blk[i].ctypes.data for i in range(3)]), 3, hop))
+        got = np.stack(_pop(h, P, 6))
+        want = oracle.resonator_spectrogram(oracle.params_from_dict(d), mixed)["rgba"]
+        assert np.array_equal(got, want), int((got != want).sum())
+    finally:
+        api.lib().sgz_spectrum_destroy(h)
