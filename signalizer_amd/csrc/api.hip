@@ -373,11 +373,14 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
     const bool noFused = !p.optFusedColour;                                  // (sgz_plan_set_option: A/B switch for measurements)
+    // the one-launch form of the step with line results / state (one pair, 2 .. 64 chunks; not the scan half of the two-step K_B,
+    // whose aggregates the emit half needs in HBM)
+    const bool fullFused = !noFused && !magnitudeOnly && p.cfg.channel_mode != SGZ_CH_PHASE && prm.numChunks > 1 && decayFullFusedApplies(prm);
     if (p.lateDeferred) {
         // the channel-split K_A in front of this call left its late pixels to whoever reads its magnitudes next (runStft, deferLate)
         float *pending = const_cast<float *>(p.lateDeferred);
         p.lateDeferred = nullptr;
-        if (d_mapped == pending && !noFused && p.cfg.channel_mode != SGZ_CH_PHASE && decayColourFusedApplies(prm)) {
+        if (d_mapped == pending && !noFused && p.cfg.channel_mode != SGZ_CH_PHASE && (decayColourFusedApplies(prm) || fullFused)) {
             // the fused colour kernel completes those pixels as it loads the magnitudes (spectrum_post.hip): the step stays at two
             // launches.  (Tried for the scan / emit kernels as well: the extra loads sit on their critical path, +3 us each,
             // against 2-5 us for realLateKernel as a launch of its own.)
@@ -401,6 +404,11 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     }
     if (!noFused && decayColourFusedApplies(prm)) {
         SGZ_HIP(launchDecayColourFused(prm, stream));
+        return SGZ_OK;
+    }
+    if (fullFused) {
+        prm.stateStash = nullptr;                              // (the kernel parks its pixels' carry-in in LDS before anything writes the state)
+        SGZ_HIP(launchDecayFullFused(prm, stream));
         return SGZ_OK;
     }
     if (prm.numChunks > 1) {

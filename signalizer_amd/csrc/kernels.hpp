@@ -142,6 +142,8 @@ hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream);
 // colour column only, one pair, <= 64 time chunks: scan + fold + emit as one launch
 bool decayColourFusedApplies(const DecayParams &prm);
 hipError_t launchDecayColourFused(const DecayParams &prm, hipStream_t stream);
+bool decayFullFusedApplies(const DecayParams &prm);
+hipError_t launchDecayFullFused(const DecayParams &prm, hipStream_t stream);
 // agg[d] <- max(agg[d], decay(carry)) for aggregates that were scanned from a zero carry-in (multi-GPU carry-apply pass)
 hipError_t launchDecayApplyCarry(const DecayParams &prm, const float *carry, hipStream_t stream);
 // SpectrumChannels::Phase: sequential-in-time K_B (the cancellation smoother is a linear recurrence: no exact chunk fold);

@@ -270,6 +270,115 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     }
 }
 
+// The same single launch for the step the reference performs on every frame -- line results of both graphs and the decay state after
+// the last frame, with or without the colour column -- for one pair and at most kFusedChunks chunks.  A 1024-thread workgroup owns PX
+// pixels for the whole time axis and all SIDES x G (side, graph) combinations of them: magnitudes of both sides and the carry-in state
+// into LDS (late pixels of a channel-split K_A completed on the way, late_fix.hpp), zero-carry chunk scans, the exact sequential fold
+// per combination, then the frames x PX emissions shared by all threads (replay, dB map of every combination, lines, colour of
+// (side 0, graph 0), the new state at the last frame).  Replaces realLateKernel + decayLocalCarryKernel + decayEmitKernel.
+template <int PX, int SIDES>
+__global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams prm)
+{
+    constexpr int NCMB = SIDES * G;                             // combination m = side * G + graph
+    __shared__ float aggS[kFusedChunks][NCMB][PX];
+    __shared__ float carryS[kFusedChunks][NCMB][PX];
+    __shared__ float magS[kFusedChunks * kMaxChunk][SIDES][PX];
+    __shared__ float stIn[NCMB][PX];
+    const uint32_t tid = threadIdx.x;
+    const size_t perFrame = size_t(SIDES) * prm.P;              // (one pair)
+    const uint32_t items = uint32_t(prm.frames) * PX;
+    // 1a. magnitudes of both sides, carry-in state
+    for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX * SIDES; e += 1024) {
+        const uint32_t px = e % PX, side = (e / PX) % SIDES, f = e / (PX * SIDES);
+        const uint32_t pixel = blockIdx.x * PX + px;
+        const bool in = f < uint32_t(prm.frames) && pixel < prm.P;
+        float m = in ? prm.mapped[size_t(f) * perFrame + size_t(side) * prm.P + pixel] * prm.magScale : 0.f;
+        if (prm.hasLate && in && pixel >= (side ? prm.late.fixFrom1 : prm.late.fixFrom0))
+            m = lateNyquistPixel(prm.late, lateNyquistBin(prm.late, long(f)), lateBestSquare(prm.late, long(f), int(side), pixel), m);
+        magS[f][side][px] = m;
+    }
+    if (tid < NCMB * PX) {
+        const uint32_t px = tid % PX, m = tid / PX, side = m / G, k = m % G;
+        const uint32_t pixel = blockIdx.x * PX + px;
+        stIn[m][px] = (prm.stateIn && pixel < prm.P) ? prm.stateIn[((size_t(k)) * prm.P + pixel) * 2 + side] : 0.f;
+    }
+    __syncthreads();
+    // 1b. zero-carry scan of every (chunk, combination, pixel); chunk 0 starts from the carry-in
+    if (tid < kFusedChunks * NCMB * PX) {
+        const uint32_t px = tid % PX, m = (tid / PX) % NCMB, chunk = tid / (PX * NCMB);
+        const uint32_t side = m / G, k = m % G;
+        const float pole = prm.sc.pole[k];
+        const long f0 = long(chunk) * kMaxChunk;
+        const int len = chunk < prm.numChunks ? int(min(long(kMaxChunk), prm.frames - f0)) : 0;
+        float a = chunk == 0 ? stIn[m][px] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kMaxChunk; ++t)
+            if (t < len) {
+                const float v = magS[chunk * kMaxChunk + t][side][px];
+                a = a * pole;                                   // states[i] *= pole, TransformDSP.inl:1336,:1370
+                if (v > a) a = v;                               // :1338-1341
+            }
+        aggS[chunk][m][px] = a;
+    }
+    __syncthreads();
+    // 2. the fold, one thread per (combination, pixel)
+    if (tid < NCMB * PX) {
+        const uint32_t px = tid % PX, m = tid / PX;
+        const float pole = prm.sc.pole[m % G];
+        float c = aggS[0][m][px];
+        carryS[0][m][px] = c;
+        for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = aggS[min(d0 + j, uint32_t(kFusedChunks - 1))][m][px];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (d0 + j < prm.numChunks) {
+#pragma unroll
+                    for (int i = 0; i < kMaxChunk; ++i) c = c * pole;  // every chunk before the last is full
+                    if (v[j] > c) c = v[j];
+                    carryS[d0 + j][m][px] = c;
+                }
+        }
+    }
+    __syncthreads();
+    // 3. emissions
+    for (uint32_t e = tid; e < items; e += 1024) {
+        const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
+        const uint32_t pixel = blockIdx.x * PX + px;
+        if (pixel >= prm.P) continue;
+        const float slope = prm.slope[pixel];
+        float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const float pole = prm.sc.pole[k];
+            float res[2] = {0.f, 0.f};                          // (results[i].phase = 0 in the one-channel modes, :1347)
+#pragma unroll
+            for (int side = 0; side < SIDES; ++side) {
+                const int m = side * G + k;
+                float a = chunk == 0 ? stIn[m][px] : 0.f;
+                float cr = chunk > 0 ? carryS[chunk - 1][m][px] : 0.f;
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i)
+                    if (uint32_t(i) <= t) {
+                        const float v = magS[chunk * kMaxChunk + i][side][px];
+                        a = a * pole;
+                        if (v > a) a = v;
+                        cr = cr * pole;
+                    }
+                const float st = a > cr ? a : cr;
+                if (prm.state && long(f) == prm.frames - 1) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st;
+                const bool colour = side == 0 && k == 0 && prm.rgba;
+                if (!colour && !prm.lines) continue;
+                res[side] = dbMap(slope, st, prm.sc);
+                if (colour) blendColour(cb, res[side], prm.colourTables, prm.sc);
+            }
+            if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
+        }
+        if (prm.rgba) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+    }
+}
+
 // K_B2 (after K_B1 + K_B1b): one thread per (frame, pixel); a workgroup is one chunk x 32 pixels, so the GPU sees frames*P
 // threads (the fp64 log of dbMap is ~200 instructions; with one thread per (chunk, pixel) a wave would issue eight of them
 // back to back on an otherwise empty SIMD).  A state-only pass (no colour, no lines: the multi-GPU carry exchange) only
@@ -521,6 +630,17 @@ hipError_t launchDecayCarry(const DecayParams &prm, hipStream_t stream)
 bool decayColourFusedApplies(const DecayParams &prm)
 {
     return prm.rgba && !prm.lines && !prm.state && prm.C == 1 && prm.numChunks <= uint32_t(kFusedChunks);
+}
+bool decayFullFusedApplies(const DecayParams &prm)
+{
+    return (prm.lines || prm.state) && prm.C == 1 && prm.numChunks <= uint32_t(kFusedChunks) && (prm.sides == 1 || prm.sides == 2);
+}
+hipError_t launchDecayFullFused(const DecayParams &prm, hipStream_t stream)
+{
+    constexpr int PX = 4;
+    if (prm.sides == 2) hipLaunchKernelGGL((decayFullFusedKernel<PX, 2>), dim3((prm.P + PX - 1) / PX), dim3(1024), 0, stream, prm);
+    else hipLaunchKernelGGL((decayFullFusedKernel<PX, 1>), dim3((prm.P + PX - 1) / PX), dim3(1024), 0, stream, prm);
+    return hipGetLastError();
 }
 hipError_t launchDecayColourFused(const DecayParams &prm, hipStream_t stream)
 {
