@@ -155,6 +155,8 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 #define SGZ_OPT_CHANNEL_SPLIT 1u
 #define SGZ_OPT_FUSED_COLOUR  2u
 #define SGZ_OPT_FETCH_WINDOW  3u
+#define SGZ_OPT_MATRIX_RESONATOR 4u /* 1 (default): RSNT frames from rest run on the fp32 matrix cores when hop is a multiple of 1024
+                                      (resonator.hip resonateMfmaKernel); 0: the vector-ALU block form everywhere */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

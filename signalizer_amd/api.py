@@ -266,7 +266,7 @@ def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
-OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW = 1, 2, 3
+OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW, OPT_MATRIX_RESONATOR = 1, 2, 3, 4
 
 
 class Plan:

@@ -164,12 +164,15 @@ struct ResParams {
     const float4 *cpow;               // [V][P]: pole^hop as (re, im, re_lo, im_lo)
     const float2 *cpowB;              // [V][P][8]: pole^1 .. pole^8
     const float2 *cpowBLo;            // [V][P][2]: low words of pole^4, pole^8
+    const float2 *w1, *w2;            // [V][P][32]: resonateMfmaKernel's weights (null: not available for this hop)
+    const float4 *tilePow;            // [V][P]: pole^1024 (hi, lo)
     const float *gain;                // [P]
     float weights[9];                 // [V]
     float2 *state;                    // [C][2][V][P]
     float2 *local;                    // [frames][C][signals][V][P]
     float *mapped;                    // [frames][C][sides][P]
 };
-hipError_t launchResonator(const ResParams &prm, hipStream_t stream);
+// aux / evFork / evJoin: a second stream and two events (may be null: then everything runs on `stream`)
+hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin);
 
 }  // namespace sgz

@@ -506,6 +506,10 @@ static void buildResonator(Plan &p)
     p.resPow.assign(size_t(V) * P * 4, 0.f);
     p.resPowB.assign(size_t(V) * P * 8 * 2, 0.f);
     p.resPowBLo.assign(size_t(V) * P * 2 * 2, 0.f);
+    // matrix-core form of the frames from rest (resonator.hip resonateMfmaKernel): needs whole tiles of 32 blocks x 32 samples per frame
+    const bool mfma = cfg.hop % 1024u == 0;
+    p.resW1.clear(); p.resW2.clear(); p.resTile.clear();
+    if (mfma) { p.resW1.assign(size_t(V) * P * 32 * 2, 0.f); p.resW2.assign(size_t(V) * P * 32 * 2, 0.f); p.resTile.assign(size_t(V) * P * 4, 0.f); }
     p.resGain.assign(P, 0.f);
     for (uint32_t i = 0; i < P; ++i) {
         const uint32_t k = i + 1 >= P ? P - 2 : i;
@@ -534,6 +538,28 @@ static void buildResonator(Plan &p)
             p.resPow[(size_t(v) * P + i) * 4 + 1] = float(pi);
             p.resPow[(size_t(v) * P + i) * 4 + 2] = float(pr - double(float(pr)));
             p.resPow[(size_t(v) * P + i) * 4 + 3] = float(pi - double(float(pi)));
+            if (mfma) {
+                // W1[b] = pole^(31 - b): the weight of sample b of a 32-sample block;  W2[a] = pole^(32 (31 - a)): the weight of block a of a
+                // 32-block tile;  pole^1024 (hi, lo): what a tile multiplies the state by.  All from the fp32 pole in double, rounded once.
+                auto cpowd = [&](uint32_t e, double &xr, double &xi) {
+                    double br = cr, bi = ci; xr = 1.0; xi = 0.0;
+                    for (; e; e >>= 1) {
+                        if (e & 1u) { const double t = xr * br - xi * bi; xi = xr * bi + xi * br; xr = t; }
+                        const double t = br * br - bi * bi; bi = 2.0 * br * bi; br = t;
+                    }
+                };
+                for (uint32_t k = 0; k < 32; ++k) {
+                    double xr, xi;
+                    cpowd(31 - k, xr, xi);
+                    p.resW1[((size_t(v) * P + i) * 32 + k) * 2] = float(xr); p.resW1[((size_t(v) * P + i) * 32 + k) * 2 + 1] = float(xi);
+                    cpowd(32 * (31 - k), xr, xi);
+                    p.resW2[((size_t(v) * P + i) * 32 + k) * 2] = float(xr); p.resW2[((size_t(v) * P + i) * 32 + k) * 2 + 1] = float(xi);
+                }
+                double tr, ti;
+                cpowd(1024, tr, ti);
+                float *q = &p.resTile[(size_t(v) * P + i) * 4];
+                q[0] = float(tr); q[1] = float(ti); q[2] = float(tr - double(q[0])); q[3] = float(ti - double(q[1]));
+            }
             // (the fp32 pole)^1 .. ^8, each rounded once from double: what the block steps of the frames from rest multiply by -- powers
             // built up in fp32 would be a slightly different pole, and a resonator that remembers 1e5 samples notices 1e-7 of that
             double qr = cr, qi = ci;

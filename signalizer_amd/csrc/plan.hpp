@@ -111,11 +111,13 @@ struct Plan {
     std::vector<float> resPow;          // [V][P] (re, im, re_lo, im_lo): (the fp32 pole)^hop, evaluated in double, as hi + lo fp32 words -- the carry of a whole frame
     std::vector<float> resPowB;         // [V][P][8] (re, im): (the fp32 pole)^1 .. ^8, rounded once each -- the block steps of resonateKernel
     std::vector<float> resPowBLo;       // [V][P][2] (re, im): low words of pole^4 and pole^8
+    std::vector<float> resW1, resW2;    // hop % 1024 == 0: [V][P][32] (re, im): pole^(31 - b) and pole^(32 (31 - a)), the weights of resonateMfmaKernel
+    std::vector<float> resTile;         // [V][P] (re, im, re_lo, im_lo): pole^1024
     std::vector<float> resGain;         // [P]
     float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
     // sgz_plan_set_option
-    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false;
+    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optMatrixResonator = true;
 
     // device mirrors (owned)
     bool uploaded = false;
@@ -146,7 +148,7 @@ struct Plan {
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
     void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
-    float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resPowB = nullptr, *d_resPowBLo = nullptr, *d_resGain = nullptr;
+    float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resPowB = nullptr, *d_resPowBLo = nullptr, *d_resW1 = nullptr, *d_resW2 = nullptr, *d_resTile = nullptr, *d_resGain = nullptr;
     float *d_resState = nullptr;                          // [C][2][V][P] (re, im): the resonators between calls
     float *d_resLocal = nullptr; size_t resLocalCap = 0;  // [frames][C][signals][V][P] (re, im): per-frame sums from rest
     float *d_shard = nullptr; size_t shardCap = 0;        // sgz_spectrogram_render_sharded: end state, carry, gathered states, halo packs

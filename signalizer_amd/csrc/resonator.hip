@@ -8,15 +8,15 @@
 // mathematics it implements (plan.cpp buildResonator; oracle/resonator.c is the checker and states the same choices).
 //
 // MI355X form.  The recurrence  s[n] = c s[n-1] + x[n]  is sequential in time per resonator but linear, so time is cut at the frame
-// boundaries: frame f's workgroups run the recurrence over that frame's `hop` samples -- frame 0 continuing from the carried state
-// (sequential semantics: a one-frame launch, the real-time case, is the reference's recurrence step for step), frames f > 0 from
-// rest -- and a fold kernel chains them:  s_f = c^hop s_{f-1} + local_f,  c^hop evaluated in double from the fp32 pole on the host.
-// Every thread owns one axis point (all V vectors of it: V independent dependency chains); the samples are uniform across a
-// workgroup and are staged through LDS 256 at a time (one coalesced load + channel mix per thread, then broadcast reads).
-// Against the sequential fp32 recurrence the chained result differs by the rounding of one complex product per frame: ~1e-7 of the
-// state.  Bytes: 8 hop per (frame, pair) in, 8 V P per (frame, signal) through HBM between the two kernels: the path is
-// VALU-bound (per sample and axis point 7 V fp32 operations without contraction in the continuing frame, ~2.4 V fused ones in the
-// others, which take the samples eight at a time against the pole's powers).
+// boundaries: frame 0 continues the carried state sample by sample on the vector ALUs, contraction-free (sequential semantics: a
+// one-frame launch, the real-time case, is the reference's recurrence step for step); frames f > 0 start from rest and are chained
+// afterwards:  s_f = c^hop s_{f-1} + local_f  (resonatorChainKernel; c^hop in double from the fp32 pole, carried as hi + lo words).
+// The frames from rest are block sums against the pole's powers -- a matrix product: on the fp32 matrix cores when hop is a multiple
+// of 1024 (resonateMfmaKernel: 32 x 32 block sums per 32 MFMAs, then a dot product with the powers of pole^32), else on the vector
+// ALUs eight samples per step (resonateKernel's block form).  resonatorWindowKernel applies the frequency-domain window and writes
+// the planes K_B reads.  Samples are uniform across a workgroup and are staged through LDS.  Against the sequential fp32 recurrence
+// the chained result differs by the roundings of a random walk over the resonator's memory (tests/test_gpu_resonator.py states the
+// bar).  Bytes: 8 hop per (frame, pair) in, 8 V P per (frame, signal) through HBM between the kernels: the path is compute-bound.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -167,106 +167,233 @@ __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
     }
 }
 
-// chains the frames (s_f = c^hop s_{f-1} + local_f), leaves the last state for the next call and writes every frame's windowed state
-// as the planes K_B reads: getWholeWindowedState + the RSNT branch of mapToLinearSpace (:1103-1133) + the magnitude
-// mapAndTransformDFTFilters takes first (sqrt(re^2 + im^2), :1329-1331, :1361-1366)
+// ---- the frames from rest on the matrix cores.  A frame's `hop` samples are tiles of 32 blocks x 32 samples; for one tile and 32
+// resonators n the block sums are a matrix product
+//     Y[a][n] = sum_b x[32 a + b] pole_n^(31 - b),          a, b < 32
+// i.e. D (32 x 32) += A (32 x 2: two samples of every block) x B (2 x 32: the 32 resonators' weights of those two samples), sixteen
+// v_mfma_f32_32x32x2_f32 per real / imaginary part (exact fp32 fused multiply-add chains).  The tile's contribution to the state is
+//     T[n] = sum_a Y[a][n] pole_n^(32 (31 - a)),            state <- pole^1024 state + T
+// (a lane holds 16 of a resonator's 32 block sums -- rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of D's column lane & 31 -- and the lane
+// 32 further the others: each takes its partial dot product, one cross-lane add joins them).  The weights are plan tables (double,
+// rounded once); pole^1024 is carried as hi + lo words like pole^hop.  One wave = 32 resonators of one vector; a 256-thread workgroup =
+// 4 such groups sharing the tile's samples in LDS.  Per tile and wave: 32 MFMAs (2 048 issue clocks) against ~100 vector instructions.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void resonateMfmaKernel(ResParams prm, int V)
+{
+    __shared__ float xs[2 * 32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const uint32_t groups = (prm.P + 31) / 32;                       // resonator groups per vector
+    const uint32_t g = blockIdx.x * 4 + wave;                        // (vector, group) of this wave
+    const bool liveWave = g < uint32_t(V) * groups;
+    const uint32_t v = liveWave ? g / groups : 0u;
+    const uint32_t i = liveWave ? (g - v * groups) * 32 + (lane & 31) : 0u;
+    const bool live = liveWave && i < prm.P;
+    const uint32_t unit = blockIdx.y;                                // (frame - 1, pair, signal)
+    const int signal = int(unit % uint32_t(prm.signals));
+    const uint32_t pair = (unit / uint32_t(prm.signals)) % prm.C;
+    const long frame = 1 + long(unit / (uint32_t(prm.signals) * prm.C));
+    const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
+    const float *R = L + prm.chStride;
+    const size_t at = (size_t(v) * prm.P + (live ? i : 0u));
+    // this lane's weights: samples 2 s + h of a block (B operand of step s), blocks (r & 3) + 8 (r >> 2) + 4 h of a tile
+    float w1r[16], w1i[16], w2r[16], w2i[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float2 q = live ? prm.w1[at * 32 + 2 * s + h] : float2{0.f, 0.f};
+        w1r[s] = q.x; w1i[s] = q.y;
+        const int a = (s & 3) + 8 * (s >> 2) + 4 * h;
+        const float2 u = live ? prm.w2[at * 32 + a] : float2{0.f, 0.f};
+        w2r[s] = u.x; w2i[s] = u.y;
+    }
+    const float4 tp = live ? prm.tilePow[at] : float4{0.f, 0.f, 0.f, 0.f};
+    float sre = 0.f, sim = 0.f;
+    // the tile's samples: fetched one tile ahead into registers, parked in one of two LDS buffers (one barrier per tile)
+    float nx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; nx[k] = resMix(prm.mode, signal, L[e], R[e]); }
+    int buf = 0;
+    for (uint32_t t0 = 0; t0 < prm.hop; t0 += 1024, buf ^= 1) {
+        float *xb = xs + buf * (32 * 33);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; xb[(e >> 5) * 33 + (e & 31)] = nx[k]; }
+        __syncthreads();                                             // (the other buffer was read two tiles ago: every wave is past it)
+        if (t0 + 1024 < prm.hop) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const uint32_t e = t0 + 1024 + uint32_t(tid) + 256u * k; nx[k] = resMix(prm.mode, signal, L[e], R[e]); }
+        }
+        f32x16 dre = {0}, dim = {0};
+        const float *arow = xb + (lane & 31) * 33 + h;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a = arow[2 * s];
+            dre = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1r[s], dre, 0, 0, 0);
+            dim = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1i[s], dim, 0, 0, 0);
+        }
+        float pr = 0.f, pi = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pr = __builtin_fmaf(dre[r], w2r[r], __builtin_fmaf(-dim[r], w2i[r], pr));
+            pi = __builtin_fmaf(dre[r], w2i[r], __builtin_fmaf(dim[r], w2r[r], pi));
+        }
+        pr += __shfl_xor(pr, 32);
+        pi += __shfl_xor(pi, 32);
+        const float nre = __builtin_fmaf(sre, tp.x, __builtin_fmaf(-sim, tp.y, __builtin_fmaf(sre, tp.z, -sim * tp.w))) + pr;
+        const float nim = __builtin_fmaf(sre, tp.y, __builtin_fmaf(sim, tp.x, __builtin_fmaf(sre, tp.w, sim * tp.z))) + pi;
+        sre = nre; sim = nim;
+    }
+    if (live && h == 0)
+        prm.local[((size_t(frame) * prm.C + pair) * size_t(prm.signals) + size_t(signal)) * V * prm.P + size_t(v) * prm.P + i] = float2{sre, sim};
+}
+
+// chains the frames: s_f = c^hop s_{f-1} + local_f, in place (local_f becomes the state after frame f), and leaves the last state for the
+// next call.  One thread per (pair, signal, vector, axis point): the only sequential part of a render, `frames` dependent complex
+// multiply-adds per thread; the loads do not depend on the chain and run four frames ahead.
 template <int V>
-__global__ __launch_bounds__(kResBlock) void resonatorFoldKernel(ResParams prm)
+__global__ __launch_bounds__(kResBlock) void resonatorChainKernel(ResParams prm)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t unit = blockIdx.y;                              // (pair, signal, vector)
+    const uint32_t v = unit % uint32_t(V), sg = (unit / uint32_t(V)) % uint32_t(prm.signals), pair = unit / (uint32_t(V) * uint32_t(prm.signals));
+    const float4 c = prm.cpow[size_t(v) * prm.P + i];              // c^hop = hi + lo (plan.cpp): the low word keeps the chain from drifting off the sample-by-sample recurrence
+    const size_t stride = size_t(prm.C) * size_t(prm.signals) * V * prm.P;      // one frame of `local`
+    float2 *loc = prm.local + ((size_t(pair) * size_t(prm.signals) + sg) * V + v) * prm.P + i;
+    float2 s = loc[0];                                             // frame 0 already continued from the carried state
+    long f = 1;
+    for (; f + 4 <= prm.frames; f += 4) {
+        float2 l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l[k] = loc[size_t(f + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + l[k].x;
+            const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + l[k].y;
+            s = float2{nre, nim};
+            loc[size_t(f + k) * stride] = s;
+        }
+    }
+    for (; f < prm.frames; ++f) {
+        const float2 l = loc[size_t(f) * stride];
+        const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + l.x;
+        const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + l.y;
+        s = float2{nre, nim};
+        loc[size_t(f) * stride] = s;
+    }
+    prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i] = s;
+}
+
+// every frame's windowed state as the planes K_B reads: getWholeWindowedState + the RSNT branch of mapToLinearSpace (:1103-1133) + the
+// magnitude mapAndTransformDFTFilters takes first (sqrt(re^2 + im^2), :1329-1331, :1361-1366).  One thread per (frame, pair, axis point).
+template <int V>
+__global__ __launch_bounds__(kResBlock) void resonatorWindowKernel(ResParams prm)
 {
 #pragma clang fp contract(off)
     const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
     if (i >= prm.P) return;
-    const uint32_t pair = blockIdx.y;
+    const uint32_t pair = blockIdx.y % prm.C;
+    const long f = long(blockIdx.y / prm.C);
     constexpr int K = (V + 1) / 2;
     const int S = prm.signals;
-    float pr[V], pi[V], qr[V], qi[V], w[V];
-    float sre[2][V], sim[2][V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-        const float4 c = prm.cpow[size_t(v) * prm.P + i];
-        pr[v] = c.x; pi[v] = c.y; qr[v] = c.z; qi[v] = c.w; w[v] = prm.weights[v];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { sre[s][v] = 0.f; sim[s][v] = 0.f; }
-    }
     const float gain = prm.gain[i];
-    for (long f = 0; f < prm.frames; ++f) {
-        float ore[2] = {0.f, 0.f}, oim[2] = {0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s >= S) break;
-            const float2 *loc = prm.local + ((size_t(f) * prm.C + pair) * size_t(S) + size_t(s)) * V * prm.P + i;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const float2 l = loc[size_t(v) * prm.P];
-                if (f == 0) { sre[s][v] = l.x; sim[s][v] = l.y; }            // frame 0 already continued from the carried state
-                else {
-                    // c^hop = hi + lo (plan.cpp): the low word keeps the chain from drifting off the sample-by-sample recurrence
-                    const float nre = __builtin_fmaf(sre[s][v], pr[v], __builtin_fmaf(-sim[s][v], pi[v], __builtin_fmaf(sre[s][v], qr[v], -sim[s][v] * qi[v]))) + l.x;
-                    const float nim = __builtin_fmaf(sre[s][v], pi[v], __builtin_fmaf(sim[s][v], pr[v], __builtin_fmaf(sre[s][v], qi[v], sim[s][v] * qr[v]))) + l.y;
-                    sre[s][v] = nre; sim[s][v] = nim;
-                }
-            }
-            // frequency-domain window: centre first, then -m, +m outwards (oracle/resonator.c sgzo_resonator_windowed_state)
-            float re = w[K - 1] * sre[s][K - 1], im = w[K - 1] * sim[s][K - 1];
-#pragma unroll
-            for (int m = 1; m < K; ++m) {
-                re = re + w[K - 1 - m] * sre[s][K - 1 - m];
-                im = im + w[K - 1 - m] * sim[s][K - 1 - m];
-                re = re + w[K - 1 + m] * sre[s][K - 1 + m];
-                im = im + w[K - 1 + m] * sim[s][K - 1 + m];
-            }
-            ore[s] = re * gain; oim[s] = im * gain;
-        }
-        float *out = prm.mapped + (size_t(f) * prm.C + pair) * size_t(prm.sides) * prm.P + i;
-        if (prm.mode == SGZ_CH_PHASE) {                                       // :1111-1127
-            const float sr = ore[0] + ore[1], si = oim[0] + oim[1];
-            const float cancellation = sqrtf(sr * sr + si * si);
-            const float mid = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]) + sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
-            out[0] = mid;
-            out[prm.P] = 1.0f - (mid > 0 ? cancellation / mid : 0.0f);
-        } else {
-            out[0] = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]);
-            if (prm.sides == 2) out[prm.P] = sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
-        }
-    }
+    float ore[2] = {0.f, 0.f}, oim[2] = {0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if (s >= S) break;
+        const float2 *loc = prm.local + ((size_t(f) * prm.C + pair) * size_t(S) + size_t(s)) * V * prm.P + i;
+        float sre[V], sim[V];
 #pragma unroll
-        for (int v = 0; v < V; ++v) prm.state[(size_t(pair) * 2 + size_t(s)) * V * prm.P + size_t(v) * prm.P + i] = float2{sre[s][v], sim[s][v]};
+        for (int v = 0; v < V; ++v) { const float2 z = loc[size_t(v) * prm.P]; sre[v] = z.x; sim[v] = z.y; }
+        // frequency-domain window: centre first, then -m, +m outwards (oracle/resonator.c sgzo_resonator_windowed_state)
+        float re = prm.weights[K - 1] * sre[K - 1], im = prm.weights[K - 1] * sim[K - 1];
+#pragma unroll
+        for (int m = 1; m < K; ++m) {
+            re = re + prm.weights[K - 1 - m] * sre[K - 1 - m];
+            im = im + prm.weights[K - 1 - m] * sim[K - 1 - m];
+            re = re + prm.weights[K - 1 + m] * sre[K - 1 + m];
+            im = im + prm.weights[K - 1 + m] * sim[K - 1 + m];
+        }
+        ore[s] = re * gain; oim[s] = im * gain;
+    }
+    float *out = prm.mapped + (size_t(f) * prm.C + pair) * size_t(prm.sides) * prm.P + i;
+    if (prm.mode == SGZ_CH_PHASE) {                                       // :1111-1127
+        const float sr = ore[0] + ore[1], si = oim[0] + oim[1];
+        const float cancellation = sqrtf(sr * sr + si * si);
+        const float mid = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]) + sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
+        out[0] = mid;
+        out[prm.P] = 1.0f - (mid > 0 ? cancellation / mid : 0.0f);
+    } else {
+        out[0] = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]);
+        if (prm.sides == 2) out[prm.P] = sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
     }
 }
 
 template <int V>
-hipError_t launchV(const ResParams &prm, hipStream_t stream)
+hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin)
 {
     const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
-    // grid.y is limited to 65535: long renders go in slabs of frames (the kernel reads the frame from blockIdx.y plus the slab's base)
+    // frames from rest on the matrix cores when the plan has the weights (hop a multiple of 1024); frame 0, which continues the carried
+    // state sample by sample, always on the vector ALUs -- a few workgroups walking `hop` dependent steps: on its own stream beside the
+    // matrix kernel, or it would be a quarter of the render
+    const bool matrix = prm.w1 && prm.frames > 1 && prm.hop % 1024u == 0;
+    const long valuFrames = matrix ? 1 : prm.frames;
+    hipStream_t s0 = stream;
+    if (matrix && aux) {
+        if (hipError_t e = hipEventRecord(evFork, stream); e != hipSuccess) return e;
+        if (hipError_t e = hipStreamWaitEvent(aux, evFork, 0); e != hipSuccess) return e;
+        s0 = aux;
+    }
+    // grid.y is limited to 65535: long renders go in slabs of frames
     const long perSlab = std::max<long>(1, long(65535u / (prm.C * uint32_t(prm.signals))));
-    for (long f0 = 0; f0 < prm.frames; f0 += perSlab) {
+    for (long f0 = 0; f0 < valuFrames; f0 += perSlab) {
         ResParams q = prm;
-        const long nf = std::min(perSlab, prm.frames - f0);
+        const long nf = std::min(perSlab, valuFrames - f0);
         q.frames = nf;
         q.planar = prm.planar + size_t(f0) * prm.hop;
         q.local = prm.local + size_t(f0) * prm.C * size_t(prm.signals) * V * prm.P;
         q.firstContinues = f0 == 0;
-        hipLaunchKernelGGL(resonateKernel<V>, dim3(tiles, unsigned(nf * prm.C * prm.signals)), dim3(kResBlock), 0, stream, q);
+        hipLaunchKernelGGL(resonateKernel<V>, dim3(tiles, unsigned(nf * prm.C * prm.signals)), dim3(kResBlock), 0, s0, q);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(resonatorFoldKernel<V>, dim3(tiles, prm.C), dim3(kResBlock), 0, stream, prm);
-    return hipGetLastError();
+    if (matrix) {
+        const unsigned groups = (prm.P + 31) / 32 * unsigned(V);
+        for (long f0 = 1; f0 < prm.frames; f0 += perSlab) {
+            ResParams q = prm;
+            const long nf = std::min(perSlab, prm.frames - f0);
+            q.planar = prm.planar + size_t(f0 - 1) * prm.hop;           // (the kernel counts its frames from 1)
+            q.local = prm.local + size_t(f0 - 1) * prm.C * size_t(prm.signals) * V * prm.P;
+            hipLaunchKernelGGL(resonateMfmaKernel<0>, dim3((groups + 3) / 4, unsigned(nf * prm.C * prm.signals)), dim3(256), 0, stream, q, V);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        }
+        if (s0 != stream) {
+            if (hipError_t e = hipEventRecord(evJoin, s0); e != hipSuccess) return e;
+            if (hipError_t e = hipStreamWaitEvent(stream, evJoin, 0); e != hipSuccess) return e;
+        }
+    }
+    hipLaunchKernelGGL(resonatorChainKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    for (long f0 = 0; f0 < prm.frames; f0 += long(65535u / prm.C)) {
+        ResParams q = prm;
+        const long nf = std::min<long>(long(65535u / prm.C), prm.frames - f0);
+        q.local = prm.local + size_t(f0) * prm.C * size_t(prm.signals) * V * prm.P;
+        q.mapped = prm.mapped + size_t(f0) * prm.C * size_t(prm.sides) * prm.P;
+        hipLaunchKernelGGL(resonatorWindowKernel<V>, dim3(tiles, unsigned(nf) * prm.C), dim3(kResBlock), 0, stream, q);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace
 
-hipError_t launchResonator(const ResParams &prm, hipStream_t stream)
+hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin)
 {
     switch (prm.V) {
-    case 1: return launchV<1>(prm, stream);
-    case 3: return launchV<3>(prm, stream);
-    case 5: return launchV<5>(prm, stream);
-    case 7: return launchV<7>(prm, stream);
-    case 9: return launchV<9>(prm, stream);
+    case 1: return launchV<1>(prm, stream, aux, evFork, evJoin);
+    case 3: return launchV<3>(prm, stream, aux, evFork, evJoin);
+    case 5: return launchV<5>(prm, stream, aux, evFork, evJoin);
+    case 7: return launchV<7>(prm, stream, aux, evFork, evJoin);
+    case 9: return launchV<9>(prm, stream, aux, evFork, evJoin);
     default: return hipErrorInvalidValue;
     }
 }

@@ -20,7 +20,10 @@ def main():
         cfg = config.spectrum_config(algorithm=config.ALGO_RSNT, **over)
         x = synth.gen(config.CFG2_SEED, 48000, int(config.CFG2_SECONDS * 48000), 2)
         xs = torch.from_numpy(x).to(dev)
-        plan = api.Plan(cfg).upload()
+        plan = api.Plan(cfg)
+        if "--valu" in sys.argv:
+            plan.set_option(api.OPT_MATRIX_RESONATOR, 0)
+        plan.upload()
         F = plan.num_frames(x.shape[1])
         rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
         V = plan.resonator()[0].shape[0]

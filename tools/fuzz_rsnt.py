@@ -24,7 +24,7 @@ worst = 0.0
 for case in range(cases):
     mode = int(rng.integers(0, 8))
     d = cf.spectrum_config(algorithm=cf.ALGO_RSNT, channel_mode=mode, window_type=int(rng.integers(0, 13)),
-                           window_size=int(rng.choice([512, 4096, 32768])), hop=int(rng.integers(40, 3000)),
+                           window_size=int(rng.choice([512, 4096, 32768])), hop=int(rng.choice([int(rng.integers(40, 3000)), 1024, 2048, 3072])),   # (multiples of 1024: the matrix-core kernel)
                            axis_points=int(rng.integers(2, 1500)), num_pairs=int(rng.integers(1, 4)), free_q=int(rng.integers(0, 2)),
                            view_scaling=int(rng.integers(0, 2)), sample_rate=float(rng.choice([44100.0, 48000.0, 96000.0])),
                            view_left=float(rng.uniform(0, 0.3)), view_right=float(rng.uniform(0.5, 1.0)),
