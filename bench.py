@@ -300,9 +300,9 @@ def rsnt_extra(dev, x_host) -> dict:
     flops = 8.0 * F * cfg["hop"] * 2 * V * plan.P
     return {"metric": "RSNT (resonator bank) spectrogram frames/sec, stereo 48 kHz, 1024 axis points, Hann (3 vectors), one frame per 8192 samples",
             "value": F / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames": F, "realtime_factor": 60.0 / (ms * 1e-3),
-            "kernel": "resonateKernel<3> + resonatorFoldKernel<3> + K_B", "fp32_tflops": flops / (ms * 1e-3) / 1e12,
-            "note": "VALU-bound; fp32_tflops counts the recurrence's 8 flops per sample, resonator, vector and signal (the kernel takes eight "
-                    "samples per step against the pole's powers and executes ~60 % of them); 157.3 TFLOP/s is the fp32 vector peak"}
+            "kernel": "resonateMfmaKernel (fp32 MFMA block sums) + resonateKernel<3> (frame 0) + resonatorChainKernel<3> + resonatorWindowKernel<3> + K_B", "fp32_tflops": flops / (ms * 1e-3) / 1e12,
+            "note": "compute-bound; fp32_tflops counts the recurrence's 8 flops per sample, resonator, vector and signal (the matrix kernel "
+                    "executes 4 of them as v_mfma_f32_32x32x2_f32 block sums); 157.3 TFLOP/s is the fp32 MFMA = vector peak"}
 
 
 def main() -> None:
