@@ -420,7 +420,8 @@ sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t cha
  * trigger mode Spectral (sgz_scope_analyse = calculateFundamentalPeriod + calculateTriggeringOffset,
  * OscilloscopeDSP.inl:62-308, on the device ring) and the per-sample frequency colouring of audioProcessing (:445-647: 3-band
  * Linkwitz-Riley split -> smoothed band energies -> RGB, kept in colour rings beside the audio rings and swapped with them).
- * Not built (SGZ_EUNSUPPORTED): trigger modes Window / EnvelopeHold, interpolation None / Rectangular. */
+ * The remaining modes too: EnvelopeHold (PeakHoldProcessor, StreamPreprocessing.h:270-310, inside the ingest kernel), Window
+ * (sgz_scope_set_transport), customTrigger, and the None / Rectangular interpolations of drawWavePlot. */
 typedef struct sgz_scope_config {
     double   sample_rate;
     double   window_size;        /* state.effectiveWindowSize in samples (fractions allowed)                     */

@@ -215,15 +215,18 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     r.mapped = d_mapped;
     // frame 0's sample-by-sample walk runs beside the matrix kernel on the plan's second stream (the one the sharded render uses for
     // its halo: RSNT renders are single device)
-    if (r.w1 && frames > 1 && !p.shardStream) {
-        hipStream_t cs; hipEvent_t e0, e1;
-        SGZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        SGZ_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        SGZ_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        p.shardStream = cs; p.shardEv[0] = e0; p.shardEv[1] = e1;
-    }
+    if (r.w1 && frames > 1)
+        if (sgz_status s2 = ensureSecondStream(p); s2 != SGZ_OK) return s2;
     SGZ_HIP(launchResonator(r, stream, static_cast<hipStream_t>(p.shardStream), static_cast<hipEvent_t>(p.shardEv[0]),
                             static_cast<hipEvent_t>(p.shardEv[1])));
+    return SGZ_OK;
+}
+
+sgz_status ensureSecondStream(Plan &p)
+{
+    if (!p.shardStream) { hipStream_t cs; SGZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking)); p.shardStream = cs; }
+    for (void *&e : p.shardEv)
+        if (!e) { hipEvent_t ne; SGZ_HIP(hipEventCreateWithFlags(&ne, hipEventDisableTiming)); e = ne; }
     return SGZ_OK;
 }
 

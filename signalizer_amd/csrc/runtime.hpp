@@ -23,6 +23,8 @@ int numCUs();
 // K_A over `frames` frames (ideal STFT framing from d_planar); any of mapped/binsOut may be null
 // deferLate: the caller's next call is runDecayColour on the same d_mapped with only an image wanted -- a channel-split launch may then
 // leave its late pixels (late_fix.hpp) to K_B's fused kernel instead of a launch of its own (runDecayColour checks Plan::lateDeferred)
+// the plan's second stream and the fork / join events that tie it to the caller's (created on first use, destroyed with the plan)
+sgz_status ensureSecondStream(Plan &p);
 sgz_status resetResonator(Plan &p, hipStream_t stream);
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                    float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock = nullptr,

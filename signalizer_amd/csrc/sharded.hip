@@ -195,13 +195,7 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
     float *d_end = p.d_shard, *d_carry = d_end + stateN, *d_all = d_carry + stateN;
     float *d_send = d_all + stateN * world, *d_recv = d_send + size_t(nch) * haloOut;
     // the halo's own stream and the two events that tie it to the caller's
-    if (!p.shardStream) {
-        hipStream_t cs; hipEvent_t e0, e1;
-        SGZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        SGZ_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        SGZ_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        p.shardStream = cs; p.shardEv[0] = e0; p.shardEv[1] = e1;
-    }
+    if (sgz_status s2 = ensureSecondStream(p); s2 != SGZ_OK) return bail(s2);
     hipStream_t cs = static_cast<hipStream_t>(p.shardStream);
     hipEvent_t evFork = static_cast<hipEvent_t>(p.shardEv[0]), evJoin = static_cast<hipEvent_t>(p.shardEv[1]);
     const bool wantRecv = haloIn && rank + 1 < world;
