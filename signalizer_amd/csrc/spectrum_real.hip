@@ -30,15 +30,25 @@
 
 #include "chunk_map.hpp"
 #include "fft_scalar.hpp"
-#include "fft_scalar.hpp"
 
 #ifdef SGZ_DEBUG
 #define RCLK(slot)                                                                                                     \
     do {                                                                                                               \
         if (prm.phaseClock && (tid & 63) == 0 && unit == long(prm.clkUnit)) prm.phaseClock[16 * (tid >> 6) + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
+// clkUnit == 0xffff: instead, every workgroup leaves (start, end) in the 100 MHz wall clock all CUs share, HW_ID and XCC_ID behind
+// the 256 phase slots: the launch's schedule (tools/unit_trace.py)
+#define RTRACE(which)                                                                                                  \
+    do {                                                                                                               \
+        if (prm.phaseClock && prm.clkUnit == 0xffffu && tid == 0) {                                                    \
+            unsigned long long *t = prm.phaseClock + 256 + 4 * unit;                                                   \
+            t[which] = __builtin_amdgcn_s_memrealtime();                                                               \
+            if (which == 0) { t[2] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); t[3] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); } \
+        }                                                                                                              \
+    } while (0)
 #else
 #define RCLK(slot) do { } while (0)
+#define RTRACE(which) do { } while (0)
 #endif
 
 namespace sgz {
@@ -113,6 +123,7 @@ __device__ __forceinline__ void realMapSettle(const RealParams &prm, float *lds,
     RCLK(8);
     mapper.run(tb, at, lds, re, ce, prm.invSize, tid);
     RCLK(9);
+    RTRACE(1);
     if (MONO) {
         // the pixels whose tap windows leave the magnitudes (wrap below bin 0: csf[N - j] = conj X[j], csf[N] = 0; or reach csf[N/2 ..]):
         // complex sums in the reference's order (complex_dc.hpp), from entries written before the last barrier; the mapping skipped them
@@ -187,6 +198,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ChunkMap<T> mapper;
 
     RCLK(0);
+    RTRACE(0);
     if constexpr (LR1 >= 4) {
         // the pass-2 twiddle table -> LDS (8 KB behind the exchange areas; the map's maxima take the place later)
         if (tid < 512) reinterpret_cast<float4 *>(lds + XFLOATS)[tid] = prm.tw2Full[tid];
