@@ -192,6 +192,15 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
 //   2. 4 threads fold the chunk-end states with the same sequential multiplies as decayCarryKernel;
 //   3. ALL threads share the frames x 4 emissions (replay <= 8 steps from the LDS magnitudes on the folded carry-in, dB map, colour).
 // Nothing goes through HBM between the steps and there is one launch instead of two.
+// Workgroup -> group of PX adjacent pixels.  Workgroup b runs on XCD b % 8 (observed; a speed assumption only): XCD x takes the x-th
+// eighth of the pixels, so that the 16-byte pieces its workgroups read of every magnitude row (and write of every image row) add up to
+// whole cache lines inside ONE L2 -- with group = b, the eight workgroups that share a line sit on eight XCDs and each fetches it.
+__device__ __forceinline__ uint32_t pixelGroup()
+{
+    const uint32_t b = blockIdx.x, n = gridDim.x;
+    return (n & 7u) == 0 ? (b & 7u) * (n >> 3) + (b >> 3) : b;
+}
+
 template <int PX>
 __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams prm)
 {
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     const uint32_t items = uint32_t(prm.frames) * PX;
     for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX; e += 1024) {
         const uint32_t px = e % PX, f = e / PX;
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         float m = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] * prm.magScale : 0.f;   // (x 1 is exact)
         if (prm.hasLate && e < items && pixel >= prm.late.fixFrom0 && pixel < prm.P)                            // (late_fix.hpp)
             m = lateNyquistPixel(prm.late, lateNyquistBin(prm.late, long(f)), lateBestSquare(prm.late, long(f), 0, pixel), m);
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     // 1b. zero-carry scan of every chunk
     if (tid < kFusedChunks * PX) {
         const uint32_t px = tid % PX, chunk = tid / PX;
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         const long f0 = long(chunk) * kMaxChunk;
         const int len = chunk < prm.numChunks ? int(min(long(kMaxChunk), prm.frames - f0)) : 0;
         float a = (pixel < prm.P && chunk == 0 && prm.stateIn) ? prm.stateIn[size_t(pixel) * 2] : 0.f;
@@ -251,7 +260,7 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     __syncthreads();
     for (uint32_t e = tid; e < items; e += 1024) {
         const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         if (pixel >= prm.P) continue;
         float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[size_t(pixel) * 2] : 0.f;
         float cr = chunk > 0 ? carryS[chunk - 1][px] : 0.f;    // exact state at the end of the previous chunk
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     // 1a. magnitudes of both sides, carry-in state
     for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX * SIDES; e += 1024) {
         const uint32_t px = e % PX, side = (e / PX) % SIDES, f = e / (PX * SIDES);
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         const bool in = f < uint32_t(prm.frames) && pixel < prm.P;
         float m = in ? prm.mapped[size_t(f) * perFrame + size_t(side) * prm.P + pixel] * prm.magScale : 0.f;
         if (prm.hasLate && in && pixel >= (side ? prm.late.fixFrom1 : prm.late.fixFrom0))
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     }
     if (tid < NCMB * PX) {
         const uint32_t px = tid % PX, m = tid / PX, side = m / G, k = m % G;
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         stIn[m][px] = (prm.stateIn && pixel < prm.P) ? prm.stateIn[((size_t(k)) * prm.P + pixel) * 2 + side] : 0.f;
     }
     __syncthreads();
@@ -343,39 +352,38 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     }
     __syncthreads();
     // 3. emissions
-    for (uint32_t e = tid; e < items; e += 1024) {
+    // one item per (graph, frame, pixel): 2 x 348 x 4 items on 1024 threads are three rounds of one graph each instead of two rounds of both
+    for (uint32_t e0 = tid; e0 < items * G; e0 += 1024) {
+        const uint32_t k = e0 / items, e = e0 - k * items;
         const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
-        const uint32_t pixel = blockIdx.x * PX + px;
+        const uint32_t pixel = pixelGroup() * PX + px;
         if (pixel >= prm.P) continue;
         const float slope = prm.slope[pixel];
         float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
+        const float pole = prm.sc.pole[k];
+        float res[2] = {0.f, 0.f};                              // (results[i].phase = 0 in the one-channel modes, :1347)
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const float pole = prm.sc.pole[k];
-            float res[2] = {0.f, 0.f};                          // (results[i].phase = 0 in the one-channel modes, :1347)
+        for (int side = 0; side < SIDES; ++side) {
+            const uint32_t m = side * G + k;
+            float a = chunk == 0 ? stIn[m][px] : 0.f;
+            float cr = chunk > 0 ? carryS[chunk - 1][m][px] : 0.f;
 #pragma unroll
-            for (int side = 0; side < SIDES; ++side) {
-                const int m = side * G + k;
-                float a = chunk == 0 ? stIn[m][px] : 0.f;
-                float cr = chunk > 0 ? carryS[chunk - 1][m][px] : 0.f;
-#pragma unroll
-                for (int i = 0; i < kMaxChunk; ++i)
-                    if (uint32_t(i) <= t) {
-                        const float v = magS[chunk * kMaxChunk + i][side][px];
-                        a = a * pole;
-                        if (v > a) a = v;
-                        cr = cr * pole;
-                    }
-                const float st = a > cr ? a : cr;
-                if (prm.state && long(f) == prm.frames - 1) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st;
-                const bool colour = side == 0 && k == 0 && prm.rgba;
-                if (!colour && !prm.lines) continue;
-                res[side] = dbMap(slope, st, prm.sc);
-                if (colour) blendColour(cb, res[side], prm.colourTables, prm.sc);
-            }
-            if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
+            for (int i = 0; i < kMaxChunk; ++i)
+                if (uint32_t(i) <= t) {
+                    const float v = magS[chunk * kMaxChunk + i][side][px];
+                    a = a * pole;
+                    if (v > a) a = v;
+                    cr = cr * pole;
+                }
+            const float st = a > cr ? a : cr;
+            if (prm.state && long(f) == prm.frames - 1) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st;
+            const bool colour = side == 0 && k == 0 && prm.rgba;
+            if (!colour && !prm.lines) continue;
+            res[side] = dbMap(slope, st, prm.sc);
+            if (colour) blendColour(cb, res[side], prm.colourTables, prm.sc);
         }
-        if (prm.rgba) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+        if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
+        if (prm.rgba && k == 0) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
     }
 }
 

@@ -42,4 +42,5 @@ def main():
         out[name] = dict(ka_us=round(m, 2), ka_min_us=round(mn, 2), frac=round(byts / (m * 1e-6) / 8e12, 4), step_us=round(fm, 2),
                          per_task_ns=round(m * 1e3 / (F * pairs), 1))
     print(out)
-main()
+if __name__ == "__main__":
+    main()
