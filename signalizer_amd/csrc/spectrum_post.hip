@@ -192,6 +192,18 @@ __global__ void __launch_bounds__(1024) decayLocalCarryKernel(const DecayParams 
 //   2. 4 threads fold the chunk-end states with the same sequential multiplies as decayCarryKernel;
 //   3. ALL threads share the frames x 4 emissions (replay <= 8 steps from the LDS magnitudes on the folded carry-in, dB map, colour).
 // Nothing goes through HBM between the steps and there is one launch instead of two.
+// The fused kernels' fold publishes how many chunk carries are final; the emitting waves wait for the one they need.
+#define SGZ_PUBLISH(n) asm volatile("ds_write_b32 %0, %1" :: "v"(progressAddr), "v"(uint32_t(n)) : "memory")
+__device__ __forceinline__ void awaitCarries(uint32_t progressAddr, uint32_t chunk)
+{
+    for (;;) {
+        uint32_t seen;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(progressAddr) : "memory");
+        if (seen >= chunk) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Workgroup -> group of PX adjacent pixels.  Workgroup b runs on XCD b % 8 (observed; a speed assumption only): XCD x takes the x-th
 // eighth of the pixels, so that the 16-byte pieces its workgroups read of every magnitude row (and write of every image row) add up to
 // whole cache lines inside ONE L2 -- with group = b, the eight workgroups that share a line sit on eight XCDs and each fetches it.
@@ -207,6 +219,9 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     __shared__ float aggS[kFusedChunks][PX];                    // chunk-end states of the zero-carry scans
     __shared__ float carryS[kFusedChunks][PX];                  // exact state at the end of chunk d (after the fold)
     __shared__ float magS[kFusedChunks * kMaxChunk][PX];
+    __shared__ uint32_t progress;                               // carryS[d] is final for every d < progress
+    const uint32_t progressAddr = uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)&progress));
+    if (threadIdx.x == 0) progress = 0;
     const uint32_t tid = threadIdx.x;
     const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
     const float pole = prm.sc.pole[0];
@@ -241,27 +256,42 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     // 2. the fold: sequential by nature (8 dependent multiplies per chunk); the aggregates are read 16 at a time so that the chain
     //    never waits for LDS
     if (tid < PX) {
+        // (whole batches without a branch per chunk: this chain is what the kernel waits for)
+        // The other waves emit chunk c as soon as carryS[c - 1] is published: the emissions run beside the fold instead of behind it
+        // (-1.1 us).  LDS operations of one wave are carried out in order, so a reader that sees the counter sees the carries stored
+        // before it.
         float c = aggS[0][tid];
         carryS[0][tid] = c;
-        for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
-            float v[16];
+        SGZ_PUBLISH(1);
+        uint32_t d = 1;
+        for (; d + 8 <= prm.numChunks; d += 8) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = aggS[min(d0 + j, uint32_t(kFusedChunks - 1))][tid];
+            for (int j = 0; j < 8; ++j) v[j] = aggS[d + j][tid];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (d0 + j < prm.numChunks) {
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
-                    for (int i = 0; i < kMaxChunk; ++i) c = c * pole;  // every chunk before the last is full
-                    if (v[j] > c) c = v[j];
-                    carryS[d0 + j][tid] = c;
-                }
+                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;        // every chunk before the last is full
+                if (v[j] > c) c = v[j];
+                carryS[d + j][tid] = c;
+                if (j & 1) SGZ_PUBLISH(d + j + 1);
+            }
+        }
+        for (; d < prm.numChunks; ++d) {
+            const float v = aggS[d][tid];
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) c = c * pole;
+            if (v > c) c = v;
+            carryS[d][tid] = c;
+            SGZ_PUBLISH(d + 1);
         }
     }
-    __syncthreads();
-    for (uint32_t e = tid; e < items; e += 1024) {
+    if (tid < 64) return;                                       // the fold's wave is done
+    for (uint32_t e = tid - 64; e < items; e += 960) {
         const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
         const uint32_t pixel = pixelGroup() * PX + px;
         if (pixel >= prm.P) continue;
+        awaitCarries(progressAddr, chunk);
         float a = (chunk == 0 && prm.stateIn) ? prm.stateIn[size_t(pixel) * 2] : 0.f;
         float cr = chunk > 0 ? carryS[chunk - 1][px] : 0.f;    // exact state at the end of the previous chunk
 #pragma unroll
@@ -293,6 +323,9 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     __shared__ float carryS[kFusedChunks][NCMB][PX];
     __shared__ float magS[kFusedChunks * kMaxChunk][SIDES][PX];
     __shared__ float stIn[NCMB][PX];
+    __shared__ uint32_t progress;                               // carryS[d] is final for every d < progress (all combinations)
+    const uint32_t progressAddr = uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)&progress));
+    if (threadIdx.x == 0) progress = 0;
     const uint32_t tid = threadIdx.x;
     const size_t perFrame = size_t(SIDES) * prm.P;              // (one pair)
     const uint32_t items = uint32_t(prm.frames) * PX;
@@ -336,28 +369,39 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
         const float pole = prm.sc.pole[m % G];
         float c = aggS[0][m][px];
         carryS[0][m][px] = c;
-        for (uint32_t d0 = 1; d0 < prm.numChunks; d0 += 16) {
-            float v[16];
+        SGZ_PUBLISH(1);
+        uint32_t d = 1;
+        for (; d + 8 <= prm.numChunks; d += 8) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = aggS[min(d0 + j, uint32_t(kFusedChunks - 1))][m][px];
+            for (int j = 0; j < 8; ++j) v[j] = aggS[d + j][m][px];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (d0 + j < prm.numChunks) {
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
-                    for (int i = 0; i < kMaxChunk; ++i) c = c * pole;  // every chunk before the last is full
-                    if (v[j] > c) c = v[j];
-                    carryS[d0 + j][m][px] = c;
-                }
+                for (int i = 0; i < kMaxChunk; ++i) c = c * pole;      // every chunk before the last is full
+                if (v[j] > c) c = v[j];
+                carryS[d + j][m][px] = c;
+                if (j & 1) SGZ_PUBLISH(d + j + 1);
+            }
+        }
+        for (; d < prm.numChunks; ++d) {
+            const float v = aggS[d][m][px];
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i) c = c * pole;
+            if (v > c) c = v;
+            carryS[d][m][px] = c;
+            SGZ_PUBLISH(d + 1);
         }
     }
-    __syncthreads();
+    if (tid < 64) return;                                       // (the fold's wave; the others emit beside it)
     // 3. emissions
     // one item per (graph, frame, pixel): 2 x 348 x 4 items on 1024 threads are three rounds of one graph each instead of two rounds of both
-    for (uint32_t e0 = tid; e0 < items * G; e0 += 1024) {
+    for (uint32_t e0 = tid - 64; e0 < items * G; e0 += 960) {
         const uint32_t k = e0 / items, e = e0 - k * items;
         const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
         const uint32_t pixel = pixelGroup() * PX + px;
         if (pixel >= prm.P) continue;
+        awaitCarries(progressAddr, chunk);
         const float slope = prm.slope[pixel];
         float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
         const float pole = prm.sc.pole[k];
