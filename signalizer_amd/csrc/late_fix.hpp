@@ -35,12 +35,15 @@ struct LateFix {
     uint32_t nyIsBin;         // sgz_stage_map_from_bins: ny[task][0] holds csf[N/2]
 };
 
-// csf[N/2] of a task, as the reference computes it from the packed bin (:863)
-__device__ __forceinline__ float lateNyquistBin(const LateFix &lf, long task)
+// csf[N/2] of a task, as the reference computes it from the packed bin (:863); nyRe / nyIm = lf.ny[2 task], lf.ny[2 task + 1]
+__device__ __forceinline__ float lateNyquistValue(const LateFix &lf, float nyRe, float nyIm)
 {
 #pragma clang fp contract(off)
-    const float nyRe = lf.ny[2 * task], nyIm = lf.ny[2 * task + 1];          // the left channel's is the real part
     return lf.nyIsBin ? nyRe : 0.5f * __builtin_amdgcn_sqrtf(nyRe * nyRe + nyIm * nyIm);
+}
+__device__ __forceinline__ float lateNyquistBin(const LateFix &lf, long task)
+{
+    return lateNyquistValue(lf, lf.ny[2 * task], lf.ny[2 * task + 1]);      // the left channel's is the real part
 }
 // the winning square the channel's workgroup left for pixel x >= fixFrom[side] of (task, side); +inf (csf[N/2] cannot win) outside the 64 slots
 __device__ __forceinline__ float lateBestSquare(const LateFix &lf, long task, int side, uint32_t x)

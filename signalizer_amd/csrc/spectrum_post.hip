@@ -227,13 +227,33 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     const float pole = prm.sc.pole[0];
     // 1a. every thread fetches its share of the frames x PX magnitudes (side 0 of the pair)
     const uint32_t items = uint32_t(prm.frames) * PX;
-    for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX; e += 1024) {
-        const uint32_t px = e % PX, f = e / PX;
-        const uint32_t pixel = pixelGroup() * PX + px;
-        float m = (e < items && pixel < prm.P) ? prm.mapped[size_t(f) * perFrame + pixel] * prm.magScale : 0.f;   // (x 1 is exact)
-        if (prm.hasLate && e < items && pixel >= prm.late.fixFrom0 && pixel < prm.P)                            // (late_fix.hpp)
-            m = lateNyquistPixel(prm.late, lateNyquistBin(prm.late, long(f)), lateBestSquare(prm.late, long(f), 0, pixel), m);
-        magS[f][px] = m;
+    // (every load of every round is requested before the first is waited for: as a loop with the late pixels' dependent reads inside, a
+    // workgroup took two to four memory round trips here)
+    {
+        constexpr int ROUNDS = kFusedChunks * kMaxChunk * PX / 1024;
+        float m[ROUNDS], nyRe[ROUNDS], nyIm[ROUNDS], best[ROUNDS];
+        const bool lateGroup = prm.hasLate && pixelGroup() * PX + PX > prm.late.fixFrom0;     // (uniform)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = tid + 1024u * r, px = e % PX, f = e / PX;
+            const uint32_t pixel = pixelGroup() * PX + px;
+            const bool in = e < items && pixel < prm.P;
+            m[r] = in ? prm.mapped[size_t(f) * perFrame + pixel] : 0.f;
+            nyRe[r] = nyIm[r] = 0.f; best[r] = __builtin_inff();
+            if (lateGroup && in && pixel >= prm.late.fixFrom0) {                               // (late_fix.hpp)
+                nyRe[r] = prm.late.ny[2 * size_t(f)]; nyIm[r] = prm.late.ny[2 * size_t(f) + 1];
+                best[r] = lateBestSquare(prm.late, long(f), 0, pixel);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = tid + 1024u * r, px = e % PX, f = e / PX;
+            const uint32_t pixel = pixelGroup() * PX + px;
+            float v = m[r] * prm.magScale;                                                     // (x 1 is exact)
+            if (lateGroup && e < items && pixel >= prm.late.fixFrom0 && pixel < prm.P)
+                v = lateNyquistPixel(prm.late, lateNyquistValue(prm.late, nyRe[r], nyIm[r]), best[r], v);
+            magS[f][px] = v;
+        }
     }
     __syncthreads();
     // 1b. zero-carry scan of every chunk
@@ -330,14 +350,33 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     const size_t perFrame = size_t(SIDES) * prm.P;              // (one pair)
     const uint32_t items = uint32_t(prm.frames) * PX;
     // 1a. magnitudes of both sides, carry-in state
-    for (uint32_t e = tid; e < kFusedChunks * kMaxChunk * PX * SIDES; e += 1024) {
-        const uint32_t px = e % PX, side = (e / PX) % SIDES, f = e / (PX * SIDES);
-        const uint32_t pixel = pixelGroup() * PX + px;
-        const bool in = f < uint32_t(prm.frames) && pixel < prm.P;
-        float m = in ? prm.mapped[size_t(f) * perFrame + size_t(side) * prm.P + pixel] * prm.magScale : 0.f;
-        if (prm.hasLate && in && pixel >= (side ? prm.late.fixFrom1 : prm.late.fixFrom0))
-            m = lateNyquistPixel(prm.late, lateNyquistBin(prm.late, long(f)), lateBestSquare(prm.late, long(f), int(side), pixel), m);
-        magS[f][side][px] = m;
+    {
+        constexpr int ROUNDS = kFusedChunks * kMaxChunk * PX * SIDES / 1024;      // (all loads requested before the first wait, as above)
+        float m[ROUNDS], nyRe[ROUNDS], nyIm[ROUNDS], best[ROUNDS];
+        const uint32_t lowestFix = prm.late.fixFrom0 < prm.late.fixFrom1 ? prm.late.fixFrom0 : prm.late.fixFrom1;
+        const bool lateGroup = prm.hasLate && pixelGroup() * PX + PX > lowestFix;             // (uniform)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = tid + 1024u * r, px = e % PX, side = (e / PX) % SIDES, f = e / (PX * SIDES);
+            const uint32_t pixel = pixelGroup() * PX + px;
+            const bool in = f < uint32_t(prm.frames) && pixel < prm.P;
+            m[r] = in ? prm.mapped[size_t(f) * perFrame + size_t(side) * prm.P + pixel] : 0.f;
+            nyRe[r] = nyIm[r] = 0.f; best[r] = __builtin_inff();
+            if (lateGroup && in && pixel >= (side ? prm.late.fixFrom1 : prm.late.fixFrom0)) {
+                nyRe[r] = prm.late.ny[2 * size_t(f)]; nyIm[r] = prm.late.ny[2 * size_t(f) + 1];
+                best[r] = lateBestSquare(prm.late, long(f), int(side), pixel);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t e = tid + 1024u * r, px = e % PX, side = (e / PX) % SIDES, f = e / (PX * SIDES);
+            const uint32_t pixel = pixelGroup() * PX + px;
+            const bool in = f < uint32_t(prm.frames) && pixel < prm.P;
+            float v = m[r] * prm.magScale;
+            if (lateGroup && in && pixel >= (side ? prm.late.fixFrom1 : prm.late.fixFrom0))
+                v = lateNyquistPixel(prm.late, lateNyquistValue(prm.late, nyRe[r], nyIm[r]), best[r], v);
+            magS[f][side][px] = v;
+        }
     }
     if (tid < NCMB * PX) {
         const uint32_t px = tid % PX, m = tid / PX, side = m / G, k = m % G;
