@@ -62,10 +62,11 @@ __device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalar
 }
 
 // renderSf + the additive blend of one pair's colour into the column buffer, SpectrumDSP.cpp:119-174
-__device__ __forceinline__ void blendColour(float (&cb)[3], float intensity, const float *sca, const DeviceScalars &sc)
+// the colour a pair contributes at `intensity` (false: nothing, intensity < 0), and its blend into the column buffer
+__device__ __forceinline__ bool colourOf(float intensity, const float *sca, const DeviceScalars &sc, float (&colourv)[3])
 {
-    if (intensity < 0.f) return;
-    float colourv[3] = {sca[(NC - 1) * 3 + 0], sca[(NC - 1) * 3 + 1], sca[(NC - 1) * 3 + 2]};
+    if (intensity < 0.f) return false;
+    colourv[0] = sca[(NC - 1) * 3 + 0]; colourv[1] = sca[(NC - 1) * 3 + 1]; colourv[2] = sca[(NC - 1) * 3 + 2];
     if (intensity < 0.999f) {
         float accumulatedSum = 0.f;
         for (int c = 1; c < NC; ++c) {
@@ -84,8 +85,17 @@ __device__ __forceinline__ void blendColour(float (&cb)[3], float intensity, con
             }
         }
     }
+    return true;
+}
+__device__ __forceinline__ void screenBlend(float (&cb)[3], const float (&colourv)[3])
+{
 #pragma unroll
     for (int c = 0; c < 3; ++c) cb[c] += (1.f - cb[c]) * colourv[c];   // GL_ONE_MINUS_SRC_COLOR
+}
+__device__ __forceinline__ void blendColour(float (&cb)[3], float intensity, const float *sca, const DeviceScalars &sc)
+{
+    float colourv[3];
+    if (colourOf(intensity, sca, sc, colourv)) screenBlend(cb, colourv);
 }
 
 __device__ __forceinline__ uchar4 toRgba8(const float (&cb)[3])

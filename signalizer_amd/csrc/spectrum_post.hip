@@ -740,11 +740,95 @@ hipError_t launchDecayColourFused(const DecayParams &prm, hipStream_t stream)
     return hipGetLastError();
 }
 
+// Several pairs: the same outputs with the pairs side by side.  decayEmitKernel's thread owns one (frame, pixel) and walks the pairs one
+// after the other -- 32 dependent rounds of (loads, replay of the chunk up to its frame, dB map, blend) at cfg5, 114 us for 91 MB.  Here a
+// thread owns (pair, pixel) for the 8 frames of the chunk: it reads each magnitude once, runs the recurrence once from the exact
+// carry (max(a, decayed carry) of emitPixel is that recurrence: the decay is monotone, D(max(x, y)) = max(D(x), D(y))), and leaves
+// every frame's colour contribution in LDS; the (frame, pixel) owners then blend 8 pairs' contributions in pair order (the screen
+// blend is the only step that couples the pairs, SpectrumDSP.cpp:170-174; a pair with nothing to add contributes zeros:
+// cb + (1 - cb) 0 == cb).
+__global__ void __launch_bounds__(256) decayEmitPairsKernel(const DecayParams prm, const uint32_t firstChunk)
+{
+    constexpr int PL = 8;                                       // pairs per pass
+    __shared__ float cv[kMaxChunk][PL][32][3];
+    __shared__ float st[kMaxChunk][256];
+    static_assert(G == 2, "two line graphs");
+    const int px = threadIdx.x & 31, pl = threadIdx.x >> 5;     // pl: pair lane (contributions) / frame in the chunk (blend)
+    const uint32_t groups = (prm.P + 31) / 32;
+    const uint32_t chunk = firstChunk + blockIdx.x / groups;
+    const uint32_t pixel = (blockIdx.x - (chunk - firstChunk) * groups) * 32 + px;
+    const long f0 = long(chunk) * kMaxChunk;
+    const int len = int(min(long(kMaxChunk), prm.frames - f0));
+    const bool live = pixel < prm.P;
+    const bool allCombos = prm.lines || (f0 + len == prm.frames && prm.state);
+    const size_t perFrame = size_t(prm.C) * prm.sides * prm.P;
+    const float slope = live ? prm.slope[pixel] : 0.f;
+    float cb[3] = {0.f, 0.f, 0.f};                              // colourBuffer of (frame f0 + pl, pixel)
+    for (uint32_t p0 = 0; p0 < prm.C; p0 += PL) {
+        const uint32_t pair = p0 + pl;
+#pragma unroll
+        for (int i = 0; i < kMaxChunk; ++i) { cv[i][pl][px][0] = 0.f; cv[i][pl][px][1] = 0.f; cv[i][pl][px][2] = 0.f; }
+        if (live && pair < prm.C) {
+            const float *sca = prm.colourTables + size_t(pair) * NC * 3;
+#pragma unroll 1
+            for (uint32_t side = 0; side < prm.sides; ++side) {
+                if (!allCombos && side != 0) continue;          // only (side 0, graph 0) feeds the colour column
+                const uint32_t ps = pair * prm.sides + side;
+                float mag[kMaxChunk];
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i)
+                    mag[i] = i < len ? prm.mapped[size_t(f0 + i) * perFrame + size_t(ps) * prm.P + pixel] * prm.magScale : 0.f;
+#pragma unroll 1
+                for (int k = 0; k < G; ++k) {
+                    const bool colour = (side == 0 && k == 0 && prm.rgba);
+                    if (!colour && !allCombos) continue;
+                    const float pole = k ? prm.sc.pole[G - 1] : prm.sc.pole[0];
+                    float s = chunk > 0 ? prm.agg[(size_t(chunk - 1) * prm.C * prm.sides * G + (ps * G + k)) * prm.P + pixel]
+                                        : (prm.stateIn ? prm.stateIn[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] : 0.f);
+                    // the chunk's states (unrolled: the chain), parked in LDS so that the per-frame outputs below are ONE copy of the
+                    // dB map's code in a rolled loop (unrolled over sides x graphs x frames the kernel needed 136 registers)
+#pragma unroll
+                    for (int i = 0; i < kMaxChunk; ++i) {
+                        s = s * pole;                           // states[i] *= pole, TransformDSP.inl:1336,:1370
+                        if (mag[i] > s) s = mag[i];             // :1338-1341
+                        st[i][threadIdx.x] = s;
+                    }
+#pragma unroll 1
+                    for (int i = 0; i < len; ++i) {
+                        const float si = st[i][threadIdx.x];
+                        const long f = f0 + i;
+                        if (prm.state && f == prm.frames - 1) prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = si;
+                        if (!colour && !prm.lines) continue;
+                        const float result = dbMap(slope, si, prm.sc);
+                        if (prm.lines) {
+                            float *lr = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
+                            lr[side] = result;
+                            if (prm.sides == 1) lr[1] = 0.f;    // results[i].phase = 0 in the one-channel modes (:1347)
+                        }
+                        float c3[3];
+                        if (colour && colourOf(result, sca, prm.sc, c3)) { cv[i][pl][px][0] = c3[0]; cv[i][pl][px][1] = c3[1]; cv[i][pl][px][2] = c3[2]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (prm.rgba) {
+#pragma unroll
+            for (int q = 0; q < PL; ++q)
+                if (p0 + q < prm.C) { const float c3[3] = {cv[pl][q][px][0], cv[pl][q][px][1], cv[pl][q][px][2]}; screenBlend(cb, c3); }
+        }
+        __syncthreads();
+    }
+    if (prm.rgba && live && pl < len) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f0 + pl) * prm.P + pixel] = toRgba8(cb);
+}
+
 hipError_t launchDecayEmit(const DecayParams &prm, hipStream_t stream)
 {
     const uint32_t firstChunk = (prm.rgba || prm.lines) ? 0u : prm.numChunks - 1;        // state-only pass: last chunk
     const unsigned grid = unsigned(size_t((prm.P + 31) / 32) * (prm.numChunks - firstChunk));
-    hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(256), 0, stream, prm, firstChunk);
+    static_assert(kMaxChunk == 8, "decayEmitPairsKernel: 8 frames x 32 pixels = one workgroup");
+    if (prm.C >= 2) hipLaunchKernelGGL(decayEmitPairsKernel, dim3(grid), dim3(256), 0, stream, prm, firstChunk);
+    else hipLaunchKernelGGL(decayEmitKernel, dim3(grid), dim3(256), 0, stream, prm, firstChunk);
     return hipGetLastError();
 }
 
