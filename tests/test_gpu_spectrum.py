@@ -141,6 +141,42 @@ def test_decay_colour_bit_exact_given_mapped(gpu, oracle):
     assert np.array_equal(rgba, r["rgba"])
 
 
+@pytest.mark.parametrize("pairs,frames,P", [(1, 1, 1024), (1, 8, 1024), (1, 9, 333), (1, 65, 1024), (1, 348, 1024), (1, 512, 40), (1, 513, 1024),
+                                              (2, 17, 1024), (9, 70, 333), (32, 24, 96)])
+def test_decay_colour_every_kernel(gpu, oracle, pairs, frames, P):
+    """K_B's launch forms on identical magnitudes, bit for bit against the oracle: the fused colour kernel and the fused kernel with
+    lines + state (one pair, <= 64 chunks: XCD-ordered pixel groups, emissions pipelined beside the fold -- 1 frame, whole and partial
+    chunks, the 64-chunk limit), the scan / emit kernels beyond it, and the several-pairs emit kernel (partial passes of 8 pairs)."""
+    import torch
+    po = oracle
+    cfg = config.spectrum_config(window_size=512, hop=128, num_pairs=pairs, axis_points=P, low_db=-90.0, high_db=3.0)
+    p = po.params_from_dict(cfg)
+    S = 512 + (frames - 1) * 128
+    x = synth.gen(31 + pairs, 48000, S, 2 * pairs)
+    x[:, S // 3: S // 2] = 0                        # silence: pure decay + clip path
+    r = po.spectrogram(p, x, want_lines=True, want_mapped=True)
+    mapped = r["mapped"].reshape(frames, pairs, 2, P)
+    mag = torch.from_numpy(np.sqrt((mapped.real ** 2 + mapped.imag ** 2).astype(np.float32)).astype(np.float32)).to(gpu)
+    plan = api.Plan(cfg).upload()
+    ref = np.stack([r["lines"].real, r["lines"].imag], axis=-1).astype(np.float32)
+    img, _ = plan.stage_decay_colour(mag)                                         # image only
+    assert np.array_equal(img.cpu().numpy(), r["rgba"])
+    state = torch.zeros((pairs, 2, P, 2), dtype=torch.float32, device=gpu)
+    img2, lines = plan.stage_decay_colour(mag, want_lines=True, state=state)      # with lines and state
+    assert np.array_equal(img2.cpu().numpy(), r["rgba"])
+    lines = lines.cpu().numpy()
+    assert np.array_equal(lines.view(np.uint32), ref.view(np.uint32)), np.abs(lines - ref).max()
+    # the end state continues the recurrence: two calls with the state carried == the one call (which equals the oracle)
+    if frames >= 2:
+        h = frames // 2
+        st = torch.zeros((pairs, 2, P, 2), dtype=torch.float32, device=gpu)
+        a_img, a_lines = plan.stage_decay_colour(mag[:h].contiguous(), want_lines=True, state=st)
+        b_img, b_lines = plan.stage_decay_colour(mag[h:].contiguous(), want_lines=True, state=st)
+        assert np.array_equal(torch.cat([a_img, b_img]).cpu().numpy(), r["rgba"])
+        assert np.array_equal(torch.cat([a_lines, b_lines]).cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        assert torch.equal(st, state)
+
+
 def test_logf_equals_libm_over_every_positive_float(gpu, oracle):
     """dB map's std::log(float): the device port of glibc's logf against libm's logf (what the oracle -- and the reference on
     Linux -- call), over all 2^31 - 2^23 - 1 positive finite floats, bit for bit."""
