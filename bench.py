@@ -180,6 +180,13 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                        envelope_window=0.3, stereo_window=0.1)
     x = synth.gen(31 + rank, int(sr), per_frame * 64, nch)
     refused = 0
+    # the vertex streams are read back into pinned buffers the caller keeps (what a plugin's render thread would hand to glBufferSubData)
+    pinned = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory().numpy()
+    if scope:
+        nv = L.sgz_scope_vertex_count(h.h, ctypes.byref(view))
+        outs = [(pinned((nv, 3), torch.float32), pinned((nv, 4), torch.uint8)) for _ in (0, 1)]
+    else:
+        outs = (pinned((nch // 2, W, 3), torch.float32), pinned((nch // 2, W, 3), torch.float32))
 
     def push(block):
         nonlocal refused
@@ -198,11 +205,11 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
             h.peak_filter(1 / 60, 8)
             n = 0
             for ev in (0, 1):
-                xyz, _ = h.vertices(view, ev, 0)
+                xyz, _ = h.vertices(view, ev, 0, out=outs[ev])
                 n += xyz.shape[0]
         else:
             h.peak_filter(1 / 60)
-            xyz, _ = h.vertices_all()                              # every pair's vertex stream, one wait for the GPU
+            xyz, _ = h.vertices_all(out=outs)                      # every pair's vertex stream, one wait for the GPU
             n = xyz.shape[0] * xyz.shape[1]
         frame += 1
         units = n

@@ -487,7 +487,9 @@ size_t     sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view
 /* One evaluator's line strip.  evaluator: SGZ_OSC_LEFT / RIGHT (channel `channel` / `channel` + 1) or SGZ_OSC_MID / SIDE (0.5 (l +- r)
  * of the pair at `channel`); view->window_size is ignored (the stream's is used).  xyz: float3 per vertex, rgba: RGBA8 per vertex
  * (may be NULL); *count: in = capacity of the buffers in vertices, out = vertices written.  Lanczos below one pixel per sample
- * falls back to Linear like the reference (OscilloscopeRendering.cpp:575-578): x is then the sample index (sample space). */
+ * falls back to Linear like the reference (OscilloscopeRendering.cpp:575-578): x is then the sample index (sample space).
+ * Host buffers that are pinned (hipHostMalloc / hipHostRegister) are written by the DMA engine directly; pageable ones go through a
+ * pinned bounce buffer and a host copy (the same holds for sgz_vector_vertices / _all). */
 sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz,
                               uint8_t *rgba, uint32_t *count);
 /* The same stream into DEVICE buffers -- a mapped vertex buffer object, or memory from sgz_export_alloc that the display GPU's GL /

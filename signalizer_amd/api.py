@@ -568,11 +568,18 @@ class Scope:
         check(lib().sgz_scope_peak_filter(self.h, delta_time, lanes, C.byref(g)))
         return g.value
 
-    def vertices(self, view: ScopeView, evaluator: int, channel: int = 0, want_colours: bool = True):
+    def vertices(self, view: ScopeView, evaluator: int, channel: int = 0, want_colours: bool = True, out=None):
+        """out: (xyz float32 [>= n][3], rgba uint8 [>= n][4] or None) buffers the caller keeps (pinned ones make the read-back a DMA);
+        default: fresh arrays"""
         self.flush()
         n = lib().sgz_scope_vertex_count(self.h, C.byref(view))
-        xyz = np.zeros((n, 3), np.float32)
-        rgba = np.zeros((n, 4), np.uint8) if want_colours else None
+        if out is not None:
+            xyz, rgba = out
+            assert xyz.shape[0] >= n and (rgba is None or rgba.shape[0] >= n)
+            want_colours = rgba is not None
+        else:
+            xyz = np.empty((n, 3), np.float32)
+            rgba = np.empty((n, 4), np.uint8) if want_colours else None
         cnt = C.c_uint32(n)
         check(lib().sgz_scope_vertices(self.h, C.byref(view), evaluator, channel, _np_ptr(xyz),
                                        _np_ptr(rgba) if want_colours else None, C.byref(cnt)))
@@ -633,11 +640,17 @@ class Vector:
         check(lib().sgz_vector_peak_filter(self.h, delta_time, C.byref(g)))
         return g.value
 
-    def vertices_all(self, want_colours: bool = True):
+    def vertices_all(self, want_colours: bool = True, out=None):
+        """out: (xyz float32 [pairs][n][3], rgb float32 [pairs][n][3] or None) buffers the caller keeps; default: fresh arrays"""
         self.flush()
         n, pairs = self.cfg.window_size, self.cfg.num_channels // 2
-        xyz = np.zeros((pairs, n, 3), np.float32)
-        rgb = np.zeros((pairs, n, 3), np.float32) if want_colours else None
+        if out is not None:
+            xyz, rgb = out
+            assert xyz.shape == (pairs, n, 3) and (rgb is None or rgb.shape == (pairs, n, 3))
+            want_colours = rgb is not None
+        else:
+            xyz = np.empty((pairs, n, 3), np.float32)
+            rgb = np.empty((pairs, n, 3), np.float32) if want_colours else None
         cnt = C.c_uint32(n)
         check(lib().sgz_vector_vertices_all(self.h, _np_ptr(xyz), _np_ptr(rgb) if want_colours else None, C.byref(cnt)))
         return xyz, rgb

@@ -13,6 +13,32 @@
 
 namespace sgz {
 
+// Is `p` memory the DMA engines can write directly (hipHostMalloc / hipHostRegister, i.e. pinned)?  A plain malloc'd pointer makes
+// hipPointerGetAttributes fail: the sticky error is cleared.
+inline bool isPinnedHost(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+// Device results -> the caller's host buffers, then wait.  Pinned destinations are written by the DMA engine directly; others go
+// through the handle's pinned bounce buffer `h_bounce` (room for both parts) and a host copy.
+inline sgz_status readBack(void *dstA, const void *d_a, size_t bytesA, void *dstB, const void *d_b, size_t bytesB, void *h_bounce,
+                           hipStream_t stream)
+{
+    const bool direct = isPinnedHost(dstA) && (!dstB || isPinnedHost(dstB));
+    char *hb = static_cast<char *>(h_bounce);
+    SGZ_HIP(hipMemcpyAsync(direct ? dstA : hb, d_a, bytesA, hipMemcpyDeviceToHost, stream));
+    if (dstB) SGZ_HIP(hipMemcpyAsync(direct ? dstB : hb + bytesA, d_b, bytesB, hipMemcpyDeviceToHost, stream));
+    SGZ_HIP(hipStreamSynchronize(stream));
+    if (!direct) {
+        std::memcpy(dstA, hb, bytesA);
+        if (dstB) std::memcpy(dstB, hb + bytesA, bytesB);
+    }
+    return SGZ_OK;
+}
+
 struct StageRing {
     static constexpr int kSlots = 8;
     float *h = nullptr;            // pinned  [kSlots][channels][maxBlock]

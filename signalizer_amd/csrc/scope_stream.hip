@@ -226,16 +226,30 @@ __device__ __forceinline__ double trigSample(uint32_t mode, const float *a, cons
 
 __device__ __forceinline__ unsigned long long minU64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
 
+#ifdef SGZ_DEBUG
+__device__ unsigned long long g_ingestClk[8];
+#define ICLK(k) do { if (threadIdx.x == 0) g_ingestClk[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ICLK(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams col)
 {
     __shared__ long long sScan[16];
     __shared__ unsigned int sSum[16];
     __shared__ unsigned int sNumSwaps, sLastStart, sLastLen, sCursor0;
     __shared__ unsigned long long sWritten0;
-    ScopeDev *st = prm.st;
+    // The stream state lives in LDS for the length of the kernel (one coalesced read, one write-back): the phases below touch its fields
+    // some thirty times, mostly from one lane and each time behind the last (the kernels of the render thread read the copy in HBM,
+    // between launches)
+    __shared__ ScopeDev sState;
     const uint32_t n = prm.n, C = prm.channels;
     const int tid = threadIdx.x, T = blockDim.x;
+    static_assert(sizeof(ScopeDev) % 4 == 0, "copied as words");
+    for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(&sState)[w] = reinterpret_cast<const uint32_t *>(prm.st)[w];
+    __syncthreads();
+    ScopeDev *st = &sState;
     const unsigned long long playhead = st->playhead;
+    ICLK(0);
 
     // ---- update(), StreamPreprocessing.h:55-76 (thread 0; the queue edits must precede phase A's appends)
     if (tid == 0) {
@@ -352,7 +366,19 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         __syncthreads();
     }
 
-    // ---- B: processMutating's automaton (thread 0) -> swap list
+    ICLK(1);
+    // ---- B: processMutating's automaton (thread 0) -> swap list.  The head of the trigger queue is fetched by 64 lanes at once and the
+    // swap list starts in LDS: the automaton then walks without memory round trips (a block holds a handful of triggers)
+    constexpr unsigned int kStage = 64;
+    __shared__ unsigned long long sPeaks[kStage];
+    __shared__ Swap sSwaps[kStage];
+    if (hold && tid < int(kStage) && uint32_t(tid) < st->qCount) sPeaks[tid] = prm.peaks[(st->qHead + uint32_t(tid)) % kPeakCap];
+    const unsigned int qHeadIn = st->qHead;
+    __syncthreads();
+    auto peakAt = [&](unsigned int q) {
+        const unsigned int k = (q + kPeakCap - qHeadIn) % kPeakCap;
+        return k < kStage ? sPeaks[k] : prm.peaks[q];
+    };
     if (tid == 0) {
         unsigned int numSwaps = 0, lastStart = 0, lastLen = n;
         sCursor0 = st->frontCursor;
@@ -381,7 +407,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                 if (!qCount) { processIntoBackBuffer(numSamples); break; }
                 else if (!isWorkingOnPeak) {
                     isWorkingOnPeak = 1;
-                    const unsigned long long nextPeak = prm.peaks[qHead];
+                    const unsigned long long nextPeak = peakAt(qHead);
                     if (nextPeak >= steadyClock) {
                         const unsigned long long deltaToPeak = nextPeak - steadyClock;
                         const unsigned long long toProcess = minU64(numSamples, (unsigned long long)(double(deltaToPeak) + halfSize));
@@ -415,8 +441,9 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     const unsigned long long cappedSize = minU64(bufferedSamples, (unsigned long long)ceil(amount + 1));
                     // swapBuffers(cappedSize, -bufferedSamples): source = the oldest buffered sample onwards
                     if (numSwaps < kMaxSwaps) {
-                        prm.swapList[numSwaps].src = (sWritten0 + consumed) - bufferedSamples;
-                        prm.swapList[numSwaps].len = (unsigned int)cappedSize;
+                        Swap &sw = numSwaps < kStage ? sSwaps[numSwaps] : prm.swapList[numSwaps];
+                        sw.src = (sWritten0 + consumed) - bufferedSamples;
+                        sw.len = (unsigned int)cappedSize;
                         ++numSwaps;
                     }
                     bufferedSamples -= minU64(bufferedSamples, cappedSize);
@@ -435,6 +462,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     }
     __syncthreads();
 
+    ICLK(2);
     // ---- F: per-sample colours of the block (audioProcessing :445-517, :588-647).  Every sample passes through audioProcessing exactly
     // once and in order, whatever the split into calls, so the filters run over the block as a whole.
     if (prm.colours) {
@@ -497,6 +525,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     // ---- C: swaps (ZeroCrossing) or the block itself (None / Spectral: audioProcessing straight into the front buffer), in order
     const uint32_t size = prm.size;
     uint32_t cursor = sCursor0;
+    ICLK(3);
     const unsigned long long written0 = sWritten0;
     // `later`: samples that swaps after this one (same block) will append.  The ring holds `size` samples, so whatever this swap writes
     // survives only where fewer than `size` samples follow: a noisy signal fires a dozen triggers per block, each swap copies a
@@ -534,13 +563,16 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         const uint32_t ns = sNumSwaps;
         // suffix sums of the swap lengths: thread-private walk from the back (the list is short)
         unsigned long long later = 0;
-        for (uint32_t k = 0; k < ns; ++k) later += prm.swapList[k].len;
+        auto swapAt = [&](uint32_t k) { return k < kStage ? sSwaps[k] : prm.swapList[k]; };
+        for (uint32_t k = 0; k < ns; ++k) later += swapAt(k).len;
         for (uint32_t k = 0; k < ns; ++k) {
-            later -= prm.swapList[k].len;
-            appendFront(prm.swapList[k].src, prm.swapList[k].len, later);
+            const Swap sw = swapAt(k);
+            later -= sw.len;
+            appendFront(sw.src, sw.len, later);
         }
     } else appendFront(written0, n, 0ull);
 
+    ICLK(4);
     // ---- D: the block goes into the back rings (ZeroCrossing / EnvelopeHold only; absolute index mod backCap)
     if (hold) {
         const uint32_t keep = n > prm.backCap ? prm.backCap : n, first = n - keep;
@@ -555,8 +587,10 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             }
     }
 
+    ICLK(5);
     // ---- E: RMS envelope (audioProcessing, OscilloscopeDSP.inl:520-585, :676-693); wave 0, lane c = recurrence c
-    if (prm.envMode != 0u && tid < 64) {
+    // (the reference runs the recurrence in PeakDecay mode too and throws the result away, :506-585 against :676: only RMS stores it)
+    if (prm.envMode == 1u && tid < 64) {
         const bool active = tid < int(C);
         const float k = prm.envelopeCoeff;
         const uint32_t mode = prm.oscMode;
@@ -600,11 +634,15 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         }
     }
     __syncthreads();
+    ICLK(6);
     if (tid == 0) {
         st->frontCursor = cursor;
         if (hold) st->written = written0 + n;
         st->playhead = playhead + n;
     }
+    __syncthreads();
+    for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(prm.st)[w] = reinterpret_cast<const uint32_t *>(&sState)[w];
+    ICLK(7);
 }
 
 // ---- Oscilloscope::runPeakFilter on the front rings (memory order, last size mod lanes slots dropped), every channel mode
@@ -1123,6 +1161,15 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
 
 extern "C" {
 
+#ifdef SGZ_DEBUG
+sgz_status sgz_debug_ingest_clocks(unsigned long long *out8)
+{
+    SGZ_HIP(hipDeviceSynchronize());
+    SGZ_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ingestClk), 8 * sizeof(unsigned long long)));
+    return SGZ_OK;
+}
+#endif
+
 sgz_status sgz_scope_create(const sgz_scope_config *cfg, sgz_scope **out)
 {
     if (!cfg || !out) return fail(SGZ_EINVAL, "null argument");
@@ -1375,13 +1422,8 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     size_t points = 0;
     const sgz_status st = scopeVerticesInto(s, view, evaluator, channel, s->d_xyz, rgba ? s->d_rgba : nullptr, need, &points);
     if (st != SGZ_OK) return st;
-    float *hx = static_cast<float *>(s->h_out);
-    uint32_t *hc = reinterpret_cast<uint32_t *>(hx + need * 3);
-    SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, points * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    if (rgba) SGZ_HIP(hipMemcpyAsync(hc, s->d_rgba, points * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    SGZ_HIP(hipStreamSynchronize(s->stream));
-    std::memcpy(xyz, hx, points * 3 * sizeof(float));
-    if (rgba) std::memcpy(rgba, hc, points * 4);
+    if (sgz_status rb = readBack(xyz, s->d_xyz, points * 3 * sizeof(float), rgba, s->d_rgba, points * sizeof(uint32_t), s->h_out, s->stream);
+        rb != SGZ_OK) return rb;
     *count = uint32_t(points);
     return SGZ_OK;
 }

@@ -460,12 +460,8 @@ sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
     const sgz_status st = vectorVerticesInto(s, pair, s->d_xyz, rgb ? s->d_rgb : nullptr);
     if (st != SGZ_OK) return st;
-    float *hx = static_cast<float *>(s->h_out);
-    SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    if (rgb) SGZ_HIP(hipMemcpyAsync(hx + size_t(size) * 3, s->d_rgb, size_t(size) * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    SGZ_HIP(hipStreamSynchronize(s->stream));
-    std::memcpy(xyz, hx, size_t(size) * 3 * sizeof(float));
-    if (rgb) std::memcpy(rgb, hx + size_t(size) * 3, size_t(size) * 3 * sizeof(float));
+    const size_t bytes = size_t(size) * 3 * sizeof(float);
+    if (sgz_status rb = readBack(xyz, s->d_xyz, bytes, rgb, s->d_rgb, bytes, s->h_out, s->stream); rb != SGZ_OK) return rb;
     *count = size;
     return SGZ_OK;
 }
@@ -480,12 +476,8 @@ sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32
         const sgz_status st = vectorVerticesInto(s, p, s->d_xyz + p * per, rgb ? s->d_rgb + p * per : nullptr);
         if (st != SGZ_OK) return st;
     }
-    float *hx = static_cast<float *>(s->h_out);
-    SGZ_HIP(hipMemcpyAsync(hx, s->d_xyz, pairs * per * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    if (rgb) SGZ_HIP(hipMemcpyAsync(hx + pairs * per, s->d_rgb, pairs * per * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-    SGZ_HIP(hipStreamSynchronize(s->stream));
-    std::memcpy(xyz, hx, pairs * per * sizeof(float));
-    if (rgb) std::memcpy(rgb, hx + pairs * per, pairs * per * sizeof(float));
+    const size_t bytes = pairs * per * sizeof(float);
+    if (sgz_status rb = readBack(xyz, s->d_xyz, bytes, rgb, s->d_rgb, bytes, s->h_out, s->stream); rb != SGZ_OK) return rb;
     *count = size;
     return SGZ_OK;
 }
