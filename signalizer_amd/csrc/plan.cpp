@@ -551,9 +551,9 @@ static void buildResonator(Plan &p)
                 for (uint32_t k = 0; k < 32; ++k) {
                     double xr, xi;
                     cpowd(31 - k, xr, xi);
-                    p.resW1[((size_t(v) * P + i) * 32 + k) * 2] = float(xr); p.resW1[((size_t(v) * P + i) * 32 + k) * 2 + 1] = float(xi);
+                    p.resW1[((size_t(k) * V + v) * P + i) * 2] = float(xr); p.resW1[((size_t(k) * V + v) * P + i) * 2 + 1] = float(xi);
                     cpowd(32 * (31 - k), xr, xi);
-                    p.resW2[((size_t(v) * P + i) * 32 + k) * 2] = float(xr); p.resW2[((size_t(v) * P + i) * 32 + k) * 2 + 1] = float(xi);
+                    p.resW2[((size_t(k) * V + v) * P + i) * 2] = float(xr); p.resW2[((size_t(k) * V + v) * P + i) * 2 + 1] = float(xi);
                 }
                 double tr, ti;
                 cpowd(1024, tr, ti);

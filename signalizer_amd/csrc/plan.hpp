@@ -111,7 +111,7 @@ struct Plan {
     std::vector<float> resPow;          // [V][P] (re, im, re_lo, im_lo): (the fp32 pole)^hop, evaluated in double, as hi + lo fp32 words -- the carry of a whole frame
     std::vector<float> resPowB;         // [V][P][8] (re, im): (the fp32 pole)^1 .. ^8, rounded once each -- the block steps of resonateKernel
     std::vector<float> resPowBLo;       // [V][P][2] (re, im): low words of pole^4 and pole^8
-    std::vector<float> resW1, resW2;    // hop % 1024 == 0: [V][P][32] (re, im): pole^(31 - b) and pole^(32 (31 - a)), the weights of resonateMfmaKernel
+    std::vector<float> resW1, resW2;    // hop % 1024 == 0: [32][V][P] (re, im): pole^(31 - b) and pole^(32 (31 - a)), the weights of resonateMfmaKernel (resonator index last: a wave's 32 lanes read 32 neighbours)
     std::vector<float> resTile;         // [V][P] (re, im, re_lo, im_lo): pole^1024
     std::vector<float> resGain;         // [P]
     float resWeights[9] = {0};          // [V]

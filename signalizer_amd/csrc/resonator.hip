@@ -201,10 +201,11 @@ __global__ __launch_bounds__(256) void resonateMfmaKernel(ResParams prm, int V)
     float w1r[16], w1i[16], w2r[16], w2i[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const float2 q = live ? prm.w1[at * 32 + 2 * s + h] : float2{0.f, 0.f};
+        const size_t VP = size_t(V) * prm.P;                             // tables are [32][V][P]: coalesced across the lanes
+        const float2 q = live ? prm.w1[size_t(2 * s + h) * VP + at] : float2{0.f, 0.f};
         w1r[s] = q.x; w1i[s] = q.y;
         const int a = (s & 3) + 8 * (s >> 2) + 4 * h;
-        const float2 u = live ? prm.w2[at * 32 + a] : float2{0.f, 0.f};
+        const float2 u = live ? prm.w2[size_t(a) * VP + at] : float2{0.f, 0.f};
         w2r[s] = u.x; w2i[s] = u.y;
     }
     const float4 tp = live ? prm.tilePow[at] : float4{0.f, 0.f, 0.f, 0.f};
