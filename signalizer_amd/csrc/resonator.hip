@@ -211,18 +211,20 @@ __global__ __launch_bounds__(256) void resonateMfmaKernel(ResParams prm, int V)
     const float4 tp = live ? prm.tilePow[at] : float4{0.f, 0.f, 0.f, 0.f};
     float sre = 0.f, sim = 0.f;
     // the tile's samples: fetched one tile ahead into registers, parked in one of two LDS buffers (one barrier per tile)
-    float nx[4];
+    // (raw left / right values: the channel mix is applied when they are parked -- mixing at the load makes the wave wait for the
+    // loads right there, a memory round trip per tile in front of the matrix products: the kernel ran at half the pipe's rate)
+    float nl[4], nr[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; nx[k] = resMix(prm.mode, signal, L[e], R[e]); }
+    for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; nl[k] = L[e]; nr[k] = R[e]; }
     int buf = 0;
     for (uint32_t t0 = 0; t0 < prm.hop; t0 += 1024, buf ^= 1) {
         float *xb = xs + buf * (32 * 33);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; xb[(e >> 5) * 33 + (e & 31)] = nx[k]; }
+        for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; xb[(e >> 5) * 33 + (e & 31)] = resMix(prm.mode, signal, nl[k], nr[k]); }
         __syncthreads();                                             // (the other buffer was read two tiles ago: every wave is past it)
         if (t0 + 1024 < prm.hop) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const uint32_t e = t0 + 1024 + uint32_t(tid) + 256u * k; nx[k] = resMix(prm.mode, signal, L[e], R[e]); }
+            for (int k = 0; k < 4; ++k) { const uint32_t e = t0 + 1024 + uint32_t(tid) + 256u * k; nl[k] = L[e]; nr[k] = R[e]; }
         }
         f32x16 dre = {0}, dim = {0};
         const float *arow = xb + (lane & 31) * 33 + h;
