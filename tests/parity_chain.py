@@ -15,7 +15,7 @@ magnitude crosses a uint8 truncation.  Instead of a blanket "x % of bytes may di
 import numpy as np
 
 MAP_TOL = 4e-6          # same bar as the bins (tests/test_gpu_spectrum.py BIN_TOL)
-TIE_REL = 1e-5          # relative key distance that counts as an FFT-rounding tie
+TIE_REL = 1e-5          # relative key distance that counts as an FFT-rounding tie (or the bins' own bar, see _phase_tie_ok)
 CH_PHASE = 4
 
 
@@ -55,9 +55,14 @@ def _phase_tie_ok(po, p, plan, x, hop, f, pair, px, got, ref, tol, tolc):
     canc = 1.0 - np.abs(Lk + Rk) / np.maximum(mid, 1e-300)
     is_g = (np.abs(val - got[0]) <= tol) & (np.abs(canc - got[1]) <= tolc)
     is_o = (np.abs(val - ref[0]) <= tol) & (np.abs(canc - ref[1]) <= tolc)
+    # a tie: the keys differ by no more than TIE_REL, or by no more than link 1's own bar allows -- `tol` on a mapped value is
+    # tol / scale on a raw |L| or |R|, i.e. 2 sqrt(key) tol / scale on a key (low bins of a loud frame: the bar is absolute, the
+    # keys are small; seed 600 of the wild sweep met two keys 1.6e-5 apart at 0.2 % of the frame's maximum)
+    tol_raw = tol / (plan.window_scale / (W * 0.5))
     for g in np.nonzero(is_g)[0]:
         for o in np.nonzero(is_o)[0]:
-            if g != o and abs(key[g] - key[o]) <= TIE_REL * max(key[g], key[o]):
+            top = max(key[g], key[o])
+            if g != o and abs(key[g] - key[o]) <= max(TIE_REL * top, 2.0 * np.sqrt(top) * tol_raw):
                 return True
     return False
 

@@ -5,8 +5,7 @@ from signalizer_amd import api, config, synth
 from oracle import pyoracle as po
 import parity_chain as pc
 cases = [
- (219134, 227, {"sample_rate": 48000.0, "window_size": 30951, "hop": 24199, "axis_points": 3501, "channel_mode": 4, "bin_interp": 1, "view_scaling": 0, "window_type": 3, "window_symmetry": 0, "num_pairs": 4, "window_alpha": 0.9984475263199435, "window_beta": 5.940136518994648, "view_left": 0.32076750693059997, "view_right": 0.7800275537619439, "min_log_freq": 21.948234491973718, "low_db": -26.720321558724876, "high_db": 5.678858040526887, "clip_db": -384.0, "slope_a": 0.0, "slope_b": 0.7, "pole": [0.9, 0.999], "ratios": [0.2, 0.2, 0.2, 0.2, 0.2]}, (5,1,1566)),
- (36078, 387, {"sample_rate": 44100.0, "window_size": 16384, "hop": 9088, "axis_points": 3221, "channel_mode": 4, "bin_interp": 1, "view_scaling": 1, "window_type": 0, "window_symmetry": 0, "num_pairs": 2, "window_alpha": 0.10917435600777625, "window_beta": 2.7452406144578054, "view_left": 0.24545190254984617, "view_right": 1.0, "min_log_freq": 192.91710683396533, "low_db": -128.73327234069512, "high_db": -3.8151905534295905, "clip_db": -384.0, "slope_a": 0.0, "slope_b": 0.7, "pole": [0.5, 0.99], "ratios": [0.2, 0.2, 0.2, 0.2, 0.2]}, (2,0,2261)),
+ (266395, 273, {"sample_rate": 192000.0, "window_size": 41576, "hop": 28126, "axis_points": 1276, "channel_mode": 4, "bin_interp": 1, "view_scaling": 0, "window_type": 5, "window_symmetry": 0, "num_pairs": 3, "window_alpha": 1.3655544878677526, "window_beta": 4.306534423327001, "view_left": 0.6286670910667574, "view_right": 1.0, "min_log_freq": 101.4876458107646, "low_db": -143.5860671359662, "high_db": -1.054302015974292, "clip_db": -384.0, "slope_a": 0.0, "slope_b": 1.0, "pole": [0.0, 0.9], "ratios": [0.2, 0.2, 0.2, 0.2, 0.2]}, (7,1,1229)),
 ]
 for S, seed, over, (f, c, px) in cases:
     cfg = config.spectrum_config(**over)
