@@ -366,6 +366,11 @@ def test_vertices_into_device_buffers(gpu):
     for evaluator in (0, 3):
         want_xyz, want_rgba = dev.vertices(v, evaluator, 0)
         n = want_xyz.shape[0]
+        # pinned host buffers: written by the DMA engine directly (rt_common.hpp readBack), the same bytes as through the bounce buffer
+        pin_xyz = torch.full((n, 3), float("nan"), dtype=torch.float32).pin_memory().numpy()
+        pin_rgba = torch.zeros((n, 4), dtype=torch.uint8).pin_memory().numpy()
+        got_xyz, got_rgba = dev.vertices(v, evaluator, 0, out=(pin_xyz, pin_rgba))
+        assert np.array_equal(got_xyz.view(np.uint32), want_xyz.view(np.uint32)) and np.array_equal(got_rgba, want_rgba)
         # exported memory: one allocation for vertices + colours
         d_ptr, got_bytes, fd = C.c_void_p(), C.c_size_t(0), C.c_int(-1)
         api.check(L.sgz_export_alloc(n * 16, C.byref(d_ptr), C.byref(got_bytes), C.byref(fd)))

@@ -136,4 +136,12 @@ def test_vertices_all_equals_per_pair_calls(gpu):
         xyz, rgb = h.vertices(p)
         assert np.array_equal(all_xyz[p].view(np.uint32), xyz.view(np.uint32)), p
         assert np.array_equal(all_rgb[p].view(np.uint32), rgb.view(np.uint32)), p
+    # pinned caller buffers are written by the DMA engine directly (rt_common.hpp readBack): the same floats as through the bounce buffer
+    import torch
+    pin = lambda: torch.empty((nch // 2, W, 3), dtype=torch.float32).pin_memory().numpy()
+    out = (pin(), pin())
+    out[0][:] = np.nan; out[1][:] = np.nan
+    got_xyz, got_rgb = h.vertices_all(out=out)
+    assert got_xyz is out[0] and np.array_equal(got_xyz.view(np.uint32), all_xyz.view(np.uint32))
+    assert np.array_equal(got_rgb.view(np.uint32), all_rgb.view(np.uint32))
     h.close()
