@@ -31,7 +31,10 @@ __device__ static const double kLogfTab[16][2] = {
     {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
     {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
     {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
-__device__ __forceinline__ float glibcLogf(float x)
+// tab: the table's home -- constant memory, or a workgroup's copy in LDS (the fused K_B kernels: two table reads per dB value are
+// dependent loads in front of the fp64 chain)
+typedef const double (*LogfTable)[2];
+__device__ __forceinline__ float glibcLogf(float x, LogfTable tab = kLogfTab)
 {
     uint32_t ix = __float_as_uint(x);
     if (ix == 0x3f800000u) return 0.f;
@@ -44,7 +47,7 @@ __device__ __forceinline__ float glibcLogf(float x)
     const int i = int((tmp >> 19) & 15u);
     const int k = int(tmp) >> 23;                               // arithmetic shift
     const uint32_t iz = ix - (tmp & (0x1ffu << 23));
-    const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
+    const double invc = tab[i][0], logc = tab[i][1];
     const double z = double(__uint_as_float(iz));
     const double r = z * invc - 1.0;
     const double y0 = logc + double(k) * 0x1.62e42fefa39efp-1;
@@ -55,10 +58,15 @@ __device__ __forceinline__ float glibcLogf(float x)
     return float(y);
 }
 
-__device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalars &sc)
+__device__ __forceinline__ float dbMap(float slope, float st, const DeviceScalars &sc, LogfTable tab = kLogfTab)
 {
     const float deltaX = slope * st * sc.minFracRecip;          // :1343 (left-to-right fp32)
-    return deltaX > 0.f ? glibcLogf(deltaX) * sc.deltaYRecip : sc.lowerClip;   // :1345, std::log(float) = logf
+    return deltaX > 0.f ? glibcLogf(deltaX, tab) * sc.deltaYRecip : sc.lowerClip;   // :1345, std::log(float) = logf
+}
+// the table into LDS (every thread of the workgroup calls; a barrier must follow before the first use)
+__device__ __forceinline__ void stageLogfTable(double (*dst)[2])
+{
+    if (threadIdx.x < 32) reinterpret_cast<double *>(dst)[threadIdx.x] = reinterpret_cast<const double *>(kLogfTab)[threadIdx.x];
 }
 
 // renderSf + the additive blend of one pair's colour into the column buffer, SpectrumDSP.cpp:119-174

@@ -220,6 +220,8 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
     __shared__ float carryS[kFusedChunks][PX];                  // exact state at the end of chunk d (after the fold)
     __shared__ float magS[kFusedChunks * kMaxChunk][PX];
     __shared__ uint32_t progress;                               // carryS[d] is final for every d < progress
+    __shared__ double logTab[16][2];
+    stageLogfTable(logTab);
     const uint32_t progressAddr = uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)&progress));
     if (threadIdx.x == 0) progress = 0;
     const uint32_t tid = threadIdx.x;
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(1024) decayColourFusedKernel(const DecayParams
             }
         const float st = a > cr ? a : cr;
         float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
-        blendColour(cb, dbMap(prm.slope[pixel], st, prm.sc), prm.colourTables, prm.sc);
+        blendColour(cb, dbMap(prm.slope[pixel], st, prm.sc, logTab), prm.colourTables, prm.sc);
         reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
     }
 }
@@ -344,6 +346,8 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
     __shared__ float magS[kFusedChunks * kMaxChunk][SIDES][PX];
     __shared__ float stIn[NCMB][PX];
     __shared__ uint32_t progress;                               // carryS[d] is final for every d < progress (all combinations)
+    __shared__ double logTab[16][2];
+    stageLogfTable(logTab);
     const uint32_t progressAddr = uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)&progress));
     if (threadIdx.x == 0) progress = 0;
     const uint32_t tid = threadIdx.x;
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
             if (prm.state && long(f) == prm.frames - 1) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st;
             const bool colour = side == 0 && k == 0 && prm.rgba;
             if (!colour && !prm.lines) continue;
-            res[side] = dbMap(slope, st, prm.sc);
+            res[side] = dbMap(slope, st, prm.sc, logTab);
             if (colour) blendColour(cb, res[side], prm.colourTables, prm.sc);
         }
         if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
@@ -752,6 +756,8 @@ __global__ void __launch_bounds__(256) decayEmitPairsKernel(const DecayParams pr
     constexpr int PL = 8;                                       // pairs per pass
     __shared__ float cv[kMaxChunk][PL][32][3];
     __shared__ float st[kMaxChunk][256];
+    __shared__ double logTab[16][2];
+    stageLogfTable(logTab);
     static_assert(G == 2, "two line graphs");
     const int px = threadIdx.x & 31, pl = threadIdx.x >> 5;     // pl: pair lane (contributions) / frame in the chunk (blend)
     const uint32_t groups = (prm.P + 31) / 32;
@@ -799,7 +805,7 @@ __global__ void __launch_bounds__(256) decayEmitPairsKernel(const DecayParams pr
                         const long f = f0 + i;
                         if (prm.state && f == prm.frames - 1) prm.state[((size_t(pair) * G + k) * prm.P + pixel) * 2 + side] = si;
                         if (!colour && !prm.lines) continue;
-                        const float result = dbMap(slope, si, prm.sc);
+                        const float result = dbMap(slope, si, prm.sc, logTab);
                         if (prm.lines) {
                             float *lr = prm.lines + (((size_t(f) * prm.C + pair) * G + k) * prm.P + pixel) * 2;
                             lr[side] = result;
