@@ -120,6 +120,20 @@ def test_library_exports_every_symbol_the_header_declares():
     assert L.sgz_abi_version() == 3
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/sgz.h is the drop-in boundary: it must compile as C99 and as C++11 on its own (no torch / HIP types in the signatures)"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "sgz.h"\nint main(void) { sgz_spectrum_config c; sgz_scope_config s; sgz_vector_config v; (void)c; (void)s; (void)v; return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"], ["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the C layout (the parity tests pass these structs across the ABI)"""
     assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4 + 8   # incl. align padding; algorithm, free_q
