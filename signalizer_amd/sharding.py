@@ -223,9 +223,9 @@ class TimeChunkRenderer:
         sync(); dist.barrier(); sync()
         return (time.perf_counter() - t0) / iters * 1e3
 
-    def time_stft_kernel(self, iters: int = 50) -> float:
-        """duration (ms) of the dominant kernel's launch -- K_A alone, sgz_stage_mapped_dominant -- HIP events on the launch stream around
-        every launch, median over `iters` (warm-up, then the median)"""
+    def time_stft_kernel(self, iters: int = 50, spin_ms: float = 60.0) -> float:
+        """average launch duration (ms) of the dominant kernel -- K_A alone, sgz_stage_mapped_dominant -- HIP events on the launch stream
+        around batches of `iters` launches, median of five batches, at the device's sustained clock"""
         import ctypes
         torch = self.torch
         from . import api
@@ -234,20 +234,30 @@ class TimeChunkRenderer:
         F = self.local_frames
         mapped = torch.empty((F, self.plan.C, self.plan.sides, self.plan.P), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream().cuda_stream
-        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-        hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
         call = lambda: api.check(api.lib().sgz_stage_mapped_dominant(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1],
                                                            mapped.data_ptr(), stream))
-        for _ in range(5):
-            call()
+        # `spin_ms` of untimed launches first: the device's clock settles only under sustained load (tools/clock_ramp_probe.py), and a
+        # host wait after every launch would idle the GPU for ~20 us each time
+        import time
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < spin_ms:
+            for _ in range(32):
+                call()
+            torch.cuda.synchronize()
+        # one event pair around `iters` launches back to back (an event between every two launches costs ~2 us of its own): the
+        # average launch duration of the batch; the median of five batches
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
         samples = []
-        for _ in range(iters):
+        for _ in range(5):
             hip.hipEventRecord(e0, ctypes.c_void_p(stream))
-            call()
+            for i in range(iters):
+                call()
             hip.hipEventRecord(e1, ctypes.c_void_p(stream))
             hip.hipEventSynchronize(e1)
             ms = ctypes.c_float()
             hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)
-            samples.append(ms.value)
+            samples.append(ms.value / iters)
+        hip.hipEventDestroy(e0); hip.hipEventDestroy(e1)
         samples.sort()
         return samples[len(samples) // 2]
