@@ -1,4 +1,4 @@
-"""K_A timing loop for kernel work: average launch duration (HIP events on the launch stream) of sgz_stage_mapped at
+"""K_A timing loop for kernel work: average launch duration (HIP events on the launch stream, sustained clock) of sgz_stage_mapped at
 cfg2 (348 frames, 2 rounds on 256 CUs) and at a tail-free size (8 pairs x 348 = 2784 tasks), plus the whole step.
 usage: [SGZ_WHOLE_FRAME=1] ka_time.py [iters]     (SGZ_WHOLE_FRAME=1: plan option SGZ_OPT_CHANNEL_SPLIT = 0, the whole-frame / halves kernels)"""
 import sys, os, ctypes
@@ -6,18 +6,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from signalizer_amd import api, config, synth
 
-def timeit(fn, iters):
+def timeit(fn, iters, spin_ms=60.0, batches=5):
+    """(median, min) over `batches` of the average duration (us) of `iters` calls back to back between ONE event pair, after `spin_ms` of
+    untimed calls: the device's clock settles only under sustained load (tools/clock_ramp_probe.py; an event pair around every call
+    also adds ~2 us to each)"""
+    import time
     hip = ctypes.CDLL("libamdhip64.so")
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
     hip.hipEventCreate(ctypes.byref(e0)); hip.hipEventCreate(ctypes.byref(e1))
-    for _ in range(10): fn()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_ms:
+        for _ in range(32): fn()
+        torch.cuda.synchronize()
     tot = []
-    for _ in range(iters):
-        hip.hipEventRecord(e0, ctypes.c_void_p(stream)); fn(); hip.hipEventRecord(e1, ctypes.c_void_p(stream))
+    for _ in range(batches):
+        hip.hipEventRecord(e0, ctypes.c_void_p(stream))
+        for _ in range(iters): fn()
+        hip.hipEventRecord(e1, ctypes.c_void_p(stream))
         hip.hipEventSynchronize(e1)
-        ms = ctypes.c_float(); hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1); tot.append(ms.value * 1e3)
-    return float(np.mean(tot)), float(np.min(tot))
+        ms = ctypes.c_float(); hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1); tot.append(ms.value * 1e3 / iters)
+    return float(np.median(tot)), float(np.min(tot))
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100

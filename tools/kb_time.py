@@ -1,5 +1,4 @@
-"""K_B alone on precomputed magnitudes (sgz_stage_decay_colour), image only and with line results + state: HIP events around one
-launch (≈ 2 us of event overhead included).  usage: [SGZ_LIB=...] kb_time.py [iters]"""
+"""K_B alone on precomputed magnitudes (sgz_stage_decay_colour), image only and with line results + state: HIP events around batches of launches at the sustained clock.  usage: [SGZ_LIB=...] kb_time.py [iters]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""The step with line results and end state (K_A + the full fused K_B), and that K_B alone on precomputed magnitudes: HIP events.
+"""The step with line results and end state (K_A + the full fused K_B), and that K_B alone on precomputed magnitudes: HIP events around batches at the sustained clock.
 usage: [SGZ_LIB=...] state_time.py [iters]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
