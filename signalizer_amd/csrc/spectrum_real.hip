@@ -169,6 +169,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         const long per = nbr / 8, extra = nbr % 8;
         unit = base + x * per + (x < extra ? x : extra) + i;
     }
+    // Wave priorities for a launch of two full generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident per CU).
+    // tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the older ones free, and the
+    // launch ends when IT ends -- the chain "older workgroup -> third generation" is the critical path, the younger co-residents have
+    // ~10 us of slack.  Generations 0 and 2 run at priority 3, generation 1 at 0: -0.34 us of 28.7 (sustained clock, tools/ab3.sh);
+    // with more generations one of every two co-residents starves (+8 % on a 2784-workgroup launch), hence the narrow condition.
+    // (A speed assumption only.)
+    if constexpr (LR1 == 4) {
+        const uint32_t cus = prm.roundSize >> 1;
+        if (cus && gridDim.x > 2u * cus && gridDim.x <= 3u * cus) {
+            if (blockIdx.x / cus == 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+        }
+    }
     const int side = MONO ? 0 : int(unit & 1);
     long task = MONO ? unit : unit >> 1;                // (frame, pair)
     if (prm.C > 1) { const long pr = task / prm.frames, fr = task - pr * prm.frames; task = fr * prm.C + pr; }
