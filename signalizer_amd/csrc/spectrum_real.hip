@@ -169,16 +169,17 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         const long per = nbr / 8, extra = nbr % 8;
         unit = base + x * per + (x < extra ? x : extra) + i;
     }
-    // Wave priorities for a launch of two full generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident per CU).
-    // tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the older ones free, and the
-    // launch ends when IT ends -- the chain "older workgroup -> third generation" is the critical path, the younger co-residents have
-    // ~10 us of slack.  Generations 0 and 2 run at priority 3, generation 1 at 0: -0.34 us of 28.7 (sustained clock, tools/ab3.sh);
-    // with more generations one of every two co-residents starves (+8 % on a 2784-workgroup launch), hence the narrow condition.
-    // (A speed assumption only.)
+    // Wave priorities for a launch of two full dispatch generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident
+    // per CU).  tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the first frees
+    // and the launch ends when IT ends; its workgroups share their CU with second-generation ones that have ~10 us of slack.  Third
+    // generation at priority 3, first at 2, second at 1: -0.6 us of a 28.7 us launch at the sustained clock (tools/ab3.sh; every
+    // assignment with the last generation on top measures within 0.1 us of this one, 3 / 0 / 3 half the gain, 3 / 0 / 0 a loss).
+    // Longer launches are left alone.  (A speed assumption only.)
     if constexpr (LR1 == 4) {
         const uint32_t cus = prm.roundSize >> 1;
         if (cus && gridDim.x > 2u * cus && gridDim.x <= 3u * cus) {
-            if (blockIdx.x / cus == 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+            const uint32_t generation = blockIdx.x / cus;
+            if (generation == 0u) __builtin_amdgcn_s_setprio(2); else if (generation == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
         }
     }
     const int side = MONO ? 0 : int(unit & 1);
