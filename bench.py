@@ -318,7 +318,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--spinup-ms", type=float, default=80.0, help="untimed back-to-back steps before the warm-up steps, so that the device runs at "
+    ap.add_argument("--spinup-ms", type=float, default=150.0, help="untimed back-to-back steps before the warm-up steps, so that the device runs at "
                                                                    "its sustained clock when the timed region starts (0: none)")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the contract line (tail-free launch, step with state "
                                                               "outputs): tools/profile.sh, so that the profiled dispatches are the workload's only")
@@ -408,14 +408,26 @@ def main() -> None:
     # launch for the first ~4 ms from idle and settles at ~31 us after ~35 ms).  SURVEY.md 8(d)'s steady-state protocol repeats the job
     # back to back; a timed region of K = 20 steps is 0.8 ms.  So the device is spun up with the same steps first (untimed, not part
     # of the W warm-up steps), and the line says for how long.
-    spin_t0 = time.perf_counter()
+    # (the number of steps is the same on every rank -- a step of a sharded render holds collectives: 32 steps are timed, the slowest
+    # rank's time decides)
     spun = 0
-    while (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
+    if args.spinup_ms > 0:
+        torch.cuda.synchronize()
+        spin_t0 = time.perf_counter()
         for _ in range(32):
             step()
-        spun += 32
-        if spun % 256 == 0:
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        probe = torch.tensor([time.perf_counter() - spin_t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+        per_step_ms = max(float(probe.item()) * 1e3 / 32, 1e-3)          # (measured from idle with a wait at the end: an overestimate)
+        spun = 32
+        todo = min(int(args.spinup_ms / per_step_ms), 20000) // 32 * 32
+        for i in range(todo):
+            step()
+            if i % 256 == 255:
+                torch.cuda.synchronize()
+        spun += todo
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
