@@ -20,8 +20,10 @@ extern "C" {
 #endif
 
 /* 3: sgz_spectrum_config grew algorithm / free_q, sgz_scope_config custom_trigger / custom_trigger_frequency (round 3);
+ * 4: sgz_spectrum_config grew display_mode (ZERO = the line graph, as in the reference's enum), sgz_spectrum_render_lines,
+ *    sgz_spectrum_set_option (round 4);
  * a binding compares sgz_abi_version() with the header it was compiled against */
-#define SGZ_ABI_VERSION 3
+#define SGZ_ABI_VERSION 4
 
 typedef enum sgz_status {
     SGZ_OK = 0,
@@ -43,6 +45,12 @@ enum { SGZ_CH_LEFT = 0, SGZ_CH_RIGHT, SGZ_CH_MERGE, SGZ_CH_SIDE, SGZ_CH_PHASE, S
  * a frame is the windowed resonator state every `hop` samples (audioEntryPoint :1172-1201, mapToLinearSpace :1103-1133).  The
  * resonator itself is cpl::dsp::CComplexResonator (absent submodule): restated from its published mathematics, see resonator.hip. */
 enum { SGZ_ALGO_FFT = 0, SGZ_ALGO_RSNT = 1 };
+/* SpectrumContent::DisplayMode, Source/Spectrum/SpectrumParameters.h:60-64 (constant.displayMode, Spectrum.cpp:439).  Only the real-time
+ * handle reads it: LINE_GRAPH -- the audio thread transforms nothing (TransformDSP.inl:1167; RSNT: it keeps the resonators running,
+ * :1206-1209) and the render thread transforms the current history once per video frame (sgz_spectrum_render_lines =
+ * SpectrumRendering.cpp:617-635); COLOUR_SPECTRUM -- a frame every `hop` samples on the audio thread, columns through the frame queue.
+ * Plans and the offline / stage entry points ignore it (they are the colour spectrum's chain). */
+enum { SGZ_DISPLAY_LINE_GRAPH = 0, SGZ_DISPLAY_COLOUR_SPECTRUM = 1 };
 /* SpectrumContent::BinInterpolation */
 enum { SGZ_INTERP_NONE = 0, SGZ_INTERP_LINEAR, SGZ_INTERP_LANCZOS };
 /* SpectrumContent::ViewScaling */
@@ -89,6 +97,8 @@ typedef struct sgz_spectrum_config {
     double   ratios[SGZ_NUM_SPEC_COLOURS];            /* content->specRatios (normalised values)      */
     uint32_t algorithm;          /* SGZ_ALGO_*: constant.algo, Spectrum.cpp:367                                  */
     uint32_t free_q;             /* RSNT: content->freeQ (Spectrum.cpp:593): bandwidths not bounded by the window */
+    uint32_t display_mode;       /* SGZ_DISPLAY_*: constant.displayMode (real-time handle only)                   */
+    uint32_t _reserved;
 } sgz_spectrum_config;
 
 typedef struct sgz_timing {         /* filled by the batch entry points when non-NULL */
@@ -346,8 +356,31 @@ sgz_status sgz_spectrum_bind_image(sgz_spectrum *s, void *d_image, uint32_t colu
 sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d_image, size_t *pitch_bytes, int *dmabuf_fd);
 sgz_status sgz_spectrum_bind_gl_buffer(sgz_spectrum *s, unsigned int gl_buffer, uint32_t columns, size_t pitch_bytes);
 sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, uint32_t *count);
-/* lineGraphs[graph].getResults(P) for pair `pair`: float2 [P] (TransformPair.h:72-76) */
+/* lineGraphs[graph].getResults(P) for pair `pair`: float2 [P] (TransformPair.h:72-76).  COLOUR_SPECTRUM: the results of the newest
+ * frame whose copy has reached the host (a pinned triple buffer the producer's stream fills: this call waits for nothing and never
+ * touches the producer's stream); LINE_GRAPH: the results of the last sgz_spectrum_render_lines. */
 sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t graph, float *out /*2*P*/);
+/* DisplayMode::LineGraph, once per video frame on the render (consumer) thread: Spectrum::vectorGLRendering's
+ *     pair.prepareTransform(constant, views) -> doTransform -> mapToLinearSpace -> postProcessStdTransform
+ * for every pair (Source/Spectrum/SpectrumRendering.cpp:617-635; whole-ring prepareTransform TransformDSP.inl:39-231): the W newest
+ * samples of the device ring are transformed and mapped, BOTH graphs' peak-decay filters advance once, and lineGraphs[k].results of every
+ * pair come back: out = float2 [pairs][graphs][P] (what renderTransformAsGraph reads, SpectrumRendering.cpp:823-891).  RSNT: the windowed
+ * state of the resonators as of the last pushed block (mapToLinearSpace's RSNT branch, :1103-1133).
+ * poles: the graphs' decay for THIS video frame (the reference derives it from openGLDeltaTime(), Spectrum.cpp:388-394), or NULL =
+ * the configured ones.  Waits for its own result (it is the render thread's call); never delays push.  SGZ_EINVAL on a
+ * COLOUR_SPECTRUM handle. */
+sgz_status sgz_spectrum_render_lines(sgz_spectrum *s, const float *poles /*[SGZ_NUM_GRAPHS] or NULL*/, float *out /*[pairs][graphs][P][2]*/);
+/* Handle switches (consumer thread, between create / configure and the first push; a configure keeps them):
+ *   SGZ_RT_OPT_STRICT_REFERENCE_QUIRKS  0 (default): ideal STFT framing -- a frame fires every `hop` samples wherever that falls inside a
+ *       host block.  1: audioEntryPoint as written (TransformDSP.inl:1165-1211): every frame of one callback is prepared
+ *       from the history BEFORE the callback plus the first min(availableSamples, W) samples of the UN-offset block (Q1: a 512-sample
+ *       block at hop 200 yields the same window twice), and with an audio history longer than the window the frame is
+ *       `history - W` samples short and zero-padded (Q2, :245-257).  Identical to the default whenever blocks divide the hop.
+ *   SGZ_RT_OPT_AUDIO_HISTORY            the reference stream's audioHistorySize in samples (>= W; default and 0 = W, what
+ *       Spectrum.cpp:472-477 asks for).  Read in strict mode only. */
+#define SGZ_RT_OPT_STRICT_REFERENCE_QUIRKS 1u
+#define SGZ_RT_OPT_AUDIO_HISTORY 2u
+sgz_status sgz_spectrum_set_option(sgz_spectrum *s, uint32_t option, uint64_t value);
 sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                                   /* clearAudioState, TransformPair.h:177-184 */
 /* MixGraphListener::deliver's routing: destination channel d (of the 2*num_pairs the transform sees) = the sum of the source channels
  * c with matrix[d * num_sources + c] != 0, added in ascending c onto a cleared row (copyFromHead<true> into matrix.clear()'ed
@@ -355,7 +388,8 @@ sgz_status sgz_spectrum_clear_state(sgz_spectrum *s);                           
 sgz_status sgz_spectrum_set_mix(sgz_spectrum *s, uint32_t num_sources, const uint8_t *matrix /*[2*num_pairs][num_sources]*/);
 /* columns dropped because the queue was full (SpectrumDSP.cpp:185-186) and pushes refused with SGZ_BUSY, since create */
 sgz_status sgz_spectrum_stats(sgz_spectrum *s, uint64_t *dropped_columns, uint64_t *refused_pushes);
-/* push never waits and never leaves a hole in the stream: a block the GPU is not ready for (all 8 staging slots in flight) waits in a
+/* (sgz_spectrum_backlog and sgz_spectrum_stats read atomics: a UI thread may poll them while the audio thread pushes.)
+ * push never waits and never leaves a hole in the stream: a block the GPU is not ready for (all 8 staging slots in flight) waits in a
  * host FIFO -- one second of audio deep, like the reference's cpl::AudioStream in front of its listeners (PluginProcessor.cpp:195-198,
  * MixGraphListener.cpp:336-387) -- and is enqueued, in order, by the next push that finds a slot free.  SGZ_BUSY is returned only when
  * that FIFO is full (or a reconfiguration holds the handle).  deferred_blocks: blocks that ever waited there; waiting_now: its depth.

@@ -72,7 +72,7 @@ class VectorFilters(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "scope_spectral.c", "resonator.c", "sgz_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "scope_spectral.c", "resonator.c", "spectrum_stream.c", "sgz_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -193,12 +193,29 @@ def lib() -> C.CDLL:
         L.sgzo_colour_smooth_pole.argtypes = [C.c_double, C.c_double]
         L.sgzo_colour_accumulate.restype = None
         L.sgzo_colour_accumulate.argtypes = [vp, vp, vp, C.c_float, vp]
+        L.sgzo_stream_create.restype = vp
+        L.sgzo_stream_create.argtypes = [C.POINTER(SpectrumParams), C.c_uint32, C.c_size_t]
+        L.sgzo_stream_destroy.restype = None
+        L.sgzo_stream_destroy.argtypes = [vp]
+        L.sgzo_stream_audio.restype = C.c_long
+        L.sgzo_stream_audio.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, C.c_size_t]
+        L.sgzo_stream_render_lines.restype = C.c_int
+        L.sgzo_stream_render_lines.argtypes = [vp, vp, vp]
+        L.sgzo_stream_filters_given.restype = None
+        L.sgzo_stream_filters_given.argtypes = [vp, vp, vp, vp]
+        L.sgzo_stream_history.restype = None
+        L.sgzo_stream_history.argtypes = [vp, C.c_uint32, C.c_size_t, vp]
+        L.sgzo_stream_counter.restype = C.c_size_t
+        L.sgzo_stream_counter.argtypes = [vp]
         _lib = L
     return _lib
 
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+_PARAM_FIELDS = {f[0] for f in SpectrumParams._fields_}
 
 
 def params_from_dict(d: dict) -> SpectrumParams:
@@ -215,7 +232,7 @@ def params_from_dict(d: dict) -> SpectrumParams:
         elif k == "ratios":
             for i in range(NUM_SPEC_COLOURS):
                 p.ratios[i] = float(v[i])
-        else:
+        elif k in _PARAM_FIELDS:                      # (keys of the handle's configuration the chain does not read, e.g. display_mode, are not params)
             setattr(p, k, v)
     return p
 
@@ -634,3 +651,61 @@ def track_peak(p: SpectrumParams, source: np.ndarray, scale: float, mouse_fracti
     lib().sgzo_track_peak(C.byref(p), _ptr(src), src.size - 1, _ptr(mapped), scale, mouse_fraction, _ptr(out))
     keys = ("peak_offset", "peak_fraction", "peak_frequency", "peak_dbs", "alpha", "beta", "gamma", "phi")
     return dict(zip(keys, out.tolist()))
+
+
+# ----------------------------------------------------------------------------- the Spectrum view as a stream (spectrum_stream.c)
+DISPLAY_LINE_GRAPH, DISPLAY_COLOUR_SPECTRUM = 0, 1
+
+
+class SpectrumStream:
+    """The reference's two threads on one pair list: audio(block) = onStreamAudio (audioEntryPoint with quirks Q1 / Q2, frames blended
+    into columns), render_lines() = vectorGLRendering's LineGraph case (whole-ring transform, filters advanced once per call)."""
+
+    def __init__(self, p: SpectrumParams, display_mode: int = DISPLAY_COLOUR_SPECTRUM, history: int = 0):
+        self.p = p
+        self.h = lib().sgzo_stream_create(C.byref(p), display_mode, history)
+        assert self.h, "sgzo_stream_create failed"
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sgzo_stream_destroy(self.h)
+            self.h = None
+
+    def audio(self, block: np.ndarray, max_frames: int | None = None):
+        """block [2*pairs][n] float32 -> dict(frames, rgba [frames][P][4], lines [C][G][P] c64, mapped [frames][C][2P] c64)"""
+        block = np.ascontiguousarray(block, np.float32)
+        nch, n = block.shape
+        assert nch == 2 * self.p.num_pairs
+        P, Cn = self.p.axis_points, self.p.num_pairs
+        if max_frames is None:
+            max_frames = n // max(1, self.p.hop) + 2
+        rgba = np.zeros((max_frames, P, 4), np.uint8)
+        lines = np.zeros((Cn, NUM_GRAPHS, P), np.complex64)
+        mapped = np.zeros((max_frames, Cn, 2 * P), np.complex64)
+        ptrs = (C.c_void_p * nch)(*[block[c].ctypes.data for c in range(nch)])
+        F = lib().sgzo_stream_audio(self.h, ptrs, n, _ptr(rgba), _ptr(lines), _ptr(mapped), max_frames)
+        F = min(int(F), max_frames)
+        return dict(frames=F, rgba=rgba[:F], lines=lines, mapped=mapped[:F])
+
+    def render_lines(self):
+        P, Cn = self.p.axis_points, self.p.num_pairs
+        results = np.zeros((Cn, NUM_GRAPHS, P), np.complex64)
+        mapped = np.zeros((Cn, 2 * P), np.complex64)
+        ok = lib().sgzo_stream_render_lines(self.h, _ptr(results), _ptr(mapped))
+        return dict(ok=bool(ok), results=results, mapped=mapped)
+
+    def filters_given(self, csp_all: np.ndarray, want_rgba: bool = False):
+        P, Cn = self.p.axis_points, self.p.num_pairs
+        csp = np.ascontiguousarray(csp_all, np.complex64).reshape(Cn, 2 * P)
+        results = np.zeros((Cn, NUM_GRAPHS, P), np.complex64)
+        rgba = np.zeros((P, 4), np.uint8) if want_rgba else None
+        lib().sgzo_stream_filters_given(self.h, _ptr(csp), _ptr(results), _ptr(rgba) if want_rgba else None)
+        return results, rgba
+
+    def history(self, channel: int, count: int) -> np.ndarray:
+        out = np.zeros(count, np.float32)
+        lib().sgzo_stream_history(self.h, channel, count, _ptr(out))
+        return out
+
+    def counter(self) -> int:
+        return int(lib().sgzo_stream_counter(self.h))

@@ -128,6 +128,28 @@ void sgzo_track_peak(const sgzo_spectrum_params *p, const sgzo_cf *source, uint3
 long sgzo_decay_colour(const sgzo_spectrum_params *p, const sgzo_cf *csp_all, long F, uint8_t *rgba_out, sgzo_cf *line_out);
 void sgzo_logf_array(const float *x, float *y, size_t n);
 
+/* ---------------- the Spectrum view as a stream (spectrum_stream.c): block structure, quirks Q1 / Q2, the line-graph render path ---------------- */
+/* SpectrumContent::DisplayMode (Source/Spectrum/SpectrumParameters.h): LineGraph = the render thread transforms the current history
+ * once per video frame (SpectrumRendering.cpp:617-635); ColourSpectrum = the audio thread emits a frame every `hop` samples */
+enum { SGZO_DISPLAY_LINE_GRAPH = 0, SGZO_DISPLAY_COLOUR_SPECTRUM = 1 };
+typedef struct sgzo_spectrum_stream sgzo_spectrum_stream;
+/* history: audioHistorySize in samples (0 = the window size, what Spectrum.cpp:472-477 asks for; larger values exercise quirk Q2) */
+sgzo_spectrum_stream *sgzo_stream_create(const sgzo_spectrum_params *p, uint32_t display_mode, size_t history);
+void   sgzo_stream_destroy(sgzo_spectrum_stream *s);
+/* onStreamAudio -> AudioDispatcher::dispatch (SpectrumDSP.cpp:63-108) -> audioEntryPoint (TransformDSP.inl:1165-1211, block
+ * prepareTransform :234-484) -> blendAndDispatchSpectrums; then the block enters the history.  rgba_out [max_frames][P][4]; line_out
+ * [pair][graph][P] = lineGraphs[k].results after the callback; mapped_out [max_frames][pair][2P] = every frame's csp.  Returns the
+ * number of frames the callback produced. */
+long   sgzo_stream_audio(sgzo_spectrum_stream *s, const float *const *planar, size_t n, uint8_t *rgba_out, sgzo_cf *line_out,
+                         sgzo_cf *mapped_out, size_t max_frames);
+/* vectorGLRendering's LineGraph case (SpectrumRendering.cpp:617-635; whole-ring prepareTransform TransformDSP.inl:39-231):
+ * results [pair][graph][P], mapped_out [pair][2P] (optional) */
+int    sgzo_stream_render_lines(sgzo_spectrum_stream *s, sgzo_cf *results, sgzo_cf *mapped_out);
+/* parity-chain twin: the filters of every pair advanced by one frame of GIVEN csp values [pair][2P] */
+void   sgzo_stream_filters_given(sgzo_spectrum_stream *s, const sgzo_cf *csp_all, sgzo_cf *results, uint8_t *rgba_out);
+void   sgzo_stream_history(const sgzo_spectrum_stream *s, uint32_t channel, size_t count, float *out);
+size_t sgzo_stream_counter(const sgzo_spectrum_stream *s);           /* pairs[0].processedSamplesSinceLastFrame */
+
 /* ---------------- Oscilloscope (a10..a12) ---------------- */
 typedef struct sgzo_zero_crossing_state {   /* Source/Oscilloscope/StreamPreprocessing.h:315-349 */
     double   state;

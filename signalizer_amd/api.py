@@ -38,7 +38,7 @@ class SpectrumConfig(C.Structure):
         ("clip_db", C.c_double), ("slope_a", C.c_double), ("slope_b", C.c_double),
         ("pole", C.c_float * NUM_GRAPHS), ("colours", (C.c_uint8 * 3) * (NUM_SPEC_COLOURS + 1)),
         ("_pad", C.c_uint8 * 2), ("ratios", C.c_double * NUM_SPEC_COLOURS),
-        ("algorithm", C.c_uint32), ("free_q", C.c_uint32),
+        ("algorithm", C.c_uint32), ("free_q", C.c_uint32), ("display_mode", C.c_uint32), ("_reserved", C.c_uint32),
     ]
 
 
@@ -122,7 +122,7 @@ EXPORTS = [
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
     "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
-    "sgz_spectrum_flush_columns",
+    "sgz_spectrum_flush_columns", "sgz_spectrum_render_lines", "sgz_spectrum_set_option",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
@@ -206,6 +206,8 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_push.argtypes = [vp, vp, u32, u32]
     L.sgz_spectrum_pop_column.argtypes = [vp, vp, C.POINTER(u32)]
     L.sgz_spectrum_line_results.argtypes = [vp, u32, u32, vp]
+    L.sgz_spectrum_render_lines.argtypes = [vp, vp, vp]
+    L.sgz_spectrum_set_option.argtypes = [vp, u32, C.c_uint64]
     L.sgz_spectrum_clear_state.argtypes = [vp]
     L.sgz_spectrum_set_mix.argtypes = [vp, u32, vp]
     L.sgz_spectrum_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -11,6 +11,7 @@ VIEW_LINEAR, VIEW_LOG = range(2)
  WIN_BLACKMAN_NUTTALL, WIN_BLACKMAN_HARRIS, WIN_TRIANGULAR, WIN_WELCH, WIN_GAUSSIAN, WIN_KAISER) = range(13)
 WIN_SYMMETRIC, WIN_PERIODIC = range(2)
 ALGO_FFT, ALGO_RSNT = range(2)   # SpectrumContent::TransformAlgorithm (Source/Spectrum/SpectrumParameters.h:66-69)
+DISPLAY_LINE_GRAPH, DISPLAY_COLOUR_SPECTRUM = range(2)   # SpectrumContent::DisplayMode (SpectrumParameters.h:60-64); real-time handle only
 
 DEFAULT_COLOURS = [(0, 0, 0), (0, 0, 64), (0, 128, 255), (0, 255, 128), (255, 255, 0), (255, 64, 0)]
 
@@ -25,7 +26,7 @@ def spectrum_config(**over) -> dict:
         window_alpha=0.0, window_beta=0.0, view_left=0.0, view_right=1.0, min_log_freq=10.0,
         low_db=-120.0, high_db=0.0, clip_db=-384.0, slope_a=0.0, slope_b=1.0,
         pole=(0.9, 0.99), colours=DEFAULT_COLOURS, ratios=(0.2, 0.2, 0.2, 0.2, 0.2),
-        algorithm=ALGO_FFT, free_q=0,
+        algorithm=ALGO_FFT, free_q=0, display_mode=DISPLAY_COLOUR_SPECTRUM,
     )
     cfg.update(over)
     return cfg

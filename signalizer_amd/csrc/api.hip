@@ -191,13 +191,16 @@ sgz_status resetResonator(Plan &p, hipStream_t stream)
     return SGZ_OK;
 }
 
-static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
+// hopOverride (line-graph mode of the real-time handle): ONE "frame" of that many samples -- the resonators advance over a whole host
+// block (TransformDSP.inl:1206-1209), sample by sample from the carried state, and d_mapped receives the windowed state afterwards
+static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream, uint32_t hopOverride = 0)
 {
     if (frames <= 0) return SGZ_OK;
     if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
+    if (hopOverride && frames != 1) return fail(SGZ_EINVAL, "a block advance of the resonators is one frame");
     ResParams r{};
     r.planar = d_planar; r.chStride = chStride; r.frames = frames;
-    r.hop = p.cfg.hop; r.C = p.C; r.P = p.P; r.mode = p.cfg.channel_mode;
+    r.hop = hopOverride ? hopOverride : p.cfg.hop; r.C = p.C; r.P = p.P; r.mode = p.cfg.channel_mode;
     r.V = p.resV; r.signals = p.stateChannels; r.sides = p.sides; r.firstContinues = true;
     r.coeff = reinterpret_cast<const float2 *>(p.d_resCoeff);
     r.cpow = reinterpret_cast<const float4 *>(p.d_resPow);
@@ -222,6 +225,13 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     return SGZ_OK;
 }
 
+sgz_status runResonatorAdvance(Plan &p, const float *d_planar, size_t chStride, uint32_t nsamples, float *d_mapped, hipStream_t stream)
+{
+    if (!isResonator(p)) return fail(SGZ_EINVAL, "not a resonator plan");
+    if (nsamples == 0) return SGZ_OK;
+    return runResonator(p, d_planar, chStride, 1, d_mapped, stream, nsamples);
+}
+
 sgz_status ensureSecondStream(Plan &p)
 {
     if (!p.shardStream) { hipStream_t cs; SGZ_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking)); p.shardStream = cs; }
@@ -233,7 +243,7 @@ sgz_status ensureSecondStream(Plan &p)
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                           float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock, bool deferLate)
 {
-    p.lateDeferred = nullptr;
+    p.lateDeferred = nullptr; p.lateFrames = 0;
     if (isResonator(p)) {
         if (d_binsOut || d_binsIn) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins");
         return runResonator(p, d_planar, chStride, frames, d_mapped, stream);
@@ -279,7 +289,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         rp.fixFrom[0] = p.realFixFrom[0]; rp.fixFrom[1] = p.realFixFrom[1];
         // the pixels that need both channels: realLateKernel behind the channel workgroups, or -- an image-only render, no low pixels --
         // K_B's fused kernel while it loads the magnitudes (then the step stays at two launches)
-        if (deferLate && !p.realMono && d_mapped && !d_binsOut && p.realLowCount[0] + p.realLowCount[1] == 0) { rp.lateInNext = 1u; p.lateDeferred = d_mapped; }
+        if (deferLate && !p.realMono && d_mapped && !d_binsOut && p.realLowCount[0] + p.realLowCount[1] == 0) { rp.lateInNext = 1u; p.lateDeferred = d_mapped; p.lateFrames = frames; }
         rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
@@ -386,6 +396,11 @@ static sgz_status fillDecayParams(Plan &p, const float *d_mapped, long frames, u
 sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *d_rgba, float *d_lines,
                                  float *d_state, hipStream_t stream, bool magnitudeOnly)
 {
+    // the channel-split K_A in front of this call may have left its late pixels to whoever reads its magnitudes next (runStft, deferLate):
+    // taken over -- buffer and frame count -- before anything can return, so that no later call completes them on another launch's tables
+    float *pending = const_cast<float *>(p.lateDeferred);
+    const long pendingFrames = p.lateFrames;
+    p.lateDeferred = nullptr; p.lateFrames = 0;
     if (frames <= 0) return SGZ_OK;
     p.aggMapped = nullptr;                                   // whatever d_agg held is about to be overwritten (or left stale by a fused launch)
     DecayParams prm;
@@ -395,18 +410,15 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     // the one-launch form of the step with line results / state (one pair, 2 .. 64 chunks; not the scan half of the two-step K_B,
     // whose aggregates the emit half needs in HBM)
     const bool fullFused = !noFused && !magnitudeOnly && p.cfg.channel_mode != SGZ_CH_PHASE && prm.numChunks > 1 && decayFullFusedApplies(prm);
-    if (p.lateDeferred) {
-        // the channel-split K_A in front of this call left its late pixels to whoever reads its magnitudes next (runStft, deferLate)
-        float *pending = const_cast<float *>(p.lateDeferred);
-        p.lateDeferred = nullptr;
-        if (d_mapped == pending && !noFused && p.cfg.channel_mode != SGZ_CH_PHASE && (decayColourFusedApplies(prm) || fullFused)) {
+    if (pending) {
+        if (d_mapped == pending && frames == pendingFrames && !noFused && p.cfg.channel_mode != SGZ_CH_PHASE && (decayColourFusedApplies(prm) || fullFused)) {
             // the fused colour kernel completes those pixels as it loads the magnitudes (spectrum_post.hip): the step stays at two
             // launches.  (Tried for the scan / emit kernels as well: the extra loads sit on their critical path, +3 us each,
             // against 2-5 us for realLateKernel as a launch of its own.)
             prm.late = LateFix{p.d_ny, p.d_nyBest, p.realFixFrom[0], p.realFixFrom[1], p.P, p.scalars.invSize, 0u};
             prm.hasLate = 1u;
         } else {
-            SGZ_HIP(launchRealLate(fillRealLate(p, frames, pending), p.N, stream));
+            SGZ_HIP(launchRealLate(fillRealLate(p, pendingFrames, pending), p.N, stream));
         }
     }
     if (p.cfg.channel_mode == SGZ_CH_PHASE && !magnitudeOnly) {

@@ -845,7 +845,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024 - ldsFloats * 4 - 16;
         if (std::max(nLeft, nRight) * 4 > budget) p.realSplit = false;
     }
-    // Every eligible plan takes it.  Measured on MI355X (tools/ka_time.py, tools/hybrid_probe.py), since the pair exchange stopped costing
+    // Every eligible plan takes it.  Measured on MI355X (tools/ka_time.py; the hybrid whole-frame + half-task launch of round 2 is in NOTES.md), since the pair exchange stopped costing
     // cache maintenance: N = 65536 (cfg5, 32 pairs) 693 us per K_A pass against 1199 us for the half-frame kernels + map kernel;
     // N = 32768 (cfg2, 348 frames = 696 channel workgroups, two per CU) 38.2 us against 44.0 us for the whole-frame kernel; N = 16384
     // 6.9 M against 2.9 M transforms/s for the generic passes.  sgz_plan_set_option(SGZ_OPT_CHANNEL_SPLIT, 0) keeps a plan off it (A/B runs, parity tests against the other kernels).

@@ -147,6 +147,7 @@ struct Plan {
     uint32_t *d_chunkEnds = nullptr, *d_chunkReBase = nullptr, *d_chunkRec = nullptr; float *d_weights12 = nullptr;
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
+    long lateFrames = 0;                   // ... and how many frames that launch covered (d_ny / d_nyBest hold exactly those)
     void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
     float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resPowB = nullptr, *d_resPowBLo = nullptr, *d_resW1 = nullptr, *d_resW2 = nullptr, *d_resTile = nullptr, *d_resGain = nullptr;
     float *d_resState = nullptr;                          // [C][2][V][P] (re, im): the resonators between calls

@@ -26,6 +26,9 @@ int numCUs();
 // the plan's second stream and the fork / join events that tie it to the caller's (created on first use, destroyed with the plan)
 sgz_status ensureSecondStream(Plan &p);
 sgz_status resetResonator(Plan &p, hipStream_t stream);
+// RSNT, line-graph mode: the resonators advance over one host block of `nsamples` (sample by sample from the carried state); d_mapped
+// [C][sides][P] receives the windowed state afterwards
+sgz_status runResonatorAdvance(Plan &p, const float *d_planar, size_t chStride, uint32_t nsamples, float *d_mapped, hipStream_t stream);
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                    float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock = nullptr,
                    bool deferLate = false);
