@@ -15,6 +15,13 @@ magnitude crosses a uint8 truncation.  Instead of a blanket "x % of bytes may di
 import numpy as np
 
 MAP_TOL = 4e-6          # same bar as the bins (tests/test_gpu_spectrum.py BIN_TOL)
+# K_A evaluates a periodic Hann / Hamming window inside the kernel as p0 - p1 cos(phase) (plan option SGZ_OPT_FETCH_WINDOW = 0): every
+# coefficient carries an ABSOLUTE rounding of about one ulp of the window's peak, where the oracle's table (fp64, rounded once)
+# carries a relative one.  On a bin that is sum_n dw_n x_n e^{..}: a random walk of ~ 2^-25 |x_n|, i.e. <= WIN_ABS * invSize * ||x||_2
+# at six sigma (per coefficient: the angle addition's two products and the subtraction, ~ 2.5e-8 rms).  Invisible next to MAP_TOL * (largest bin) for any frame whose energy is spread over the window (8.8e-10 against
+# 1e-6 at cfg2); it is the larger term only where a frame's whole energy sits under the window's feet (the first frames of a stream
+# that starts from silence: tests/test_gpu_stream_modes.py renders one with 480 of 32768 samples non-zero).
+WIN_ABS = 2e-7
 TIE_REL = 1e-5          # relative key distance that counts as an FFT-rounding tie (or the bins' own bar, see _phase_tie_ok)
 CH_PHASE = 4
 
@@ -67,7 +74,7 @@ def _phase_tie_ok(po, p, plan, x, hop, f, pair, px, got, ref, tol, tolc):
     return False
 
 
-def check_render(po, plan, cfg, x, gpu, want_lines=False):
+def check_render(po, plan, cfg, x, gpu, want_lines=False, win_abs=WIN_ABS):
     """Returns (problems: list[str], stats: dict).  x: host float32 [2C][S]."""
     import torch
     p = po.params_from_dict(cfg)
@@ -106,8 +113,8 @@ def check_render(po, plan, cfg, x, gpu, want_lines=False):
     scale = np.zeros((ref.shape[0], ref.shape[1], 1))
     for f in range(ref.shape[0]):
         for c in range(ref.shape[1]):
-            z = (x[2 * c, f * hop:f * hop + W].astype(np.float64) + 1j * x[2 * c + 1, f * hop:f * hop + W]) * win
-            scale[f, c, 0] = inv_size * np.abs(np.fft.fft(z, N)).max()
+            z = (x[2 * c, f * hop:f * hop + W].astype(np.float64) + 1j * x[2 * c + 1, f * hop:f * hop + W])
+            scale[f, c, 0] = inv_size * np.abs(np.fft.fft(z * win, N)).max() + (win_abs / MAP_TOL) * inv_size * np.sqrt((np.abs(z) ** 2).sum())
     scale = np.maximum(scale, 1e-30)
     ties = 0
     finite = np.isfinite(ref) & np.isfinite(got_mapped)
