@@ -68,20 +68,52 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
-    """The CPU oracle (a restatement: 'port') timed on this host, 1 thread, on a bounded sample of the
-    same workload: the first frames of the same buffer until ~budget_s of CPU work."""
+def _native_oracle():
+    """the oracle built for THIS host's ISA (gcc -O3 -march=native, contraction allowed) in a temp dir: timing only (SURVEY.md 8(d));
+    None when the build fails"""
+    import subprocess
+    import tempfile
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="sgz_oracle_native_"), "libsgz_oracle_native.so")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", f"OUT={out}"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = ctypes.CDLL(out)
+        L.sgzo_spectrogram_range.restype = ctypes.c_long
+        return L
+    except Exception:                                              # noqa: BLE001 -- no compiler on the box, unknown -march: report the strict build only
+        return None
+
+
+def cpu_baseline(cfg: dict, x: np.ndarray, budget_s: float = 14.0) -> dict:
+    """The CPU oracle (a restatement: 'port') timed on this host, 1 thread (the reference transforms one stereo pair on one thread,
+    SpectrumDSP.cpp:83), on a bounded sample of the same workload: the first frames of the same buffer, ~budget_s of CPU work in all.
+    Two builds of the same C: the parity build (gcc -O3, strict fp, generic x86-64) and the host's own (gcc -O3 -march=native, contraction
+    allowed -- SURVEY.md 8(d)); `value` is the faster."""
     from oracle import pyoracle as po
     p = po.params_from_dict(cfg)
-    t0 = time.perf_counter()
-    po.spectrogram_range(p, x, 0, 4)
-    per = (time.perf_counter() - t0) / 4
-    nfr = int(max(8, min(348, budget_s / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    po.spectrogram_range(p, x, 0, nfr)
-    dt = time.perf_counter() - t0
-    return {"value": nfr / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {nfr} of 348 frames of the same 60 s stereo buffer, oracle/libsgz_oracle.so (gcc -O3, strict fp), 1 thread of {os.cpu_count()}"}
+    xs = np.ascontiguousarray(x, np.float32)
+    ptrs = (ctypes.c_void_p * xs.shape[0])(*[xs[c].ctypes.data for c in range(xs.shape[0])])
+
+    def run(L, nfr):
+        t0 = time.perf_counter()
+        L.sgzo_spectrogram_range(ctypes.byref(p), ptrs, ctypes.c_size_t(xs.shape[1]), ctypes.c_long(0), ctypes.c_long(nfr), None)
+        return time.perf_counter() - t0
+
+    builds = [("strict", po.lib())]
+    nat = _native_oracle()
+    if nat is not None:
+        builds.append(("native", nat))
+    rates = {}
+    nfr_used = 0
+    for name, L in builds:
+        per = run(L, 4) / 4
+        nfr = int(max(8, min(348, (budget_s / len(builds)) / max(per, 1e-6))))
+        rates[name] = nfr / run(L, nfr)
+        nfr_used = max(nfr_used, nfr)
+    best = max(rates, key=rates.get)
+    return {"value": rates[best], "unit": "frames/s", "cores": 1, "kind": "port", "build": best,
+            "strict_build_value": rates["strict"], "native_build_value": rates.get("native"),
+            "sample": f"first {nfr_used} (at most) of 348 frames of the same 60 s stereo buffer, oracle/*.c (scalar radix-2 FFT): parity build gcc -O3 strict fp "
+                      f"and host build gcc -O3 -march=native, 1 thread of {os.cpu_count()} (the reference runs one thread per stereo pair)"}
 
 
 def cpu_baseline_pairs(cfg: dict, x: np.ndarray, budget_s: float = 12.0) -> dict:
@@ -305,11 +337,20 @@ def rsnt_extra(dev, x_host) -> dict:
         ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
     flops = 8.0 * F * cfg["hop"] * 2 * V * plan.P
+    # what resonateMfmaKernel EXECUTES on the matrix cores: per frame from rest, (signal, vector, 32 resonators) wave and 1024-sample tile
+    # 32 v_mfma_f32_32x32x2_f32 (16 for the real, 16 for the imaginary weights) of 32 * 32 * 2 multiply-adds each
+    mfma = (F - 1) * 2 * V * (plan.P // 32) * (cfg["hop"] // 1024) * 32
+    mfma_flops = mfma * 32 * 32 * 2 * 2
+    FP32_MFMA_PEAK = 157.3
     return {"metric": "RSNT (resonator bank) spectrogram frames/sec, stereo 48 kHz, 1024 axis points, Hann (3 vectors), one frame per 8192 samples",
             "value": F / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames": F, "realtime_factor": 60.0 / (ms * 1e-3),
-            "kernel": "resonateMfmaKernel (fp32 MFMA block sums) + resonateKernel<3> (frame 0) + resonatorChainKernel<3> + resonatorWindowKernel<3> + K_B", "fp32_tflops": flops / (ms * 1e-3) / 1e12,
-            "note": "compute-bound; fp32_tflops counts the recurrence's 8 flops per sample, resonator, vector and signal (the matrix kernel "
-                    "executes 4 of them as v_mfma_f32_32x32x2_f32 block sums); 157.3 TFLOP/s is the fp32 MFMA = vector peak"}
+            "kernel": "resonateMfmaKernel (fp32 MFMA block sums) + resonateKernel<3> (frame 0) + resonatorChainKernel<3> + resonatorWindowKernel<3> + K_B",
+            "mfma_instructions": mfma, "mfma_tflops": mfma_flops / (ms * 1e-3) / 1e12, "mfma_frac_of_peak": mfma_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK,
+            "recurrence_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
+            "note": "compute-bound.  mfma_tflops = multiply-adds the matrix kernel executes (x 2) over the WHOLE render's time (chain, window and K_B "
+                    "kernels included) against the 157.3 TFLOP/s fp32 MFMA peak; profiles/r04*/rsnt_* hold the kernel's own duration and the MFMA "
+                    "counters.  recurrence_equivalent_tflops prices the sample-by-sample recurrence the reference runs (8 flops per sample, "
+                    "resonator, vector and signal) at the same time: a statement about the algorithm, not about the pipe"}
 
 
 def main() -> None:
@@ -332,6 +373,9 @@ def main() -> None:
                     help="N > 1: sgz_spectrogram_render_sharded on its own RCCL communicator (default), or signalizer_amd.sharding over "
                          "torch.distributed's nccl backend")
     ap.add_argument("--halo", choices=("p2p", "allgather"), default="p2p", help="torch implementation only: halo exchange form")
+    ap.add_argument("--allow-torch-fallback", action="store_true",
+                    help="N > 1 with --shard-impl c_abi: if the library's own RCCL path fails on any rank, time signalizer_amd.sharding (the "
+                         "torch.distributed twin) instead of exiting non-zero.  Off by default: a scaling run must never time the twin silently")
     args = ap.parse_args()
 
     import torch
@@ -396,8 +440,14 @@ def main() -> None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             shard, shard_note = cand, "c_abi"
-        else:
+        elif args.allow_torch_fallback:
             shard_note = "torch (the library's own RCCL path failed on some rank" + (f": {err}" if err else "") + ")"
+        else:
+            # loud: sgz_spectrogram_render_sharded is what a scaling run is meant to measure
+            sys.stderr.write(f"[bench rank {rank}] sgz_spectrogram_render_sharded / sgz_comm_create failed" + (f": {err}" if err else " on another rank")
+                             + " -- not falling back to the torch path (pass --allow-torch-fallback or --shard-impl torch to time that one)\n")
+            dist.destroy_process_group()
+            raise SystemExit(3)
     frames_per_rank = shard.local_frames
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -557,8 +607,14 @@ def main() -> None:
             out["roofline"]["frac_no_tail"] = nt["achieved"] / HBM_PEAK_GBPS
             out["roofline"]["no_tail"] = {"tasks": nt["tasks"], "kernel_ms": nt["kernel_ms"], "achieved": nt["achieved"],
                                           "note": "8 stereo pairs of the cfg2 buffer: many rounds of workgroups, so the partial last round does not count (the same channel-split kernel as the headline launch)"}
+        # the like-for-like step (the reference updates lineGraphs[k].states / .results on every frame, TransformDSP.inl:1336-1349) and the
+        # cold number, beside `value` at top level
+        out["single_shot"] = {"ms": single_shot_ms, "value": total_frames * pairs / (single_shot_ms * 1e-3), "unit": "frames/s",
+                              "note": "one render from an idle device (host clock around enqueue + wait; the device is at its idle clock)"}
         if "ms_per_step_with_state" in extra:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
+            out["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
+            out["value_with_state"] = total_frames * pairs / (extra["ms_per_step_with_state"] * 1e-3)
         if "two_in_flight" in extra:
             out["config"]["two_in_flight"] = extra["two_in_flight"]
         if world == 1 and not strong and not args.no_extras:

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "runtime.hpp"
+#include "trace.hpp"
 
 namespace sgz {
 
@@ -243,6 +244,7 @@ sgz_status ensureSecondStream(Plan &p)
 sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped,
                           float *d_binsOut, const float *d_binsIn, hipStream_t stream, unsigned long long *d_phaseClock, bool deferLate)
 {
+    TraceRange range("sgz::runStft (K_A)");
     p.lateDeferred = nullptr; p.lateFrames = 0;
     if (isResonator(p)) {
         if (d_binsOut || d_binsIn) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins");
@@ -398,6 +400,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
 {
     // the channel-split K_A in front of this call may have left its late pixels to whoever reads its magnitudes next (runStft, deferLate):
     // taken over -- buffer and frame count -- before anything can return, so that no later call completes them on another launch's tables
+    TraceRange range("sgz::runDecayColour (K_B)");
     float *pending = const_cast<float *>(p.lateDeferred);
     const long pendingFrames = p.lateFrames;
     p.lateDeferred = nullptr; p.lateFrames = 0;

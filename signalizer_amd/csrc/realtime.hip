@@ -55,6 +55,7 @@
 #include <vector>
 
 #include "rt_common.hpp"
+#include "trace.hpp"
 
 using namespace sgz;
 
@@ -383,6 +384,7 @@ static sgz_status emitFrames(sgz_spectrum *s, uint32_t frames)
 static sgz_status spectrumPushNow(sgz_spectrum *s, const float *const *blk, uint32_t nch, uint32_t n)
 {
     Plan &p = *s->plan;
+    TraceRange range("sgz::spectrum push (stage + ingest + frames)");
     const uint32_t pieces = (n + kPiece - 1) / kPiece;
     // all or nothing: every piece's staging slot must be free now
     for (uint32_t k = 0; k < pieces; ++k) {
@@ -655,6 +657,7 @@ sgz_status sgz_spectrum_render_lines(sgz_spectrum *s, const float *poles, float 
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
     Plan &p = *s->trackPlan;                                  // the consumer's plan (per-launch scratch is per plan)
+    TraceRange range("sgz::spectrum render_lines");
     if (p.cfg.display_mode != SGZ_DISPLAY_LINE_GRAPH) return fail(SGZ_EINVAL, "sgz_spectrum_render_lines: the handle is configured for SGZ_DISPLAY_COLOUR_SPECTRUM");
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     const float *mapped = s->d_lineMapped;

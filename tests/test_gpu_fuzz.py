@@ -47,3 +47,9 @@ def test_stage_realtime_and_scope_sweeps(gpu, tool, count):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(count), "1"], capture_output=True, text=True, timeout=900)
     bad = [l for l in r.stdout.splitlines() if " BAD " in l or l.startswith("BAD") or l.startswith("EXC")]
     assert r.returncode == 0 and not bad, (bad[:5], r.stderr[-500:])
+    # ... and the sweep must have RUN: every tool ends with "bad: <b> of <n>" -- a crash that prints nothing and exits 0 fails here
+    import re
+    tally = [re.match(r"bad: (\d+) of (\d+)", l) for l in r.stdout.splitlines()]
+    tally = [m for m in tally if m]
+    assert len(tally) == 1, (r.stdout[-400:], r.stderr[-400:])
+    assert int(tally[0].group(1)) == 0 and int(tally[0].group(2)) >= count, tally[0].group(0)

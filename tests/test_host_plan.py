@@ -117,7 +117,8 @@ def test_library_exports_every_symbol_the_header_declares():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(api.EXPORTS) == declared
-    assert L.sgz_abi_version() == 3
+    m = re.search(r"#define SGZ_ABI_VERSION (\d+)", hdr)
+    assert m and L.sgz_abi_version() == int(m.group(1)) == 4          # the binary is the header's (4: display_mode, render_lines, handle options)
 
 
 def test_header_is_plain_c(tmp_path):
@@ -136,7 +137,23 @@ def test_header_is_plain_c(tmp_path):
 
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the C layout (the parity tests pass these structs across the ABI)"""
-    assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4 + 8   # incl. align padding; algorithm, free_q
+    assert C.sizeof(api.SpectrumConfig) == 4 * 10 + 8 * 10 + 8 + 18 + 2 + 40 + 4 + 8 + 8   # incl. align padding; algorithm, free_q; display_mode, _reserved
+    # ... and against the compiler's own view of include/sgz.h
+    import shutil
+    import subprocess
+    import tempfile
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "layout.c")
+            open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "sgz.h"\nint main(void) { printf("%zu %zu %zu %zu %zu", '
+                                 'sizeof(sgz_spectrum_config), offsetof(sgz_spectrum_config, display_mode), offsetof(sgz_spectrum_config, ratios), '
+                                 'sizeof(sgz_scope_config), sizeof(sgz_vector_config)); return 0; }\n')
+            exe = os.path.join(d, "layout")
+            subprocess.check_call([cc, "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+            got = [int(v) for v in subprocess.check_output([exe]).split()]
+        assert got == [C.sizeof(api.SpectrumConfig), api.SpectrumConfig.display_mode.offset, api.SpectrumConfig.ratios.offset,
+                       C.sizeof(api.ScopeConfig), C.sizeof(api.VectorConfig)], got
     assert api.SpectrumConfig.ratios.offset % 8 == 0 and api.SpectrumConfig.window_alpha.offset == 40
     assert C.sizeof(api.ScopeView) == 40 and C.sizeof(api.ZeroCrossingState) == 48 and C.sizeof(api.VectorFilters) == 32
 
