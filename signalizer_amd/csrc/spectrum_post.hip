@@ -437,40 +437,62 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
         }
     }
     if (tid < 64) return;                                       // (the fold's wave; the others emit beside it)
-    // 3. emissions
-    // one item per (graph, frame, pixel): 2 x 348 x 4 items on 1024 threads are three rounds of one graph each instead of two rounds of both
-    for (uint32_t e0 = tid - 64; e0 < items * G; e0 += 960) {
-        const uint32_t k = e0 / items, e = e0 - k * items;
-        const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
+    // 3. emissions: one WALKER per (chunk, pixel, graph, half of the chunk).  It starts from the exact state at the end of the previous
+    //    chunk and runs the reference's recurrence itself (state *= pole; if (mag > state) state = mag, TransformDSP.inl:1336-1341 --
+    //    max(local scan, decayed carry) of the per-frame form is that recurrence, the decay being monotone), so a frame costs three
+    //    operations per side before its dB map instead of a replay of the chunk up to it, and the carries are awaited once per walker.
+    constexpr int HALF = kMaxChunk / 2;
+    const uint32_t walkers = prm.numChunks * PX * G * 2;
+    for (uint32_t w = tid - 64; w < walkers; w += 960) {
+        // chunk-major: the first threads take the chunks whose carries are final first
+        const uint32_t h = w & 1u, k = (w >> 1) % G, px = (w / (2 * G)) % PX, chunk = w / (2 * G * PX);
         const uint32_t pixel = pixelGroup() * PX + px;
         if (pixel >= prm.P) continue;
         awaitCarries(progressAddr, chunk);
         const float slope = prm.slope[pixel];
-        float cb[3] = {0.f, 0.f, 0.f};                          // colourBuffer, SpectrumDSP.cpp:170-174
         const float pole = prm.sc.pole[k];
-        float res[2] = {0.f, 0.f};                              // (results[i].phase = 0 in the one-channel modes, :1347)
+        const long f0 = long(chunk) * kMaxChunk;
+        const int len = int(min(long(kMaxChunk), prm.frames - f0));
+        float st[SIDES];
 #pragma unroll
-        for (int side = 0; side < SIDES; ++side) {
-            const uint32_t m = side * G + k;
-            float a = chunk == 0 ? stIn[m][px] : 0.f;
-            float cr = chunk > 0 ? carryS[chunk - 1][m][px] : 0.f;
+        for (int side = 0; side < SIDES; ++side) st[side] = chunk == 0 ? stIn[side * G + k][px] : carryS[chunk - 1][side * G + k][px];
+        if (h) {                                                 // the second half passes over the first half's frames
 #pragma unroll
-            for (int i = 0; i < kMaxChunk; ++i)
-                if (uint32_t(i) <= t) {
-                    const float v = magS[chunk * kMaxChunk + i][side][px];
-                    a = a * pole;
-                    if (v > a) a = v;
-                    cr = cr * pole;
+            for (int i = 0; i < HALF; ++i)
+                if (i < len) {
+#pragma unroll
+                    for (int side = 0; side < SIDES; ++side) {
+                        const float v = magS[f0 + i][side][px];
+                        st[side] = st[side] * pole;
+                        if (v > st[side]) st[side] = v;
+                    }
                 }
-            const float st = a > cr ? a : cr;
-            if (prm.state && long(f) == prm.frames - 1) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st;
-            const bool colour = side == 0 && k == 0 && prm.rgba;
-            if (!colour && !prm.lines) continue;
-            res[side] = dbMap(slope, st, prm.sc, logTab);
-            if (colour) blendColour(cb, res[side], prm.colourTables, prm.sc);
         }
-        if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
-        if (prm.rgba && k == 0) reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+        const int i0 = h ? HALF : 0;
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int i = i0 + j;
+            if (i >= len) break;
+            const long f = f0 + i;
+            float res[2] = {0.f, 0.f};                          // (results[i].phase = 0 in the one-channel modes, :1347)
+#pragma unroll
+            for (int side = 0; side < SIDES; ++side) {
+                const float v = magS[f][side][px];
+                st[side] = st[side] * pole;                     // states[i] *= pole, TransformDSP.inl:1336,:1370
+                if (v > st[side]) st[side] = v;                 // :1338-1341
+                if (prm.lines || (side == 0 && k == 0 && prm.rgba)) res[side] = dbMap(slope, st[side], prm.sc, logTab);
+            }
+            if (prm.state && f == prm.frames - 1) {
+#pragma unroll
+                for (int side = 0; side < SIDES; ++side) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st[side];
+            }
+            if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
+            if (prm.rgba && k == 0) {
+                float cb[3] = {0.f, 0.f, 0.f};                  // colourBuffer, SpectrumDSP.cpp:170-174
+                blendColour(cb, res[0], prm.colourTables, prm.sc);
+                reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+            }
+        }
     }
 }
 
