@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -94,6 +95,108 @@ struct StageRing {
         SGZ_HIP(hipEventRecord(ev[slot], stream));
         used[slot] = true;
         ++seq;
+        return SGZ_OK;
+    }
+};
+
+// Staging for handles whose ingest kernel takes SEVERAL host blocks per launch (Oscilloscope, Vectorscope): push only copies the block
+// behind the ones already waiting in the current pinned slot; the upload and the kernel are enqueued at once when the GPU has finished
+// the previous batch (an idle GPU starts on a block straight away, as before) and otherwise when somebody needs the result -- the render
+// thread's calls (flush on read), a full slot, flush().  A GPU that is behind therefore catches up with ONE staged copy and ONE launch
+// for everything that arrived meanwhile, instead of one of each per audio callback.  Blocks keep their boundaries: the kernel runs the
+// per-callback state machine over them in order.  (Measured, round 4: deferring EVERY submission to the render thread's read -- one
+// launch per rendered frame -- made BASELINE configs[2] / [3] slower, 0.43 -> 0.61 ms and 0.19 -> 0.41 ms per frame: the ingest kernel
+// costs ~20 us per block whether the blocks come in one launch or seven, and what the eager form overlaps with the audio thread's next
+// callbacks the deferred form runs while the render thread waits.)
+//
+// Two threads touch the open batch: the producer (append, submit when full) and the consumer (submit on read).  `busy` is a spin
+// flag around every such step; the producer only ever TRIES it (a block that finds it held waits its turn in the Backlog like one that
+// finds no slot free), the consumer may spin for the few microseconds an append or an enqueue takes.
+struct BatchRing {
+    static constexpr int kSlots = 8;
+    static constexpr uint32_t kMaxBlocks = 16;
+    float *h = nullptr;            // pinned  [kSlots][channels * slotSamples]
+    float *d = nullptr;            // device  [kSlots][channels * slotSamples]
+    hipEvent_t ev[kSlots] = {};
+    bool used[kSlots] = {};
+    uint32_t channels = 0, slotSamples = 0;
+    uint64_t seq = 0;
+    // the open batch lives in slot seq % kSlots: block b = [channels][len[b]] at float offset off[b]
+    uint32_t count = 0, samples = 0;
+    uint32_t off[kMaxBlocks] = {}, len[kMaxBlocks] = {};
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;
+
+    bool tryLock() { return !busy.test_and_set(std::memory_order_acquire); }
+    void lock() { while (busy.test_and_set(std::memory_order_acquire)) { } }
+    void unlock() { busy.clear(std::memory_order_release); }
+
+    sgz_status init(uint32_t nch, uint32_t samplesPerSlot)
+    {
+        release();
+        channels = nch; slotSamples = samplesPerSlot;
+        const size_t bytes = size_t(kSlots) * nch * samplesPerSlot * sizeof(float);
+        SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+        for (int i = 0; i < kSlots; ++i) {
+            SGZ_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            used[i] = false;
+        }
+        seq = 0; count = samples = 0;
+        return SGZ_OK;
+    }
+    void release()
+    {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr;
+        for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        count = samples = 0;
+    }
+    bool fits(uint32_t n) const { return count < kMaxBlocks && samples + n <= slotSamples; }
+    // has the GPU finished with everything submitted so far?  (then a new block may as well start now: batching is for a GPU that is
+    // behind, not a reason to let an idle one wait for the render thread)
+    bool idle()
+    {
+        if (seq == 0) return true;
+        const int slot = int((seq - 1) % kSlots);
+        return !used[slot] || hipEventQuery(ev[slot]) == hipSuccess;
+    }
+    // SGZ_OK: the slot of a NEW batch is free; SGZ_BUSY: its previous upload / kernel is still in flight (nothing waited for)
+    sgz_status slotReady()
+    {
+        const int slot = int(seq % kSlots);
+        if (!used[slot]) return SGZ_OK;
+        const hipError_t q = hipEventQuery(ev[slot]);
+        if (q == hipErrorNotReady) return SGZ_BUSY;
+        if (q != hipSuccess) return hipFail(q, "hipEventQuery");
+        used[slot] = false;
+        return SGZ_OK;
+    }
+    void append(const float *const *planar, uint32_t n)
+    {
+        const int slot = int(seq % kSlots);
+        float *dst = h + size_t(slot) * channels * slotSamples + size_t(channels) * samples;
+        for (uint32_t c = 0; c < channels; ++c) std::memcpy(dst + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
+        off[count] = channels * samples; len[count] = n;
+        samples += n; ++count;
+    }
+    // the open batch -> device (one copy); returns the device address of its first block
+    const float *upload(hipStream_t stream, sgz_status *st)
+    {
+        const int slot = int(seq % kSlots);
+        const size_t at = size_t(slot) * channels * slotSamples;
+        const hipError_t e = hipMemcpyAsync(d + at, h + at, size_t(channels) * samples * sizeof(float), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { *st = hipFail(e, "hipMemcpyAsync"); return nullptr; }
+        *st = SGZ_OK;
+        return d + at;
+    }
+    // after the kernel that reads the batch has been enqueued
+    sgz_status commit(hipStream_t stream)
+    {
+        const int slot = int(seq % kSlots);
+        SGZ_HIP(hipEventRecord(ev[slot], stream));
+        used[slot] = true;
+        ++seq; count = samples = 0;
         return SGZ_OK;
     }
 };

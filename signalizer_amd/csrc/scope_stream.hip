@@ -108,8 +108,9 @@ struct IngestParams {
     ScopeDev *st;
     unsigned long long *peaks;                // [kPeakCap]
     Swap *swapList;                           // [kMaxSwaps]
-    const float *block;                       // [channels][n]
-    uint32_t n, channels;
+    const float *batch;                       // the staged blocks, back to back: block b = [channels][blockLen[b]] at batch + blockOff[b]
+    uint32_t numBlocks, channels;
+    uint32_t blockOff[BatchRing::kMaxBlocks], blockLen[BatchRing::kMaxBlocks];
     float *front; uint32_t size;              // [channels][size]
     float *back; uint32_t backCap;            // [channels][backCap], power of two
     uint32_t triggerMode, oscMode, envMode;
@@ -242,12 +243,22 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     // some thirty times, mostly from one lane and each time behind the last (the kernels of the render thread read the copy in HBM,
     // between launches)
     __shared__ ScopeDev sState;
-    const uint32_t n = prm.n, C = prm.channels;
+    const uint32_t C = prm.channels;
     const int tid = threadIdx.x, T = blockDim.x;
     static_assert(sizeof(ScopeDev) % 4 == 0, "copied as words");
     for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(&sState)[w] = reinterpret_cast<const uint32_t *>(prm.st)[w];
     __syncthreads();
     ScopeDev *st = &sState;
+    constexpr unsigned int kStage = 64;
+    __shared__ unsigned long long sPeaks[kStage];
+    __shared__ Swap sSwaps[kStage];
+    // One launch ingests every block that was waiting (sgz_scope_push only stages; whoever needs the state -- the render thread's calls, a
+    // full batch, sgz_scope_flush -- submits): the blocks go through the reference's per-callback state machine ONE AFTER THE OTHER, with
+    // their boundaries where the host put them (audioEntryPoint runs once per onStreamAudio: update(), the detector, processMutating's
+    // window selection all see callback extents), the stream state staying in LDS in between.
+    for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
+    const float *const blk = prm.batch + prm.blockOff[blockIndex];
+    const uint32_t n = prm.blockLen[blockIndex];
     const unsigned long long playhead = st->playhead;
     ICLK(0);
 
@@ -273,10 +284,10 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             uint32_t localMode = prm.oscMode, pair = prm.trigPair;
             if (localMode == SGZ_OSC_MIDSIDE) { localMode = SGZ_OSC_MID; pair = prm.trigSeparate & ~1u; }     // :340-352
             const float *a, *b;
-            if (localMode == SGZ_OSC_RIGHT) a = b = prm.block + size_t(pair + 1) * n;
-            else if (localMode == SGZ_OSC_LEFT) a = b = prm.block + size_t(pair) * n;
-            else if (localMode == SGZ_OSC_SEPARATE) a = b = prm.block + size_t(prm.trigSeparate) * n;
-            else { a = prm.block + size_t(pair) * n; b = a + n; }
+            if (localMode == SGZ_OSC_RIGHT) a = b = blk + size_t(pair + 1) * n;
+            else if (localMode == SGZ_OSC_LEFT) a = b = blk + size_t(pair) * n;
+            else if (localMode == SGZ_OSC_SEPARATE) a = b = blk + size_t(prm.trigSeparate) * n;
+            else { a = blk + size_t(pair) * n; b = a + n; }
             double state = st->state;
             const double thr2 = st->threshold * st->threshold, hysteresis = st->hysteresis;
             int holding = st->isPeakHold;
@@ -309,10 +320,10 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         uint32_t localMode = prm.oscMode, pair = prm.trigPair;
         if (localMode == SGZ_OSC_MIDSIDE) { localMode = SGZ_OSC_MID; pair = prm.trigSeparate & ~1u; }     // :340-352
         const float *a, *b;
-        if (localMode == SGZ_OSC_RIGHT) a = b = prm.block + size_t(pair + 1) * n;
-        else if (localMode == SGZ_OSC_LEFT) a = b = prm.block + size_t(pair) * n;
-        else if (localMode == SGZ_OSC_SEPARATE) a = b = prm.block + size_t(prm.trigSeparate) * n;
-        else { a = prm.block + size_t(pair) * n; b = a + n; }
+        if (localMode == SGZ_OSC_RIGHT) a = b = blk + size_t(pair + 1) * n;
+        else if (localMode == SGZ_OSC_LEFT) a = b = blk + size_t(pair) * n;
+        else if (localMode == SGZ_OSC_SEPARATE) a = b = blk + size_t(prm.trigSeparate) * n;
+        else { a = blk + size_t(pair) * n; b = a + n; }
         const double threshold = st->threshold, prevState = st->state;
         const int armedIn = st->isPeakHold;
         const unsigned long long originIn = st->crossOrigin;
@@ -369,9 +380,6 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     ICLK(1);
     // ---- B: processMutating's automaton (thread 0) -> swap list.  The head of the trigger queue is fetched by 64 lanes at once and the
     // swap list starts in LDS: the automaton then walks without memory round trips (a block holds a handful of triggers)
-    constexpr unsigned int kStage = 64;
-    __shared__ unsigned long long sPeaks[kStage];
-    __shared__ Swap sSwaps[kStage];
     if (hold && tid < int(kStage) && uint32_t(tid) < st->qCount) sPeaks[tid] = prm.peaks[(st->qHead + uint32_t(tid)) % kPeakCap];
     const unsigned int qHeadIn = st->qHead;
     __syncthreads();
@@ -474,7 +482,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             float k0[5]; for (int j = 0; j < 5; ++j) k0[j] = k[j];
             float (*z)[2] = cs->z[c] + (hp ? 2 : 0);
             float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
-            const float *x = prm.block + size_t(c) * n;
+            const float *x = blk + size_t(c) * n;
             float *out = col.bands + (size_t(c) * 4 + (hp ? 3 : 0)) * MB;
             walkSequential(n, [&](uint32_t i) { return x[i]; },
                            [&](uint32_t i, float v) { out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, v)); });
@@ -542,7 +550,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         for (uint32_t c = 0; c < C; ++c)
             for (uint32_t i = tid; i < m; i += T) {
                 const unsigned long long abs = src + skip + dead + i;
-                const float v = abs >= written0 ? prm.block[size_t(c) * n + uint32_t(abs - written0)]
+                const float v = abs >= written0 ? blk[size_t(c) * n + uint32_t(abs - written0)]
                                                 : prm.back[size_t(c) * prm.backCap + uint32_t(abs & (prm.backCap - 1))];
                 uint32_t d = (cur0 + dead + i) % size;
                 prm.front[size_t(c) * size + d] = v;
@@ -578,7 +586,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         const uint32_t keep = n > prm.backCap ? prm.backCap : n, first = n - keep;
         for (uint32_t e = tid; e < keep * C; e += T) {
             const uint32_t c = e / keep, i = first + (e - c * keep);
-            prm.back[size_t(c) * prm.backCap + uint32_t((written0 + i) & (prm.backCap - 1))] = prm.block[size_t(c) * n + i];
+            prm.back[size_t(c) * prm.backCap + uint32_t((written0 + i) & (prm.backCap - 1))] = blk[size_t(c) * n + i];
         }
         if (prm.colours)
             for (uint32_t e = tid; e < keep * 2 * C; e += T) {
@@ -599,7 +607,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         // from their stored envelope in every call, so only the last call's samples matter for them
         const uint32_t from = tid < 2 ? 0u : lastStart, to = lastStart + lastLen;
         float y = active ? st->envelope[tid] : 0.f;
-        const float *b0 = prm.block, *b1 = prm.block + n, *bc = prm.block + size_t(active ? tid : 0) * n;
+        const float *b0 = blk, *b1 = blk + n, *bc = blk + size_t(active ? tid : 0) * n;
         bool own = false;
         if (mode == SGZ_OSC_SEPARATE) {
             own = true;
@@ -641,6 +649,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         st->playhead = playhead + n;
     }
     __syncthreads();
+    }   // next block of the batch
     for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(prm.st)[w] = reinterpret_cast<const uint32_t *>(&sState)[w];
     ICLK(7);
 }
@@ -977,7 +986,8 @@ struct sgz_scope {
     sgz_scope_config cfg{};
     std::mutex mu;                    // configure (consumer thread) against push (producer: try_lock only, never waits)
     hipStream_t stream = nullptr;
-    StageRing stage;
+    BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
+    uint32_t maxBlock = 0;
     Backlog backlog;                           // blocks waiting for a staging slot (rt_common.hpp)
     ScopeDev *d_state = nullptr;
     unsigned long long *d_peaks = nullptr;
@@ -1003,7 +1013,7 @@ static void scopeFree(sgz_scope *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    s->stage.release();
+    s->batch.release();
     s->backlog.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_peaks, (void *)s->d_swaps, (void *)s->d_front, (void *)s->d_back, (void *)s->d_xyz,
                     (void *)s->d_rgba, (void *)s->col.st, (void *)s->col.bands, (void *)s->col.sm, (void *)s->col.block, (void *)s->col.front,
@@ -1061,7 +1071,7 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
     uint32_t backCap = 1; while (backCap < size) backCap <<= 1;
     const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
     const bool colours = cfg->colour_by_frequency != 0;
-    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock ||
+    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->maxBlock ||
                          colours != (s->cfg.colour_by_frequency != 0);
     ScopeDev h{};
     if (!fresh) SGZ_HIP(hipMemcpy(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost));
@@ -1071,7 +1081,9 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_back), size_t(C) * backCap * sizeof(float)));
         SGZ_HIP(hipMemset(s->d_front, 0, size_t(C) * size * sizeof(float)));
         SGZ_HIP(hipMemset(s->d_back, 0, size_t(C) * backCap * sizeof(float)));
-        if ((st = s->stage.init(C, maxBlock)) != SGZ_OK) return st;
+        // a slot takes a whole batch: the blocks of one rendered frame and more (at least 8192 samples)
+        if ((st = s->batch.init(C, std::max<uint32_t>(maxBlock, 8192u))) != SGZ_OK) return st;
+        s->maxBlock = maxBlock;
         // one second of audio may wait for the GPU (at least 32 blocks)
         if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
         if (!s->d_state) {
@@ -1185,29 +1197,56 @@ sgz_status sgz_scope_create(const sgz_scope_config *cfg, sgz_scope **out)
 
 void sgz_scope_destroy(sgz_scope *s) { scopeFree(s); }
 
+static sgz_status scopeSync(sgz_scope *s);
+
 sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg)
 {
     if (!s || !cfg) return fail(SGZ_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // the audio already taken goes through the old configuration
     return scopeSetup(s, cfg, false);
 }
 
-// one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
-static sgz_status scopePushNow(sgz_scope *s, const float *const *blk, uint32_t nch, uint32_t n)
+// the open batch -> GPU: one staged copy, one launch of the ingest kernel over its blocks (caller holds the batch flag; count > 0)
+static sgz_status scopeSubmit(sgz_scope *s)
 {
     sgz_status st;
-    const float *d_block = s->stage.stage(blk, n, s->stream, &st);
-    if (!d_block) return st;
+    const float *d_batch = s->batch.upload(s->stream, &st);
+    if (!d_batch) return st;
     IngestParams prm{};
     prm.st = s->d_state; prm.peaks = s->d_peaks; prm.swapList = s->d_swaps;
-    prm.block = d_block; prm.n = n; prm.channels = nch;
+    prm.batch = d_batch; prm.numBlocks = s->batch.count; prm.channels = s->cfg.num_channels;
+    for (uint32_t b = 0; b < s->batch.count; ++b) { prm.blockOff[b] = s->batch.off[b]; prm.blockLen[b] = s->batch.len[b]; }
     prm.front = s->d_front; prm.size = s->size; prm.back = s->d_back; prm.backCap = s->backCap;
     prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
     prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
     prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
     hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->col);
     SGZ_HIP(hipGetLastError());
-    return s->stage.commit(s->stream);
+    return s->batch.commit(s->stream);
+}
+
+// one block behind the ones already staged (caller holds the batch flag); SGZ_BUSY (nothing consumed) when a new batch would need a
+// slot whose last upload is still in flight
+static sgz_status scopePushNow(sgz_scope *s, const float *const *blk, uint32_t nch, uint32_t n)
+{
+    (void)nch;
+    if (s->batch.count && !s->batch.fits(n))
+        if (sgz_status st = scopeSubmit(s); st != SGZ_OK) return st;
+    if (s->batch.count == 0)
+        if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
+    s->batch.append(blk, n);
+    if (s->batch.idle()) return scopeSubmit(s);                  // nothing in flight: start now (a busy GPU picks the block up with the next ones)
+    return SGZ_OK;
+}
+
+// consumer side (flush on read): what waits in the open batch goes to the GPU in front of the caller's own work
+static sgz_status scopeSync(sgz_scope *s)
+{
+    s->batch.lock();
+    const sgz_status st = s->batch.count ? scopeSubmit(s) : SGZ_OK;
+    s->batch.unlock();
+    return st;
 }
 
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
@@ -1217,10 +1256,17 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
     if (num_channels != s->cfg.num_channels) return fail(SGZ_EINVAL, "num_channels differs from the configuration");
     if (nsamples == 0) return SGZ_OK;                              // audioEntryPoint returns at once (:403-404)
-    if (nsamples > s->stage.maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_scope_config::max_block");
+    if (nsamples > s->maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_scope_config::max_block");
+    // never waits: the render thread is submitting the open batch right now -> the block waits its turn in the host FIFO, like one
+    // the GPU is not ready for (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
+    if (!s->batch.tryLock()) {
+        const bool queued = s->backlog.push(planar, num_channels, nsamples);
+        if (!queued) s->busy++;
+        return queued ? SGZ_OK : SGZ_BUSY;
+    }
     auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return scopePushNow(s, blk, nch, n); };
-    // never waits: a block the GPU is not ready for queues up behind the earlier ones (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
     const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
+    s->batch.unlock();
     if (st == SGZ_BUSY) s->busy++;
     return st;
 }
@@ -1229,21 +1275,26 @@ sgz_status sgz_scope_flush(sgz_scope *s)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
+    s->batch.lock();
     const float *ptrs[64];
+    sgz_status out = SGZ_OK;
     while (s->backlog.count) {
         const Backlog::Entry e = s->backlog.front();
         for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
         const sgz_status st = scopePushNow(s, ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) { SGZ_HIP(hipStreamSynchronize(s->stream)); continue; }      // this call may wait: it is not the audio thread's
+        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }         // this call may wait: it is not the audio thread's
         s->backlog.pop();
-        if (st != SGZ_OK) return st;
+        if (st != SGZ_OK) { out = st; break; }
     }
-    return SGZ_OK;
+    if (out == SGZ_OK && s->batch.count) out = scopeSubmit(s);
+    s->batch.unlock();
+    return out;
 }
 
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain)
 {
     if (!s || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     // coeff = pow(exp(-lanes / (envelopeWindow * sampleRate)), numSamples * dt), OscilloscopeDSP.inl:745-747
     const bool spectral = s->cfg.trigger_mode == SGZ_TRIG_SPECTRAL;
     const uint32_t numSamples = spectral ? uint32_t(s->trig.ring_size) : s->size;          // audioData.getSize()
@@ -1263,6 +1314,7 @@ sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes
 sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     ScopeDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -1274,6 +1326,7 @@ sgz_status sgz_scope_gains(sgz_scope *s, double *envelope_gain, float *envelopes
 sgz_status sgz_scope_front(sgz_scope *s, uint32_t channel, float *out, uint32_t *size, uint32_t *cursor)
 {
     if (!s || channel >= s->cfg.num_channels) return fail(SGZ_EINVAL, "bad argument");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     ScopeDev h;
     if (out) SGZ_HIP(hipMemcpyAsync(out, s->d_front + size_t(channel) * s->size, size_t(s->size) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
@@ -1287,6 +1340,7 @@ sgz_status sgz_scope_front_colours(sgz_scope *s, uint32_t channel, uint32_t aux,
 {
     if (!s || !out || channel >= s->cfg.num_channels || aux > 1) return fail(SGZ_EINVAL, "bad argument");
     if (!s->cfg.colour_by_frequency) return fail(SGZ_EINVAL, "colour_by_frequency is off");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     const size_t plane = size_t(aux ? s->cfg.num_channels : 0u) + channel;
     SGZ_HIP(hipMemcpyAsync(out, s->col.front + plane * s->size, size_t(s->size) * 4, hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -1308,6 +1362,7 @@ sgz_status sgz_scope_debug_median(sgz_scope *s, double out[24])
 sgz_status sgz_scope_debug_state(sgz_scope *s, uint64_t out[8])
 {
     if (!s || !out) return fail(SGZ_EINVAL, "null argument");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     ScopeDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -1334,6 +1389,7 @@ size_t sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view)
 sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel, sgz_trigger_state *out)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     if (s->cfg.trigger_mode == SGZ_TRIG_SPECTRAL) {
         const uint32_t C = s->cfg.num_channels;
         uint32_t chA, chB, evalMode;
@@ -1373,6 +1429,7 @@ sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel,
 static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
                                     uint32_t *d_rgba, size_t capacity, size_t *points)
 {
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     const uint32_t C = s->cfg.num_channels;
     // SampleColourEvaluator<OscChannels::...>, SampleColourEvaluators.h: Left / Right read one channel, Mid / Side 0.5 (l +- r)
     uint32_t chA, chB, evalMode, colourCh;

@@ -35,7 +35,8 @@ struct VecDev {
 
 struct VecIngest {
     VecDev *st;
-    const float *block; uint32_t n, channels;
+    const float *batch; uint32_t numBlocks, channels;         // the staged blocks back to back: block b = [channels][blockLen[b]] at batch + blockOff[b]
+    uint32_t blockOff[BatchRing::kMaxBlocks], blockLen[BatchRing::kMaxBlocks];
     float *ring; uint32_t size;
     uint32_t lanes, envMode;
     float envelope, pole0, pole1;
@@ -46,7 +47,12 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     __shared__ float sL[64], sR[64], sP[64];
     VecDev *st = prm.st;
     const int tid = threadIdx.x;
-    const uint32_t n = prm.n, size = prm.size, C = prm.channels;
+    const uint32_t size = prm.size, C = prm.channels;
+    // one launch takes every block that was waiting (rt_common.hpp BatchRing), one after the other with the host's block boundaries:
+    // audioProcessing drops the SIMD tail of EVERY callback (Vectorscope.cpp:292)
+    for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
+    const float *const blk = prm.batch + prm.blockOff[blockIndex];
+    const uint32_t n = prm.blockLen[blockIndex];
     const uint32_t cursor0 = st->cursor;
     // ring append (only the newest `size` samples of a longer block survive)
     const uint32_t skip = n > size ? n - size : 0, m = n - skip;
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     for (uint32_t e = tid; e < m * C; e += blockDim.x) {
         const uint32_t c = e / m, i = e - c * m;
         uint32_t d = cur0 + i; if (d >= size) d -= size;
-        prm.ring[size_t(c) * size + d] = prm.block[size_t(c) * n + skip + i];
+        prm.ring[size_t(c) * size + d] = blk[size_t(c) * n + skip + i];
     }
     // audioProcessing on channels 0 / 1 (Vectorscope.cpp:268-377): wave 0; lane k < 8 owns one recurrence:
     // 0,1 envelope L/R; 2,3 slow balance L/R; 4,5 fast balance L/R; 6 slow phase; 7 fast phase
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
             a = lane < 2 ? prm.envelope : ((lane == 2 || lane == 3 || lane == 6) ? prm.pole0 : prm.pole1);
         }
         const int sel = (lane == 0 || lane == 2 || lane == 4) ? 0 : ((lane == 1 || lane == 3 || lane == 5) ? 1 : 2);
-        const float *L = prm.block, *R = prm.block + n;
+        const float *L = blk, *R = blk + n;
         for (uint32_t base = 0; base < np; base += 64) {
             const uint32_t i = base + lane;
             if (i < np) {
@@ -113,6 +119,8 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     }
     __syncthreads();
     if (tid == 0) { st->cursor = (cursor0 + n) % size; st->written += n; }
+    __syncthreads();                                                      // (the next block reads the cursor and the filter states)
+    }
 }
 
 // VectorScope::runPeakFilter: memory-order maximum of |x| over channels 0 / 1 (the last size mod lanes slots dropped), then
@@ -241,7 +249,8 @@ struct sgz_vector {
     sgz_vector_config cfg{};
     std::mutex mu;
     hipStream_t stream = nullptr;
-    StageRing stage;
+    BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
+    uint32_t maxBlock = 0;
     Backlog backlog;                           // blocks waiting for a staging slot (rt_common.hpp)
     VecDev *d_state = nullptr;
     float *d_ring = nullptr;
@@ -260,7 +269,7 @@ static void vectorFree(sgz_vector *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    s->stage.release();
+    s->batch.release();
     s->backlog.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_ring, (void *)s->d_ramp, (void *)s->d_tail, (void *)s->d_xyz, (void *)s->d_rgb})
         if (p) (void)hipFree(p);
@@ -284,7 +293,7 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
     const uint32_t C = cfg->num_channels, size = cfg->window_size;
     if (cfg->max_block > (1u << 17)) return fail(SGZ_EINVAL, "max_block above 131072 samples");
     const uint32_t maxBlock = cfg->max_block ? cfg->max_block : 8192u;
-    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->stage.maxBlock;
+    const bool realloc = fresh || C != s->cfg.num_channels || size != s->size || maxBlock != s->maxBlock;
     if (realloc) {
         for (void **p : {(void **)&s->d_ring, (void **)&s->d_ramp, (void **)&s->d_xyz, (void **)&s->d_rgb}) if (*p) { (void)hipFree(*p); *p = nullptr; }
         if (s->h_out) { (void)hipHostFree(s->h_out); s->h_out = nullptr; }
@@ -296,7 +305,8 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_xyz), pairsCap * size * 3 * sizeof(float)));
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rgb), pairsCap * size * 3 * sizeof(float)));
         SGZ_HIP(hipHostMalloc(&s->h_out, pairsCap * size * 6 * sizeof(float), hipHostMallocDefault));
-        sgz_status st = s->stage.init(C, maxBlock);
+        sgz_status st = s->batch.init(C, std::max<uint32_t>(maxBlock, 8192u));     // a slot takes a whole batch: the blocks of a rendered frame and more
+        s->maxBlock = maxBlock;
         if (st != SGZ_OK) return st;
         // one second of audio may wait for the GPU (at least 32 blocks)
         if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
@@ -339,25 +349,54 @@ sgz_status sgz_vector_create(const sgz_vector_config *cfg, sgz_vector **out)
 
 void sgz_vector_destroy(sgz_vector *s) { vectorFree(s); }
 
+static sgz_status vectorSync(sgz_vector *s);
+
 sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg)
 {
     if (!s || !cfg) return fail(SGZ_EINVAL, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
+    if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // the audio already taken goes through the old configuration
     return vectorSetup(s, cfg, false);
 }
 
-// one block into a staging slot and behind it the kernels that consume it; SGZ_BUSY (nothing consumed) when no slot is free
-static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t nch, uint32_t n)
+// the open batch -> GPU: one staged copy, one launch of the ingest kernel over its blocks (caller holds the batch flag; count > 0)
+static sgz_status vectorSubmit(sgz_vector *s)
 {
     sgz_status st;
-    const float *d_block = s->stage.stage(blk, n, s->stream, &st);
-    if (!d_block) return st;
-    VecIngest prm{s->d_state, d_block, n, nch, s->d_ring, s->size, s->cfg.lanes, s->cfg.envelope_mode,
-                  s->envelopeCoeff, s->stereoCoeff, s->pole1};
+    const float *d_batch = s->batch.upload(s->stream, &st);
+    if (!d_batch) return st;
+    VecIngest prm{};
+    prm.st = s->d_state; prm.batch = d_batch; prm.numBlocks = s->batch.count; prm.channels = s->cfg.num_channels;
+    for (uint32_t b = 0; b < s->batch.count; ++b) { prm.blockOff[b] = s->batch.off[b]; prm.blockLen[b] = s->batch.len[b]; }
+    prm.ring = s->d_ring; prm.size = s->size; prm.lanes = s->cfg.lanes; prm.envMode = s->cfg.envelope_mode;
+    prm.envelope = s->envelopeCoeff; prm.pole0 = s->stereoCoeff; prm.pole1 = s->pole1;
     hipLaunchKernelGGL(vectorIngestKernel, dim3(1), dim3(256), 0, s->stream, prm);
     SGZ_HIP(hipGetLastError());
-    s->pushes.fetch_add(1, std::memory_order_release);
-    return s->stage.commit(s->stream);
+    s->pushes.fetch_add(s->batch.count, std::memory_order_release);
+    return s->batch.commit(s->stream);
+}
+
+// one block behind the ones already staged (caller holds the batch flag); SGZ_BUSY (nothing consumed) when a new batch would need a
+// slot whose last upload is still in flight
+static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t nch, uint32_t n)
+{
+    (void)nch;
+    if (s->batch.count && !s->batch.fits(n))
+        if (sgz_status st = vectorSubmit(s); st != SGZ_OK) return st;
+    if (s->batch.count == 0)
+        if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
+    s->batch.append(blk, n);
+    if (s->batch.idle()) return vectorSubmit(s);                  // nothing in flight: start now (a busy GPU picks the block up with the next ones)
+    return SGZ_OK;
+}
+
+// consumer side (flush on read): what waits in the open batch goes to the GPU in front of the caller's own work
+static sgz_status vectorSync(sgz_vector *s)
+{
+    s->batch.lock();
+    const sgz_status st = s->batch.count ? vectorSubmit(s) : SGZ_OK;
+    s->batch.unlock();
+    return st;
 }
 
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
@@ -367,10 +406,17 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     if (!lk.owns_lock()) { s->busy++; return SGZ_BUSY; }
     if (num_channels != s->cfg.num_channels) return fail(SGZ_EINVAL, "num_channels differs from the configuration");
     if (nsamples == 0) return SGZ_OK;
-    if (nsamples > s->stage.maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_vector_config::max_block");
+    if (nsamples > s->maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_vector_config::max_block");
+    // never waits: the render thread is submitting the open batch right now -> the block waits its turn in the host FIFO, like one the
+    // GPU is not ready for (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
+    if (!s->batch.tryLock()) {
+        const bool queued = s->backlog.push(planar, num_channels, nsamples);
+        if (!queued) s->busy++;
+        return queued ? SGZ_OK : SGZ_BUSY;
+    }
     auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return vectorPushNow(s, blk, nch, n); };
-    // never waits: a block the GPU is not ready for queues up behind the earlier ones (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
     const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
+    s->batch.unlock();
     if (st == SGZ_BUSY) s->busy++;
     return st;
 }
@@ -379,21 +425,26 @@ sgz_status sgz_vector_flush(sgz_vector *s)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
+    s->batch.lock();
     const float *ptrs[64];
+    sgz_status out = SGZ_OK;
     while (s->backlog.count) {
         const Backlog::Entry e = s->backlog.front();
         for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
         const sgz_status st = vectorPushNow(s, ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) { SGZ_HIP(hipStreamSynchronize(s->stream)); continue; }      // this call may wait: it is not the audio thread's
+        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }         // this call may wait: it is not the audio thread's
         s->backlog.pop();
-        if (st != SGZ_OK) return st;
+        if (st != SGZ_OK) { out = st; break; }
     }
-    return SGZ_OK;
+    if (out == SGZ_OK && s->batch.count) out = vectorSubmit(s);
+    s->batch.unlock();
+    return out;
 }
 
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // (flush on read: the blocks that wait in the open batch come first)
     // coeff = pow(envelopeCoeff, numSamples * openGLDeltaTime()), VectorscopeRendering.cpp:838-842 (envelopeCoeff is a float)
     const double coeff = std::pow(double(s->envelopeCoeff), double(s->size) * delta_time);
     hipLaunchKernelGGL(vectorPeakKernel, dim3(1), dim3(1024), 0, s->stream, s->d_state, s->d_ring, s->size, s->cfg.lanes, coeff);
@@ -409,6 +460,7 @@ sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *enve
 sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // (flush on read: the blocks that wait in the open batch come first)
     VecDev h;
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipStreamSynchronize(s->stream));
@@ -423,6 +475,7 @@ sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, do
 sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint32_t *size, uint32_t *cursor)
 {
     if (!s || channel >= s->cfg.num_channels) return fail(SGZ_EINVAL, "bad argument");
+    if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // (flush on read: the blocks that wait in the open batch come first)
     VecDev h;
     if (out) SGZ_HIP(hipMemcpyAsync(out, s->d_ring + size_t(channel) * s->size, size_t(s->size) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     SGZ_HIP(hipMemcpyAsync(&h, s->d_state, sizeof(h), hipMemcpyDeviceToHost, s->stream));
@@ -435,6 +488,7 @@ sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint3
 // the kernels of one pair's vertex stream into DEVICE buffers (the handle's own, or the caller's mapped VBO)
 static sgz_status vectorVerticesInto(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb)
 {
+    if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // (flush on read: the blocks that wait in the open batch come first)
     const uint32_t size = s->size;
     const uint64_t now = s->pushes.load(std::memory_order_acquire);
     if (s->rampAt != now) {                                    // (1 200 dependent additions at cfg4: 36 us, once per rendered frame instead of once per pair)
