@@ -178,14 +178,19 @@ __global__ __launch_bounds__(kResBlock) void resonateKernel(ResParams prm)
 // rounded once); pole^1024 is carried as hi + lo words like pole^hop.  One wave = 32 resonators of one vector; a 256-thread workgroup =
 // 4 such groups sharing the tile's samples in LDS.  Per tile and wave: 32 MFMAs (2 048 issue clocks) against ~100 vector instructions.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef SGZ_RES_WAVES
+#define SGZ_RES_WAVES 4
+#endif
 
-template <int DUMMY = 0>
-__global__ __launch_bounds__(256) void resonateMfmaKernel(ResParams prm, int V)
+// WAVES: (vector, group) waves per workgroup -- they share the tile's samples in LDS and meet at one barrier per tile
+template <int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, 4) void resonateMfmaKernel(ResParams prm, int V)
 {
+    constexpr int TH = 64 * WAVES, PER = 1024 / TH;                  // threads, samples a thread stages per tile
     __shared__ float xs[2 * 32 * 33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const uint32_t groups = (prm.P + 31) / 32;                       // resonator groups per vector
-    const uint32_t g = blockIdx.x * 4 + wave;                        // (vector, group) of this wave
+    const uint32_t g = blockIdx.x * WAVES + wave;                    // (vector, group) of this wave
     const bool liveWave = g < uint32_t(V) * groups;
     const uint32_t v = liveWave ? g / groups : 0u;
     const uint32_t i = liveWave ? (g - v * groups) * 32 + (lane & 31) : 0u;
@@ -213,18 +218,18 @@ __global__ __launch_bounds__(256) void resonateMfmaKernel(ResParams prm, int V)
     // the tile's samples: fetched one tile ahead into registers, parked in one of two LDS buffers (one barrier per tile)
     // (raw left / right values: the channel mix is applied when they are parked -- mixing at the load makes the wave wait for the
     // loads right there, a memory round trip per tile in front of the matrix products: the kernel ran at half the pipe's rate)
-    float nl[4], nr[4];
+    float nl[PER], nr[PER];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; nl[k] = L[e]; nr[k] = R[e]; }
+    for (int k = 0; k < PER; ++k) { const uint32_t e = uint32_t(tid) + uint32_t(TH) * k; nl[k] = L[e]; nr[k] = R[e]; }
     int buf = 0;
     for (uint32_t t0 = 0; t0 < prm.hop; t0 += 1024, buf ^= 1) {
         float *xb = xs + buf * (32 * 33);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const uint32_t e = uint32_t(tid) + 256u * k; xb[(e >> 5) * 33 + (e & 31)] = resMix(prm.mode, signal, nl[k], nr[k]); }
+        for (int k = 0; k < PER; ++k) { const uint32_t e = uint32_t(tid) + uint32_t(TH) * k; xb[(e >> 5) * 33 + (e & 31)] = resMix(prm.mode, signal, nl[k], nr[k]); }
         __syncthreads();                                             // (the other buffer was read two tiles ago: every wave is past it)
         if (t0 + 1024 < prm.hop) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const uint32_t e = t0 + 1024 + uint32_t(tid) + 256u * k; nl[k] = L[e]; nr[k] = R[e]; }
+            for (int k = 0; k < PER; ++k) { const uint32_t e = t0 + 1024 + uint32_t(tid) + uint32_t(TH) * k; nl[k] = L[e]; nr[k] = R[e]; }
         }
         f32x16 dre = {0}, dim = {0};
         const float *arow = xb + (lane & 31) * 33 + h;
@@ -366,7 +371,8 @@ hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hi
             const long nf = std::min(perSlab, prm.frames - f0);
             q.planar = prm.planar + size_t(f0 - 1) * prm.hop;           // (the kernel counts its frames from 1)
             q.local = prm.local + size_t(f0 - 1) * prm.C * size_t(prm.signals) * V * prm.P;
-            hipLaunchKernelGGL(resonateMfmaKernel<0>, dim3((groups + 3) / 4, unsigned(nf * prm.C * prm.signals)), dim3(256), 0, stream, q, V);
+            constexpr int WAVES = SGZ_RES_WAVES;
+            hipLaunchKernelGGL(resonateMfmaKernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, unsigned(nf * prm.C * prm.signals)), dim3(64 * WAVES), 0, stream, q, V);
             if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
         }
         if (s0 != stream) {

@@ -16,7 +16,10 @@ from signalizer_amd import api, config, synth
 def main():
     dev = torch.device("cuda", 0)
     out = {}
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None       # one window only (profiling runs)
     for name, over in (("hann", dict()), ("rect", dict(window_type=config.WIN_RECT)), ("blackman_harris", dict(window_type=config.WIN_BLACKMAN_HARRIS))):
+        if only and name != only:
+            continue
         cfg = config.spectrum_config(algorithm=config.ALGO_RSNT, **over)
         x = synth.gen(config.CFG2_SEED, 48000, int(config.CFG2_SECONDS * 48000), 2)
         xs = torch.from_numpy(x).to(dev)
