@@ -318,6 +318,18 @@ typedef struct sgz_transport {
 sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport *transport, uint32_t rank, uint32_t world, float *d_chunk,
                                              size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
                                              void *stream);
+/* The same protocol for a host that drives several GPUs from ONE process (a thread per rank, no RCCL): an sgz_transport whose three
+ * collectives are hipMemcpyPeerAsync copies over xGMI, each enqueued by the receiving rank on its own stream behind an event of the
+ * sender's -- stream-ordered like their RCCL counterparts, and no host thread ever waits for a GPU (only for its peer to have enqueued).
+ * devices[r] = HIP device of rank r (ranks may share a device: the copies are then plain device copies, which is how the tests run
+ * it on one GPU).  One group per set of ranks; every rank takes its own transport from it and calls
+ * sgz_spectrogram_render_sharded_on from its own thread with that device current.  *ctx_storage is released with
+ * sgz_peer_transport_release when the rank is done. */
+typedef struct sgz_peer_group sgz_peer_group;
+sgz_status sgz_peer_group_create(uint32_t world, const int *devices /*[world]*/, sgz_peer_group **out);
+void       sgz_peer_group_destroy(sgz_peer_group *group);
+sgz_status sgz_peer_transport(sgz_peer_group *group, uint32_t rank, sgz_transport *out, void **ctx_storage);
+void       sgz_peer_transport_release(void *ctx_storage);
 
 /* ------------------------------------------------------------------------------------------------
  * Real-time per-block path: replaces Spectrum::ProcessorShell::onStreamAudio (SpectrumDSP.cpp:210-216)

@@ -118,7 +118,7 @@ EXPORTS = [
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames", "sgz_plan_num_frames", "sgz_plan_get_resonator", "sgz_plan_reset_resonator",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant", "sgz_plan_set_option",
     "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout", "sgz_spectrogram_render_sharded_on",
-    "sgz_spectrogram_render_sharded",
+    "sgz_spectrogram_render_sharded", "sgz_peer_group_create", "sgz_peer_group_destroy", "sgz_peer_transport", "sgz_peer_transport_release",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
     "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",

@@ -16,9 +16,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
+#include <vector>
 
 #include "runtime.hpp"
 
@@ -90,6 +93,137 @@ struct Shard {
     }
 };
 
+// ---- A transport for hosts that drive several GPUs from ONE process (a thread per rank): hipMemcpyPeerAsync over xGMI, no RCCL.
+// Every transfer is a peer copy enqueued by the RECEIVER on its own stream behind an event the sender recorded on its stream; the
+// sender's stream in turn waits for the event the receiver records behind the copy, so that -- as with ncclSend / ncclAllGather -- a
+// buffer belongs to the transfer until the call is complete ON THE STREAM, whichever side is faster.  The host side only hands
+// pointers and events across (mutex + condition variable): no thread ever waits for a GPU, only for its peer to have ENQUEUED.
+struct PeerSlot {
+    const float *ptr = nullptr; size_t count = 0;
+    uint64_t posted = 0, taken = 0;                 // messages the sender has posted / the receiver has enqueued the copy of
+    hipEvent_t ready = nullptr, done = nullptr;     // recorded by the sender behind its data / by the receiver behind its copy
+};
+}  // namespace
+struct sgz_peer_group {
+    uint32_t world = 0;
+    std::vector<int> device;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<PeerSlot> p2p;                      // [src * world + dst]: send / recv
+    std::vector<PeerSlot> ag;                       // [src * world + dst]: all-gather, src's block as read by dst
+    std::vector<uint64_t> agRound;                  // [rank]: all-gathers this rank has entered
+    std::vector<uint64_t> pendingSend;              // [src * world + dst]: message whose `done` the sender's stream still has to wait for (0 = none)
+    bool aborted = false;
+};
+struct PeerCtx { sgz_peer_group *g; uint32_t rank; };
+namespace {
+constexpr int kPeerErr = 1000;
+int peerWaitTaken(sgz_peer_group *g, PeerSlot &sl, uint64_t msg, hipStream_t stream)
+{
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return sl.taken >= msg || g->aborted; });
+    if (g->aborted) return kPeerErr;
+    lk.unlock();
+    return hipStreamWaitEvent(stream, sl.done, 0) == hipSuccess ? 0 : kPeerErr + 1;
+}
+int peerSend(void *ctx, const float *d_buf, size_t count, uint32_t peer, void *stream)
+{
+    PeerCtx *c = static_cast<PeerCtx *>(ctx);
+    sgz_peer_group *g = c->g;
+    if (peer >= g->world || peer == c->rank) return kPeerErr + 2;
+    PeerSlot &sl = g->p2p[size_t(c->rank) * g->world + peer];
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // the previous message to this peer: its buffer is the same one more often than not
+    if (g->pendingSend[size_t(c->rank) * g->world + peer])
+        if (int e = peerWaitTaken(g, sl, g->pendingSend[size_t(c->rank) * g->world + peer], s); e) return e;
+    if (hipEventRecord(sl.ready, s) != hipSuccess) return kPeerErr + 3;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        sl.ptr = d_buf; sl.count = count; sl.posted++;
+        g->pendingSend[size_t(c->rank) * g->world + peer] = sl.posted;
+    }
+    g->cv.notify_all();
+    return 0;
+}
+int peerRecv(void *ctx, float *d_buf, size_t count, uint32_t peer, void *stream)
+{
+    PeerCtx *c = static_cast<PeerCtx *>(ctx);
+    sgz_peer_group *g = c->g;
+    if (peer >= g->world || peer == c->rank) return kPeerErr + 2;
+    PeerSlot &sl = g->p2p[size_t(peer) * g->world + c->rank];
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float *src; size_t n;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->cv.wait(lk, [&] { return sl.posted > sl.taken || g->aborted; });
+        if (g->aborted) return kPeerErr;
+        src = sl.ptr; n = sl.count;
+    }
+    if (n != count) return kPeerErr + 4;
+    if (hipStreamWaitEvent(s, sl.ready, 0) != hipSuccess) return kPeerErr + 5;
+    if (hipMemcpyPeerAsync(d_buf, g->device[c->rank], src, g->device[peer], count * sizeof(float), s) != hipSuccess) return kPeerErr + 6;
+    if (hipEventRecord(sl.done, s) != hipSuccess) return kPeerErr + 7;
+    { std::lock_guard<std::mutex> lk(g->mu); sl.taken++; }
+    g->cv.notify_all();
+    return 0;
+}
+// group_end: the sends of this exchange are complete on the stream once the receivers' copies are
+int peerGroupEnd(void *ctx)
+{
+    (void)ctx;                                       // (nothing to close: a send's completion is awaited by the next send / the all-gather)
+    return 0;
+}
+int peerAllGather(void *ctx, const float *d_send, float *d_recv, size_t count, void *stream)
+{
+    PeerCtx *c = static_cast<PeerCtx *>(ctx);
+    sgz_peer_group *g = c->g;
+    const uint32_t W = g->world, r = c->rank;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // outstanding halo sends of this call complete here at the latest (their buffers are the caller's again after the render)
+    for (uint32_t q = 0; q < W; ++q)
+        if (uint64_t m = g->pendingSend[size_t(r) * W + q]) {
+            if (int e = peerWaitTaken(g, g->p2p[size_t(r) * W + q], m, s); e) return e;
+            g->pendingSend[size_t(r) * W + q] = 0;
+        }
+    // my block is ready behind this event; every reader (myself included: a plain device copy) gets its own slot
+    PeerSlot &mine = g->ag[size_t(r) * W + r];
+    if (hipEventRecord(mine.ready, s) != hipSuccess) return kPeerErr + 3;
+    uint64_t round;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        round = ++g->agRound[r];
+        for (uint32_t q = 0; q < W; ++q) { PeerSlot &sl = g->ag[size_t(r) * W + q]; sl.ptr = d_send; sl.count = count; sl.posted = round; }
+    }
+    g->cv.notify_all();
+    for (uint32_t q = 0; q < W; ++q) {                // read rank q's block
+        PeerSlot &sl = g->ag[size_t(q) * W + r];
+        const float *src; size_t n;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv.wait(lk, [&] { return sl.posted >= round || g->aborted; });
+            if (g->aborted) return kPeerErr;
+            src = sl.ptr; n = sl.count;
+        }
+        if (n != count) return kPeerErr + 4;
+        if (hipStreamWaitEvent(s, g->ag[size_t(q) * W + q].ready, 0) != hipSuccess) return kPeerErr + 5;
+        if (hipMemcpyPeerAsync(d_recv + size_t(q) * count, g->device[r], src, g->device[q], count * sizeof(float), s) != hipSuccess) return kPeerErr + 6;
+        if (hipEventRecord(sl.done, s) != hipSuccess) return kPeerErr + 7;
+        { std::lock_guard<std::mutex> lk(g->mu); sl.taken = round; }
+        g->cv.notify_all();
+    }
+    // like ncclAllGather, the operation is complete on this stream only when everybody has read my block
+    for (uint32_t q = 0; q < W; ++q)
+        if (q != r)
+            if (int e = peerWaitTaken(g, g->ag[size_t(r) * W + q], round, s); e) return e;
+    return 0;
+}
+void peerAbort(void *ctx)
+{
+    sgz_peer_group *g = static_cast<PeerCtx *>(ctx)->g;
+    { std::lock_guard<std::mutex> lk(g->mu); g->aborted = true; }
+    g->cv.notify_all();
+}
+
 }  // namespace
 
 struct sgz_plan { Plan impl; };
@@ -157,6 +291,64 @@ static int rcclAllGather(void *ctx, const float *d_send, float *d_recv, size_t n
 static int rcclGroupBegin(void *) { return rccl()->GroupStart(); }
 static int rcclGroupEnd(void *) { return rccl()->GroupEnd(); }
 static void rcclAbort(void *ctx) { if (rccl()->CommAbort) (void)rccl()->CommAbort(static_cast<ncclComm_t>(ctx)); }
+
+// ---- the peer-copy transport's lifetime (sgz.h)
+sgz_status sgz_peer_group_create(uint32_t world, const int *devices, sgz_peer_group **out)
+{
+    if (!devices || !out || world == 0 || world > 64) return fail(SGZ_EINVAL, "bad argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(SGZ_EHIP, "no HIP device visible");
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    sgz_peer_group *g = new (std::nothrow) sgz_peer_group();
+    if (!g) return fail(SGZ_ENOMEM, "out of memory");
+    g->world = world;
+    g->device.assign(devices, devices + world);
+    g->p2p.resize(size_t(world) * world); g->ag.resize(size_t(world) * world);
+    g->agRound.assign(world, 0); g->pendingSend.assign(size_t(world) * world, 0);
+    sgz_status st = SGZ_OK;
+    for (uint32_t a = 0; a < world && st == SGZ_OK; ++a) {
+        if (devices[a] < 0 || devices[a] >= count) { st = fail(SGZ_EINVAL, "device index out of range"); break; }
+        for (uint32_t b = 0; b < world && st == SGZ_OK; ++b) {
+            // `ready` is recorded on a stream of the source's device, `done` on one of the reader's
+            for (int which = 0; which < 2 && st == SGZ_OK; ++which) {
+                std::vector<PeerSlot> &v = which ? g->ag : g->p2p;
+                PeerSlot &sl = v[size_t(a) * world + b];
+                if (hipSetDevice(devices[a]) != hipSuccess || hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess ||
+                    hipSetDevice(devices[b]) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
+                    st = fail(SGZ_EHIP, "event creation failed");
+            }
+            if (st == SGZ_OK && devices[a] != devices[b]) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, devices[b], devices[a]);
+                if (can) { (void)hipSetDevice(devices[b]); const hipError_t e = hipDeviceEnablePeerAccess(devices[a], 0); if (e != hipSuccess) (void)hipGetLastError(); }   // (already enabled is fine; without access the copies are staged by the runtime)
+            }
+        }
+    }
+    (void)hipSetDevice(keep);
+    if (st != SGZ_OK) { sgz_peer_group_destroy(g); return st; }
+    *out = g;
+    return SGZ_OK;
+}
+
+void sgz_peer_group_destroy(sgz_peer_group *g)
+{
+    if (!g) return;
+    for (std::vector<PeerSlot> *v : {&g->p2p, &g->ag})
+        for (PeerSlot &sl : *v) { if (sl.ready) (void)hipEventDestroy(sl.ready); if (sl.done) (void)hipEventDestroy(sl.done); }
+    delete g;
+}
+
+sgz_status sgz_peer_transport(sgz_peer_group *g, uint32_t rank, sgz_transport *out, void **ctx_storage)
+{
+    if (!g || !out || !ctx_storage || rank >= g->world) return fail(SGZ_EINVAL, "bad argument");
+    PeerCtx *c = new (std::nothrow) PeerCtx{g, rank};
+    if (!c) return fail(SGZ_ENOMEM, "out of memory");
+    *ctx_storage = c;
+    *out = sgz_transport{c, peerSend, peerRecv, peerAllGather, nullptr, peerGroupEnd, peerAbort};
+    return SGZ_OK;
+}
+void sgz_peer_transport_release(void *ctx_storage) { delete static_cast<PeerCtx *>(ctx_storage); }
 
 sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint32_t rank, uint32_t world, float *d_chunk,
                                           size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
@@ -234,7 +426,20 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
     }
     if (hipError_t e = hipMemsetAsync(d_end, 0, stateN * sizeof(float), s); e != hipSuccess) return bail(hipFail(e, "hipMemsetAsync"));
     if (frames && (st = runDecayColour(p, p.d_mapped, long(frames), nullptr, nullptr, d_end, s, /*magnitudeOnly=*/true)) != SGZ_OK) return bail(st);
-    // A2: end states of every rank, exact fold of the predecessors
+    // A2: end states of every rank, exact fold of the predecessors.  Rank 0 has no predecessor: its emit pass does not read the gathered
+    // states, so there the all-gather (which the OTHER ranks need its contribution for) runs on the second stream beside it.  On the
+    // ranks behind it the carry stands in front of every emitted frame -- with both graphs' poles near 1 it outlives a rank's whole
+    // chunk (0.99^44 = 0.64 at 8 ranks), so there is nothing a speculative emit could keep.
+    if (rank == 0 && world > 1 && frames) {
+        if (hipError_t e = hipEventRecord(evFork, s); e != hipSuccess) return bail(hipFail(e, "hipEventRecord"));
+        if (hipError_t e = hipStreamWaitEvent(cs, evFork, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
+        if ((st = coll(t->allgather(t->ctx, d_end, d_all, stateN, cs), "end-state all-gather")) != SGZ_OK) return st;
+        if (hipError_t e = hipEventRecord(evJoin, cs); e != hipSuccess) return bail(hipFail(e, "hipEventRecord"));
+        st = runDecayEmitWithCarry(p, p.d_mapped, long(frames), nullptr, d_rgba, nullptr, nullptr, s);
+        // (the call's work is ordered on `s`: the gather's buffers belong to it until the caller's stream has passed this point)
+        if (hipError_t e = hipStreamWaitEvent(s, evJoin, 0); e != hipSuccess) return bail(hipFail(e, "hipStreamWaitEvent"));
+        return st == SGZ_OK ? SGZ_OK : bail(st);
+    }
     if ((st = coll(t->allgather(t->ctx, d_end, d_all, stateN, s), "end-state all-gather")) != SGZ_OK) return st;
     const float *carry = nullptr;
     if (rank > 0) {

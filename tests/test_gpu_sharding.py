@@ -293,3 +293,78 @@ def test_rccl_paths_at_world_one(gpu, window, hop, pairs, S):
     assert out["frames"] == ref.shape[0]
     for k in ("p2p", "allgather", "c_abi"):
         assert np.array_equal(out[k], ref), k
+
+
+@pytest.mark.parametrize("window,hop,pairs,S,world,mode", [
+    (32768, 8192, 1, 32768 * 3 + 1234, 2, config.CH_SEPARATE),        # the bench's transform, hop not dividing the chunk
+    (4096, 1024, 2, 4096 * 4, 4, config.CH_MIDSIDE),                  # four ranks, hop divides the chunk: every rank but the last needs a halo
+    (65536, 16384, 2, 65536 * 3 + 999, 3, config.CH_SEPARATE)])       # cfg5's transform
+def test_peer_copy_transport_ranks_as_threads_of_one_process(gpu, window, hop, pairs, S, world, mode):
+    """VERDICT r3 #7c: a host that drives its GPUs from ONE process (a thread per rank) needs no RCCL -- sgz_peer_transport moves the halo
+    and the end states with hipMemcpyPeerAsync, enqueued by the receiver behind the sender's event.  Here every rank's "device" is GPU 0
+    (the copies degenerate to device copies; the rendezvous, the event ordering and the buffer-reuse rules are the real ones): `world`
+    Python threads call sgz_spectrogram_render_sharded_on concurrently -- ctypes drops the GIL around the call -- three times in a row,
+    and the columns are the single-device render's, bit for bit."""
+    import ctypes as C
+    import threading
+
+    import torch
+    from signalizer_amd import api
+    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=300, pole=(0.97, 0.5), channel_mode=mode)
+    L = api.lib()
+
+    class Transport(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("send", C.c_void_p), ("recv", C.c_void_p), ("allgather", C.c_void_p), ("group_begin", C.c_void_p),
+                    ("group_end", C.c_void_p), ("abort", C.c_void_p)]
+
+    L.sgz_peer_group_create.argtypes = [C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    L.sgz_peer_group_destroy.argtypes = [C.c_void_p]
+    L.sgz_peer_group_destroy.restype = None
+    L.sgz_peer_transport.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Transport), C.POINTER(C.c_void_p)]
+    L.sgz_peer_transport_release.argtypes = [C.c_void_p]
+    L.sgz_peer_transport_release.restype = None
+    L.sgz_spectrogram_render_sharded_on.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                    C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    group = C.c_void_p()
+    devices = (C.c_int * world)(*([0] * world))
+    api.check(L.sgz_peer_group_create(world, devices, C.byref(group)))
+    full = synth.gen(78, 48000, S * world, 2 * pairs)
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                buf = torch.zeros((full.shape[0], (S + window + 63) // 64 * 64), dtype=torch.float32, device=gpu)
+                buf[:, :S] = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy()).to(gpu)
+                plan = api.Plan(cfg).upload()
+                lf = C.c_uint64()
+                api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), None, None, None))
+                rgba = torch.empty((max(int(lf.value), 1), plan.P, 4), dtype=torch.uint8, device=gpu)
+                tr, store = Transport(), C.c_void_p()
+                api.check(L.sgz_peer_transport(group, rank, C.byref(tr), C.byref(store)))
+                outs = []
+                for _ in range(3):
+                    frames = C.c_uint64(0)
+                    api.check(L.sgz_spectrogram_render_sharded_on(plan.h, C.byref(tr), rank, world, buf.data_ptr(), buf.stride(0), S,
+                                                                   rgba.data_ptr(), C.byref(frames), stream.cuda_stream))
+                    stream.synchronize()
+                    assert int(frames.value) == int(lf.value)
+                    outs.append(rgba[:int(lf.value)].cpu().numpy().copy())
+                assert all(np.array_equal(outs[0], o) for o in outs[1:])
+                results[rank] = outs[0]
+                L.sgz_peer_transport_release(store)
+        except BaseException as e:                     # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    L.sgz_peer_group_destroy(group)
+    ref = api.Plan(cfg).upload().render(torch.from_numpy(full).to(gpu)).cpu().numpy()
+    out = np.concatenate([results[r] for r in range(world)])
+    assert out.shape == ref.shape and np.array_equal(out, ref)
