@@ -289,7 +289,10 @@ sgz_status sgz_decay_fold_carry(sgz_plan *plan, const float *d_aggs, const int64
  * the neighbours (exactly the samples the last frames reach into the next rank's chunk), K_A, zero-carry K_B scan, ncclAllGather of
  * the end states, exact fold, K_B emit.  Rank r holds samples [r S, (r+1) S) of the stream in d_chunk (2*num_pairs channels, S =
  * chunk_samples, channel_stride >= S + halo_in: the halo is written behind the chunk); d_rgba receives this rank's columns
- * [local_frames][P][4].  Bit-identical to a single-device render of the concatenated stream.  nccl_comm: an ncclComm_t (RCCL is
+ * [local_frames][P][4].  Bit-identical to a single-device render of the concatenated stream.  (RSNT plans shard too: chunks of whole hops,
+ * no halo; the resonators' linear recurrence is cut the same way -- every rank from rest, one all-gather of the resonators' end
+ * states, the entering state folded in fp64 and added to every frame before the window kernel -- and the frames then equal a single
+ * device's to within the bar its own chained frames are held to, not bit for bit: sharded.hip renderShardedResonator.)  nccl_comm: an ncclComm_t (RCCL is
  * bound with dlopen at first use; sgz_comm_* are conveniences for hosts that do not link RCCL themselves: sgz_comm_unique_id on
  * one rank, the 128 bytes handed to every rank by the host's own means, sgz_comm_create on all). */
 sgz_status sgz_comm_unique_id(uint8_t out[128]);

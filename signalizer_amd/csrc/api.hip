@@ -194,12 +194,9 @@ sgz_status resetResonator(Plan &p, hipStream_t stream)
 
 // hopOverride (line-graph mode of the real-time handle): ONE "frame" of that many samples -- the resonators advance over a whole host
 // block (TransformDSP.inl:1206-1209), sample by sample from the carried state, and d_mapped receives the windowed state afterwards
-static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream, uint32_t hopOverride = 0)
+static sgz_status fillResParams(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, uint32_t hopOverride, ResParams &r)
 {
-    if (frames <= 0) return SGZ_OK;
-    if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
-    if (hopOverride && frames != 1) return fail(SGZ_EINVAL, "a block advance of the resonators is one frame");
-    ResParams r{};
+    r = ResParams{};
     r.planar = d_planar; r.chStride = chStride; r.frames = frames;
     r.hop = hopOverride ? hopOverride : p.cfg.hop; r.C = p.C; r.P = p.P; r.mode = p.cfg.channel_mode;
     r.V = p.resV; r.signals = p.stateChannels; r.sides = p.sides; r.firstContinues = true;
@@ -217,12 +214,47 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     if (st != SGZ_OK) return st;
     r.local = reinterpret_cast<float2 *>(p.d_resLocal);
     r.mapped = d_mapped;
+    return SGZ_OK;
+}
+
+static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream, uint32_t hopOverride = 0,
+                               bool skipWindow = false)
+{
+    if (frames <= 0) return SGZ_OK;
+    if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
+    if (hopOverride && frames != 1) return fail(SGZ_EINVAL, "a block advance of the resonators is one frame");
+    ResParams r;
+    if (sgz_status st = fillResParams(p, d_planar, chStride, frames, d_mapped, hopOverride, r); st != SGZ_OK) return st;
+    r.skipWindow = skipWindow;
     // frame 0's sample-by-sample walk runs beside the matrix kernel on the plan's second stream (the one the sharded render uses for
     // its halo: RSNT renders are single device)
     if (r.w1 && frames > 1)
         if (sgz_status s2 = ensureSecondStream(p); s2 != SGZ_OK) return s2;
     SGZ_HIP(launchResonator(r, stream, static_cast<hipStream_t>(p.shardStream), static_cast<hipEvent_t>(p.shardEv[0]),
                             static_cast<hipEvent_t>(p.shardEv[1])));
+    return SGZ_OK;
+}
+
+// The two halves of a sharded RSNT render (sharded.hip): the resonators over this rank's chunk FROM REST, chained, windows not yet
+// applied (the plan's state = the end state from rest, what the ranks exchange); then the entering state folded from the gathered
+// end states is added to every frame and the window kernel fills d_mapped.
+sgz_status runResonatorFromRest(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
+{
+    if (sgz_status st = resetResonator(p, stream); st != SGZ_OK) return st;
+    return runResonator(p, d_planar, chStride, frames, d_mapped, stream, 0, /*skipWindow=*/true);
+}
+sgz_status runResonatorJoin(Plan &p, long frames, float *d_mapped, const float *d_allEnd, const long long *framesPerRank, uint32_t world, uint32_t rank,
+                            float *d_carry, hipStream_t stream)
+{
+    if (frames <= 0) return SGZ_OK;
+    ResParams r;
+    if (sgz_status st = fillResParams(p, nullptr, 0, frames, d_mapped, 0, r); st != SGZ_OK) return st;
+    const float2 *carry = nullptr;
+    if (rank > 0) {
+        SGZ_HIP(launchResonatorFold(r, reinterpret_cast<const float2 *>(d_allEnd), framesPerRank, world, rank, reinterpret_cast<float2 *>(d_carry), stream));
+        carry = reinterpret_cast<const float2 *>(d_carry);
+    }
+    SGZ_HIP(launchResonatorCarry(r, carry, stream));
     return SGZ_OK;
 }
 

@@ -171,8 +171,17 @@ struct ResParams {
     float2 *state;                    // [C][2][V][P]
     float2 *local;                    // [frames][C][signals][V][P]
     float *mapped;                    // [frames][C][sides][P]
+    bool skipWindow;                  // stop behind the chain (sharded render: the carry of the ranks in front is added first, launchResonatorCarry)
 };
 // aux / evFork / evJoin: a second stream and two events (may be null: then everything runs on `stream`)
 hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin);
+// Time-chunk sharding of an RSNT render (sharded.hip).  The recurrence is linear: a rank that starts from rest is short of
+// pole^(samples since its chunk began) x (the state that entered its chunk), for every frame.  fold: that entering state from the
+// gathered end states of the ranks in front, s <- pole^(chunk_q) s + end_q in fp64 (pole^chunk by squaring pole^hop, hi + lo words);
+// carry: local_f += pole^((f + 1) hop) carry for every frame (fp64 walk, one rounding per frame), the plan's state likewise, then the
+// window kernel on the corrected states.  carry == null: the window kernel alone (rank 0).
+hipError_t launchResonatorFold(const ResParams &prm, const float2 *allEnd /*[world][C][2][V][P]*/, const long long *framesPerRank, uint32_t world,
+                               uint32_t rank, float2 *carry /*[C][2][V][P]*/, hipStream_t stream);
+hipError_t launchResonatorCarry(const ResParams &prm, const float2 *carry, hipStream_t stream);
 
 }  // namespace sgz

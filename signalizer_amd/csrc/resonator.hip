@@ -338,6 +338,9 @@ __global__ __launch_bounds__(kResBlock) void resonatorWindowKernel(ResParams prm
 }
 
 template <int V>
+hipError_t launchWindow(const ResParams &prm, hipStream_t stream);
+
+template <int V>
 hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin)
 {
     const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
@@ -382,6 +385,14 @@ hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hi
     }
     hipLaunchKernelGGL(resonatorChainKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    if (prm.skipWindow) return hipSuccess;
+    return launchWindow<V>(prm, stream);
+}
+
+template <int V>
+hipError_t launchWindow(const ResParams &prm, hipStream_t stream)
+{
+    const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
     for (long f0 = 0; f0 < prm.frames; f0 += long(65535u / prm.C)) {
         ResParams q = prm;
         const long nf = std::min<long>(long(65535u / prm.C), prm.frames - f0);
@@ -391,6 +402,77 @@ hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hi
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+struct FoldFrames { long long n[64]; };
+
+__device__ __forceinline__ void cmulD(double &re, double &im, double cr, double ci)
+{
+    const double nr = re * cr - im * ci, ni = re * ci + im * cr;
+    re = nr; im = ni;
+}
+
+// the state entering rank `rank`: s <- pole^(frames_q hop) s + end_q over the ranks in front, fp64.  One thread per (pair, signal slot,
+// vector, axis point) = one entry of the plan's state layout [C][2][V][P].
+__global__ __launch_bounds__(kResBlock) void resonatorFoldKernel(ResParams prm, const float2 *allEnd, FoldFrames fr, uint32_t rank, float2 *carry)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t unit = blockIdx.y;                              // (pair, slot, vector)
+    const uint32_t v = unit % uint32_t(prm.V);
+    const size_t at = size_t(unit) * prm.P + i, perRank = size_t(prm.C) * 2 * size_t(prm.V) * prm.P;
+    const float4 c = prm.cpow[size_t(v) * prm.P + i];              // pole^hop = hi + lo
+    const double hr = double(c.x) + double(c.z), hi = double(c.y) + double(c.w);
+    double sr = 0.0, si = 0.0;
+    for (uint32_t q = 0; q < rank; ++q) {
+        // pole^(frames_q hop) by squaring
+        double pr = 1.0, pi = 0.0, br = hr, bi = hi;
+        for (long long e = fr.n[q]; e > 0; e >>= 1) {
+            if (e & 1) cmulD(pr, pi, br, bi);
+            cmulD(br, bi, br, bi);
+        }
+        cmulD(sr, si, pr, pi);
+        const float2 eq = allEnd[size_t(q) * perRank + at];
+        sr += double(eq.x); si += double(eq.y);
+    }
+    carry[at] = float2{float(sr), float(si)};
+}
+
+// local_f += pole^((f + 1) hop) carry, f = 0 .. frames - 1 (fp64 walk); the plan's state (the end state from rest) likewise
+template <int V>
+__global__ __launch_bounds__(kResBlock) void resonatorCarryKernel(ResParams prm, const float2 *carry)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t unit = blockIdx.y;                              // (pair, signal, vector)
+    const uint32_t v = unit % uint32_t(V), sg = (unit / uint32_t(V)) % uint32_t(prm.signals), pair = unit / (uint32_t(V) * uint32_t(prm.signals));
+    const float4 c = prm.cpow[size_t(v) * prm.P + i];
+    const double hr = double(c.x) + double(c.z), hi = double(c.y) + double(c.w);
+    const size_t stAt = (size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i;
+    const float2 c0 = carry[stAt];
+    double tr = double(c0.x), ti = double(c0.y);
+    const size_t stride = size_t(prm.C) * size_t(prm.signals) * V * prm.P;
+    float2 *loc = prm.local + ((size_t(pair) * size_t(prm.signals) + sg) * V + v) * prm.P + i;
+    for (long f = 0; f < prm.frames; ++f) {
+        cmulD(tr, ti, hr, hi);
+        float2 l = loc[size_t(f) * stride];
+        l.x = float(double(l.x) + tr); l.y = float(double(l.y) + ti);
+        loc[size_t(f) * stride] = l;
+    }
+    float2 s = prm.state[stAt];
+    s.x = float(double(s.x) + tr); s.y = float(double(s.y) + ti);
+    prm.state[stAt] = s;
+}
+
+template <int V>
+hipError_t launchCarryV(const ResParams &prm, const float2 *carry, hipStream_t stream)
+{
+    const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
+    if (carry) {
+        hipLaunchKernelGGL(resonatorCarryKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm, carry);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return launchWindow<V>(prm, stream);
 }
 
 }  // namespace
@@ -403,6 +485,29 @@ hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t
     case 5: return launchV<5>(prm, stream, aux, evFork, evJoin);
     case 7: return launchV<7>(prm, stream, aux, evFork, evJoin);
     case 9: return launchV<9>(prm, stream, aux, evFork, evJoin);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launchResonatorFold(const ResParams &prm, const float2 *allEnd, const long long *framesPerRank, uint32_t world, uint32_t rank,
+                               float2 *carry, hipStream_t stream)
+{
+    if (world > 64 || rank >= world) return hipErrorInvalidValue;
+    FoldFrames fr{};
+    for (uint32_t q = 0; q < world; ++q) fr.n[q] = framesPerRank[q];
+    const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
+    hipLaunchKernelGGL(resonatorFoldKernel, dim3(tiles, prm.C * 2u * unsigned(prm.V)), dim3(kResBlock), 0, stream, prm, allEnd, fr, rank, carry);
+    return hipGetLastError();
+}
+
+hipError_t launchResonatorCarry(const ResParams &prm, const float2 *carry, hipStream_t stream)
+{
+    switch (prm.V) {
+    case 1: return launchCarryV<1>(prm, carry, stream);
+    case 3: return launchCarryV<3>(prm, carry, stream);
+    case 5: return launchCarryV<5>(prm, carry, stream);
+    case 7: return launchCarryV<7>(prm, carry, stream);
+    case 9: return launchCarryV<9>(prm, carry, stream);
     default: return hipErrorInvalidValue;
     }
 }

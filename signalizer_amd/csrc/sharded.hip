@@ -265,7 +265,15 @@ sgz_status sgz_shard_layout(const sgz_plan *plan, uint32_t rank, uint32_t world,
 {
     if (!plan || rank >= world || world == 0) return fail(SGZ_EINVAL, "bad argument");
     const Plan &p = plan->impl;
-    if (isResonator(p)) return fail(SGZ_EUNSUPPORTED, "RSNT renders are single device");
+    if (isResonator(p)) {
+        // RSNT: a frame per `hop` samples, no window history -- whole hops per chunk, no halo
+        if (chunk_samples == 0 || chunk_samples % p.cfg.hop) return fail(SGZ_EINVAL, "RSNT: a chunk is a whole number of hops");
+        if (local_frames) *local_frames = chunk_samples / p.cfg.hop;
+        if (first_frame) *first_frame = uint64_t(rank) * (chunk_samples / p.cfg.hop);
+        if (halo_in) *halo_in = 0;
+        if (halo_out) *halo_out = 0;
+        return SGZ_OK;
+    }
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
     const Shard sh{chunk_samples, p.W, p.cfg.hop, world};
     if (local_frames) *local_frames = sh.framesOf(rank);
@@ -359,6 +367,46 @@ sgz_status sgz_spectrogram_render_sharded(sgz_plan *plan, void *nccl_comm, uint3
     return sgz_spectrogram_render_sharded_on(plan, &t, rank, world, d_chunk, channel_stride, chunk_samples, d_rgba, local_frames, stream);
 }
 
+// RSNT across ranks.  The resonator recurrence s[n] = c s[n-1] + x[n] is linear, so a rank renders its chunk FROM REST and is then
+// short, in every frame f, of c^((f + 1) hop) x (the state that entered its chunk).  That state is a fold of the ranks' end states --
+// one all-gather of [C][2][V][P] complex values (196 KB per rank at cfg2 sizes) -- evaluated in fp64 (launchResonatorFold), added to the
+// chained states (launchResonatorCarry), and only then do the window kernel and K_B run; K_B's own carry travels as for the FFT
+// plans.  No halo: an RSNT frame consumes exactly its `hop` samples.  Against a single-device render the frames differ by the
+// roundings of that one extra fp64 -> fp32 addition per frame: the same bar as the chained frames of a single device
+// (tests/test_gpu_resonator.py), not bit-identity.
+static sgz_status renderShardedResonator(Plan &p, const sgz_transport *t, uint32_t rank, uint32_t world, float *d_chunk, size_t channel_stride,
+                                         size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames, hipStream_t s)
+{
+    if (chunk_samples == 0 || chunk_samples % p.cfg.hop) return fail(SGZ_EINVAL, "RSNT: a chunk is a whole number of hops");
+    if (channel_stride < chunk_samples) return fail(SGZ_EINVAL, "channel_stride shorter than the chunk");
+    const long frames = long(chunk_samples / p.cfg.hop);
+    if (local_frames) *local_frames = uint64_t(frames);
+    auto bail = [&](sgz_status st) { if (world > 1 && t->abort) t->abort(t->ctx); return st; };
+    auto coll = [&](int e, const char *what) { return e == 0 ? SGZ_OK : bail(fail(SGZ_EHIP, std::string(what) + " failed (transport error " + std::to_string(e) + ")")); };
+    const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
+    const size_t resN = size_t(p.C) * 2 * size_t(p.resV) * p.P * 2;              // the resonators' state, floats
+    // work buffer: [decay end state][decay carry][world x decay end states][resonator carry][world x resonator end states]
+    sgz_status st = ensureCap(&p.d_shard, &p.shardCap, stateN * (2 + world) + resN * (1 + world));
+    if (st != SGZ_OK) return bail(st);
+    float *d_end = p.d_shard, *d_carry = d_end + stateN, *d_all = d_carry + stateN, *d_resCarry = d_all + stateN * world, *d_resAll = d_resCarry + resN;
+    if ((st = ensureCap(&p.d_mapped, &p.mappedCap, size_t(frames) * p.C * p.sides * p.P)) != SGZ_OK) return bail(st);
+    if ((st = runResonatorFromRest(p, d_chunk, channel_stride, frames, p.d_mapped, s)) != SGZ_OK) return bail(st);
+    if ((st = coll(t->allgather(t->ctx, p.d_resState, d_resAll, resN, s), "resonator end-state all-gather")) != SGZ_OK) return st;
+    long long fr[64];
+    for (uint32_t q = 0; q < world; ++q) fr[q] = frames;
+    if ((st = runResonatorJoin(p, frames, p.d_mapped, d_resAll, fr, world, rank, d_resCarry, s)) != SGZ_OK) return bail(st);
+    // the decay filters: zero-carry scan -> all-gather -> exact fold -> emit, as for the FFT plans
+    if (hipError_t e = hipMemsetAsync(d_end, 0, stateN * sizeof(float), s); e != hipSuccess) return bail(hipFail(e, "hipMemsetAsync"));
+    if ((st = runDecayColour(p, p.d_mapped, frames, nullptr, nullptr, d_end, s, /*magnitudeOnly=*/true)) != SGZ_OK) return bail(st);
+    if ((st = coll(t->allgather(t->ctx, d_end, d_all, stateN, s), "end-state all-gather")) != SGZ_OK) return st;
+    const float *carry = nullptr;
+    if (rank > 0) {
+        SGZ_HIP(launchDecayFold(d_all, fr, world, rank, stateN, p.P, p.scalars, d_carry, s));
+        carry = d_carry;
+    }
+    return runDecayEmitWithCarry(p, p.d_mapped, frames, carry, d_rgba, nullptr, nullptr, s);
+}
+
 sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport *t, uint32_t rank, uint32_t world, float *d_chunk,
                                              size_t channel_stride, size_t chunk_samples, uint8_t *d_rgba, uint64_t *local_frames,
                                              void *stream)
@@ -367,8 +415,7 @@ sgz_status sgz_spectrogram_render_sharded_on(sgz_plan *plan, const sgz_transport
         return fail(SGZ_EINVAL, "bad argument");
     Plan &p = plan->impl;
     if (!p.uploaded) { std::string err; sgz_status st = uploadPlan(p, err); if (st != SGZ_OK) return fail(st, err); }
-    if (isResonator(p))
-        return fail(SGZ_EUNSUPPORTED, "RSNT: a rank's resonators would need every earlier rank's end state (an IIR carry); single device only");
+    if (isResonator(p)) return renderShardedResonator(p, t, rank, world, d_chunk, channel_stride, chunk_samples, d_rgba, local_frames, reinterpret_cast<hipStream_t>(stream));
     if (chunk_samples < p.W) return fail(SGZ_EINVAL, "a chunk must hold at least one window");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Shard sh{chunk_samples, p.W, p.cfg.hop, world};
