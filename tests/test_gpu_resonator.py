@@ -179,7 +179,12 @@ def test_unsupported_combinations_say_so(gpu):
     x = torch.zeros((2, 4096), dtype=torch.float32, device=gpu)
     bins = torch.empty((4, 1, plan.N + 1), dtype=torch.float32, device=gpu)
     assert api.lib().sgz_stage_bins(plan.h, x.data_ptr(), x.stride(0), 4096, bins.data_ptr(), None) == api.SGZ_EUNSUPPORTED
-    assert api.lib().sgz_shard_layout(plan.h, 0, 2, 8192, None, None, None, None) == api.SGZ_EUNSUPPORTED
+    # (round 4: RSNT renders shard -- chunks of whole hops, tests/test_gpu_sharding.py::test_rsnt_shards_by_end_state_fold)
+    hop = plan.cfg.hop
+    assert api.lib().sgz_shard_layout(plan.h, 0, 2, 8 * hop + 1, None, None, None, None) == api.SGZ_EINVAL
+    lf = C.c_uint64()
+    api.check(api.lib().sgz_shard_layout(plan.h, 1, 2, 8 * hop, C.byref(lf), None, None, None))
+    assert lf.value == 8
 
 
 def _pop(h, P, want, timeout=10.0):
