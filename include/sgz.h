@@ -464,7 +464,8 @@ sgz_status sgz_peak_filter_device(const float *d_ch, size_t stride, uint32_t cha
  * Oscilloscope::runPeakFilter (OscilloscopeDSP.inl:713-886) and drawWavePlot (OscilloscopeRendering.cpp:551-891, the Linear and
  * Lanczos branches) -> the (x, y, z) + colour stream PrimitiveDrawer::addVertex / addColour receive.
  * The trigger detector, TriggeringProcessor::processMutating's window selection (StreamPreprocessing.h:79-206), the back / front
- * rings (ChannelData.h) and the envelope all live in HBM; one push = one staged copy + one kernel launch, and push never waits for
+ * rings (ChannelData.h) and the envelope all live in HBM; push stages the block -- an idle GPU starts on it at once, a busy one takes
+ * everything that arrived meanwhile in ONE staged copy + ONE launch (the blocks keep their boundaries) --, and push never waits for
  * the GPU (SGZ_BUSY instead).  One producer thread (push), one consumer thread (everything else).
  * trigger mode Spectral (sgz_scope_analyse = calculateFundamentalPeriod + calculateTriggeringOffset,
  * OscilloscopeDSP.inl:62-308, on the device ring) and the per-sample frequency colouring of audioProcessing (:445-647: 3-band
@@ -567,7 +568,7 @@ sgz_status sgz_vector_audio_processing_device(sgz_vector_filters *f, const float
 /* Vectorscope real-time handle: replaces VectorScope::Processor::onStreamAudio -> audioProcessing (Source/Vectorscope/Vectorscope.h:141,
  * Vectorscope.cpp:268-392) and the cpl::AudioStream history the renderer reads, and on the render thread VectorScope::runPeakFilter
  * (VectorscopeRendering.cpp:826-889) and drawPolarPlot (:500-746) for every channel pair -> the (x, y, z) + (r, g, b) stream
- * PrimitiveDrawer::addVertex / addColour receive.  History ring, filter states and gain live in HBM; push = one staged copy + one
+ * PrimitiveDrawer::addVertex / addColour receive.  History ring, filter states and gain live in HBM; push = (batched, as sgz_scope_push) one staged copy + one
  * launch and never waits for the GPU (SGZ_BUSY instead).  One producer thread (push), one consumer thread (everything else). */
 typedef struct sgz_vector_config {
     double   sample_rate;
