@@ -43,7 +43,14 @@ enum { SGZ_CH_LEFT = 0, SGZ_CH_RIGHT, SGZ_CH_MERGE, SGZ_CH_SIDE, SGZ_CH_PHASE, S
 /* SpectrumContent::TransformAlgorithm, Source/Spectrum/SpectrumParameters.h:66-69.  RSNT ("Resonator"): a bank of complex
  * one-pole resonators, one per axis point, advanced by every sample (TransformPair::resonatingDispatch, TransformDSP.inl:1213-1295);
  * a frame is the windowed resonator state every `hop` samples (audioEntryPoint :1172-1201, mapToLinearSpace :1103-1133).  The
- * resonator itself is cpl::dsp::CComplexResonator (absent submodule): restated from its published mathematics, see resonator.hip. */
+ * resonator itself is cpl::dsp::CComplexResonator (absent submodule): restated from its published mathematics, see resonator.hip.
+ * EXPERIMENTAL as a drop-in: Signalizer's own part of this algorithm (dispatch, cadence, Phase post-processing, everything behind the
+ * frame) follows the reference line by line, but the bank's constants -- bandwidth = spacing to the next axis point, the Q bound by the
+ * window size, pole radius exp(-pi B / fs), gain 1 - r, V = 2 K - 1 detuned vectors with the cosine-sum weights a_m / 2, the ignored
+ * vectorLength argument of mapSystemHz -- are this build's reading of what such a bank must be, checked against mathematics (an
+ * exponentially windowed DFT) and against nothing of cpl's.  A maintainer with the cpl sources should compare
+ * sgz_plan_get_resonator() with CComplexResonator::Constant after mapSystemHz (and the vector count with
+ * cpl::dsp::windowCoefficients(window).second) before shipping it; the FFT algorithm carries no such caveat beyond "parity unpinned". */
 enum { SGZ_ALGO_FFT = 0, SGZ_ALGO_RSNT = 1 };
 /* SpectrumContent::DisplayMode, Source/Spectrum/SpectrumParameters.h:60-64 (constant.displayMode, Spectrum.cpp:439).  Only the real-time
  * handle reads it: LINE_GRAPH -- the audio thread transforms nothing (TransformDSP.inl:1167; RSNT: it keeps the resonators running,
@@ -167,6 +174,9 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 #define SGZ_OPT_FETCH_WINDOW  3u
 #define SGZ_OPT_MATRIX_RESONATOR 4u /* 1 (default): RSNT frames from rest run on the fp32 matrix cores when hop is a multiple of 1024
                                       (resonator.hip resonateMfmaKernel); 0: the vector-ALU block form everywhere */
+#define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
+                                      slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab's first frame continues the state
+                                      the one before it left, sample by sample */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

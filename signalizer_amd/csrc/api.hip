@@ -223,6 +223,21 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     if (frames <= 0) return SGZ_OK;
     if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
     if (hopOverride && frames != 1) return fail(SGZ_EINVAL, "a block advance of the resonators is one frame");
+    // long renders go in slabs of frames: the per-frame states between the kernels ([frames][C][signals][V][P] complex) are V times the
+    // mapped buffer -- a ten-minute flat-top render at hop 1024 would ask for gigabytes.  A slab's first frame continues the state the
+    // slab before it left in the plan, sample by sample, exactly as the first frame of a render continues the carried state.
+    if (!skipWindow && !hopOverride) {
+        const size_t perFrame = size_t(p.C) * size_t(p.stateChannels) * size_t(p.resV) * p.P * 2 * sizeof(float);
+        const long slab = p.optResonatorSlab ? long(p.optResonatorSlab) : long(std::max<size_t>(64, (size_t(256) << 20) / perFrame));
+        if (frames > slab) {
+            for (long f0 = 0; f0 < frames; f0 += slab) {
+                const long nf = std::min(slab, frames - f0);
+                const sgz_status st = runResonator(p, d_planar + size_t(f0) * p.cfg.hop, chStride, nf, d_mapped + size_t(f0) * p.C * p.sides * p.P, stream);
+                if (st != SGZ_OK) return st;
+            }
+            return SGZ_OK;
+        }
+    }
     ResParams r;
     if (sgz_status st = fillResParams(p, d_planar, chStride, frames, d_mapped, hopOverride, r); st != SGZ_OK) return st;
     r.skipWindow = skipWindow;
@@ -585,6 +600,7 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     case SGZ_OPT_FUSED_COLOUR: p.optFusedColour = value != 0; return SGZ_OK;
     case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
     case SGZ_OPT_MATRIX_RESONATOR: p.optMatrixResonator = value != 0; return SGZ_OK;
+    case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
     default: return fail(SGZ_EINVAL, "unknown plan option");
     }
 }

@@ -118,6 +118,7 @@ struct Plan {
     DeviceScalars scalars{};
     // sgz_plan_set_option
     bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optMatrixResonator = true;
+    uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
 
     // device mirrors (owned)
     bool uploaded = false;

@@ -196,7 +196,7 @@ static sgz_status uploadMix(sgz_spectrum *s, uint32_t numSources, const uint8_t 
     SGZ_HIP(hipMemcpy(s->d_mix, m.data(), m.size(), hipMemcpyHostToDevice));
     s->numSources = numSources;
     // one second of audio may wait for the GPU (at least 32 staging pieces)
-    if (sgz_status st = s->backlog.init(size_t(numSources) * std::max<size_t>(size_t(s->plan->cfg.sample_rate), size_t(32) * kPiece)); st != SGZ_OK) return st;
+    if (sgz_status st = s->backlog.init(backlogFloats(numSources, s->plan->cfg.sample_rate, 8 * kPiece)); st != SGZ_OK) return st;
     return s->stage.init(numSources, kPiece);
 }
 

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -248,6 +249,15 @@ struct Backlog {
         if (!count) { head = tail = used = 0; }
     }
 };
+
+// The FIFO's size in floats: one second of audio, at least four of the longest blocks -- and never more than 64 MiB however long a block
+// the host announces (a 64-channel handle with max_block = 131072 asked for 1 GiB of host memory under the old "32 blocks" rule)
+inline size_t backlogFloats(uint32_t channels, double sampleRate, uint32_t maxBlock)
+{
+    const size_t perChannel = std::max<size_t>(size_t(sampleRate), size_t(4) * maxBlock);
+    const size_t cap = (size_t(64) << 20) / sizeof(float);
+    return std::max<size_t>(std::min<size_t>(size_t(channels) * perChannel, cap), size_t(channels) * maxBlock);
+}
 
 // push with the FIFO in front: drain what waited (in order) while the GPU takes it, then the new block -- directly if nothing is waiting
 // and a slot is free, behind the others otherwise.  pushNow(planar, channels, n) is the handle's own enqueue (SGZ_BUSY = no slot free,

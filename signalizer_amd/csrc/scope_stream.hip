@@ -1085,7 +1085,7 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
         if ((st = s->batch.init(C, std::max<uint32_t>(maxBlock, 8192u))) != SGZ_OK) return st;
         s->maxBlock = maxBlock;
         // one second of audio may wait for the GPU (at least 32 blocks)
-        if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
+        if ((st = s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) != SGZ_OK) return st;
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(ScopeDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peaks), size_t(kPeakCap) * sizeof(unsigned long long)));

@@ -309,7 +309,7 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         s->maxBlock = maxBlock;
         if (st != SGZ_OK) return st;
         // one second of audio may wait for the GPU (at least 32 blocks)
-        if ((st = s->backlog.init(size_t(C) * std::max<size_t>(size_t(cfg->sample_rate), size_t(32) * maxBlock))) != SGZ_OK) return st;
+        if ((st = s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) != SGZ_OK) return st;
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(VecDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_tail), 2 * sizeof(float)));

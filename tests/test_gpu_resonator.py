@@ -140,6 +140,29 @@ def test_carried_state_continues_the_stream(gpu, oracle):
     assert np.array_equal(a, whole[:8]) and diff.max() <= 1 and (diff > 0).mean() < 0.01
 
 
+def test_long_renders_go_in_slabs_of_frames(gpu, oracle):
+    """the per-frame resonator states between the kernels are V times the mapped buffer -- a long render holds them for one
+    slab of frames at a time (SGZ_OPT_RESONATOR_SLAB; default: what fits 256 MiB), each slab's first frame continuing the state the
+    slab before it left.  Slabs of 5 frames against one slab: the frames are the oracle's at the chain's bar either way, and a slab's
+    first frame (sample by sample from the exact state) costs nothing in accuracy."""
+    d = _cfg(axis_points=256)
+    hop, P, F = d["hop"], 256, 17
+    x = synth.gen(10, 48000, F * hop, 2)
+    p = oracle.params_from_dict(d)
+    xs = _cuda(x, gpu)
+    one = api.Plan(d).upload().stage_mapped(xs).cpu().numpy()
+    plan = api.Plan(d)
+    plan.set_option(api.OPT_RESONATOR_SLAB, 5)
+    slabbed = plan.upload().stage_mapped(xs).cpu().numpy()
+    r = oracle.resonator_spectrogram(p, x, want_mapped=True, want_scale=True)
+    ref = _planes(r["mapped"], d["channel_mode"], P)
+    for got in (one, slabbed):
+        problems, worst = check_planes(got, ref, r["scale"], d["channel_mode"], oracle.resonator_map(p)[1])
+        assert not problems, (problems[:5], worst)
+    assert np.array_equal(one[:5], slabbed[:5])                              # the first slab is the same launch
+    assert np.array_equal(plan.render(xs).cpu().numpy()[:5], api.Plan(d).upload().render(xs).cpu().numpy()[:5])
+
+
 @pytest.mark.parametrize("block,mode", [(256, cf.CH_SEPARATE), (480, cf.CH_PHASE), (1024, cf.CH_MERGE)])
 def test_real_time_handle_is_the_oracle_frame_by_frame(gpu, oracle, block, mode):
     """sgz_spectrum_push in RSNT mode: every block advances the resonators, a column fires every hop samples (audioEntryPoint
