@@ -233,8 +233,11 @@ __device__ unsigned long long g_ingestClk[8];
 #else
 #define ICLK(k) do { } while (0)
 #endif
-__global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams col)
+// (the colour parameters -- ~100 words with the per-channel keys -- come through a pointer: as a by-value argument they stayed live in
+// scalar registers across the loop over the batch's blocks and pushed four vector registers into scratch)
+__global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams *colp)
 {
+    const ColourParams &col = *colp;
     __shared__ long long sScan[16];
     __shared__ unsigned int sSum[16];
     __shared__ unsigned int sNumSwaps, sLastStart, sLastLen, sCursor0;
@@ -256,9 +259,15 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     // full batch, sgz_scope_flush -- submits): the blocks go through the reference's per-callback state machine ONE AFTER THE OTHER, with
     // their boundaries where the host put them (audioEntryPoint runs once per onStreamAudio: update(), the detector, processMutating's
     // window selection all see callback extents), the stream state staying in LDS in between.
+    // (the block table goes through LDS: a run-time subscript into the by-value argument struct would move the struct to scratch)
+    __shared__ uint32_t sBlockOff[BatchRing::kMaxBlocks], sBlockLen[BatchRing::kMaxBlocks];
+#pragma unroll
+    for (uint32_t b = 0; b < BatchRing::kMaxBlocks; ++b)
+        if (tid == int(b)) { sBlockOff[b] = prm.blockOff[b]; sBlockLen[b] = prm.blockLen[b]; }
+    __syncthreads();
     for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
-    const float *const blk = prm.batch + prm.blockOff[blockIndex];
-    const uint32_t n = prm.blockLen[blockIndex];
+    const float *const blk = prm.batch + sBlockOff[blockIndex];
+    const uint32_t n = sBlockLen[blockIndex];
     const unsigned long long playhead = st->playhead;
     ICLK(0);
 
@@ -998,6 +1007,7 @@ struct sgz_scope {
     float envelopeCoeff = 0.f;
     // frequency colouring (colour_by_frequency)
     ColourParams col{};
+    ColourParams *d_col = nullptr;               // device copy of `col`, what the ingest kernel reads
     // Spectral triggering
     SpectralDev *d_spectral = nullptr;
     double2 *d_tw = nullptr;
@@ -1017,7 +1027,7 @@ static void scopeFree(sgz_scope *s)
     s->backlog.release();
     for (void *p : {(void *)s->d_state, (void *)s->d_peaks, (void *)s->d_swaps, (void *)s->d_front, (void *)s->d_back, (void *)s->d_xyz,
                     (void *)s->d_rgba, (void *)s->col.st, (void *)s->col.bands, (void *)s->col.sm, (void *)s->col.block, (void *)s->col.front,
-                    (void *)s->col.back, (void *)s->d_spectral, (void *)s->d_tw})
+                    (void *)s->col.back, (void *)s->d_spectral, (void *)s->d_tw, (void *)s->d_col})
         if (p) (void)hipFree(p);
     if (s->h_out) (void)hipHostFree(s->h_out);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1167,6 +1177,9 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
     s->trigSeparate = uint32_t(std::min<size_t>(C - 1, idx));
     s->trigPair = uint32_t(std::min<size_t>(C / 4, idx) * 2);
     s->envelopeCoeff = float(std::exp(-1.0 / (cfg->envelope_window * cfg->sample_rate)));   // OscilloscopeDSP.inl:448
+    if (!s->d_col) SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_col), sizeof(ColourParams)));
+    SGZ_HIP(hipStreamSynchronize(s->stream));                                               // (no ingest launch is reading the old copy)
+    SGZ_HIP(hipMemcpy(s->d_col, &s->col, sizeof(ColourParams), hipMemcpyHostToDevice));
     s->cfg = *cfg;
     return SGZ_OK;
 }
@@ -1221,7 +1234,7 @@ static sgz_status scopeSubmit(sgz_scope *s)
     prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
     prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
     prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
-    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->col);
+    hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->d_col);
     SGZ_HIP(hipGetLastError());
     return s->batch.commit(s->stream);
 }

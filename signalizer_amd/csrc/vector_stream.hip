@@ -50,9 +50,15 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     const uint32_t size = prm.size, C = prm.channels;
     // one launch takes every block that was waiting (rt_common.hpp BatchRing), one after the other with the host's block boundaries:
     // audioProcessing drops the SIMD tail of EVERY callback (Vectorscope.cpp:292)
+    // (the block table goes through LDS: a run-time subscript into the by-value argument struct would move the struct to scratch)
+    __shared__ uint32_t sBlockOff[BatchRing::kMaxBlocks], sBlockLen[BatchRing::kMaxBlocks];
+#pragma unroll
+    for (uint32_t b = 0; b < BatchRing::kMaxBlocks; ++b)
+        if (tid == int(b)) { sBlockOff[b] = prm.blockOff[b]; sBlockLen[b] = prm.blockLen[b]; }
+    __syncthreads();
     for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
-    const float *const blk = prm.batch + prm.blockOff[blockIndex];
-    const uint32_t n = prm.blockLen[blockIndex];
+    const float *const blk = prm.batch + sBlockOff[blockIndex];
+    const uint32_t n = sBlockLen[blockIndex];
     const uint32_t cursor0 = st->cursor;
     // ring append (only the newest `size` samples of a longer block survive)
     const uint32_t skip = n > size ? n - size : 0, m = n - skip;
