@@ -24,6 +24,21 @@ inline bool isPinnedHost(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+// The address under which a kernel can write `p` directly, if `p` is pinned host memory that is mapped into the device's address space
+// (hipHostMalloc, hipHostRegister with hipHostRegisterMapped; torch's pin_memory): the vertex kernels then store straight into the
+// caller's buffers over PCIe -- no device-side staging, no DMA copy behind the kernel.  nullptr otherwise.
+inline void *mappedDevicePointer(const void *p)
+{
+#ifdef SGZ_NO_DIRECT_HOST_WRITES
+    (void)p; return nullptr;
+#else
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer || (reinterpret_cast<uintptr_t>(at.devicePointer) & 3)) return nullptr;
+    return at.devicePointer;
+#endif
+}
+
 // Device results -> the caller's host buffers, then wait.  Pinned destinations are written by the DMA engine directly; others go
 // through the handle's pinned bounce buffer `h_bounce` (room for both parts) and a host copy.
 inline sgz_status readBack(void *dstA, const void *d_a, size_t bytesA, void *dstB, const void *d_b, size_t bytesB, void *h_bounce,

@@ -1490,6 +1490,16 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
         s->vertexCap = need;
     }
     size_t points = 0;
+    // pinned, device-mapped destinations: the vertex kernel writes them itself (2.4 MB per evaluator at cfg3: the DMA copy behind the
+    // kernel was most of a rendered frame's GPU time)
+    void *mx = mappedDevicePointer(xyz), *mc = rgba ? mappedDevicePointer(rgba) : nullptr;
+    if (mx && (!rgba || mc)) {
+        const sgz_status sd = scopeVerticesInto(s, view, evaluator, channel, static_cast<float *>(mx), static_cast<uint32_t *>(mc), need, &points);
+        if (sd != SGZ_OK) return sd;
+        SGZ_HIP(hipStreamSynchronize(s->stream));
+        *count = uint32_t(points);
+        return SGZ_OK;
+    }
     const sgz_status st = scopeVerticesInto(s, view, evaluator, channel, s->d_xyz, rgba ? s->d_rgba : nullptr, need, &points);
     if (st != SGZ_OK) return st;
     if (sgz_status rb = readBack(xyz, s->d_xyz, points * 3 * sizeof(float), rgba, s->d_rgba, points * sizeof(uint32_t), s->h_out, s->stream);

@@ -532,6 +532,17 @@ sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32
     const uint32_t size = s->size, pairs = s->cfg.num_channels / 2;
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size per pair)"); }
     const size_t per = size_t(size) * 3;
+    // pinned, device-mapped destinations: the polar kernels write them themselves (no staging, no DMA copy behind the kernels)
+    float *mx = static_cast<float *>(mappedDevicePointer(xyz)), *mc = rgb ? static_cast<float *>(mappedDevicePointer(rgb)) : nullptr;
+    if (mx && (!rgb || mc)) {
+        for (uint32_t p = 0; p < pairs; ++p) {
+            const sgz_status st = vectorVerticesInto(s, p, mx + p * per, rgb ? mc + p * per : nullptr);
+            if (st != SGZ_OK) return st;
+        }
+        SGZ_HIP(hipStreamSynchronize(s->stream));
+        *count = size;
+        return SGZ_OK;
+    }
     for (uint32_t p = 0; p < pairs; ++p) {
         const sgz_status st = vectorVerticesInto(s, p, s->d_xyz + p * per, rgb ? s->d_rgb + p * per : nullptr);
         if (st != SGZ_OK) return st;
