@@ -44,7 +44,8 @@ struct VecIngest {
 
 __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
 {
-    __shared__ float sL[64], sR[64], sP[64];
+    constexpr int kTile = 2048;
+    __shared__ float sL[kTile], sR[kTile], sP[kTile];
     VecDev *st = prm.st;
     const int tid = threadIdx.x;
     const uint32_t size = prm.size, C = prm.channels;
@@ -71,49 +72,47 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     // audioProcessing on channels 0 / 1 (Vectorscope.cpp:268-377): wave 0; lane k < 8 owns one recurrence:
     // 0,1 envelope L/R; 2,3 slow balance L/R; 4,5 fast balance L/R; 6 slow phase; 7 fast phase
     const uint32_t np = n - (n & (prm.lanes - 1));                        // :292, the SIMD tail of the block is dropped
+    // The eight recurrences' inputs -- l^2, r^2 and cos(2 atan(vY / vX)) of every sample -- do not depend on the recurrences: all 256
+    // threads evaluate them for a tile of kTile samples into LDS, then lanes 0 .. 7 of wave 0 walk the tile, sixteen inputs per LDS
+    // round trip.  (Until round 4 wave 0 alternated the two in 64-sample steps with two wave barriers each: the other three waves
+    // idled and the chain stopped for an atan and a cos every 64 steps -- 13 us per 512-sample block.)
+    float y = 0.f, a = 0.f;
+    if (tid < 8) {
+        const float *sp = reinterpret_cast<const float *>(st);
+        y = sp[tid];
+        a = tid < 2 ? prm.envelope : ((tid == 2 || tid == 3 || tid == 6) ? prm.pole0 : prm.pole1);
+    }
+    const int sel = (tid == 0 || tid == 2 || tid == 4) ? 0 : ((tid == 1 || tid == 3 || tid == 5) ? 1 : 2);
+    for (uint32_t base = 0; base < np; base += kTile) {
+        const uint32_t cnt = min(uint32_t(kTile), np - base);
+        const float *L = blk, *R = blk + n;
+        for (uint32_t k = tid; k < cnt; k += blockDim.x) {
+            const float l = L[base + k], r = R[base + k];
+            const float mReal = -0.70710678118654752440f, mImag = 0.70710678118654752440f;
+            const float vX = l * mReal - r * mImag;                    // :303
+            const float vY = r * mImag + l * mReal;                    // :304
+            const float radians = atanf(vY / vX);                      // :310
+            const float ang = (vX == 0.f && vY == 0.f) ? 0.78539816339744830962f : radians;   // :311
+            sP[k] = cosf(ang * 2.0f);                                  // :316
+            sL[k] = l * l; sR[k] = r * r;                              // :323-324
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float *src = sel == 0 ? sL : (sel == 1 ? sR : sP);
+            uint32_t k0 = 0;
+            for (; k0 + 16 <= cnt; k0 += 16) {                         // whole batches: straight-line chain, no predicate per step
+                float xs[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xs[j] = src[k0 + uint32_t(j)];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const float x = xs[j]; y = x + a * (y - x); }                       // :327-342
+            }
+            for (; k0 < cnt; ++k0) { const float x = src[k0]; y = x + a * (y - x); }
+        }
+        __syncthreads();
+    }
     if (tid < 64) {
         const int lane = tid;
-        float y = 0.f, a = 0.f;
-        if (lane < 8) {
-            const float *s = reinterpret_cast<const float *>(st);
-            y = s[lane];
-            a = lane < 2 ? prm.envelope : ((lane == 2 || lane == 3 || lane == 6) ? prm.pole0 : prm.pole1);
-        }
-        const int sel = (lane == 0 || lane == 2 || lane == 4) ? 0 : ((lane == 1 || lane == 3 || lane == 5) ? 1 : 2);
-        const float *L = blk, *R = blk + n;
-        for (uint32_t base = 0; base < np; base += 64) {
-            const uint32_t i = base + lane;
-            if (i < np) {
-                const float l = L[i], r = R[i];
-                const float mReal = -0.70710678118654752440f, mImag = 0.70710678118654752440f;
-                const float vX = l * mReal - r * mImag;                    // :303
-                const float vY = r * mImag + l * mReal;                    // :304
-                const float radians = atanf(vY / vX);                      // :310
-                const float ang = (vX == 0.f && vY == 0.f) ? 0.78539816339744830962f : radians;   // :311
-                sP[lane] = cosf(ang * 2.0f);                               // :316
-                sL[lane] = l * l; sR[lane] = r * r;                        // :323-324
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < 8) {
-                const float *src = sel == 0 ? sL : (sel == 1 ? sR : sP);
-                const int cnt = int(min(64u, np - base));
-                // (sixteen inputs at a time into registers, then the dependent steps: one LDS round trip per sixteen instead of one per step,
-                // which is what the 22 us of this kernel were)
-                for (int k0 = 0; k0 < cnt; k0 += 16) {
-                    float xs[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) xs[j] = src[(k0 + j) & 63];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (k0 + j < cnt) { const float x = xs[j]; y = x + a * (y - x); }                    // :327-342
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
         // :346-376: the envelope filters are stored (and the gain refreshed) only in the RMS mode; balance and phase always
         const float e0 = __shfl(y, 0), e1 = __shfl(y, 1);
         if (lane < 8 && (lane >= 2 || prm.envMode == 1u)) reinterpret_cast<float *>(st)[lane] = y;
