@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 
 #include <cmath>
 #include <cstring>
@@ -173,32 +174,33 @@ __device__ __forceinline__ uint32_t accumulateColour(const float st[3], const fl
     return out;
 }
 
-__device__ __forceinline__ long long waveInclusiveMax(long long v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long u = __shfl_up(v, o);
-        if (lane >= o && u > v) v = u;
-    }
-    return v;
-}
-// exclusive prefix-max over the workgroup's threads in thread order, seeded with `init`; *total = max over everything (and init)
-__device__ __forceinline__ long long blockExclusiveMax(long long v, long long init, long long *lds, long long *total)
+// two exclusive prefix-max scans at once on 32-bit values (the zero-crossing phase's "last arm" / "last threshold crossing": sample
+// indices of one block and small negative sentinels) -- one pass of shuffles, one pair of barriers.  (As two 64-bit scans they were
+// 3.7 us of the phase's 6.6: every 64-bit shuffle is two permutes, every scan two barriers of sixteen waves.)
+__device__ __forceinline__ void blockExclusiveMax2(int va, int initA, int vb, int initB, int *lds /*[32]*/, int &inA, int &inB, int &totA, int &totB)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const long long inc = waveInclusiveMax(v);
-    if (lane == 63) lds[wave] = inc;
+    int ia = va, ib = vb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+        if (lane >= o) { ia = ua > ia ? ua : ia; ib = ub > ib ? ub : ib; }
+    }
+    if (lane == 63) { lds[wave] = ia; lds[16 + wave] = ib; }
     __syncthreads();
-    long long base = init;
-    for (int w = 0; w < wave; ++w) base = lds[w] > base ? lds[w] : base;
-    long long tot = init;
-    for (int w = 0; w < waves; ++w) tot = lds[w] > tot ? lds[w] : tot;
-    long long prev = __shfl_up(inc, 1);
-    if (lane == 0) prev = -(1ll << 62);
+    int baseA = initA, baseB = initB, ta = initA, tb = initB;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int pa = lds[w], pb = lds[16 + w];
+        if (w < wave) { baseA = pa > baseA ? pa : baseA; baseB = pb > baseB ? pb : baseB; }
+        if (w < waves) { ta = pa > ta ? pa : ta; tb = pb > tb ? pb : tb; }
+    }
+    int prevA = __shfl_up(ia, 1), prevB = __shfl_up(ib, 1);
+    if (lane == 0) { prevA = INT_MIN; prevB = INT_MIN; }
     __syncthreads();
-    *total = tot;
-    return prev > base ? prev : base;
+    totA = ta; totB = tb;
+    inA = prevA > baseA ? prevA : baseA;
+    inB = prevB > baseB ? prevB : baseB;
 }
 __device__ __forceinline__ unsigned int blockExclusiveSum(unsigned int v, unsigned int *lds, unsigned int *total)
 {
@@ -238,7 +240,7 @@ __device__ unsigned long long g_ingestClk[8];
 __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams *colp)
 {
     const ColourParams &col = *colp;
-    __shared__ long long sScan[16];
+    __shared__ int sScan2[32];
     __shared__ unsigned int sSum[16];
     __shared__ unsigned int sNumSwaps, sLastStart, sLastLen, sCursor0;
     __shared__ unsigned long long sWritten0;
@@ -342,23 +344,22 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         const uint32_t i0 = min(n, uint32_t(tid) * seg), i1 = min(n, i0 + seg);
         // arm_i = (s_i > 0 && s_{i-1} < 0); fire_i <=> s_i > threshold && lastArm(i) > lastThr(i-1)  (virtual indices: an arm
         // inherited from the previous block sits at -1, "no arm" at -3, "no threshold crossing yet" at -2)
-        long long segArm = -(1ll << 62), segThr = -(1ll << 62);
+        int segArm = INT_MIN, segThr = INT_MIN;                           // (sample indices of this block, < 2^31; "nothing yet" below every sentinel)
         for (uint32_t i = i0; i < i1; ++i) {
             const double s = trigSample(localMode, a, b, i);
             const double prev = i ? trigSample(localMode, a, b, i - 1) : prevState;
-            if (s > 0 && prev < 0) segArm = i;
-            if (s > threshold) segThr = i;
+            if (s > 0 && prev < 0) segArm = int(i);
+            if (s > threshold) segThr = int(i);
         }
-        long long totArm, totThr;
-        const long long inArm = blockExclusiveMax(segArm, armedIn ? -1 : -3, sScan, &totArm);
-        const long long inThr = blockExclusiveMax(segThr, -2, sScan, &totThr);
-        long long la = inArm, lt = inThr;
+        int totArm, totThr, inArm, inThr;
+        blockExclusiveMax2(segArm, armedIn ? -1 : -3, segThr, -2, sScan2, inArm, inThr, totArm, totThr);
+        int la = inArm, lt = inThr;
         unsigned int fires = 0;
         for (uint32_t i = i0; i < i1; ++i) {
             const double s = trigSample(localMode, a, b, i);
             const double prev = i ? trigSample(localMode, a, b, i - 1) : prevState;
-            if (s > 0 && prev < 0) la = i;
-            if (s > threshold) { if (la > lt) ++fires; lt = i; }
+            if (s > 0 && prev < 0) la = int(i);
+            if (s > threshold) { if (la > lt) ++fires; lt = int(i); }
         }
         unsigned int totalFires;
         unsigned int pos = blockExclusiveSum(fires, sSum, &totalFires);
@@ -367,13 +368,13 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         for (uint32_t i = i0; i < i1; ++i) {
             const double s = trigSample(localMode, a, b, i);
             const double prev = i ? trigSample(localMode, a, b, i - 1) : prevState;
-            if (s > 0 && prev < 0) la = i;
+            if (s > 0 && prev < 0) la = int(i);
             if (s > threshold) {
                 if (la > lt) {
                     if (qc0 + pos < kPeakCap) prm.peaks[(q0 + qc0 + pos) % kPeakCap] = (la == -1) ? originIn : playhead + (unsigned long long)la;
                     ++pos;
                 }
-                lt = i;
+                lt = int(i);
             }
         }
         __syncthreads();
