@@ -286,3 +286,87 @@ def test_colour_mode_line_results_are_the_newest_frames(gpu):
             assert np.array_equal(one.view(np.uint32), want[g].view(np.uint32))
     finally:
         L.sgz_spectrum_destroy(h)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_block_structures_through_both_modes(gpu, seed):
+    """seeded sweep: random window / hop / block-size mixes / audio histories / channel modes through the strict framing AND the line
+    graph -- the handle's bytes against the offline render of the frames tests/stream_windows.py says each path sees (that render is
+    held to the oracle by the named tests above and by tests/test_gpu_fuzz.py)"""
+    rng = np.random.default_rng(1000 + seed)
+    L = api.lib()
+    for case in range(6):
+        W = int(rng.choice([1024, 2048, 4096]))
+        hop = int(rng.integers(50, W))
+        P = int(rng.integers(40, 300))
+        mode = int(rng.choice([config.CH_LEFT, config.CH_MERGE, config.CH_SEPARATE, config.CH_MIDSIDE, config.CH_COMPLEX]))
+        pairs = int(rng.integers(1, 3))
+        sizes = [int(v) for v in rng.integers(1, 3000, size=int(rng.integers(1, 5)))]
+        x = synth.gen(int(rng.integers(1, 1 << 20)), 48000, int(rng.integers(3 * W, 6 * W)), 2 * pairs)
+        blocks = cut(x, sizes)
+        extra = int(rng.choice([0, 0, 1, 37, W // 2]))
+        # --- strict framing
+        cfg = config.spectrum_config(window_size=W, hop=hop, axis_points=P, channel_mode=mode, num_pairs=pairs)
+        frames, per_block = strict_frames(blocks, W, hop, history=W + extra)
+        if frames:
+            want, _, _, _, _ = _offline(cfg, frames, gpu)
+            h = _create(cfg)
+            try:
+                api.check(L.sgz_spectrum_set_option(h, OPT_STRICT, 1))
+                api.check(L.sgz_spectrum_set_option(h, OPT_HISTORY, W + extra))
+                got, expect, at = [], [], 0
+                for blk, n in zip(blocks, per_block):
+                    _push(h, blk)
+                    kept = min(n, 10)
+                    cols = _pop(h, P, kept)
+                    assert len(cols) == kept, (seed, case)
+                    got += cols
+                    expect += list(want[at:at + kept])
+                    at += n
+                if got:
+                    assert np.array_equal(np.stack(got), np.stack(expect)), (seed, case, W, hop, sizes, extra, mode)
+            finally:
+                L.sgz_spectrum_destroy(h)
+        # --- line graph
+        cfg = dict(cfg, display_mode=config.DISPLAY_LINE_GRAPH)
+        render_after = sorted(int(v) for v in rng.integers(0, len(blocks), size=5))
+        wins = newest_windows(blocks, W, render_after)
+        _, want, _, _, _ = _offline(cfg, wins, gpu, want_lines=True)
+        h = _create(cfg)
+        try:
+            out, got = np.zeros((pairs, 2, P, 2), np.float32), []
+            for k, blk in enumerate(blocks):
+                _push(h, blk)
+                for _ in [q for q in render_after if q == k]:
+                    api.check(L.sgz_spectrum_render_lines(h, None, out.ctypes.data_as(C.c_void_p)))
+                    got.append(out.copy())
+            got = np.stack(got)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, case, W, sizes, mode)
+        finally:
+            L.sgz_spectrum_destroy(h)
+
+
+def test_strict_quirks_with_callbacks_longer_than_a_staged_piece(gpu):
+    """a 40 000-sample callback is staged in three pieces and makes 57 frames, every one of them from the history before the callback and
+    the first <= hop samples of the block (all after the first piece): the frame queue keeps ten of them, the states advance over all"""
+    W, hop, P = 4096, 700, 120
+    cfg = config.spectrum_config(window_size=W, hop=hop, axis_points=P)
+    x = synth.gen(48, 48000, 93000, 2)
+    blocks = cut(x, [40000, 20000, 33000])
+    frames, per_block = strict_frames(blocks, W, hop)
+    want, _, _, _, _ = _offline(cfg, frames, gpu)
+    h = _create(cfg)
+    try:
+        api.check(api.lib().sgz_spectrum_set_option(h, OPT_STRICT, 1))
+        at = 0
+        for blk, n in zip(blocks, per_block):
+            assert n > 10
+            _push(h, blk)
+            cols = _pop(h, P, 10)
+            assert len(cols) == 10 and np.array_equal(np.stack(cols), want[at:at + 10]), at
+            at += n
+        dropped, refused = C.c_uint64(0), C.c_uint64(0)
+        api.check(api.lib().sgz_spectrum_stats(h, C.byref(dropped), C.byref(refused)))
+        assert dropped.value == sum(per_block) - 30 and refused.value == 0
+    finally:
+        api.lib().sgz_spectrum_destroy(h)
