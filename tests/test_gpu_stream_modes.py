@@ -370,3 +370,56 @@ def test_strict_quirks_with_callbacks_longer_than_a_staged_piece(gpu):
         assert dropped.value == sum(per_block) - 30 and refused.value == 0
     finally:
         api.lib().sgz_spectrum_destroy(h)
+
+
+def test_render_thread_and_audio_thread_run_concurrently(gpu):
+    """the render thread's calls (render_lines, track_peak, line_results, backlog / stats polling) take no lock against push: a producer
+    thread pushes 3000 blocks flat out while the consumer renders as fast as it can.  No call may fail or refuse, and once the producer
+    has stopped the next render is exactly the offline result for the ring's final window (nothing was torn on the way)."""
+    import threading
+    W, P = 4096, 200
+    cfg = config.spectrum_config(window_size=W, hop=1024, axis_points=P, display_mode=config.DISPLAY_LINE_GRAPH, pole=(0.0, 0.0))
+    x = synth.gen(49, 48000, 3000 * 160, 2)
+    blocks = cut(x, [160])
+    h = _create(cfg)
+    L = api.lib()
+    L.sgz_spectrum_backlog.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    errors, renders = [], [0]
+    stop = threading.Event()
+
+    def producer():
+        try:
+            for blk in blocks:
+                ptrs = (C.c_void_p * 2)(blk[0].ctypes.data, blk[1].ctypes.data)
+                st = L.sgz_spectrum_push(h, ptrs, 2, blk.shape[1])
+                if st != api.SGZ_OK:
+                    errors.append(("push", st))
+                    return
+        finally:
+            stop.set()
+
+    def consumer():
+        out = np.zeros((1, 2, P, 2), np.float32)
+        pk = api.Peak()
+        d, w = C.c_uint64(), C.c_uint32()
+        while not stop.is_set():
+            for st in (L.sgz_spectrum_render_lines(h, None, out.ctypes.data_as(C.c_void_p)), L.sgz_spectrum_track_peak(h, 0, 0.5, C.byref(pk)),
+                       L.sgz_spectrum_backlog(h, C.byref(d), C.byref(w))):
+                if st != api.SGZ_OK:
+                    errors.append(("consumer", st, L.sgz_last_error()))
+                    return
+            renders[0] += 1
+
+    tp, tc = threading.Thread(target=producer), threading.Thread(target=consumer)
+    tc.start(); tp.start(); tp.join(timeout=120); tc.join(timeout=120)
+    try:
+        assert not errors and not tp.is_alive() and not tc.is_alive(), errors[:3]
+        assert renders[0] > 10
+        api.check(L.sgz_spectrum_flush(h))
+        out = np.zeros((1, 2, P, 2), np.float32)
+        api.check(L.sgz_spectrum_render_lines(h, None, out.ctypes.data_as(C.c_void_p)))
+        # poles 0: the filters hold no memory, so the result is the newest window's alone
+        _, want, _, _, _ = _offline(cfg, [np.ascontiguousarray(x[:, -W:])], gpu, want_lines=True)
+        assert np.array_equal(out.view(np.uint32), want[0].view(np.uint32))
+    finally:
+        L.sgz_spectrum_destroy(h)
