@@ -42,8 +42,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         else:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",
                    "-x", "hip", "-c", s, "-o", o] + os.environ.get("SGZ_EXTRA_HIPCC_FLAGS", "").split()
-            if s.endswith("spectrum_fft.hip") or s.endswith("spectrum_real.hip"):
-                cmd.append("-fno-slp-vectorize")   # packed-f32 SLP adds v_mov shuffles around the butterflies (measured -2.5 %)
+            if s.endswith(("spectrum_fft.hip", "spectrum_real.hip", "resonator.hip")):
+                cmd.append("-fno-slp-vectorize")   # packed-f32 SLP adds v_mov shuffles around the butterflies (measured -2.5 %) and beside the MFMAs
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -38,7 +38,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resPowB, d_resPowBLo, d_resW1, d_resW2, d_resTile, d_resGain, d_resState, d_resLocal};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resPowB, d_resPowBLo, d_resW1, d_resW2, d_resW1b, d_resTile, d_resGain, d_resState, d_resLocal};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -98,6 +98,7 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.resPowBLo, &p.d_resPowBLo)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resW1, &p.d_resW1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resW2, &p.d_resW2)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.resW1b, &p.d_resW1b)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resTile, &p.d_resTile)) != SGZ_OK) return st;
     if ((st = uploadVec(p.resGain, &p.d_resGain)) != SGZ_OK) return st;
     if (isResonator(p)) {                                  // the resonators start from rest (TransformPair.h:183 resetState)
@@ -204,8 +205,10 @@ static sgz_status fillResParams(Plan &p, const float *d_planar, size_t chStride,
     r.cpow = reinterpret_cast<const float4 *>(p.d_resPow);
     r.cpowB = reinterpret_cast<const float2 *>(p.d_resPowB);
     r.cpowBLo = reinterpret_cast<const float2 *>(p.d_resPowBLo);
+    r.matrixForm = p.optMatrixResonator;
     r.w1 = p.optMatrixResonator ? reinterpret_cast<const float2 *>(p.d_resW1) : nullptr;       // (null: hop is not a multiple of 1024)
     r.w2 = reinterpret_cast<const float2 *>(p.d_resW2);
+    r.w1b = reinterpret_cast<const uint4 *>(p.d_resW1b);
     r.tilePow = reinterpret_cast<const float4 *>(p.d_resTile);
     r.gain = p.d_resGain;
     for (int v = 0; v < 9; ++v) r.weights[v] = p.resWeights[v];
@@ -241,12 +244,7 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     ResParams r;
     if (sgz_status st = fillResParams(p, d_planar, chStride, frames, d_mapped, hopOverride, r); st != SGZ_OK) return st;
     r.skipWindow = skipWindow;
-    // frame 0's sample-by-sample walk runs beside the matrix kernel on the plan's second stream (the one the sharded render uses for
-    // its halo: RSNT renders are single device)
-    if (r.w1 && frames > 1)
-        if (sgz_status s2 = ensureSecondStream(p); s2 != SGZ_OK) return s2;
-    SGZ_HIP(launchResonator(r, stream, static_cast<hipStream_t>(p.shardStream), static_cast<hipEvent_t>(p.shardEv[0]),
-                            static_cast<hipEvent_t>(p.shardEv[1])));
+    SGZ_HIP(launchResonator(r, stream));
     return SGZ_OK;
 }
 
@@ -599,7 +597,7 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     case SGZ_OPT_CHANNEL_SPLIT: p.optChannelSplit = value != 0; return SGZ_OK;
     case SGZ_OPT_FUSED_COLOUR: p.optFusedColour = value != 0; return SGZ_OK;
     case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
-    case SGZ_OPT_MATRIX_RESONATOR: p.optMatrixResonator = value != 0; return SGZ_OK;
+    case SGZ_OPT_MATRIX_RESONATOR: if (value > 2) return fail(SGZ_EINVAL, "SGZ_OPT_MATRIX_RESONATOR: 0, 1 or 2"); p.optMatrixResonator = int(value); return SGZ_OK;
     case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
     default: return fail(SGZ_EINVAL, "unknown plan option");
     }

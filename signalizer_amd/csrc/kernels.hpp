@@ -164,17 +164,19 @@ struct ResParams {
     const float4 *cpow;               // [V][P]: pole^hop as (re, im, re_lo, im_lo)
     const float2 *cpowB;              // [V][P][8]: pole^1 .. pole^8
     const float2 *cpowBLo;            // [V][P][2]: low words of pole^4, pole^8
-    const float2 *w1, *w2;            // [V][P][32]: resonateMfmaKernel's weights (null: not available for this hop)
+    const float2 *w1, *w2;            // [32][V][P]: the matrix kernels' weights (null: not available for this hop, or switched off)
+    const uint4 *w1b;                 // [2 kh][2 h][3 parts][re, im][V][P]: w1 as bf16 parts, eight consecutive samples' weights per entry (B operands)
+    int matrixForm;                   // 1: bfloat16 matrix cores, every fp32 value as three exact bf16 parts (default); 2: fp32 matrix cores
     const float4 *tilePow;            // [V][P]: pole^1024 (hi, lo)
     const float *gain;                // [P]
     float weights[9];                 // [V]
     float2 *state;                    // [C][2][V][P]
     float2 *local;                    // [frames][C][signals][V][P]
     float *mapped;                    // [frames][C][sides][P]
+    bool allFromRest;                 // set by the launcher: every frame of `local` started from rest (matrix kernels), the chain starts at `state`
     bool skipWindow;                  // stop behind the chain (sharded render: the carry of the ranks in front is added first, launchResonatorCarry)
 };
-// aux / evFork / evJoin: a second stream and two events (may be null: then everything runs on `stream`)
-hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin);
+hipError_t launchResonator(const ResParams &prm, hipStream_t stream);
 // Time-chunk sharding of an RSNT render (sharded.hip).  The recurrence is linear: a rank that starts from rest is short of
 // pole^(samples since its chunk began) x (the state that entered its chunk), for every frame.  fold: that entering state from the
 // gathered end states of the ranks in front, s <- pole^(chunk_q) s + end_q in fp64 (pole^chunk by squaring pole^hop, hi + lo words);

@@ -508,8 +508,8 @@ static void buildResonator(Plan &p)
     p.resPowBLo.assign(size_t(V) * P * 2 * 2, 0.f);
     // matrix-core form of the frames from rest (resonator.hip resonateMfmaKernel): needs whole tiles of 32 blocks x 32 samples per frame
     const bool mfma = cfg.hop % 1024u == 0;
-    p.resW1.clear(); p.resW2.clear(); p.resTile.clear();
-    if (mfma) { p.resW1.assign(size_t(V) * P * 32 * 2, 0.f); p.resW2.assign(size_t(V) * P * 32 * 2, 0.f); p.resTile.assign(size_t(V) * P * 4, 0.f); }
+    p.resW1.clear(); p.resW2.clear(); p.resTile.clear(); p.resW1b.clear();
+    if (mfma) { p.resW1.assign(size_t(V) * P * 32 * 2, 0.f); p.resW2.assign(size_t(V) * P * 32 * 2, 0.f); p.resTile.assign(size_t(V) * P * 4, 0.f); p.resW1b.assign(size_t(24) * V * P * 4, 0u); }
     p.resGain.assign(P, 0.f);
     for (uint32_t i = 0; i < P; ++i) {
         const uint32_t k = i + 1 >= P ? P - 2 : i;
@@ -555,6 +555,28 @@ static void buildResonator(Plan &p)
                     cpowd(32 * (31 - k), xr, xi);
                     p.resW2[((size_t(k) * V + v) * P + i) * 2] = float(xr); p.resW2[((size_t(k) * V + v) * P + i) * 2 + 1] = float(xi);
                 }
+                // the same weights as three bfloat16 parts each: h = bf16(x), m = bf16(x - h), l = x - h - m (at most eight significant bits
+                // are left: exact), round to nearest even; entry [kh][h][part][re / im] holds samples 16 kh + 8 h + 0 .. 7 of a block
+                auto bf16High = [](float x) { uint32_t u; std::memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return u & 0xffff0000u; };
+                auto asFloat = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+                for (uint32_t kh = 0; kh < 2; ++kh)
+                    for (uint32_t hh = 0; hh < 2; ++hh)
+                        for (uint32_t c = 0; c < 2; ++c) {
+                            uint32_t part[3][8];
+                            for (uint32_t e = 0; e < 8; ++e) {
+                                const float x = p.resW1[((size_t(16 * kh + 8 * hh + e) * V + v) * P + i) * 2 + c];
+                                part[0][e] = bf16High(x);
+                                const float r1 = x - asFloat(part[0][e]);
+                                part[1][e] = bf16High(r1);
+                                const float r2 = r1 - asFloat(part[1][e]);
+                                std::memcpy(&part[2][e], &r2, 4);
+                                part[2][e] &= 0xffff0000u;
+                            }
+                            for (uint32_t q = 0; q < 3; ++q) {
+                                uint32_t *dst = &p.resW1b[((size_t(((kh * 2 + hh) * 3 + q) * 2 + c) * V + v) * P + i) * 4];
+                                for (uint32_t w = 0; w < 4; ++w) dst[w] = (part[q][2 * w] >> 16) | part[q][2 * w + 1];
+                            }
+                        }
                 double tr, ti;
                 cpowd(1024, tr, ti);
                 float *q = &p.resTile[(size_t(v) * P + i) * 4];

@@ -112,12 +112,14 @@ struct Plan {
     std::vector<float> resPowB;         // [V][P][8] (re, im): (the fp32 pole)^1 .. ^8, rounded once each -- the block steps of resonateKernel
     std::vector<float> resPowBLo;       // [V][P][2] (re, im): low words of pole^4 and pole^8
     std::vector<float> resW1, resW2;    // hop % 1024 == 0: [32][V][P] (re, im): pole^(31 - b) and pole^(32 (31 - a)), the weights of resonateMfmaKernel (resonator index last: a wave's 32 lanes read 32 neighbours)
+    std::vector<uint32_t> resW1b;       // [2][2][3][2][V][P][4]: resW1 as three bfloat16 parts each (x = h + m + l exactly), packed as the B operands of resonateMfmaBf16Kernel
     std::vector<float> resTile;         // [V][P] (re, im, re_lo, im_lo): pole^1024
     std::vector<float> resGain;         // [P]
     float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
     // sgz_plan_set_option
-    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optMatrixResonator = true;
+    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false;
+    int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
 
     // device mirrors (owned)
@@ -150,6 +152,7 @@ struct Plan {
     const float *lateDeferred = nullptr;   // the `mapped` buffer whose channel-split K_A left its late pixels (late_fix.hpp) to the next K_B on it, or null
     long lateFrames = 0;                   // ... and how many frames that launch covered (d_ny / d_nyBest hold exactly those)
     void *shardStream = nullptr; void *shardEv[2] = {nullptr, nullptr};   // sgz_spectrogram_render_sharded: the halo exchange's own stream (hipStream_t / hipEvent_t)
+    uint32_t *d_resW1b = nullptr;
     float *d_resCoeff = nullptr, *d_resPow = nullptr, *d_resPowB = nullptr, *d_resPowBLo = nullptr, *d_resW1 = nullptr, *d_resW2 = nullptr, *d_resTile = nullptr, *d_resGain = nullptr;
     float *d_resState = nullptr;                          // [C][2][V][P] (re, im): the resonators between calls
     float *d_resLocal = nullptr; size_t resLocalCap = 0;  // [frames][C][signals][V][P] (re, im): per-frame sums from rest

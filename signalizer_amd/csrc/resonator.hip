@@ -181,6 +181,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SGZ_RES_WAVES
 #define SGZ_RES_WAVES 4
 #endif
+#ifndef SGZ_RES_UPW
+#define SGZ_RES_UPW 4
+#endif
+constexpr unsigned kResUnitsPerWg = SGZ_RES_UPW;                     // units (frame, pair, signal) a workgroup of the bf16 form walks in a row
+#ifndef SGZ_RES_BF16_OCC
+#define SGZ_RES_BF16_OCC 3                                          // waves per SIMD the bf16 form is compiled for (168 registers)
+#endif
 
 // WAVES: (vector, group) waves per workgroup -- they share the tile's samples in LDS and meet at one barrier per tile
 template <int WAVES = 4>
@@ -195,10 +202,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void resonateMfmaKernel(ResParams pr
     const uint32_t v = liveWave ? g / groups : 0u;
     const uint32_t i = liveWave ? (g - v * groups) * 32 + (lane & 31) : 0u;
     const bool live = liveWave && i < prm.P;
-    const uint32_t unit = blockIdx.y;                                // (frame - 1, pair, signal)
+    const uint32_t unit = blockIdx.y;                                // (frame, pair, signal)
     const int signal = int(unit % uint32_t(prm.signals));
     const uint32_t pair = (unit / uint32_t(prm.signals)) % prm.C;
-    const long frame = 1 + long(unit / (uint32_t(prm.signals) * prm.C));
+    const long frame = long(unit / (uint32_t(prm.signals) * prm.C));
     const float *L = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;
     const float *R = L + prm.chStride;
     const size_t at = (size_t(v) * prm.P + (live ? i : 0u));
@@ -255,6 +262,203 @@ __global__ __launch_bounds__(64 * WAVES, 4) void resonateMfmaKernel(ResParams pr
         prm.local[((size_t(frame) * prm.C + pair) * size_t(prm.signals) + size_t(signal)) * V * prm.P + size_t(v) * prm.P + i] = float2{sre, sim};
 }
 
+// ---- the same block sums on the bfloat16 matrix cores, sixteen times the fp32 form's rate, without giving up fp32 accuracy: every
+// fp32 value is the EXACT sum of three bfloat16 (x = h + m + l: 24 significant bits = 3 x 8, each part the round-to-nearest of what
+// the parts before left; the last residual has at most eight significant bits), so
+//     x w = hh + (hm + mh) + (hl + lh + mm) + [ml + lm + ll  <  2^-23 |x w|: dropped],
+// six v_mfma_f32_32x32x16_bf16 products with exact bf16 x bf16 terms accumulated in fp32 -- 24 MFMAs of 32 cycles per tile instead of
+// 32 of 64 cycles, small terms first.  A operand: lane l holds block a = l & 31, samples k = 16 kh + 8 (l >> 5) + e (e < 8) of the
+// block; B operand: resonator n = l & 31, the weights of the same samples (the contraction index only has to agree between the two).
+// The samples are split when they are parked in LDS (three bf16 planes, rows padded to 80 bytes: a wave's ds_read_b128 touch every
+// bank once), the weights once per workgroup from the same fp32 table as the fp32 form's.  Everything behind the block sums (the dot
+// product with the powers of pole^32, the tile recurrence) is the fp32 form's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// resMix as  x = cl l + cr r  with cl, cr in {0, 1, -1}: the products are exact and the sum rounds once, as the reference's l + r / l - r
+__device__ __forceinline__ void resMixCoeff(uint32_t mode, int signal, float &cl, float &cr)
+{
+    switch (mode) {
+    case SGZ_CH_RIGHT: cl = 0.f; cr = 1.f; break;
+    case SGZ_CH_LEFT: cl = 1.f; cr = 0.f; break;
+    case SGZ_CH_MERGE: cl = 1.f; cr = 1.f; break;
+    case SGZ_CH_SIDE: cl = 1.f; cr = -1.f; break;
+    case SGZ_CH_MIDSIDE: cl = 1.f; cr = signal == 0 ? -1.f : 1.f; break;
+    default: cl = signal == 0 ? 1.f : 0.f; cr = signal == 0 ? 0.f : 1.f; break;
+    }
+}
+
+// The loop is software-pipelined by hand.  Back-to-back MFMAs of one wave wait in the SIMD's issue stage for the matrix pipe and
+// nothing else issues meanwhile (first form of this kernel: MFMA pipe 51 % busy, vector issue 58 %, the two adding up instead of
+// overlapping), so every MFMA is followed by a handful of independent vector instructions of the SAME wave: while the twelve
+// products of the real block sums run, the previous tile's imaginary block sums are folded into the state; while the twelve of the
+// imaginary sums run, the next tile's samples are split and parked and this tile's real sums are folded (sched_barrier pins the
+// order).  The two 32-lane halves of a wave hold 16 block sums each of every resonator: the tile recurrence is linear, so each half
+// carries its own partial state and the halves meet once per unit.  A workgroup walks `unitsPerWg` consecutive units (frame, pair,
+// signal) as ONE stream of tiles -- the weights are fetched once and the pipeline never drains between units (samples of the next
+// unit are requested and parked while the last tiles of this one are multiplied).
+template <int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16Kernel(ResParams prm, int V, uint32_t nUnits, uint32_t unitsPerWg)
+{
+    constexpr int TH = 64 * WAVES, PER = 1024 / TH;                  // threads, samples a thread stages per tile
+    constexpr int ROW = 40;                                          // uint16 per padded row of 32 samples (80 bytes)
+    __shared__ __attribute__((aligned(16))) uint16_t xs[2][3][32 * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const uint32_t groups = (prm.P + 31) / 32;
+    const uint32_t g = blockIdx.x * WAVES + wave;
+    const bool liveWave = g < uint32_t(V) * groups;
+    const uint32_t v = liveWave ? g / groups : 0u;
+    const uint32_t i = liveWave ? (g - v * groups) * 32 + (lane & 31) : 0u;
+    const bool live = liveWave && i < prm.P;
+    const size_t at = (size_t(v) * prm.P + (live ? i : 0u));
+    const size_t VP = size_t(V) * prm.P;
+    // this lane's first-level weights as B operands, [part][kh], real and imaginary: split into bf16 parts by the plan (plan.cpp)
+    uint4 wr[3][2], wi[3][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const size_t row = size_t(((kh * 2 + h) * 3 + p) * 2);
+            wr[p][kh] = live ? prm.w1b[row * VP + at] : uint4{0u, 0u, 0u, 0u};
+            wi[p][kh] = live ? prm.w1b[(row + 1) * VP + at] : uint4{0u, 0u, 0u, 0u};
+        }
+    float w2r[16], w2i[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int a = (s & 3) + 8 * (s >> 2) + 4 * h;
+        const float2 u = live ? prm.w2[size_t(a) * VP + at] : float2{0.f, 0.f};
+        w2r[s] = u.x; w2i[s] = u.y;
+    }
+    const float4 tp = live ? prm.tilePow[at] : float4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t tiles = prm.hop / 1024u;
+    const uint32_t u0 = blockIdx.y * unitsPerWg, u1 = min(nUnits, u0 + unitsPerWg);
+    const uint32_t nT = (u1 - u0) * tiles;                           // the workgroup's stream of tiles
+    // where a unit's samples are and how its signal mixes them (uniform: scalar registers)
+    auto enter = [&](uint32_t unit, const float *&pl, const float *&pr2, float &cl, float &cr) {
+        const int signal = int(unit % uint32_t(prm.signals));
+        const uint32_t pair = (unit / uint32_t(prm.signals)) % prm.C;
+        const long frame = long(unit / (uint32_t(prm.signals) * prm.C));            // (of this launch: planar / local point at its first frame)
+        pl = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;        // (uniform: a scalar base, the lane's offset is tid)
+        pr2 = pl + prm.chStride;
+        resMixCoeff(prm.mode, signal, cl, cr);
+    };
+    // a sample's three parts by truncation (the high halves of x, x - h, x - h - m: exact as well, and the stores take the high half
+    // of a register as it is); the weights' parts are rounded, so the dropped cross terms carry no sign of their own
+    const uint32_t slot = uint32_t(tid >> 5) * ROW + uint32_t(tid & 31);            // sample tid + TH k of a tile: row (tid >> 5) + 8 k
+    // the request stream runs two tiles ahead of the products, the parking one tile ahead; the registers nl / nr hold the tile
+    // between the two, (clHeld, crHeld) the mix of the unit it belongs to
+    const float *pl, *pr2;
+    float clHeld, crHeld, clNext, crNext;
+    uint32_t uReq = u0, tReq = 0;
+    enter(uReq, pl, pr2, clHeld, crHeld);
+    float nl[PER], nr[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k]; }
+    auto advance = [&]() {                                           // the request stream one tile on (stays on the last tile at the end)
+        clNext = clHeld; crNext = crHeld;
+        if (tReq + 1 < tiles) { ++tReq; pl += 1024; pr2 += 1024; }
+        else if (uReq + 1 < u1) { ++uReq; tReq = 0; enter(uReq, pl, pr2, clNext, crNext); }
+    };
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                                  // tile 0 parked
+        const float x = __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
+        const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+        const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
+        xs[0][0][o] = uint16_t(__float_as_uint(x) >> 16); xs[0][1][o] = uint16_t(__float_as_uint(r1) >> 16); xs[0][2][o] = uint16_t(__float_as_uint(r2) >> 16);
+    }
+    advance();
+    clHeld = clNext; crHeld = crNext;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k]; }     // tile 1 held
+    float sre = 0.f, sim = 0.f, pr = 0.f, pi = 0.f;                  // this half's partial state; the open tile's partial sums
+    f32x16 dre = {0}, dim = {0};                                     // ("tile -1": zero block sums, folded like any other)
+    const bf16x8 *Wr = reinterpret_cast<const bf16x8 *>(&wr[0][0]), *Wi = reinterpret_cast<const bf16x8 *>(&wi[0][0]);
+    // (sample part, weight part): the terms of 2^-16 first, then 2^-8, then the leading one
+    constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};
+    auto finish = [&](uint32_t unit) {                               // a unit's state: the halves together, out, and from rest again
+        const float fre = sre + __shfl_xor(sre, 32), fim = sim + __shfl_xor(sim, 32);
+        if (live && h == 0) prm.local[size_t(unit) * V * prm.P + size_t(v) * prm.P + i] = float2{fre, fim};
+        sre = 0.f; sim = 0.f;
+    };
+    uint32_t uMul = u0, tMul = 0;                                    // the unit and tile the products are at
+    for (uint32_t T = 0; T < nT; ++T) {
+        const int buf = int(T & 1u);
+        const bool unitEnded = tMul == 0 && T > 0;                   // the tile folded in phase A closes the unit before this one
+        advance();                                                   // (scalar: where tile T + 2 is, and how it mixes)
+        __syncthreads();                                             // tile T is parked (its other buffer was read a tile ago: every wave is past it)
+        bf16x8 A[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                A[p][kh] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(&xs[buf][p][(lane & 31) * ROW + 16 * kh + 8 * h]));
+        // ---- phase A: the real block sums of tile T  |  the imaginary block sums of tile T - 1 into the partial sums, the state onwards
+        // (sched_barrier(0): nothing crosses -- the order below IS the instruction stream)
+        f32x16 acc = {0};
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < 8) {
+#pragma unroll
+                for (int r = 2 * m; r < 2 * m + 2; ++r) {
+                    pr = __builtin_fmaf(-dim[r], w2i[r], pr);
+                    pi = __builtin_fmaf(dim[r], w2r[r], pi);
+                }
+            } else if (m == 8) {
+                const float nre = __builtin_fmaf(sre, tp.x, __builtin_fmaf(-sim, tp.y, __builtin_fmaf(sre, tp.z, -sim * tp.w))) + pr;
+                const float nim = __builtin_fmaf(sre, tp.y, __builtin_fmaf(sim, tp.x, __builtin_fmaf(sre, tp.w, sim * tp.z))) + pi;
+                sre = nre; sim = nim;
+            } else if (m == 9) {
+                if (unitEnded) finish(uMul - 1);
+            }
+            asm volatile("" : "+v"(pr), "+v"(pi), "+v"(sre), "+v"(sim));          // (pins this step's vector work between its neighbours' ...
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TP[m >> 1]][m & 1], Wr[TQ[m >> 1] * 2 + (m & 1)], acc, 0, 0, 0);
+            asm volatile("" : "+v"(acc));                                         //  ... and the product behind it: both are pure values otherwise)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dre = acc;
+        // ---- phase B: the imaginary block sums of tile T  |  tile T + 1 parked, tile T + 2 requested, the real block sums folded
+        f32x16 acc2 = {0};
+        pr = 0.f; pi = 0.f;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            if (m < PER) {                                           // one sample of tile T + 1 split and parked, its register refilled
+                const int k = m;
+                const float x = __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
+                const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+                const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
+                xs[buf ^ 1][0][o] = uint16_t(__float_as_uint(x) >> 16); xs[buf ^ 1][1][o] = uint16_t(__float_as_uint(r1) >> 16); xs[buf ^ 1][2][o] = uint16_t(__float_as_uint(r2) >> 16);
+                nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k];
+            } else {
+#pragma unroll
+                for (int r = 2 * (m - 4); r < 2 * (m - 4) + 2; ++r) {
+                    pr = __builtin_fmaf(dre[r], w2r[r], pr);
+                    pi = __builtin_fmaf(dre[r], w2i[r], pi);
+                }
+            }
+            asm volatile("" : "+v"(pr), "+v"(pi));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TP[m >> 1]][m & 1], Wi[TQ[m >> 1] * 2 + (m & 1)], acc2, 0, 0, 0);
+            asm volatile("" : "+v"(acc2));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dim = acc2;
+        clHeld = clNext; crHeld = crNext;
+        if (++tMul == tiles) { tMul = 0; ++uMul; }
+    }
+    // the last tile's imaginary block sums, and the last unit out
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        pr = __builtin_fmaf(-dim[r], w2i[r], pr);
+        pi = __builtin_fmaf(dim[r], w2r[r], pi);
+    }
+    {
+        const float nre = __builtin_fmaf(sre, tp.x, __builtin_fmaf(-sim, tp.y, __builtin_fmaf(sre, tp.z, -sim * tp.w))) + pr;
+        const float nim = __builtin_fmaf(sre, tp.y, __builtin_fmaf(sim, tp.x, __builtin_fmaf(sre, tp.w, sim * tp.z))) + pi;
+        sre = nre; sim = nim;
+    }
+    if (nT) finish(u1 - 1);
+}
+
 // chains the frames: s_f = c^hop s_{f-1} + local_f, in place (local_f becomes the state after frame f), and leaves the last state for the
 // next call.  One thread per (pair, signal, vector, axis point): the only sequential part of a render, `frames` dependent complex
 // multiply-adds per thread; the loads do not depend on the chain and run four frames ahead.
@@ -268,8 +472,12 @@ __global__ __launch_bounds__(kResBlock) void resonatorChainKernel(ResParams prm)
     const float4 c = prm.cpow[size_t(v) * prm.P + i];              // c^hop = hi + lo (plan.cpp): the low word keeps the chain from drifting off the sample-by-sample recurrence
     const size_t stride = size_t(prm.C) * size_t(prm.signals) * V * prm.P;      // one frame of `local`
     float2 *loc = prm.local + ((size_t(pair) * size_t(prm.signals) + sg) * V + v) * prm.P + i;
-    float2 s = loc[0];                                             // frame 0 already continued from the carried state
+    float2 s = loc[0];                                             // frame 0 already continued from the carried state ...
     long f = 1;
+    if (prm.allFromRest) {                                         // ... or it started from rest like the others: the chain starts at the carried state
+        s = prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i];
+        f = 0;
+    }
     for (; f + 4 <= prm.frames; f += 4) {
         float2 l[4];
 #pragma unroll
@@ -341,47 +549,37 @@ template <int V>
 hipError_t launchWindow(const ResParams &prm, hipStream_t stream);
 
 template <int V>
-hipError_t launchV(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin)
+hipError_t launchV(const ResParams &prm0, hipStream_t stream)
 {
+    ResParams prm = prm0;
     const unsigned tiles = (prm.P + kResBlock - 1) / kResBlock;
-    // frames from rest on the matrix cores when the plan has the weights (hop a multiple of 1024); frame 0, which continues the carried
-    // state sample by sample, always on the vector ALUs -- a few workgroups walking `hop` dependent steps: on its own stream beside the
-    // matrix kernel, or it would be a quarter of the render
+    // a launch of several frames at a hop the plan has the weights for (a multiple of 1024): EVERY frame from rest on the matrix cores,
+    // the chain starts at the carried state.  (Until round 4 frame 0 continued the carried state sample by sample on the vector ALUs
+    // beside the matrix kernel: 8 workgroups walking `hop` dependent steps, 0.25-0.4 ms -- longer than the matrix kernel is now.)
+    // A one-frame launch -- the real-time case -- is the reference's recurrence step for step.
     const bool matrix = prm.w1 && prm.frames > 1 && prm.hop % 1024u == 0;
-    const long valuFrames = matrix ? 1 : prm.frames;
-    hipStream_t s0 = stream;
-    if (matrix && aux) {
-        if (hipError_t e = hipEventRecord(evFork, stream); e != hipSuccess) return e;
-        if (hipError_t e = hipStreamWaitEvent(aux, evFork, 0); e != hipSuccess) return e;
-        s0 = aux;
-    }
+    prm.allFromRest = matrix;
     // grid.y is limited to 65535: long renders go in slabs of frames
     const long perSlab = std::max<long>(1, long(65535u / (prm.C * uint32_t(prm.signals))));
-    for (long f0 = 0; f0 < valuFrames; f0 += perSlab) {
+    for (long f0 = 0; f0 < prm.frames; f0 += perSlab) {
         ResParams q = prm;
-        const long nf = std::min(perSlab, valuFrames - f0);
+        const long nf = std::min(perSlab, prm.frames - f0);
         q.frames = nf;
         q.planar = prm.planar + size_t(f0) * prm.hop;
         q.local = prm.local + size_t(f0) * prm.C * size_t(prm.signals) * V * prm.P;
         q.firstContinues = f0 == 0;
-        hipLaunchKernelGGL(resonateKernel<V>, dim3(tiles, unsigned(nf * prm.C * prm.signals)), dim3(kResBlock), 0, s0, q);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    }
-    if (matrix) {
-        const unsigned groups = (prm.P + 31) / 32 * unsigned(V);
-        for (long f0 = 1; f0 < prm.frames; f0 += perSlab) {
-            ResParams q = prm;
-            const long nf = std::min(perSlab, prm.frames - f0);
-            q.planar = prm.planar + size_t(f0 - 1) * prm.hop;           // (the kernel counts its frames from 1)
-            q.local = prm.local + size_t(f0 - 1) * prm.C * size_t(prm.signals) * V * prm.P;
+        if (!matrix) hipLaunchKernelGGL(resonateKernel<V>, dim3(tiles, unsigned(nf * prm.C * prm.signals)), dim3(kResBlock), 0, stream, q);
+        else {
+            const unsigned groups = (prm.P + 31) / 32 * unsigned(V);
             constexpr int WAVES = SGZ_RES_WAVES;
-            hipLaunchKernelGGL(resonateMfmaKernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, unsigned(nf * prm.C * prm.signals)), dim3(64 * WAVES), 0, stream, q, V);
-            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+            const unsigned units = unsigned(nf * prm.C * prm.signals);
+            // the bf16 form walks kResUnitsPerWg units per workgroup, fewer when that would leave compute units without work
+            unsigned upw = kResUnitsPerWg;
+            while (upw > 1 && size_t((groups + WAVES - 1) / WAVES) * ((units + upw - 1) / upw) < 4096) upw /= 2;
+            if (prm.matrixForm == 2) hipLaunchKernelGGL(resonateMfmaKernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, units), dim3(64 * WAVES), 0, stream, q, V);
+            else hipLaunchKernelGGL(resonateMfmaBf16Kernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, (units + upw - 1) / upw), dim3(64 * WAVES), 0, stream, q, V, units, upw);
         }
-        if (s0 != stream) {
-            if (hipError_t e = hipEventRecord(evJoin, s0); e != hipSuccess) return e;
-            if (hipError_t e = hipStreamWaitEvent(stream, evJoin, 0); e != hipSuccess) return e;
-        }
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(resonatorChainKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -477,14 +675,14 @@ hipError_t launchCarryV(const ResParams &prm, const float2 *carry, hipStream_t s
 
 }  // namespace
 
-hipError_t launchResonator(const ResParams &prm, hipStream_t stream, hipStream_t aux, hipEvent_t evFork, hipEvent_t evJoin)
+hipError_t launchResonator(const ResParams &prm, hipStream_t stream)
 {
     switch (prm.V) {
-    case 1: return launchV<1>(prm, stream, aux, evFork, evJoin);
-    case 3: return launchV<3>(prm, stream, aux, evFork, evJoin);
-    case 5: return launchV<5>(prm, stream, aux, evFork, evJoin);
-    case 7: return launchV<7>(prm, stream, aux, evFork, evJoin);
-    case 9: return launchV<9>(prm, stream, aux, evFork, evJoin);
+    case 1: return launchV<1>(prm, stream);
+    case 3: return launchV<3>(prm, stream);
+    case 5: return launchV<5>(prm, stream);
+    case 7: return launchV<7>(prm, stream);
+    case 9: return launchV<9>(prm, stream);
     default: return hipErrorInvalidValue;
     }
 }

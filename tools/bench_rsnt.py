@@ -26,6 +26,8 @@ def main():
         plan = api.Plan(cfg)
         if "--valu" in sys.argv:
             plan.set_option(api.OPT_MATRIX_RESONATOR, 0)
+        if "--fp32-matrix" in sys.argv:
+            plan.set_option(api.OPT_MATRIX_RESONATOR, 2)
         plan.upload()
         F = plan.num_frames(x.shape[1])
         rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)

@@ -38,6 +38,7 @@ def main():
         x = torch.from_numpy(synth.gen(2, sr, S, 2 * pairs)).cuda()
         plan = api.Plan(cfg)
         if os.environ.get('SGZ_WHOLE_FRAME') == '1': plan.set_option(api.OPT_CHANNEL_SPLIT, 0)
+        if os.environ.get('SGZ_FETCH_WINDOW') == '1': plan.set_option(3, 1)
         plan.upload()
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
