@@ -337,20 +337,23 @@ def rsnt_extra(dev, x_host) -> dict:
         ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
     flops = 8.0 * F * cfg["hop"] * 2 * V * plan.P
-    # what resonateMfmaKernel EXECUTES on the matrix cores: per frame from rest, (signal, vector, 32 resonators) wave and 1024-sample tile
-    # 32 v_mfma_f32_32x32x2_f32 (16 for the real, 16 for the imaginary weights) of 32 * 32 * 2 multiply-adds each
-    mfma = (F - 1) * 2 * V * (plan.P // 32) * (cfg["hop"] // 1024) * 32
-    mfma_flops = mfma * 32 * 32 * 2 * 2
-    FP32_MFMA_PEAK = 157.3
+    # what resonateMfmaBf16Kernel EXECUTES on the matrix cores: per frame (all from rest), (signal, vector, 32 resonators) wave and
+    # 1024-sample tile 24 v_mfma_f32_32x32x16_bf16 (six bf16 x bf16 part products x two K halves, for the real and for the imaginary
+    # weights) of 32 * 32 * 16 multiply-adds each
+    mfma = F * 2 * V * (plan.P // 32) * (cfg["hop"] // 1024) * 24
+    mfma_flops = mfma * 32 * 32 * 16 * 2
+    BF16_MFMA_PEAK = 2500.0
     return {"metric": "RSNT (resonator bank) spectrogram frames/sec, stereo 48 kHz, 1024 axis points, Hann (3 vectors), one frame per 8192 samples",
             "value": F / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames": F, "realtime_factor": 60.0 / (ms * 1e-3),
-            "kernel": "resonateMfmaKernel (fp32 MFMA block sums) + resonateKernel<3> (frame 0) + resonatorChainKernel<3> + resonatorWindowKernel<3> + K_B",
-            "mfma_instructions": mfma, "mfma_tflops": mfma_flops / (ms * 1e-3) / 1e12, "mfma_frac_of_peak": mfma_flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK,
+            "kernel": "resonateMfmaBf16Kernel (block sums on the bf16 matrix cores, every fp32 value as three exact bf16 parts) + "
+                      "resonatorSegmentKernel / SegmentFoldKernel / ChainWindowKernel<3> + K_B",
+            "mfma_instructions": mfma, "mfma_tflops": mfma_flops / (ms * 1e-3) / 1e12, "mfma_frac_of_peak": mfma_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK,
             "recurrence_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
-            "note": "compute-bound.  mfma_tflops = multiply-adds the matrix kernel executes (x 2) over the WHOLE render's time (chain, window and K_B "
-                    "kernels included) against the 157.3 TFLOP/s fp32 MFMA peak; profiles/r04*/rsnt_* hold the kernel's own duration and the MFMA "
-                    "counters.  recurrence_equivalent_tflops prices the sample-by-sample recurrence the reference runs (8 flops per sample, "
-                    "resonator, vector and signal) at the same time: a statement about the algorithm, not about the pipe"}
+            "note": "compute-bound.  mfma_tflops = bf16 multiply-adds the matrix kernel executes (x 2) over the WHOLE render's time (chain, window "
+                    "and K_B kernels included) against the 2500 TFLOP/s dense bf16 MFMA peak -- six bf16 products stand for one fp32 product, so "
+                    "the fp32-equivalent rate is a sixth of it; profiles/r04c/rsnt_* hold the kernel's own duration and the MFMA counters.  "
+                    "recurrence_equivalent_tflops prices the sample-by-sample recurrence the reference runs (8 flops per sample, resonator, "
+                    "vector and signal) at the same time: a statement about the algorithm, not about the pipe"}
 
 
 def main() -> None:

@@ -172,11 +172,15 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 #define SGZ_OPT_CHANNEL_SPLIT 1u
 #define SGZ_OPT_FUSED_COLOUR  2u
 #define SGZ_OPT_FETCH_WINDOW  3u
-#define SGZ_OPT_MATRIX_RESONATOR 4u /* 1 (default): RSNT frames from rest run on the fp32 matrix cores when hop is a multiple of 1024
-                                      (resonator.hip resonateMfmaKernel); 0: the vector-ALU block form everywhere */
+#define SGZ_OPT_MATRIX_RESONATOR 4u /* RSNT launches of several frames at a hop that is a multiple of 1024: every frame starts from rest as block
+                                      sums on the matrix cores and the frames are chained afterwards (a one-frame launch -- the real-time case --
+                                      is always the reference's recurrence sample by sample).  1 (default): the bf16 matrix cores, every fp32
+                                      sample and weight as the exact sum of three bf16 parts, six part products (fp32-equivalent accuracy:
+                                      resonator.hip resonateMfmaBf16Kernel); 2: the fp32 matrix cores (resonateMfmaKernel); 0: the vector-ALU
+                                      block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
-                                      slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab's first frame continues the state
-                                      the one before it left, sample by sample */
+                                      slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one
+                                      before it left */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

@@ -213,9 +213,11 @@ static sgz_status fillResParams(Plan &p, const float *d_planar, size_t chStride,
     r.gain = p.d_resGain;
     for (int v = 0; v < 9; ++v) r.weights[v] = p.resWeights[v];
     r.state = reinterpret_cast<float2 *>(p.d_resState);
-    sgz_status st = ensureCap(&p.d_resLocal, &p.resLocalCap, size_t(frames) * p.C * size_t(r.signals) * size_t(r.V) * p.P * 2);
+    const size_t perFrame = size_t(p.C) * size_t(r.signals) * size_t(r.V) * p.P;                 // complex values; the segments' end states follow the frames
+    sgz_status st = ensureCap(&p.d_resLocal, &p.resLocalCap, (size_t(frames) + size_t(kResSegments)) * perFrame * 2);
     if (st != SGZ_OK) return st;
     r.local = reinterpret_cast<float2 *>(p.d_resLocal);
+    r.segEnd = r.local + size_t(frames) * perFrame;
     r.mapped = d_mapped;
     return SGZ_OK;
 }
@@ -227,8 +229,8 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
     if (!d_mapped) return fail(SGZ_EUNSUPPORTED, "the resonator algorithm has no transform bins: ask for mapped values");
     if (hopOverride && frames != 1) return fail(SGZ_EINVAL, "a block advance of the resonators is one frame");
     // long renders go in slabs of frames: the per-frame states between the kernels ([frames][C][signals][V][P] complex) are V times the
-    // mapped buffer -- a ten-minute flat-top render at hop 1024 would ask for gigabytes.  A slab's first frame continues the state the
-    // slab before it left in the plan, sample by sample, exactly as the first frame of a render continues the carried state.
+    // mapped buffer -- a ten-minute flat-top render at hop 1024 would ask for gigabytes.  A slab continues the state the slab before it
+    // left in the plan, exactly as a render continues the carried state.
     if (!skipWindow && !hopOverride) {
         const size_t perFrame = size_t(p.C) * size_t(p.stateChannels) * size_t(p.resV) * p.P * 2 * sizeof(float);
         const long slab = p.optResonatorSlab ? long(p.optResonatorSlab) : long(std::max<size_t>(64, (size_t(256) << 20) / perFrame));

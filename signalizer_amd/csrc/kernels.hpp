@@ -155,6 +155,7 @@ hipError_t launchDecayFold(const float *aggs, const long long *framesPerRank, ui
                            uint32_t P, const DeviceScalars &sc, float *carry, hipStream_t stream);
 
 // RSNT (resonator.hip): the resonator bank over `frames` frames of `hop` samples each, starting at planar; state carried in `state`
+constexpr int kResSegments = 32;      // segments of frames the chain of a matrix-form launch is cut into (at least 8 frames each)
 struct ResParams {
     const float *planar; size_t chStride; long frames;
     uint32_t hop, C, P, mode;
@@ -173,6 +174,8 @@ struct ResParams {
     float2 *state;                    // [C][2][V][P]
     float2 *local;                    // [frames][C][signals][V][P]
     float *mapped;                    // [frames][C][sides][P]
+    float2 *segEnd;                   // [kResSegments][C][signals][V][P]: the segments' end states from rest (resonatorSegmentKernel), or null
+    long segLen;                      // set by the launcher: frames per segment
     bool allFromRest;                 // set by the launcher: every frame of `local` started from rest (matrix kernels), the chain starts at `state`
     bool skipWindow;                  // stop behind the chain (sharded render: the carry of the ranks in front is added first, launchResonatorCarry)
 };

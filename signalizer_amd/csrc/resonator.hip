@@ -8,15 +8,18 @@
 // mathematics it implements (plan.cpp buildResonator; oracle/resonator.c is the checker and states the same choices).
 //
 // MI355X form.  The recurrence  s[n] = c s[n-1] + x[n]  is sequential in time per resonator but linear, so time is cut at the frame
-// boundaries: frame 0 continues the carried state sample by sample on the vector ALUs, contraction-free (sequential semantics: a
-// one-frame launch, the real-time case, is the reference's recurrence step for step); frames f > 0 start from rest and are chained
-// afterwards:  s_f = c^hop s_{f-1} + local_f  (resonatorChainKernel; c^hop in double from the fp32 pole, carried as hi + lo words).
-// The frames from rest are block sums against the pole's powers -- a matrix product: on the fp32 matrix cores when hop is a multiple
-// of 1024 (resonateMfmaKernel: 32 x 32 block sums per 32 MFMAs, then a dot product with the powers of pole^32), else on the vector
-// ALUs eight samples per step (resonateKernel's block form).  resonatorWindowKernel applies the frequency-domain window and writes
-// the planes K_B reads.  Samples are uniform across a workgroup and are staged through LDS.  Against the sequential fp32 recurrence
-// the chained result differs by the roundings of a random walk over the resonator's memory (tests/test_gpu_resonator.py states the
-// bar).  Bytes: 8 hop per (frame, pair) in, 8 V P per (frame, signal) through HBM between the kernels: the path is compute-bound.
+// boundaries.  A ONE-frame launch (the real-time case) continues the carried state sample by sample on the vector ALUs,
+// contraction-free: the reference's recurrence step for step.  In a launch of several frames every frame starts from rest and the
+// frames are chained afterwards:  s_f = c^hop s_{f-1} + local_f  (c^hop in double from the fp32 pole, carried as hi + lo words).
+// The frames from rest are block sums against the pole's powers -- a matrix product.  When hop is a multiple of 1024 they run on the
+// matrix cores: resonateMfmaBf16Kernel (default: every fp32 sample and weight as the exact sum of three bfloat16 parts, six part
+// products on v_mfma_f32_32x32x16_bf16, fp32-equivalent accuracy at 2.7x the fp32 matrix rate) or resonateMfmaKernel (fp32 matrix
+// cores), then a dot product with the powers of pole^32 per 1024-sample tile; the chain is cut into segments of frames that run in
+// parallel (resonatorSegmentKernel / SegmentFoldKernel / ChainWindowKernel, the window and the magnitudes behind every chain step).
+// Any other hop: the vector ALUs eight samples per step (resonateKernel's block form; frame 0 of the launch continues the carried
+// state exactly), resonatorChainKernel, resonatorWindowKernel.  Against the sequential fp32 recurrence the chained result differs by
+// the roundings of a random walk over the resonator's memory (tests/test_gpu_resonator.py states the bar).  Bytes: 8 hop per
+// (frame, pair) in, 8 V P per (frame, signal) through HBM between the kernels: the path is compute-bound.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -296,7 +299,8 @@ __device__ __forceinline__ void resMixCoeff(uint32_t mode, int signal, float &cl
 // carries its own partial state and the halves meet once per unit.  A workgroup walks `unitsPerWg` consecutive units (frame, pair,
 // signal) as ONE stream of tiles -- the weights are fetched once and the pipeline never drains between units (samples of the next
 // unit are requested and parked while the last tiles of this one are multiplied).
-template <int WAVES = 4>
+// SINGLE: every signal is one input channel as it is (every mode but Merge, Side, MidSide): only that channel is requested, nothing is mixed
+template <int WAVES = 4, bool SINGLE = false>
 __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16Kernel(ResParams prm, int V, uint32_t nUnits, uint32_t unitsPerWg)
 {
     constexpr int TH = 64 * WAVES, PER = 1024 / TH;                  // threads, samples a thread stages per tile
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
         pl = prm.planar + size_t(2 * pair) * prm.chStride + size_t(frame) * prm.hop;        // (uniform: a scalar base, the lane's offset is tid)
         pr2 = pl + prm.chStride;
         resMixCoeff(prm.mode, signal, cl, cr);
+        if constexpr (SINGLE) { if (cl == 0.f) pl = pr2; }           // (the one channel this signal is)
     };
     // a sample's three parts by truncation (the high halves of x, x - h, x - h - m: exact as well, and the stores take the high half
     // of a register as it is); the weights' parts are rounded, so the dropped cross terms carry no sign of their own
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
     enter(uReq, pl, pr2, clHeld, crHeld);
     float nl[PER], nr[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k]; }
+    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; if constexpr (!SINGLE) nr[k] = pr2[tid + TH * k]; }
     auto advance = [&]() {                                           // the request stream one tile on (stays on the last tile at the end)
         clNext = clHeld; crNext = crHeld;
         if (tReq + 1 < tiles) { ++tReq; pl += 1024; pr2 += 1024; }
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
     };
 #pragma unroll
     for (int k = 0; k < PER; ++k) {                                  // tile 0 parked
-        const float x = __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
+        const float x = SINGLE ? nl[k] : __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
         const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
         const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
         const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
     advance();
     clHeld = clNext; crHeld = crNext;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k]; }     // tile 1 held
+    for (int k = 0; k < PER; ++k) { nl[k] = pl[tid + TH * k]; if constexpr (!SINGLE) nr[k] = pr2[tid + TH * k]; }     // tile 1 held
     float sre = 0.f, sim = 0.f, pr = 0.f, pi = 0.f;                  // this half's partial state; the open tile's partial sums
     f32x16 dre = {0}, dim = {0};                                     // ("tile -1": zero block sums, folded like any other)
     const bf16x8 *Wr = reinterpret_cast<const bf16x8 *>(&wr[0][0]), *Wi = reinterpret_cast<const bf16x8 *>(&wi[0][0]);
@@ -423,12 +428,12 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
         for (int m = 0; m < 12; ++m) {
             if (m < PER) {                                           // one sample of tile T + 1 split and parked, its register refilled
                 const int k = m;
-                const float x = __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
+                const float x = SINGLE ? nl[k] : __builtin_fmaf(crHeld, nr[k], clHeld * nl[k]);
                 const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
                 const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
                 const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
                 xs[buf ^ 1][0][o] = uint16_t(__float_as_uint(x) >> 16); xs[buf ^ 1][1][o] = uint16_t(__float_as_uint(r1) >> 16); xs[buf ^ 1][2][o] = uint16_t(__float_as_uint(r2) >> 16);
-                nl[k] = pl[tid + TH * k]; nr[k] = pr2[tid + TH * k];
+                nl[k] = pl[tid + TH * k]; if constexpr (!SINGLE) nr[k] = pr2[tid + TH * k];
             } else {
 #pragma unroll
                 for (int r = 2 * (m - 4); r < 2 * (m - 4) + 2; ++r) {
@@ -459,9 +464,15 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
     if (nT) finish(u1 - 1);
 }
 
+__device__ __forceinline__ void cmulD(double &re, double &im, double cr, double ci)
+{
+    const double nr = re * cr - im * ci, ni = re * ci + im * cr;
+    re = nr; im = ni;
+}
+
 // chains the frames: s_f = c^hop s_{f-1} + local_f, in place (local_f becomes the state after frame f), and leaves the last state for the
 // next call.  One thread per (pair, signal, vector, axis point): the only sequential part of a render, `frames` dependent complex
-// multiply-adds per thread; the loads do not depend on the chain and run four frames ahead.
+// multiply-adds per thread; the loads do not depend on the chain and run eight frames ahead.
 template <int V>
 __global__ __launch_bounds__(kResBlock) void resonatorChainKernel(ResParams prm)
 {
@@ -478,39 +489,73 @@ __global__ __launch_bounds__(kResBlock) void resonatorChainKernel(ResParams prm)
         s = prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i];
         f = 0;
     }
-    for (; f + 4 <= prm.frames; f += 4) {
-        float2 l[4];
+    // eight frames are multiplied while the next eight are in flight: a step is four dependent operations, a load a memory round trip
+    constexpr int D = 8;
+    float2 cur[D], nxt[D];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) l[k] = loc[size_t(f + k) * stride];
+    for (int k = 0; k < D; ++k) cur[k] = f + k < prm.frames ? loc[size_t(f + k) * stride] : float2{0.f, 0.f};
+    for (; f < prm.frames; f += D) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + l[k].x;
-            const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + l[k].y;
-            s = float2{nre, nim};
-            loc[size_t(f + k) * stride] = s;
+        for (int k = 0; k < D; ++k) nxt[k] = f + D + k < prm.frames ? loc[size_t(f + D + k) * stride] : float2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (f + k < prm.frames) {
+                const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + cur[k].x;
+                const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + cur[k].y;
+                s = float2{nre, nim};
+                loc[size_t(f + k) * stride] = s;
+            }
         }
-    }
-    for (; f < prm.frames; ++f) {
-        const float2 l = loc[size_t(f) * stride];
-        const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + l.x;
-        const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + l.y;
-        s = float2{nre, nim};
-        loc[size_t(f) * stride] = s;
+#pragma unroll
+        for (int k = 0; k < D; ++k) cur[k] = nxt[k];
     }
     prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i] = s;
 }
 
 // every frame's windowed state as the planes K_B reads: getWholeWindowedState + the RSNT branch of mapToLinearSpace (:1103-1133) + the
 // magnitude mapAndTransformDFTFilters takes first (sqrt(re^2 + im^2), :1329-1331, :1361-1366).  One thread per (frame, pair, axis point).
+// the frequency-domain window over a signal's V resonator states (getWholeWindowedState; oracle/resonator.c
+// sgzo_resonator_windowed_state): centre first, then -m, +m outwards, times the gain; operation by operation, no contraction
+template <int V>
+__device__ __forceinline__ void resWindowed(const ResParams &prm, const float (&sre)[V], const float (&sim)[V], float gain, float &ore, float &oim)
+{
+#pragma clang fp contract(off)
+    constexpr int K = (V + 1) / 2;
+    float re = prm.weights[K - 1] * sre[K - 1], im = prm.weights[K - 1] * sim[K - 1];
+#pragma unroll
+    for (int m = 1; m < K; ++m) {
+        re = re + prm.weights[K - 1 - m] * sre[K - 1 - m];
+        im = im + prm.weights[K - 1 - m] * sim[K - 1 - m];
+        re = re + prm.weights[K - 1 + m] * sre[K - 1 + m];
+        im = im + prm.weights[K - 1 + m] * sim[K - 1 + m];
+    }
+    ore = re * gain; oim = im * gain;
+}
+// the RSNT branch of mapToLinearSpace (:1103-1133) + the magnitude mapAndTransformDFTFilters takes first (sqrt(re^2 + im^2), :1329-1331,
+// :1361-1366): the planes K_B reads
+__device__ __forceinline__ void resEmit(const ResParams &prm, const float (&ore)[2], const float (&oim)[2], float *out)
+{
+#pragma clang fp contract(off)
+    if (prm.mode == SGZ_CH_PHASE) {                                       // :1111-1127
+        const float sr = ore[0] + ore[1], si = oim[0] + oim[1];
+        const float cancellation = sqrtf(sr * sr + si * si);
+        const float mid = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]) + sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
+        out[0] = mid;
+        out[prm.P] = 1.0f - (mid > 0 ? cancellation / mid : 0.0f);
+    } else {
+        out[0] = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]);
+        if (prm.sides == 2) out[prm.P] = sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
+    }
+}
+
+// every frame's windowed state as the planes K_B reads.  One thread per (frame, pair, axis point).
 template <int V>
 __global__ __launch_bounds__(kResBlock) void resonatorWindowKernel(ResParams prm)
 {
-#pragma clang fp contract(off)
     const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
     if (i >= prm.P) return;
     const uint32_t pair = blockIdx.y % prm.C;
     const long f = long(blockIdx.y / prm.C);
-    constexpr int K = (V + 1) / 2;
     const int S = prm.signals;
     const float gain = prm.gain[i];
     float ore[2] = {0.f, 0.f}, oim[2] = {0.f, 0.f};
@@ -521,27 +566,141 @@ __global__ __launch_bounds__(kResBlock) void resonatorWindowKernel(ResParams prm
         float sre[V], sim[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) { const float2 z = loc[size_t(v) * prm.P]; sre[v] = z.x; sim[v] = z.y; }
-        // frequency-domain window: centre first, then -m, +m outwards (oracle/resonator.c sgzo_resonator_windowed_state)
-        float re = prm.weights[K - 1] * sre[K - 1], im = prm.weights[K - 1] * sim[K - 1];
-#pragma unroll
-        for (int m = 1; m < K; ++m) {
-            re = re + prm.weights[K - 1 - m] * sre[K - 1 - m];
-            im = im + prm.weights[K - 1 - m] * sim[K - 1 - m];
-            re = re + prm.weights[K - 1 + m] * sre[K - 1 + m];
-            im = im + prm.weights[K - 1 + m] * sim[K - 1 + m];
-        }
-        ore[s] = re * gain; oim[s] = im * gain;
+        resWindowed<V>(prm, sre, sim, gain, ore[s], oim[s]);
     }
-    float *out = prm.mapped + (size_t(f) * prm.C + pair) * size_t(prm.sides) * prm.P + i;
-    if (prm.mode == SGZ_CH_PHASE) {                                       // :1111-1127
-        const float sr = ore[0] + ore[1], si = oim[0] + oim[1];
-        const float cancellation = sqrtf(sr * sr + si * si);
-        const float mid = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]) + sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
-        out[0] = mid;
-        out[prm.P] = 1.0f - (mid > 0 ? cancellation / mid : 0.0f);
-    } else {
-        out[0] = sqrtf(ore[0] * ore[0] + oim[0] * oim[0]);
-        if (prm.sides == 2) out[prm.P] = sqrtf(ore[1] * ore[1] + oim[1] * oim[1]);
+    resEmit(prm, ore, oim, prm.mapped + (size_t(f) * prm.C + pair) * size_t(prm.sides) * prm.P + i);
+}
+
+// ---- chain and window of a launch whose frames all started from rest (the matrix forms), parallel over SEGMENTS of frames: the
+// sequential chain (one thread per resonator walking every frame, each step behind a memory round trip: 40 us of a 0.38 ms render)
+// becomes  (1) every segment's end state from rest, all segments at once;  (2) the state entering every segment, folded from the
+// carried state and the ends of the segments in front (fp64, pole^(hop len) by squaring the hi + lo pole^hop -- the sharded render's
+// fold, sharded.hip);  (3) per segment the chain over the segment's frames with the window and the magnitudes behind every step: no second pass
+// over the states, which are written back only when a caller needs them (skipWindow: the sharded render adds its carry first).
+template <int V>
+__global__ __launch_bounds__(kResBlock) void resonatorSegmentKernel(ResParams prm)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t unit = blockIdx.y, g = blockIdx.z;               // (pair, signal, vector); segment (the last one's end is nobody's carry)
+    const uint32_t v = unit % uint32_t(V);
+    const float4 c = prm.cpow[size_t(v) * prm.P + i];
+    const size_t stride = size_t(prm.C) * size_t(prm.signals) * V * prm.P;
+    const long f0 = long(g) * prm.segLen, f1 = min(prm.frames, f0 + prm.segLen);
+    const float2 *loc = prm.local + size_t(unit) * prm.P + i;
+    float2 s{0.f, 0.f};
+    constexpr int D = 4;
+    for (long f = f0; f < f1; f += D) {
+        float2 l[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) l[k] = f + k < f1 ? loc[size_t(f + k) * stride] : float2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (f + k < f1) {
+                const float nre = __builtin_fmaf(s.x, c.x, __builtin_fmaf(-s.y, c.y, __builtin_fmaf(s.x, c.z, -s.y * c.w))) + l[k].x;
+                const float nim = __builtin_fmaf(s.x, c.y, __builtin_fmaf(s.y, c.x, __builtin_fmaf(s.x, c.w, s.y * c.z))) + l[k].y;
+                s = float2{nre, nim};
+            }
+    }
+    prm.segEnd[(size_t(g) * gridDim.y + unit) * prm.P + i] = s;
+}
+
+// the state entering every segment but the first, in place of the end state of the segment in front of it:
+//     enter_{q+1} = pole^(hop segLen) enter_q + end_q,      enter_0 = the carried state,
+// fp64, pole^(hop segLen) by squaring the hi + lo pole^hop.  One thread per resonator; the ends are all requested before the walk.
+template <int V>
+__global__ __launch_bounds__(kResBlock) void resonatorSegmentFoldKernel(ResParams prm, uint32_t ends)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t unit = blockIdx.y;                              // (pair, signal, vector)
+    const uint32_t v = unit % uint32_t(V), sg = (unit / uint32_t(V)) % uint32_t(prm.signals), pair = unit / (uint32_t(V) * uint32_t(prm.signals));
+    const float4 c = prm.cpow[size_t(v) * prm.P + i];
+    float2 e[kResSegments - 1];
+#pragma unroll
+    for (int q = 0; q < kResSegments - 1; ++q) e[q] = prm.segEnd[(size_t(min(uint32_t(q), ends - 1u)) * gridDim.y + unit) * prm.P + i];     // (no branch: a clamped index)
+#pragma unroll
+    for (int q = 0; q < kResSegments - 1; ++q) asm volatile("" ::"v"(e[q].x), "v"(e[q].y));      // (all in flight before the walk: it is one round trip, not `ends`)
+    double pr = 1.0, pi = 0.0, br = double(c.x) + double(c.z), bi = double(c.y) + double(c.w);
+    for (long x = prm.segLen; x > 0; x >>= 1) {
+        if (x & 1) cmulD(pr, pi, br, bi);
+        cmulD(br, bi, br, bi);
+    }
+    const float2 s0 = prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i];
+    double sr = double(s0.x), si = double(s0.y);
+#pragma unroll
+    for (int q = 0; q < kResSegments - 1; ++q) {
+        if (uint32_t(q) < ends) {                                  // (no break: e[] is indexed by constants and stays in registers)
+            cmulD(sr, si, pr, pi);
+            sr += double(e[q].x); si += double(e[q].y);
+            prm.segEnd[(size_t(q) * gridDim.y + unit) * prm.P + i] = float2{float(sr), float(si)};
+            sr = double(float(sr)); si = double(float(si));       // (the segment starts from the fp32 state it is handed)
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(kResBlock) void resonatorChainWindowKernel(ResParams prm)
+{
+    const uint32_t i = blockIdx.x * kResBlock + threadIdx.x;
+    if (i >= prm.P) return;
+    const uint32_t pair = blockIdx.y, g = blockIdx.z;
+    const int S = prm.signals;
+    const uint32_t units = prm.C * uint32_t(S) * uint32_t(V);
+    const long f0 = long(g) * prm.segLen, f1 = min(prm.frames, f0 + prm.segLen);
+    const float gain = prm.gain[i];
+    float4 c[V];
+    float sre[2][V], sim[2][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        c[v] = prm.cpow[size_t(v) * prm.P + i];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s >= S) break;
+            const size_t unit = (size_t(pair) * size_t(S) + size_t(s)) * V + v;
+            // the state entering this segment: the carried one, or what resonatorSegmentFoldKernel left in the slot of the segment in front
+            const float2 s0 = g == 0 ? prm.state[(size_t(pair) * 2 + s) * V * prm.P + size_t(v) * prm.P + i] : prm.segEnd[(size_t(g - 1) * units + unit) * prm.P + i];
+            sre[s][v] = s0.x; sim[s][v] = s0.y;
+        }
+    }
+    const size_t stride = size_t(units) * prm.P;
+    float2 *loc = prm.local + size_t(pair) * size_t(S) * V * prm.P + i;
+    constexpr int D = V <= 3 ? 2 : 1;                                // frames requested ahead (2 S V values each; 4 measured no faster)
+    for (long f = f0; f < f1; f += D) {
+        float2 l[D][2][V];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    l[k][s][v] = (s < S && f + k < f1) ? loc[size_t(f + k) * stride + (size_t(s) * V + v) * prm.P] : float2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (f + k >= f1) break;
+            float ore[2] = {0.f, 0.f}, oim[2] = {0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s >= S) break;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float nre = __builtin_fmaf(sre[s][v], c[v].x, __builtin_fmaf(-sim[s][v], c[v].y, __builtin_fmaf(sre[s][v], c[v].z, -sim[s][v] * c[v].w))) + l[k][s][v].x;
+                    const float nim = __builtin_fmaf(sre[s][v], c[v].y, __builtin_fmaf(sim[s][v], c[v].x, __builtin_fmaf(sre[s][v], c[v].w, sim[s][v] * c[v].z))) + l[k][s][v].y;
+                    sre[s][v] = nre; sim[s][v] = nim;
+                    if (prm.skipWindow) loc[size_t(f + k) * stride + (size_t(s) * V + v) * prm.P] = float2{nre, nim};
+                }
+                if (!prm.skipWindow) resWindowed<V>(prm, sre[s], sim[s], gain, ore[s], oim[s]);
+            }
+            if (!prm.skipWindow) resEmit(prm, ore, oim, prm.mapped + (size_t(f + k) * prm.C + pair) * size_t(prm.sides) * prm.P + i);
+        }
+    }
+    if (g + 1 == gridDim.z) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s >= S) break;
+#pragma unroll
+            for (int v = 0; v < V; ++v) prm.state[(size_t(pair) * 2 + s) * V * prm.P + size_t(v) * prm.P + i] = float2{sre[s][v], sim[s][v]};
+        }
     }
 }
 
@@ -577,9 +736,26 @@ hipError_t launchV(const ResParams &prm0, hipStream_t stream)
             unsigned upw = kResUnitsPerWg;
             while (upw > 1 && size_t((groups + WAVES - 1) / WAVES) * ((units + upw - 1) / upw) < 4096) upw /= 2;
             if (prm.matrixForm == 2) hipLaunchKernelGGL(resonateMfmaKernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, units), dim3(64 * WAVES), 0, stream, q, V);
-            else hipLaunchKernelGGL(resonateMfmaBf16Kernel<WAVES>, dim3((groups + WAVES - 1) / WAVES, (units + upw - 1) / upw), dim3(64 * WAVES), 0, stream, q, V, units, upw);
+            else if (prm.mode != SGZ_CH_MERGE && prm.mode != SGZ_CH_SIDE && prm.mode != SGZ_CH_MIDSIDE)
+                hipLaunchKernelGGL((resonateMfmaBf16Kernel<WAVES, true>), dim3((groups + WAVES - 1) / WAVES, (units + upw - 1) / upw), dim3(64 * WAVES), 0, stream, q, V, units, upw);
+            else hipLaunchKernelGGL((resonateMfmaBf16Kernel<WAVES, false>), dim3((groups + WAVES - 1) / WAVES, (units + upw - 1) / upw), dim3(64 * WAVES), 0, stream, q, V, units, upw);
         }
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    if (matrix && prm.segEnd) {
+        // (the carried state is read by every segment's fold and written by the last segment: the kernel's own two phases are ordered
+        //  by the launch order of the two kernels -- the first never touches it)
+        const long segs = std::max<long>(1, std::min<long>(kResSegments, prm.frames / 8));
+        prm.segLen = (prm.frames + segs - 1) / segs;
+        const unsigned G = unsigned((prm.frames + prm.segLen - 1) / prm.segLen);
+        if (G > 1) {
+            hipLaunchKernelGGL(resonatorSegmentKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V), G - 1), dim3(kResBlock), 0, stream, prm);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+            hipLaunchKernelGGL(resonatorSegmentFoldKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm, G - 1);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(resonatorChainWindowKernel<V>, dim3(tiles, prm.C, G), dim3(kResBlock), 0, stream, prm);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(resonatorChainKernel<V>, dim3(tiles, prm.C * unsigned(prm.signals) * unsigned(V)), dim3(kResBlock), 0, stream, prm);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -603,12 +779,6 @@ hipError_t launchWindow(const ResParams &prm, hipStream_t stream)
 }
 
 struct FoldFrames { long long n[64]; };
-
-__device__ __forceinline__ void cmulD(double &re, double &im, double cr, double ci)
-{
-    const double nr = re * cr - im * ci, ni = re * ci + im * cr;
-    re = nr; im = ni;
-}
 
 // the state entering rank `rank`: s <- pole^(frames_q hop) s + end_q over the ranks in front, fp64.  One thread per (pair, signal slot,
 // vector, axis point) = one entry of the plan's state layout [C][2][V][P].

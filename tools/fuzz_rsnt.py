@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """random RSNT (resonator algorithm) configurations against oracle/resonator.c: windowed magnitudes within the chain tolerance (frame 0
-bit-exact), decay / dB / colour byte for byte given the device's own magnitudes.   usage: fuzz_rsnt.py <cases> <seed>"""
+bit-exact wherever it continues the state sample by sample: one-frame launches, hops the matrix kernels do not take), decay / dB / colour byte for byte given the device's own magnitudes.   usage: fuzz_rsnt.py <cases> <seed>"""
 import os
 import sys
 
@@ -40,7 +40,9 @@ for case in range(cases):
         got = plan.stage_mapped(xs).cpu().numpy()
         r = po.resonator_spectrogram(p, x, want_mapped=True, want_scale=True)
         ref = _planes(r["mapped"], mode, d["axis_points"])
-        ok = got.shape == ref.shape and np.array_equal(got[0], ref[0])
+        ok = got.shape == ref.shape
+        if F == 1 or d["hop"] % 1024:                             # (a launch of several frames on the matrix cores starts every frame from rest)
+            ok &= np.array_equal(got[0], ref[0])
         problems, worst_case = check_planes(got, ref, r["scale"], mode, po.resonator_map(p)[1])
         ok &= not problems
         if problems:
