@@ -235,10 +235,7 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
             push(x[:, pos:min(pos + 512, a + per_frame)])
         if scope:
             h.peak_filter(1 / 60, 8)
-            n = 0
-            for ev in (0, 1):
-                xyz, _ = h.vertices(view, ev, 0, out=outs[ev])
-                n += xyz.shape[0]
+            n = sum(xyz.shape[0] for xyz, _ in h.vertices_all(view, (0, 1), (0, 0), outs))      # both channels' strips, one wait
         else:
             h.peak_filter(1 / 60)
             xyz, _ = h.vertices_all(out=outs)                      # every pair's vertex stream, one wait for the GPU

@@ -556,6 +556,12 @@ size_t     sgz_scope_vertex_count(const sgz_scope *s, const sgz_scope_view *view
  * pinned bounce buffer and a host copy (the same holds for sgz_vector_vertices / _all). */
 sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *xyz,
                               uint8_t *rgba, uint32_t *count);
+/* Several evaluators' line strips of one rendered frame (the reference draws them one after the other inside one paint,
+ * OscilloscopeRendering.cpp drawWavePlot per channel): item k is sgz_scope_vertices(s, view, evaluators[k], channels[k], xyz[k],
+ * rgba ? rgba[k] : NULL, &counts[k]), but the kernels are enqueued back to back and the call waits ONCE.  Same results, same buffer
+ * rules; any failing item fails the call (counts[k] holds the required size where a buffer was too small). */
+sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint32_t items, const uint32_t *evaluators, const uint32_t *channels,
+                                  float *const *xyz, uint8_t *const *rgba, uint32_t *counts);
 /* The same stream into DEVICE buffers -- a mapped vertex buffer object, or memory from sgz_export_alloc that the display GPU's GL /
  * Vulkan imported -- without the D2H copy.  In place when the call returns. */
 sgz_status sgz_scope_vertices_device(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,

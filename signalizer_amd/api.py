@@ -124,7 +124,7 @@ EXPORTS = [
     "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
     "sgz_spectrum_flush_columns", "sgz_spectrum_render_lines", "sgz_spectrum_set_option",
     "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
-    "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
+    "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_vertices_all", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
     "sgz_vector_filters_get", "sgz_vector_vertices", "sgz_vector_vertices_all", "sgz_spectrum_backlog", "sgz_spectrum_stream", "sgz_spectrum_flush", "sgz_scope_flush", "sgz_scope_set_transport", "sgz_vector_flush", "sgz_vector_history",
@@ -231,6 +231,7 @@ def lib() -> C.CDLL:
     L.sgz_scope_analyse.argtypes = [vp, u32, u32, C.POINTER(TriggerState)]
     L.sgz_scope_front_colours.argtypes = [vp, u32, u32, vp]
     L.sgz_scope_vertices_device.argtypes = [vp, C.POINTER(ScopeView), u32, u32, vp, vp, C.POINTER(u32)]
+    L.sgz_scope_vertices_all.argtypes = [vp, C.POINTER(ScopeView), u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(vp), C.POINTER(vp), C.POINTER(u32)]
     L.sgz_vector_vertices_device.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
     L.sgz_export_alloc.argtypes = [sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int)]
     L.sgz_export_free.argtypes = [vp]
@@ -586,6 +587,20 @@ class Scope:
         check(lib().sgz_scope_vertices(self.h, C.byref(view), evaluator, channel, _np_ptr(xyz),
                                        _np_ptr(rgba) if want_colours else None, C.byref(cnt)))
         return xyz[:cnt.value], (rgba[:cnt.value] if want_colours else None)
+
+
+    def vertices_all(self, view: ScopeView, evaluators, channels, out):
+        """sgz_scope_vertices_all: out = [(xyz, rgba or None), ...] one per item, buffers the caller keeps; one wait for all of them"""
+        self.flush()
+        k = len(evaluators)
+        n = lib().sgz_scope_vertex_count(self.h, C.byref(view))
+        ev = (C.c_uint32 * k)(*evaluators); ch = (C.c_uint32 * k)(*channels)
+        xs = (C.c_void_p * k)(*[o[0].ctypes.data for o in out])
+        want = all(o[1] is not None for o in out)
+        cs = (C.c_void_p * k)(*[o[1].ctypes.data if o[1] is not None else None for o in out])
+        cnt = (C.c_uint32 * k)(*[o[0].shape[0] for o in out])
+        check(lib().sgz_scope_vertices_all(self.h, C.byref(view), k, ev, ch, xs, cs if want else None, cnt))
+        return [(o[0][:cnt[i]], o[1][:cnt[i]] if o[1] is not None else None) for i, o in enumerate(out)]
 
 
 class Vector:

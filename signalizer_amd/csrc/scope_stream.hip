@@ -1562,6 +1562,39 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     return SGZ_OK;
 }
 
+sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint32_t items, const uint32_t *evaluators, const uint32_t *channels,
+                                  float *const *xyz, uint8_t *const *rgba, uint32_t *counts)
+{
+    if (!s || !view || !evaluators || !channels || !xyz || !counts) return fail(SGZ_EINVAL, "null argument");
+    if (view->width < 2 || !(view->right > view->left)) return fail(SGZ_EINVAL, "bad view");
+    sgz_scope_view v = *view;
+    v.window_size = s->cfg.window_size;
+    const size_t need = scopeVertexCount(v, s->cfg.interpolation, s->cfg.trigger_mode, s->trig.cycle_samples);
+    bool small = false, direct = true;
+    for (uint32_t k = 0; k < items; ++k) {
+        if (!xyz[k]) return fail(SGZ_EINVAL, "null argument");
+        if (need > counts[k]) { counts[k] = uint32_t(need); small = true; }
+        direct = direct && mappedDevicePointer(xyz[k]) && (!rgba || !rgba[k] || mappedDevicePointer(rgba[k]));
+    }
+    if (small) return fail(SGZ_EINVAL, "vertex buffer too small (counts hold the required size)");
+    if (!direct) {                                            // a pageable buffer among them: item by item through the bounce buffer
+        for (uint32_t k = 0; k < items; ++k) {
+            const sgz_status st = sgz_scope_vertices(s, view, evaluators[k], channels[k], xyz[k], rgba ? rgba[k] : nullptr, &counts[k]);
+            if (st != SGZ_OK) return st;
+        }
+        return SGZ_OK;
+    }
+    for (uint32_t k = 0; k < items; ++k) {
+        size_t points = 0;
+        const sgz_status st = scopeVerticesInto(s, view, evaluators[k], channels[k], static_cast<float *>(mappedDevicePointer(xyz[k])),
+                                                rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k])) : nullptr, need, &points);
+        if (st != SGZ_OK) { (void)hipStreamSynchronize(s->stream); return st; }
+        counts[k] = uint32_t(points);
+    }
+    SGZ_HIP(hipStreamSynchronize(s->stream));
+    return SGZ_OK;
+}
+
 sgz_status sgz_scope_vertices_device(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
                                      uint8_t *d_rgba, uint32_t *count)
 {

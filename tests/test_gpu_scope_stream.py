@@ -390,6 +390,20 @@ def test_vertices_into_device_buffers(gpu):
         finally:
             os.close(fd.value)
             L.sgz_export_free(d_ptr)
+    # several evaluators in one call (sgz_scope_vertices_all): the same strips, pinned buffers (one wait) and pageable ones (item by item)
+    items = (0, 1, 2, 3)
+    singles = [dev.vertices(v, e, 0) for e in items]
+    n = singles[0][0].shape[0]
+    for pinned in (True, False):
+        mk = (lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory().numpy()) if pinned else (lambda shape, dt: torch.zeros(shape, dtype=dt).numpy())
+        outs = [(mk((n, 3), torch.float32), mk((n, 4), torch.uint8)) for _ in items]
+        got = dev.vertices_all(v, items, (0,) * len(items), outs)
+        for (gx, gc), (wx, wc) in zip(got, singles):
+            assert np.array_equal(gx.view(np.uint32), wx.view(np.uint32)) and np.array_equal(gc, wc)
+    cnts = (C.c_uint32 * 2)(n, n - 1)
+    xs = (C.c_void_p * 2)(outs[0][0].ctypes.data, outs[1][0].ctypes.data)
+    ev = (C.c_uint32 * 2)(0, 1); ch = (C.c_uint32 * 2)(0, 0)
+    assert L.sgz_scope_vertices_all(dev.h, C.byref(v), 2, ev, ch, xs, None, cnts) == api.SGZ_EINVAL and cnts[1] == n
     dev.close()
 
     vec = api.Vector(sample_rate=96000.0, num_channels=4, window_size=2000, envelope_mode=2, lanes=8, fade_history=1, max_block=512,
