@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgz.so")
 SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_generic.hip", "spectrum_post.hip", "resonator.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "tracker.hip", "api.hip", "realtime.hip"]
-HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", os.path.join("..", "..", "include", "sgz.h")]
+HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
 def _hipcc() -> str:

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "runtime.hpp"
+#include "fade_chain.hpp"
 
 #pragma clang fp contract(off)
 
@@ -348,29 +349,37 @@ peakKernel(const float *ch, size_t stride, size_t stop, float *peaks)
 
 // ------------------------------------------------------------------------------------------- K12
 // The reference's fade ramp is a running fp32 sum per SIMD lane (vSampleFade += fadePerSample * V once per iteration,
-// VectorscopeRendering.cpp:528-543,:592): sequential by construction, but it only depends on (n, lanes).  One small
-// kernel replays it -- one thread per lane, `iters` dependent adds -- into ramp[k][lane] = outFade of iteration k,
-// lane; the per-sample kernel then just looks its value up.
+// VectorscopeRendering.cpp:528-543,:592): sequential as written, but it only depends on (n, lanes).  One small kernel replays it
+// into ramp[k][lane] = outFade of iteration k, lane; the per-sample kernel then just looks its value up.  The replay is not a walk:
+// one thread per lane finds the sum's arithmetic progressions (fade_chain.hpp), all threads evaluate them; only a chain with ties at
+// every step is walked addition by addition.
 __global__ void __launch_bounds__(256) fadeRampKernel(size_t n, uint32_t lanes, long iters, float *ramp /*[iters][lanes]*/)
 {
-    // the chain itself is `iters` dependent adds per lane; it is written through LDS so that the (few) chain threads never wait for
-    // global stores (a lone wave has 64 stores in flight at most: 25 ns per iteration when it stored directly)
-    __shared__ float buf[8192];
+    constexpr uint32_t kLanes = 16;
+    __shared__ FadeSeg segs[kLanes][kFadeSegs];
+    __shared__ int nseg[kLanes], overflow;
     const uint32_t tid = threadIdx.x;
     const float fadePerSample = 1.0f / float(n);
-    float f = fadePerSample * float(tid);
     const float incr = fadePerSample * float(lanes);
-    const long chunk = long(8192 / lanes);
-    for (long k0 = 0; k0 < iters; k0 += chunk) {
-        const long m = iters - k0 < chunk ? iters - k0 : chunk;
-        if (tid < lanes)
-            for (long k = 0; k < m; ++k) {
-                buf[k * lanes + tid] = f - 1.0f;
-                f += incr;
-            }
-        __syncthreads();
-        for (long e = tid; e < m * long(lanes); e += 256) ramp[k0 * lanes + e] = buf[e];
-        __syncthreads();
+    if (tid == 0) overflow = (lanes > kLanes || iters > 0x7fffffffL) ? 1 : 0;
+    __syncthreads();
+    if (tid < lanes && !overflow) {
+        float f = fadePerSample * float(tid), last = 0.f;
+        int cnt = 0;
+        if (!fadeChainSegments(f, incr, uint32_t(iters), segs[tid], cnt, last)) atomicExch(&overflow, 1);
+        nseg[tid] = cnt;
+    }
+    __syncthreads();
+    if (!overflow) {
+        fadeChainFill(&segs[0][0], nseg, lanes, uint32_t(iters), tid, 256u, -1.0f, ramp);
+        return;
+    }
+    if (tid < lanes) {                                        // (the reference's walk: `iters` dependent additions per lane)
+        float f = fadePerSample * float(tid);
+        for (long k = 0; k < iters; ++k) {
+            ramp[k * long(lanes) + tid] = f - 1.0f;
+            f += incr;
+        }
     }
 }
 

@@ -19,6 +19,7 @@
 #include <new>
 
 #include "rt_common.hpp"
+#include "fade_chain.hpp"
 
 #pragma clang fp contract(off)
 
@@ -152,16 +153,12 @@ __global__ void __launch_bounds__(1024) vectorPeakKernel(VecDev *st, const float
 }
 
 // The fade ramp is a running fp32 SIMD sum (vSampleFade += fadePerSample * V once per SIMD iteration, += fadePerSample *
-// remainder after each section, VectorscopeRendering.cpp:528-543, :592, :634): sequential by construction but a function of
-// (size, cursor, lanes) only.  One lane per SIMD lane replays it into ramp[] = vSampleFade of every SIMD-body sample (in vertex
-// order), and tail[s] = outFade[V-1] as the scalar tail of section s sees it.
-__global__ void __launch_bounds__(256) vectorRampKernel(const VecDev *st, uint32_t size, uint32_t lanes, float *ramp, float *tail)
+// remainder after each section, VectorscopeRendering.cpp:528-543, :592, :634): sequential as written but a function of
+// (size, cursor, lanes) only.  ramp[] = vSampleFade of every SIMD-body sample (in vertex order), tail[s] = outFade[V-1] as the
+// scalar tail of section s sees it.  One thread per SIMD lane finds the chain's arithmetic progressions (fade_chain.hpp: one per
+// binade the sum crosses), all threads evaluate; a chain with ties at every step is walked the reference's way (rampSequential).
+__device__ void rampSequential(float *buf, uint32_t lane, uint32_t lanes, uint32_t size, uint32_t cursor, float *ramp, float *tail)
 {
-    // the chain threads (one per SIMD lane) write through LDS, everybody copies out: a lone wave storing to global memory directly has
-    // 64 stores in flight at most (25 ns per iteration measured)
-    __shared__ float buf[8192];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t cursor = st->cursor;
     const long V = long(lanes);
     const float fadePerSample = 1.0f / float(size);
     const float incr = fadePerSample * float(V);
@@ -175,18 +172,10 @@ __global__ void __launch_bounds__(256) vectorRampKernel(const VecDev *st, uint32
         for (long i0 = 0; i0 < body; i0 += chunk) {
             const long m = body - i0 < chunk ? body - i0 : chunk;
             if (lane < lanes) {
-                // (the chain itself -- one dependent fp32 addition per SIMD iteration, 1 200 at cfg4 -- is the reference's; what made this
-                // kernel 37 us was 64-bit index arithmetic and a rolled loop around it: 32-bit indices, unrolled by sixteen)
                 const int steps = int(m / V), stride = int(V);
                 float *dst = buf + lane;
-                int k = 0;
                 float prev = f;
-                for (; k + 16 <= steps; k += 16) {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) { dst[u * stride] = f; prev = f; f += incr; }
-                    dst += 16 * stride;
-                }
-                for (; k < steps; ++k) { *dst = f; prev = f; f += incr; dst += stride; }
+                for (int k = 0; k < steps; ++k) { *dst = f; prev = f; f += incr; dst += stride; }
                 if (steps > 0) lastOut = prev - 1.0f;
             }
             __syncthreads();
@@ -200,19 +189,89 @@ __global__ void __launch_bounds__(256) vectorRampKernel(const VecDev *st, uint32
     }
 }
 
+constexpr uint32_t kRampLanes = 16;                           // SIMD widths the progression form keeps tables for (wider: sequential)
+
+// The first section's chain starts at fadePerSample * lane whatever the cursor is: its progressions are found ONCE per (size, lanes)
+// (one more step than any section has: the value the walk would write next is what the second section starts from); n[lane] = -1:
+// the table overflowed (ties at every step) and the per-frame kernel walks.
+__global__ void __launch_bounds__(64) vectorRampTableKernel(uint32_t size, uint32_t lanes, FadeSeg *table /*[kRampLanes][kFadeSegs]*/, int *count /*[kRampLanes]*/)
+{
+    const uint32_t lane = threadIdx.x;
+    if (lane >= lanes || lane >= kRampLanes) return;
+    const float fadePerSample = 1.0f / float(size);
+    float f = fadePerSample * float(lane), last = 0.f;
+    int n = 0;
+    const bool ok = fadeChainSegments(f, fadePerSample * float(lanes), size / lanes + 1u, table + size_t(lane) * kFadeSegs, n, last);
+    count[lane] = ok ? n : -1;
+}
+
+// Per rendered frame: the second section's chain starts where the first one's ended plus the scalar tail's share -- a function of the
+// cursor.  One thread per lane reads that value off the configured table and finds the second section's progressions (one to three
+// where the ring is half full or more); frame[lane] / frameCount[lane] and tail[] are what the polar kernel evaluates per vertex.
+// frameCount[0] = -1: some chain overflowed its table -- ramp[] was filled the reference's way and the polar kernel reads that.
+__global__ void __launch_bounds__(256) vectorRampKernel(const VecDev *st, uint32_t size, uint32_t lanes, const FadeSeg *table, const int *tableCount,
+                                                        FadeSeg *frame, int *frameCount, float *ramp, float *tail)
+{
+    __shared__ float buf[8192];
+    __shared__ int overflow;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t cursor = st->cursor;
+    const long V = long(lanes);
+    if (lane == 0) overflow = lanes > kRampLanes ? 1 : 0;
+    __syncthreads();
+    long bodyOf[2], nOf[2];
+    for (int section = 0; section < 2; ++section) {
+        nOf[section] = section == 0 ? long(size - cursor) : long(cursor);
+        bodyOf[section] = nOf[section] - V > 0 ? ((nOf[section] - V + V - 1) / V) * V : 0;     // samples the SIMD loop (i < n - V; i += V) covers
+    }
+    if (lane < lanes && lanes <= kRampLanes) {
+        const int n0 = tableCount[lane];
+        if (n0 < 0) atomicExch(&overflow, 1);
+        else {
+            const float fadePerSample = 1.0f / float(size);
+            const float incr = fadePerSample * float(V);
+            const uint32_t steps0 = uint32_t(bodyOf[0] / V), steps1 = uint32_t(bodyOf[1] / V);
+            const FadeSeg *mine = table + size_t(lane) * kFadeSegs;
+            float lastOut = fadePerSample * float(lane), tails[2];
+            if (steps0 > 0) lastOut = fadeChainValueAt(mine, n0, steps0 - 1u) - 1.0f;
+            tails[0] = lastOut;
+            float f = fadeChainValueAt(mine, n0, steps0);                          // what the walk would write next
+            f += fadePerSample * float(nOf[0] - bodyOf[0] > 0 ? nOf[0] - bodyOf[0] : 0);
+            float last = 0.f;
+            int n = 0;
+            const bool ok = fadeChainSegments(f, incr, steps1, frame + size_t(lane) * kFadeSegs, n, last);
+            if (steps1 > 0) lastOut = last - 1.0f;
+            tails[1] = lastOut;
+            if (!ok) atomicExch(&overflow, 1);
+            else {
+                frameCount[lane] = n;
+                if (lane == lanes - 1) { tail[0] = tails[0]; tail[1] = tails[1]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (overflow) {                                            // (uniform)
+        rampSequential(buf, lane, lanes, size, cursor, ramp, tail);
+        if (lane == 0) frameCount[0] = -1;
+    }
+}
+
 struct PolarParams {
     const VecDev *st;
     const float *ring; uint32_t size, lanes, fade;
-    const float *ramp, *tail;
-    float3 *xyz, *rgb;
-    float colour[3];
-    uint32_t pair;
+    const float *ramp, *tail;                                  // ramp: only read when frameCount[0] < 0 (vectorRampKernel's fallback)
+    const FadeSeg *table, *frame; const int *tableCount, *frameCount;
+    float3 *xyz, *rgb; size_t pairStride;                      // pair p's streams at xyz + p * pairStride (vertices)
+    float colour[32][3];
+    uint32_t firstPair;
 };
+// grid (vertices / 256, pairs of this call)
 __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams prm)
 {
     const size_t v = size_t(blockIdx.x) * blockDim.x + threadIdx.x;     // vertex index: section 0 then section 1
     const uint32_t size = prm.size;
     if (v >= size) return;
+    const uint32_t pair = prm.firstPair + blockIdx.y;
     const uint32_t cursor = prm.st->cursor;
     const long V = long(prm.lanes);
     const long n0 = long(size - cursor);
@@ -220,8 +279,8 @@ __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams p
     const long n = section == 0 ? n0 : long(cursor);
     const long i = section == 0 ? long(v) : long(v) - n0;               // index inside the section
     const uint32_t mem = section == 0 ? cursor + uint32_t(i) : uint32_t(i);
-    const float l = prm.ring[size_t(2 * prm.pair) * size + mem];
-    const float r = prm.ring[size_t(2 * prm.pair + 1) * size + mem];
+    const float l = prm.ring[size_t(2 * pair) * size + mem];
+    const float r = prm.ring[size_t(2 * pair + 1) * size + mem];
     const float cosineRotation = -0.70710678118654752440f, sineRotation = 0.70710678118654752440f;   // :521-524
     const float length = fmaxf(fabsf(l), fabsf(r));                                                 // :563
     const float vY = l * cosineRotation - r * sineRotation;                                          // :566
@@ -236,16 +295,22 @@ __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams p
     const float fadePerSample = 1.0f / float(size);
     float z, cf;
     if (i < mainEnd) {
-        const float sf = prm.ramp[v];
+        float sf;
+        if (prm.frameCount[0] >= 0) {                          // vSampleFade of SIMD iteration i / V, lane i % V: off the chain's progressions
+            const uint32_t shift = uint32_t(__ffs(int(prm.lanes)) - 1), ln = uint32_t(i) & (prm.lanes - 1u), k = uint32_t(i) >> shift;   // (lanes: a power of two)
+            sf = section == 0 ? fadeChainValueAt(prm.table + size_t(ln) * kFadeSegs, prm.tableCount[ln], k)
+                              : fadeChainValueAt(prm.frame + size_t(ln) * kFadeSegs, prm.frameCount[ln], k);
+        } else sf = prm.ramp[v];
         z = sf - 1.0f;                                       // outFade = vSampleFade - 1 (:592)
         cf = sf;                                             // colour * vSampleFade (:697-699)
     } else {
         z = prm.tail[section] - float(i - mainEnd) * fadePerSample;      // :600, :634
         cf = z + 1.0f;                                       // colour * (currentFade + 1) (:738)
     }
-    prm.xyz[v] = make_float3(sx * length, cy * length, z);
-    if (prm.rgb) prm.rgb[v] = prm.fade ? make_float3(prm.colour[0] * cf, prm.colour[1] * cf, prm.colour[2] * cf)
-                                       : make_float3(prm.colour[0], prm.colour[1], prm.colour[2]);
+    const size_t at = size_t(blockIdx.y) * prm.pairStride + v;
+    prm.xyz[at] = make_float3(sx * length, cy * length, z);
+    const float *col = prm.colour[blockIdx.y];
+    if (prm.rgb) prm.rgb[at] = prm.fade ? make_float3(col[0] * cf, col[1] * cf, col[2] * cf) : make_float3(col[0], col[1], col[2]);
 }
 
 }  // namespace
@@ -262,6 +327,8 @@ struct sgz_vector {
     uint32_t size = 0;
     float envelopeCoeff = 0.f, stereoCoeff = 0.f, pole1 = 0.f;
     float *d_ramp = nullptr, *d_tail = nullptr, *d_xyz = nullptr, *d_rgb = nullptr;
+    FadeSeg *d_rampTable = nullptr; int *d_rampCount = nullptr;     // the first section's progressions, per (size, lanes); the second's, per frame, behind them
+    uint32_t rampTableSize = 0, rampTableLanes = 0;
     void *h_out = nullptr;
     uint64_t busy = 0;
     // the fade ramp is a function of (size, cursor, lanes): one replay serves every pair of a rendered frame -- it is redone when a block
@@ -276,7 +343,7 @@ static void vectorFree(sgz_vector *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     s->batch.release();
     s->backlog.release();
-    for (void *p : {(void *)s->d_state, (void *)s->d_ring, (void *)s->d_ramp, (void *)s->d_tail, (void *)s->d_xyz, (void *)s->d_rgb})
+    for (void *p : {(void *)s->d_state, (void *)s->d_ring, (void *)s->d_ramp, (void *)s->d_tail, (void *)s->d_rampTable, (void *)s->d_rampCount, (void *)s->d_xyz, (void *)s->d_rgb})
         if (p) (void)hipFree(p);
     if (s->h_out) (void)hipHostFree(s->h_out);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -490,23 +557,37 @@ sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out, uint3
     return SGZ_OK;
 }
 
-// the kernels of one pair's vertex stream into DEVICE buffers (the handle's own, or the caller's mapped VBO)
-static sgz_status vectorVerticesInto(sgz_vector *s, uint32_t pair, float *d_xyz, float *d_rgb)
+// the kernels of `pairs` consecutive pairs' vertex streams into DEVICE buffers (the handle's own, or the caller's mapped VBO): pair
+// firstPair + p at d_xyz + p * 3 size floats
+static sgz_status vectorVerticesInto(sgz_vector *s, uint32_t firstPair, uint32_t pairs, float *d_xyz, float *d_rgb)
 {
     if (sgz_status sy = vectorSync(s); sy != SGZ_OK) return sy;           // (flush on read: the blocks that wait in the open batch come first)
     const uint32_t size = s->size;
     const uint64_t now = s->pushes.load(std::memory_order_acquire);
-    if (s->rampAt != now) {                                    // (1 200 dependent additions at cfg4: 36 us, once per rendered frame instead of once per pair)
-        hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_ramp, s->d_tail);
+    if (!s->d_rampTable) {
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rampTable), size_t(2) * kRampLanes * kFadeSegs * sizeof(FadeSeg)));
+        SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_rampCount), 2 * kRampLanes * sizeof(int)));
+    }
+    FadeSeg *frame = s->d_rampTable + size_t(kRampLanes) * kFadeSegs;
+    int *frameCount = s->d_rampCount + kRampLanes;
+    if (s->rampAt != now) {                                    // (a function of (size, cursor, lanes): once per rendered frame, not once per pair)
+        if (s->rampTableSize != size || s->rampTableLanes != s->cfg.lanes) {
+            hipLaunchKernelGGL(vectorRampTableKernel, dim3(1), dim3(64), 0, s->stream, size, s->cfg.lanes, s->d_rampTable, s->d_rampCount);
+            s->rampTableSize = size; s->rampTableLanes = s->cfg.lanes;
+        }
+        hipLaunchKernelGGL(vectorRampKernel, dim3(1), dim3(256), 0, s->stream, s->d_state, size, s->cfg.lanes, s->d_rampTable, s->d_rampCount, frame, frameCount,
+                           s->d_ramp, s->d_tail);
         s->rampAt = now;
     }
     PolarParams prm{};
     prm.st = s->d_state; prm.ring = s->d_ring; prm.size = size; prm.lanes = s->cfg.lanes; prm.fade = s->cfg.fade_history ? 1u : 0u;
     prm.ramp = s->d_ramp; prm.tail = s->d_tail;
-    prm.xyz = reinterpret_cast<float3 *>(d_xyz); prm.rgb = reinterpret_cast<float3 *>(d_rgb);
-    for (int k = 0; k < 3; ++k) prm.colour[k] = s->cfg.colours[pair][k];
-    prm.pair = pair;
-    hipLaunchKernelGGL(vectorPolarViewKernel, dim3((size + 255) / 256), dim3(256), 0, s->stream, prm);
+    prm.table = s->d_rampTable; prm.tableCount = s->d_rampCount; prm.frame = frame; prm.frameCount = frameCount;
+    prm.xyz = reinterpret_cast<float3 *>(d_xyz); prm.rgb = reinterpret_cast<float3 *>(d_rgb); prm.pairStride = size;
+    for (uint32_t p = 0; p < pairs; ++p)
+        for (int k = 0; k < 3; ++k) prm.colour[p][k] = s->cfg.colours[firstPair + p][k];
+    prm.firstPair = firstPair;
+    hipLaunchKernelGGL(vectorPolarViewKernel, dim3((size + 255) / 256, pairs), dim3(256), 0, s->stream, prm);
     SGZ_HIP(hipGetLastError());
     return SGZ_OK;
 }
@@ -517,7 +598,7 @@ sgz_status sgz_vector_vertices(sgz_vector *s, uint32_t pair, float *xyz, float *
     if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
     const uint32_t size = s->size;
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
-    const sgz_status st = vectorVerticesInto(s, pair, s->d_xyz, rgb ? s->d_rgb : nullptr);
+    const sgz_status st = vectorVerticesInto(s, pair, 1, s->d_xyz, rgb ? s->d_rgb : nullptr);
     if (st != SGZ_OK) return st;
     const size_t bytes = size_t(size) * 3 * sizeof(float);
     if (sgz_status rb = readBack(xyz, s->d_xyz, bytes, rgb, s->d_rgb, bytes, s->h_out, s->stream); rb != SGZ_OK) return rb;
@@ -534,18 +615,13 @@ sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32
     // pinned, device-mapped destinations: the polar kernels write them themselves (no staging, no DMA copy behind the kernels)
     float *mx = static_cast<float *>(mappedDevicePointer(xyz)), *mc = rgb ? static_cast<float *>(mappedDevicePointer(rgb)) : nullptr;
     if (mx && (!rgb || mc)) {
-        for (uint32_t p = 0; p < pairs; ++p) {
-            const sgz_status st = vectorVerticesInto(s, p, mx + p * per, rgb ? mc + p * per : nullptr);
-            if (st != SGZ_OK) return st;
-        }
+        const sgz_status st = vectorVerticesInto(s, 0, pairs, mx, rgb ? mc : nullptr);       // every pair in one launch
+        if (st != SGZ_OK) return st;
         SGZ_HIP(hipStreamSynchronize(s->stream));
         *count = size;
         return SGZ_OK;
     }
-    for (uint32_t p = 0; p < pairs; ++p) {
-        const sgz_status st = vectorVerticesInto(s, p, s->d_xyz + p * per, rgb ? s->d_rgb + p * per : nullptr);
-        if (st != SGZ_OK) return st;
-    }
+    if (const sgz_status st = vectorVerticesInto(s, 0, pairs, s->d_xyz, rgb ? s->d_rgb : nullptr); st != SGZ_OK) return st;
     const size_t bytes = pairs * per * sizeof(float);
     if (sgz_status rb = readBack(xyz, s->d_xyz, bytes, rgb, s->d_rgb, bytes, s->h_out, s->stream); rb != SGZ_OK) return rb;
     *count = size;
@@ -557,7 +633,7 @@ sgz_status sgz_vector_vertices_device(sgz_vector *s, uint32_t pair, float *d_xyz
     if (!s || !d_xyz || !count) return fail(SGZ_EINVAL, "null argument");
     if (pair >= s->cfg.num_channels / 2) return fail(SGZ_EINVAL, "pair out of range");
     if (*count < s->size) { *count = s->size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size)"); }
-    const sgz_status st = vectorVerticesInto(s, pair, d_xyz, d_rgb);
+    const sgz_status st = vectorVerticesInto(s, pair, 1, d_xyz, d_rgb);
     if (st != SGZ_OK) return st;
     SGZ_HIP(hipStreamSynchronize(s->stream));                 // the vertices are in place when the call returns
     *count = s->size;
