@@ -255,7 +255,39 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt_python = time.perf_counter() - t0
+    # the same loop with the host side in C++ (tools/rt_driver.cpp -> signalizer_amd/librtdriver.so: what a plugin's audio callback and
+    # paint would execute; the Python loop above pays 60-100 us of interpreter and ctypes time per frame on top of the library's own)
+    dt = dt_python
+    host = "python"
+    from signalizer_amd import build as sgz_build
+    if os.path.exists(sgz_build.DRIVER) and not os.environ.get("SGZ_LIB"):
+        D = C.CDLL(sgz_build.DRIVER)
+        busy, verts = C.c_uint64(0), C.c_uint32(0)
+        xc = np.ascontiguousarray(x)
+        if scope:
+            D.sgz_bench_scope_loop.restype = C.c_double
+            ev = (C.c_uint32 * 2)(0, 1); ch = (C.c_uint32 * 2)(0, 0)
+            xs = (C.c_void_p * 2)(outs[0][0].ctypes.data, outs[1][0].ctypes.data)
+            cs = (C.c_void_p * 2)(outs[0][1].ctypes.data, outs[1][1].ctypes.data)
+            run = lambda warm, n: D.sgz_bench_scope_loop(h.h, C.c_void_p(xc.ctypes.data), C.c_size_t(xc.shape[1]), C.c_uint32(nch), C.c_uint32(per_frame),
+                                                         C.c_uint32(512), C.c_uint32(64), C.byref(view), C.c_uint32(2), ev, ch, xs, cs, C.c_uint32(nv),
+                                                         C.c_double(1 / 60), C.c_uint32(8), C.c_int(warm), C.c_int(n), C.byref(busy), C.byref(verts))
+        else:
+            D.sgz_bench_vector_loop.restype = C.c_double
+            run = lambda warm, n: D.sgz_bench_vector_loop(h.h, C.c_void_p(xc.ctypes.data), C.c_size_t(xc.shape[1]), C.c_uint32(nch), C.c_uint32(per_frame),
+                                                          C.c_uint32(512), C.c_uint32(64), C.c_void_p(outs[0].ctypes.data), C.c_void_p(outs[1].ctypes.data),
+                                                          C.c_uint32(W), C.c_double(1 / 60), C.c_int(warm), C.c_int(n), C.byref(busy), C.byref(verts))
+        if world > 1:
+            dist.barrier()
+        d = run(70, nsteps)
+        if world > 1:
+            dist.barrier()
+        if d < 0:
+            raise RuntimeError(f"rt_driver: C-ABI call failed ({d})")
+        dt, host = float(d), "c++ (tools/rt_driver.cpp)"
+        refused += busy.value
+        assert verts.value == units, (verts.value, units)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -301,7 +333,8 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                                "(one staged copy + one kernel each), then peak filter and the vertices of every channel / pair into host buffers "
                                "(vectorscope: sgz_vector_vertices_all, one wait for the four pairs)",
                        "parallelism": "replicas only" if world > 1 else "single device", "vertices_per_step": units,
-                       "realtime_factor": (1 / 60) / (dt / nsteps), "pushes_refused_busy": refused},
+                       "realtime_factor": (1 / 60) / (dt / nsteps), "pushes_refused_busy": refused, "host_loop": host,
+                       "ms_per_step_python_host": dt_python / nsteps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
                          "note": "a few MB per launch: the kernel is bound by its launch latency and (scope) its fp64 weight arithmetic, not by HBM"},

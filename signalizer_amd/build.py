@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgz.so")
 SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_generic.hip", "spectrum_post.hip", "resonator.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "tracker.hip", "api.hip", "realtime.hip"]
+DRIVER = os.path.join(HERE, "librtdriver.so")
+DRIVER_SRC = os.path.join(os.path.dirname(HERE), "tools", "rt_driver.cpp")
 HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
@@ -23,7 +25,7 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__), DRIVER_SRC]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -54,7 +56,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {s}")
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
+    build_driver()
     return LIB
+
+
+
+def build_driver() -> str:
+    """tools/rt_driver.cpp: bench.py's frame loop for the real-time handles in C++ (plain host code against include/sgz.h; not part of
+    the product)"""
+    if os.path.exists(DRIVER_SRC):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", DRIVER, DRIVER_SRC, "-L" + HERE, "-l:libsgz.so",
+                               "-Wl,-rpath,$ORIGIN"])
+    return DRIVER
 
 
 if __name__ == "__main__":
