@@ -402,12 +402,14 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     if (tid == 0) {
         unsigned int numSwaps = 0, lastStart = 0, lastLen = n;
         sCursor0 = st->frontCursor;
-        sWritten0 = st->written;
+        const unsigned long long written0 = st->written;
+        sWritten0 = written0;
         if (hold) {
             unsigned long long bufferedSamples = st->bufferedSamples, frontOrigin = st->frontOrigin, steadyClock = st->steadyClock;
             unsigned long long oldPeak = st->oldPeak, currentPeak = st->currentPeak;
             unsigned int qHead = st->qHead, qCount = st->qCount;
             int isWorkingOnPeak = st->isWorkingOnPeak;
+            unsigned int swapsDone = 0;
             unsigned long long numSamples = n, consumed = 0;
             if (frontOrigin + bufferedSamples < steadyClock) { frontOrigin = steadyClock; bufferedSamples = 0; }   // :81-85
             const double ceilingSize = ceil(st->windowSize);
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     // swapBuffers(cappedSize, -bufferedSamples): source = the oldest buffered sample onwards
                     if (numSwaps < kMaxSwaps) {
                         Swap &sw = numSwaps < kStage ? sSwaps[numSwaps] : prm.swapList[numSwaps];
-                        sw.src = (sWritten0 + consumed) - bufferedSamples;
+                        sw.src = (written0 + consumed) - bufferedSamples;
                         sw.len = (unsigned int)cappedSize;
                         ++numSwaps;
                     }
@@ -471,9 +473,10 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     oldPeak = currentPeak;
                     isWorkingOnPeak = 0;
                     if (qCount) { qHead = (qHead + 1) % kPeakCap; qCount--; }
-                    st->swaps++;
+                    ++swapsDone;
                 }
             }
+            st->swaps += swapsDone;                                // (once: a read-modify-write of global memory inside the walk is a round trip per trigger)
             st->bufferedSamples = bufferedSamples; st->frontOrigin = frontOrigin; st->steadyClock = steadyClock;
             st->oldPeak = oldPeak; st->currentPeak = currentPeak; st->qHead = qHead; st->qCount = qCount;
             st->isWorkingOnPeak = isWorkingOnPeak;
