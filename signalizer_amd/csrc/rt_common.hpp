@@ -132,6 +132,7 @@ struct BatchRing {
     static constexpr int kSlots = 8;
     static constexpr uint32_t kMaxBlocks = 16;
     float *h = nullptr;            // pinned  [kSlots][channels * slotSamples]
+    float *hd = nullptr;           // the same memory as the device sees it (null: not mapped -- the batch is copied by the DMA engine)
     float *d = nullptr;            // device  [kSlots][channels * slotSamples]
     hipEvent_t ev[kSlots] = {};
     bool used[kSlots] = {};
@@ -153,6 +154,7 @@ struct BatchRing {
         const size_t bytes = size_t(kSlots) * nch * samplesPerSlot * sizeof(float);
         SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+        hd = static_cast<float *>(mappedDevicePointer(h));
         for (int i = 0; i < kSlots; ++i) {
             SGZ_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
             used[i] = false;
@@ -196,14 +198,19 @@ struct BatchRing {
         off[count] = channels * samples; len[count] = n;
         samples += n; ++count;
     }
-    // the open batch -> device (one copy); returns the device address of its first block
-    const float *upload(hipStream_t stream, sgz_status *st)
+    // the open batch -> device; returns the device address of its first block.  When the pinned slot is mapped into the device's address
+    // space the ingest kernel fetches the batch itself (batchFetch below: *fetchFrom = the slot as the device sees it, `floats` values):
+    // a copy command in front of every ingest launch cost 5 us of engine time and 10-25 us of gaps around it.  Otherwise one DMA copy.
+    const float *upload(hipStream_t stream, sgz_status *st, const float **fetchFrom, uint32_t *floats)
     {
         const int slot = int(seq % kSlots);
         const size_t at = size_t(slot) * channels * slotSamples;
+        *st = SGZ_OK;
+        *floats = channels * samples;
+        if (hd) { *fetchFrom = hd + at; return d + at; }
+        *fetchFrom = nullptr;
         const hipError_t e = hipMemcpyAsync(d + at, h + at, size_t(channels) * samples * sizeof(float), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { *st = hipFail(e, "hipMemcpyAsync"); return nullptr; }
-        *st = SGZ_OK;
         return d + at;
     }
     // after the kernel that reads the batch has been enqueued
@@ -216,6 +223,21 @@ struct BatchRing {
         return SGZ_OK;
     }
 };
+
+// first thing in an ingest kernel (ONE workgroup): the staged batch from the mapped pinned slot into its HBM twin, every thread 16 bytes
+// at a time (one PCIe round trip for the lot); the phases behind it read the HBM copy as before.  (Slot bases are multiples of four
+// floats: channels x slotSamples, slotSamples >= 8192.)
+#ifdef __HIPCC__
+__device__ __forceinline__ void batchFetch(const float *from, float *to, uint32_t floats, int tid, int threads)
+{
+    if (!from) return;                                       // (uniform: the host copied)
+    const uint32_t quads = floats / 4u;
+    for (uint32_t q = uint32_t(tid); q < quads; q += uint32_t(threads)) reinterpret_cast<float4 *>(to)[q] = reinterpret_cast<const float4 *>(from)[q];
+    for (uint32_t e = quads * 4u + uint32_t(tid); e < floats; e += uint32_t(threads)) to[e] = from[e];
+    __threadfence_block();
+    __syncthreads();
+}
+#endif
 
 // Blocks the GPU was not ready for, in arrival order.  Touched by the producer thread only (under the handle's push lock); storage is
 // allocated when the handle is configured, never on the audio thread.  Capacity: `seconds` of audio at the handle's rate (and at

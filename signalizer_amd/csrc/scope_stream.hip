@@ -110,6 +110,7 @@ struct IngestParams {
     unsigned long long *peaks;                // [kPeakCap]
     Swap *swapList;                           // [kMaxSwaps]
     const float *batch;                       // the staged blocks, back to back: block b = [channels][blockLen[b]] at batch + blockOff[b]
+    const float *batchHost; uint32_t batchFloats;   // the pinned slot they are fetched from first (rt_common.hpp batchFetch), or null
     uint32_t numBlocks, channels;
     uint32_t blockOff[BatchRing::kMaxBlocks], blockLen[BatchRing::kMaxBlocks];
     float *front; uint32_t size;              // [channels][size]
@@ -269,6 +270,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     for (uint32_t b = 0; b < BatchRing::kMaxBlocks; ++b)
         if (tid == int(b)) { sBlockOff[b] = prm.blockOff[b]; sBlockLen[b] = prm.blockLen[b]; }
     __syncthreads();
+    batchFetch(prm.batchHost, const_cast<float *>(prm.batch), prm.batchFloats, tid, T);
     for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
     const float *const blk = prm.batch + sBlockOff[blockIndex];
     const uint32_t n = sBlockLen[blockIndex];
@@ -1281,9 +1283,11 @@ sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg)
 static sgz_status scopeSubmit(sgz_scope *s)
 {
     sgz_status st;
-    const float *d_batch = s->batch.upload(s->stream, &st);
+    const float *fetchFrom; uint32_t floats;
+    const float *d_batch = s->batch.upload(s->stream, &st, &fetchFrom, &floats);
     if (!d_batch) return st;
     IngestParams prm{};
+    prm.batchHost = fetchFrom; prm.batchFloats = floats;
     prm.st = s->d_state; prm.peaks = s->d_peaks; prm.swapList = s->d_swaps;
     prm.batch = d_batch; prm.numBlocks = s->batch.count; prm.channels = s->cfg.num_channels;
     for (uint32_t b = 0; b < s->batch.count; ++b) { prm.blockOff[b] = s->batch.off[b]; prm.blockLen[b] = s->batch.len[b]; }

@@ -36,6 +36,7 @@ struct VecDev {
 
 struct VecIngest {
     VecDev *st;
+    const float *batchHost; uint32_t batchFloats;             // the pinned slot the blocks are fetched from first (rt_common.hpp batchFetch), or null
     const float *batch; uint32_t numBlocks, channels;         // the staged blocks back to back: block b = [channels][blockLen[b]] at batch + blockOff[b]
     uint32_t blockOff[BatchRing::kMaxBlocks], blockLen[BatchRing::kMaxBlocks];
     float *ring; uint32_t size;
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) vectorIngestKernel(const VecIngest prm)
     for (uint32_t b = 0; b < BatchRing::kMaxBlocks; ++b)
         if (tid == int(b)) { sBlockOff[b] = prm.blockOff[b]; sBlockLen[b] = prm.blockLen[b]; }
     __syncthreads();
+    batchFetch(prm.batchHost, const_cast<float *>(prm.batch), prm.batchFloats, tid, 256);
     for (uint32_t blockIndex = 0; blockIndex < prm.numBlocks; ++blockIndex) {
     const float *const blk = prm.batch + sBlockOff[blockIndex];
     const uint32_t n = sBlockLen[blockIndex];
@@ -435,9 +437,11 @@ sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg)
 static sgz_status vectorSubmit(sgz_vector *s)
 {
     sgz_status st;
-    const float *d_batch = s->batch.upload(s->stream, &st);
+    const float *fetchFrom; uint32_t floats;
+    const float *d_batch = s->batch.upload(s->stream, &st, &fetchFrom, &floats);
     if (!d_batch) return st;
     VecIngest prm{};
+    prm.batchHost = fetchFrom; prm.batchFloats = floats;
     prm.st = s->d_state; prm.batch = d_batch; prm.numBlocks = s->batch.count; prm.channels = s->cfg.num_channels;
     for (uint32_t b = 0; b < s->batch.count; ++b) { prm.blockOff[b] = s->batch.off[b]; prm.blockLen[b] = s->batch.len[b]; }
     prm.ring = s->d_ring; prm.size = s->size; prm.lanes = s->cfg.lanes; prm.envMode = s->cfg.envelope_mode;
