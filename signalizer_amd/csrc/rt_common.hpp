@@ -59,6 +59,7 @@ inline sgz_status readBack(void *dstA, const void *d_a, size_t bytesA, void *dst
 struct StageRing {
     static constexpr int kSlots = 8;
     float *h = nullptr;            // pinned  [kSlots][channels][maxBlock]
+    float *hd = nullptr;           // the same memory as the device sees it (null: not mapped)
     float *d = nullptr;            // device  [kSlots][channels][maxBlock]
     hipEvent_t ev[kSlots] = {};
     bool used[kSlots] = {};
@@ -72,6 +73,7 @@ struct StageRing {
         const size_t bytes = size_t(kSlots) * nch * block * sizeof(float);
         SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));
         SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+        hd = static_cast<float *>(mappedDevicePointer(h));
         for (int i = 0; i < kSlots; ++i) {
             SGZ_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
             used[i] = false;
@@ -86,8 +88,9 @@ struct StageRing {
         h = d = nullptr;
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
-    // Copies the block into the next pinned slot and enqueues its upload; returns the device copy ([channels][n], row stride n)
-    // or nullptr with *st = SGZ_BUSY when the GPU is kSlots blocks behind (nothing waited for, nothing enqueued).
+    // Copies the block into the next pinned slot; returns what the ingest kernel reads ([channels][n], row stride n): the slot itself
+    // as the device sees it (every sample is read once: no copy command in front of the launch), or its uploaded twin when the slot
+    // is not mapped -- or nullptr with *st = SGZ_BUSY when the GPU is kSlots blocks behind (nothing waited for, nothing enqueued).
     const float *stage(const float *const *planar, uint32_t n, hipStream_t stream, sgz_status *st)
     {
         const int slot = int(seq % kSlots);
@@ -99,6 +102,8 @@ struct StageRing {
         float *hs = h + size_t(slot) * channels * maxBlock;
         float *ds = d + size_t(slot) * channels * maxBlock;
         for (uint32_t c = 0; c < channels; ++c) std::memcpy(hs + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
+        *st = SGZ_OK;
+        if (hd) return hd + size_t(slot) * channels * maxBlock;
         const hipError_t e = hipMemcpyAsync(ds, hs, size_t(channels) * n * sizeof(float), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { *st = hipFail(e, "hipMemcpyAsync"); return nullptr; }
         *st = SGZ_OK;
