@@ -571,6 +571,17 @@ def main() -> None:
             plan.render(view, rgba=rgba, lines=lines, state=state)
         torch.cuda.synchronize()
         extra["ms_per_step_with_state"] = (time.perf_counter() - ts) / 50 * 1e3
+        # (ii-b) ... and the step that leaves what the reference HOLDS once the buffer has gone through: the image and the decay state after
+        #        the last frame (lineGraphs[k].results is one buffer, overwritten by every frame: only the last frame's survives)
+        state.zero_()
+        for _ in range(5):
+            plan.render(view, rgba=rgba, state=state)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(50):
+            plan.render(view, rgba=rgba, state=state)
+        torch.cuda.synchronize()
+        extra["ms_per_step_with_end_state"] = (time.perf_counter() - ts) / 50 * 1e3
         # (iii) two buffers in flight: independent renders (two plans -- a plan owns its scratch --, two streams) alternate, so that one
         #       buffer's K_B and the partly filled last round of its K_A overlap the other buffer's K_A.  What a job of many buffers gets;
         #       NOT the contract line's value (steps there run one after the other on one stream), and a kernel's own duration grows under it.
@@ -648,6 +659,12 @@ def main() -> None:
             out["config"]["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
             out["ms_per_step_with_state"] = extra["ms_per_step_with_state"]
             out["value_with_state"] = total_frames * pairs / (extra["ms_per_step_with_state"] * 1e-3)
+        if "ms_per_step_with_end_state" in extra:
+            out["ms_per_step_with_end_state"] = extra["ms_per_step_with_end_state"]
+            out["value_with_end_state"] = total_frames * pairs / (extra["ms_per_step_with_end_state"] * 1e-3)
+            out["config"]["with_state_note"] = ("value_with_state: line results of both graphs for EVERY frame + the decay state after the last one; "
+                                                "value_with_end_state: the image + the decay state after the last frame (what the reference holds "
+                                                "after the same audio: its line results are one buffer that every frame overwrites)")
         if "two_in_flight" in extra:
             out["config"]["two_in_flight"] = extra["two_in_flight"]
         if world == 1 and not strong and not args.no_extras:

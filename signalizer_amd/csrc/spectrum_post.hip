@@ -435,12 +435,58 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
             carryS[d][m][px] = c;
             SGZ_PUBLISH(d + 1);
         }
+        // the state after the last frame IS the fold's last value (the chunked form is the recurrence itself: multiplying by the pole
+        // is monotone, so max(local scan, decayed carry) = the sequential state)
+        // (the loop above decays by a full chunk in front of every aggregate: right for the carries the emissions read, not for a
+        //  last chunk that is shorter)
+        const uint32_t pixel = pixelGroup() * PX + px;
+        if (prm.state && pixel < prm.P) {
+            float fin = c;
+            if (prm.numChunks > 1) {
+                const int lenLast = int(prm.frames - long(prm.numChunks - 1) * kMaxChunk);
+                fin = carryS[prm.numChunks - 2][m][px];
+#pragma unroll
+                for (int i = 0; i < kMaxChunk; ++i)
+                    if (i < lenLast) fin = fin * pole;
+                const float v = aggS[prm.numChunks - 1][m][px];
+                if (v > fin) fin = v;
+            }
+            prm.state[(size_t(m % G) * prm.P + pixel) * 2 + m / G] = fin;
+        }
     }
     if (tid < 64) return;                                       // (the fold's wave; the others emit beside it)
     // 3. emissions: one WALKER per (chunk, pixel, graph, half of the chunk).  It starts from the exact state at the end of the previous
     //    chunk and runs the reference's recurrence itself (state *= pole; if (mag > state) state = mag, TransformDSP.inl:1336-1341 --
     //    max(local scan, decayed carry) of the per-frame form is that recurrence, the decay being monotone), so a frame costs three
     //    operations per side before its dB map instead of a replay of the chunk up to it, and the carries are awaited once per walker.
+    if (!prm.lines) {
+        // no line results wanted (the image and the state after the last frame: what the reference holds when the same audio has gone
+        // through): only (side 0, main graph) is emitted, one item per (frame, pixel) as in decayColourFusedKernel -- a walker's four
+        // dB maps in a row would be the launch's critical path here
+        if (!prm.rgba) return;
+        const float pole = prm.sc.pole[0];
+        for (uint32_t e = tid - 64; e < items; e += 960) {
+            const uint32_t px = e % PX, f = e / PX, chunk = f / kMaxChunk, t = f % kMaxChunk;
+            const uint32_t pixel = pixelGroup() * PX + px;
+            if (pixel >= prm.P) continue;
+            awaitCarries(progressAddr, chunk);
+            float a = chunk == 0 ? stIn[0][px] : 0.f;
+            float cr = chunk > 0 ? carryS[chunk - 1][0][px] : 0.f;   // exact state at the end of the previous chunk
+#pragma unroll
+            for (int i = 0; i < kMaxChunk; ++i)
+                if (uint32_t(i) <= t) {
+                    const float m = magS[chunk * kMaxChunk + i][0][px];
+                    a = a * pole;
+                    if (m > a) a = m;
+                    cr = cr * pole;
+                }
+            const float st = a > cr ? a : cr;
+            float cb[3] = {0.f, 0.f, 0.f};                      // colourBuffer, SpectrumDSP.cpp:170-174
+            blendColour(cb, dbMap(prm.slope[pixel], st, prm.sc, logTab), prm.colourTables, prm.sc);
+            reinterpret_cast<uchar4 *>(prm.rgba)[size_t(f) * prm.P + pixel] = toRgba8(cb);
+        }
+        return;
+    }
     constexpr int HALF = kMaxChunk / 2;
     const uint32_t walkers = prm.numChunks * PX * G * 2;
     for (uint32_t w = tid - 64; w < walkers; w += 960) {
@@ -481,10 +527,6 @@ __global__ void __launch_bounds__(1024) decayFullFusedKernel(const DecayParams p
                 st[side] = st[side] * pole;                     // states[i] *= pole, TransformDSP.inl:1336,:1370
                 if (v > st[side]) st[side] = v;                 // :1338-1341
                 if (prm.lines || (side == 0 && k == 0 && prm.rgba)) res[side] = dbMap(slope, st[side], prm.sc, logTab);
-            }
-            if (prm.state && f == prm.frames - 1) {
-#pragma unroll
-                for (int side = 0; side < SIDES; ++side) prm.state[(size_t(k) * prm.P + pixel) * 2 + side] = st[side];
             }
             if (prm.lines) reinterpret_cast<float2 *>(prm.lines)[(size_t(f) * G + k) * prm.P + pixel] = float2{res[0], res[1]};
             if (prm.rgba && k == 0) {

@@ -19,4 +19,6 @@ L = api.lib()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 img = timeit(lambda: api.check(L.sgz_stage_decay_colour(plan.h, mapped.data_ptr(), F, rgba.data_ptr(), None, None, st)), iters)
 full = timeit(lambda: api.check(L.sgz_stage_decay_colour(plan.h, mapped.data_ptr(), F, rgba.data_ptr(), lines.data_ptr(), state.data_ptr(), st)), iters)
+ends = timeit(lambda: api.check(L.sgz_stage_decay_colour(plan.h, mapped.data_ptr(), F, rgba.data_ptr(), None, state.data_ptr(), st)), iters)
+print(f"K_B image + end state (no per-frame lines) {ends[0]:.2f}/{ends[1]:.2f} us")
 print(f"K_B image only {img[0]:.2f}/{img[1]:.2f} us   with lines + state {full[0]:.2f}/{full[1]:.2f} us")
