@@ -105,6 +105,13 @@ struct ColourParams {
     uint32_t keys[kMaxCh];                    // defaultKey per channel, RGBA8
 };
 
+struct PeakParams {           // Oscilloscope::runPeakFilter (scopePeakBody below)
+    ScopeDev *st;
+    const float *front; uint32_t size, channels, mode, lanes;
+    double coeff;
+    uint32_t len;       // Spectral: the reference's ring of the moment (the newest len samples, taken as memory order); else 0
+};
+
 struct IngestParams {
     ScopeDev *st;
     unsigned long long *peaks;                // [kPeakCap]
@@ -119,6 +126,7 @@ struct IngestParams {
     uint32_t trigSeparate, trigPair;
     float envelopeCoeff;
     uint32_t colours;                         // colour_by_frequency
+    uint32_t doPeak; PeakParams peak;         // the render thread's peak filter behind the batch's last block (sgz_scope_peak_filter found a batch waiting: one launch)
 };
 
 // A lane that walks a block sequentially (a recurrence) must not wait a memory round trip per sample: the samples come in batches of
@@ -238,6 +246,8 @@ __device__ unsigned long long g_ingestClk[8];
 #endif
 // (the colour parameters -- ~100 words with the per-channel keys -- come through a pointer: as a by-value argument they stayed live in
 // scalar registers across the loop over the batch's blocks and pushed four vector registers into scratch)
+__device__ void scopePeakBody(const PeakParams &prm);
+
 __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm, const ColourParams *colp)
 {
     const ColourParams &col = *colp;
@@ -720,16 +730,16 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     }   // next block of the batch
     for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(prm.st)[w] = reinterpret_cast<const uint32_t *>(&sState)[w];
     ICLK(7);
+    if (prm.doPeak) {                                            // (uniform) the rings and the state this launch wrote, as every lane sees them
+        __threadfence();
+        __syncthreads();
+        scopePeakBody(prm.peak);
+    }
 }
 
-// ---- Oscilloscope::runPeakFilter on the front rings (memory order, last size mod lanes slots dropped), every channel mode
-struct PeakParams {
-    ScopeDev *st;
-    const float *front; uint32_t size, channels, mode, lanes;
-    double coeff;
-    uint32_t len;       // Spectral: the reference's ring of the moment (the newest len samples, taken as memory order); else 0
-};
-__global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
+// ---- Oscilloscope::runPeakFilter on the front rings (memory order, last size mod lanes slots dropped), every channel mode.
+// A 1024-thread workgroup: scopePeakKernel, or the tail of scopeIngestKernel.
+__device__ void scopePeakBody(const PeakParams &prm)
 {
     __shared__ float sL[kMaxCh][16], sR[16];
     const uint32_t C = prm.channels, size = prm.size;
@@ -801,6 +811,7 @@ __global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm)
     for (uint32_t c = 0; c < C; ++c) start = fmaxf(start, __builtin_sqrtf(st->envelope[c]));
     st->autoGain = 1.0 / double(start);
 }
+__global__ void __launch_bounds__(1024) scopePeakKernel(const PeakParams prm) { scopePeakBody(prm); }
 
 
 // ---- Spectral triggering: Oscilloscope::calculateFundamentalPeriod + calculateTriggeringOffset (OscilloscopeDSP.inl:62-308)
@@ -1280,7 +1291,7 @@ sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg)
 }
 
 // the open batch -> GPU: one staged copy, one launch of the ingest kernel over its blocks (caller holds the batch flag; count > 0)
-static sgz_status scopeSubmit(sgz_scope *s)
+static sgz_status scopeSubmit(sgz_scope *s, const PeakParams *peak = nullptr)
 {
     sgz_status st;
     const float *fetchFrom; uint32_t floats;
@@ -1295,6 +1306,7 @@ static sgz_status scopeSubmit(sgz_scope *s)
     prm.triggerMode = s->cfg.trigger_mode; prm.oscMode = s->cfg.channel_mode; prm.envMode = s->cfg.envelope_mode;
     prm.trigSeparate = s->trigSeparate; prm.trigPair = s->trigPair; prm.envelopeCoeff = s->envelopeCoeff;
     prm.colours = s->cfg.colour_by_frequency ? 1u : 0u;
+    if (peak) { prm.doPeak = 1u; prm.peak = *peak; }
     hipLaunchKernelGGL(scopeIngestKernel, dim3(1), dim3(1024), 0, s->stream, prm, s->d_col);
     SGZ_HIP(hipGetLastError());
     return s->batch.commit(s->stream);
@@ -1368,15 +1380,23 @@ sgz_status sgz_scope_flush(sgz_scope *s)
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain)
 {
     if (!s || lanes == 0 || (lanes & (lanes - 1))) return fail(SGZ_EINVAL, "bad argument");
-    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     // coeff = pow(exp(-lanes / (envelopeWindow * sampleRate)), numSamples * dt), OscilloscopeDSP.inl:745-747
     const bool spectral = s->cfg.trigger_mode == SGZ_TRIG_SPECTRAL;
     const uint32_t numSamples = spectral ? uint32_t(s->trig.ring_size) : s->size;          // audioData.getSize()
     const double power = double(numSamples) * delta_time;
     const double coeff = std::pow(std::exp(-double(lanes) / (s->cfg.envelope_window * s->cfg.sample_rate)), power);
     PeakParams prm{s->d_state, s->d_front, s->size, s->cfg.num_channels, s->cfg.channel_mode, lanes, coeff, spectral ? numSamples : 0u};
-    hipLaunchKernelGGL(scopePeakKernel, dim3(1), dim3(1024), 0, s->stream, prm);
-    SGZ_HIP(hipGetLastError());
+    // flush on read: the blocks that wait in the open batch come first -- and the filter rides on their launch (one workgroup either
+    // way: a launch and the gap in front of it less per rendered frame)
+    s->batch.lock();
+    const bool fused = s->batch.count != 0;
+    const sgz_status sy = fused ? scopeSubmit(s, &prm) : SGZ_OK;
+    s->batch.unlock();
+    if (sy != SGZ_OK) return sy;
+    if (!fused) {
+        hipLaunchKernelGGL(scopePeakKernel, dim3(1), dim3(1024), 0, s->stream, prm);
+        SGZ_HIP(hipGetLastError());
+    }
     if (auto_gain) {
         SGZ_HIP(hipMemcpyAsync(auto_gain, reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, autoGain), sizeof(double),
                                hipMemcpyDeviceToHost, s->stream));
