@@ -91,6 +91,37 @@ def test_stream_state_machine_is_bit_exact(gpu, oracle, over):
         assert np.array_equal(env[:2].view(np.uint32), ref.envelopes()[:2].view(np.uint32))
 
 
+@pytest.mark.parametrize("over,max_block", [
+    (dict(), 700),                                                     # BASELINE cfg3, a dozen callbacks per launch
+    (dict(window_size=480.3, trigger_threshold=0.0), 300),             # many triggers per callback
+    (dict(window_size=1000.0, channel_mode=2, trigger_threshold=0.2), 64),
+    (dict(window_size=777.0, channel_mode=3, num_channels=4, trigger_channel=2.0), 1500),
+    (dict(window_size=300.0, channel_mode=5, envelope_mode=1, trigger_threshold=0.3), 9),          # tiny callbacks: sixteen per launch
+    (dict(window_size=2048.0, channel_mode=4, num_channels=6, trigger_channel=5.0, envelope_mode=1), 400),
+])
+def test_batched_launches_are_the_callback_walk(gpu, oracle, over, max_block, monkeypatch):
+    """the ingest kernel takes every callback that waited in ONE launch, with the zero-crossing detector run once over their
+    concatenation (scopeIngestKernel, "A for the whole batch"): SGZ_RT_DEFER_SUBMIT makes every launch a multi-callback one (blocks wait
+    for a full batch or a reader), and the state machine, the rings and the gains are still the oracle's callback-by-callback walk"""
+    monkeypatch.setenv("SGZ_RT_DEFER_SUBMIT", "1")
+    po = oracle
+    cfg = _cfg(**over)
+    x = _signal(5, 60000, cfg["num_channels"])
+    dev, ref = _feed(po, cfg, x, seed=23, max_block=max_block)
+    assert dev.state() == ref.state()
+    if cfg["trigger_threshold"] < 1:
+        assert ref.state()["swaps"] > 10
+    for c in range(cfg["num_channels"]):
+        got, gcur = dev.front(c)
+        want, wcur = ref.front(c)
+        assert gcur == wcur
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (c, int((got != want).sum()))
+    gain, env = dev.gains()
+    if cfg["envelope_mode"] == 1:
+        assert gain == ref.envelope_gain
+        assert np.array_equal(env[:2].view(np.uint32), ref.envelopes()[:2].view(np.uint32))
+
+
 @pytest.mark.parametrize("mode,channels", [(0, 2), (1, 2), (2, 2), (3, 2), (4, 6), (5, 4)])
 def test_peak_filter_every_channel_mode(gpu, oracle, mode, channels):
     """Oscilloscope::runPeakFilter incl. the Mid / Side / MidSide mixes and Separate's running maximum (OscilloscopeDSP.inl:770-880)"""
