@@ -145,3 +145,31 @@ def test_vertices_all_equals_per_pair_calls(gpu):
     assert got_xyz is out[0] and np.array_equal(got_xyz.view(np.uint32), all_xyz.view(np.uint32))
     assert np.array_equal(got_rgb.view(np.uint32), all_rgb.view(np.uint32))
     h.close()
+
+
+@pytest.mark.parametrize("size,lanes", [(9600, 8), (4096, 8), (4096, 4), (1000, 16), (777, 8), (65536, 8), (12345, 2), (9600, 32), (3001, 64),
+                                        (100000, 8), (33, 8), (17, 16)])
+def test_fade_ramp_is_the_reference_sum(gpu, oracle, size, lanes):
+    """the fade ramp (z of every vertex) at many (size, cursor, lanes): the handle evaluates it from the arithmetic progressions of the
+    fp32 running sum (fade_chain.hpp; lanes > 16 walk the sum as the reference does) -- bit for bit the oracle's SIMD-lane replay,
+    at cursors that put the section boundary everywhere (sizes that are powers of two make every step exact, the others cross binades
+    with ties on the way)"""
+    po = oracle
+    dev = api.Vector(sample_rate=SR, num_channels=2, window_size=size, envelope_mode=0, lanes=lanes, fade_history=1, max_block=4096,
+                     envelope_window=0.3, stereo_window=0.05, colours=[(1.0, 0.5, 0.25)])
+    mem = np.zeros((2, size), np.float32)
+    cursor = 0
+    rng = np.random.default_rng(size + lanes)
+    x = synth.gen(6, SR, 4096, 2)
+    for step in range(14):
+        n = [1, lanes - 1, lanes, lanes + 1, 37, 511, 1000, 2047, 4096, 3, 64, 999, 4095, 2][step]
+        blk = np.ascontiguousarray(x[:, :n])
+        _push(dev, blk)
+        idx = (cursor + np.arange(n)) % size
+        mem[:, idx] = blk
+        cursor = int((cursor + n) % size)
+        xyz, rgb = dev.vertices(0)
+        want, wrgb = po.vector_polar_view(mem[0], mem[1], cursor, lanes, True, (1.0, 0.5, 0.25))
+        assert np.array_equal(xyz[:, 2].view(np.uint32), want[:, 2].view(np.uint32)), (step, cursor, int((xyz[:, 2] != want[:, 2]).sum()))
+        assert np.array_equal(rgb.view(np.uint32), wrgb.view(np.uint32))
+    dev.close()
