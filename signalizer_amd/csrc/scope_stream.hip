@@ -509,11 +509,11 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         const unsigned int k = (q + kPeakCap - qHeadIn) % kPeakCap;
         return k < kStage ? sPeaks[k] : prm.peaks[q];
     };
-    if (tid == 0) {
+    if (tid < 64) {                                                  // wave 0, every lane the same scalar walk (lane 0 stores); the rounds below use all of them
+        const bool lane0 = tid == 0;
         unsigned int numSwaps = 0, lastStart = 0, lastLen = n;
-        sCursor0 = st->frontCursor;
         const unsigned long long written0 = st->written;
-        sWritten0 = written0;
+        if (lane0) { sCursor0 = st->frontCursor; sWritten0 = written0; }
         if (hold) {
             unsigned long long bufferedSamples = st->bufferedSamples, frontOrigin = st->frontOrigin, steadyClock = st->steadyClock;
             unsigned long long oldPeak = st->oldPeak, currentPeak = st->currentPeak;
@@ -548,6 +548,69 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
             // one trigger ahead, measured no faster).  Anything else -- a trigger outside the window -- leaves the state exactly as
             // the general body expects it at that point and falls through to it.
             while (numSamples != 0) {
+                // ---- a ROUND: up to 64 queued triggers at once, one per lane.  For a trigger that is fetched with the running clock
+                // already past it (no samples swallowed at the fetch, :128), inside the window and in order, the walk does
+                //     taken = max(missing - buffered, 0) samples from the callback;  swap min(max(buffered, missing), missing + 1);
+                //     buffered <- max(buffered - (missing + 1), 0)
+                // -- maps that compose by addition: buffered in front of trigger l is max(buffered_0 - sum_{i<l}(missing_i + 1), 0),
+                // so every trigger's numbers are prefix sums.  The round takes the longest run of such triggers that the callback's
+                // samples cover (the first one fetched at or after the running clock, out of order, outside the window, or short of
+                // samples ends it) and leaves the walk's state behind it; the scalar iteration below handles whatever comes next.
+                if (!isWorkingOnPeak && qCount >= 4u && halfCeil <= (1ull << 24) && bufferedSamples <= bufferedCap && bufferedSamples < (1ull << 30) &&
+                    numSamples < (1ull << 30) && steadyClock < (1ull << 51)) {
+                    const unsigned long long base = steadyClock;
+                    auto fits = [&](unsigned long long v) { const long long r = (long long)(v - base); return r > -(1ll << 30) && r < (1ll << 30); };
+                    if (fits(oldPeak)) {
+                        const unsigned int lane = (unsigned int)tid, cnt = qCount < 64u ? qCount : 64u;
+                        const unsigned int buf0 = (unsigned int)bufferedSamples, ns0 = (unsigned int)numSamples, hc = (unsigned int)halfCeil;
+                        auto scan = [&](unsigned int v) {                         // inclusive prefix sum over the wave
+#pragma unroll
+                            for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o); if (lane >= (unsigned int)o) v += u; }
+                            return v;
+                        };
+                        const unsigned long long pk = lane < cnt ? peakAt((qHead + lane) % kPeakCap) : 0ull;
+                        bool ok = lane < cnt && fits(pk);
+                        const int p = ok ? int((long long)(pk - base)) : 0;
+                        int prev = __shfl_up(p, 1);
+                        if (lane == 0) prev = int((long long)(oldPeak - base));
+                        ok = ok && p >= prev;
+                        const unsigned int d = ok ? (unsigned int)(p - prev) : 0u;
+                        ok = ok && d < hc;
+                        const unsigned int a = ok ? d + 1u : 0u;
+                        const unsigned int S = scan(a), Sprev = S - a;
+                        const unsigned int bufL = buf0 > Sprev ? buf0 - Sprev : 0u;
+                        const unsigned int tp = ok && d > bufL ? d - bufL : 0u;
+                        const unsigned int Cc = scan(tp), Cprev = Cc - tp;
+                        const bool swallow = ok && p >= 0 && (unsigned int)p >= Cprev;       // fetched at or after the running clock (base + Cprev)
+                        const bool stop = !ok || swallow || Cc > ns0 || Cprev >= ns0;
+                        const unsigned long long stops = __ballot(stop);
+                        const unsigned int m = stops ? (unsigned int)__builtin_ctzll(stops) : 64u;   // triggers 0 .. m-1 complete
+                        if (m > 0) {
+                            const unsigned int bufTake = bufL > d ? bufL : d, capped = bufTake < d + 1u ? bufTake : d + 1u;
+                            const unsigned int capSum = scan(lane < m ? capped : 0u);
+                            if (lane < m && numSwaps + lane < kMaxSwaps) {
+                                const Swap sw{written0 + consumed + Cc - bufTake, capped};
+                                if (numSwaps + lane < kStage) sSwaps[numSwaps + lane] = sw; else prm.swapList[numSwaps + lane] = sw;
+                            }
+                            const unsigned long long took = __ballot(lane < m && tp > 0u);
+                            if (took) {
+                                const int hl = 63 - __builtin_clzll(took);
+                                lastStart = (unsigned int)consumed + __shfl(Cprev, hl);
+                                lastLen = __shfl(tp, hl);
+                            }
+                            const unsigned int Sm = __shfl(S, int(m) - 1), Cm = __shfl(Cc, int(m) - 1), capM = __shfl(capSum, int(m) - 1);
+                            const int pm = __shfl(p, int(m) - 1);
+                            bufferedSamples = buf0 > Sm ? buf0 - Sm : 0u;
+                            numSamples -= Cm; consumed += Cm; steadyClock += Cm;
+                            frontOrigin += capM;
+                            oldPeak = currentPeak = base + (unsigned long long)(long long)pm;
+                            qHead = (qHead + m) % kPeakCap; qCount -= m;
+                            swapsDone += m;
+                            numSwaps = numSwaps + m < kMaxSwaps ? numSwaps + m : kMaxSwaps;
+                            continue;
+                        }
+                    }
+                }
                 bool fastDone = false;
                 if (qCount) do {
                     if (!isWorkingOnPeak) {                                          // :120-141
@@ -574,7 +637,7 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     const unsigned long long cappedSize = minU64(bufferedSamples, d + 1ull);
                     if (numSwaps < kMaxSwaps) {
                         const Swap sw{(written0 + consumed) - bufferedSamples, (unsigned int)cappedSize};
-                        if (numSwaps < kStage) sSwaps[numSwaps] = sw; else prm.swapList[numSwaps] = sw;      // (two stores: a selected reference is a flat one)
+                        if (lane0) { if (numSwaps < kStage) sSwaps[numSwaps] = sw; else prm.swapList[numSwaps] = sw; }     // (two stores: a selected reference is a flat one)
                         ++numSwaps;
                     }
                     bufferedSamples -= cappedSize;
@@ -623,9 +686,8 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     const unsigned long long cappedSize = minU64(bufferedSamples, (unsigned long long)ceil(amount + 1));
                     // swapBuffers(cappedSize, -bufferedSamples): source = the oldest buffered sample onwards
                     if (numSwaps < kMaxSwaps) {
-                        Swap &sw = numSwaps < kStage ? sSwaps[numSwaps] : prm.swapList[numSwaps];
-                        sw.src = (written0 + consumed) - bufferedSamples;
-                        sw.len = (unsigned int)cappedSize;
+                        const Swap sw{(written0 + consumed) - bufferedSamples, (unsigned int)cappedSize};
+                        if (lane0) { if (numSwaps < kStage) sSwaps[numSwaps] = sw; else prm.swapList[numSwaps] = sw; }
                         ++numSwaps;
                     }
                     bufferedSamples -= minU64(bufferedSamples, cappedSize);
@@ -636,12 +698,14 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
                     ++swapsDone;
                 }
             }
-            st->swaps += swapsDone;                                // (once: a read-modify-write of global memory inside the walk is a round trip per trigger)
-            st->bufferedSamples = bufferedSamples; st->frontOrigin = frontOrigin; st->steadyClock = steadyClock;
-            st->oldPeak = oldPeak; st->currentPeak = currentPeak; st->qHead = qHead; st->qCount = qCount;
-            st->isWorkingOnPeak = isWorkingOnPeak;
+            if (lane0) {
+                st->swaps += swapsDone;                            // (once: a read-modify-write of global memory inside the walk is a round trip per trigger)
+                st->bufferedSamples = bufferedSamples; st->frontOrigin = frontOrigin; st->steadyClock = steadyClock;
+                st->oldPeak = oldPeak; st->currentPeak = currentPeak; st->qHead = qHead; st->qCount = qCount;
+                st->isWorkingOnPeak = isWorkingOnPeak;
+            }
         }
-        sNumSwaps = numSwaps; sLastStart = lastStart; sLastLen = lastLen;
+        if (lane0) { sNumSwaps = numSwaps; sLastStart = lastStart; sLastLen = lastLen; }
     }
     __syncthreads();
 
