@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "runtime.hpp"
@@ -625,12 +626,34 @@ sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_
     if (lanes > 64) return fail(SGZ_EINVAL, "lanes > 64");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long iters = (long(n) > long(lanes)) ? (long(n) - 1) / long(lanes) : 0;      // VectorscopeRendering.cpp:528
-    // the ramp table depends on (n, lanes) only; this stateless stage call rebuilds it in stream order (the sgz_vector_* handle keeps
-    // its own and rebuilds it on configure only)
+    // the ramp table depends on (n, lanes) only: the first call with a pair of them builds it (and waits for it once, so that any
+    // stream may read it afterwards), later calls find it -- a few tables per device are kept for the life of the process; beyond
+    // that the call rebuilds its own in stream order as it always did
     StreamScratch ramp(s);
-    SGZ_HIP(ramp.get((size_t(iters) * lanes + 1) * sizeof(float)));
-    float *d_ramp = reinterpret_cast<float *>(ramp.p);
-    if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(256), 0, s, n, lanes, iters, d_ramp);
+    float *d_ramp = nullptr;
+    {
+        struct Entry { int device; size_t n; uint32_t lanes; float *table; };
+        static std::mutex mu;
+        static std::vector<Entry> cache;
+        int device = 0;
+        SGZ_HIP(hipGetDevice(&device));
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry &e : cache)
+            if (e.device == device && e.n == n && e.lanes == lanes) { d_ramp = e.table; break; }
+        if (!d_ramp && cache.size() < 8) {
+            float *t = nullptr;
+            SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&t), (size_t(iters) * lanes + 1) * sizeof(float)));
+            if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(256), 0, s, n, lanes, iters, t);
+            if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) { (void)hipFree(t); return hipFail(e, "hipStreamSynchronize"); }
+            cache.push_back(Entry{device, n, lanes, t});
+            d_ramp = t;
+        }
+    }
+    if (!d_ramp) {
+        SGZ_HIP(ramp.get((size_t(iters) * lanes + 1) * sizeof(float)));
+        d_ramp = reinterpret_cast<float *>(ramp.p);
+        if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(256), 0, s, n, lanes, iters, d_ramp);
+    }
     const int block = 256;
     dim3 grid(unsigned((n + block - 1) / block), pairs);
     hipLaunchKernelGGL(vectorPolarKernel, grid, dim3(block), 0, s, d_planar, stride, pairs, n, lanes, iters, d_ramp,
