@@ -650,3 +650,58 @@ def test_custom_trigger_frequency(gpu, oracle):
         assert abs(got.sample_offset - ts.sample_offset) <= 1e-6, (frame, got.sample_offset, ts.sample_offset)
         sz = max(int(0.5 + ts.cycle_samples + np.ceil(window)), 8192)
         assert got.ring_size == sz
+
+
+def test_audio_and_render_threads_run_concurrently(gpu, oracle):
+    """a producer thread pushes 1500 callbacks flat out while the render thread runs its frame (peak filter -- riding on the waiting
+    batch's launch when there is one --, both channels' strips, state reads): no call fails, no callback is lost or reordered -- the
+    trigger state machine and the rings end where the oracle's callback-by-callback walk ends (they depend on the pushes alone)"""
+    import threading
+    po = oracle
+    cfg = _cfg(window_size=3000.0, trigger_threshold=0.02, envelope_mode=2)
+    x = _signal(8, 1500 * 160, 2)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(cfg["num_channels"], cfg["sample_rate"], cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"],
+                         cfg["channel_mode"], cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
+    errors, frames = [], [0]
+    done = threading.Event()
+
+    def producer():
+        try:
+            for pos in range(0, x.shape[1], 160):
+                blk = np.ascontiguousarray(x[:, pos:pos + 160])
+                while True:
+                    st = dev.push(blk)
+                    if st == api.SGZ_OK:
+                        break
+                    if st != api.SGZ_BUSY:
+                        errors.append(("push", st)); return
+        finally:
+            done.set()
+
+    def render():
+        import torch
+        view = api.ScopeView(3000.0, 0.0, 1.0, 1.0, 1500, 0)
+        n = api.lib().sgz_scope_vertex_count(dev.h, C.byref(view))
+        outs = [(torch.zeros((n, 3), dtype=torch.float32).pin_memory().numpy(), torch.zeros((n, 4), dtype=torch.uint8).pin_memory().numpy()) for _ in (0, 1)]
+        try:
+            while not done.is_set():
+                dev.peak_filter(1 / 60, 8)
+                dev.vertices_all(view, (0, 1), (0, 0), outs)
+                frames[0] += 1
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(("render", repr(e)))
+
+    import ctypes as C
+    tp, tr = threading.Thread(target=producer), threading.Thread(target=render)
+    tr.start(); tp.start(); tp.join(timeout=180); tr.join(timeout=180)
+    assert not errors and not tp.is_alive() and not tr.is_alive(), errors[:3]
+    assert frames[0] > 5
+    for pos in range(0, x.shape[1], 160):
+        ref.audio(np.ascontiguousarray(x[:, pos:pos + 160]))
+    assert dev.state() == ref.state()
+    for c in range(2):
+        got, gcur = dev.front(c)
+        want, wcur = ref.front(c)
+        assert gcur == wcur and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    dev.close()
