@@ -173,3 +173,58 @@ def test_fade_ramp_is_the_reference_sum(gpu, oracle, size, lanes):
         assert np.array_equal(xyz[:, 2].view(np.uint32), want[:, 2].view(np.uint32)), (step, cursor, int((xyz[:, 2] != want[:, 2]).sum()))
         assert np.array_equal(rgb.view(np.uint32), wrgb.view(np.uint32))
     dev.close()
+
+
+def test_audio_and_render_threads_run_concurrently(gpu, oracle):
+    """a producer thread pushes 1500 callbacks flat out while the render thread draws (peak filter, every pair's vertices): no call
+    fails and no callback is lost or reordered -- history rings, balance and phase filters end where the oracle's walk ends"""
+    import threading
+    import torch
+    po = oracle
+    channels, size = 4, 4800
+    dev = api.Vector(sample_rate=SR, num_channels=channels, window_size=size, envelope_mode=2, lanes=8, fade_history=1, max_block=512,
+                     envelope_window=0.3, stereo_window=0.05, colours=[(1.0, 0.5, 0.25), (0.2, 0.9, 0.4)])
+    ref = RefVector(po, channels, size, 2, 0.3, 0.05, 8)
+    x = synth.gen(12, SR, 1500 * 200, channels)
+    errors, frames = [], [0]
+    done = threading.Event()
+
+    def producer():
+        try:
+            for pos in range(0, x.shape[1], 200):
+                blk = np.ascontiguousarray(x[:, pos:pos + 200])
+                while True:
+                    st = dev.push(blk)
+                    if st == api.SGZ_OK:
+                        break
+                    if st != api.SGZ_BUSY:
+                        errors.append(("push", st)); return
+        finally:
+            done.set()
+
+    def render():
+        outs = (torch.zeros((channels // 2, size, 3), dtype=torch.float32).pin_memory().numpy(),
+                torch.zeros((channels // 2, size, 3), dtype=torch.float32).pin_memory().numpy())
+        try:
+            while not done.is_set():
+                dev.peak_filter(1 / 60)
+                dev.vertices_all(out=outs)
+                frames[0] += 1
+        except Exception as e:                                     # noqa: BLE001
+            errors.append(("render", repr(e)))
+
+    tp, tr = threading.Thread(target=producer), threading.Thread(target=render)
+    tr.start(); tp.start(); tp.join(timeout=180); tr.join(timeout=180)
+    assert not errors and not tp.is_alive() and not tr.is_alive(), errors[:3]
+    assert frames[0] > 5
+    for pos in range(0, x.shape[1], 200):
+        ref.audio(np.ascontiguousarray(x[:, pos:pos + 200]))
+    for c in range(channels):
+        mem, cur = dev.history(c)
+        assert cur == ref.cursor and np.array_equal(mem.view(np.uint32), ref.mem[c].view(np.uint32))
+    f, _ = dev.filters()
+    gb = np.array([list(r) for r in f.balance], np.float32)
+    rb = np.array([list(r) for r in ref.f.balance], np.float32)
+    assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32))
+    assert np.abs(np.array(f.phase[:]) - np.array(ref.f.phase[:])).max() <= 1e-5
+    dev.close()
