@@ -229,6 +229,26 @@ __device__ __forceinline__ unsigned int blockExclusiveSum(unsigned int v, unsign
     return base + inc - v;
 }
 
+// inclusive prefix sum over the workgroup (all threads call it); lds: 16 words of T
+template <typename T>
+__device__ __forceinline__ T blockInclusiveSum(T v, T *lds, T *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < waves; ++w) { if (w < wave) base += lds[w]; tot += lds[w]; }
+    __syncthreads();
+    *total = tot;
+    return base + inc;
+}
+
 __device__ __forceinline__ double trigSample(uint32_t mode, const float *a, const float *b, uint32_t i)
 {
     if (mode == SGZ_OSC_MID) return double(0.5f * (a[i] + b[i]));          // OscilloscopeDSP.inl:371-376
@@ -265,11 +285,13 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     for (uint32_t w = tid; w < sizeof(ScopeDev) / 4; w += T) reinterpret_cast<uint32_t *>(&sState)[w] = reinterpret_cast<const uint32_t *>(prm.st)[w];
     __syncthreads();
     ScopeDev *st = &sState;
-    constexpr unsigned int kStage = 64;
+    constexpr unsigned int kStage = 64;             // triggers / swaps staged in LDS
+    constexpr unsigned int kFlat = 1024;            // swaps of a callback the one-pass copy takes (one per thread; more: one after the other)
     __shared__ unsigned long long sPeaks[kStage];
     __shared__ Swap sSwaps[kStage];
-    __shared__ unsigned long long sFlatSrc[kStage];
-    __shared__ uint32_t sFlatDst[kStage], sFlatEnd[kStage], sFlatTotal, sCursorEnd;
+    __shared__ unsigned long long sFlatSrc[kFlat];
+    __shared__ uint32_t sFlatDst[kFlat], sFlatEnd[kFlat], sFlatTotal, sCursorEnd;
+    __shared__ unsigned long long sScan64[16];
     // One launch ingests every block that was waiting (sgz_scope_push only stages; whoever needs the state -- the render thread's calls, a
     // full batch, sgz_scope_flush -- submits): the blocks go through the reference's per-callback state machine ONE AFTER THE OTHER, with
     // their boundaries where the host put them (audioEntryPoint runs once per onStreamAudio: update(), the detector, processMutating's
@@ -806,14 +828,39 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
         cursor = uint32_t((cursor + len) % size);
         __syncthreads();
     };
-    if (hold && sNumSwaps <= kStage) {
+    if (hold && sNumSwaps <= kFlat) {
         // The usual case -- a handful of swaps, all in LDS -- as ONE pass: no two swaps of a block write the same ring slot (what a later
         // swap would overwrite is `dead` and never written), and their sources are read-only here, so they need no order among
         // themselves.  Lane k of wave 0 works out swap k's surviving range from prefix sums of the lengths; then every thread
         // copies its share of the concatenation.  (One swap after the other with a barrier each cost a memory round trip per swap:
         // 8.9 us of a 25 us block at a dozen swaps, tools/ingest_clocks.py; now 1.9 us.)
         const uint32_t ns = sNumSwaps;
-        if (tid < 64) {
+        if (ns > kStage) {
+            // more swaps than a wave has lanes (a 10 kHz tone at 48 kHz crosses zero 107 times per 512-sample callback): the same
+            // tables from workgroup-wide prefix sums, one swap per thread (the swaps beyond the staged ones are read back from HBM).
+            // One after the other they cost 0.65 us each: 74 us per callback at 107, 143 us at 213.
+            const uint32_t k = uint32_t(tid);
+            const bool live = k < ns;
+            Swap sw{0ull, 0u, 0u};
+            if (live) sw = k < kStage ? sSwaps[k] : prm.swapList[k];
+            const uint32_t len = sw.len;
+            unsigned long long total;
+            const unsigned long long inc = blockInclusiveSum<unsigned long long>(len, sScan64, &total);
+            const unsigned long long before = inc - len, later = total - inc;
+            const uint32_t skip = len > size ? len - size : 0u;
+            const uint32_t m0 = len - skip;
+            const unsigned long long room = later >= size ? 0ull : size - later;
+            const uint32_t dead = m0 > room ? uint32_t(m0 - room) : 0u;
+            const uint32_t m = m0 - dead;
+            uint32_t totalM;
+            const uint32_t incM = blockInclusiveSum<uint32_t>(m, sSum, &totalM);
+            if (live) {
+                sFlatSrc[k] = sw.src + skip + dead;
+                sFlatDst[k] = uint32_t((sCursor0 + before + skip + dead) % size);
+                sFlatEnd[k] = incM;
+            }
+            if (tid == 0) { sFlatTotal = totalM; sCursorEnd = uint32_t((sCursor0 + total) % size); }
+        } else if (tid < 64) {
             const uint32_t k = uint32_t(tid);
             const bool live = k < ns;
             const uint32_t len = live ? sSwaps[live ? k : 0].len : 0u;

@@ -705,3 +705,28 @@ def test_audio_and_render_threads_run_concurrently(gpu, oracle):
         want, wcur = ref.front(c)
         assert gcur == wcur and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     dev.close()
+
+
+@pytest.mark.parametrize("freq,block", [(10000.0, 512), (20000.0, 512), (15000.0, 4096), (7000.0, 1000)])
+def test_dense_triggers_one_pass_copy(gpu, oracle, freq, block):
+    """a tone whose zero crossings make a hundred and more swaps per callback (more than a wave has lanes, up to the 1024 the one-pass
+    copy takes, and beyond: 15 kHz in 4096-sample callbacks is 1280): rings and state are the oracle's"""
+    po = oracle
+    sr = 48000.0
+    cfg = _cfg(sample_rate=sr, window_size=4800.0, trigger_threshold=0.05, max_block=4096)
+    t = np.arange(block * 40) / sr
+    x = np.stack([0.5 * np.sin(2 * np.pi * freq * t), 0.4 * np.sin(2 * np.pi * freq * t + 0.3)]).astype(np.float32)
+    dev = api.Scope(**cfg)
+    ref = po.ScopeStream(cfg["num_channels"], cfg["sample_rate"], cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"],
+                         cfg["channel_mode"], cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
+    for pos in range(0, x.shape[1], block):
+        blk = np.ascontiguousarray(x[:, pos:pos + block])
+        _push(dev, blk)
+        ref.audio(blk)
+    assert dev.state() == ref.state()
+    assert ref.state()["swaps"] > 40 * 60
+    for c in range(2):
+        got, gcur = dev.front(c)
+        want, wcur = ref.front(c)
+        assert gcur == wcur and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (c, int((got != want).sum()))
+    dev.close()
