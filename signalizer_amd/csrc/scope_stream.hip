@@ -735,59 +735,88 @@ __global__ void __launch_bounds__(1024) scopeIngestKernel(const IngestParams prm
     // ---- F: per-sample colours of the block (audioProcessing :445-517, :588-647).  Every sample passes through audioProcessing exactly
     // once and in order, whatever the split into calls, so the filters run over the block as a whole.
     if (prm.colours) {
+        // The three filter stages hand their per-sample outputs on through LDS, a tile of the callback at a time (samples in, band
+        // signals, smoothed energies: 11 floats per channel and sample; a stereo tile is 416 samples).  Through the HBM scratch every
+        // sixteen samples of every stage waited for a memory round trip of its own: 64 us per stage, 193 us of a 206 us callback.
+        constexpr uint32_t kFFloats = 9216;
+        __shared__ float sF[kFFloats];
         const uint32_t MB = col.maxBlock;
         ColourDev *cs = col.st;
-        if (uint32_t(tid) < 2 * C) {                                   // F1: low = LP4_f1(x), rest = HP4_f1(x)
-            const uint32_t c = uint32_t(tid) >> 1, hp = uint32_t(tid) & 1u;
-            const float *k = hp ? col.hp1 : col.lp1;
-            float k0[5]; for (int j = 0; j < 5; ++j) k0[j] = k[j];
-            float (*z)[2] = cs->z[c] + (hp ? 2 : 0);
-            float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
-            const float *x = blk + size_t(c) * n;
-            float *out = col.bands + (size_t(c) * 4 + (hp ? 3 : 0)) * MB;
-            walkSequential(n, [&](uint32_t i) { return x[i]; },
-                           [&](uint32_t i, float v) { out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, v)); });
-            z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
+        uint32_t tile = kFFloats / (11u * C);
+        tile = tile >= 16u ? (tile & ~15u) : (tile ? tile : 1u);
+        if (tile > 512u) tile = 512u;
+        float *sX = sF, *sB = sX + size_t(C) * tile, *sS = sB + size_t(4 * C) * tile;       // [C][tile], [4 C][tile], [6 C][tile]
+        // the lanes' filter states stay in registers from tile to tile
+        const bool r12 = uint32_t(tid) < 2 * C, r3 = uint32_t(tid) < 6 * C;
+        const uint32_t fc = uint32_t(tid) >> 1, fhp = uint32_t(tid) & 1u;
+        float k1[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, k2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f, y = 0.f;
+        float *stp = nullptr;
+        const uint32_t pair3 = uint32_t(tid) / 12u, r = uint32_t(tid) % 12u, sig3 = r / 3u, band3 = r % 3u;
+        if (r12) {
+            const float *ka = fhp ? col.hp1 : col.lp1, *kb = fhp ? col.hp2 : col.lp2;
+            for (int j = 0; j < 5; ++j) { k1[j] = ka[j]; k2[j] = kb[j]; }
+            float (*z1)[2] = cs->z[fc] + (fhp ? 2 : 0), (*z2)[2] = cs->z[fc] + (fhp ? 6 : 4);
+            a0 = z1[0][0]; a1 = z1[0][1]; b0 = z1[1][0]; b1 = z1[1][1];
+            c0 = z2[0][0]; c1 = z2[0][1]; d0 = z2[1][0]; d1 = z2[1][1];
         }
-        __syncthreads();
-        if (uint32_t(tid) < 2 * C) {                                   // F2: mid = LP4_f2(rest), high = HP4_f2(rest)
-            const uint32_t c = uint32_t(tid) >> 1, hp = uint32_t(tid) & 1u;
-            const float *k = hp ? col.hp2 : col.lp2;
-            float k0[5]; for (int j = 0; j < 5; ++j) k0[j] = k[j];
-            float (*z)[2] = cs->z[c] + (hp ? 6 : 4);
-            float a0 = z[0][0], a1 = z[0][1], b0 = z[1][0], b1 = z[1][1];
-            const float *x = col.bands + (size_t(c) * 4 + 3) * MB;
-            float *out = col.bands + (size_t(c) * 4 + (hp ? 2 : 1)) * MB;
-            walkSequential(n, [&](uint32_t i) { return x[i]; },
-                           [&](uint32_t i, float v) { out[i] = biquadStep(k0, b0, b1, biquadStep(k0, a0, a1, v)); });
-            z[0][0] = a0; z[0][1] = a1; z[1][0] = b0; z[1][1] = b1;
+        if (r3) {
+            stp = sig3 == 0 ? &cs->smooth[2 * pair3][band3] : sig3 == 1 ? &cs->smooth[2 * pair3 + 1][band3]
+                : sig3 == 2 ? &cs->aux[2 * pair3][band3] : &cs->aux[2 * pair3 + 1][band3];
+            y = *stp;
         }
-        __syncthreads();
-        if (uint32_t(tid) < 6 * C) {                                   // F3: filterStates (:460-468) of left, right, mid, side
-            const uint32_t pair = uint32_t(tid) / 12u, r = uint32_t(tid) % 12u, sig = r / 3u, band = r % 3u;
-            const float *l = col.bands + (size_t(2 * pair) * 4 + band) * MB, *rr = col.bands + (size_t(2 * pair + 1) * 4 + band) * MB;
-            float *stp = sig == 0 ? &cs->smooth[2 * pair][band] : sig == 1 ? &cs->smooth[2 * pair + 1][band]
-                       : sig == 2 ? &cs->aux[2 * pair][band] : &cs->aux[2 * pair + 1][band];
-            float y = *stp;
-            const float pole = col.pole;
-            float *out = col.sm + size_t(tid) * MB;
-            walkSequential(n, [&](uint32_t i) { return sig == 0 ? l[i] : sig == 1 ? rr[i] : sig == 2 ? l[i] + rr[i] : l[i] - rr[i]; },
-                           [&](uint32_t i, float v) {
-                               const float input = v * v;
-                               y = input + pole * (y - input);
-                               out[i] = y;
-                           });
-            *stp = y;
+        const float pole = col.pole;
+        for (uint32_t t0 = 0; t0 < n; t0 += tile) {
+            const uint32_t m = min(tile, n - t0);
+            for (uint32_t e = tid; e < C * m; e += T) { const uint32_t c = e / m, i = e - c * m; sX[size_t(c) * tile + i] = blk[size_t(c) * n + t0 + i]; }
+            __syncthreads();
+            if (r12) {                                                     // F1: low = LP4_f1(x), rest = HP4_f1(x)
+                const float *x = sX + size_t(fc) * tile;
+                float *out = sB + (size_t(fc) * 4 + (fhp ? 3 : 0)) * tile;
+                walkSequential(m, [&](uint32_t i) { return x[i]; },
+                               [&](uint32_t i, float v) { out[i] = biquadStep(k1, b0, b1, biquadStep(k1, a0, a1, v)); });
+            }
+            __syncthreads();
+            if (r12) {                                                     // F2: mid = LP4_f2(rest), high = HP4_f2(rest)
+                const float *x = sB + (size_t(fc) * 4 + 3) * tile;
+                float *out = sB + (size_t(fc) * 4 + (fhp ? 2 : 1)) * tile;
+                walkSequential(m, [&](uint32_t i) { return x[i]; },
+                               [&](uint32_t i, float v) { out[i] = biquadStep(k2, d0, d1, biquadStep(k2, c0, c1, v)); });
+            }
+            __syncthreads();
+            if (r3) {                                                      // F3: filterStates (:460-468) of left, right, mid, side
+                const float *l = sB + (size_t(2 * pair3) * 4 + band3) * tile, *rr = sB + (size_t(2 * pair3 + 1) * 4 + band3) * tile;
+                float *out = sS + size_t(tid) * tile;
+                // (which signal a lane smooths is a lane constant: both inputs are read and the lane's one picked by selects -- as a
+                // branch inside the batched loads the four cases ran one after the other: 90 us of a 150 us callback)
+                const bool isL = sig3 == 0, isR = sig3 == 1, isMid = sig3 == 2;
+                walkSequential(m, [&](uint32_t i) { return l[i]; },
+                               [&](uint32_t i, float lv) {
+                                   const float rv = rr[i];
+                                   const float sum = lv + rv, dif = lv - rv;
+                                   const float v = isL ? lv : (isR ? rv : (isMid ? sum : dif));
+                                   const float input = v * v;
+                                   y = input + pole * (y - input);
+                                   out[i] = y;
+                               });
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < 2 * C * m; e += T) {                // F4: accumulateColour per (signal, sample)
+                const uint32_t q = e / m, i = e - q * m, pair = q >> 2, sig = q & 3u;
+                const float *sp = sS + size_t(pair * 12 + sig * 3) * tile + i;
+                const float stv[3] = {sp[0], sp[tile], sp[2 * size_t(tile)]};
+                const uint32_t keyCh = 2 * pair + (sig & 1u);              // left / mid: the left key, right / side: the right key
+                const uint32_t plane = (sig < 2 ? 0u : C) + keyCh;         // cwLeft, cwRight -> colourData; cwMid, cwSide -> auxColourData
+                col.block[size_t(plane) * MB + t0 + i] = accumulateColour(stv, col.band, col.keys[keyCh], col.blend);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t e = tid; e < 2 * C * n; e += T) {                // F4: accumulateColour per (signal, sample)
-            const uint32_t q = e / n, i = e - q * n, pair = q >> 2, sig = q & 3u;
-            const float *sp = col.sm + size_t(pair * 12 + sig * 3) * MB + i;
-            const float stv[3] = {sp[0], sp[MB], sp[2 * size_t(MB)]};
-            const uint32_t keyCh = 2 * pair + (sig & 1u);              // left / mid: the left key, right / side: the right key
-            const uint32_t plane = (sig < 2 ? 0u : C) + keyCh;         // cwLeft, cwRight -> colourData; cwMid, cwSide -> auxColourData
-            col.block[size_t(plane) * MB + i] = accumulateColour(stv, col.band, col.keys[keyCh], col.blend);
+        if (r12) {
+            float (*z1)[2] = cs->z[fc] + (fhp ? 2 : 0), (*z2)[2] = cs->z[fc] + (fhp ? 6 : 4);
+            z1[0][0] = a0; z1[0][1] = a1; z1[1][0] = b0; z1[1][1] = b1;
+            z2[0][0] = c0; z2[0][1] = c1; z2[1][0] = d0; z2[1][1] = d1;
         }
+        if (r3) *stp = y;
         __syncthreads();
     }
 

@@ -6,7 +6,7 @@ import numpy as np
 from signalizer_amd import api, synth
 x = synth.gen(3, 192000, 512 * 64, 2)
 BANDS = [(1.0, 0.25, 0.1), (0.2, 1.0, 0.3), (0.15, 0.35, 1.0)]
-for name, kw in [("None", dict(trigger_mode=0)), ("ZeroCrossing", dict(trigger_mode=4)), ("Spectral", dict(trigger_mode=1)),
+for name, kw in [("None", dict(trigger_mode=0)), ("ZeroCrossing", dict(trigger_mode=4)), ("EnvelopeHold", dict(trigger_mode=3)), ("Spectral", dict(trigger_mode=1)),
                  ("ZeroCrossing + colours", dict(trigger_mode=4, colour_by_frequency=1, frequency_colouring_blend=0.8, colour_smoothing_ms=4.0, band_colours=BANDS)),
                  ("ZeroCrossing + RMS", dict(trigger_mode=4, envelope_mode=1)), ("None + RMS", dict(trigger_mode=0, envelope_mode=1)),
                  ("None + RMS, Separate", dict(trigger_mode=0, envelope_mode=1, channel_mode=4)),

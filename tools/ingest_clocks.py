@@ -6,8 +6,15 @@ import numpy as np, torch
 from signalizer_amd import api, synth
 L = api.lib()
 sr, W, nch = 192000.0, 19200, 2
-h = api.Scope(sample_rate=sr, window_size=float(W), num_channels=nch, trigger_mode=4, channel_mode=0, envelope_mode=2,
-              interpolation=3, max_block=512, trigger_threshold=0.05, trigger_channel=1.0, envelope_window=0.3)
+extra = {}
+if os.environ.get("SGZ_CLOCKS_COLOURS") == "1":                    # phase F as well
+    extra = dict(colour_by_frequency=1, frequency_colouring_blend=0.8, colour_smoothing_ms=4.0, band_colours=[(1.0, 0.25, 0.1), (0.2, 1.0, 0.3), (0.15, 0.35, 1.0)])
+if os.environ.get("SGZ_CLOCKS_MODE"):
+    extra["trigger_mode"] = int(os.environ["SGZ_CLOCKS_MODE"])
+cfgd = dict(sample_rate=sr, window_size=float(W), num_channels=nch, trigger_mode=4, channel_mode=0, envelope_mode=2,
+            interpolation=3, max_block=512, trigger_threshold=0.05, trigger_channel=1.0, envelope_window=0.3)
+cfgd.update(extra)
+h = api.Scope(**cfgd)
 x = synth.gen(31, int(sr), 3200 * 16, nch)
 names = ["state in LDS -> A done (zero crossings)", "B done (automaton)", "(colours)", "swap list read", "swaps copied", "back ring", "envelope", "state written back"]
 acc = np.zeros(7); cnt = 0
