@@ -7,10 +7,13 @@ import numpy as np
 from signalizer_amd import api, config, synth
 
 def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    N = int(nums[0]) if nums else 4096
+    pairs = int(nums[1]) if len(nums) > 1 else 1
     P = 1024
-    cfg = config.spectrum_config(window_size=N, hop=1024, axis_points=P, num_pairs=pairs, display_mode=config.DISPLAY_LINE_GRAPH)
+    extra = dict(algorithm=config.ALGO_RSNT) if "rsnt" in sys.argv else {}
+    blk_len = 512 if "b512" in sys.argv else 100
+    cfg = config.spectrum_config(window_size=N, hop=1024, axis_points=P, num_pairs=pairs, display_mode=config.DISPLAY_LINE_GRAPH, **extra)
     L = api.lib()
     c = api.config_from_dict(cfg)
     h = C.c_void_p()
@@ -22,9 +25,9 @@ def main():
     for frame in range(400):
         t0 = time.perf_counter()
         for b in range(8):
-            blk = np.ascontiguousarray(x[:, pos:pos + 100]); pos = (pos + 100) % (x.shape[1] - 100)
+            blk = np.ascontiguousarray(x[:, pos:pos + blk_len]); pos = (pos + blk_len) % (x.shape[1] - blk_len)
             ptrs = (C.c_void_p * (2 * pairs))(*[blk[i].ctypes.data for i in range(2 * pairs)])
-            api.check(L.sgz_spectrum_push(h, ptrs, 2 * pairs, 100))
+            api.check(L.sgz_spectrum_push(h, ptrs, 2 * pairs, blk_len))
         t1 = time.perf_counter()
         api.check(L.sgz_spectrum_render_lines(h, None, out.ctypes.data_as(C.c_void_p)))
         t2 = time.perf_counter()
