@@ -269,7 +269,7 @@ def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
-OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW, OPT_MATRIX_RESONATOR, OPT_RESONATOR_SLAB = 1, 2, 3, 4, 5
+OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW, OPT_MATRIX_RESONATOR, OPT_RESONATOR_SLAB, OPT_WIDE_GROUPS = 1, 2, 3, 4, 5, 6
 
 
 class Plan:

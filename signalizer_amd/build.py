@@ -8,10 +8,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsgz.so")
-SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_generic.hip", "spectrum_post.hip", "resonator.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "tracker.hip", "api.hip", "realtime.hip"]
+SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_real16.hip", "spectrum_generic.hip", "spectrum_post.hip", "resonator.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "tracker.hip", "api.hip", "realtime.hip"]
 DRIVER = os.path.join(HERE, "librtdriver.so")
 DRIVER_SRC = os.path.join(os.path.dirname(HERE), "tools", "rt_driver.cpp")
-HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
+HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "real_common.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
 def _hipcc() -> str:
@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         else:
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt",
                    "-x", "hip", "-c", s, "-o", o] + os.environ.get("SGZ_EXTRA_HIPCC_FLAGS", "").split()
-            if s.endswith(("spectrum_fft.hip", "spectrum_real.hip", "resonator.hip")):
+            if s.endswith(("spectrum_fft.hip", "spectrum_real.hip", "spectrum_real16.hip", "resonator.hip")):
                 cmd.append("-fno-slp-vectorize")   # packed-f32 SLP adds v_mov shuffles around the butterflies (measured -2.5 %) and beside the MFMAs
         if verbose:
             print(" ".join(cmd))

@@ -38,7 +38,7 @@ Plan::~Plan()
 {
     // best effort; ignore errors on teardown
     void *ptrs[] = {d_window, d_slope, d_colourTables, d_weights, d_weights11, d_recsReal, d_realLowPixels, d_low, d_tw1, d_tw2, d_twN, d_tw1odd, d_recs, d_items, d_mapped, d_agg, d_scratch,
-                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resPowB, d_resPowBLo, d_resW1, d_resW2, d_resW1b, d_resTile, d_resGain, d_resState, d_resLocal};
+                    d_stateCopy, d_work0, d_work1, d_binsWork, d_halfBins, d_dcPixels, d_dcWork, d_phaseType, d_phaseNorm, d_phaseWork, d_shard, d_twReal1, d_twRealPost, d_tw2Full, d_tw16, d_twPost16, d_windowHalf, d_winPhase, d_winPhaseT, d_ny, d_nyBest, d_chunkEnds, d_chunkReBase, d_chunkRec, d_weights12, d_resCoeff, d_resPow, d_resPowB, d_resPowBLo, d_resW1, d_resW2, d_resW1b, d_resTile, d_resGain, d_resState, d_resLocal};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)d_hostAudio, (void *)d_hostRgba, (void *)d_hostLines})
@@ -81,6 +81,9 @@ sgz_status uploadPlan(Plan &p, std::string &err)
     if ((st = uploadVec(p.twReal1, &p.d_twReal1)) != SGZ_OK) return st;
     if ((st = uploadVec(p.twRealPost, &p.d_twRealPost)) != SGZ_OK) return st;
     if ((st = uploadVec(p.tw2Full, &p.d_tw2Full)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.tw16, &p.d_tw16)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.windowHalf, &p.d_windowHalf)) != SGZ_OK) return st;
+    if ((st = uploadVec(p.twPost16, &p.d_twPost16)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhase, &p.d_winPhase)) != SGZ_OK) return st;
     if ((st = uploadVec(p.winPhaseT, &p.d_winPhaseT)) != SGZ_OK) return st;
     if ((st = uploadVec(p.chunkEnds, &p.d_chunkEnds)) != SGZ_OK) return st;
@@ -322,12 +325,13 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         RealParams rp{};
         rp.planar = d_planar; rp.chStride = chStride; rp.frames = frames;
         rp.hop = p.cfg.hop; rp.C = p.C; rp.P = p.P; rp.mode = p.cfg.channel_mode;
-        rp.window = p.d_window;
-        rp.winPhase = p.optFetchWindow ? nullptr : reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = p.winP0; rp.winP1 = p.winP1;
+        rp.window = p.d_windowHalf;                                       // these kernels transform x w / 2 (real_common.hpp realBinMag)
+        rp.winPhase = p.optFetchWindow ? nullptr : reinterpret_cast<const float4 *>(p.d_winPhase); rp.winP0 = 0.5f * p.winP0; rp.winP1 = 0.5f * p.winP1;
         rp.tw1 = reinterpret_cast<const float2 *>(p.d_twReal1);
         rp.tw2 = reinterpret_cast<const float2 *>(p.d_tw2);
         rp.twPost = reinterpret_cast<const float2 *>(p.d_twRealPost);
         rp.tw2Full = reinterpret_cast<const float4 *>(p.d_tw2Full);
+        rp.tw16 = p.optWideGroups ? reinterpret_cast<const float4 *>(p.d_tw16) : nullptr; rp.twPost16 = reinterpret_cast<const float2 *>(p.d_twPost16);
         rp.recs = p.d_recsReal ? p.d_recsReal : p.d_recs; rp.recsFull = p.d_recs; rp.weights = p.d_weights;
         rp.chunkEnds = p.d_chunkEnds; rp.chunkReBase = p.d_chunkReBase; rp.chunkRec = p.d_chunkRec; rp.weights12 = p.d_weights12;
         rp.chunkSlots[0] = p.chunkSlots[0]; rp.chunkSlots[1] = p.chunkSlots[1];
@@ -601,6 +605,7 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
     case SGZ_OPT_MATRIX_RESONATOR: if (value > 2) return fail(SGZ_EINVAL, "SGZ_OPT_MATRIX_RESONATOR: 0, 1 or 2"); p.optMatrixResonator = int(value); return SGZ_OK;
     case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
+    case SGZ_OPT_WIDE_GROUPS: p.optWideGroups = value != 0; return SGZ_OK;
     default: return fail(SGZ_EINVAL, "unknown plan option");
     }
 }

@@ -132,9 +132,11 @@ struct ChunkMap {
         // ---- this thread's chunk
         float v[32];
         {
-            const float2 *src = reinterpret_cast<const float2 *>(lds + chunkPos(32 * tid));
+            v2 t[16];                                                   // sixteen single ds_read_b64 (fft_common.hpp ldsRead64: paired reads run at half the rate)
+            ldsReadRun64<16, 8>(t, ldsAddress(lds + chunkPos(32 * tid)));
+            ldsReadsDone(t);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { const float2 t = src[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+            for (int j = 0; j < 16; ++j) { v[2 * j] = t[j].x; v[2 * j + 1] = t[j].y; }
         }
         v[0] = __builtin_fabsf(v[0]);                                   // csf[0] (left side, chunk 0) is a signed real; every other entry is a magnitude
         // ---- segmented running maximum + tile maxima.  The lane mask "element j closes a tile" is a compare of the thread's end bits

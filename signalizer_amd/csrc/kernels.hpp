@@ -57,8 +57,10 @@ struct RealParams {
     const float4 *winPhase; float winP0, winP1;
     const float2 *tw1;        // [3 + R1/4 - 1][1024]  pass-1 twiddles W_{N/2}^{c q}
     const float2 *tw2;        // [10][32]  (the whole-frame kernels' pass-2 table: N = 16384 builds the other rows as products)
-    const float4 *tw2Full;    // N >= 32768: all 32 rows [32][32] float2, copied to LDS by every workgroup (one twiddle = one ds_read_b64)
+    const float4 *tw2Full;    // N >= 32768: W_1024^{c q} as [c < 32][34] float2 (q < 32, two pad entries), copied to LDS by every workgroup: a thread's 32 factors are 16 ds_read_b128
     const float2 *twPost;     // [R1 * 32]  W_N^{kc}
+    const float4 *tw16;       // N = 32768, 1024-thread form (spectrum_real16.hip): [16][64] + [4][16] float2, staged in LDS; null: the 512-thread form
+    const float2 *twPost16;   // [1024] W_N^{kb}
     const PixelRec *recs; const float *weights;
     // the chunk-scan pixel map (chunk_map.hpp; plan.cpp buildChunkMap): per side, [T] end bits, [T] slot bases, [P] records
     const uint32_t *chunkEnds; const uint32_t *chunkReBase; const uint32_t *chunkRec; const float *weights12;

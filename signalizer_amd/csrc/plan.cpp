@@ -931,7 +931,7 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         const bool ok = buildChunkMap(p, p.recsReal.empty() ? p.recs : p.recsReal, p.realSplit ? 2 : 1);
         const size_t Mh = p.N / 2, Tt = Mh / 32;
         const size_t sFloats = size_t(chunkPos(int(Mh))) + 32;
-        const size_t extra = std::max<size_t>(size_t(std::max(p.chunkSlots[0], p.chunkSlots[1])) + 1 + Tt, p.N >= 32768 ? 2048 : 0) + 64;   // (+ column 0's scratch)
+        const size_t extra = std::max<size_t>(size_t(std::max(p.chunkSlots[0], p.chunkSlots[1])) + 1 + Tt, p.N >= 32768 ? 2180 : 0) + 64;   // (+ column 0's scratch)
         const size_t budget = (p.N == 16384 ? size_t(40) : p.N == 32768 ? size_t(80) : size_t(160)) * 1024;    // (the kernels have no static LDS)
         if (!ok || (sFloats + extra + (p.realMono ? 2 * 16 : 0)) * 4 > budget) { p.realSplit = false; p.realMono = false; p.recsReal.clear(); p.realLowPixels.clear(); p.realLowCount[0] = p.realLowCount[1] = 0; }
     }
@@ -948,14 +948,17 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
                 p.twReal1[(size_t(row) * 1024 + c) * 2 + 0] = float(std::cos(ang));
                 p.twReal1[(size_t(row) * 1024 + c) * 2 + 1] = float(std::sin(ang));
             }
+        p.windowHalf.resize(p.window.size());
+        for (size_t i = 0; i < p.window.size(); ++i) p.windowHalf[i] = 0.5f * p.window[i];
         if (cosWindow) {
             p.winPhase.resize(1024 * 4);
             for (uint32_t c = 0; c < 1024; ++c)
                 for (int e = 0; e < 2; ++e) {
                     const double ang = kTwoPi * double(2 * c + e) / double(p.N);
                     // p1 x (cos even, cos odd, sin even, sin odd): two aligned pairs, the window's cosine coefficient folded in
-                    p.winPhase[size_t(c) * 4 + e] = float(double(p.winP1) * std::cos(ang));
-                    p.winPhase[size_t(c) * 4 + 2 + e] = float(double(p.winP1) * std::sin(ang));
+                    // (halved: these kernels transform x w / 2, see real_common.hpp realBinMag -- exact, the factor is a power of two)
+                    p.winPhase[size_t(c) * 4 + e] = 0.5f * float(double(p.winP1) * std::cos(ang));
+                    p.winPhase[size_t(c) * 4 + 2 + e] = 0.5f * float(double(p.winP1) * std::sin(ang));
                 }
         }
         if (p.tw2.empty()) {                                   // N = 16384 has no R^3 tables of its own: the channel transform's passes 2 / 3 are radix 32
@@ -971,12 +974,14 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
         }
         p.tw2Full.clear();
         if (p.N >= 32768) {
-            p.tw2Full.resize(size_t(32) * 32 * 2);
+            // [c < 32][34] float2: a thread's 32 factors W_1024^{c q} are contiguous (16 ds_read_b128), rows of 32 + 2 entries keep the 16 lanes
+            // an LDS cycle serves on 16 different bank quads
+            p.tw2Full.assign(size_t(32) * 34 * 2, 0.0f);
             for (uint32_t q = 0; q < 32; ++q)
                 for (uint32_t c = 0; c < 32; ++c) {
                     const double ang = -kTwoPi * double((q * c) % 1024u) / 1024.0;
-                    p.tw2Full[(size_t(q) * 32 + c) * 2 + 0] = float(std::cos(ang));
-                    p.tw2Full[(size_t(q) * 32 + c) * 2 + 1] = float(std::sin(ang));
+                    p.tw2Full[(size_t(c) * 34 + q) * 2 + 0] = float(std::cos(ang));
+                    p.tw2Full[(size_t(c) * 34 + q) * 2 + 1] = float(std::sin(ang));
                 }
         }
         p.twRealPost.resize(size_t(T) * 2);
@@ -984,6 +989,35 @@ sgz_status buildPlan(const sgz_spectrum_config &cfg, Plan &p, std::string &err)
             const double ang = -kTwoPi * double(kc) / double(p.N);
             p.twRealPost[size_t(kc) * 2 + 0] = float(std::cos(ang));
             p.twRealPost[size_t(kc) * 2 + 1] = float(std::sin(ang));
+        }
+        // The 1024-thread form of the N = 32768 channel transform (spectrum_real16.hip): M = 16 x 16 x (4 across a lane quad x 16).
+        //   tw16: [16 q2][64 c_lo] W_1024^{c_lo q2} (pass 2), then [4 l][16 r] sign_l W_64^{r m}, m = brev2(l) (pass 3: the quad's
+        //         radix-4 stage leaves lane l with sign_l a_m, signs (+, -, -, -): tools/emulate_real16.py), staged in LDS by every workgroup
+        //   twPost16: [1024] W_N^{kb}, kb = q1 + 16 q2 + 256 m: the recombination twiddle of a thread's first bin
+        p.tw16.clear(); p.twPost16.clear();
+        if (p.N == 32768 && p.realSplit) {
+            p.tw16.resize(size_t(16 * 64 + 4 * 16) * 2);
+            for (uint32_t q = 0; q < 16; ++q)
+                for (uint32_t c = 0; c < 64; ++c) {
+                    const double ang = -kTwoPi * double((q * c) % 1024u) / 1024.0;
+                    p.tw16[(size_t(q) * 64 + c) * 2 + 0] = float(std::cos(ang));
+                    p.tw16[(size_t(q) * 64 + c) * 2 + 1] = float(std::sin(ang));
+                }
+            for (uint32_t l = 0; l < 4; ++l) {
+                const uint32_t m = ((l & 1u) << 1) | (l >> 1);
+                const double sign = l == 0 ? 1.0 : -1.0;
+                for (uint32_t r = 0; r < 16; ++r) {
+                    const double ang = -kTwoPi * double((r * m) % 64u) / 64.0;
+                    p.tw16[(size_t(16 * 64) + size_t(l) * 16 + r) * 2 + 0] = float(sign * std::cos(ang));
+                    p.tw16[(size_t(16 * 64) + size_t(l) * 16 + r) * 2 + 1] = float(sign * std::sin(ang));
+                }
+            }
+            p.twPost16.resize(size_t(1024) * 2);
+            for (uint32_t kb = 0; kb < 1024; ++kb) {
+                const double ang = -kTwoPi * double(kb) / double(p.N);
+                p.twPost16[size_t(kb) * 2 + 0] = float(std::cos(ang));
+                p.twPost16[size_t(kb) * 2 + 1] = float(std::sin(ang));
+            }
         }
     }
     return SGZ_OK;

@@ -94,8 +94,10 @@ struct Plan {
     std::vector<float> twReal1;         // pass-1 twiddles W_{N/2}^{c q}, factorised rows [3 + R1/4 - 1][1024] (re, im)
     uint32_t realFixFrom[2] = {0, 0};   // per side: first pixel whose arg-max run ends on csf[N/2] (the one cross-channel entry); [from, P) are settled late
     std::vector<float> winPhaseT;       // fused whole-frame kernel, same idea: (cos, sin) of 2 pi t / N, t < R^2
+    std::vector<float> windowHalf;      // channel-split path: window / 2 (those kernels transform x w / 2: real_common.hpp realBinMag)
     std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
     std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
+    std::vector<float> tw16, twPost16;  // the 1024-thread form of the N = 32768 channel transform (spectrum_real16.hip): pass-2 / pass-3 twiddles (LDS-staged), W_N^{kb}
     std::vector<float> tw2Full;         // channel-split kernels, N >= 32768: the whole pass-2 table W_1024^{c q}, [q < 32][c < 32] (re, im), staged in LDS
     // Chunk-scan pixel map of the channel-split kernels (chunk_map.hpp, built by buildChunkMap): a side's M magnitudes are cut into
     // T chunks of 32 consecutive entries, one per thread; the arg-max runs of >= 2 entries ("tiles") are segments of a segmented
@@ -118,7 +120,7 @@ struct Plan {
     float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
     // sgz_plan_set_option
-    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false;
+    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = true;
     int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
 
@@ -146,6 +148,7 @@ struct Plan {
     void *hostStream = nullptr;                           // hipStream_t / hipEvent_t (this header is also compiled as plain C++)
     void *hostEv[4] = {nullptr, nullptr, nullptr, nullptr};
     float *d_tw2Full = nullptr;
+    float *d_tw16 = nullptr, *d_twPost16 = nullptr, *d_windowHalf = nullptr;
     float *d_twReal1 = nullptr, *d_twRealPost = nullptr, *d_winPhase = nullptr, *d_winPhaseT = nullptr;
     uint32_t *d_chunkEnds = nullptr, *d_chunkReBase = nullptr, *d_chunkRec = nullptr; float *d_weights12 = nullptr;
     float *d_ny = nullptr, *d_nyBest = nullptr; size_t nyCap = 0;   // channel-split path: what a frame's two channel workgroups leave for realLateKernel

@@ -28,8 +28,7 @@
 // on the whole-frame kernels; plan.cpp decides (Plan::realSplit).
 #include <algorithm>
 
-#include "chunk_map.hpp"
-#include "fft_scalar.hpp"
+#include "real_common.hpp"
 
 #ifdef SGZ_DEBUG
 #define RCLK(slot)                                                                                                     \
@@ -52,38 +51,6 @@
 #endif
 
 namespace sgz {
-
-// csf index -> LDS float index of this side's array: left holds csf[0 .. M], right csf[M .. N], both as entries 0 .. M at chunkPos()
-struct ChannelIndex {
-    int n, off;
-    __device__ __forceinline__ int size() const { return n; }
-    __device__ __forceinline__ int operator()(int k) const { return chunkPos(k - off); }
-    __device__ __forceinline__ bool holds(int k) const { return k >= off && k <= off + n / 2; }
-};
-
-// floats of a side's magnitude array: entries 0 .. M at chunkPos(), then 16 zeroed floats (a tap window is read as kTapFloats
-// contiguous floats from its first entry)
-constexpr int realXFloats(int M) { return (chunkPos(M) + 1 + 16 + 1) & ~1; }
-
-// floats behind the magnitudes that change hands during a workgroup's life: the pass-2 twiddle table (N >= 32768: 32 x 32 float2),
-// later the map's tile maxima (slots + 1) and chunk maxima (T)
-constexpr size_t realExtraFloats(uint32_t maxSlots, uint32_t T, bool tw2InLds)
-{
-    const size_t a = size_t(maxSlots) + 1 + T, b = tw2InLds ? 2048 : 0;
-    return a > b ? a : b;
-}
-
-// |X[k]| of the real-input transform from a = Z[k], b = Z[M - k] and w = W_N^k = (cos, -sin):
-//   2 X = (a + conj b) - i w (a - conj b)
-__device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
-{
-    const float ex = a.x + b.x, ey = a.y - b.y;          // a + conj b
-    const float dx = a.x - b.x, dy = a.y + b.y;          // a - conj b
-    // -i w d = -i (w.x + i w.y)(dx + i dy) = (w.x dy + w.y dx) + i (w.y dy - w.x dx)
-    const float xr = ex + (w.x * dy + w.y * dx);
-    const float xi = ey + (w.y * dy - w.x * dx);
-    return 0.5f * __builtin_amdgcn_sqrtf(xr * xr + xi * xi);
-}
 
 // the R1-point DIFs of a thread's U = R / R1 columns (registers [u R1, (u + 1) R1))
 template <int R, int R1, int U, int LR1, int u = 0>
@@ -150,25 +117,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     constexpr bool MONO = MIX == 1 || MIX == 3;
     constexpr bool mixed = MIX >= 2;                    // the signal is (l +- r) / 2: compile-time, the second channel's loads cost registers
     constexpr int PADSTRIDE = chunkPos(T);              // padded distance between k and k + T
-    constexpr int TILE = R * (R + 1);
+    constexpr int ROW = R + 2, TILE = R * ROW;            // exchange 2: rows of 32 + 2 floats (8-byte aligned rows: the transposed reads are ds_read_b64, free of bank conflicts)
     constexpr int XFLOATS = realXFloats(M);             // this side's |X| array (padded) -- the map's tile and chunk maxima follow it
+    static_assert((T / R) * TILE <= XFLOATS, "the exchange-2 tiles end below the twiddle table");
+    constexpr int TAB = (XFLOATS + 3) & ~3;               // the pass-2 twiddle table (16-byte aligned)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
     const int q1 = half ? (slot == 0 ? R1 / 2 : R1 - slot) : slot;
     const int ix = half ? R - 1 - l : l;                // c_lo in pass 2, q2 in pass 3
 
-    // ---- work list: unit = (frame, pair, channel); XCD-aware order as in stft_body.hpp (a speed assumption only)
-    const long units = prm.frames * long(prm.C) * (MONO ? 1 : 2);
-    long unit = blockIdx.x;
-    if (units >= 64 && prm.roundSize >= 8 && prm.roundSize % 8 == 0) {
-        const long nb = gridDim.x, bid = blockIdx.x;
-        const long base = (bid / prm.roundSize) * prm.roundSize;
-        const long nbr = nb - base < long(prm.roundSize) ? nb - base : long(prm.roundSize);
-        const long x = (bid - base) % 8, i = (bid - base) / 8;
-        const long per = nbr / 8, extra = nbr % 8;
-        unit = base + x * per + (x < extra ? x : extra) + i;
-    }
+    const UnitId uid = unitOf<MONO>(prm);                    // (frame, pair, channel) or (frame, pair); real_common.hpp
+    [[maybe_unused]] const long unit = MONO ? long(uid.task) : long(uid.self);   // (debug clocks)
     // Wave priorities for a launch of two full dispatch generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident
     // per CU).  tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the first frees
     // and the launch ends when IT ends; its workgroups share their CU with second-generation ones that have ~10 us of slack.  Third
@@ -182,12 +142,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             if (generation == 0u) __builtin_amdgcn_s_setprio(2); else if (generation == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
         }
     }
-    const int side = MONO ? 0 : int(unit & 1);
-    long task = MONO ? unit : unit >> 1;                // (frame, pair)
-    if (prm.C > 1) { const long pr = task / prm.frames, fr = task - pr * prm.frames; task = fr * prm.C + pr; }
-    const long frame = task / prm.C;
-    const int pair = int(task - frame * prm.C);
-    const long self = (task << 1) | side;               // ny / low / nyBest slots are indexed by task * 2 + side
+    const int side = uid.side, pair = uid.pair;
+    const long task = uid.task, frame = uid.frame, self = uid.self;
 
     // map tables of this side (chunk_map.hpp)
     const uint32_t maxSlots = prm.chunkSlots[0] > prm.chunkSlots[1] ? prm.chunkSlots[0] : prm.chunkSlots[1];
@@ -212,10 +168,20 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
 
     RCLK(0);
     RTRACE(0);
-    if constexpr (LR1 >= 4) {
-        // the pass-2 twiddle table -> LDS (8 KB behind the exchange areas; the map's maxima take the place later)
-        if (tid < 512) reinterpret_cast<float4 *>(lds + XFLOATS)[tid] = prm.tw2Full[tid];
+    // Every table value this thread needs before the first barrier is REQUESTED here, behind the samples and in front of the first wait:
+    // the window phases, the two fetched pass-1 twiddle rows of every column and this thread's piece of the pass-2 table (which goes to
+    // LDS in front of exchange 1).  Requested where they are used -- as this kernel did until round 5 -- each is a memory round trip of
+    // its own in the workgroup's dependent chain: table -> LDS copy (waited for before the first sample was requested), samples,
+    // second column's phases, first column's twiddles, second column's twiddles.  (N = 16384: 256 threads x four columns at the
+    // 128-register limit: requested where used, as before.)
+    constexpr bool FRONT = LR1 >= 4 && !mixed;               // (the mixed modes hold a second channel's samples on top: they would spill)
+    if constexpr (LR1 >= 4 && !FRONT) {
+        // the pass-2 twiddle table -> LDS (8.5 KB behind the exchange areas; the map's maxima take the place later)
+        for (int i = tid; i < kTw2Floats / 4; i += T) reinterpret_cast<float4 *>(lds + TAB)[i] = prm.tw2Full[i];
     }
+    [[maybe_unused]] float4 phase[U];
+    [[maybe_unused]] float2 twA[U], twB[U];
+    [[maybe_unused]] float4 tw2piece, tw2tail;                  // (T = 512: threads 0 .. 31 carry a second piece of the 544)
     v2 c[R];
     {
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
@@ -231,7 +197,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return T * u + RR * j; };
         const uint32_t lane8 = uint32_t(tid) * 8u;
 #pragma unroll
-        for (int i = 0; i < R; ++i) { const float2 xv = ldg(reinterpret_cast<const float2 *>(X) + elemOf(i), lane8); c[i] = v2{xv.x, xv.y}; }
+        for (int i = 0; i < R; ++i) c[i] = ldgPinned<v2>(X, uint32_t(elemOf(i)) * 8u, lane8);
+        if constexpr (FRONT) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (WCOS) phase[u] = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);
+                twA[u] = ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
+                twB[u] = ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
+            }
+            if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid];
+            if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) tw2tail = prm.tw2Full[T + tid];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (mixed) {
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
@@ -255,7 +232,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const v2 p0 = v2{prm.winP0, prm.winP0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 ph = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
+                const float4 ph = FRONT ? phase[u] : ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
                 const v2 pc = v2{ph.x, ph.y}, ps = v2{ph.z, ph.w};
 #pragma unroll
                 for (int j = 0; j < R1 / 2; ++j) {
@@ -324,8 +301,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // row and workgroup, and what a workgroup fetches costs as much as what it computes)
         auto sq = [](float2 w) { return float2{w.x * w.x - w.y * w.y, 2.f * w.x * w.y}; };
         auto mul = [](float2 p, float2 q) { return float2{p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x}; };
-        a[0] = ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
-        if (NB > 0) b[0] = ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
+        a[0] = FRONT ? twA[u] : ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
+        if (NB > 0) b[0] = FRONT ? twB[u] : ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
         a[1] = sq(a[0]); a[2] = mul(a[1], a[0]);
 #pragma unroll
         for (int i = 1; i < NB; ++i) b[i] = (i & 1) ? sq(b[i / 2]) : mul(b[i - 1], b[0]);
@@ -356,17 +333,25 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         };
         const int rd = q1 * 512 + ix;
         v2 lo[R / 2];
+        if constexpr (FRONT) {
+            // the pass-2 twiddle table -> LDS (8.5 KB behind the exchange areas; the map's maxima take the place later)
+            if (tid < kTw2Floats / 4) reinterpret_cast<float4 *>(lds + TAB)[tid] = tw2piece;
+            if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) reinterpret_cast<float4 *>(lds + TAB)[T + tid] = tw2tail;
+        }
         writeRound(0);
         ldsBarrier();
-#pragma unroll
-        for (int h = 0; h < R / 2; ++h) lo[h] = lds2[rd + R * h];           // c_hi = h
+        const uint32_t rdAddr = ldsAddress(lds2 + rd);
+        ldsReadRun64<16, R * 8>(lo, rdAddr);                              // c_hi = h
+        ldsReadsDone(lo);
         ldsBarrier();
         writeRound(1);
         ldsBarrier();
+        {
+            v2 hi[16];
+            ldsReadRun64<16, R * 8>(hi, rdAddr);                          // c_hi = 16 + h
+            ldsReadsDone(hi);
 #pragma unroll
-        for (int h = 0; h < R / 2; ++h) {
-            c[h + R / 2] = lds2[rd + R * h];                                // c_hi = 16 + h
-            c[h] = lo[h];
+            for (int h = 0; h < R / 2; ++h) { c[h + R / 2] = hi[h]; c[h] = lo[h]; }
         }
     }
     ldsBarrier();                                                        // every wave has read exchange 1: the tiles may overwrite it
@@ -376,9 +361,13 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     if constexpr (LR1 >= 4) {
         // times W_1024^{c_lo q2}: the whole table sits in LDS behind the exchange areas (copied at the start of the kernel) -- one
         // ds_read_b64 and one complex product per value, instead of 10 fetched rows and 21 products to build the other 21
-        const v2 *tab = reinterpret_cast<const v2 *>(lds + XFLOATS) + ix;
+        const float4 *tab = reinterpret_cast<const float4 *>(lds + TAB + ix * kTw2Row);      // this thread's 32 factors, contiguous: 16 ds_read_b128
 #pragma unroll
-        for (int q = 1; q < R; ++q) c[brev(q, LR)] = cmul(c[brev(q, LR)], tab[q * R]);
+        for (int i = 0; i < R / 2; ++i) {
+            const float4 w = tab[i];
+            if (i > 0) c[brev(2 * i, LR)] = cmul(c[brev(2 * i, LR)], v2{w.x, w.y});
+            c[brev(2 * i + 1, LR)] = cmul(c[brev(2 * i + 1, LR)], v2{w.z, w.w});
+        }
     } else {
         TwFactors<LR> tw;
         tw.load(prm.tw2, ix, R);
@@ -388,22 +377,25 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // -------------------------------------------------------------------------- exchange 2: wave-local R x R transposes
     {
         const int tile = group * TILE;
+        const uint32_t rowAddr = ldsAddress(lds + tile + ix * ROW);       // single ds_read_b64s (fft_common.hpp ldsRead64)
 #pragma unroll
-        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].x;
+        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * ROW + ix] = c[brev(q2, LR)].x;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        { v2 t[16]; ldsReadRun64<16, 8>(t, rowAddr); ldsReadsDone(t);
 #pragma unroll
-        for (int j = 0; j < R; ++j) c[j].x = lds[tile + ix * (R + 1) + j];
+          for (int j = 0; j < R / 2; ++j) { c[2 * j].x = t[j].x; c[2 * j + 1].x = t[j].y; } }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * (R + 1) + ix] = c[brev(q2, LR)].y;
+        for (int q2 = 0; q2 < R; ++q2) lds[tile + q2 * ROW + ix] = c[brev(q2, LR)].y;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        { v2 t[16]; ldsReadRun64<16, 8>(t, rowAddr); ldsReadsDone(t);
 #pragma unroll
-        for (int j = 0; j < R; ++j) c[j].y = lds[tile + ix * (R + 1) + j];
+          for (int j = 0; j < R / 2; ++j) { c[2 * j].y = t[j].x; c[2 * j + 1].y = t[j].y; } }
     }
     RCLK(4);
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
@@ -419,7 +411,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             lds[SCRATCH + 2 * m3 + 1] = c[brev(m3, LR)].y;
         }
         // this channel's Nyquist bin X[M] = Re Z[0] - Im Z[0]: csf[N/2] needs both channels' (realLateKernel)
-        if (!MONO) prm.ny[self] = c[0].x - c[0].y;
+        if (!MONO) prm.ny[self] = 2.f * (c[0].x - c[0].y);                  // (the transform runs on x w / 2)
     }
     // Column 0 (k = T m3, all in thread 0) pairs m3 with R - m3 inside one thread and holds DC / Nyquist: lanes 0 .. R/2 of wave 0 redo it
     // from thread 0's scratch copy right away (the scratch is not part of the tiles), keep the values and store them after the
@@ -437,8 +429,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             fixA = realBinMag(a, b, v2{cs, -sn});
             fixB = realBinMag(b, a, v2{-cs, -sn});                          // W_{2R}^{R - m3} = (-cos, -sin)
         } else {
-            fixA = 0.5f * (lds[SCRATCH] + lds[SCRATCH + 1]);                // csf[0] = Re(csf[0]) * 0.5 / csf[N] = Im(csf[0]) * 0.5 (:861-862): X_c[0] / 2, signed
-            if (MONO) { fixA = __builtin_fabsf(fixA); fixB = 0.5f * (lds[SCRATCH] - lds[SCRATCH + 1]); }   // |X[0]| / 2 and X[N/2] / 2 (:547-552)
+            fixA = lds[SCRATCH] + lds[SCRATCH + 1];                         // csf[0] = Re(csf[0]) * 0.5 / csf[N] = Im(csf[0]) * 0.5 (:861-862): X_c[0] / 2, signed (the 1/2 came in with the window)
+            if (MONO) { fixA = __builtin_fabsf(fixA); fixB = lds[SCRATCH] - lds[SCRATCH + 1]; }   // |X[0]| / 2 and X[N/2] / 2 (:547-552)
         }
     }
     // ---- recombination.  a = Z[k] (own register m3 < R/2), b = Z[M - k] (lane L ^ R, register R-1-m3):
@@ -475,13 +467,13 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             sq = re2 * re2;
             asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(sq) : "v"(im2), "v"(sq));
             const float pr = re2.x, mr = re2.y, pi = im2.x, mi = im2.y;
-            magA[m3] = 0.5f * __builtin_amdgcn_sqrtf(sq.x);
-            magB[m3] = 0.5f * __builtin_amdgcn_sqrtf(sq.y);
+            magA[m3] = __builtin_amdgcn_sqrtf(sq.x);                       // (|2 X| / 2: the 1/2 came in with the window)
+            magB[m3] = __builtin_amdgcn_sqrtf(sq.y);
             if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
                 // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
                 // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
-                spec[2 * (8 - kc)] = 0.5f * pr; spec[2 * (8 - kc) + 1] = -0.5f * pi;
-                if (kc < 8) { spec[2 * (8 + kc)] = 0.5f * mr; spec[2 * (8 + kc) + 1] = 0.5f * mi; }
+                spec[2 * (8 - kc)] = pr; spec[2 * (8 - kc) + 1] = -pi;
+                if (kc < 8) { spec[2 * (8 + kc)] = mr; spec[2 * (8 + kc) + 1] = mi; }
             }
         }
     }
@@ -633,23 +625,13 @@ hipError_t launchFinishPixel(const float *x, float *y, size_t n, hipStream_t str
     return hipGetLastError();
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
-static hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64])
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && granted[dev] >= need) return hipSuccess;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(need));
-    if (e == hipSuccess && dev >= 0 && dev < 64) granted[dev] = need;
-    return e;
-}
-
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
 {
     const bool mono = prm.mode != SGZ_CH_SEPARATE && prm.mode != SGZ_CH_MIDSIDE;
     const long units = prm.frames * long(prm.C) * (mono ? 1 : 2);
     if (units <= 0) return hipSuccess;
+    // N = 32768, pairs: the 1024-thread form (spectrum_real16.hip) unless the plan switched it off or its LDS layout does not fit
+    if (N == 32768 && !mono && prm.tw16 && real16LdsBytes(std::max(prm.chunkSlots[0], prm.chunkSlots[1])) <= 80 * 1024) return launchStftReal16(prm, stream);
     const uint32_t M = N / 2, T = M / 32;
     const uint32_t maxSlots = std::max(prm.chunkSlots[0], prm.chunkSlots[1]);
     // magnitudes, then the map's tile / chunk maxima (the same floats hold column 0's scratch during the recombination), then (mono) the complex entries

@@ -36,9 +36,11 @@ def main():
         sr = int(cfg["sample_rate"])
         S = int(config.CFG2_SECONDS * 48000) if name != "cfg5_20s" else 20 * sr
         x = torch.from_numpy(synth.gen(2, sr, S, 2 * pairs)).cuda()
+        if os.environ.get('SGZ_ZERO_INPUT') == '1': x.zero_()      # (clock experiment: no toggling in the data path)
         plan = api.Plan(cfg)
         if os.environ.get('SGZ_WHOLE_FRAME') == '1': plan.set_option(api.OPT_CHANNEL_SPLIT, 0)
         if os.environ.get('SGZ_FETCH_WINDOW') == '1': plan.set_option(3, 1)
+        if os.environ.get('SGZ_NARROW') == '1': plan.set_option(api.OPT_WIDE_GROUPS, 0)     # the 512-thread form at N = 32768
         plan.upload()
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")
