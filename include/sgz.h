@@ -181,8 +181,9 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
                                       slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one
                                       before it left */
-#define SGZ_OPT_WIDE_GROUPS 6u       /* N = 32768 channel-split plans (pairs): 1 (default): one 1024-thread workgroup per (frame, pair, channel), sixteen
-                                      values per thread (spectrum_real16.hip); 0: the 512-thread, 32-values-per-thread form (spectrum_real.hip) */
+#define SGZ_OPT_WIDE_GROUPS 6u       /* N = 32768 channel-split plans (pairs): 0 (default): one 512-thread workgroup per (frame, pair, channel), 32 values
+                                      per thread (spectrum_real.hip); 1: 1024 threads of sixteen values (spectrum_real16.hip: 8 waves per SIMD; measured
+                                      7-12 % slower on MI355X -- NOTES.md round 5 -- and kept as a tested alternative) */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

@@ -120,7 +120,7 @@ struct Plan {
     float resWeights[9] = {0};          // [V]
     DeviceScalars scalars{};
     // sgz_plan_set_option
-    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = true;
+    bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = false;
     int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
 

@@ -468,17 +468,22 @@ def test_unsupported_and_errors(gpu):
     (32768, 48000.0, 1, 4, dict(view_scaling=0, bin_interp=1)), (65536, 96000.0, 1, 3, dict(view_scaling=0)),
     # MidSide: the same two workgroups on (l + r) / 2 and (l - r) / 2
     (32768, 48000.0, 2, 5, dict(channel_mode=config.CH_MIDSIDE)), (65536, 96000.0, 1, 3, dict(channel_mode=config.CH_MIDSIDE)),
-    (16384, 48000.0, 1, 7, dict(channel_mode=config.CH_MIDSIDE))])
+    (16384, 48000.0, 1, 7, dict(channel_mode=config.CH_MIDSIDE)),
+    # the 1024-thread form of the N = 32768 kernel (spectrum_real16.hip; plan option SGZ_OPT_WIDE_GROUPS)
+    (32768, 48000.0, 1, 5, dict(wide=1)), (32768, 48000.0, 3, 4, dict(wide=1)), (32768, 48000.0, 2, 4, dict(view_scaling=0, wide=1)),
+    (32768, 48000.0, 2, 5, dict(channel_mode=config.CH_MIDSIDE, wide=1)), (32768, 44100.0, 1, 4, dict(window_type=config.WIN_BLACKMAN_HARRIS, wide=1))])
 def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr, pairs, frames, over):
     """spectrum_real.hip (one workgroup per (frame, pair, channel), real-input FFT; the default at N = 16384 and 65536, forced here at
     N = 32768 too) through the parity chain, and bin for bin against the whole-frame kernels: same csf within the FFT tolerance -- including
     csf[0], csf[N], csf[N/2 - 1] (quirk Q3) and csf[N/2], the one entry that needs both channels and is settled by whichever
     workgroup finishes second -- and identical pixels given identical bins."""
     from parity_chain import check_render
+    over = dict(over)
+    wide = over.pop("wide", 0)
     cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, num_pairs=pairs, **over)
     S = N + (frames - 1) * (N // 4)
     x = synth.gen(23, int(sr), S, 2 * pairs)
-    split = api.Plan(cfg).upload()
+    split = api.Plan(cfg).set_option(api.OPT_WIDE_GROUPS, wide).upload()
     whole = api.Plan(cfg).set_option(api.OPT_CHANNEL_SPLIT, 0).upload()
     assert split.path & 8 and not whole.path & 8
     xg = _planar_cuda(x, gpu)
@@ -504,7 +509,11 @@ def test_channel_split_kernel_against_the_oracle(gpu, oracle, monkeypatch, N, sr
     # a linear view from 0 Hz: the first pixels' tap windows reach over bin 0 into the other channel's bins (realLateKernel's low pixels)
     (32768, 48000.0, dict(view_scaling=config.VIEW_LINEAR, view_left=0.0, view_right=0.02, axis_points=777)),
     (16384, 48000.0, dict(bin_interp=config.INTERP_NONE, axis_points=2500)),       # more pixels than two per thread: the map's further rounds
-    (65536, 96000.0, dict(axis_points=300, min_log_freq=40.0))])                   # long runs: many chunks per pixel
+    (65536, 96000.0, dict(axis_points=300, min_log_freq=40.0)),                    # long runs: many chunks per pixel
+    # the 1024-thread form's map (two lanes per row of 32 magnitudes: spectrum_real16.hip ChunkMap16)
+    (32768, 48000.0, dict(wide=1)), (32768, 48000.0, dict(channel_mode=config.CH_MIDSIDE, bin_interp=config.INTERP_LINEAR, wide=1)),
+    (32768, 48000.0, dict(view_scaling=config.VIEW_LINEAR, view_left=0.0, view_right=0.02, axis_points=777, wide=1)),
+    (32768, 48000.0, dict(bin_interp=config.INTERP_NONE, axis_points=2500, wide=1)), (32768, 48000.0, dict(axis_points=300, min_log_freq=40.0, wide=1))])
 def test_channel_split_mapping_bit_exact_given_bins(gpu, oracle, monkeypatch, N, sr, over):
     """Chain link 2 on the kernels the bench runs: sgz_stage_map_from_bins on a channel-split plan feeds the oracle's csf magnitudes to
     realMapFromBinsKernel -- the chunk-scan map, the late-pixel bookkeeping and realLateKernel are the very functions stftRealKernel
@@ -512,13 +521,15 @@ def test_channel_split_mapping_bit_exact_given_bins(gpu, oracle, monkeypatch, N,
     the pixels whose taps reach over bin 0, must equal the oracle's mapToLinearSpace (TransformDSP.inl:871-985) bit for bit."""
     import torch
     po = oracle
+    over = dict(over)
+    wide = over.pop("wide", 0)
     cfg = config.spectrum_config(sample_rate=sr, window_size=N, hop=N // 4, **over)
     p = po.params_from_dict(cfg)
     frames = 3
     x = synth.gen(23, int(sr), N + (frames - 1) * (N // 4), 2)
     x[0, 1::2] -= 0.4                                   # energy at Nyquist in the left channel: csf[N/2] wins the top pixels
     x[0, 0::2] += 0.4
-    plan = api.Plan(cfg).upload()
+    plan = api.Plan(cfg).set_option(api.OPT_WIDE_GROUPS, wide).upload()
     assert plan.path & 8
     csfs = np.zeros((frames, 1, plan.N + 1), np.float32)
     want = np.zeros((frames, 1, 2, plan.P), np.float32)

@@ -147,6 +147,35 @@ def test_KA9_hsb_rotation_properties(oracle):
     assert worst <= 2.0          # integer rounding at three places
 
 
+def test_KA9_hsb_rotation_equals_the_compiled_reference(oracle):
+    """The one link of the chain that is pinned to the reference itself (container-only): juce::Colour::withRotatedHue compiled from
+    the sources under /root/reference (oracle/ref_juce_colour.cpp -> oracle/_ref/, oracle/pyref.py) against the oracle's restatement
+    (primitives.c) and the product's host function (plan.cpp rotateHueRgb8) over 200 000 random colours and rotation amounts, plus
+    ColourRotation::operator[]'s own amounts index / size for 1 .. 16 pairs.  Skipped where the reference is not present (the GPU
+    box): there tests/test_golden.py holds both to the committed vectors this library generated."""
+    from oracle import pyref
+    if not pyref.available():
+        pytest.skip("the reference's sources are not in this environment (oracle/_ref is container-only)")
+    from signalizer_amd import api
+    po = oracle
+    L, O, A = pyref.lib(), po.lib(), api.lib()
+    import ctypes as C
+    rng = np.random.default_rng(2026)
+    n = 200000
+    cols = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    amt = rng.random(n).astype(np.float32)
+    amt[: 16 * 17 // 2] = [np.float32(i) / np.float32(p) for p in range(1, 17) for i in range(p)]        # index / size as ColourRotation computes it
+    ref, got_o, got_p = np.zeros((n, 3), np.uint8), np.zeros((n, 3), np.uint8), np.zeros((n, 3), np.uint8)
+    vp = C.c_void_p
+    for i in range(n):
+        a = C.c_float(float(amt[i]))
+        L.sgzref_rotate_hue_rgb8(vp(cols[i].ctypes.data), a, vp(ref[i].ctypes.data))
+        O.sgzo_rotate_hue_rgb8(vp(cols[i].ctypes.data), a, vp(got_o[i].ctypes.data))
+        A.sgz_rotate_hue_rgb8(vp(cols[i].ctypes.data), a, vp(got_p[i].ctypes.data))
+    assert np.array_equal(got_o, ref), int((got_o != ref).any(axis=1).sum())
+    assert np.array_equal(got_p, ref), int((got_p != ref).any(axis=1).sum())
+
+
 def test_KA10_lanczos_kernel(oracle):
     po = oracle
     L = po.lib()

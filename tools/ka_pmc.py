@@ -10,7 +10,7 @@ cfg = config.cfg2(); cfg["num_pairs"] = pairs
 S = int(config.CFG2_SECONDS * 48000)
 x = torch.from_numpy(synth.gen(2, 48000, S, 2 * pairs)).cuda()
 plan = api.Plan(cfg)
-if os.environ.get("SGZ_NARROW") == "1": plan.set_option(api.OPT_WIDE_GROUPS, 0)
+if os.environ.get("SGZ_WIDE") == "1": plan.set_option(api.OPT_WIDE_GROUPS, 1)
 plan.upload()
 F = plan.num_frames(S)
 mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")

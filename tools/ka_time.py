@@ -40,7 +40,7 @@ def main():
         plan = api.Plan(cfg)
         if os.environ.get('SGZ_WHOLE_FRAME') == '1': plan.set_option(api.OPT_CHANNEL_SPLIT, 0)
         if os.environ.get('SGZ_FETCH_WINDOW') == '1': plan.set_option(3, 1)
-        if os.environ.get('SGZ_NARROW') == '1': plan.set_option(api.OPT_WIDE_GROUPS, 0)     # the 512-thread form at N = 32768
+        if os.environ.get('SGZ_WIDE') == '1': plan.set_option(api.OPT_WIDE_GROUPS, 1)     # the 1024-thread form at N = 32768
         plan.upload()
         F = plan.num_frames(S)
         mapped = torch.empty((F, pairs, 2, plan.P), dtype=torch.float32, device="cuda")

@@ -2,7 +2,8 @@
 
 The reference ships no tests or golden vectors and cannot be built here, so these
 fixtures pin the oracle itself (against silent regressions) and give the GPU tests a data-only target
-that travels to the GPU box.  Inputs are re-synthesised from seeds (signalizer_amd.synth), only
+that travels to the GPU box.  Exception: hsb_table.npz and colour_tables.npz come from the reference's own
+juce::Colour::withRotatedHue, compiled from /root/reference (oracle/ref_juce_colour.cpp).  Inputs are re-synthesised from seeds (signalizer_amd.synth), only
 parameters and expected outputs are stored.  Run:  python tools/make_golden.py
 """
 import os
@@ -62,8 +63,25 @@ def main():
     cols = rng.integers(0, 256, (4096, 3)).astype(np.uint8)
     cols[:8] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128], [0, 128, 255], [255, 64, 0]]
     amt = rng.choice(np.array([0.0, 0.25, 0.5, 1.0 / 3.0, 1.0 / 32.0, 0.75], np.float32), 4096).astype(np.float32)
-    outc = np.stack([po.rotate_hue(cols[i], float(amt[i])) for i in range(4096)])
-    np.savez_compressed(os.path.join(OUT, "hsb_table.npz"), rgb=cols, amount=amt, rotated=outc)
+    # ... from the REFERENCE ITSELF: juce::Colour::withRotatedHue compiled from /root/reference (oracle/ref_juce_colour.cpp, oracle/pyref.py).
+    # The one fixture family in this directory that does not come from the oracle: it pins the oracle's and the product's HSB round trip.
+    from oracle import pyref
+    if not pyref.available():
+        raise SystemExit("tools/make_golden.py needs /root/reference for the colour fixtures (oracle/_ref)")
+    outc = np.stack([pyref.rotate_hue(cols[i], float(amt[i])) for i in range(4096)])
+    np.savez_compressed(os.path.join(OUT, "hsb_table.npz"), rgb=cols, amount=amt, rotated=outc, source="juce::Colour::withRotatedHue, compiled reference")
+    # generateSpectrogramColourRotation(p) for 1 .. 16 pairs through ColourRotation::operator[]'s float index / size
+    # (TransformConstant.h:55-65, CommonSignalizer.h:931-937, Spectrum.cpp:398-402), the default colours and a random set
+    sets = {"default": np.array(config.spectrum_config()["colours"], np.uint8), "random": rng.integers(0, 256, (6, 3)).astype(np.uint8)}
+    tables = {}
+    for name, base in sets.items():
+        t = np.zeros((16, 16, 6, 3), np.uint8)                                   # [pairs - 1][rotation][stop][rgb]
+        for pairs in range(1, 17):
+            for rot in range(pairs):
+                t[pairs - 1, rot] = pyref.spectrogram_colours(base, pairs, rot)
+        tables["base_" + name] = base
+        tables["table_" + name] = t
+    np.savez_compressed(os.path.join(OUT, "colour_tables.npz"), **tables)
     # zero-crossing triggers (KA11)
     sig = synth.gen(3, 192000, 48000, 2)
     st = po.ZeroCrossingState(state=0.0, threshold=0.05, steady_clock=0, cross_origin=0, count=0, armed=0)

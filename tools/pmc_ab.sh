@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters + timing of K_A for several builds on one box: tools/pmc_ab.sh <tag> <lib.so> [<lib.so> ...]   (SGZ_NARROW=1: the 512-thread form)
+# counters + timing of K_A for several builds on one box: tools/pmc_ab.sh <tag> <lib.so> [<lib.so> ...]   (SGZ_WIDE=1: the 1024-thread form)
 TAG=$1; shift
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
