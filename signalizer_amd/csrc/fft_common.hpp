@@ -175,6 +175,20 @@ __device__ __forceinline__ float ldsRead32(uint32_t addr)
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
+template <int OFF>
+__device__ __forceinline__ void ldsWrite64(uint32_t addr, v2 v)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+typedef float v4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void ldsWrite128(uint32_t addr, v2 lo, v2 hi)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    const v4 v = v4{lo.x, lo.y, hi.x, hi.y};
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void ldsReadsDone(v2 (&t)[16])
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -185,6 +199,22 @@ template <int N, int STRIDE, int I = 0>
 __device__ __forceinline__ void ldsReadRun64(v2 (&t)[16], uint32_t addr)
 {
     if constexpr (I < N) { t[I] = ldsRead64<I * STRIDE>(addr); ldsReadRun64<N, STRIDE, I + 1>(t, addr); }
+}
+
+// Four (re, im) pairs <- the same registers of lane L ^ 32, on the vector ALUs: v_permlane32_swap_b32 vdst, src exchanges vdst's upper
+// half-wave with src's lower one; swap(x, y) then swap(y, x) leaves x's halves exchanged in y and y's in x.  The leading s_nop covers the
+// two wait states a swap needs behind a vector write of its operands (inline assembly is invisible to the hazard recogniser); a pair's
+// second swap follows its first at a distance of four.  (The builtin form -- r1 = __builtin_amdgcn_permlane32_swap(x, y, ..); r2 =
+// ..swap(r1[1], r1[0], ..) -- is miscompiled by ROCm 7.2's hipcc, which copies y over x in front of the first swap:
+// tools/ubench/permswap.hip.)
+__device__ __forceinline__ void halfWaveExchange4(v2 &a, v2 &b, v2 &c, v2 &d)
+{
+    float x0 = a.x, y0 = a.y, x1 = b.x, y1 = b.y, x2 = c.x, y2 = c.y, x3 = d.x, y3 = d.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
+                 "v_permlane32_swap_b32 %1, %0\n\tv_permlane32_swap_b32 %3, %2\n\tv_permlane32_swap_b32 %5, %4\n\tv_permlane32_swap_b32 %7, %6"
+                 : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3));
+    a = v2{y0, x0}; b = v2{y1, x1}; c = v2{y2, x2}; d = v2{y3, x3};           // (the pairs come out crossed)
 }
 
 // An opaque copy of a per-thread constant: address arithmetic derived from it cannot be hoisted out of the frame

@@ -52,6 +52,20 @@
 
 namespace sgz {
 
+// exchange 1's stores of one column as single ds_write_b64 (fft_common.hpp ldsWrite64)
+template <int R1, int LR1, int BASE, int Q = 0>
+__device__ __forceinline__ void e1WriteRun(uint32_t wa, const v2 (&c)[32])
+{
+    if constexpr (Q < R1) { ldsWrite64<(Q & 15) * 512 * 8>(wa + uint32_t(Q >> 4) * 65536u, c[BASE + brev(Q, LR1)]); e1WriteRun<R1, LR1, BASE, Q + 1>(wa, c); }
+}
+
+// ... of two neighbouring columns (registers [0, R1) and [R1, 2 R1)) as one ds_write_b128 per row
+template <int R1, int LR1, int Q = 0>
+__device__ __forceinline__ void e1WritePairRun(uint32_t wa, const v2 (&c)[32])
+{
+    if constexpr (Q < R1) { ldsWrite128<(Q & 15) * 512 * 8>(wa + uint32_t(Q >> 4) * 65536u, c[brev(Q, LR1)], c[R1 + brev(Q, LR1)]); e1WritePairRun<R1, LR1, Q + 1>(wa, c); }
+}
+
 // the R1-point DIFs of a thread's U = R / R1 columns (registers [u R1, (u + 1) R1))
 template <int R, int R1, int U, int LR1, int u = 0>
 __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
@@ -174,7 +188,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // its own in the workgroup's dependent chain: table -> LDS copy (waited for before the first sample was requested), samples,
     // second column's phases, first column's twiddles, second column's twiddles.  (N = 16384: 256 threads x four columns at the
     // 128-register limit: requested where used, as before.)
-    constexpr bool FRONT = LR1 >= 4 && !mixed;               // (the mixed modes hold a second channel's samples on top: they would spill)
+    constexpr bool PAIRED = U == 2;                          // thread -> columns 2 tid, 2 tid + 1 (otherwise tid + T u): see the sample loads
+    constexpr int COLSTEP = PAIRED ? 1 : T, COLLANE = PAIRED ? 2 : 1;     // column of (tid, u) = COLLANE tid + COLSTEP u
+    constexpr bool FRONT = LR1 >= 4 && !mixed && WCOS;       // (the mixed modes and a fetched window hold more values in flight: they would spill)
     if constexpr (LR1 >= 4 && !FRONT) {
         // the pass-2 twiddle table -> LDS (8.5 KB behind the exchange areas; the map's maxima take the place later)
         for (int i = tid; i < kTw2Floats / 4; i += T) reinterpret_cast<float4 *>(lds + TAB)[i] = prm.tw2Full[i];
@@ -194,16 +210,25 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
         // (element = compile-time part + tid.  Pinning the compile-time part to scalar base registers -- `global_load v, v_lane, s[base]`, no
         // vector address arithmetic per load -- was measured on one box against this form: cfg2 -1 %, cfg5 +1.3 %: not kept)
-        auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return T * u + RR * j; };
-        const uint32_t lane8 = uint32_t(tid) * 8u;
+        // PAIRED (two columns per thread, N = 32768): the thread owns the NEIGHBOURING columns 2 tid and 2 tid + 1, so that a sample request is
+        // 16 bytes per lane (global_load_dwordx4: 1 KB per wave-instruction) -- the per-CU fetch path serves 8-byte requests at 0.54-0.70 of
+        // its 16-byte rate (MI355X_MICROARCH.md), and the samples' arrival is the longest phase of a workgroup's life (tools/phase_clocks.py)
+        auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return (PAIRED ? u : T * u) + RR * j; };
+        const uint32_t lane8 = uint32_t(tid) * (PAIRED ? 16u : 8u);
+        if constexpr (PAIRED) {
+            typedef float v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < R; ++i) c[i] = ldgPinned<v2>(X, uint32_t(elemOf(i)) * 8u, lane8);
+            for (int j = 0; j < R1; ++j) { const v4 xv = ldgPinned<v4>(X, uint32_t(RR * j) * 8u, lane8); c[j] = v2{xv.x, xv.y}; c[R1 + j] = v2{xv.z, xv.w}; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) c[i] = ldgPinned<v2>(X, uint32_t(elemOf(i)) * 8u, lane8);
+        }
         if constexpr (FRONT) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (WCOS) phase[u] = ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);
-                twA[u] = ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
-                twB[u] = ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
+                if (WCOS) phase[u] = ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);
+                twA[u] = ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
+                twB[u] = ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
             }
             if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid];
             if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) tw2tail = prm.tw2Full[T + tid];
@@ -213,7 +238,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
             const float sgn = (MONO ? prm.mode == SGZ_CH_SIDE : side == 1) ? -1.f : 1.f;
-            constexpr int YB = LR1 == 5 ? 4 : 8;        // 1024 threads: 128 registers, 64 of them hold the left channel
+            constexpr int YB = (LR1 == 5 || (PAIRED && !WCOS)) ? 4 : 8;        // 1024 threads: 128 registers, 64 of them hold the left channel
 #pragma unroll
             for (int b0 = 0; b0 < R; b0 += YB) {
                 float2 y[YB];
@@ -232,7 +257,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const v2 p0 = v2{prm.winP0, prm.winP0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 ph = FRONT ? phase[u] : ldg(prm.winPhase + T * u, uint32_t(tid) * 16u);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
+                const float4 ph = FRONT ? phase[u] : ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
                 const v2 pc = v2{ph.x, ph.y}, ps = v2{ph.z, ph.w};
 #pragma unroll
                 for (int j = 0; j < R1 / 2; ++j) {
@@ -296,13 +321,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     for (int u = 0; u < U; ++u) {
         constexpr int NB = R1 / 4 - 1;
         float2 a[3], b[NB];
-        const int col = tid + T * u;
         // W^c and W^{4c} from the table, the other rows as their powers (two loads per column instead of 3 + NB: the table is 8 KB per
         // row and workgroup, and what a workgroup fetches costs as much as what it computes)
         auto sq = [](float2 w) { return float2{w.x * w.x - w.y * w.y, 2.f * w.x * w.y}; };
         auto mul = [](float2 p, float2 q) { return float2{p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x}; };
-        a[0] = FRONT ? twA[u] : ldg(prm.tw1 + (T * u), uint32_t(tid) * 8u);
-        if (NB > 0) b[0] = FRONT ? twB[u] : ldg(prm.tw1 + (T * u + 3 * RR), uint32_t(tid) * 8u);
+        a[0] = FRONT ? twA[u] : ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
+        if (NB > 0) b[0] = FRONT ? twB[u] : ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
         a[1] = sq(a[0]); a[2] = mul(a[1], a[0]);
 #pragma unroll
         for (int i = 1; i < NB; ++i) b[i] = (i & 1) ? sq(b[i / 2]) : mul(b[i - 1], b[0]);
@@ -322,12 +346,26 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     {
         v2 *lds2 = reinterpret_cast<v2 *>(lds);
         auto writeRound = [&](int r) {
+            if constexpr (PAIRED) {
+                // columns 2 tid, 2 tid + 1: waves 0 .. 3 own round 0, waves 4 .. 7 round 1; sixteen ds_write_b128 (wide stores reach the LDS's
+                // store rate from one wave per SIMD, ds_write_b64 needs four: MI355X_MICROARCH.md)
+                if ((tid >> 8) == r) e1WritePairRun<R1, LR1>(ldsAddress(lds2 + ((2 * tid) & 511)), c);
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int col = tid + T * u;
+                const int col = COLLANE * tid + COLSTEP * u;
                 if ((col >> 9) == r) {
+#ifndef SGZ_E1_PAIRED_WRITES   // single ds_write_b64 (hipcc pairs them into ds_write2st64_b64 otherwise: measured 0.5 % slower)
+                    const uint32_t wa = ldsAddress(lds2 + (col & 511));
+                    if (u == 0) e1WriteRun<R1, LR1, 0>(wa, c);
+                    else if (u == 1) e1WriteRun<R1, LR1, (U > 1 ? R1 : 0)>(wa, c);
+                    else if (u == 2) e1WriteRun<R1, LR1, (U > 2 ? 2 * R1 : 0)>(wa, c);
+                    else e1WriteRun<R1, LR1, (U > 3 ? 3 * R1 : 0)>(wa, c);
+#else
 #pragma unroll
                     for (int q = 0; q < R1; ++q) lds2[q * 512 + (col & 511)] = c[u * R1 + brev(q, LR1)];
+#endif
                 }
             }
         };
@@ -448,11 +486,26 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         auto partnerOf = [&](float v) {
             return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plane, __builtin_bit_cast(int, v)));
         };
+        // The upper registers are only read by the partner lane: they are exchanged in place.  Slots >= 1: the partner is lane L ^ 32, two
+        // v_permlane32_swap_b32 per value on the vector ALUs (fft_common.hpp halfWaveExchange4), no LDS crossbar.  Slot 0 (q1 = 0 and R1/2)
+        // pairs lanes inside each half: ds_bpermute.
+#ifdef SGZ_MIRROR_BPERMUTE
+        if (true) {
+#else
+        if (slot == 0) {
+#endif
+#pragma unroll
+            for (int m3 = 0; m3 < R / 2; ++m3) { const int ip = brev(R - 1 - m3, LR); c[ip] = v2{partnerOf(c[ip].x), partnerOf(c[ip].y)}; }
+        } else {
+#pragma unroll
+            for (int m3 = 0; m3 < R / 2; m3 += 4)
+                halfWaveExchange4(c[brev(R - 1 - m3, LR)], c[brev(R - 2 - m3, LR)], c[brev(R - 3 - m3, LR)], c[brev(R - 4 - m3, LR)]);
+        }
 #pragma unroll
         for (int m3 = 0; m3 < R / 2; ++m3) {
             const int i = brev(m3, LR), ip = brev(R - 1 - m3, LR);
             const v2 a = c[i];
-            const v2 b = v2{partnerOf(c[ip].x), partnerOf(c[ip].y)};
+            const v2 b = c[ip];
             const v2 w = m3 == 0 ? v2{wk.x, wk.y} : cmulConjK(v2{wk.x, wk.y}, v2{cos64(m3), sin64(m3)});
             // on (re, im) pairs: E = a + conj b, D = a - conj b, O = -i w D = (w.x D.y + w.y D.x, w.y D.y - w.x D.x); then the real parts
             // (E.x + O.x, E.x - O.x) of 2 X[k], 2 X[M - k] in one pair and the imaginary parts (E.y + O.y, E.y - O.y) in another: both
