@@ -50,7 +50,8 @@ struct ChunkTables {
 template <int T>
 struct ChunkMap {
     static constexpr int RB = 2;                                        // pixels per thread in the first round (records stay in registers across the barrier)
-    PixelRec rec[RB];
+    // Everything the map needs per pixel is in the two words of its ChunkRec (plan.hpp); the PixelRec -- 16 more bytes per pixel and
+    // workgroup through the CU's fetch path -- is only read by the literal replay of a run without a normal square.
     uint2 cr[RB];
     uint32_t slotBase, endBits;
 
@@ -61,10 +62,10 @@ struct ChunkMap {
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const int x = tid + b * T;
-            rec[b] = x < tb.P ? tb.recs[x] : PixelRec{2, 0, 0, 0};
-            cr[b] = x < tb.P ? tb.crec[x] : uint2{0u, 0u};
+            cr[b] = x < tb.P ? tb.crec[x] : uint2{0u, kChunkOff};
         }
     }
+    static __device__ __forceinline__ bool interpolated(const uint2 c) { return (c.y & kChunkInterp) != 0u; }
 
     // <= 10 taps as kTapFloats contiguous floats, accumulated in tap order; entries that are not taps carry weight +0 and read a finite
     // value -- a zeroed pad slot or a neighbouring bin -- so they add +-0 to a sum that is never -0: the same sum bit for bit
@@ -84,10 +85,10 @@ struct ChunkMap {
 
     template <typename Index>
     static __device__ __forceinline__ void resolve(const ChunkTables &tb, const Index at, const float *lds, const float *re, const float *ce,
-                                                   float invSize, const PixelRec &r, const uint2 c, int x)
+                                                   float invSize, const uint2 c, int x)
     {
 #pragma clang fp contract(off)
-        if (!(r.kind & 1)) return;
+        if (c.y & (kChunkInterp | kChunkOff)) return;
         float best = 0.f;
         if (c.y & kChunkDirect) best = __builtin_fabsf(lds[c.x]);
         else if (!(c.y & kChunkNoScan)) {
@@ -100,6 +101,7 @@ struct ChunkMap {
         if (!(best >= 0x1p-62f)) {
             // the run's squares are denormal, zero or NaN: distinct values can tie there -- the reference's scan, literally
             // (first strictly greater square in offset order; initial arg = bin, :953)
+            const PixelRec r = tb.recs[x];
             const int N = at.size();
             int arg = r.c;
             bestSq = 0.f;
@@ -123,11 +125,16 @@ struct ChunkMap {
     {
         // ---- tap weights of the first round's pixels (unconditional, independent loads -- an arg-max pixel reads row 0; they are
         // consumed behind the scan, which hides their latency)
+        // (a wave none of whose lanes interpolates -- the upper pixels of a log view -- neither fetches weights nor runs the taps)
         float4 wq[RB][3];
+        bool anyInterp[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(rec[b].kind == 0 ? cr[b].x : 0u) * kTapFloats);
-            wq[b][0] = wp[0]; wq[b][1] = wp[1]; wq[b][2] = wp[2];
+            anyInterp[b] = __builtin_amdgcn_ballot_w64(interpolated(cr[b])) != 0ull;
+            if (anyInterp[b]) {
+                const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(interpolated(cr[b]) ? cr[b].x : 0u) * kTapFloats);
+                wq[b][0] = wp[0]; wq[b][1] = wp[1]; wq[b][2] = wp[2];
+            }
         }
         // ---- this thread's chunk
         float v[32];
@@ -160,8 +167,10 @@ struct ChunkMap {
         // ---- interpolated pixels of the first round
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-            const float acc = taps(lds, rec[b].kind == 0 ? cr[b].y : 0u, wq[b]);
-            if (rec[b].kind == 0 && tb.out) tb.out[tid + b * T] = finishPixel<5>(invSize * acc);
+            if (anyInterp[b]) {
+                const float acc = taps(lds, interpolated(cr[b]) ? (cr[b].y & 0xFFFFu) : 0u, wq[b]);
+                if (interpolated(cr[b]) && tb.out) tb.out[tid + b * T] = finishPixel<5>(invSize * acc);
+            }
         }
         SGZ_MAPCLK(11);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the tile stores above are invisible to the compiler's counters
@@ -169,20 +178,19 @@ struct ChunkMap {
         SGZ_MAPCLK(12);
         // ---- one thread per arg-max pixel
 #pragma unroll
-        for (int b = 0; b < RB; ++b) resolve(tb, at, lds, re, ce, invSize, rec[b], cr[b], tid + b * T);
+        for (int b = 0; b < RB; ++b) resolve(tb, at, lds, re, ce, invSize, cr[b], tid + b * T);
         // ---- further rounds (more than RB T pixels per side)
         for (int base = RB * T; base < tb.P; base += T) {
             const int x = base + tid;
             if (x < tb.P) {
-                const PixelRec r = tb.recs[x];
                 const uint2 c = tb.crec[x];
-                if (r.kind == 0) {
+                if (interpolated(c)) {
                     const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(c.x) * kTapFloats);
                     const float4 q[3] = {wp[0], wp[1], wp[2]};
-                    const float acc = taps(lds, c.y, q);
+                    const float acc = taps(lds, c.y & 0xFFFFu, q);
                     if (tb.out) tb.out[x] = finishPixel<5>(invSize * acc);
                 }
-                resolve(tb, at, lds, re, ce, invSize, r, c, x);
+                resolve(tb, at, lds, re, ce, invSize, c, x);
             }
         }
     }

@@ -420,7 +420,8 @@ static bool buildChunkMap(Plan &p, const std::vector<PixelRec> &recs, int nSides
                 const long i0 = long(rec.a) - off;
                 if (i0 < 0 || i0 + rec.b - 1 > M || rec.b > kMaxTaps) return false;
                 cr[0] = uint32_t(p.weights12.size() / kTapFloats);
-                cr[1] = uint32_t(chunkPos(int(i0)));
+                if (chunkPos(int(i0)) > 0xFFFF) return false;
+                cr[1] = uint32_t(chunkPos(int(i0))) | kChunkInterp;
                 p.weights12.insert(p.weights12.end(), size_t(kTapFloats), 0.0f);
                 float *w = &p.weights12[p.weights12.size() - kTapFloats];
                 for (int t = 0; t < rec.b; ++t) {
@@ -442,7 +443,7 @@ static bool buildChunkMap(Plan &p, const std::vector<PixelRec> &recs, int nSides
                     tiles.push_back(Tile{lo, hi, x});
                     cr[1] = flags;                                       // completed below
                 }
-            }
+            } else cr[1] = kChunkOff;                                    // (a pixel the channel-split kernels leave to realLateKernel)
         }
         for (const Tile &t : tiles) {
             end[size_t(t.hi)] = 1;

@@ -36,12 +36,14 @@ struct MaxItem {
 constexpr int chunkPos(int i) { return i + ((i >> 5) << 1); }
 constexpr int kTapFloats = kMaxTaps + 2;          // a tap window as contiguous floats: <= 10 taps + the 2 pad slots it may step over
 // ChunkRec = two words per (side, pixel):
-//   interpolated pixel:  [0] = row of its weights in weights12,  [1] = float position of its first tap
+//   interpolated pixel:  [0] = row of its weights in weights12,  [1] = float position of its first tap | kChunkInterp
 //   arg-max pixel:       [1] = chunks before the last one that its run covers | flags << 16;
 //                        [0] = index of the run's tile maximum | first of those chunks << 16   (kChunkDirect: float position of the run's one entry)
 constexpr uint32_t kChunkDirect = 1u << 16;       // the run has one entry inside the chunks: read it
 constexpr uint32_t kChunkPlusM = 1u << 17;        // the run includes entry M (csf[N/2] of the left side / a mono signal), which no chunk holds
 constexpr uint32_t kChunkNoScan = 1u << 18;       // the run has no entry inside the chunks
+constexpr uint32_t kChunkInterp = 1u << 19;       // [1]: an interpolated pixel (its float position in the low 16 bits)
+constexpr uint32_t kChunkOff = 1u << 20;          // [1]: nothing to map here (a pixel settled elsewhere: realLowPixels; or no pixel at all)
 
 // Scalars the kernels need (all derived on the host exactly as the reference derives them).
 struct DeviceScalars {

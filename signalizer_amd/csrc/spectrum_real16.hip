@@ -78,7 +78,6 @@ __device__ __forceinline__ void quadStepNear(float &f0, float &f1, float &f2, fl
 // its own open run (unless the row's element 15 closed a tile): into the first tile it closes (an LDS float maximum on that slot,
 // behind this lane's own store to it) or, with no tile end in its half, into the row's running value CE[r].
 struct ChunkMap16 {
-    PixelRec rec;
     uint2 cr;
     uint32_t slotBase, endBits, rowEnds;
 
@@ -89,8 +88,7 @@ struct ChunkMap16 {
         const uint32_t base = tb.reBase[row];
         endBits = (tid & 1) ? rowEnds >> 16 : rowEnds & 0xFFFFu;
         slotBase = base + ((tid & 1) ? uint32_t(__builtin_popcount(rowEnds & 0xFFFFu)) : 0u);
-        rec = tid < tb.P ? tb.recs[tid] : PixelRec{2, 0, 0, 0};
-        cr = tid < tb.P ? tb.crec[tid] : uint2{0u, 0u};
+        cr = tid < tb.P ? tb.crec[tid] : uint2{0u, kChunkOff};
     }
 
     template <typename Index>
@@ -98,8 +96,10 @@ struct ChunkMap16 {
     {
         using Wide = ChunkMap<512>;
         float4 wq[3];
-        {
-            const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(rec.kind == 0 ? cr.x : 0u) * kTapFloats);
+        const bool interp = Wide::interpolated(cr);
+        const bool anyInterp = __builtin_amdgcn_ballot_w64(interp) != 0ull;
+        if (anyInterp) {
+            const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(interp ? cr.x : 0u) * kTapFloats);
             wq[0] = wp[0]; wq[1] = wp[1]; wq[2] = wp[2];
         }
         float v[16];
@@ -134,25 +134,24 @@ struct ChunkMap16 {
             if (tid & 1) ce[tid >> 1] = fin;
         }
         // ---- this thread's interpolated pixel
-        {
-            const float acc = Wide::taps(lds, rec.kind == 0 ? cr.y : 0u, wq);
-            if (rec.kind == 0 && tb.out) tb.out[tid] = finishPixel<5>(invSize * acc);
+        if (anyInterp) {
+            const float acc = Wide::taps(lds, interp ? (cr.y & 0xFFFFu) : 0u, wq);
+            if (interp && tb.out) tb.out[tid] = finishPixel<5>(invSize * acc);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the tile stores above are invisible to the compiler's counters
         ldsBarrier();
-        Wide::resolve(tb, at, lds, re, ce, invSize, rec, cr, tid);
+        Wide::resolve(tb, at, lds, re, ce, invSize, cr, tid);
         for (int base = kT; base < tb.P; base += kT) {                  // more than 1024 pixels per side
             const int x = base + tid;
             if (x < tb.P) {
-                const PixelRec r = tb.recs[x];
                 const uint2 c = tb.crec[x];
-                if (r.kind == 0) {
+                if (Wide::interpolated(c)) {
                     const float4 *wp = reinterpret_cast<const float4 *>(tb.weights12 + size_t(c.x) * kTapFloats);
                     const float4 q[3] = {wp[0], wp[1], wp[2]};
-                    const float acc = Wide::taps(lds, c.y, q);
+                    const float acc = Wide::taps(lds, c.y & 0xFFFFu, q);
                     if (tb.out) tb.out[x] = finishPixel<5>(invSize * acc);
                 }
-                Wide::resolve(tb, at, lds, re, ce, invSize, r, c, x);
+                Wide::resolve(tb, at, lds, re, ce, invSize, c, x);
             }
         }
     }
