@@ -22,8 +22,9 @@ extern "C" {
 /* 3: sgz_spectrum_config grew algorithm / free_q, sgz_scope_config custom_trigger / custom_trigger_frequency (round 3);
  * 4: sgz_spectrum_config grew display_mode (ZERO = the line graph, as in the reference's enum), sgz_spectrum_render_lines,
  *    sgz_spectrum_set_option (round 4);
+ * 5: sgz_scope_set_option / sgz_vector_set_option (SGZ_RT_OPT_DEFER_SUBMIT), sgz_spectrum_track_peak_lines, plan option SGZ_OPT_WIDE_GROUPS (round 5);
  * a binding compares sgz_abi_version() with the header it was compiled against */
-#define SGZ_ABI_VERSION 4
+#define SGZ_ABI_VERSION 5
 
 typedef enum sgz_status {
     SGZ_OK = 0,
@@ -272,6 +273,23 @@ typedef struct sgz_peak {
     double phi;                  /* fractional bin offset of the parabola   */
 } sgz_peak;
 sgz_status sgz_stage_track_peak(sgz_plan *plan, const float *d_bins, double mouse_fraction, sgz_peak *out, void *stream);
+/* The tracker's OTHER branch (SpectrumRendering.cpp:300-377): in Complex mode, for the RSNT algorithm and for the LineMain / LineSecond
+ * graphs the reference looks for the peak in lineGraphs[graph].getResults(axisPoints) -- the displayed line -- instead of the raw bins:
+ * first largest leftMagnitude within +-3 % of the axis around the mouse position, the walk along a still rising edge at a boundary of
+ * that range, then peakFrequency = mapFrequency(peak), peakDeviance from the neighbouring axis points (for the FFT algorithm with a
+ * non-Lanczos bin interpolation at least half a bin in axis points, :355-358), peakFractionY = the line's value there and its dB
+ * value on the view's dB range.  `results`: HOST float2 [P] as sgz_spectrum_line_results / sgz_spectrum_render_lines deliver them --
+ * the reference reads the same host-resident display results on its GUI thread; this is host arithmetic on a few thousand floats,
+ * nothing is launched.  (peak_dbs = low_db + y (high_db - low_db): cpl::Math::UnityScale::linear, absent, by its name.) */
+typedef struct sgz_line_peak {
+    double peak_offset;          /* axis point of the peak (peakX)               */
+    double peak_frequency;       /* mappedFrequencies[peak], Hz                  */
+    double peak_deviance;        /* Hz                                           */
+    double peak_fraction_y;      /* results[peak].leftMagnitude                  */
+    double peak_dbs;
+    double peak_slope;           /* slopeMap[peak]                               */
+} sgz_line_peak;
+sgz_status sgz_track_peak_lines(const sgz_plan *plan, const float *results /*HOST float2 [P]*/, double mouse_fraction, sgz_line_peak *out);
 
 /* K_B in two steps, for the multi-GPU carry exchange (collective A2).  scan: the chunk scans of `frames` frames from a
  * ZERO carry-in; writes that zero-carry end state (what a rank publishes) to d_end_state [pairs][graphs][P][2] and keeps the chunk
@@ -435,6 +453,9 @@ void      *sgz_spectrum_stream(sgz_spectrum *s);
 /* the frequency tracker on the newest window of pair `pair` (consumer thread): transforms the device ring's current window and runs
  * sgz_stage_track_peak's search on it */
 sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_fraction, sgz_peak *out);
+/* sgz_track_peak_lines on the handle's newest line results of (pair, graph) -- what sgz_spectrum_line_results would return now
+ * (Complex mode, RSNT and the LineMain / LineSecond graphs: SpectrumRendering.cpp:300-377) */
+sgz_status sgz_spectrum_track_peak_lines(sgz_spectrum *s, uint32_t pair, uint32_t graph, double mouse_fraction, sgz_line_peak *out);
 /* parity hook: the W newest samples of destination channel `channel`, exactly the range of the device ring a frame firing now
  * would transform (call it from the producer's thread, or with the producer idle) */
 sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out /*W*/);
@@ -533,6 +554,12 @@ sgz_status sgz_scope_configure(sgz_scope *s, const sgz_scope_config *cfg);
 /* onStreamAudio(ctx, float** buffer, numChannels, numSamples); the steady clock is the running count of pushed samples */
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
 sgz_status sgz_scope_flush(sgz_scope *s);      /* as sgz_spectrum_flush */
+/* Handle switch (consumer thread, between create / configure and the first push; the library reads no environment variable):
+ *   SGZ_RT_OPT_DEFER_SUBMIT  0 (default): a pushed block goes to the GPU at once when nothing of the handle is in flight, otherwise it
+ *       joins the open batch, which the next submission takes in ONE launch.  1: every block waits for a full batch or a reader
+ *       (flush on read) -- every launch a multi-callback one.  Results are identical; the tests pin the batched paths down with it. */
+#define SGZ_RT_OPT_DEFER_SUBMIT 3u
+sgz_status sgz_scope_set_option(sgz_scope *s, uint32_t option, uint64_t value);
 /* TriggeringMode::Window draws the window at the host transport's phase: position_in_samples = cs.transportPosition =
  * playhead.getPositionInSamples() + numSamples of the newest block (OscilloscopeDSP.inl:706; OscilloscopeRendering.cpp:588-592,
  * :798-801).  Any thread, any time (one atomic store); ignored by the other modes. */
@@ -611,6 +638,7 @@ void       sgz_vector_destroy(sgz_vector *s);
 sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg);
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
 sgz_status sgz_vector_flush(sgz_vector *s);    /* as sgz_spectrum_flush */
+sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value);   /* SGZ_RT_OPT_DEFER_SUBMIT, as sgz_scope_set_option */
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain /*optional: reading it waits*/);
 sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain);
 /* xyz: float3 [window_size], rgb: float3 [window_size] or NULL; *count: in = capacity in vertices, out = window_size.  Vertex

@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         L.sgzo_resonator_spectrogram.restype = C.c_long
         L.sgzo_resonator_spectrogram.argtypes = [C.POINTER(SpectrumParams), vp, C.c_size_t, vp, vp, vp]
         L.sgzo_track_peak.argtypes = [C.POINTER(SpectrumParams), vp, C.c_uint32, vp, C.c_double, C.c_double, vp]
+        L.sgzo_track_peak_lines.argtypes = [C.POINTER(SpectrumParams), vp, vp, vp, C.c_uint32, C.c_double, vp]
         L.sgzo_decay_colour.restype = C.c_long
         L.sgzo_decay_colour.argtypes = [C.POINTER(SpectrumParams), vp, C.c_long, vp, vp]
         L.sgzo_logf_array.argtypes = [vp, vp, C.c_size_t]
@@ -650,6 +651,17 @@ def track_peak(p: SpectrumParams, source: np.ndarray, scale: float, mouse_fracti
     out = np.zeros(8, np.float64)
     lib().sgzo_track_peak(C.byref(p), _ptr(src), src.size - 1, _ptr(mapped), scale, mouse_fraction, _ptr(out))
     keys = ("peak_offset", "peak_fraction", "peak_frequency", "peak_dbs", "alpha", "beta", "gamma", "phi")
+    return dict(zip(keys, out.tolist()))
+
+
+def track_peak_lines(p: SpectrumParams, results: np.ndarray, transform_size: int, mouse_fraction: float) -> dict:
+    """the tracker's line-results branch (SpectrumRendering.cpp:300-377) on lineGraphs[g].results: float2 [P] (left, right)"""
+    r = np.ascontiguousarray(results, np.float32)
+    mapped = remap_frequencies(p)
+    slope = slope_map(p, mapped)
+    out = np.zeros(6, np.float64)
+    lib().sgzo_track_peak_lines(C.byref(p), _ptr(r), _ptr(mapped), _ptr(slope), int(transform_size), mouse_fraction, _ptr(out))
+    keys = ("peak_offset", "peak_frequency", "peak_deviance", "peak_fraction_y", "peak_dbs", "peak_slope")
     return dict(zip(keys, out.tolist()))
 
 

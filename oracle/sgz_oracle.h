@@ -124,6 +124,8 @@ long sgzo_num_frames(size_t nsamples, uint32_t W, uint32_t hop);
 /* frequency tracker, raw-FFT branch (SpectrumRendering.cpp:379-469): out = {peakOffset, peakFraction, peakFrequency, peakDBs, alpha, beta, gamma, phi} */
 void sgzo_track_peak(const sgzo_spectrum_params *p, const sgzo_cf *source, uint32_t N, const float *mapped, double window_scale,
                      double mouse_fraction, double out[8]);
+void sgzo_track_peak_lines(const sgzo_spectrum_params *p, const float *results, const float *mapped, const float *slope, uint32_t transform_size,
+                           double mouse_fraction, double out[6]);
 /* test hooks: a5 + a7 over F frames of given csp values [F][C][2P] (states start from zero); libm logf over an array */
 long sgzo_decay_colour(const sgzo_spectrum_params *p, const sgzo_cf *csp_all, long F, uint8_t *rgba_out, sgzo_cf *line_out);
 void sgzo_logf_array(const float *x, float *y, size_t n);

@@ -666,3 +666,54 @@ void sgzo_track_peak(const sgzo_spectrum_params *p, const sgzo_cf *source, uint3
     out[0] = (double)peakOffset; out[1] = peakFraction; out[2] = peakFrequency; out[3] = peakDBs;
     out[4] = alpha; out[5] = beta; out[6] = gamma; out[7] = phi;
 }
+
+/* The tracker's line-results branch, Spectrum::drawFrequencyTracking (Source/Spectrum/SpectrumRendering.cpp:300-377): Complex mode, the
+ * RSNT algorithm and the LineMain / LineSecond graphs look for the peak in lineGraphs[graphN].getResults(axisPoints).
+ * results: UComplex [P] as (leftMagnitude, rightMagnitude); mapped: mappedFrequencies[P]; slope: slopeMap[P].
+ * out: {peakOffset, peakFrequency, peakDeviance, peakFractionY, peakDBs, peakSlope}.
+ * (cpl::Math::round / confineTo / UnityScale::linear are absent: round-half-away, clamp, min + x (max - min).) */
+void sgzo_track_peak_lines(const sgzo_spectrum_params *p, const float *results, const float *mapped, const float *slope, uint32_t transform_size,
+                           double mouse_fraction, double out[6])
+{
+    double mouseFraction = mouse_fraction < 0 ? 0 : (mouse_fraction > 1 ? 1 : mouse_fraction);          /* :292 */
+    const double nearbyFractionToConsider = 0.03;
+    const size_t N = p->axis_points;                                                                 /* results.size() */
+    const size_t pivot = (size_t)llround((double)N * mouseFraction);                                 /* :308 */
+    const size_t range = (size_t)llround((double)N * nearbyFractionToConsider);
+    const size_t lowerBound = range > pivot ? 0 : pivot - range;
+    const size_t higherBound = range + pivot > N ? N : range + pivot;
+#define LEFT(i) results[2 * (i)]
+    /* std::max_element(begin + lowerBound, begin + higherBound, left.leftMagnitude < right.leftMagnitude): the first largest */
+    size_t peak = lowerBound < N ? lowerBound : N - 1;                                               /* (empty range: stay inside the results) */
+    for (size_t i = lowerBound + 1; i < higherBound; ++i)
+        if (LEFT(peak) < LEFT(i)) peak = i;
+    if (peak == lowerBound && lowerBound != 0) {                                                     /* :320-332 */
+        while (1) {
+            const size_t nextPeak = peak - 1;
+            if (nextPeak == 0) break;                                                                /* nextPeak == results.begin() */
+            else if (LEFT(nextPeak) < LEFT(peak)) break;
+            else peak = nextPeak;
+        }
+    } else if (higherBound != 0 && peak == higherBound - 1) {                                        /* :333-345 */
+        while (1) {
+            const size_t nextPeak = peak + 1;
+            if (nextPeak == N) break;                                                                /* results.end() */
+            else if (LEFT(nextPeak) < LEFT(peak)) break;
+            else peak = nextPeak;
+        }
+    }
+    const size_t peakOffset = peak;
+    const double peakFrequency = (double)mapped[peakOffset];                                         /* constant.mapFrequency(peakOffset) */
+    const int offsetIsEnd = peakOffset == (size_t)p->axis_points - 1;
+    const size_t hi = offsetIsEnd ? peakOffset : peakOffset + 1, lo = offsetIsEnd ? (peakOffset == 0 ? 0 : peakOffset - 1) : peakOffset;
+    double peakDeviance = (double)(mapped[hi] - mapped[lo]);                                         /* T = float arithmetic */
+    if (p->algorithm == 0 /* FFT */ && p->bin_interp != 2 /* Lanczos */) {
+        const double alt = 0.5 * (double)transform_size / (double)N;
+        if (peakDeviance < alt) peakDeviance = alt;                                                  /* std::max */
+    }
+    const double peakFractionY = (double)LEFT(peakOffset);
+#undef LEFT
+    out[0] = (double)peakOffset; out[1] = peakFrequency; out[2] = peakDeviance; out[3] = peakFractionY;
+    out[4] = p->low_db + peakFractionY * (p->high_db - p->low_db);
+    out[5] = (double)slope[peakOffset];
+}

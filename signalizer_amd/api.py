@@ -49,6 +49,13 @@ class Peak(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class LinePeak(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("peak_offset", "peak_frequency", "peak_deviance", "peak_fraction_y", "peak_dbs", "peak_slope")]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class Timing(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("frames", C.c_uint64)]
 
@@ -117,13 +124,13 @@ EXPORTS = [
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames", "sgz_plan_num_frames", "sgz_plan_get_resonator", "sgz_plan_reset_resonator",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant", "sgz_plan_set_option",
-    "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout", "sgz_spectrogram_render_sharded_on",
+    "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_track_peak_lines", "sgz_spectrum_track_peak_lines", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout", "sgz_spectrogram_render_sharded_on",
     "sgz_spectrogram_render_sharded", "sgz_peer_group_create", "sgz_peer_group_destroy", "sgz_peer_transport", "sgz_peer_transport_release",
     "sgz_spectrum_create", "sgz_spectrum_destroy", "sgz_spectrum_configure", "sgz_spectrum_push",
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
     "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
     "sgz_spectrum_flush_columns", "sgz_spectrum_render_lines", "sgz_spectrum_set_option",
-    "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
+    "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_set_option", "sgz_vector_set_option", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_vertices_all", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
@@ -191,6 +198,8 @@ def lib() -> C.CDLL:
     L.sgz_stage_finish_pixel.argtypes = [vp, vp, sz, vp]
     L.sgz_stage_track_peak.argtypes = [vp, vp, C.c_double, C.POINTER(Peak), vp]
     L.sgz_spectrum_track_peak.argtypes = [vp, u32, C.c_double, C.POINTER(Peak)]
+    L.sgz_track_peak_lines.argtypes = [vp, vp, C.c_double, C.POINTER(LinePeak)]
+    L.sgz_spectrum_track_peak_lines.argtypes = [vp, u32, u32, C.c_double, C.POINTER(LinePeak)]
     L.sgz_comm_unique_id.argtypes = [vp]
     L.sgz_comm_create.argtypes = [vp, u32, u32, C.POINTER(vp)]
     L.sgz_comm_destroy.argtypes = [vp]
@@ -217,6 +226,8 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_bind_gl_buffer.argtypes = [vp, C.c_uint, u32, sz]
     L.sgz_spectrum_flush_columns.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_create.argtypes = [C.POINTER(ScopeConfig), C.POINTER(vp)]
+    L.sgz_scope_set_option.argtypes = [vp, u32, C.c_uint64]
+    L.sgz_vector_set_option.argtypes = [vp, u32, C.c_uint64]
     L.sgz_scope_destroy.argtypes = [vp]
     L.sgz_scope_destroy.restype = None
     L.sgz_scope_configure.argtypes = [vp, C.POINTER(ScopeConfig)]
@@ -269,6 +280,7 @@ def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+RT_OPT_STRICT_REFERENCE_QUIRKS, RT_OPT_AUDIO_HISTORY, RT_OPT_DEFER_SUBMIT = 1, 2, 3
 OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW, OPT_MATRIX_RESONATOR, OPT_RESONATOR_SLAB, OPT_WIDE_GROUPS = 1, 2, 3, 4, 5, 6
 
 
@@ -355,6 +367,14 @@ class Plan:
         out = np.zeros(NUM_SPEC_COLOURS + 1, np.float32)
         check(lib().sgz_plan_get_colour_ratios(self.h, _np_ptr(out)))
         return out
+
+    def track_peak_lines(self, results: np.ndarray, mouse_fraction: float) -> dict:
+        """sgz_track_peak_lines: the tracker's line-results branch on host results float2 [P] (no upload needed: host arithmetic)"""
+        r = np.ascontiguousarray(results, np.float32)
+        assert r.size == 2 * self.P
+        out = LinePeak()
+        check(lib().sgz_track_peak_lines(self.h, _np_ptr(r), float(mouse_fraction), C.byref(out)))
+        return out.asdict()
 
     def colour_table(self, pair: int) -> np.ndarray:
         out = np.zeros((NUM_SPEC_COLOURS + 1, 3), np.float32)
@@ -499,6 +519,11 @@ class Scope:
         self.h = C.c_void_p()
         check(lib().sgz_scope_create(C.byref(self.cfg), C.byref(self.h)))
 
+    def set_option(self, option: int, value: int):
+        """sgz_scope_set_option (RT_OPT_DEFER_SUBMIT)"""
+        check(lib().sgz_scope_set_option(self.h, option, value))
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             lib().sgz_scope_destroy(self.h)
@@ -617,6 +642,11 @@ class Vector:
                 self.cfg.colours[p][j] = float(col[j])
         self.h = C.c_void_p()
         check(lib().sgz_vector_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def set_option(self, option: int, value: int):
+        """sgz_vector_set_option (RT_OPT_DEFER_SUBMIT)"""
+        check(lib().sgz_vector_set_option(self.h, option, value))
+        return self
 
     def close(self):
         if getattr(self, "h", None):

@@ -732,6 +732,15 @@ sgz_status sgz_spectrum_track_peak(sgz_spectrum *s, uint32_t pair, double mouse_
     return SGZ_OK;
 }
 
+sgz_status sgz_spectrum_track_peak_lines(sgz_spectrum *s, uint32_t pair, uint32_t graph, double mouse_fraction, sgz_line_peak *out)
+{
+    if (!s || !out) return fail(SGZ_EINVAL, "null argument");
+    const Plan &p = *s->plan;
+    std::vector<float> results(size_t(p.P) * 2);
+    if (sgz_status st = sgz_spectrum_line_results(s, pair, graph, results.data()); st != SGZ_OK) return st;
+    return trackPeakLines(p, results.data(), mouse_fraction, out);
+}
+
 /* parity hook: the W newest samples of destination channel `channel` as K_A would read them (one contiguous range of the mirrored
  * ring) */
 sgz_status sgz_spectrum_history(sgz_spectrum *s, uint32_t channel, float *out)

@@ -46,4 +46,5 @@ sgz_status runDecayEmitWithCarry(Plan &p, const float *d_mapped, long frames, co
                                  float *d_stateOut, hipStream_t stream);
 // frequency tracker (tracker.hip): peak search + parabolic fit on one (frame, pair)'s csf magnitudes; d_out: DEVICE sgz_peak
 sgz_status runTrackPeak(const Plan &p, const float *d_bins, double mouseFraction, sgz_peak *d_out, hipStream_t stream);
+sgz_status trackPeakLines(const Plan &p, const float *results /*host float2 [P]*/, double mouseFraction, sgz_line_peak *out);   // tracker.hip
 }  // namespace sgz

@@ -1351,7 +1351,7 @@ __global__ void __launch_bounds__(1024) scopeSpectralKernel(const SpectralParams
 
 struct sgz_scope {
     sgz_scope_config cfg{};
-    bool deferSubmit = std::getenv("SGZ_RT_DEFER_SUBMIT") != nullptr && std::getenv("SGZ_RT_DEFER_SUBMIT")[0] == '1';
+    bool deferSubmit = false;                  // sgz_scope_set_option(SGZ_RT_OPT_DEFER_SUBMIT)
     std::mutex mu;                    // configure (consumer thread) against push (producer: try_lock only, never waits)
     hipStream_t stream = nullptr;
     BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
@@ -1611,8 +1611,8 @@ static sgz_status scopePushNow(sgz_scope *s, const float *const *blk, uint32_t n
     if (s->batch.count == 0)
         if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
     s->batch.append(blk, n);
-    // nothing in flight: start now (a busy GPU picks the block up with the next ones).  SGZ_RT_DEFER_SUBMIT=1 in the environment
-    // (read when the handle is created; tests): every block waits for a full batch or a reader -- multi-block launches on demand
+    // nothing in flight: start now (a busy GPU picks the block up with the next ones).  SGZ_RT_OPT_DEFER_SUBMIT: every block waits for a
+    // full batch or a reader -- multi-block launches on demand (tests)
     if (!s->deferSubmit && s->batch.idle()) return scopeSubmit(s);
     return SGZ_OK;
 }
@@ -1646,6 +1646,15 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     s->batch.unlock();
     if (st == SGZ_BUSY) s->busy++;
     return st;
+}
+
+sgz_status sgz_scope_set_option(sgz_scope *s, uint32_t option, uint64_t value)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (option != SGZ_RT_OPT_DEFER_SUBMIT) return fail(SGZ_EINVAL, "unknown scope option");
+    s->deferSubmit = value != 0;
+    return SGZ_OK;
 }
 
 sgz_status sgz_scope_flush(sgz_scope *s)

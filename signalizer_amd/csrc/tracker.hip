@@ -6,6 +6,7 @@
 // One workgroup: the range is at most a few thousand bins; the reduction key is (square, smaller index wins), i.e. max_element's.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "runtime.hpp"
@@ -95,7 +96,66 @@ sgz_status runTrackPeak(const Plan &p, const float *d_bins, double mouseFraction
 
 }  // namespace sgz
 
+namespace sgz {
+
+// The tracker's line-results branch (SpectrumRendering.cpp:300-377), host arithmetic on host-resident results (see sgz.h).
+sgz_status trackPeakLines(const Plan &p, const float *results, double mouseFraction, sgz_line_peak *out)
+{
+    if (!std::isfinite(mouseFraction)) return fail(SGZ_EINVAL, "mouse_fraction");
+    mouseFraction = mouseFraction < 0 ? 0 : (mouseFraction > 1 ? 1 : mouseFraction);                      // :292
+    const double nearbyFractionToConsider = 0.03;
+    const size_t N = p.P;                                                                                 // results.size()
+    if (N == 0) return fail(SGZ_EINVAL, "no axis points");
+    auto left = [&](size_t i) { return results[2 * i]; };                                                 // UComplex::leftMagnitude
+    const size_t pivot = size_t(std::llround(double(N) * mouseFraction));
+    const size_t range = size_t(std::llround(double(N) * nearbyFractionToConsider));
+    const size_t lowerBound = range > pivot ? 0 : pivot - range;
+    const size_t higherBound = range + pivot > N ? N : range + pivot;
+    // std::max_element over [lowerBound, higherBound): the first largest (an empty range -- fewer than 17 axis points -- yields its own
+    // begin in the reference; confined to the last point here so that nothing is read behind the results)
+    size_t peak = lowerBound < N ? lowerBound : N - 1;
+    for (size_t i = lowerBound + 1; i < higherBound; ++i)
+        if (left(peak) < left(i)) peak = i;
+    if (peak == lowerBound && lowerBound != 0) {                                                          // :320-332
+        for (;;) {
+            const size_t next = peak - 1;
+            if (next == 0) break;
+            else if (left(next) < left(peak)) break;
+            else peak = next;
+        }
+    } else if (higherBound != 0 && peak == higherBound - 1) {                                             // :333-345
+        for (;;) {
+            const size_t next = peak + 1;
+            if (next == N) break;
+            else if (left(next) < left(peak)) break;
+            else peak = next;
+        }
+    }
+    const size_t peakOffset = peak;
+    const bool offsetIsEnd = peakOffset == size_t(p.cfg.axis_points) - 1;
+    // mapFrequency returns T = float: the difference is a float subtraction (TransformConstant.h:99-102)
+    const size_t hi = offsetIsEnd ? peakOffset : peakOffset + 1, lo = offsetIsEnd ? (peakOffset == 0 ? 0 : peakOffset - 1) : peakOffset;
+    double peakDeviance = double(p.mapped[hi] - p.mapped[lo]);
+    if (p.cfg.algorithm == SGZ_ALGO_FFT && p.cfg.bin_interp != SGZ_INTERP_LANCZOS)
+        peakDeviance = std::max(peakDeviance, 0.5 * double(p.N) / double(N));                             // :355-358
+    out->peak_offset = double(peakOffset);
+    out->peak_frequency = double(p.mapped[peakOffset]);
+    out->peak_deviance = peakDeviance;
+    out->peak_fraction_y = double(left(peakOffset));
+    out->peak_dbs = p.cfg.low_db + double(left(peakOffset)) * (p.cfg.high_db - p.cfg.low_db);
+    out->peak_slope = double(p.slope[peakOffset]);
+    return SGZ_OK;
+}
+
+}  // namespace sgz
+
 struct sgz_plan { Plan impl; };
+
+extern "C" sgz_status sgz_track_peak_lines(const sgz_plan *plan, const float *results, double mouse_fraction, sgz_line_peak *out)
+{
+    if (!plan || !results || !out) return fail(SGZ_EINVAL, "null argument");
+    return trackPeakLines(plan->impl, results, mouse_fraction, out);
+}
 
 extern "C" sgz_status sgz_stage_track_peak(sgz_plan *plan, const float *d_bins, double mouse_fraction, sgz_peak *out, void *stream)
 {

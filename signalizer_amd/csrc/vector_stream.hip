@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams p
 
 struct sgz_vector {
     sgz_vector_config cfg{};
+    bool deferSubmit = false;                  // sgz_vector_set_option(SGZ_RT_OPT_DEFER_SUBMIT)
     std::mutex mu;
     hipStream_t stream = nullptr;
     BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
@@ -462,7 +463,8 @@ static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t
     if (s->batch.count == 0)
         if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
     s->batch.append(blk, n);
-    if (s->batch.idle()) return vectorSubmit(s);                  // nothing in flight: start now (a busy GPU picks the block up with the next ones)
+    // nothing in flight: start now (a busy GPU picks the block up with the next ones); SGZ_RT_OPT_DEFER_SUBMIT: wait for a full batch or a reader
+    if (!s->deferSubmit && s->batch.idle()) return vectorSubmit(s);
     return SGZ_OK;
 }
 
@@ -495,6 +497,15 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     s->batch.unlock();
     if (st == SGZ_BUSY) s->busy++;
     return st;
+}
+
+sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value)
+{
+    if (!s) return fail(SGZ_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (option != SGZ_RT_OPT_DEFER_SUBMIT) return fail(SGZ_EINVAL, "unknown vector option");
+    s->deferSubmit = value != 0;
+    return SGZ_OK;
 }
 
 sgz_status sgz_vector_flush(sgz_vector *s)

@@ -33,9 +33,11 @@ def _push(dev, blk):
         assert st == api.SGZ_BUSY
 
 
-def _feed(po, cfg, x, seed, max_block=3000):
+def _feed(po, cfg, x, seed, max_block=3000, defer=False):
     """the same random block schedule into the HIP handle and the oracle stream"""
     dev = api.Scope(**cfg)
+    if defer:
+        dev.set_option(api.RT_OPT_DEFER_SUBMIT, 1)
     ref = po.ScopeStream(cfg["num_channels"], cfg["sample_rate"], cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"],
                          cfg["channel_mode"], cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
     rng = np.random.default_rng(seed)
@@ -101,13 +103,12 @@ def test_stream_state_machine_is_bit_exact(gpu, oracle, over):
 ])
 def test_batched_launches_are_the_callback_walk(gpu, oracle, over, max_block, monkeypatch):
     """the ingest kernel takes every callback that waited in ONE launch, with the zero-crossing detector run once over their
-    concatenation (scopeIngestKernel, "A for the whole batch"): SGZ_RT_DEFER_SUBMIT makes every launch a multi-callback one (blocks wait
-    for a full batch or a reader), and the state machine, the rings and the gains are still the oracle's callback-by-callback walk"""
-    monkeypatch.setenv("SGZ_RT_DEFER_SUBMIT", "1")
+    concatenation (scopeIngestKernel, "A for the whole batch"): SGZ_RT_OPT_DEFER_SUBMIT makes every launch a multi-callback one (blocks
+    wait for a full batch or a reader), and the state machine, the rings and the gains are still the oracle's callback-by-callback walk"""
     po = oracle
     cfg = _cfg(**over)
     x = _signal(5, 60000, cfg["num_channels"])
-    dev, ref = _feed(po, cfg, x, seed=23, max_block=max_block)
+    dev, ref = _feed(po, cfg, x, seed=23, max_block=max_block, defer=True)
     assert dev.state() == ref.state()
     if cfg["trigger_threshold"] < 1:
         assert ref.state()["swaps"] > 10

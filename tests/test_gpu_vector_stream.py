@@ -93,6 +93,49 @@ def test_vector_stream_against_the_oracle(gpu, oracle, channels, size, env_mode,
             _push(dev, more); ref.audio(more)
 
 
+@pytest.mark.parametrize("channels,size,env_mode,max_block", [(2, 9600, 1, 700), (8, 9600, 1, 300), (4, 777, 0, 64), (2, 13, 1, 9), (6, 2048, 1, 1500)])
+def test_batched_launches_are_the_callback_walk(gpu, oracle, channels, size, env_mode, max_block):
+    """vectorIngestKernel takes every callback that waited in ONE launch, keeping the callbacks' boundaries (Vectorscope.cpp:268-377 runs
+    once per callback: the envelope gain and the balance / phase filters are read at callback ends).  SGZ_RT_OPT_DEFER_SUBMIT makes EVERY
+    launch a multi-callback one -- blocks wait for a full batch or a reader -- and the ring, the cursor, the envelopes, the balance and the
+    phase filters must still be the oracle's callback-by-callback walk (ring, envelopes and balance bit for bit)."""
+    po = oracle
+    dev = api.Vector(sample_rate=SR, num_channels=channels, window_size=size, envelope_mode=env_mode, lanes=8, fade_history=1,
+                     max_block=4096, envelope_window=0.3, stereo_window=0.05).set_option(api.RT_OPT_DEFER_SUBMIT, 1)
+    ref = RefVector(po, channels, size, env_mode, 0.3, 0.05, 8)
+    x = synth.gen(7, SR, 40000, channels)
+    x[:, 3000:3100] = 0
+    rng = np.random.default_rng(31)
+    pos, pushes, reads = 0, 0, 0
+    while pos < x.shape[1]:
+        n = int(rng.integers(1, max_block))
+        blk = x[:, pos:pos + n]
+        _push(dev, blk); ref.audio(blk)
+        pos += blk.shape[1]
+        pushes += 1
+        if rng.random() < 0.04:                                       # a reader in mid-stream: flush on read, then the comparison
+            f, gain = dev.filters()
+            reads += 1
+            gb = np.array([list(r) for r in f.balance], np.float32)
+            rb = np.array([list(r) for r in ref.f.balance], np.float32)
+            assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32)), pushes
+            if env_mode == 1:
+                assert np.float32(gain) == np.float32(ref.gain), pushes
+    assert pushes > 3 * max(reads, 1)                                 # several callbacks per launch on average
+    for c in range(channels):
+        mem, cur = dev.history(c)
+        assert cur == ref.cursor
+        assert np.array_equal(mem.view(np.uint32), ref.mem[c].view(np.uint32)), c
+    f, gain = dev.filters()
+    if env_mode == 1:
+        assert np.array_equal(np.array(f.env[:], np.float32).view(np.uint32), np.array(ref.f.env[:], np.float32).view(np.uint32))
+        assert np.float32(gain) == np.float32(ref.gain)
+    gb = np.array([list(r) for r in f.balance], np.float32)
+    rb = np.array([list(r) for r in ref.f.balance], np.float32)
+    assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32))
+    assert np.abs(np.array(f.phase[:]) - np.array(ref.f.phase[:])).max() <= 1e-5
+
+
 def test_cfg4_shape(gpu, oracle):
     """BASELINE configs[3]: 8 channels 96 kHz, 100 ms window = 9600 samples per pair, blocks of 480"""
     po = oracle

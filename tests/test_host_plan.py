@@ -118,7 +118,7 @@ def test_library_exports_every_symbol_the_header_declares():
     assert not missing, missing
     assert sorted(api.EXPORTS) == declared
     m = re.search(r"#define SGZ_ABI_VERSION (\d+)", hdr)
-    assert m and L.sgz_abi_version() == int(m.group(1)) == 4          # the binary is the header's (4: display_mode, render_lines, handle options)
+    assert m and L.sgz_abi_version() == int(m.group(1)) == 5          # the binary is the header's (5: scope / vector handle options, line-results tracker)
 
 
 def test_header_is_plain_c(tmp_path):

@@ -81,3 +81,79 @@ def test_gpu_tracker_on_the_realtime_handle(gpu, oracle):
         assert abs(got.peak_dbs - 20 * np.log10(0.5)) < 0.3
     finally:
         api.lib().sgz_spectrum_destroy(h)
+
+
+@pytest.mark.parametrize("over", [dict(), dict(bin_interp=config.INTERP_LINEAR), dict(channel_mode=config.CH_COMPLEX, bin_interp=config.INTERP_NONE),
+                                  dict(algorithm=1, window_size=4096, hop=1024), dict(axis_points=10), dict(axis_points=33, view_scaling=config.VIEW_LINEAR),
+                                  dict(axis_points=3000, window_size=32768, hop=8192)])
+def test_line_results_tracker_equals_the_oracle(oracle, over):
+    """The tracker's OTHER branch (Complex mode, RSNT, LineMain / LineSecond: SpectrumRendering.cpp:300-377) picks the peak from the
+    displayed line.  It is host arithmetic on host-resident results in the reference and here (sgz_track_peak_lines): the library's
+    function against the oracle's line-by-line restatement, every output bit for bit -- random lines, plateaus (max_element takes the
+    FIRST largest), monotone ramps (the walks along a rising edge at either boundary of the +-3 % range) and the ends of the axis."""
+    from signalizer_amd import api
+    po = oracle
+    cfg = config.spectrum_config(**{**dict(window_size=8192, hop=2048), **over})
+    p = po.params_from_dict(cfg)
+    plan = api.Plan(cfg)
+    P = plan.P
+    rng = np.random.default_rng(5)
+    lines = []
+    for kind in range(6):
+        r = np.zeros((P, 2), np.float32)
+        if kind == 0: r[:, 0] = rng.random(P)
+        elif kind == 1: r[:, 0] = np.round(rng.random(P) * 4) / 4                      # plateaus: ties
+        elif kind == 2: r[:, 0] = np.linspace(0, 1, P)                                  # rising to the right: the upward walk to the end
+        elif kind == 3: r[:, 0] = np.linspace(1, 0, P)                                  # rising to the left: the downward walk (stops at 1, not 0)
+        elif kind == 4: r[:, 0] = np.exp(-0.5 * ((np.arange(P) - 0.37 * P) / (0.02 * P + 1)) ** 2)
+        else: r[:, 0] = 0.25
+        r[:, 1] = rng.random(P)                                                         # (the right magnitudes are never looked at)
+        lines.append(r)
+    n = 0
+    for r in lines:
+        for mf in (-0.3, 0.0, 0.01, 0.029, 0.03, 0.2, 0.37, 0.5, 0.77, 0.969, 0.97, 0.99, 1.0, 1.4):
+            want = po.track_peak_lines(p, r, plan.N, mf)
+            got = plan.track_peak_lines(r, mf)
+            for k, v in want.items():
+                assert np.float64(got[k]).view(np.uint64) == np.float64(v).view(np.uint64), (over, mf, k, got, want)
+            n += 1
+    assert n == 84
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("over,graph", [(dict(channel_mode=config.CH_COMPLEX), 0), (dict(algorithm=1), 0), (dict(), 1), (dict(channel_mode=config.CH_MIDSIDE), 1)])
+def test_handle_tracks_the_peak_of_its_line_results(gpu, oracle, over, graph):
+    """sgz_spectrum_track_peak_lines = sgz_track_peak_lines on what sgz_spectrum_line_results returns at that moment: Complex mode, RSNT
+    and the LineSecond graph -- the cases the raw-bin tracker does not serve (SpectrumRendering.cpp:301)"""
+    from signalizer_amd import api
+    po = oracle
+    cfg = config.spectrum_config(**{**dict(window_size=4096, hop=1024, axis_points=512), **over})
+    p = po.params_from_dict(cfg)
+    x = _tone(2500.0, 48000, 4096 * 6)
+    L = api.lib()
+    c = api.config_from_dict(cfg)
+    h = C.c_void_p()
+    api.check(L.sgz_spectrum_create(C.byref(c), C.byref(h)))
+    try:
+        for o in range(0, x.shape[1], 512):
+            blk = np.ascontiguousarray(x[:, o:o + 512])
+            api.check(L.sgz_spectrum_push(h, (C.c_void_p * 2)(blk[0].ctypes.data, blk[1].ctypes.data), 2, 512))
+        L.sgz_spectrum_flush.argtypes = [C.c_void_p]
+        api.check(L.sgz_spectrum_flush(h))
+        import torch
+        torch.cuda.synchronize()
+        res = np.zeros((512, 2), np.float32)
+        for _ in range(50):                                              # (the newest results reach the host behind the producer's stream)
+            api.check(L.sgz_spectrum_line_results(h, 0, graph, res.ctypes.data_as(C.c_void_p)))
+            if np.abs(res[:, 0]).max() > 0:
+                break
+        assert np.abs(res[:, 0]).max() > 0
+        N = api.Plan(cfg).N
+        for mf in (0.1, 0.45, 0.6, 0.9):
+            got = api.LinePeak()
+            api.check(L.sgz_spectrum_track_peak_lines(h, 0, graph, mf, C.byref(got)))
+            want = po.track_peak_lines(p, res, N, mf)
+            for k, v in want.items():
+                assert np.float64(getattr(got, k)).view(np.uint64) == np.float64(v).view(np.uint64), (mf, k, got.asdict(), want)
+    finally:
+        L.sgz_spectrum_destroy(h)
