@@ -260,6 +260,7 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
     # paint would execute; the Python loop above pays 60-100 us of interpreter and ctypes time per frame on top of the library's own)
     dt = dt_python
     host = "python"
+    dt_resident = None
     from signalizer_amd import build as sgz_build
     if os.path.exists(sgz_build.DRIVER) and not os.environ.get("SGZ_LIB"):
         D = C.CDLL(sgz_build.DRIVER)
@@ -288,36 +289,70 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
         dt, host = float(d), "c++ (tools/rt_driver.cpp)"
         refused += busy.value
         assert verts.value == units, (verts.value, units)
+        # the same frames with the vertex streams left in HBM (caller-owned DEVICE buffers: a mapped vertex buffer object / exported memory
+        # the display GPU imported -- SURVEY 8(f) #1): nothing crosses PCIe on the way out
+        if scope:
+            dxs = [torch.empty((nv, 3), dtype=torch.float32, device=dev) for _ in (0, 1)]
+            dcs = [torch.empty((nv, 4), dtype=torch.uint8, device=dev) for _ in (0, 1)]
+            xs = (C.c_void_p * 2)(dxs[0].data_ptr(), dxs[1].data_ptr()); cs = (C.c_void_p * 2)(dcs[0].data_ptr(), dcs[1].data_ptr())
+        else:
+            dxyz = torch.empty((nch // 2, W, 3), dtype=torch.float32, device=dev); drgb = torch.empty((nch // 2, W, 3), dtype=torch.float32, device=dev)
+            run = lambda warm, n: D.sgz_bench_vector_loop(h.h, C.c_void_p(xc.ctypes.data), C.c_size_t(xc.shape[1]), C.c_uint32(nch), C.c_uint32(per_frame),
+                                                          C.c_uint32(512), C.c_uint32(64), C.c_void_p(dxyz.data_ptr()), C.c_void_p(drgb.data_ptr()),
+                                                          C.c_uint32(W), C.c_double(1 / 60), C.c_int(warm), C.c_int(n), C.byref(busy), C.byref(verts))
+        d2 = run(20, nsteps)
+        if d2 < 0:
+            raise RuntimeError(f"rt_driver (device-resident): C-ABI call failed ({d2})")
+        dt_resident = float(d2)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # the dominant kernel on its own: stage call on the launch stream, HIP events
-    stream = torch.cuda.current_stream().cuda_stream
+    # The kernel that dominates the timed step (profiles/r05*/cfg{3,4}_kernel_summary.txt), timed on the HANDLE's own stream with HIP
+    # events around the call that launches it, SURVEY 8(d)'s bytes:
+    #   cfg3: scopeWaveLanczosKernel, one launch per channel strip (19 200 samples in, 153 601 vertices x 12 B + colours out), both with
+    #         the strips going to HBM (kernel_ms) and to the caller's pinned buffers over PCIe (kernel_ms_pinned_destination);
+    #   cfg4: vectorIngestKernel, one launch per 512-sample callback of 8 channels when the GPU keeps up (ring + eight one-pole filters).
+    hstream = (L.sgz_scope_stream if scope else L.sgz_vector_stream)(h.h)
     ev = HipEvents(2)
+    h.flush()
+    torch.cuda.synchronize()
+    extra_kernel = {}
     if scope:
-        ring = torch.from_numpy(synth.gen(3, int(sr), W, 2)).to(dev)
-        v = api.ScopeView(float(W), 0.0, 1.0, 1.0, width, 0)
-        npts = L.sgz_scope_num_points(C.byref(v))
-        verts = torch.zeros((2, npts, 2), dtype=torch.float32, device=dev)
-        call = lambda: api.check(L.sgz_scope_lanczos_device(C.byref(v), ring.data_ptr(), W, ring.stride(0), 2, verts.data_ptr(), stream))
-        alg = 2 * (W * 4 + npts * 8)
-        kname = "scopeLanczosKernel (both channels; the handle's scopeWaveLanczosKernel is the same arithmetic per channel)"
+        dxs = [torch.empty((nv, 3), dtype=torch.float32, device=dev) for _ in (0, 1)]
+        dcs = [torch.empty((nv, 4), dtype=torch.uint8, device=dev) for _ in (0, 1)]
+        evs = (C.c_uint32 * 2)(0, 1); chs = (C.c_uint32 * 2)(0, 0)
+
+        def strips(xptrs, cptrs, reps=30):
+            cnts = (C.c_uint32 * 2)(nv, nv)
+            tot = 0.0
+            for _ in range(reps):
+                cnts[0] = cnts[1] = nv
+                ev.record(0, hstream)
+                api.check(L.sgz_scope_vertices_all(h.h, C.byref(view), 2, evs, chs, xptrs, cptrs, cnts))
+                ev.record(1, hstream)
+                torch.cuda.synchronize()
+                tot += ev.elapsed_ms(0, 1)
+            return tot / reps / 2                                       # two launches per call
+        kern_ms = strips((C.c_void_p * 2)(dxs[0].data_ptr(), dxs[1].data_ptr()), (C.c_void_p * 2)(dcs[0].data_ptr(), dcs[1].data_ptr()))
+        extra_kernel["kernel_ms_pinned_destination"] = strips((C.c_void_p * 2)(outs[0][0].ctypes.data, outs[1][0].ctypes.data),
+                                                              (C.c_void_p * 2)(outs[0][1].ctypes.data, outs[1][1].ctypes.data))
+        alg = W * 4 + nv * 12
+        kname = "scopeWaveLanczosKernel (one channel's strip per launch; vertices + colours to HBM)"
     else:
-        xx = torch.from_numpy(synth.gen(4, int(sr), W, nch)).to(dev)
-        pol = torch.zeros((nch // 2, W, 3), dtype=torch.float32, device=dev)
-        call = lambda: api.check(L.sgz_vector_polar_device(xx.data_ptr(), xx.stride(0), nch // 2, W, 8, pol.data_ptr(), stream))
-        alg = (nch // 2) * (2 * W * 4 + W * 12)
-        kname = "vectorPolarKernel (4 pairs; the handle's vectorPolarViewKernel adds the colour stream)"
-    for _ in range(10):
-        call()
-    torch.cuda.synchronize()
-    ev.record(0, stream)
-    for _ in range(100):
-        call()
-    ev.record(1, stream)
-    torch.cuda.synchronize()
-    kern_ms = ev.elapsed_ms(0, 1) / 100
+        blk = np.ascontiguousarray(x[:, :512])
+        tot, reps = 0.0, 60
+        for _ in range(reps):
+            h.flush()
+            torch.cuda.synchronize()
+            ev.record(0, hstream)
+            push(blk)                                                   # an idle handle starts the block at once: one vectorIngestKernel
+            ev.record(1, hstream)
+            torch.cuda.synchronize()
+            tot += ev.elapsed_ms(0, 1)
+        kern_ms = tot / reps
+        alg = nch * 512 * 4 * 2                                         # 512 samples of 8 channels in, the same into the history ring
+        kname = "vectorIngestKernel (one 512-sample callback of 8 channels per launch)"
     if rank == 0:
         achieved = alg / (kern_ms * 1e-3) / 1e9
         out = {
@@ -334,10 +369,14 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                                "(vectorscope: sgz_vector_vertices_all, one wait for the four pairs)",
                        "parallelism": "replicas only" if world > 1 else "single device", "vertices_per_step": units,
                        "realtime_factor": (1 / 60) / (dt / nsteps), "pushes_refused_busy": refused, "host_loop": host,
-                       "ms_per_step_python_host": dt_python / nsteps * 1e3},
+                       "ms_per_step_python_host": dt_python / nsteps * 1e3,
+                       "ms_per_step_device_resident": (dt_resident / nsteps * 1e3) if dt_resident is not None else None,
+                       "device_resident_note": "the same frames with every vertex stream written to caller-owned DEVICE buffers (sgz_*_vertices_all on device memory)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
-                         "note": "a few MB per launch: the kernel is bound by its launch latency and (scope) its fp64 weight arithmetic, not by HBM"},
+                         "traffic": None, "kernel": kname, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg, **extra_kernel,
+                         "note": "the kernel that dominates the timed step, HIP events on the handle's stream around the call that launches it "
+                                 "(an event pair around one launch includes ~2 us of event overhead); a few MB per launch at most: bound by launch "
+                                 "latency, the PCIe stores (pinned destination) and (scope) its fp64 weight arithmetic, not by HBM"},
         }
         if emit:
             print(json.dumps(out), flush=True)
@@ -345,6 +384,39 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
         out = None
     h.close()
     return out
+
+
+def cfg5_extra(dev) -> dict:
+    """BASELINE configs[4] on ONE GPU, the largest single-GPU configuration (348 frames x 32 pairs at N = 65536): whole step and K_A alone,
+    the same protocol as the contract line (spin-up, K_A as batches of launches between one HIP event pair on the launch stream).  The 64
+    channels are the two channels of the cfg5 signal repeated (timing does not depend on the values; 1.5 GB of audio resident in HBM)."""
+    import torch
+    from signalizer_amd import api, config, sharding, synth
+    cfg = config.cfg5()
+    pairs, sr = cfg["num_pairs"], int(cfg["sample_rate"])
+    S = int(60 * sr)
+    two = torch.from_numpy(synth.gen(5, sr, S, 2)).to(dev)
+    x = two.repeat(pairs, 1).contiguous()
+    plan = api.Plan(cfg).upload()
+    F = plan.num_frames(S)
+    rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
+    for _ in range(6):
+        plan.render(x, rgba=rgba)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 10
+    for _ in range(steps):
+        plan.render(x, rgba=rgba)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    timer = sharding.TimeChunkRenderer(plan, x, rank=0, world=1)
+    kern_ms = timer.time_stft_kernel(iters=6, spin_ms=30.0)
+    bytes_per = 2 * cfg["window_size"] * 4 + 4 * plan.P
+    achieved = F * pairs * bytes_per / (kern_ms * 1e-3) / 1e9
+    return {"metric": "65536-pt stereo-pair STFT frames/sec, 32 pairs (75% overlap), one GPU", "value": F * pairs / dt, "unit": "frame-pairs/s",
+            "ms_per_step": dt * 1e3, "frames": F, "pairs": pairs, "kernel": "stftRealKernel<5, true, 0>", "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_launch": F * pairs * bytes_per, "roofline_frac": achieved / HBM_PEAK_GBPS,
+            "note": "BASELINE.json configs[4] as ONE 60 s job on one GPU (the sharded form is --workload cfg5 --gpus N); audio resident in HBM"}
 
 
 def rsnt_extra(dev, x_host) -> dict:
@@ -676,8 +748,11 @@ def main() -> None:
                 out["extras"][w] = {"metric": v["metric"], "value": v["value"], "unit": v["unit"], "ms_per_step": v["ms_per_step"],
                                     "vertices_per_step": v["config"]["vertices_per_step"], "realtime_factor": v["config"]["realtime_factor"],
                                     "pushes_refused_busy": v["config"]["pushes_refused_busy"], "kernel": v["roofline"]["kernel"],
-                                    "kernel_ms": v["roofline"]["kernel_ms"], "roofline_frac": v["roofline"]["frac"]}
+                                    "kernel_ms": v["roofline"]["kernel_ms"], "roofline_frac": v["roofline"]["frac"],
+                                    "ms_per_step_device_resident": v["config"]["ms_per_step_device_resident"],
+                                    "kernel_ms_pinned_destination": v["roofline"].get("kernel_ms_pinned_destination")}
             out["extras"]["rsnt"] = rsnt_extra(dev, x_host)
+            out["extras"]["cfg5"] = cfg5_extra(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_pairs(cfg, x_host) if strong else cpu_baseline(cfg, x_host)
         print(json.dumps(out), flush=True)

@@ -592,6 +592,9 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
  * rules; any failing item fails the call (counts[k] holds the required size where a buffer was too small). */
 sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint32_t items, const uint32_t *evaluators, const uint32_t *channels,
                                   float *const *xyz, uint8_t *const *rgba, uint32_t *counts);
+/* (the buffers of sgz_scope_vertices_all may also be DEVICE memory -- all of them --: the kernels then write HBM, one wait, nothing crosses PCIe) */
+/* the hipStream_t the handle enqueues its work on (so that a host can order or time its own device work against the handle's) */
+void      *sgz_scope_stream(sgz_scope *s);
 /* The same stream into DEVICE buffers -- a mapped vertex buffer object, or memory from sgz_export_alloc that the display GPU's GL /
  * Vulkan imported -- without the D2H copy.  In place when the call returns. */
 sgz_status sgz_scope_vertices_device(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
@@ -648,6 +651,8 @@ sgz_status sgz_vector_vertices_device(sgz_vector *s, uint32_t pair, float *d_xyz
 /* every pair's stream with ONE wait for the GPU (the render thread draws all pairs of a frame, VectorscopeRendering.cpp:253-276):
  * xyz / rgb: float3 [num_channels / 2][window_size]; *count: in = capacity PER PAIR, out = window_size */
 sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32_t *count);
+/* (xyz / rgb of sgz_vector_vertices_all may also be DEVICE memory: the vertices stay in HBM) */
+void      *sgz_vector_stream(sgz_vector *s);       /* as sgz_scope_stream */
 /* parity hook: history ring memory of one channel + the write cursor */
 sgz_status sgz_vector_history(sgz_vector *s, uint32_t channel, float *out /*window_size*/, uint32_t *size, uint32_t *cursor);
 

@@ -130,7 +130,7 @@ EXPORTS = [
     "sgz_spectrum_pop_column", "sgz_spectrum_line_results", "sgz_spectrum_clear_state", "sgz_spectrum_set_mix",
     "sgz_spectrogram_render_host", "sgz_spectrum_stats", "sgz_spectrum_history", "sgz_spectrum_bind_image", "sgz_spectrum_create_image", "sgz_spectrum_bind_gl_buffer",
     "sgz_spectrum_flush_columns", "sgz_spectrum_render_lines", "sgz_spectrum_set_option",
-    "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_set_option", "sgz_vector_set_option", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
+    "sgz_scope_create", "sgz_scope_destroy", "sgz_scope_configure", "sgz_scope_set_option", "sgz_vector_set_option", "sgz_scope_stream", "sgz_vector_stream", "sgz_scope_push", "sgz_scope_peak_filter", "sgz_scope_gains",
     "sgz_scope_vertex_count", "sgz_scope_vertices", "sgz_scope_vertices_all", "sgz_scope_front", "sgz_scope_debug_state", "sgz_scope_analyse",
     "sgz_scope_front_colours", "sgz_scope_vertices_device", "sgz_vector_vertices_device", "sgz_export_alloc", "sgz_export_free",
     "sgz_vector_create", "sgz_vector_destroy", "sgz_vector_configure", "sgz_vector_push", "sgz_vector_peak_filter",
@@ -227,6 +227,10 @@ def lib() -> C.CDLL:
     L.sgz_spectrum_flush_columns.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.sgz_scope_create.argtypes = [C.POINTER(ScopeConfig), C.POINTER(vp)]
     L.sgz_scope_set_option.argtypes = [vp, u32, C.c_uint64]
+    L.sgz_scope_stream.argtypes = [vp]
+    L.sgz_scope_stream.restype = vp
+    L.sgz_vector_stream.argtypes = [vp]
+    L.sgz_vector_stream.restype = vp
     L.sgz_vector_set_option.argtypes = [vp, u32, C.c_uint64]
     L.sgz_scope_destroy.argtypes = [vp]
     L.sgz_scope_destroy.restype = None

@@ -24,9 +24,10 @@ inline bool isPinnedHost(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
-// The address under which a kernel can write `p` directly, if `p` is pinned host memory that is mapped into the device's address space
-// (hipHostMalloc, hipHostRegister with hipHostRegisterMapped; torch's pin_memory): the vertex kernels then store straight into the
-// caller's buffers over PCIe -- no device-side staging, no DMA copy behind the kernel.  nullptr otherwise.
+// The address under which a kernel can write `p` directly: `p` itself for DEVICE memory (a mapped vertex buffer object, exported memory
+// the display GPU imported: the vertices stay in HBM), or the device-side alias of pinned host memory that is mapped into the device's
+// address space (hipHostMalloc, hipHostRegister with hipHostRegisterMapped; torch's pin_memory): the vertex kernels then store straight
+// into the caller's buffers over PCIe -- no device-side staging, no DMA copy behind the kernel.  nullptr otherwise (pageable memory).
 inline void *mappedDevicePointer(const void *p)
 {
 #ifdef SGZ_NO_DIRECT_HOST_WRITES
@@ -34,6 +35,7 @@ inline void *mappedDevicePointer(const void *p)
 #else
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type == hipMemoryTypeDevice) return (reinterpret_cast<uintptr_t>(p) & 3) ? nullptr : const_cast<void *>(p);
     if (at.type != hipMemoryTypeHost || !at.devicePointer || (reinterpret_cast<uintptr_t>(at.devicePointer) & 3)) return nullptr;
     return at.devicePointer;
 #endif

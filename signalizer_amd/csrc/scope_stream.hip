@@ -1648,6 +1648,8 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     return st;
 }
 
+void *sgz_scope_stream(sgz_scope *s) { return s ? s->stream : nullptr; }
+
 sgz_status sgz_scope_set_option(sgz_scope *s, uint32_t option, uint64_t value)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");

@@ -499,6 +499,8 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     return st;
 }
 
+void *sgz_vector_stream(sgz_vector *s) { return s ? s->stream : nullptr; }
+
 sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");

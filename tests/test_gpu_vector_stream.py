@@ -271,3 +271,47 @@ def test_audio_and_render_threads_run_concurrently(gpu, oracle):
     assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32))
     assert np.abs(np.array(f.phase[:]) - np.array(ref.f.phase[:])).max() <= 1e-5
     dev.close()
+
+
+def test_vertices_all_into_device_memory(gpu):
+    """sgz_vector_vertices_all / sgz_scope_vertices_all with DEVICE buffers: the vertex kernels write HBM themselves, one wait, the same
+    bytes the host-buffer form returns (the device-resident hand-off bench.py times as ms_per_step_device_resident)"""
+    import ctypes as C
+    import torch
+    L = api.lib()
+    dev = api.Vector(sample_rate=SR, num_channels=4, window_size=3000, envelope_mode=1, lanes=8, fade_history=1, max_block=4096,
+                     envelope_window=0.3, stereo_window=0.05, colours=[(1.0, 0.5, 0.25), (0.2, 0.9, 0.4)])
+    x = synth.gen(12, SR, 9000, 4)
+    for pos in range(0, x.shape[1], 700):
+        _push(dev, x[:, pos:pos + 700])
+    want_xyz, want_rgb = dev.vertices_all()
+    d_xyz = torch.full((2, 3000, 3), float("nan"), dtype=torch.float32, device=gpu)
+    d_rgb = torch.zeros((2, 3000, 3), dtype=torch.float32, device=gpu)
+    cnt = C.c_uint32(3000)
+    api.check(L.sgz_vector_vertices_all(dev.h, C.c_void_p(d_xyz.data_ptr()), C.c_void_p(d_rgb.data_ptr()), C.byref(cnt)))
+    assert cnt.value == 3000
+    assert np.array_equal(d_xyz.cpu().numpy().view(np.uint32), want_xyz.view(np.uint32))
+    assert np.array_equal(d_rgb.cpu().numpy().view(np.uint32), want_rgb.view(np.uint32))
+    # Oscilloscope: two strips
+    sc = api.Scope(sample_rate=48000.0, window_size=2000.0, num_channels=2, trigger_mode=4, channel_mode=0, envelope_mode=0, interpolation=3,
+                   max_block=4096, trigger_threshold=0.05, trigger_channel=1.0, envelope_window=0.3)
+    y = synth.gen(13, 48000, 12000, 2)
+    for pos in range(0, y.shape[1], 900):
+        blk = np.ascontiguousarray(y[:, pos:pos + 900])
+        while sc.push(blk) == api.SGZ_BUSY:
+            pass
+    v = api.ScopeView(2000.0, 0.0, 1.0, 1.0, 4001, 0)
+    n = L.sgz_scope_vertex_count(sc.h, C.byref(v))
+    host = [(np.zeros((n, 3), np.float32), np.zeros((n, 4), np.uint8)) for _ in (0, 1)]
+    want = sc.vertices_all(v, (0, 1), (0, 0), host)
+    dx = [torch.full((n, 3), float("nan"), dtype=torch.float32, device=gpu) for _ in (0, 1)]
+    dc = [torch.zeros((n, 4), dtype=torch.uint8, device=gpu) for _ in (0, 1)]
+    ev = (C.c_uint32 * 2)(0, 1); ch = (C.c_uint32 * 2)(0, 0)
+    xs = (C.c_void_p * 2)(dx[0].data_ptr(), dx[1].data_ptr()); cs = (C.c_void_p * 2)(dc[0].data_ptr(), dc[1].data_ptr())
+    cnts = (C.c_uint32 * 2)(n, n)
+    api.check(L.sgz_scope_vertices_all(sc.h, C.byref(v), 2, ev, ch, xs, cs, cnts))
+    for k in (0, 1):
+        m = cnts[k]
+        assert m == want[k][0].shape[0]
+        assert np.array_equal(dx[k].cpu().numpy()[:m].view(np.uint32), want[k][0].view(np.uint32))
+        assert np.array_equal(dc[k].cpu().numpy()[:m], want[k][1])
