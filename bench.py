@@ -310,7 +310,7 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
         dt = float(t.item())
     # The kernel that dominates the timed step (profiles/r05*/cfg{3,4}_kernel_summary.txt), timed on the HANDLE's own stream with HIP
     # events around the call that launches it, SURVEY 8(d)'s bytes:
-    #   cfg3: scopeWaveLanczosKernel, one launch per channel strip (19 200 samples in, 153 601 vertices x 12 B + colours out), both with
+    #   cfg3: scopeWaveLanczosKernel<2>, both channel strips in one launch (2 x (19 200 samples in, 153 601 vertices x 12 B + colours out)), with
     #         the strips going to HBM (kernel_ms) and to the caller's pinned buffers over PCIe (kernel_ms_pinned_destination);
     #   cfg4: vectorIngestKernel, one launch per 512-sample callback of 8 channels when the GPU keeps up (ring + eight one-pole filters).
     hstream = (L.sgz_scope_stream if scope else L.sgz_vector_stream)(h.h)
@@ -333,12 +333,12 @@ def views_workload(args, rank, world, dev, workload=None, steps=None, emit=True)
                 ev.record(1, hstream)
                 torch.cuda.synchronize()
                 tot += ev.elapsed_ms(0, 1)
-            return tot / reps / 2                                       # two launches per call
+            return tot / reps                                           # ONE launch for both strips (shared tap weights)
         kern_ms = strips((C.c_void_p * 2)(dxs[0].data_ptr(), dxs[1].data_ptr()), (C.c_void_p * 2)(dcs[0].data_ptr(), dcs[1].data_ptr()))
         extra_kernel["kernel_ms_pinned_destination"] = strips((C.c_void_p * 2)(outs[0][0].ctypes.data, outs[1][0].ctypes.data),
                                                               (C.c_void_p * 2)(outs[0][1].ctypes.data, outs[1][1].ctypes.data))
-        alg = W * 4 + nv * 12
-        kname = "scopeWaveLanczosKernel (one channel's strip per launch; vertices + colours to HBM)"
+        alg = 2 * (W * 4 + nv * 12)
+        kname = "scopeWaveLanczosKernel<2> (both channels' strips in one launch, shared tap weights; vertices + colours to HBM)"
     else:
         blk = np.ascontiguousarray(x[:, :512])
         tot, reps = 0.0, 60

@@ -55,6 +55,10 @@ using namespace sgz;
 
 namespace sgz {
 // scope_vector.hip: Lanczos / linear vertex kernels on a ring whose cursor lives in device memory
+bool launchScopeLanczosPair(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *const ringA[2],
+                            const float *const ringB[2], const uint32_t evalMode[2], uint32_t size, uint32_t cap, const uint32_t *d_cursor,
+                            double cycleSamples, double sampleOffset, long long transport, const uint32_t key[2], const uint32_t *const colRing[2],
+                            float *const d_xyz[2], uint32_t *const d_rgba[2], size_t capacity, size_t *points, hipStream_t stream, hipError_t *err);
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
                                const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
                                double cycleSamples, double sampleOffset, long long transport, uint32_t rgba, const uint32_t *colRing, float *d_xyz,
@@ -1822,12 +1826,11 @@ sgz_status sgz_scope_analyse(sgz_scope *s, uint32_t evaluator, uint32_t channel,
 }
 
 // one evaluator's vertex stream into DEVICE buffers (the handle's own, or the caller's mapped VBO); *points = vertices written
-static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
-                                    uint32_t *d_rgba, size_t capacity, size_t *points)
+// what an evaluator reads: SampleColourEvaluator<OscChannels::...>, SampleColourEvaluators.h: Left / Right one channel, Mid / Side 0.5 (l +- r)
+struct StripSource { const float *ringA, *ringB; const uint32_t *colRing; uint32_t evalMode, key; };
+static sgz_status scopeStripSource(sgz_scope *s, uint32_t evaluator, uint32_t channel, bool wantColours, StripSource *out)
 {
-    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
     const uint32_t C = s->cfg.num_channels;
-    // SampleColourEvaluator<OscChannels::...>, SampleColourEvaluators.h: Left / Right read one channel, Mid / Side 0.5 (l +- r)
     uint32_t chA, chB, evalMode, colourCh;
     switch (evaluator) {
     case SGZ_OSC_LEFT: chA = chB = channel; evalMode = 0; colourCh = channel; break;
@@ -1837,19 +1840,51 @@ static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, ui
     default: return fail(SGZ_EINVAL, "evaluator: SGZ_OSC_LEFT / RIGHT / MID / SIDE");
     }
     if (chA >= C || chB >= C) return fail(SGZ_EINVAL, "channel out of range");
-    sgz_scope_view v = *view;
-    v.window_size = s->cfg.window_size;                               // state.effectiveWindowSize is the stream's
     uint32_t key;
     std::memcpy(&key, s->cfg.colours[colourCh], 4);                    // evaluator.getDefaultKey()
     // colourChannelsByFrequency: Left / Right read colourData of their channel, Mid / Side auxColourData (SampleColourEvaluators.h:64,183)
     const uint32_t *colRing = nullptr;
-    if (s->cfg.colour_by_frequency && d_rgba)
+    if (s->cfg.colour_by_frequency && wantColours)
         colRing = s->col.front + size_t((evalMode == 0 ? 0u : C) + colourCh) * s->size;
-    SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, s->d_front + size_t(chA) * s->size,
-                                s->d_front + size_t(chB) * s->size, evalMode, uint32_t(s->trig.ring_size), s->size,
+    *out = StripSource{s->d_front + size_t(chA) * s->size, s->d_front + size_t(chB) * s->size, colRing, evalMode, key};
+    return SGZ_OK;
+}
+
+static sgz_status scopeVerticesInto(sgz_scope *s, const sgz_scope_view *view, uint32_t evaluator, uint32_t channel, float *d_xyz,
+                                    uint32_t *d_rgba, size_t capacity, size_t *points)
+{
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;            // (flush on read: the blocks that wait in the open batch come first)
+    StripSource src;
+    if (sgz_status st = scopeStripSource(s, evaluator, channel, d_rgba != nullptr, &src); st != SGZ_OK) return st;
+    sgz_scope_view v = *view;
+    v.window_size = s->cfg.window_size;                               // state.effectiveWindowSize is the stream's
+    SGZ_HIP(launchScopeVertices(v, s->cfg.trigger_mode, s->cfg.interpolation, src.ringA, src.ringB, src.evalMode, uint32_t(s->trig.ring_size), s->size,
                                 reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
-                                s->trig.cycle_samples, s->trig.sample_offset, s->transport.load(std::memory_order_relaxed), key, colRing, d_xyz,
+                                s->trig.cycle_samples, s->trig.sample_offset, s->transport.load(std::memory_order_relaxed), src.key, src.colRing, d_xyz,
                                 d_rgba, capacity, points, s->stream));
+    return SGZ_OK;
+}
+
+// two strips of one view: Lanczos strips share their tap weights in ONE launch (scope_vector.hip scopeWaveLanczosKernel<2>); false: not Lanczos
+static sgz_status scopeVerticesPairInto(sgz_scope *s, const sgz_scope_view *view, const uint32_t *evaluators, const uint32_t *channels,
+                                        float *const d_xyz[2], uint32_t *const d_rgba[2], size_t capacity, size_t *points, bool *done)
+{
+    *done = false;
+    if (sgz_status sy = scopeSync(s); sy != SGZ_OK) return sy;
+    StripSource a, b;
+    if (sgz_status st = scopeStripSource(s, evaluators[0], channels[0], d_rgba[0] != nullptr, &a); st != SGZ_OK) return st;
+    if (sgz_status st = scopeStripSource(s, evaluators[1], channels[1], d_rgba[1] != nullptr, &b); st != SGZ_OK) return st;
+    sgz_scope_view v = *view;
+    v.window_size = s->cfg.window_size;
+    const float *ra[2] = {a.ringA, b.ringA}, *rb[2] = {a.ringB, b.ringB};
+    const uint32_t em[2] = {a.evalMode, b.evalMode}, key[2] = {a.key, b.key};
+    const uint32_t *cr[2] = {a.colRing, b.colRing};
+    hipError_t e = hipSuccess;
+    *done = launchScopeLanczosPair(v, s->cfg.trigger_mode, s->cfg.interpolation, ra, rb, em, uint32_t(s->trig.ring_size), s->size,
+                                   reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s->d_state) + offsetof(ScopeDev, frontCursor)),
+                                   s->trig.cycle_samples, s->trig.sample_offset, s->transport.load(std::memory_order_relaxed), key, cr, d_xyz, d_rgba,
+                                   capacity, points, s->stream, &e);
+    if (*done) SGZ_HIP(e);
     return SGZ_OK;
 }
 
@@ -1915,6 +1950,15 @@ sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint
     }
     for (uint32_t k = 0; k < items; ++k) {
         size_t points = 0;
+        if (k + 1 < items) {                                  // two strips at a time when they are Lanczos strips (shared tap weights, one launch)
+            float *px[2] = {static_cast<float *>(mappedDevicePointer(xyz[k])), static_cast<float *>(mappedDevicePointer(xyz[k + 1]))};
+            uint32_t *pc[2] = {rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k])) : nullptr,
+                               rgba && rgba[k + 1] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k + 1])) : nullptr};
+            bool done = false;
+            const sgz_status sp = scopeVerticesPairInto(s, view, evaluators + k, channels + k, px, pc, need, &points, &done);
+            if (sp != SGZ_OK) { (void)hipStreamSynchronize(s->stream); return sp; }
+            if (done) { counts[k] = counts[k + 1] = uint32_t(points); ++k; continue; }
+        }
         const sgz_status st = scopeVerticesInto(s, view, evaluators[k], channels[k], static_cast<float *>(mappedDevicePointer(xyz[k])),
                                                 rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k])) : nullptr, need, &points);
         if (st != SGZ_OK) { (void)hipStreamSynchronize(s->stream); return st; }

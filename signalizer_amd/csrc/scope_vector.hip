@@ -165,10 +165,17 @@ __device__ __forceinline__ uint32_t lerpRgba(uint32_t a, uint32_t b, double t)
     return out;
 }
 
+// Up to kWaveItems line strips of ONE view in one launch (the two channels of a rendered frame: sgz_scope_vertices_all): the twenty
+// fp64 tap weights of a point -- a sine, a sine / cosine pair and twenty divisions -- depend on the view alone and are computed once
+// for all strips.  Item fields are separate kernel arguments indexed at compile time (a run-time subscript into a by-value argument
+// struct would move it to scratch).
+constexpr int kWaveItems = 2;
+struct WaveItem { const float *ringA, *ringB; const uint32_t *colRing; float3 *xyz; uint32_t *rgba; uint32_t evalMode, key; };
+
+template <int K>
 __global__ void __launch_bounds__(256)
-scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode, uint32_t len, uint32_t cap, const uint32_t *d_cursor,
-                       size_t points, double samplePos0, double spp, double unit0, double inc, long cursor0, uint32_t key,
-                       const uint32_t *colRing, float3 *xyz, uint32_t *rgba)
+scopeWaveLanczosKernel(const WaveItem it0, const WaveItem it1, uint32_t len, uint32_t cap, const uint32_t *d_cursor,
+                       size_t points, double samplePos0, double spp, double unit0, double inc, long cursor0)
 {
     const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= points) return;
@@ -181,12 +188,26 @@ scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode
     const long cur = cursor0 + long(shifts);                // logical position of kernel[0]
     const double kPi = 3.14159265358979323846;
     const long rn = long(rint(x));
-    const double e = x - double(rn);
+    const double e = x - double(rn);                        // in [-1/2, 1/2]
     const double sPi = sin(kPi * e);
     double s10, c10;
     sincos(kPi * e / 10.0, &s10, &c10);
-    double acc = 0.0;
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
     const long idx0 = cur + (fl - 9);
+    // ringPhys(idx0 + t, ..) for the twenty taps and the two colour samples: ONE 64-bit modulo per thread (it costs ~100 instructions,
+    // and twenty-two of them were most of this kernel), then steps of one with a wrap -- the same indices
+    long q0l = idx0 % long(len);
+    if (q0l < 0) q0l += long(len);
+    const uint32_t q0 = uint32_t(q0l), lead = base + (cap - len);
+    auto physAt = [&](uint32_t t) {
+        uint32_t q = q0 + t;
+        while (q >= len) q -= len;
+        uint32_t ph = lead + q;
+        while (ph >= cap) ph -= cap;
+        return ph;
+    };
 #pragma unroll
     for (int t = 0; t < 20; ++t) {
         const long i = fl - 9 + t;
@@ -203,12 +224,18 @@ scopeWaveLanczosKernel(const float *ringA, const float *ringB, uint32_t evalMode
             const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
             wt = 10.0 * sa * sb / (pd * pd);
         }
-        acc += double(evalSample(ringA, ringB, evalMode, ringPhys(idx0 + t, base, cap, len))) * wt;
+        const uint32_t ph = physAt(uint32_t(t));
+        acc[0] += double(evalSample(it0.ringA, it0.ringB, it0.evalMode, ph)) * wt;
+        if constexpr (K > 1) acc[1] += double(evalSample(it1.ringA, it1.ringB, it1.evalMode, ph)) * wt;
     }
-    xyz[p] = make_float3(float(unit0 + double(p) * inc), float(acc), 0.f);
-    if (rgba) {
-        // colourChannelsByFrequency: the colours of the two newest kernel samples, blended by delta (:836-843, :874-877)
-        rgba[p] = colRing ? lerpRgba(colRing[ringPhys(cur + 19, base, cap, len)], colRing[ringPhys(cur + 20, base, cap, len)], delta) : key;
+    const float ux = float(unit0 + double(p) * inc);
+    const uint32_t tc = uint32_t(28 - fl);                   // cur + 19 = idx0 + (19 - (fl - 9))
+    // colourChannelsByFrequency: the colours of the two newest kernel samples, blended by delta (:836-843, :874-877)
+    it0.xyz[p] = make_float3(ux, float(acc[0]), 0.f);
+    if (it0.rgba) it0.rgba[p] = it0.colRing ? lerpRgba(it0.colRing[physAt(tc)], it0.colRing[physAt(tc + 1u)], delta) : it0.key;
+    if constexpr (K > 1) {
+        it1.xyz[p] = make_float3(ux, float(acc[1]), 0.f);
+        if (it1.rgba) it1.rgba[p] = it1.colRing ? lerpRgba(it1.colRing[physAt(tc)], it1.colRing[physAt(tc + 1u)], delta) : it1.key;
     }
 }
 
@@ -498,6 +525,26 @@ size_t scopeVertexCount(const sgz_scope_view &view, uint32_t interpolation, uint
     return waveIsRect(view, interpolation) ? 2 * samples : samples;
 }
 
+// Two Lanczos strips of one view in ONE launch (shared tap weights); false when the view's strips are not Lanczos (the caller then
+// launches them one by one)
+bool launchScopeLanczosPair(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *const ringA[2],
+                            const float *const ringB[2], const uint32_t evalMode[2], uint32_t size, uint32_t cap, const uint32_t *d_cursor,
+                            double cycleSamples, double sampleOffset, long long transport, const uint32_t key[2], const uint32_t *const colRing[2],
+                            float *const d_xyz[2], uint32_t *const d_rgba[2], size_t capacity, size_t *points, hipStream_t stream, hipError_t *err)
+{
+    if (!waveIsLanczos(view, interpolation)) return false;
+    const int block = 256;
+    const ScopeScalars s = scopeDerive(view, size, triggerMode, cycleSamples, sampleOffset, transport);
+    if (s.points > capacity) { *err = hipErrorInvalidValue; return true; }
+    const WaveItem a{ringA[0], ringB[0], colRing[0], reinterpret_cast<float3 *>(d_xyz[0]), d_rgba[0], evalMode[0], key[0]};
+    const WaveItem b{ringA[1], ringB[1], colRing[1], reinterpret_cast<float3 *>(d_xyz[1]), d_rgba[1], evalMode[1], key[1]};
+    hipLaunchKernelGGL(scopeWaveLanczosKernel<2>, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, a, b, size, cap,
+                       d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0);
+    *points = s.points;
+    *err = hipGetLastError();
+    return true;
+}
+
 // ringA / ringB / colRing: one channel's plane of the physical ring (`cap` elements); `size`: the reference's ring of the moment
 hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode, uint32_t interpolation, const float *ringA,
                                const float *ringB, uint32_t evalMode, uint32_t size, uint32_t cap, const uint32_t *d_cursor,
@@ -508,9 +555,9 @@ hipError_t launchScopeVertices(const sgz_scope_view &view, uint32_t triggerMode,
     if (waveIsLanczos(view, interpolation)) {
         const ScopeScalars s = scopeDerive(view, size, triggerMode, cycleSamples, sampleOffset, transport);
         if (s.points > capacity) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(scopeWaveLanczosKernel, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, ringA, ringB,
-                           evalMode, size, cap, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0, rgba,
-                           colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba);
+        const WaveItem it{ringA, ringB, colRing, reinterpret_cast<float3 *>(d_xyz), d_rgba, evalMode, rgba};
+        hipLaunchKernelGGL(scopeWaveLanczosKernel<1>, dim3(unsigned((s.points + block - 1) / block)), dim3(block), 0, stream, it, it,
+                           size, cap, d_cursor, s.points, s.samplePos0, s.samplesPerPixel, s.unit0, s.inc, s.cursor0);
         *points = s.points;
     } else {
         const long roundedWindow = long(std::ceil(view.window_size));
