@@ -277,6 +277,83 @@ def _rccl_worker(q, S, cfg):
     q.put((ref, out))
 
 
+def _rccl_worker_n(q, S, cfg, rank, world, port):
+    """rank `rank` of `world` processes, one GPU each, on the real backends: torch.distributed 'nccl' (= RCCL) through TimeChunkRenderer,
+    and the C ABI's sgz_spectrogram_render_sharded on an RCCL communicator of its own; rank r holds samples [r S, (r + 1) S)"""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from signalizer_amd import api
+    from signalizer_amd.sharding import TimeChunkRenderer
+    api.check(api.lib().sgz_set_device(rank))
+    full = synth.gen(79, 48000, S * world, 2 * cfg["num_pairs"])
+    x = torch.from_numpy(np.ascontiguousarray(full[:, rank * S:(rank + 1) * S])).to(dev)
+    plan = api.Plan(cfg).upload()
+    out = {}
+    for halo in ("p2p", "allgather"):
+        r = TimeChunkRenderer(plan, x, rank=rank, world=world, halo=halo)
+        out[halo] = r.render()[:r.local_frames].cpu().numpy().copy()
+    L = api.lib()
+    uid = (C.c_uint8 * 128)()
+    if rank == 0:
+        api.check(L.sgz_comm_unique_id(uid))
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=0)
+    uid = (C.c_uint8 * 128)(*box[0])
+    comm = C.c_void_p()
+    api.check(L.sgz_comm_create(uid, rank, world, C.byref(comm)))
+    buf = torch.zeros((x.shape[0], S + cfg["window_size"]), dtype=torch.float32, device=dev)
+    buf[:, :S] = x
+    lf = C.c_uint64()
+    api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), None, None, None))
+    frames = C.c_uint64(0)
+    rgba = torch.empty((max(int(lf.value), 1), plan.P, 4), dtype=torch.uint8, device=dev)
+    api.check(L.sgz_spectrogram_render_sharded(plan.h, comm, rank, world, buf.data_ptr(), buf.stride(0), S, rgba.data_ptr(), C.byref(frames),
+                                               torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    out["c_abi"] = rgba[:int(frames.value)].cpu().numpy().copy()
+    ref = plan.render(torch.from_numpy(full).to(dev)).cpu().numpy() if rank == 0 else None
+    L.sgz_comm_destroy(comm)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ref, out))
+
+
+@pytest.mark.parametrize("window,hop,pairs,S", [(32768, 8192, 1, 32768 * 3 + 1234), (4096, 1024, 2, 4096 * 4)])
+def test_rccl_paths_at_world_two(gpu, window, hop, pairs, S):
+    """The same on TWO GPUs when the box has them (skipped on a one-GPU box): the halo really crosses xGMI, the end states are really
+    all-gathered by RCCL, and the concatenated columns are the single-device render's, bit for bit -- so that the first scaling run on a
+    node exercises code a test has walked."""
+    from signalizer_amd import api
+    if api.lib().sgz_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    cfg = config.spectrum_config(window_size=window, hop=hop, num_pairs=pairs, axis_points=256, pole=(0.97, 0.5))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker_n, args=(q, S, cfg, r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    ref = None
+    for _ in range(2):
+        rank, rf, out = q.get(timeout=300)
+        got[rank] = out
+        ref = rf if rf is not None else ref
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in ("p2p", "allgather", "c_abi"):
+        whole = np.concatenate([got[0][k], got[1][k]])
+        assert whole.shape == ref.shape and np.array_equal(whole, ref), k
+
+
 @pytest.mark.parametrize("window,hop,pairs,S", [(32768, 8192, 1, 32768 * 4 + 100), (65536, 16384, 4, 65536 * 3)])
 def test_rccl_paths_at_world_one(gpu, window, hop, pairs, S):
     """the `nccl` backend and the RCCL communicator of the C ABI really run ('the nccl path has never executed'): one
@@ -326,22 +403,28 @@ def test_peer_copy_transport_ranks_as_threads_of_one_process(gpu, window, hop, p
     L.sgz_spectrogram_render_sharded_on.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
                                                     C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
     group = C.c_void_p()
-    devices = (C.c_int * world)(*([0] * world))
+    # distinct GPUs when the box has them (then the copies are real peer copies and the cross-device event handshake of sharded.hip runs);
+    # on a one-GPU box every rank's "device" is GPU 0
+    ndev = L.sgz_device_count()
+    dev_of = list(range(world)) if ndev >= world else [0] * world
+    devices = (C.c_int * world)(*dev_of)
     api.check(L.sgz_peer_group_create(world, devices, C.byref(group)))
     full = synth.gen(78, 48000, S * world, 2 * pairs)
     results, errors = {}, []
 
     def rank_main(rank):
         try:
-            torch.cuda.set_device(0)
-            stream = torch.cuda.Stream()
+            mine = torch.device("cuda", dev_of[rank])
+            torch.cuda.set_device(mine)
+            api.check(L.sgz_set_device(dev_of[rank]))
+            stream = torch.cuda.Stream(device=mine)
             with torch.cuda.stream(stream):
-                buf = torch.zeros((full.shape[0], (S + window + 63) // 64 * 64), dtype=torch.float32, device=gpu)
-                buf[:, :S] = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy()).to(gpu)
+                buf = torch.zeros((full.shape[0], (S + window + 63) // 64 * 64), dtype=torch.float32, device=mine)
+                buf[:, :S] = torch.from_numpy(full[:, rank * S:(rank + 1) * S].copy()).to(mine)
                 plan = api.Plan(cfg).upload()
                 lf = C.c_uint64()
                 api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), None, None, None))
-                rgba = torch.empty((max(int(lf.value), 1), plan.P, 4), dtype=torch.uint8, device=gpu)
+                rgba = torch.empty((max(int(lf.value), 1), plan.P, 4), dtype=torch.uint8, device=mine)
                 tr, store = Transport(), C.c_void_p()
                 api.check(L.sgz_peer_transport(group, rank, C.byref(tr), C.byref(store)))
                 outs = []
@@ -365,6 +448,8 @@ def test_peer_copy_transport_ranks_as_threads_of_one_process(gpu, window, hop, p
         t.join(timeout=120)
     assert not errors and not any(t.is_alive() for t in threads), errors
     L.sgz_peer_group_destroy(group)
+    torch.cuda.set_device(0)
+    api.check(L.sgz_set_device(0))
     ref = api.Plan(cfg).upload().render(torch.from_numpy(full).to(gpu)).cpu().numpy()
     out = np.concatenate([results[r] for r in range(world)])
     assert out.shape == ref.shape and np.array_equal(out, ref)
