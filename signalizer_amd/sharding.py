@@ -93,7 +93,8 @@ class GpuBackend:
 
 
 class TimeChunkRenderer:
-    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1, backend=None, halo: str = "p2p", always_collective: bool = False):
+    def __init__(self, plan, chunk_audio, rank: int = 0, world: int = 1, backend=None, halo: str = "p2p", always_collective: bool = False,
+                 rotate_bytes: int = 0):
         import torch
         self.torch = torch
         self.plan = plan
@@ -114,6 +115,13 @@ class TimeChunkRenderer:
         # (row stride a multiple of 64 samples: the channel-split K_A fetches sample pairs and needs 8-byte aligned rows)
         self.buf = torch.zeros((self.nch, (S + max(self.halo_max, 1) + 63) // 64 * 64), dtype=torch.float32, device=dev)
         self.buf[:, :S] = chunk_audio
+        # rotate_bytes > 0 (bench.py): consecutive renders read DISTINCT copies of the audio, enough of them to exceed `rotate_bytes` -- past
+        # the 256 MB Infinity Cache every render then streams its input from HBM instead of re-reading a cache-resident buffer
+        self._bufs = [self.buf]
+        if rotate_bytes > 0 and self.buf.is_cuda:
+            per = self.buf.numel() * 4
+            self._bufs += [self.buf.clone() for _ in range(max(0, -(-rotate_bytes // per) - 1))]
+        self._turn = 0
         self.S, self.W = S, W
         self.local_frames = self.sp.local_frames
         P, C = plan.P, plan.C
@@ -128,6 +136,11 @@ class TimeChunkRenderer:
             self.agg_all = torch.empty((world, C, 2, P, 2), dtype=torch.float32, device=dev)
             self.carry = torch.zeros((C, 2, P, 2), dtype=torch.float32, device=dev)
             self.frames_per_rank = [self.sp.frames_of(r) for r in range(world)]
+
+    def _rotate(self):
+        if len(self._bufs) > 1:
+            self._turn = (self._turn + 1) % len(self._bufs)
+            self.buf = self._bufs[self._turn]
 
     def _view(self):
         off = self.sp.local_offset
@@ -173,6 +186,7 @@ class TimeChunkRenderer:
 
     def render(self):
         """one full pass; returns this rank's RGBA8 columns [local_frames, P, 4]"""
+        self._rotate()
         if not self.collective:
             # single device: start from a zero decay state, nobody needs the end state -> no memset, no snapshot
             self.backend.render(self._view(), self.rgba, None)
@@ -234,8 +248,11 @@ class TimeChunkRenderer:
         F = self.local_frames
         mapped = torch.empty((F, self.plan.C, self.plan.sides, self.plan.P), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream().cuda_stream
-        call = lambda: api.check(api.lib().sgz_stage_mapped_dominant(self.plan.h, x.data_ptr(), x.stride(0), x.shape[1],
-                                                           mapped.data_ptr(), stream))
+
+        def call():                                                   # (rotating over the input copies like render())
+            self._rotate()
+            v = self._view()
+            api.check(api.lib().sgz_stage_mapped_dominant(self.plan.h, v.data_ptr(), v.stride(0), v.shape[1], mapped.data_ptr(), stream))
         # `spin_ms` of untimed launches first: the device's clock settles only under sustained load (tools/clock_ramp_probe.py), and a
         # host wait after every launch would idle the GPU for ~20 us each time
         import time

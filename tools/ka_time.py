@@ -47,7 +47,7 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         # SGZ_BUFFERS=n (cfg2 only): the launches rotate over n distinct copies of the audio -- 16 x 23 MB is past the 256 MB Infinity Cache,
         # so every launch streams its input from HBM (the default loop re-renders one buffer, which stays cache-resident)
-        nbuf = int(os.environ.get('SGZ_BUFFERS', '1')) if name == "cfg2_348" else 1
+        nbuf = max(1, int(os.environ.get('SGZ_BUFFERS', '1'))) if name == "cfg2_348" else 1
         xs = [x] + [x.clone() for _ in range(nbuf - 1)]
         turn = [0]
         def nextx():
