@@ -385,7 +385,8 @@ void       sgz_spectrum_destroy(sgz_spectrum *s);
 sgz_status sgz_spectrum_configure(sgz_spectrum *s, const sgz_spectrum_config *cfg);   /* handleFlagUpdates */
 /* onStreamAudio(ctx, float** buffer, numChannels, numSamples) */
 sgz_status sgz_spectrum_push(sgz_spectrum *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
-/* frameQueue.popElement -> RGBA8 column of P pixels; SGZ_EMPTY when none is ready */
+/* frameQueue.popElement -> RGBA8 column of P pixels; SGZ_EMPTY when none is ready; SGZ_EINVAL on a LINE_GRAPH handle (display_mode 0 --
+ * what a zero-initialised sgz_spectrum_config selects, as in the reference's enum -- produces no columns: sgz_spectrum_render_lines) */
 sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint32_t *axis_points);
 /* Display hand-off without the host: instead of popping columns and uploading each with
  * oglImage.updateSingleColumn (SpectrumRendering.cpp:696-721, :742-744), bind a device image of P rows x `columns` RGBA8 texels and

@@ -505,6 +505,9 @@ sgz_status sgz_spectrum_flush(sgz_spectrum *s)
 sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba, uint32_t *axis_points)
 {
     if (!s || !rgba) return fail(SGZ_EINVAL, "null argument");
+    // a LINE_GRAPH handle (display_mode 0: what a zero-initialised configuration asks for, as in the reference's enum) produces no columns:
+    // say so instead of staying empty for ever
+    if (s->plan->cfg.display_mode == SGZ_DISPLAY_LINE_GRAPH) return fail(SGZ_EINVAL, "a LINE_GRAPH handle has no colour columns (sgz_spectrum_config::display_mode)");
     const uint64_t head = s->qHead.load(std::memory_order_relaxed);
     if (head == s->qTail.load(std::memory_order_acquire)) return SGZ_EMPTY;
     const int slot = int(head % kQueueDepth);
@@ -578,6 +581,7 @@ sgz_status sgz_spectrum_bind_gl_buffer(sgz_spectrum *s, unsigned int gl_buffer, 
 sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, uint32_t *count)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
+    if (s->plan->cfg.display_mode == SGZ_DISPLAY_LINE_GRAPH) return fail(SGZ_EINVAL, "a LINE_GRAPH handle has no colour columns (sgz_spectrum_config::display_mode)");
     if (!s->d_image && !s->glResource) return fail(SGZ_EINVAL, "no image bound");
     const Plan &p = *s->plan;
     uint8_t *image = s->d_image;

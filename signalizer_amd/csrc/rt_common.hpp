@@ -157,6 +157,9 @@ struct BatchRing {
     sgz_status init(uint32_t nch, uint32_t samplesPerSlot)
     {
         release();
+        // (a multiple of four samples: every slot base -- slot x channels x slotSamples floats -- is then 16-byte aligned for batchFetch's
+        // float4 accesses whatever max_block and the channel count are)
+        samplesPerSlot = (samplesPerSlot + 3u) & ~3u;
         channels = nch; slotSamples = samplesPerSlot;
         const size_t bytes = size_t(kSlots) * nch * samplesPerSlot * sizeof(float);
         SGZ_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocDefault));

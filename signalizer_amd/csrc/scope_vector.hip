@@ -691,6 +691,7 @@ sgz_status sgz_vector_polar_device(const float *d_planar, size_t stride, uint32_
             float *t = nullptr;
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&t), (size_t(iters) * lanes + 1) * sizeof(float)));
             if (iters > 0) hipLaunchKernelGGL(fadeRampKernel, dim3(1), dim3(256), 0, s, n, lanes, iters, t);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) { (void)hipFree(t); return hipFail(e, "fadeRampKernel launch"); }   // (never cache a table that was not built)
             if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) { (void)hipFree(t); return hipFail(e, "hipStreamSynchronize"); }
             cache.push_back(Entry{device, n, lanes, t});
             d_ramp = t;

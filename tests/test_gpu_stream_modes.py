@@ -187,7 +187,7 @@ def test_line_graph_render(gpu, oracle, mode, W, pairs):
                 one = np.zeros((P, 2), np.float32)
                 api.check(L.sgz_spectrum_line_results(h, pairs - 1, 1, one.ctypes.data_as(C.c_void_p)))
                 assert np.array_equal(one, out[pairs - 1, 1])                     # lineGraphs[k].getResults of the last render
-        assert L.sgz_spectrum_pop_column(h, col.ctypes.data_as(C.c_void_p), None) == api.SGZ_EMPTY   # no frames on the audio thread (:1167)
+        assert L.sgz_spectrum_pop_column(h, col.ctypes.data_as(C.c_void_p), None) == api.SGZ_EINVAL   # no frames on the audio thread (:1167): a LINE_GRAPH handle has no columns and says so
         got = np.stack(got)                                                       # [calls][C][G][P][2]
         assert got.shape == want.shape
         bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
@@ -421,5 +421,27 @@ def test_render_thread_and_audio_thread_run_concurrently(gpu):
         # poles 0: the filters hold no memory, so the result is the newest window's alone
         _, want, _, _, _ = _offline(cfg, [np.ascontiguousarray(x[:, -W:])], gpu, want_lines=True)
         assert np.array_equal(out.view(np.uint32), want[0].view(np.uint32))
+    finally:
+        L.sgz_spectrum_destroy(h)
+
+
+def test_zero_initialised_config_is_a_line_graph_handle(gpu):
+    """A C host that zero-initialises sgz_spectrum_config and fills in the sizes gets display_mode 0 = SGZ_DISPLAY_LINE_GRAPH (the reference's
+    enum order and its default): pushes produce no columns, and sgz_spectrum_pop_column / sgz_spectrum_flush_columns say SGZ_EINVAL instead
+    of staying empty for ever; sgz_spectrum_render_lines works."""
+    L = api.lib()
+    c = api.config_from_dict(config.spectrum_config(window_size=1024, hop=256, axis_points=64))
+    c.display_mode = 0
+    h = C.c_void_p()
+    api.check(L.sgz_spectrum_create(C.byref(c), C.byref(h)))
+    try:
+        x = synth.gen(3, 48000, 4096, 2)
+        api.check(L.sgz_spectrum_push(h, (C.c_void_p * 2)(x[0].ctypes.data, x[1].ctypes.data), 2, 4096))
+        col = np.zeros((64, 4), np.uint8)
+        assert L.sgz_spectrum_pop_column(h, col.ctypes.data_as(C.c_void_p), None) == api.SGZ_EINVAL
+        assert L.sgz_spectrum_flush_columns(h, None, None) == api.SGZ_EINVAL
+        out = np.zeros((1, 2, 64, 2), np.float32)
+        api.check(L.sgz_spectrum_render_lines(h, None, out.ctypes.data_as(C.c_void_p)))
+        assert np.isfinite(out).all() and out[0, 0, :, 0].max() > 0
     finally:
         L.sgz_spectrum_destroy(h)
