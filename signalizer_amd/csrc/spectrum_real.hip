@@ -151,6 +151,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // Longer launches are left alone.  (A speed assumption only.)
     if constexpr (LR1 == 4) {
         const uint32_t cus = prm.roundSize >> 1;
+        // The two workgroups that share a CU from the first clock of a launch (b and b + #CUs) would run IN PHASE -- both fetching, both in
+        // their LDS exchanges, both in the map's scalar-heavy scan at the same time -- and take 65 k clocks each where two workgroups half
+        // a life apart take 41 k (tools/phase_clocks.py): the second one starts ~10 k clocks late.  cfg2 launch -2.3 ... -5.5 % with the
+        // input L2-resident, -5 % from HBM (tools/ab_rot.sh, two boxes; 4 k clocks: half the gain, 16 k: a loss); the workgroups of a long launch
+        // stay out of phase afterwards: 2784 workgroups 172.8 -> 156.6 us.  (A speed assumption only.)
+#ifndef SGZ_STAGGER
+#define SGZ_STAGGER 5
+#endif
+        if (cus && gridDim.x >= 2u * cus && blockIdx.x >= cus && blockIdx.x < 2u * cus) {       // (a launch with a FULL second generation: a partial one -- 1.5 generations -- loses 1.3 us to the delay)
+#pragma unroll
+            for (int k = 0; k < SGZ_STAGGER; ++k) __builtin_amdgcn_s_sleep(32);      // (32 x 64 clocks per step)
+        }
         if (cus && gridDim.x > 2u * cus && gridDim.x <= 3u * cus) {
             const uint32_t generation = blockIdx.x / cus;
             if (generation == 0u) __builtin_amdgcn_s_setprio(2); else if (generation == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);

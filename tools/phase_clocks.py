@@ -18,8 +18,12 @@ L.sgz_debug_set_ablate((int(sys.argv[2]) if len(sys.argv) > 2 else 0) | ((int(sy
 L.sgz_debug_phase_clocks.argtypes = [C.c_void_p] * 2 + [C.c_size_t] * 2 + [C.c_void_p] * 3
 names = ["start", "pass1 done", "ex1 done", "pass2 done", "ex2 done", "pass3 done", "mirror done", "M in LDS", "binsOut", "end",
          "map: pieces scanned", "map: interp done", "map: barrier", "windowed", "dif1 done"]
-for rep in range(3):
-    api.check(L.sgz_debug_phase_clocks(plan.h, x.data_ptr(), x.stride(0), S, mapped.data_ptr(), clk.data_ptr(), None))
+# SGZ_BUFFERS=n: the launches rotate over n copies of the audio (n x 23 MB at cfg2: 16 of them are past the Infinity Cache -- the input of the
+# launch that is reported then comes from HBM)
+xs = [x] + [x.clone() for _ in range(max(1, int(os.environ.get("SGZ_BUFFERS", "1"))) - 1)]
+for rep in range(max(3, 2 * len(xs))):
+    b = xs[rep % len(xs)]
+    api.check(L.sgz_debug_phase_clocks(plan.h, b.data_ptr(), b.stride(0), S, mapped.data_ptr(), clk.data_ptr(), None))
     torch.cuda.synchronize()
 c = clk.cpu().numpy().reshape(16, 16)
 c = c[:int(os.environ.get('SGZ_WAVES', '16'))]      # (the channel-split kernel at N = 32768 has 8 waves)
