@@ -68,9 +68,112 @@ ScopeScalars scopeDerive(const sgz_scope_view &v, size_t len, uint32_t triggerMo
     return s;
 }
 
-// cos / sin(pi * i / 10) as libm rounds them (the values std::cos / std::sin return for the double nearest pi*i/10), i = 0 .. 20
-__constant__ const double kCosPiI10[21] = {1.0, 0.9510565162951535, 0.8090169943749475, 0.5877852522924731, 0.30901699437494745, 6.123233995736766e-17, -0.30901699437494734, -0.587785252292473, -0.8090169943749473, -0.9510565162951535, -1.0, -0.9510565162951538, -0.8090169943749476, -0.5877852522924732, -0.30901699437494756, -1.8369701987210297e-16, 0.30901699437494723, 0.5877852522924729, 0.8090169943749473, 0.9510565162951535, 1.0};
-__constant__ const double kSinPiI10[21] = {0.0, 0.3090169943749474, 0.5877852522924731, 0.8090169943749475, 0.9510565162951535, 1.0, 0.9510565162951536, 0.8090169943749475, 0.5877852522924732, 0.3090169943749475, 1.2246467991473532e-16, -0.3090169943749469, -0.587785252292473, -0.8090169943749473, -0.9510565162951535, -1.0, -0.9510565162951536, -0.8090169943749476, -0.5877852522924734, -0.3090169943749476, -2.4492935982947064e-16};
+// cos / sin(pi * i / 10) as libm rounds them (the values std::cos / std::sin return for the double nearest pi*i/10), i = 0 .. 10:
+// compile-time constants of the unrolled taps (no table loads in the kernels)
+constexpr double kCosPiI10[11] = {1.0, 0.9510565162951535, 0.8090169943749475, 0.5877852522924731, 0.30901699437494745, 6.123233995736766e-17, -0.30901699437494734, -0.587785252292473, -0.8090169943749473, -0.9510565162951535, -1.0};
+constexpr double kSinPiI10[11] = {0.0, 0.3090169943749474, 0.5877852522924731, 0.8090169943749475, 0.9510565162951535, 1.0, 0.9510565162951536, 0.8090169943749475, 0.5877852522924732, 0.3090169943749475, 1.2246467991473532e-16};
+constexpr double kPi = 3.14159265358979323846;
+
+// sin y for |y| <= pi/2 (Taylor to y^23: truncation 1e-18) and sin / cos y for |y| <= pi/20 (to y^11 / y^12: 4e-17 / 5e-19), Horner in
+// y^2: a dozen fused multiply-adds each instead of libm's range reduction.
+__device__ __forceinline__ double sinHalfTurn(double y)
+{
+    const double y2 = y * y;
+    double r = 3.8681701706306835e-23;
+    r = fma(r, y2, -1.9572941063391263e-20);
+    r = fma(r, y2, 8.2206352466243295e-18);
+    r = fma(r, y2, -2.8114572543455206e-15);
+    r = fma(r, y2, 7.6471637318198164e-13);
+    r = fma(r, y2, -1.6059043836821613e-10);
+    r = fma(r, y2, 2.5052108385441720e-8);
+    r = fma(r, y2, -2.7557319223985893e-6);
+    r = fma(r, y2, 1.9841269841269841e-4);
+    r = fma(r, y2, -8.3333333333333332e-3);
+    r = fma(r, y2, 0.16666666666666666);
+    return fma(-(y * y2), r, y);
+}
+__device__ __forceinline__ void sincosTwentieth(double y, double &sn, double &cs)
+{
+    const double y2 = y * y;
+    double r = -2.5052108385441720e-8;
+    r = fma(r, y2, 2.7557319223985893e-6);
+    r = fma(r, y2, -1.9841269841269841e-4);
+    r = fma(r, y2, 8.3333333333333332e-3);
+    r = fma(r, y2, -0.16666666666666666);
+    sn = fma(y * y2, r, y);
+    double c = 2.0876756987868099e-9;
+    c = fma(c, y2, -2.7557319223985888e-7);
+    c = fma(c, y2, 2.4801587301587302e-5);
+    c = fma(c, y2, -1.3888888888888889e-3);
+    c = fma(c, y2, 4.1666666666666664e-2);
+    c = fma(c, y2, -0.5);
+    cs = fma(c, y2, 1.0);
+}
+
+// One output point of drawWavePlot's Lanczos branch: closed form of the reference's running sums (currentSample += spp;
+// samplePos += 1 while delta > 1, OscilloscopeRendering.cpp:846-889).  x = 10 + delta in (9, 11]; tap T reads kernel sample
+// i = floor(x) - 9 + T, and d_i = x - i = m + e with m = round(x) - i (an integer) and e = x - round(x) in [-1/2, 1/2] (exact):
+//   sin(pi d)    = (-1)^m sin(pi e)
+//   sin(pi d/10) = sin(pi m/10) cos(pi e/10) + cos(pi m/10) sin(pi e/10)
+// Only the m = 0 tap has |d| < 1/2 and it is evaluated directly, so no tap suffers cancellation (a plain angle addition around
+// floor(x) loses ~1 % on the nearest tap when x is within 1e-13 of an integer).  round(x) - floor(x) is 0 or 1, so m is one of the two
+// compile-time values 9 - T, 10 - T: the table entries are SELECTED between two literals, nothing is loaded and nothing branches.
+struct LanczosPoint {
+    double x, delta, sPi, s10, c10;
+    long fl, shifts;
+    bool up;                                                // round(x) == floor(x) + 1
+};
+__device__ __forceinline__ LanczosPoint lanczosPoint(double samplePos0, double spp, size_t p)
+{
+    LanczosPoint q;
+    const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
+    const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
+    q.shifts = long(shifts);
+    q.delta = D - shifts;
+    q.x = 10.0 + q.delta;
+    const double flx = floor(q.x), rnx = rint(q.x);
+    q.fl = long(flx);
+    q.up = rnx != flx;
+    const double e = q.x - rnx;
+    q.sPi = sinHalfTurn(kPi * e);
+    sincosTwentieth(kPi * e / 10.0, q.s10, q.c10);
+    return q;
+}
+constexpr double signedSinPiI10(int m) { return m < 0 ? -kSinPiI10[-m] : kSinPiI10[m]; }
+constexpr double cosPiI10(int m) { return kCosPiI10[m < 0 ? -m : m]; }
+// weight of tap T; the reference's loop skips a tap outside the 21-sample kernel window (lanczosTapInside)
+__device__ __forceinline__ bool lanczosTapInside(const LanczosPoint &q, int t)
+{
+    const long i = q.fl - 9 + t;
+    return i >= 0 && i < 21;
+}
+template <int T>
+__device__ __forceinline__ double lanczosTap(const LanczosPoint &q)
+{
+    constexpr int M0 = 9 - T, M1 = 10 - T;
+    constexpr double S0 = signedSinPiI10(M0), S1 = signedSinPiI10(M1), C0 = cosPiI10(M0), C1 = cosPiI10(M1);
+    const double sm = q.up ? S1 : S0, cm = q.up ? C1 : C0;
+    const bool odd = q.up ? bool(M1 & 1) : bool(M0 & 1);
+    const bool centre = q.up ? M1 == 0 : M0 == 0;
+    const double sa = odd ? -q.sPi : q.sPi;
+    const double sb = centre ? q.s10 : fma(sm, q.c10, cm * q.s10);
+    const long i = q.fl - 9 + T;
+    const double d = q.x - double(i);
+    const double pd = kPi * d, pd2 = pd * pd;
+    double r = __builtin_amdgcn_rcp(pd2);
+    r = fma(fma(-pd2, r, 1.0), r, r);
+    r = fma(fma(-pd2, r, 1.0), r, r);
+    double wt = (10.0 * sa) * sb * r;
+    return d == 0.0 ? 1.0 : wt;
+}
+template <int T = 0>
+__device__ __forceinline__ void lanczosWeights(const LanczosPoint &q, double (&w)[20])
+{
+    if constexpr (T < 20) {
+        w[T] = lanczosTap<T>(q);
+        lanczosWeights<T + 1>(q, w);
+    }
+}
 
 // one thread per output point.  y = sum_i ring[cursor + i] * L(10 + delta - i), L = Lanczos a = 10, fp64.
 __global__ void __launch_bounds__(256)
@@ -79,55 +182,28 @@ scopeLanczosKernel(const float *ring, size_t len, size_t stride, uint32_t channe
 {
     const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= points) return;
-    // closed form of the reference's running sums (currentSample += spp; samplePos += 1 while delta > 1)
-    const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
-    const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
-    const double delta = D - shifts;
-    const double x = 10.0 + delta;
-    const long fl = long(floor(x));
-    long cur = (cursor0 + long(shifts)) % long(len);
-    const double kPi = 3.14159265358979323846;
-    // d_i = x - i = m + e with m = round(x) - i (integer) and e = x - round(x) in [-1/2, 1/2] (exact):
-    //   sin(pi d)    = (-1)^m sin(pi e)
-    //   sin(pi d/10) = sin(pi m/10) cos(pi e/10) + cos(pi m/10) sin(pi e/10)
-    // Only the m = 0 tap has |d| < 1/2 and it is evaluated directly, so no tap suffers cancellation
-    // (a plain angle addition around floor(x) loses ~1 % on the nearest tap when x is within 1e-13 of an integer).
-    const long rn = long(rint(x));
-    const double e = x - double(rn);
-    const double sPi = sin(kPi * e);
-    double s10, c10;
-    sincos(kPi * e / 10.0, &s10, &c10);
+    const LanczosPoint q = lanczosPoint(samplePos0, spp, p);
     const float ux = float(unit0 + double(p) * inc);
     // the 20 tap weights depend on the point only: computed once, used by every channel
     double w[20];
-    long idx0 = cur + (fl - 9);
+    lanczosWeights(q, w);
+    const long cur = (cursor0 + q.shifts) % long(len);
+    long idx = cur + (q.fl - 9);
+    if (idx >= long(len)) idx -= long(len);
+    uint32_t at[20];
 #pragma unroll
     for (int t = 0; t < 20; ++t) {
-        const long i = fl - 9 + t;
-        const double d = x - double(i);
-        const long m = rn - i;                         // in [-10, 10]
-        double wt;
-        if (d == 0.0) wt = 1.0;
-        else {
-            const double pd = kPi * d;
-            const double sa = (m & 1) ? -sPi : sPi;
-            const long am = m < 0 ? -m : m;
-            const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
-            const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
-            wt = 10.0 * sa * sb / (pd * pd);
-        }
-        w[t] = (i < 0 || i >= 21) ? 0.0 : wt;          // taps outside the 21-sample kernel window are skipped (weight 0 is exact: acc += x * 0)
+        at[t] = uint32_t(idx);
+        idx = idx + 1 == long(len) ? 0 : idx + 1;
     }
     for (uint32_t c = 0; c < channels; ++c) {
         const float *r = ring + size_t(c) * stride;
+        float v[20];
+#pragma unroll
+        for (int t = 0; t < 20; ++t) v[t] = r[at[t]];
         double acc = 0.0;
 #pragma unroll
-        for (int t = 0; t < 20; ++t) {
-            const long i = fl - 9 + t;
-            if (i < 0 || i >= 21) continue;
-            long idx = idx0 + t; if (idx >= long(len)) idx -= long(len);
-            acc += double(r[idx]) * w[t];
-        }
+        for (int t = 0; t < 20; ++t) acc = lanczosTapInside(q, t) ? acc + double(v[t]) * w[t] : acc;
         xy[size_t(c) * points + p] = make_float2(ux, float(acc));
     }
 }
@@ -180,62 +256,72 @@ scopeWaveLanczosKernel(const WaveItem it0, const WaveItem it1, uint32_t len, uin
     const size_t p = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= points) return;
     const uint32_t base = *d_cursor;                        // cursorPosition(): the evaluator's offsets count from it
-    const double D = (floor(samplePos0) + double(p) * spp) - samplePos0;
-    const double shifts = D > 1.0 ? ceil(D - 1.0) : 0.0;
-    const double delta = D - shifts;
-    const double x = 10.0 + delta;
-    const long fl = long(floor(x));
-    const long cur = cursor0 + long(shifts);                // logical position of kernel[0]
-    const double kPi = 3.14159265358979323846;
-    const long rn = long(rint(x));
-    const double e = x - double(rn);                        // in [-1/2, 1/2]
-    const double sPi = sin(kPi * e);
-    double s10, c10;
-    sincos(kPi * e / 10.0, &s10, &c10);
-    double acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0;
-    const long idx0 = cur + (fl - 9);
+    const LanczosPoint q = lanczosPoint(samplePos0, spp, p);
+    const long idx0 = cursor0 + q.shifts + (q.fl - 9);      // logical position of tap 0
     // ringPhys(idx0 + t, ..) for the twenty taps and the two colour samples: ONE 64-bit modulo per thread (it costs ~100 instructions,
-    // and twenty-two of them were most of this kernel), then steps of one with a wrap -- the same indices
+    // and twenty-two of them were most of this kernel once), then steps of one with a wrap -- the same indices
     long q0l = idx0 % long(len);
     if (q0l < 0) q0l += long(len);
-    const uint32_t q0 = uint32_t(q0l), lead = base + (cap - len);
-    auto physAt = [&](uint32_t t) {
-        uint32_t q = q0 + t;
-        while (q >= len) q -= len;
-        uint32_t ph = lead + q;
-        while (ph >= cap) ph -= cap;
-        return ph;
+    uint32_t lead = base + (cap - len);
+    while (lead >= cap) lead -= cap;
+    uint32_t at[21];
+    {
+        uint32_t lq = uint32_t(q0l);
+#pragma unroll
+        for (int t = 0; t < 21; ++t) {
+            const uint32_t ph = lead + lq;
+            at[t] = ph >= cap ? ph - cap : ph;
+            lq = lq + 1u == len ? 0u : lq + 1u;
+        }
+    }
+    // every sample request of the point in flight before the first is used; the evaluator (SampleColourEvaluators.h) is applied to
+    // loaded pairs (mode 0 reads ring A twice: no divergent pointer)
+    const float *b0 = it0.evalMode ? it0.ringB : it0.ringA, *b1 = it1.evalMode ? it1.ringB : it1.ringA;
+    float va[K][20], vb[K][20];
+    auto sampleAt = [](const float *ring, uint32_t index) {     // a 32-bit byte offset from a scalar base (rings are < 2^30 samples)
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + size_t(index * 4u));
     };
 #pragma unroll
     for (int t = 0; t < 20; ++t) {
-        const long i = fl - 9 + t;
-        if (i < 0 || i >= 21) continue;
-        const double d = x - double(i);
-        const long m = rn - i;
-        double wt;
-        if (d == 0.0) wt = 1.0;
-        else {
-            const double pd = kPi * d;
-            const double sa = (m & 1) ? -sPi : sPi;
-            const long am = m < 0 ? -m : m;
-            const double sm = m < 0 ? -kSinPiI10[am] : kSinPiI10[am];
-            const double sb = (m == 0) ? s10 : (sm * c10 + kCosPiI10[am] * s10);
-            wt = 10.0 * sa * sb / (pd * pd);
+        va[0][t] = sampleAt(it0.ringA, at[t]);
+        vb[0][t] = sampleAt(b0, at[t]);
+        if constexpr (K > 1) {
+            va[1][t] = sampleAt(it1.ringA, at[t]);
+            vb[1][t] = sampleAt(b1, at[t]);
         }
-        const uint32_t ph = physAt(uint32_t(t));
-        acc[0] += double(evalSample(it0.ringA, it0.ringB, it0.evalMode, ph)) * wt;
-        if constexpr (K > 1) acc[1] += double(evalSample(it1.ringA, it1.ringB, it1.evalMode, ph)) * wt;
+    }
+    double w[20];
+    lanczosWeights(q, w);
+    // MidSideEvaluatorBase<0, std::plus<>> / <1, std::minus<>>: 0.5 (a + b), 0.5 (a - b) = 0.5 (a + (-b)); the mode is the same for
+    // every thread, and spelled as bit operations so that it costs no branch per tap
+    auto evaluated = [](uint32_t mode, float a, float b) {
+        const uint32_t flip = mode == 2u ? 0x80000000u : 0u, keep = mode == 0u ? 0xffffffffu : 0u;
+        const float half = 0.5f * (a + __uint_as_float(__float_as_uint(b) ^ flip));
+        return __uint_as_float((__float_as_uint(a) & keep) | (__float_as_uint(half) & ~keep));
+    };
+    double acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < 20; ++t) {
+        const bool in = lanczosTapInside(q, t);
+        const double s0 = double(evaluated(it0.evalMode, va[0][t], vb[0][t])) * w[t];
+        acc[0] = in ? acc[0] + s0 : acc[0];
+        if constexpr (K > 1) {
+            const double s1 = double(evaluated(it1.evalMode, va[1][t], vb[1][t])) * w[t];
+            acc[1] = in ? acc[1] + s1 : acc[1];
+        }
     }
     const float ux = float(unit0 + double(p) * inc);
-    const uint32_t tc = uint32_t(28 - fl);                   // cur + 19 = idx0 + (19 - (fl - 9))
-    // colourChannelsByFrequency: the colours of the two newest kernel samples, blended by delta (:836-843, :874-877)
+    // colourChannelsByFrequency: the colours of the two newest kernel samples, blended by delta (:836-843, :874-877): logical taps
+    // 28 - fl and 29 - fl (cur + 19 = idx0 + (19 - (fl - 9))), fl in {9, 10, 11}
+    const uint32_t c0 = q.fl == 11 ? at[17] : q.fl == 10 ? at[18] : at[19];
+    const uint32_t c1 = q.fl == 11 ? at[18] : q.fl == 10 ? at[19] : at[20];
     it0.xyz[p] = make_float3(ux, float(acc[0]), 0.f);
-    if (it0.rgba) it0.rgba[p] = it0.colRing ? lerpRgba(it0.colRing[physAt(tc)], it0.colRing[physAt(tc + 1u)], delta) : it0.key;
+    if (it0.rgba) it0.rgba[p] = it0.colRing ? lerpRgba(it0.colRing[c0], it0.colRing[c1], q.delta) : it0.key;
     if constexpr (K > 1) {
         it1.xyz[p] = make_float3(ux, float(acc[1]), 0.f);
-        if (it1.rgba) it1.rgba[p] = it1.colRing ? lerpRgba(it1.colRing[physAt(tc)], it1.colRing[physAt(tc + 1u)], delta) : it1.key;
+        if (it1.rgba) it1.rgba[p] = it1.colRing ? lerpRgba(it1.colRing[c0], it1.colRing[c1], q.delta) : it1.key;
     }
 }
 
