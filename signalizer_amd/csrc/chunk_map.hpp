@@ -65,6 +65,14 @@ struct ChunkMap {
             cr[b] = x < tb.P ? tb.crec[x] : uint2{0u, kChunkOff};
         }
     }
+    // The prefetched words are waited for HERE (a workgroup that walks over units requests the next unit's samples behind this point: a
+    // later wait for these words would be a wait for those samples as well -- the counter of outstanding loads is in order)
+    __device__ __forceinline__ void arrived()
+    {
+        asm volatile("" : "+v"(slotBase), "+v"(endBits));
+#pragma unroll
+        for (int b = 0; b < RB; ++b) asm volatile("" : "+v"(cr[b].x), "+v"(cr[b].y));
+    }
     static __device__ __forceinline__ bool interpolated(const uint2 c) { return (c.y & kChunkInterp) != 0u; }
 
     // <= 10 taps as kTapFloats contiguous floats, accumulated in tap order; entries that are not taps carry weight +0 and read a finite

@@ -46,11 +46,12 @@ __device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
 // windows then share one L2.  32-bit arithmetic throughout (runStft refuses launches of 2^31 tasks): the 64-bit divisions this used to
 // be written with were ~500 scalar instructions in front of every workgroup's first load.
 struct UnitId { int side, pair; uint32_t task, frame, self; };
+// (unit, nb: the workgroup's index and the launch's size -- or, for a workgroup that walks over several units, the index and the number
+// of workgroups a one-unit-per-workgroup launch would have had)
 template <bool MONO>
-__device__ __forceinline__ UnitId unitOf(const RealParams &prm)
+__device__ __forceinline__ UnitId unitOfIndex(const RealParams &prm, uint32_t unit, const uint32_t nb)
 {
-    uint32_t unit = blockIdx.x;
-    const uint32_t nb = gridDim.x, rs = prm.roundSize;
+    const uint32_t rs = prm.roundSize;
     if (nb >= 64u && rs >= 8u && (rs & 7u) == 0u) {
         const uint32_t base = (unit / rs) * rs;
         const uint32_t nbr = nb - base < rs ? nb - base : rs;
@@ -67,6 +68,9 @@ __device__ __forceinline__ UnitId unitOf(const RealParams &prm)
     u.self = (task << 1) | uint32_t(u.side);                // ny / low / nyBest slots are indexed by task * 2 + side
     return u;
 }
+
+template <bool MONO>
+__device__ __forceinline__ UnitId unitOf(const RealParams &prm) { return unitOfIndex<MONO>(prm, blockIdx.x, gridDim.x); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
 inline hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64])

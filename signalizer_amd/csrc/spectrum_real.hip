@@ -136,13 +136,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     static_assert((T / R) * TILE <= XFLOATS, "the exchange-2 tiles end below the twiddle table");
     constexpr int TAB = (XFLOATS + 3) & ~3;               // the pass-2 twiddle table (16-byte aligned)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
-    const int q1 = half ? (slot == 0 ? R1 / 2 : R1 - slot) : slot;
-    const int ix = half ? R - 1 - l : l;                // c_lo in pass 2, q2 in pass 3
+    const int tid0 = threadIdx.x;
 
-    const UnitId uid = unitOf<MONO>(prm);                    // (frame, pair, channel) or (frame, pair); real_common.hpp
-    [[maybe_unused]] const long unit = MONO ? long(uid.task) : long(uid.self);   // (debug clocks)
+    // WALK (N = 65536, pairs, window evaluated in the kernel): 1024 threads x 128 registers are the CU's whole register file, so ONE workgroup
+    // is resident and its phases run one after the other -- the 256 KB of samples arrive through the CU's ~11 B/clock fetch path while
+    // nothing computes (tools/phase_clocks.py: 22 k of a workgroup's 57 k clocks).  The launch is therefore one workgroup per CU that WALKS
+    // over the units a one-unit-per-workgroup launch would have given its slot (b, b + #workgroups, ...: the same XCD-aware order), and each
+    // wave requests the first half of the NEXT unit's rows as soon as its own magnitudes are out of the registers those rows land in --
+    // the requests are served while the slower waves still transform and the map runs; the second half follows at the top of the loop.
+    constexpr bool WALK = LR1 == 5 && MIX == 0 && WCOS;
+    const uint32_t totalUnits = WALK ? uint32_t(prm.frames) * prm.C * 2u : gridDim.x;
+    uint32_t walkIndex = blockIdx.x;
+    UnitId uid = unitOfIndex<MONO>(prm, walkIndex, totalUnits);     // (frame, pair, channel) or (frame, pair); real_common.hpp
     // Wave priorities for a launch of two full dispatch generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident
     // per CU).  tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the first frees
     // and the launch ends when IT ends; its workgroups share their CU with second-generation ones that have ~10 us of slack.  Third
@@ -168,6 +173,68 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             if (generation == 0u) __builtin_amdgcn_s_setprio(2); else if (generation == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
         }
     }
+    constexpr bool PAIRED = U == 2;                          // thread -> columns 2 tid, 2 tid + 1 (otherwise tid + T u): see the sample loads
+    constexpr int COLSTEP = PAIRED ? 1 : T, COLLANE = PAIRED ? 2 : 1;     // column of (tid, u) = COLLANE tid + COLSTEP u
+    constexpr bool FRONT = LR1 >= 4 && !mixed && WCOS;       // (the mixed modes and a fetched window hold more values in flight: they would spill)
+    [[maybe_unused]] float4 phase[U];
+    [[maybe_unused]] float2 twA[U], twB[U];
+    [[maybe_unused]] float4 tw2piece, tw2tail;                  // (T = 512: threads 0 .. 31 carry a second piece of the 544)
+    v2 c[R];
+    // which input channels feed a unit's signal: Separate: channel `side`; MidSide: (l + r) / 2 on side 0, (l - r) / 2 on side 1
+    // (prepareTransform's MidSide case, then the same split as Separate); mono: l, r, (l + r) / 2 or (l - r) / 2
+    auto samplesOf = [&](const UnitId &u) {
+        const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : (mixed ? 0 : u.side);
+        return prm.planar + size_t(2 * u.pair + firstCh) * prm.chStride + size_t(u.frame) * prm.hop;
+    };
+    auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return (PAIRED ? u : T * u) + RR * j; };
+    // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
+    // (element = compile-time part + tid.  Pinning the compile-time part to scalar base registers -- `global_load v, v_lane, s[base]`, no
+    // vector address arithmetic per load -- was measured on one box against this form: cfg2 -1 %, cfg5 +1.3 %: not kept)
+    // PAIRED (two columns per thread, N = 32768): the thread owns the NEIGHBOURING columns 2 tid and 2 tid + 1, so that a sample request is
+    // 16 bytes per lane (global_load_dwordx4: 1 KB per wave-instruction) -- the per-CU fetch path serves 8-byte requests at 0.54-0.70 of
+    // its 16-byte rate (MI355X_MICROARCH.md), and the samples' arrival is the longest phase of a workgroup's life (tools/phase_clocks.py)
+    // part 0: every row; WALK: part 1 = rows 0 .. 7 and 16 .. 23 (the window pairs row j with row j + 16), part 2 = the others
+    auto requestSamples = [&](const float *X, const int tid, auto partTag) {
+        constexpr int part = decltype(partTag)::value;
+        const uint32_t lane8 = uint32_t(tid) * (PAIRED ? 16u : 8u);
+        if constexpr (PAIRED) {
+            typedef float v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < R1; ++j) { const v4 xv = ldgPinned<v4>(X, uint32_t(RR * j) * 8u, lane8); c[j] = v2{xv.x, xv.y}; c[R1 + j] = v2{xv.z, xv.w}; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                if (part == 0 || ((i >> 3) & 1) == part - 1) c[i] = ldgPinned<v2>(X, uint32_t(elemOf(i)) * 8u, lane8);
+        }
+    };
+    // Every table value this thread needs before the first barrier is REQUESTED behind the samples and in front of the first wait:
+    // the window phases, the two fetched pass-1 twiddle rows of every column and this thread's piece of the pass-2 table (which goes to
+    // LDS in front of exchange 1).  Requested where they are used -- as this kernel did until round 5 -- each is a memory round trip of
+    // its own in the workgroup's dependent chain: table -> LDS copy (waited for before the first sample was requested), samples,
+    // second column's phases, first column's twiddles, second column's twiddles.  (N = 16384: 256 threads x four columns at the
+    // 128-register limit: requested where used, as before.)
+    auto requestTables = [&](const int tid) {
+        if constexpr (FRONT) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (WCOS) phase[u] = ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);
+                twA[u] = ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
+                twB[u] = ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
+            }
+            if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid];
+            if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) tw2tail = prm.tw2Full[T + tid];
+        }
+    };
+    if constexpr (WALK) requestSamples(samplesOf(uid), tid0, std::integral_constant<int, 1>{});
+    for (;;) {
+    // (WALK: the thread index is opaque per unit, or everything derived from it -- LDS addresses, lane offsets, twiddle indices -- is hoisted
+    // out of the loop and held in registers through every phase: 33 spilled registers in the first build)
+    const int tid = WALK ? opaque(tid0) : tid0;
+    const int slot = tid >> 6, half = (tid >> 5) & 1, l = tid & 31, group = tid >> 5;
+    const int q1 = half ? (slot == 0 ? R1 / 2 : R1 - slot) : slot;
+    const int ix = half ? R - 1 - l : l;                // c_lo in pass 2, q2 in pass 3
+    const uint32_t lane8 = uint32_t(tid) * (PAIRED ? 16u : 8u);
+    [[maybe_unused]] const long unit = MONO ? long(uid.task) : long(uid.self);   // (debug clocks)
     const int side = uid.side, pair = uid.pair;
     const long task = uid.task, frame = uid.frame, self = uid.self;
 
@@ -194,58 +261,17 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
 
     RCLK(0);
     RTRACE(0);
-    // Every table value this thread needs before the first barrier is REQUESTED here, behind the samples and in front of the first wait:
-    // the window phases, the two fetched pass-1 twiddle rows of every column and this thread's piece of the pass-2 table (which goes to
-    // LDS in front of exchange 1).  Requested where they are used -- as this kernel did until round 5 -- each is a memory round trip of
-    // its own in the workgroup's dependent chain: table -> LDS copy (waited for before the first sample was requested), samples,
-    // second column's phases, first column's twiddles, second column's twiddles.  (N = 16384: 256 threads x four columns at the
-    // 128-register limit: requested where used, as before.)
-    constexpr bool PAIRED = U == 2;                          // thread -> columns 2 tid, 2 tid + 1 (otherwise tid + T u): see the sample loads
-    constexpr int COLSTEP = PAIRED ? 1 : T, COLLANE = PAIRED ? 2 : 1;     // column of (tid, u) = COLLANE tid + COLSTEP u
-    constexpr bool FRONT = LR1 >= 4 && !mixed && WCOS;       // (the mixed modes and a fetched window hold more values in flight: they would spill)
     if constexpr (LR1 >= 4 && !FRONT) {
         // the pass-2 twiddle table -> LDS (8.5 KB behind the exchange areas; the map's maxima take the place later)
         for (int i = tid; i < kTw2Floats / 4; i += T) reinterpret_cast<float4 *>(lds + TAB)[i] = prm.tw2Full[i];
     }
-    [[maybe_unused]] float4 phase[U];
-    [[maybe_unused]] float2 twA[U], twB[U];
-    [[maybe_unused]] float4 tw2piece, tw2tail;                  // (T = 512: threads 0 .. 31 carry a second piece of the 544)
-    v2 c[R];
     {
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
-        // 8-byte loads, R of them per thread, in batches of B with the next batch in flight while this one is multiplied (the
-        // scheduling barriers keep instruction selection from hoisting all 2R loads to the top: 128 registers of raw samples)
-        // which input channels feed this workgroup's signal: Separate: channel `side`; MidSide: (l + r) / 2 on side 0, (l - r) / 2 on side 1
-        // (prepareTransform's MidSide case, then the same split as Separate); mono: l, r, (l + r) / 2 or (l - r) / 2
-        const int firstCh = MONO ? (prm.mode == SGZ_CH_RIGHT ? 1 : 0) : (mixed ? 0 : side);
-        const float *X = prm.planar + size_t(2 * pair + firstCh) * prm.chStride + size_t(frame) * prm.hop;
-        // all R sample pairs are requested at once (64 registers) and multiplied by the window in place
-        // (element = compile-time part + tid.  Pinning the compile-time part to scalar base registers -- `global_load v, v_lane, s[base]`, no
-        // vector address arithmetic per load -- was measured on one box against this form: cfg2 -1 %, cfg5 +1.3 %: not kept)
-        // PAIRED (two columns per thread, N = 32768): the thread owns the NEIGHBOURING columns 2 tid and 2 tid + 1, so that a sample request is
-        // 16 bytes per lane (global_load_dwordx4: 1 KB per wave-instruction) -- the per-CU fetch path serves 8-byte requests at 0.54-0.70 of
-        // its 16-byte rate (MI355X_MICROARCH.md), and the samples' arrival is the longest phase of a workgroup's life (tools/phase_clocks.py)
-        auto elemOf = [&](int e) { const int u = e / R1, j = e % R1; return (PAIRED ? u : T * u) + RR * j; };
-        const uint32_t lane8 = uint32_t(tid) * (PAIRED ? 16u : 8u);
-        if constexpr (PAIRED) {
-            typedef float v4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-            for (int j = 0; j < R1; ++j) { const v4 xv = ldgPinned<v4>(X, uint32_t(RR * j) * 8u, lane8); c[j] = v2{xv.x, xv.y}; c[R1 + j] = v2{xv.z, xv.w}; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R; ++i) c[i] = ldgPinned<v2>(X, uint32_t(elemOf(i)) * 8u, lane8);
-        }
-        if constexpr (FRONT) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (WCOS) phase[u] = ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);
-                twA[u] = ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
-                twB[u] = ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
-            }
-            if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid];
-            if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) tw2tail = prm.tw2Full[T + tid];
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const float *X = samplesOf(uid);
+        if constexpr (WALK) requestSamples(X, tid, std::integral_constant<int, 2>{});     // (part 1 was requested during the previous unit)
+        else requestSamples(X, tid, std::integral_constant<int, 0>{});
+        requestTables(tid);
+        if constexpr (FRONT) __builtin_amdgcn_sched_barrier(0);
         if (mixed) {
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
             const float *Y = X + prm.chStride;
@@ -452,6 +478,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     const float2 wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
     ditPacked<LR, 0>(c);
     RCLK(5);
+    if constexpr (WALK) mapper.prefetch(tb, tid);                         // (early: they are waited for before the next unit's samples are requested)
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
     const int kc = q1 + R1 * ix;
     if (tid == 0) {                                                         // column 0 (k = T m3) pairs registers inside thread 0
@@ -545,7 +572,21 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(6);
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
     if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
-    mapper.prefetch(tb, tid);
+    if constexpr (WALK) mapper.arrived(); else mapper.prefetch(tb, tid);
+    [[maybe_unused]] UnitId nextUid = uid;
+    [[maybe_unused]] bool more = false;
+    if constexpr (WALK) {
+        // the registers of c[] are free: sixteen of the next unit's rows are requested now, BEHIND the map's own
+        // requests (the counter of outstanding loads is in order: what the map waits for must be older than these)
+        const uint32_t nextIndex = walkIndex + gridDim.x;
+        more = nextIndex < totalUnits;
+        if (more) {
+            nextUid = unitOfIndex<MONO>(prm, nextIndex, totalUnits);
+            walkIndex = nextIndex;
+            requestSamples(samplesOf(nextUid), tid, std::integral_constant<int, 1>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
@@ -579,6 +620,13 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     ldsBarrier();
     RCLK(7);
     realMapSettle<LR1, MIX>(prm, lds, tid, side, task, self, tb, mapper, re, ce, spec);
+    if constexpr (!WALK) break;
+    else {
+        if (!more) break;
+        uid = nextUid;
+        ldsBarrier();                                                    // the map has read its maxima: the next unit's table and exchanges may overwrite them
+    }
+    }
 }
 
 // Test hook (sgz_stage_map_from_bins on a channel-split plan): csf magnitudes [task][N + 1] come from HBM instead of the transform;
@@ -718,7 +766,9 @@ hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream)
     auto go = [&](auto kern, int slot, unsigned threads, size_t limit) -> hipError_t {
         if (ldsBytes > limit) return hipErrorInvalidValue;
         if (hipError_t e = grantLds(reinterpret_cast<const void *>(kern), ldsBytes, granted[slot]); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(unsigned(units)), dim3(threads), ldsBytes, stream, prm);
+        // (N = 65536, pairs, window evaluated in the kernel: one workgroup per CU walks over the units -- WALK in the kernel)
+        const bool walk = N == 65536 && !mono && prm.mode == SGZ_CH_SEPARATE && wcos && prm.roundSize;
+        hipLaunchKernelGGL(kern, dim3(unsigned(walk ? std::min<long>(units, long(prm.roundSize)) : units)), dim3(threads), ldsBytes, stream, prm);
         // the pixels that need both channels (skipped when the caller's next kernel overlays them itself: prm.lateInNext)
         if (!mono && !prm.lateInNext) return launchRealLate(prm, N, stream);
         return hipSuccess;

@@ -29,7 +29,8 @@ c = clk.cpu().numpy().reshape(16, 16)
 c = c[:int(os.environ.get('SGZ_WAVES', '16'))]      # (the channel-split kernel at N = 32768 has 8 waves)
 t0 = c[:, 0].min()
 order = [0, 13, 14, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 9]
-if cfg5:   # the map slots are then written by mapSideKernel (a later launch): print the two kernels separately
+if cfg5 and os.environ.get("SGZ_REALCLK") != "1":   # halves kernel: the map slots are then written by mapSideKernel (a later launch): print the two kernels
+    # separately.  (SGZ_REALCLK=1: the plan runs the channel-split kernel at N = 65536 -- the default since round 2 --, one kernel, the full list)
     order = [0, 7, 10, 11, 12, 9] if os.environ.get("SGZ_MAPCLK") == "1" else [13, 14, 1, 2, 3, 4, 5, 6, 8]
     t0 = c[:, 0].min() if os.environ.get("SGZ_MAPCLK") == "1" else c[:, 13].min()
 print(f"{'boundary':22s} {'first wave':>10s} {'last wave':>10s} {'wave 0':>8s} {'wave 15':>8s}")
