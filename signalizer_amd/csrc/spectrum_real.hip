@@ -432,6 +432,14 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     ldsBarrier();                                                        // every wave has read exchange 1: the tiles may overwrite it
     RCLK(2);
+    // WALK: the recombination's twiddle and the map's table words are requested HERE, where nothing else of this workgroup is on its way
+    // through the CU's fetch path: requested where they are used, a late wave's few bytes queue behind the early waves' requests for the
+    // next unit's samples and it waits ~10 k clocks for them (tools/phase_clocks.py: pass 3 -> recombined 1.9 k -> 12.4 k clocks)
+    [[maybe_unused]] float2 wkEarly;
+    if constexpr (WALK) {
+        wkEarly = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
+        mapper.prefetch(tb, tid);
+    }
     // -------------------------------------------------------------------------- pass 2 (c_lo = ix): radix R over c_hi
     ditPacked<LR, 0>(c);
     if constexpr (LR1 >= 4) {
@@ -475,10 +483,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     RCLK(4);
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
-    const float2 wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
+    float2 wk;                                                           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
+    if constexpr (WALK) wk = wkEarly; else wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
     ditPacked<LR, 0>(c);
     RCLK(5);
-    if constexpr (WALK) mapper.prefetch(tb, tid);                         // (early: they are waited for before the next unit's samples are requested)
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
     const int kc = q1 + R1 * ix;
     if (tid == 0) {                                                         // column 0 (k = T m3) pairs registers inside thread 0
@@ -516,6 +524,16 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // the partner lane's registers >= R/2, and the partner does the same for ITS lower registers, whose mirrors are this lane's upper
     // ones: every bin of the lane pair is produced exactly once, with half the permutes, twiddles and adds of bin-by-bin evaluation.
     float magA[R / 2], magB[R / 2];
+    [[maybe_unused]] UnitId nextUid = uid;
+    [[maybe_unused]] bool more = false;
+    [[maybe_unused]] const float *nextX = nullptr;
+    [[maybe_unused]] v2 nextRows[R / 2];
+    if constexpr (WALK) {
+        const uint32_t nextIndex = walkIndex + gridDim.x;
+        more = nextIndex < totalUnits;
+        if (more) { nextUid = unitOfIndex<MONO>(prm, nextIndex, totalUnits); walkIndex = nextIndex; }
+        nextX = samplesOf(nextUid);                                       // (the last unit of a walk re-requests rows of its own: no branch per request)
+    }
     {
         // lane holding Z[M - k]: L ^ R, except in slot 0 (q1 = 0: q2' = R - q2 ; q1 = R1/2: q2' = R-1-q2, same half)
         const int lane = int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
@@ -561,6 +579,11 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const float pr = re2.x, mr = re2.y, pi = im2.x, mi = im2.y;
             magA[m3] = __builtin_amdgcn_sqrtf(sq.x);                       // (|2 X| / 2: the 1/2 came in with the window)
             magB[m3] = __builtin_amdgcn_sqrtf(sq.y);
+            if constexpr (WALK) {
+                // registers i and ip are free: one row of the next unit's first sixteen (rows 0 .. 7, 16 .. 23) is requested into them
+                const int row = m3 < 8 ? m3 : m3 + 8;
+                nextRows[m3] = ldgPinned<v2>(nextX, uint32_t(elemOf(row)) * 8u, lane8);
+            }
             if (MONO && m3 == 0 && prm.lowCount[0] && kc >= 1 && kc <= 8) {
                 // 2 X[kc] = (pr, pi), 2 X[M - kc] = (mr, -mi):  csf[N - kc] = Z[N - kc] = conj X[kc] (slot 8 - kc),
                 // csf[N/2 + kc] = conj X[M - kc] (slot 8 + kc; kc = 8 has none)
@@ -569,24 +592,14 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             }
         }
     }
+    if constexpr (WALK) {
+#pragma unroll
+        for (int m3 = 0; m3 < R / 2; ++m3) c[m3 < 8 ? m3 : m3 + 8] = nextRows[m3];
+    }
     RCLK(6);
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
     if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
     if constexpr (WALK) mapper.arrived(); else mapper.prefetch(tb, tid);
-    [[maybe_unused]] UnitId nextUid = uid;
-    [[maybe_unused]] bool more = false;
-    if constexpr (WALK) {
-        // the registers of c[] are free: sixteen of the next unit's rows are requested now, BEHIND the map's own
-        // requests (the counter of outstanding loads is in order: what the map waits for must be older than these)
-        const uint32_t nextIndex = walkIndex + gridDim.x;
-        more = nextIndex < totalUnits;
-        if (more) {
-            nextUid = unitOfIndex<MONO>(prm, nextIndex, totalUnits);
-            walkIndex = nextIndex;
-            requestSamples(samplesOf(nextUid), tid, std::integral_constant<int, 1>{});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
