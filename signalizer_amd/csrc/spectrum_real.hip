@@ -435,8 +435,11 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // WALK: the recombination's twiddle and the map's table words are requested HERE, where nothing else of this workgroup is on its way
     // through the CU's fetch path: requested where they are used, a late wave's few bytes queue behind the early waves' requests for the
     // next unit's samples and it waits ~10 k clocks for them (tools/phase_clocks.py: pass 3 -> recombined 1.9 k -> 12.4 k clocks)
+    // (N = 32768 as well: a workgroup's few bytes otherwise queue behind the sample requests of the workgroup it shares the CU with: cfg2 -1.8 %
+    // with the input L2-resident, -0.7 % from HBM)
+    constexpr bool EARLYTAB = WALK || (LR1 == 4 && FRONT);
     [[maybe_unused]] float2 wkEarly;
-    if constexpr (WALK) {
+    if constexpr (EARLYTAB) {
         wkEarly = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
         mapper.prefetch(tb, tid);
     }
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(4);
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
     float2 wk;                                                           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
-    if constexpr (WALK) wk = wkEarly; else wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
+    if constexpr (EARLYTAB) wk = wkEarly; else wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
     ditPacked<LR, 0>(c);
     RCLK(5);
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
@@ -599,7 +602,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     RCLK(6);
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
     if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
-    if constexpr (WALK) mapper.arrived(); else mapper.prefetch(tb, tid);
+    if constexpr (WALK) mapper.arrived(); else if constexpr (!EARLYTAB) mapper.prefetch(tb, tid);
     ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
