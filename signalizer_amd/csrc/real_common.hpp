@@ -48,8 +48,9 @@ __device__ __forceinline__ float realBinMag(v2 a, v2 b, v2 w)
 struct UnitId { int side, pair; uint32_t task, frame, self; };
 // (unit, nb: the workgroup's index and the launch's size -- or, for a workgroup that walks over several units, the index and the number
 // of workgroups a one-unit-per-workgroup launch would have had)
-template <bool MONO>
-__device__ __forceinline__ UnitId unitOfIndex(const RealParams &prm, uint32_t unit, const uint32_t nb)
+// (P: RealParams, or the same block read in place from the kernel-argument segment -- WalkParams below)
+template <bool MONO, typename P>
+__device__ __forceinline__ UnitId unitOfIndex(const P &prm, uint32_t unit, const uint32_t nb)
 {
     const uint32_t rs = prm.roundSize;
     if (nb >= 64u && rs >= 8u && (rs & 7u) == 0u) {
@@ -71,6 +72,26 @@ __device__ __forceinline__ UnitId unitOfIndex(const RealParams &prm, uint32_t un
 
 template <bool MONO>
 __device__ __forceinline__ UnitId unitOf(const RealParams &prm) { return unitOfIndex<MONO>(prm, blockIdx.x, gridDim.x); }
+
+// A kernel whose workgroups loop over units keeps every field of its parameter block it touches -- ~80 scalar registers -- alive across
+// the loop, and what does not fit is parked in lanes of vector registers (v_writelane / v_readlane: 7 % of the N = 65536 kernel's
+// vector time).  Such a kernel reads the block IN PLACE instead: the kernel-argument segment through a pointer that is opaque once per
+// unit, so that every field is an s_load where it is used.  (The kernel's only parameter must be the block.)
+typedef const RealParams __attribute__((address_space(4))) WalkParams;
+__device__ __forceinline__ WalkParams *walkParams()
+{
+    WalkParams *p = (WalkParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <bool WALK> struct ParamsOf {
+    typedef const RealParams T;
+    static __device__ __forceinline__ T *get(const RealParams &launch) { return &launch; }
+};
+template <> struct ParamsOf<true> {
+    typedef WalkParams T;
+    static __device__ __forceinline__ T *get(const RealParams &) { return walkParams(); }
+};
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember what has been granted
 inline hipError_t grantLds(const void *kernel, size_t need, size_t (&granted)[64])

@@ -80,8 +80,8 @@ __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
 // the pixel map (chunk_map.hpp) and the settlement of the pixels that need both channels.  Shared by the transform kernel and by
 // realMapFromBinsKernel (sgz_stage_map_from_bins: the same code maps injected bins, so "the mapping is bit-exact given the bins"
 // is tested on the very functions the bench kernel runs).
-template <int LR1, int MIX>
-__device__ __forceinline__ void realMapSettle(const RealParams &prm, float *lds, const int tid, const int side, const long task, const long self,
+template <int LR1, int MIX, typename P>
+__device__ __forceinline__ void realMapSettle(const P &prm, float *lds, const int tid, const int side, const long task, const long self,
                                               const ChunkTables &tb, ChunkMap<(1 << (LR1 + 5))> &mapper, float *re, float *ce, float *spec)
 {
     constexpr int R = 32, R1 = 1 << LR1, T = R1 * R, M = R1 * R * R, N = 2 * M;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void realMapSettle(const RealParams &prm, float *lds,
 // with a zero imaginary part, TransformDSP.inl:59-135): one workgroup per task, no pair exchange.  csf[0] = |X[0]| / 2 and
 // csf[N/2] = X[N/2] / 2 (:547-552; the latter stays signed: the reference leaves it complex, and X[N/2] of a real signal is real).
 template <int LR1, bool WCOS, int MIX = 0>                 // MIX: 0 Separate (two channel workgroups), 1 mono Left / Right, 2 MidSide (two workgroups on mid and side), 3 mono Merge / Side
-__global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams prm)
+__global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealParams launchPrm)
 {
     constexpr int LR = 5, R = 32, R1 = 1 << LR1, T = R1 * R, RR = R * R, M = R1 * RR, N = 2 * M, U = R / R1;
     constexpr bool MONO = MIX == 1 || MIX == 3;
@@ -145,9 +145,10 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // wave requests the first half of the NEXT unit's rows as soon as its own magnitudes are out of the registers those rows land in --
     // the requests are served while the slower waves still transform and the map runs; the second half follows at the top of the loop.
     constexpr bool WALK = LR1 == 5 && MIX == 0 && WCOS;
-    const uint32_t totalUnits = WALK ? uint32_t(prm.frames) * prm.C * 2u : gridDim.x;
+    const uint32_t totalUnits = WALK ? uint32_t(launchPrm.frames) * launchPrm.C * 2u : gridDim.x;
     uint32_t walkIndex = blockIdx.x;
-    UnitId uid = unitOfIndex<MONO>(prm, walkIndex, totalUnits);     // (frame, pair, channel) or (frame, pair); real_common.hpp
+    UnitId uid = unitOfIndex<MONO>(launchPrm, walkIndex, totalUnits);     // (frame, pair, channel) or (frame, pair); real_common.hpp
+    [[maybe_unused]] bool firstUnit = true;
     // Wave priorities for a launch of two full dispatch generations and a partial third (cfg2: 696 workgroups on 256 CUs, two resident
     // per CU).  tools/unit_trace.py: workgroups b and b + #CUs share a CU, the third generation starts in the slots the first frees
     // and the launch ends when IT ends; its workgroups share their CU with second-generation ones that have ~10 us of slack.  Third
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // assignment with the last generation on top measures within 0.1 us of this one, 3 / 0 / 3 half the gain, 3 / 0 / 0 a loss).
     // Longer launches are left alone.  (A speed assumption only.)
     if constexpr (LR1 == 4) {
-        const uint32_t cus = prm.roundSize >> 1;
+        const uint32_t cus = launchPrm.roundSize >> 1;
         // The two workgroups that share a CU from the first clock of a launch (b and b + #CUs) would run IN PHASE -- both fetching, both in
         // their LDS exchanges, both in the map's scalar-heavy scan at the same time -- and take 65 k clocks each where two workgroups half
         // a life apart take 41 k (tools/phase_clocks.py): the second one starts ~10 k clocks late.  cfg2 launch -2.3 ... -5.5 % with the
@@ -180,6 +181,9 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     [[maybe_unused]] float2 twA[U], twB[U];
     [[maybe_unused]] float4 tw2piece, tw2tail;                  // (T = 512: threads 0 .. 31 carry a second piece of the 544)
     v2 c[R];
+    for (;;) {
+    // (WALK: the parameter block is read in place, through a pointer that is opaque once per unit: real_common.hpp WalkParams)
+    typename ParamsOf<WALK>::T &prm = *ParamsOf<WALK>::get(launchPrm);
     // which input channels feed a unit's signal: Separate: channel `side`; MidSide: (l + r) / 2 on side 0, (l - r) / 2 on side 1
     // (prepareTransform's MidSide case, then the same split as Separate); mono: l, r, (l + r) / 2 or (l - r) / 2
     auto samplesOf = [&](const UnitId &u) {
@@ -215,18 +219,21 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // 128-register limit: requested where used, as before.)
     auto requestTables = [&](const int tid) {
         if constexpr (FRONT) {
+            if constexpr (WALK) tw2piece = prm.tw2Full[tid < kTw2Floats / 4 ? tid : 0];     // (unconditional: a conditional one makes the registers loop-carried)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (WCOS) phase[u] = ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);
                 twA[u] = ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
                 twB[u] = ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
             }
-            if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid];
+            if constexpr (!WALK) { if (tid < kTw2Floats / 4) tw2piece = prm.tw2Full[tid]; }
             if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) tw2tail = prm.tw2Full[T + tid];
         }
     };
-    if constexpr (WALK) requestSamples(samplesOf(uid), tid0, std::integral_constant<int, 1>{});
-    for (;;) {
+    if constexpr (WALK) {
+        if (firstUnit) requestSamples(samplesOf(uid), tid0, std::integral_constant<int, 1>{});
+        firstUnit = false;
+    }
     // (WALK: the thread index is opaque per unit, or everything derived from it -- LDS addresses, lane offsets, twiddle indices -- is hoisted
     // out of the loop and held in registers through every phase: 33 spilled registers in the first build)
     const int tid = WALK ? opaque(tid0) : tid0;
@@ -268,9 +275,18 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     {
         // ---------------------------------------------------------------- load + window: z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
         const float *X = samplesOf(uid);
-        if constexpr (WALK) requestSamples(X, tid, std::integral_constant<int, 2>{});     // (part 1 was requested during the previous unit)
-        else requestSamples(X, tid, std::integral_constant<int, 0>{});
-        requestTables(tid);
+        if constexpr (WALK) {
+            // part 1 was requested during the previous unit and is in place: the tables go FIRST, so that its rows are windowed while
+            // part 2 arrives, and the pass-2 table's piece is parked in LDS as soon as it is there (four registers less through pass 1)
+            requestTables(tid);
+            __builtin_amdgcn_sched_barrier(0);
+            requestSamples(X, tid, std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (tid < kTw2Floats / 4) reinterpret_cast<float4 *>(lds + TAB)[tid] = tw2piece;
+        } else {
+            requestSamples(X, tid, std::integral_constant<int, 0>{});
+            requestTables(tid);
+        }
         if constexpr (FRONT) __builtin_amdgcn_sched_barrier(0);
         if (mixed) {
             // (l +- r) w 0.5 (prepareTransform, TransformDSP.inl:92-135): the right channel comes in batches of 8 pairs on top of the left
@@ -409,7 +425,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         };
         const int rd = q1 * 512 + ix;
         v2 lo[R / 2];
-        if constexpr (FRONT) {
+        if constexpr (FRONT && !WALK) {
             // the pass-2 twiddle table -> LDS (8.5 KB behind the exchange areas; the map's maxima take the place later)
             if (tid < kTw2Floats / 4) reinterpret_cast<float4 *>(lds + TAB)[tid] = tw2piece;
             if (T < kTw2Floats / 4 && tid < kTw2Floats / 4 - T) reinterpret_cast<float4 *>(lds + TAB)[T + tid] = tw2tail;
