@@ -558,8 +558,12 @@ sgz_status sgz_scope_flush(sgz_scope *s);      /* as sgz_spectrum_flush */
 /* Handle switch (consumer thread, between create / configure and the first push; the library reads no environment variable):
  *   SGZ_RT_OPT_DEFER_SUBMIT  0 (default): a pushed block goes to the GPU at once when nothing of the handle is in flight, otherwise it
  *       joins the open batch, which the next submission takes in ONE launch.  1: every block waits for a full batch or a reader
- *       (flush on read) -- every launch a multi-callback one.  Results are identical; the tests pin the batched paths down with it. */
+ *       (flush on read) -- every launch a multi-callback one.  Results are identical; the tests pin the batched paths down with it.
+ *   SGZ_RT_OPT_PARK_PUSHES   0 (default).  1: every pushed block is parked in the handle's host FIFO -- where a block goes whose push finds the
+ *       render thread submitting at that moment, or no staging slot free -- until the next read (flush on read covers the FIFO), push or
+ *       flush hands it on.  Results are identical; the tests reproduce a stopped transport with it. */
 #define SGZ_RT_OPT_DEFER_SUBMIT 3u
+#define SGZ_RT_OPT_PARK_PUSHES 4u
 sgz_status sgz_scope_set_option(sgz_scope *s, uint32_t option, uint64_t value);
 /* TriggeringMode::Window draws the window at the host transport's phase: position_in_samples = cs.transportPosition =
  * playhead.getPositionInSamples() + numSamples of the newest block (OscilloscopeDSP.inl:706; OscilloscopeRendering.cpp:588-592,
@@ -642,7 +646,7 @@ void       sgz_vector_destroy(sgz_vector *s);
 sgz_status sgz_vector_configure(sgz_vector *s, const sgz_vector_config *cfg);
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples);
 sgz_status sgz_vector_flush(sgz_vector *s);    /* as sgz_spectrum_flush */
-sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value);   /* SGZ_RT_OPT_DEFER_SUBMIT, as sgz_scope_set_option */
+sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value);   /* SGZ_RT_OPT_DEFER_SUBMIT / SGZ_RT_OPT_PARK_PUSHES, as sgz_scope_set_option */
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain /*optional: reading it waits*/);
 sgz_status sgz_vector_filters_get(sgz_vector *s, sgz_vector_filters *filters, double *envelope_gain);
 /* xyz: float3 [window_size], rgb: float3 [window_size] or NULL; *count: in = capacity in vertices, out = window_size.  Vertex

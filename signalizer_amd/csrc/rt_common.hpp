@@ -249,51 +249,58 @@ __device__ __forceinline__ void batchFetch(const float *from, float *to, uint32_
 }
 #endif
 
-// Blocks the GPU was not ready for, in arrival order.  Touched by the producer thread only (under the handle's push lock); storage is
-// allocated when the handle is configured, never on the audio thread.  Capacity: `seconds` of audio at the handle's rate (and at
-// least 32 blocks of the largest push) -- with the 8 staging slots that is how far the GPU may fall behind before audio is lost; the
-// reference's stream FIFO has the same kind of bound (its `bufferSize`).
+// Blocks the GPU was not ready for, in arrival order.  One writer, one reader at a time: push() belongs to the producer thread (under the
+// handle's push lock); front() / pop() to whoever holds the right to hand blocks to the GPU -- the producer inside its push, or the
+// consumer thread in a flush-on-read (scope / vector handles: the batch flag; spectrum handle: the push lock itself) -- so a block parked
+// here while the consumer held that right reaches the GPU with the consumer's next read even if no further push ever comes (a stopped
+// transport).  Storage is allocated when the handle is configured, never on the audio thread.  Capacity: `seconds` of audio at the handle's
+// rate (and at least 32 blocks of the largest push) -- with the 8 staging slots that is how far the GPU may fall behind before audio is lost;
+// the reference's stream FIFO has the same kind of bound (its `bufferSize`).
 struct Backlog {
     static constexpr int kEntries = 256;
-    struct Entry { uint32_t n, channels; size_t off; };
+    struct Entry { uint32_t n, channels; size_t off; uint64_t end; };   // end: the write position behind this block (what pop() frees up to)
     float *buf = nullptr;
-    size_t cap = 0, head = 0, tail = 0, used = 0;       // floats; [head, tail) circular, `used` counts the padding skipped at the wrap too
+    size_t cap = 0;
     Entry ent[kEntries];
-    uint32_t eh = 0, count = 0;
+    // writer
+    uint64_t wpos = 0;                                  // floats ever written, the padding skipped at the wraps included
+    uint32_t ewr = 0;
     uint64_t deferred = 0;                              // blocks that ever waited here
+    // reader
+    uint32_t erd = 0;
+    std::atomic<uint64_t> rpos{0};                      // everything below this position has been consumed
+    std::atomic<uint32_t> count{0};                     // entries waiting (written by both sides: the entry and its samples are published by the increment)
 
     sgz_status init(size_t floats)
     {
         release();
         buf = static_cast<float *>(std::malloc(floats * sizeof(float)));
         if (!buf) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
-        cap = floats; head = tail = used = 0; eh = count = 0;
+        cap = floats;
         return SGZ_OK;
     }
-    void release() { std::free(buf); buf = nullptr; cap = 0; head = tail = used = 0; eh = count = 0; }
-    void clear() { head = tail = used = 0; eh = count = 0; }
+    void release() { std::free(buf); buf = nullptr; cap = 0; clear(); }
+    void clear() { wpos = 0; ewr = erd = 0; rpos.store(0); count.store(0); }      // (no other thread in the handle: configure / destroy)
     bool push(const float *const *planar, uint32_t channels, uint32_t n)
     {
         const size_t need = size_t(channels) * n;
-        if (count == kEntries || need > cap) return false;
-        size_t at = tail, pad = 0;
-        if (tail + need > cap) { pad = cap - tail; at = 0; }                    // does not fit behind the tail: start over at the front
-        if (used + pad + need > cap) return false;
+        if (count.load(std::memory_order_acquire) == uint32_t(kEntries) || need > cap) return false;
+        size_t at = size_t(wpos % cap), pad = 0;
+        if (at + need > cap) { pad = cap - at; at = 0; }                        // does not fit behind the tail: start over at the front
+        if (wpos - rpos.load(std::memory_order_acquire) + pad + need > cap) return false;
         for (uint32_t c = 0; c < channels; ++c) std::memcpy(buf + at + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
-        ent[(eh + count) % kEntries] = Entry{n, channels, at};
-        ++count; ++deferred;
-        tail = at + need; used += pad + need;
+        wpos += pad + need;
+        ent[ewr % kEntries] = Entry{n, channels, at, wpos};
+        ++ewr; ++deferred;
+        count.fetch_add(1, std::memory_order_release);
         return true;
     }
-    const Entry &front() const { return ent[eh]; }
+    const Entry &front() const { return ent[erd % kEntries]; }                  // (count != 0, read with acquire by the caller's test)
     void pop()
     {
-        const Entry &e = ent[eh];
-        const size_t need = size_t(e.channels) * e.n;
-        const size_t pad = e.off >= head ? e.off - head : cap - head + e.off;   // (the padding skipped when this entry wrapped)
-        head = e.off + need; used -= pad + need;
-        eh = (eh + 1) % kEntries; --count;
-        if (!count) { head = tail = used = 0; }
+        rpos.store(ent[erd % kEntries].end, std::memory_order_release);
+        ++erd;
+        count.fetch_sub(1, std::memory_order_release);
     }
 };
 
@@ -313,7 +320,7 @@ template <typename PushNow>
 sgz_status pushThroughBacklog(Backlog &bl, const float *const *planar, uint32_t channels, uint32_t n, PushNow pushNow)
 {
     const float *ptrs[64];
-    while (bl.count) {
+    while (bl.count.load(std::memory_order_acquire)) {
         const Backlog::Entry e = bl.front();
         for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = bl.buf + e.off + size_t(c) * e.n;
         const sgz_status st = pushNow(ptrs, e.channels, e.n);
@@ -321,7 +328,7 @@ sgz_status pushThroughBacklog(Backlog &bl, const float *const *planar, uint32_t 
         bl.pop();
         if (st != SGZ_OK) return st;
     }
-    if (!bl.count) {
+    if (!bl.count.load(std::memory_order_acquire)) {
         const sgz_status st = pushNow(planar, channels, n);
         if (st != SGZ_BUSY) return st;
     }

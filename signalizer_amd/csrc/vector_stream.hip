@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams p
 struct sgz_vector {
     sgz_vector_config cfg{};
     bool deferSubmit = false;                  // sgz_vector_set_option(SGZ_RT_OPT_DEFER_SUBMIT)
+    bool parkPushes = false;                   // ... (SGZ_RT_OPT_PARK_PUSHES): every push waits in the host FIFO for the next reader / flush
     std::mutex mu;
     hipStream_t stream = nullptr;
     BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
@@ -468,11 +469,31 @@ static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t
     return SGZ_OK;
 }
 
-// consumer side (flush on read): what waits in the open batch goes to the GPU in front of the caller's own work
+// The blocks a push had to park in the host FIFO (rt_common.hpp Backlog: the consumer held the batch flag, or no staging slot was free) go
+// behind the open batch's, in order.  Caller holds the batch flag and is NOT the audio thread (a staging slot that is still in flight is
+// waited for).  all = false: only the blocks that wait at the time of the call -- a producer that keeps pushing cannot keep a reader here.
+static sgz_status vectorTakeBacklog(sgz_vector *s, bool all)
+{
+    const float *ptrs[64];
+    uint32_t left = s->backlog.count.load(std::memory_order_acquire);
+    while (all ? s->backlog.count.load(std::memory_order_acquire) != 0 : left != 0) {
+        const Backlog::Entry e = s->backlog.front();
+        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
+        const sgz_status st = vectorPushNow(s, ptrs, e.channels, e.n);
+        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }
+        s->backlog.pop();
+        if (left) --left;
+        if (st != SGZ_OK) return st;
+    }
+    return SGZ_OK;
+}
+
+// consumer side (flush on read): what waits in the host FIFO and in the open batch goes to the GPU in front of the caller's own work
 static sgz_status vectorSync(sgz_vector *s)
 {
     s->batch.lock();
-    const sgz_status st = s->batch.count ? vectorSubmit(s) : SGZ_OK;
+    sgz_status st = vectorTakeBacklog(s, false);
+    if (st == SGZ_OK && s->batch.count) st = vectorSubmit(s);
     s->batch.unlock();
     return st;
 }
@@ -487,7 +508,8 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     if (nsamples > s->maxBlock) return fail(SGZ_EINVAL, "block longer than sgz_vector_config::max_block");
     // never waits: the render thread is submitting the open batch right now -> the block waits its turn in the host FIFO, like one the
     // GPU is not ready for (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
-    if (!s->batch.tryLock()) {
+    // (SGZ_RT_OPT_PARK_PUSHES: every block takes that way -- the tests' handle on a race that timing alone produces)
+    if (s->parkPushes || !s->batch.tryLock()) {
         const bool queued = s->backlog.push(planar, num_channels, nsamples);
         if (!queued) s->busy++;
         return queued ? SGZ_OK : SGZ_BUSY;
@@ -505,6 +527,7 @@ sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
+    if (option == SGZ_RT_OPT_PARK_PUSHES) { s->parkPushes = value != 0; return SGZ_OK; }
     if (option != SGZ_RT_OPT_DEFER_SUBMIT) return fail(SGZ_EINVAL, "unknown vector option");
     s->deferSubmit = value != 0;
     return SGZ_OK;
@@ -515,16 +538,7 @@ sgz_status sgz_vector_flush(sgz_vector *s)
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
     s->batch.lock();
-    const float *ptrs[64];
-    sgz_status out = SGZ_OK;
-    while (s->backlog.count) {
-        const Backlog::Entry e = s->backlog.front();
-        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
-        const sgz_status st = vectorPushNow(s, ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }         // this call may wait: it is not the audio thread's
-        s->backlog.pop();
-        if (st != SGZ_OK) { out = st; break; }
-    }
+    sgz_status out = vectorTakeBacklog(s, true);                      // (this call may wait: it is not the audio thread's)
     if (out == SGZ_OK && s->batch.count) out = vectorSubmit(s);
     s->batch.unlock();
     return out;

@@ -33,11 +33,13 @@ def _push(dev, blk):
         assert st == api.SGZ_BUSY
 
 
-def _feed(po, cfg, x, seed, max_block=3000, defer=False):
+def _feed(po, cfg, x, seed, max_block=3000, defer=False, park=False):
     """the same random block schedule into the HIP handle and the oracle stream"""
     dev = api.Scope(**cfg)
     if defer:
         dev.set_option(api.RT_OPT_DEFER_SUBMIT, 1)
+    if park:
+        dev.set_option(api.RT_OPT_PARK_PUSHES, 1)
     ref = po.ScopeStream(cfg["num_channels"], cfg["sample_rate"], cfg["window_size"], cfg["trigger_mode"], cfg["trigger_threshold"],
                          cfg["channel_mode"], cfg["trigger_channel"], cfg["envelope_mode"], cfg["envelope_window"])
     rng = np.random.default_rng(seed)
@@ -121,6 +123,36 @@ def test_batched_launches_are_the_callback_walk(gpu, oracle, over, max_block, mo
     if cfg["envelope_mode"] == 1:
         assert gain == ref.envelope_gain
         assert np.array_equal(env[:2].view(np.uint32), ref.envelopes()[:2].view(np.uint32))
+
+
+@pytest.mark.parametrize("over,max_block", [(dict(window_size=480.3, trigger_threshold=0.0), 300),
+                                            (dict(window_size=2048.0, channel_mode=4, num_channels=6, trigger_channel=5.0, envelope_mode=1), 400)])
+def test_parked_blocks_reach_the_gpu_with_the_next_read(gpu, oracle, over, max_block):
+    """A push that finds the render thread submitting (or no staging slot free) parks its block in the handle's host FIFO.  Flush on read
+    covers that FIFO: with SGZ_RT_OPT_PARK_PUSHES EVERY block goes that way, and the only thing that hands blocks to the GPU is a reader
+    (the spot checks of _feed, the reads below) -- no flush, no push that finds the way free.  State machine, rings and gains are the
+    oracle's callback walk, the blocks pushed after the last mid-stream read included (a stopped transport)."""
+    po = oracle
+    cfg = _cfg(**over)
+    x = _signal(9, 40000, cfg["num_channels"])
+    dev, ref = _feed(po, cfg, x, seed=41, max_block=max_block, park=True)
+    gain, env = dev.gains()                                           # (first read after the last push: peak-filter-free path)
+    assert dev.state() == ref.state()
+    for c in range(cfg["num_channels"]):
+        got, gcur = dev.front(c)
+        want, wcur = ref.front(c)
+        assert gcur == wcur
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (c, int((got != want).sum()))
+    if cfg["envelope_mode"] == 1:
+        assert gain == ref.envelope_gain
+        assert np.array_equal(env[:2].view(np.uint32), ref.envelopes()[:2].view(np.uint32))
+    # ... and through the peak filter's own submission (it rides on the ingest launch of whatever waits)
+    more = _signal(77, 1500, cfg["num_channels"])
+    _push(dev, more); ref.audio(more)
+    dt = 1.0 / 60
+    coeff = np.power(np.exp(-8.0 / (cfg["envelope_window"] * cfg["sample_rate"])), ref.size * dt)
+    assert dev.peak_filter(dt, 8) == ref.peak_filter(8, float(coeff))
+    assert dev.state() == ref.state()
 
 
 @pytest.mark.parametrize("mode,channels", [(0, 2), (1, 2), (2, 2), (3, 2), (4, 6), (5, 4)])

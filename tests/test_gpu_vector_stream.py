@@ -136,6 +136,37 @@ def test_batched_launches_are_the_callback_walk(gpu, oracle, channels, size, env
     assert np.abs(np.array(f.phase[:]) - np.array(ref.f.phase[:])).max() <= 1e-5
 
 
+def test_parked_blocks_reach_the_gpu_with_the_next_read(gpu, oracle):
+    """A push that finds the render thread submitting (or no staging slot free) parks its block in the handle's host FIFO.  Flush on read
+    covers that FIFO: when the transport stops -- no further push -- the newest audio still shows in the next read.  SGZ_RT_OPT_PARK_PUSHES
+    sends EVERY block that way; ring, cursor, envelopes and balance must be the oracle's walk over all of them after one read, without a
+    flush and without another push, and again after more blocks with readers in between."""
+    po = oracle
+    channels, size = 4, 3000
+    dev = api.Vector(sample_rate=SR, num_channels=channels, window_size=size, envelope_mode=1, lanes=8, fade_history=1,
+                     max_block=1024, envelope_window=0.3, stereo_window=0.05).set_option(api.RT_OPT_PARK_PUSHES, 1)
+    ref = RefVector(po, channels, size, 1, 0.3, 0.05, 8)
+    x = synth.gen(19, SR, 30000, channels)
+    rng = np.random.default_rng(5)
+    pos = 0
+    for rnd in range(6):
+        for _ in range(int(rng.integers(1, 24))):                        # more blocks than one staging batch holds, sometimes
+            n = int(rng.integers(1, 1024))
+            blk = x[:, pos:pos + n]
+            if blk.shape[1] == 0: break
+            _push(dev, blk); ref.audio(blk)
+            pos += blk.shape[1]
+        f, gain = dev.filters()                                         # the read: nothing else hands the parked blocks on
+        gb = np.array([list(r) for r in f.balance], np.float32)
+        rb = np.array([list(r) for r in ref.f.balance], np.float32)
+        assert np.array_equal(gb.view(np.uint32), rb.view(np.uint32)), rnd
+        assert np.float32(gain) == np.float32(ref.gain), rnd
+        for c in range(channels):
+            mem, cur = dev.history(c)
+            assert cur == ref.cursor
+            assert np.array_equal(mem.view(np.uint32), ref.mem[c].view(np.uint32)), (rnd, c)
+
+
 def test_cfg4_shape(gpu, oracle):
     """BASELINE configs[3]: 8 channels 96 kHz, 100 ms window = 9600 samples per pair, blocks of 480"""
     po = oracle
