@@ -181,7 +181,9 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
                                       block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
                                       slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one
-                                      before it left */
+                                      before it left.  The SHARDED render holds a rank's whole chunk of those states between its two halves
+                                      (from rest ... carry + windows) and cannot cut it: there the value is a bound (default: 8 GiB worth of
+                                      frames) and a rank's chunk above it is refused with SGZ_EUNSUPPORTED on every rank */
 #define SGZ_OPT_WIDE_GROUPS 6u       /* N = 32768 channel-split plans (pairs): 0 (default): one 512-thread workgroup per (frame, pair, channel), 32 values
                                       per thread (spectrum_real.hip); 1: 1024 threads of sixteen values (spectrum_real16.hip: 8 waves per SIMD; measured
                                       7-12 % slower on MI355X -- NOTES.md round 5 -- and kept as a tested alternative) */

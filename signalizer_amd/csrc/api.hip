@@ -258,6 +258,16 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
 // end states is added to every frame and the window kernel fills d_mapped.
 sgz_status runResonatorFromRest(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
 {
+    // The per-frame states of the WHOLE chunk stay on the device between the two halves (runResonatorJoin adds the carry to every frame of
+    // them), so this path cannot go in slabs like a plain render: the bound SGZ_OPT_RESONATOR_SLAB sets (default: 8 GiB here -- a rank's chunk
+    // of a sharded job is sized for the device, not for a plugin's working set) is enforced by refusing the chunk, on every rank alike and
+    // before anything is exchanged.
+    const size_t perFrame = size_t(p.C) * size_t(p.stateChannels) * size_t(p.resV) * p.P * 2 * sizeof(float);
+    const size_t bound = p.optResonatorSlab ? size_t(p.optResonatorSlab) : std::max<size_t>(64, (size_t(8) << 30) / std::max<size_t>(perFrame, 1));
+    if (frames > 0 && size_t(frames) > bound)
+        return fail(SGZ_EUNSUPPORTED, "sharded RSNT render: a rank's chunk of " + std::to_string(frames) + " frames holds " +
+                                          std::to_string((size_t(frames) * perFrame) >> 20) + " MiB of per-frame resonator states between the two halves of the render, above the bound of " +
+                                          std::to_string(bound) + " frames (SGZ_OPT_RESONATOR_SLAB; default 8 GiB): use more ranks or a shorter buffer per call");
     if (sgz_status st = resetResonator(p, stream); st != SGZ_OK) return st;
     return runResonator(p, d_planar, chStride, frames, d_mapped, stream, 0, /*skipWindow=*/true);
 }
