@@ -485,9 +485,12 @@ def main() -> None:
                     help="N > 1: sgz_spectrogram_render_sharded on its own RCCL communicator (default), or signalizer_amd.sharding over "
                          "torch.distributed's nccl backend")
     ap.add_argument("--halo", choices=("p2p", "allgather"), default="p2p", help="torch implementation only: halo exchange form")
-    ap.add_argument("--allow-torch-fallback", action="store_true",
-                    help="N > 1 with --shard-impl c_abi: if the library's own RCCL path fails on any rank, time signalizer_amd.sharding (the "
-                         "torch.distributed twin) instead of exiting non-zero.  Off by default: a scaling run must never time the twin silently")
+    ap.add_argument("--strict-shard-impl", action="store_true",
+                    help="N > 1 with --shard-impl c_abi: exit non-zero if the library's own RCCL path fails on any rank.  By default such a run "
+                         "times signalizer_amd.sharding instead (the same HIP kernels through the C ABI's stage calls, the collectives issued by "
+                         "torch.distributed's RCCL backend) and SAYS SO: on stderr and in config.shard_impl of the line (with the error) -- a "
+                         "scaling record with a disclosed fall-back instead of none")
+    ap.add_argument("--allow-torch-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
     args = ap.parse_args()
 
     import torch
@@ -553,12 +556,14 @@ def main() -> None:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             shard, shard_note = cand, "c_abi"
-        elif args.allow_torch_fallback:
+        elif not args.strict_shard_impl:
             shard_note = "torch (the library's own RCCL path failed on some rank" + (f": {err}" if err else "") + ")"
+            sys.stderr.write(f"[bench rank {rank}] sgz_spectrogram_render_sharded / sgz_comm_create failed" + (f": {err}" if err else " on another rank")
+                             + " -- timing the torch.distributed twin instead (config.shard_impl says so; --strict-shard-impl exits here)\n")
         else:
             # loud: sgz_spectrogram_render_sharded is what a scaling run is meant to measure
             sys.stderr.write(f"[bench rank {rank}] sgz_spectrogram_render_sharded / sgz_comm_create failed" + (f": {err}" if err else " on another rank")
-                             + " -- not falling back to the torch path (pass --allow-torch-fallback or --shard-impl torch to time that one)\n")
+                             + " (--strict-shard-impl: not falling back to the torch path)\n")
             dist.destroy_process_group()
             raise SystemExit(3)
     frames_per_rank = shard.local_frames
