@@ -41,8 +41,14 @@ for case in range(cases):
         r = po.resonator_spectrogram(p, x, want_mapped=True, want_scale=True)
         ref = _planes(r["mapped"], mode, d["axis_points"])
         ok = got.shape == ref.shape
+        if not ok:
+            print("   shape", got.shape, ref.shape)
         if F == 1 or d["hop"] % 1024:                             # (a launch of several frames on the matrix cores starts every frame from rest)
-            ok &= np.array_equal(got[0], ref[0])
+            same0 = np.array_equal(got[0], ref[0])
+            if not same0:
+                print("   frame 0 differs from the oracle's (sample-by-sample continuation): frames", F, "hop", d["hop"], "entries", int((got[0] != ref[0]).sum()),
+                      "max |diff|", float(np.nanmax(np.abs(got[0] - ref[0]))))
+            ok &= same0
         problems, worst_case = check_planes(got, ref, r["scale"], mode, po.resonator_map(p)[1])
         ok &= not problems
         if problems:
@@ -53,6 +59,10 @@ for case in range(cases):
         worst = max(worst, worst_case)
         rgba = plan.render(xs).cpu().numpy()
         want, _ = po.decay_colour(p, got)
+        if not np.array_equal(rgba, want):
+            dd = np.abs(rgba.astype(int) - want.astype(int))
+            print("   image differs from the oracle's K_B on the device's own magnitudes: bytes", int((dd > 0).sum()), "max", int(dd.max()), "frames", F,
+                  "first at", tuple(int(v) for v in np.argwhere(dd > 0)[0]))
         ok &= np.array_equal(rgba, want)
     except Exception as e:                                         # noqa: BLE001
         ok = False
