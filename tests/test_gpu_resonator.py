@@ -4,7 +4,7 @@ Bars:
   * a one-frame launch continues the carried state sample by sample: the windowed magnitudes are BIT-EXACT against the oracle's
     sequential fp32 recurrence (this is the real-time case: one frame per audio block);
   * a multi-frame launch chains the frames with c^hop (resonator.hip): magnitudes within 2e-5 of the frame's largest (measured ~3e-7)
-    plus 4 eps sqrt(1 / (1 - r)) of the size of the terms the window kernel sums (long resonators: see check_planes);
+    plus 8 eps sqrt(1 / (1 - r)) of the size of the terms the window kernel sums (long resonators: see check_planes and STATE_K);
   * decay -> dB -> colour -> RGBA8 and line results BIT-EXACT given the HIP path's own magnitudes (the same K_B as the FFT branch).
 cpl's CComplexResonator is absent: the oracle restates it (UNVERIFIED vs cpl), parity is against that restatement."""
 import ctypes as C
@@ -18,10 +18,13 @@ from signalizer_amd import api, config as cf, synth
 pytestmark = pytest.mark.gpu
 
 CHAIN_TOL = 2e-5          # of the frame's largest value: well-conditioned configurations (measured ~3e-7)
-STATE_K = 4.0             # x eps x sqrt(1 / (1 - r)) of gain * sum_v |w_v| |s_v|, the terms the window kernel sums: a resonator remembers
+STATE_K = 8.0             # x eps x sqrt(1 / (1 - r)) of gain * sum_v |w_v| |s_v|, the terms the window kernel sums: a resonator remembers
                           # ~1 / (1 - r) samples, its fp32 recurrence accumulates ~sqrt(that) roundings, and long resonators (free Q: up to
                           # 1e5 samples) make the windowed value a small difference of large states -- two correct fp32 evaluations
-                          # (sequential, chained) differ by that much of THOSE, not of the result
+                          # (sequential, chained) differ by that much of THOSE, not of the result.  4 of these units hold EITHER
+                          # evaluation against an fp64 walk of the same resonators (tools/rsnt_fp64_check.py on the two worst of 5 200 fuzz
+                          # cases: device <= 0.76, oracle <= 1.09 of a 4-unit bar -- the device's is the closer one in 33 of 35 frames); their
+                          # DIFFERENCE, which is what this file can afford to test, is held to twice that (observed: 1.25 of the 4-unit bar)
 EPS = 2.0 ** -24
 
 
