@@ -22,7 +22,8 @@ extern "C" {
 /* 3: sgz_spectrum_config grew algorithm / free_q, sgz_scope_config custom_trigger / custom_trigger_frequency (round 3);
  * 4: sgz_spectrum_config grew display_mode (ZERO = the line graph, as in the reference's enum), sgz_spectrum_render_lines,
  *    sgz_spectrum_set_option (round 4);
- * 5: sgz_scope_set_option / sgz_vector_set_option (SGZ_RT_OPT_DEFER_SUBMIT), sgz_spectrum_track_peak_lines, plan option SGZ_OPT_WIDE_GROUPS (round 5);
+ * 5: sgz_scope_set_option / sgz_vector_set_option (SGZ_RT_OPT_DEFER_SUBMIT, SGZ_RT_OPT_PARK_PUSHES), sgz_spectrum_track_peak_lines, plan option
+ *    SGZ_OPT_WIDE_GROUPS; the Oscilloscope / Vectorscope readers flush the host FIFO as well; SGZ_OPT_RESONATOR_SLAB bounds the sharded RSNT render (round 5);
  * a binding compares sgz_abi_version() with the header it was compiled against */
 #define SGZ_ABI_VERSION 5
 
