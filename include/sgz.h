@@ -23,7 +23,7 @@ extern "C" {
  * 4: sgz_spectrum_config grew display_mode (ZERO = the line graph, as in the reference's enum), sgz_spectrum_render_lines,
  *    sgz_spectrum_set_option (round 4);
  * 5: sgz_scope_set_option / sgz_vector_set_option (SGZ_RT_OPT_DEFER_SUBMIT, SGZ_RT_OPT_PARK_PUSHES), sgz_spectrum_track_peak_lines, plan option
- *    SGZ_OPT_WIDE_GROUPS; the Oscilloscope / Vectorscope readers flush the host FIFO as well; SGZ_OPT_RESONATOR_SLAB bounds the sharded RSNT render (round 5);
+ *    SGZ_OPT_WIDE_GROUPS; the Oscilloscope / Vectorscope readers flush the host FIFO as well; SGZ_OPT_RESONATOR_SLAB bounds the sharded RSNT render (round 5; its own option SGZ_OPT_RESONATOR_SHARD_BOUND from round 6);
  * a binding compares sgz_abi_version() with the header it was compiled against */
 #define SGZ_ABI_VERSION 5
 
@@ -182,12 +182,14 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
                                       block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
                                       slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one
-                                      before it left.  The SHARDED render holds a rank's whole chunk of those states between its two halves
-                                      (from rest ... carry + windows) and cannot cut it: there the value is a bound (default: 8 GiB worth of
-                                      frames) and a rank's chunk above it is refused with SGZ_EUNSUPPORTED on every rank */
+                                      before it left.  It plays no part in the sharded render (SGZ_OPT_RESONATOR_SHARD_BOUND) */
 #define SGZ_OPT_WIDE_GROUPS 6u       /* N = 32768 channel-split plans (pairs): 0 (default): one 512-thread workgroup per (frame, pair, channel), 32 values
                                       per thread (spectrum_real.hip); 1: 1024 threads of sixteen values (spectrum_real16.hip: 8 waves per SIMD; measured
                                       7-12 % slower on MI355X -- NOTES.md round 5 -- and kept as a tested alternative) */
+#define SGZ_OPT_RESONATOR_SHARD_BOUND 7u /* RSNT, sgz_spectrogram_render_sharded only: that render holds the per-frame resonator states of a rank's WHOLE
+                                      chunk between its two halves (from rest ... carry + windows) and cannot cut it, so this is a bound, in frames
+                                      (0, the default: 8 GiB worth): a rank's chunk above it is refused with SGZ_EUNSUPPORTED on every rank before
+                                      anything is allocated or exchanged (round 6; rounds 4-5 read SGZ_OPT_RESONATOR_SLAB here) */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or

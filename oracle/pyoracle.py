@@ -72,7 +72,7 @@ class VectorFilters(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "scope_spectral.c", "resonator.c", "spectrum_stream.c", "sgz_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("primitives.c", "spectrum.c", "scope_vector.c", "scope_stream.c", "scope_spectral.c", "resonator.c", "spectrum_stream.c", "fft_simd.c", "sgz_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:

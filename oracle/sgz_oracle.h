@@ -120,6 +120,10 @@ long sgzo_spectrogram(const sgzo_spectrum_params *p, const float *const *planar,
 /* same but only the FFT-heavy part of frames [f0,f1) - used by bench.py's bounded cpu_baseline sample */
 long sgzo_spectrogram_range(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
                             long f0, long f1, uint8_t *rgba_out);
+/* timing only (bench.py cpu_baseline.simd_value): the same chain on fft_simd.c's vectorisable radix-4 Stockham transform */
+long sgzo_spectrogram_range_simd(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                                 long f0, long f1, uint8_t *rgba_out);
+int  sgzo_fft_forward_simd(sgzo_cf *buf, uint32_t N);    /* fft_simd.c; same definition as sgzo_fft_forward */
 long sgzo_num_frames(size_t nsamples, uint32_t W, uint32_t hop);
 /* frequency tracker, raw-FFT branch (SpectrumRendering.cpp:379-469): out = {peakOffset, peakFraction, peakFrequency, peakDBs, alpha, beta, gamma, phi} */
 void sgzo_track_peak(const sgzo_spectrum_params *p, const sgzo_cf *source, uint32_t N, const float *mapped, double window_scale,

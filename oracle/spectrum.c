@@ -512,8 +512,12 @@ long sgzo_num_frames(size_t nsamples, uint32_t W, uint32_t hop)
 /* Offline job: ideal STFT framing (frame f covers samples [f*hop, f*hop+W)), i.e. what
  * TransformPair::audioEntryPoint (TransformDSP.inl:1165-1211) produces when every frame fires at a
  * callback end with history == W, followed by blendAndDispatchSpectrums per frame. */
+static void fft_restated(sgzo_cf *buf, uint32_t N) { sgzo_fft_forward(buf, N); }
+static void fft_vectorised(sgzo_cf *buf, uint32_t N) { if (sgzo_fft_forward_simd(buf, N)) sgzo_fft_forward(buf, N); }
+
 static long spectrogram_impl(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
-                             long f0, long f1, uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out)
+                             long f0, long f1, uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out,
+                             void (*fft)(sgzo_cf *, uint32_t))
 {
     const uint32_t W = p->window_size, N = sgzo_transform_size(W), P = p->axis_points, C = p->num_pairs;
     const long F = sgzo_num_frames(nsamples, W, p->hop);
@@ -540,7 +544,7 @@ static long spectrogram_impl(const sgzo_spectrum_params *p, const float *const *
             const float *L = planar[2 * pr] + start, *R = planar[2 * pr + 1] + start;
             sgzo_prepare_transform(p->channel_mode, L, R, window, W, N, csf);
             csf[N].re = csf[N].im = 0;                  /* mono modes never write csf[N]; defined as 0 */
-            sgzo_fft_forward(csf, N);
+            fft(csf, N);
             memset(csp, 0, sizeof(sgzo_cf) * (size_t)P * 2);
             sgzo_map_to_linear_space(p, mapped, scale, csf, N, csp);
             if (mapped_out)
@@ -563,13 +567,21 @@ long sgzo_spectrogram(const sgzo_spectrum_params *p, const float *const *planar,
                       uint8_t *rgba_out, sgzo_cf *line_out, sgzo_cf *mapped_out)
 {
     return spectrogram_impl(p, planar, nsamples, 0, sgzo_num_frames(nsamples, p->window_size, p->hop),
-                            rgba_out, line_out, mapped_out);
+                            rgba_out, line_out, mapped_out, fft_restated);
 }
 
 long sgzo_spectrogram_range(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
                             long f0, long f1, uint8_t *rgba_out)
 {
-    return spectrogram_impl(p, planar, nsamples, f0, f1, rgba_out, NULL, NULL);
+    return spectrogram_impl(p, planar, nsamples, f0, f1, rgba_out, NULL, NULL, fft_restated);
+}
+
+/* bench.py's cpu_baseline.simd_value ONLY: the same chain with fft_simd.c's vectorisable transform in the place of the restated
+ * radix-2 (the reference's is pffft, SIMD: TransformDSP.inl:487-502).  Not the parity oracle: nothing is compared against it. */
+long sgzo_spectrogram_range_simd(const sgzo_spectrum_params *p, const float *const *planar, size_t nsamples,
+                                 long f0, long f1, uint8_t *rgba_out)
+{
+    return spectrogram_impl(p, planar, nsamples, f0, f1, rgba_out, NULL, NULL, fft_vectorised);
 }
 
 /* Test hook: mapAndTransformDFTFilters + blendAndDispatchSpectrums (the two functions above, unchanged) over F frames of

@@ -256,18 +256,24 @@ static sgz_status runResonator(Plan &p, const float *d_planar, size_t chStride, 
 // The two halves of a sharded RSNT render (sharded.hip): the resonators over this rank's chunk FROM REST, chained, windows not yet
 // applied (the plan's state = the end state from rest, what the ranks exchange); then the entering state folded from the gathered
 // end states is added to every frame and the window kernel fills d_mapped.
-sgz_status runResonatorFromRest(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
+// The per-frame states of a rank's WHOLE chunk stay on the device between the two halves of a sharded RSNT render (runResonatorJoin adds
+// the carry to every frame of them), so that path cannot go in slabs like a plain render.  Its bound is an option of its own,
+// SGZ_OPT_RESONATOR_SHARD_BOUND (default: 8 GiB worth of frames -- a rank's chunk of a sharded job is sized for the device, not for a
+// plugin's working set); SGZ_OPT_RESONATOR_SLAB, the plain render's working-set knob, plays no part here.  A chunk above the bound is
+// refused, on every rank alike, before anything is allocated or exchanged.
+sgz_status checkResonatorShardBound(const Plan &p, long frames)
 {
-    // The per-frame states of the WHOLE chunk stay on the device between the two halves (runResonatorJoin adds the carry to every frame of
-    // them), so this path cannot go in slabs like a plain render: the bound SGZ_OPT_RESONATOR_SLAB sets (default: 8 GiB here -- a rank's chunk
-    // of a sharded job is sized for the device, not for a plugin's working set) is enforced by refusing the chunk, on every rank alike and
-    // before anything is exchanged.
     const size_t perFrame = size_t(p.C) * size_t(p.stateChannels) * size_t(p.resV) * p.P * 2 * sizeof(float);
-    const size_t bound = p.optResonatorSlab ? size_t(p.optResonatorSlab) : std::max<size_t>(64, (size_t(8) << 30) / std::max<size_t>(perFrame, 1));
+    const size_t bound = p.optResonatorShardBound ? size_t(p.optResonatorShardBound) : std::max<size_t>(64, (size_t(8) << 30) / std::max<size_t>(perFrame, 1));
     if (frames > 0 && size_t(frames) > bound)
         return fail(SGZ_EUNSUPPORTED, "sharded RSNT render: a rank's chunk of " + std::to_string(frames) + " frames holds " +
                                           std::to_string((size_t(frames) * perFrame) >> 20) + " MiB of per-frame resonator states between the two halves of the render, above the bound of " +
-                                          std::to_string(bound) + " frames (SGZ_OPT_RESONATOR_SLAB; default 8 GiB): use more ranks or a shorter buffer per call");
+                                          std::to_string(bound) + " frames (SGZ_OPT_RESONATOR_SHARD_BOUND; default 8 GiB): use more ranks or a shorter buffer per call");
+    return SGZ_OK;
+}
+sgz_status runResonatorFromRest(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream)
+{
+    if (sgz_status st = checkResonatorShardBound(p, frames); st != SGZ_OK) return st;
     if (sgz_status st = resetResonator(p, stream); st != SGZ_OK) return st;
     return runResonator(p, d_planar, chStride, frames, d_mapped, stream, 0, /*skipWindow=*/true);
 }
@@ -615,6 +621,7 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
     case SGZ_OPT_MATRIX_RESONATOR: if (value > 2) return fail(SGZ_EINVAL, "SGZ_OPT_MATRIX_RESONATOR: 0, 1 or 2"); p.optMatrixResonator = int(value); return SGZ_OK;
     case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
+    case SGZ_OPT_RESONATOR_SHARD_BOUND: p.optResonatorShardBound = value; return SGZ_OK;
     case SGZ_OPT_WIDE_GROUPS: p.optWideGroups = value != 0; return SGZ_OK;
     default: return fail(SGZ_EINVAL, "unknown plan option");
     }

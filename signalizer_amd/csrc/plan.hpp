@@ -100,7 +100,7 @@ struct Plan {
     std::vector<float> winPhase; float winP0 = 0.f, winP1 = 0.f;   // channel-split path, Hann / Hamming periodic: the window is computed in the kernel
     std::vector<float> twRealPost;      // W_N^{kc}, kc < R1 * 32: the real-FFT recombination twiddle of a thread's bins
     std::vector<float> tw16, twPost16;  // the 1024-thread form of the N = 32768 channel transform (spectrum_real16.hip): pass-2 / pass-3 twiddles (LDS-staged), W_N^{kb}
-    std::vector<float> tw2Full;         // channel-split kernels, N >= 32768: the whole pass-2 table W_1024^{c q}, [q < 32][c < 32] (re, im), staged in LDS
+    std::vector<float> tw2Full;         // channel-split kernels, N >= 32768: the whole pass-2 table W_1024^{c q} as [c < 32][34] float2 (re, im), q < 32 used, two pad entries per row (a thread's 32 factors are 16 ds_read_b128); staged in LDS
     // Chunk-scan pixel map of the channel-split kernels (chunk_map.hpp, built by buildChunkMap): a side's M magnitudes are cut into
     // T chunks of 32 consecutive entries, one per thread; the arg-max runs of >= 2 entries ("tiles") are segments of a segmented
     // running maximum inside the chunks.
@@ -125,6 +125,7 @@ struct Plan {
     bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = false;
     int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
+    uint32_t optResonatorShardBound = 0; // RSNT, sharded render: most frames a rank's chunk may hold (0: 8 GiB worth of per-frame states)
 
     // device mirrors (owned)
     bool uploaded = false;

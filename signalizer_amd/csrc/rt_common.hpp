@@ -24,37 +24,65 @@ inline bool isPinnedHost(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
-// The address under which a kernel can write `p` directly: `p` itself for DEVICE memory (a mapped vertex buffer object, exported memory
-// the display GPU imported: the vertices stay in HBM), or the device-side alias of pinned host memory that is mapped into the device's
-// address space (hipHostMalloc, hipHostRegister with hipHostRegisterMapped; torch's pin_memory): the vertex kernels then store straight
-// into the caller's buffers over PCIe -- no device-side staging, no DMA copy behind the kernel.  nullptr otherwise (pageable memory).
-inline void *mappedDevicePointer(const void *p)
+// Can kernels on `stream` write memory that lives on device `owner`?  Yes on the stream's own device; on another one only with peer
+// access (enabled here if the link allows it -- "already enabled" is fine).  Anything else would fault inside the vertex kernel.
+inline bool streamCanWriteDevice(hipStream_t stream, int owner)
+{
+    hipDevice_t mine = 0;
+    if (hipStreamGetDevice(stream, &mine) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (int(mine) == owner) return true;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, int(mine), owner) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    if (hipSetDevice(int(mine)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const hipError_t e = hipDeviceEnablePeerAccess(owner, 0);
+    (void)hipGetLastError();
+    (void)hipSetDevice(keep);
+    return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+}
+
+// The address under which a kernel on `stream` can write `p` directly: `p` itself for DEVICE memory of the stream's device or of a peer
+// it has access to (a mapped vertex buffer object, exported memory the display GPU imported: the vertices stay in HBM), or the
+// device-side alias of pinned host memory that is mapped into the device's address space (hipHostMalloc, hipHostRegister with
+// hipHostRegisterMapped; torch's pin_memory): the vertex kernels then store straight into the caller's buffers over PCIe -- no
+// device-side staging, no DMA copy behind the kernel.  nullptr otherwise (pageable memory, another GPU's memory without peer access:
+// those go through the staging path, whose copies the runtime routes).
+inline void *mappedDevicePointer(const void *p, hipStream_t stream = nullptr)
 {
 #ifdef SGZ_NO_DIRECT_HOST_WRITES
-    (void)p; return nullptr;
+    (void)p; (void)stream; return nullptr;
 #else
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (at.type == hipMemoryTypeDevice) return (reinterpret_cast<uintptr_t>(p) & 3) ? nullptr : const_cast<void *>(p);
+    if (at.type == hipMemoryTypeDevice)
+        return ((reinterpret_cast<uintptr_t>(p) & 3) || !streamCanWriteDevice(stream, at.device)) ? nullptr : const_cast<void *>(p);
     if (at.type != hipMemoryTypeHost || !at.devicePointer || (reinterpret_cast<uintptr_t>(at.devicePointer) & 3)) return nullptr;
     return at.devicePointer;
 #endif
 }
 
-// Device results -> the caller's host buffers, then wait.  Pinned destinations are written by the DMA engine directly; others go
-// through the handle's pinned bounce buffer `h_bounce` (room for both parts) and a host copy.
+// true when a copy command can write `p` (pinned host memory or device memory: the DMA engine / the runtime's peer path reaches it)
+inline bool isCopyTarget(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice;
+}
+
+// Device results -> the caller's buffers, then wait.  Each destination on its own: pinned host memory and DEVICE memory (a caller may
+// hand a device buffer for one part and a pageable one for the other) are written by the copy itself; pageable destinations go through
+// the handle's pinned bounce buffer `h_bounce` (room for both parts) and a host copy.
 inline sgz_status readBack(void *dstA, const void *d_a, size_t bytesA, void *dstB, const void *d_b, size_t bytesB, void *h_bounce,
                            hipStream_t stream)
 {
-    const bool direct = isPinnedHost(dstA) && (!dstB || isPinnedHost(dstB));
+    const bool directA = isCopyTarget(dstA), directB = dstB && isCopyTarget(dstB);
     char *hb = static_cast<char *>(h_bounce);
-    SGZ_HIP(hipMemcpyAsync(direct ? dstA : hb, d_a, bytesA, hipMemcpyDeviceToHost, stream));
-    if (dstB) SGZ_HIP(hipMemcpyAsync(direct ? dstB : hb + bytesA, d_b, bytesB, hipMemcpyDeviceToHost, stream));
+    SGZ_HIP(hipMemcpyAsync(directA ? dstA : hb, d_a, bytesA, hipMemcpyDefault, stream));
+    if (dstB) SGZ_HIP(hipMemcpyAsync(directB ? dstB : hb + bytesA, d_b, bytesB, hipMemcpyDefault, stream));
     SGZ_HIP(hipStreamSynchronize(stream));
-    if (!direct) {
-        std::memcpy(dstA, hb, bytesA);
-        if (dstB) std::memcpy(dstB, hb + bytesA, bytesB);
-    }
+    if (!directA) std::memcpy(dstA, hb, bytesA);
+    if (dstB && !directB) std::memcpy(dstB, hb + bytesA, bytesB);
     return SGZ_OK;
 }
 

@@ -30,6 +30,7 @@ sgz_status resetResonator(Plan &p, hipStream_t stream);
 // [C][sides][P] receives the windowed state afterwards
 sgz_status runResonatorAdvance(Plan &p, const float *d_planar, size_t chStride, uint32_t nsamples, float *d_mapped, hipStream_t stream);
 // sharded RSNT render (api.hip): this rank's chunk from rest without the window kernel; then the carry of the ranks in front + the windows
+sgz_status checkResonatorShardBound(const Plan &p, long frames);
 sgz_status runResonatorFromRest(Plan &p, const float *d_planar, size_t chStride, long frames, float *d_mapped, hipStream_t stream);
 sgz_status runResonatorJoin(Plan &p, long frames, float *d_mapped, const float *d_allEnd, const long long *framesPerRank, uint32_t world, uint32_t rank,
                             float *d_carry, hipStream_t stream);

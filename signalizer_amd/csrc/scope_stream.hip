@@ -1925,7 +1925,7 @@ sgz_status sgz_scope_vertices(sgz_scope *s, const sgz_scope_view *view, uint32_t
     size_t points = 0;
     // pinned, device-mapped destinations: the vertex kernel writes them itself (2.4 MB per evaluator at cfg3: the DMA copy behind the
     // kernel was most of a rendered frame's GPU time)
-    void *mx = mappedDevicePointer(xyz), *mc = rgba ? mappedDevicePointer(rgba) : nullptr;
+    void *mx = mappedDevicePointer(xyz, s->stream), *mc = rgba ? mappedDevicePointer(rgba, s->stream) : nullptr;
     if (mx && (!rgba || mc)) {
         const sgz_status sd = scopeVerticesInto(s, view, evaluator, channel, static_cast<float *>(mx), static_cast<uint32_t *>(mc), need, &points);
         if (sd != SGZ_OK) return sd;
@@ -1953,7 +1953,7 @@ sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint
     for (uint32_t k = 0; k < items; ++k) {
         if (!xyz[k]) return fail(SGZ_EINVAL, "null argument");
         if (need > counts[k]) { counts[k] = uint32_t(need); small = true; }
-        direct = direct && mappedDevicePointer(xyz[k]) && (!rgba || !rgba[k] || mappedDevicePointer(rgba[k]));
+        direct = direct && mappedDevicePointer(xyz[k], s->stream) && (!rgba || !rgba[k] || mappedDevicePointer(rgba[k], s->stream));
     }
     if (small) return fail(SGZ_EINVAL, "vertex buffer too small (counts hold the required size)");
     if (!direct) {                                            // a pageable buffer among them: item by item through the bounce buffer
@@ -1966,16 +1966,16 @@ sgz_status sgz_scope_vertices_all(sgz_scope *s, const sgz_scope_view *view, uint
     for (uint32_t k = 0; k < items; ++k) {
         size_t points = 0;
         if (k + 1 < items) {                                  // two strips at a time when they are Lanczos strips (shared tap weights, one launch)
-            float *px[2] = {static_cast<float *>(mappedDevicePointer(xyz[k])), static_cast<float *>(mappedDevicePointer(xyz[k + 1]))};
-            uint32_t *pc[2] = {rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k])) : nullptr,
-                               rgba && rgba[k + 1] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k + 1])) : nullptr};
+            float *px[2] = {static_cast<float *>(mappedDevicePointer(xyz[k], s->stream)), static_cast<float *>(mappedDevicePointer(xyz[k + 1], s->stream))};
+            uint32_t *pc[2] = {rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k], s->stream)) : nullptr,
+                               rgba && rgba[k + 1] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k + 1], s->stream)) : nullptr};
             bool done = false;
             const sgz_status sp = scopeVerticesPairInto(s, view, evaluators + k, channels + k, px, pc, need, &points, &done);
             if (sp != SGZ_OK) { (void)hipStreamSynchronize(s->stream); return sp; }
             if (done) { counts[k] = counts[k + 1] = uint32_t(points); ++k; continue; }
         }
-        const sgz_status st = scopeVerticesInto(s, view, evaluators[k], channels[k], static_cast<float *>(mappedDevicePointer(xyz[k])),
-                                                rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k])) : nullptr, need, &points);
+        const sgz_status st = scopeVerticesInto(s, view, evaluators[k], channels[k], static_cast<float *>(mappedDevicePointer(xyz[k], s->stream)),
+                                                rgba && rgba[k] ? static_cast<uint32_t *>(mappedDevicePointer(rgba[k], s->stream)) : nullptr, need, &points);
         if (st != SGZ_OK) { (void)hipStreamSynchronize(s->stream); return st; }
         counts[k] = uint32_t(points);
     }

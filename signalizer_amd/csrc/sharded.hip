@@ -385,6 +385,7 @@ static sgz_status renderShardedResonator(Plan &p, const sgz_transport *t, uint32
     auto coll = [&](int e, const char *what) { return e == 0 ? SGZ_OK : bail(fail(SGZ_EHIP, std::string(what) + " failed (transport error " + std::to_string(e) + ")")); };
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     const size_t resN = size_t(p.C) * 2 * size_t(p.resV) * p.P * 2;              // the resonators' state, floats
+    if (sgz_status bs = checkResonatorShardBound(p, frames); bs != SGZ_OK) return bail(bs);      // before anything is allocated or exchanged
     // work buffer: [decay end state][decay carry][world x decay end states][resonator carry][world x resonator end states]
     sgz_status st = ensureCap(&p.d_shard, &p.shardCap, stateN * (2 + world) + resN * (1 + world));
     if (st != SGZ_OK) return bail(st);

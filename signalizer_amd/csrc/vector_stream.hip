@@ -644,7 +644,7 @@ sgz_status sgz_vector_vertices_all(sgz_vector *s, float *xyz, float *rgb, uint32
     if (*count < size) { *count = size; return fail(SGZ_EINVAL, "vertex buffer too small (count holds the required size per pair)"); }
     const size_t per = size_t(size) * 3;
     // pinned, device-mapped destinations: the polar kernels write them themselves (no staging, no DMA copy behind the kernels)
-    float *mx = static_cast<float *>(mappedDevicePointer(xyz)), *mc = rgb ? static_cast<float *>(mappedDevicePointer(rgb)) : nullptr;
+    float *mx = static_cast<float *>(mappedDevicePointer(xyz, s->stream)), *mc = rgb ? static_cast<float *>(mappedDevicePointer(rgb, s->stream)) : nullptr;
     if (mx && (!rgb || mc)) {
         const sgz_status st = vectorVerticesInto(s, 0, pairs, mx, rgb ? mc : nullptr);       // every pair in one launch
         if (st != SGZ_OK) return st;

@@ -454,6 +454,21 @@ def test_vertices_into_device_buffers(gpu):
         finally:
             os.close(fd.value)
             L.sgz_export_free(d_ptr)
+    # mixed destinations (round-5 advisor): vertices into DEVICE memory, colours into a pageable host array -- and the reverse.  Neither
+    # pair is "all mapped", so the call stages in the handle's own buffers; the copy behind it must treat each destination on its own
+    # (a host memcpy into a device pointer would fault)
+    want_xyz, want_rgba = dev.vertices(v, 0, 0)
+    n = want_xyz.shape[0]
+    d_xyz = torch.full((n, 3), float("nan"), dtype=torch.float32, device=gpu)
+    h_rgba = np.zeros((n, 4), np.uint8)
+    cnt = C.c_uint32(n)
+    api.check(L.sgz_scope_vertices(dev.h, C.byref(v), 0, 0, C.c_void_p(d_xyz.data_ptr()), C.c_void_p(h_rgba.ctypes.data), C.byref(cnt)))
+    assert cnt.value == n and np.array_equal(d_xyz.cpu().numpy().view(np.uint32), want_xyz.view(np.uint32)) and np.array_equal(h_rgba, want_rgba)
+    h_xyz = np.full((n, 3), np.nan, np.float32)
+    d_rgba = torch.zeros((n, 4), dtype=torch.uint8, device=gpu)
+    cnt = C.c_uint32(n)
+    api.check(L.sgz_scope_vertices(dev.h, C.byref(v), 0, 0, C.c_void_p(h_xyz.ctypes.data), C.c_void_p(d_rgba.data_ptr()), C.byref(cnt)))
+    assert cnt.value == n and np.array_equal(h_xyz.view(np.uint32), want_xyz.view(np.uint32)) and np.array_equal(d_rgba.cpu().numpy(), want_rgba)
     # several evaluators in one call (sgz_scope_vertices_all): the same strips, pinned buffers (one wait) and pageable ones (item by item)
     items = (0, 1, 2, 3)
     singles = [dev.vertices(v, e, 0) for e in items]

@@ -455,9 +455,9 @@ def test_peer_copy_transport_ranks_as_threads_of_one_process(gpu, window, hop, p
     assert out.shape == ref.shape and np.array_equal(out, ref)
 
 
-def _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=None):
+def _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=None, bound=None):
     """an RSNT render cut over `world` ranks = threads of this process on the peer-copy transport; returns {rank: rgba} -- or, with `slab`
-    (plan option SGZ_OPT_RESONATOR_SLAB set to it), {rank: status of the sharded render}"""
+    / `bound` (plan options SGZ_OPT_RESONATOR_SLAB / SGZ_OPT_RESONATOR_SHARD_BOUND set to them), {rank: status of the sharded render}"""
     import ctypes as C
     import threading
 
@@ -490,6 +490,8 @@ def _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=No
                 plan = api.Plan(cfg)
                 if slab is not None:
                     plan.set_option(api.OPT_RESONATOR_SLAB, slab)
+                if bound is not None:
+                    plan.set_option(api.OPT_RESONATOR_SHARD_BOUND, bound)
                 plan.upload()
                 lf, ff = C.c_uint64(), C.c_uint64()
                 api.check(L.sgz_shard_layout(plan.h, rank, world, S, C.byref(lf), C.byref(ff), None, None))
@@ -503,13 +505,13 @@ def _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=No
                     frames = C.c_uint64(0)
                     st = L.sgz_spectrogram_render_sharded_on(plan.h, C.byref(tr), rank, world, buf.data_ptr(), buf.stride(0), S,
                                                              rgba.data_ptr(), C.byref(frames), stream.cuda_stream)
-                    if slab is not None:
+                    if slab is not None or bound is not None:
                         results[rank] = st
                         break
                     api.check(st)
                     stream.synchronize()
                     outs.append(rgba.cpu().numpy().copy())
-                if slab is None:
+                if slab is None and bound is None:
                     assert np.array_equal(outs[0], outs[1])
                     results[rank] = outs[0]
                 L.sgz_peer_transport_release(store)
@@ -528,17 +530,20 @@ def _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=No
 
 def test_rsnt_shard_larger_than_its_state_bound_is_refused(gpu):
     """The sharded RSNT render holds the per-frame resonator states of a rank's WHOLE chunk between its two halves (from rest ... carry +
-    windows): SGZ_OPT_RESONATOR_SLAB -- the bound on that buffer in frames -- cannot be honoured by cutting the chunk there, so a chunk above
-    it is refused on every rank before anything is exchanged (SGZ_EUNSUPPORTED), not rendered with the option silently ignored."""
+    windows): it cannot go in slabs, so its bound -- SGZ_OPT_RESONATOR_SHARD_BOUND, in frames -- is enforced by refusing a chunk above it on
+    every rank before anything is allocated or exchanged (SGZ_EUNSUPPORTED).  SGZ_OPT_RESONATOR_SLAB, the PLAIN render's working-set knob,
+    plays no part here (round-5 advisor: a host that caps a plain render's slabs at a few frames must not lose the sharded render)."""
     from signalizer_amd import api
     hop, P, pairs, world, frames_per_rank = 2048, 256, 1, 2, 5
     S = hop * frames_per_rank
     cfg = config.spectrum_config(window_size=4096, hop=hop, num_pairs=pairs, axis_points=P, algorithm=config.ALGO_RSNT, pole=(0.9, 0.99))
     full = synth.gen(80, 48000, S * world, 2 * pairs)
-    st = _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=4)
+    st = _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, bound=4)
     assert st == {0: api.SGZ_EUNSUPPORTED, 1: api.SGZ_EUNSUPPORTED}, st
-    ok = _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=5)           # exactly the bound: rendered
+    ok = _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, bound=5)          # exactly the bound: rendered
     assert ok == {0: api.SGZ_OK, 1: api.SGZ_OK}, ok
+    small_slab = _rsnt_ranks_as_threads(gpu, world, cfg, full, S, frames_per_rank, P, slab=2)   # a small plain-render slab: no refusal
+    assert small_slab == {0: api.SGZ_OK, 1: api.SGZ_OK}, small_slab
 
 
 @pytest.mark.parametrize("world,mode,win", [(2, config.CH_SEPARATE, config.WIN_HANN), (4, config.CH_MIDSIDE, config.WIN_BLACKMAN_HARRIS),

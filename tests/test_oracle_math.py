@@ -18,6 +18,33 @@ def test_fft_vs_numpy_fp64(oracle):
         assert np.abs(po.fft64(x) - ref).max() <= 1e-14 * np.abs(ref).max()
 
 
+def test_simd_baseline_transform_vs_numpy_and_the_restated_one(oracle):
+    """oracle/fft_simd.c (bench.py's cpu_baseline.simd_value only -- timing, not parity) computes the same forward, unnormalised,
+    natural-order transform as the restated radix-2, and a whole render on it stays within a byte of the port's."""
+    po = oracle
+    rng = np.random.default_rng(1)
+    for N in (2, 4, 8, 32, 64, 1024, 4096, 32768, 65536):
+        x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+        ref = np.fft.fft(x.astype(np.complex128))
+        buf = x.copy()
+        assert po.lib().sgzo_fft_forward_simd(buf.ctypes.data_as(C.c_void_p), C.c_uint32(N)) == 0
+        assert np.abs(buf - ref).max() <= 4e-7 * np.abs(ref).max()
+        assert np.abs(buf - po.fft32(x)).max() <= 6e-7 * np.abs(ref).max()
+    assert po.lib().sgzo_fft_forward_simd(x.ctypes.data_as(C.c_void_p), C.c_uint32(48)) == -1       # not a power of two: refused
+    cfg = config.spectrum_config(window_size=4096, hop=1024)
+    p = po.params_from_dict(cfg)
+    from signalizer_amd import synth
+    xs = synth.gen(7, 48000, 4096 + 1024 * 11, 2)
+    want = po.spectrogram_range(p, xs, 0, 12)
+    got = np.zeros_like(want)
+    ptrs = (C.c_void_p * 2)(*[xs[c].ctypes.data for c in range(2)])
+    fn = po.lib().sgzo_spectrogram_range_simd
+    fn.restype = C.c_long
+    assert fn(C.byref(p), ptrs, C.c_size_t(xs.shape[1]), C.c_long(0), C.c_long(12), got.ctypes.data_as(C.c_void_p)) == 12
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
 def test_windows_vs_scipy(oracle):
     import scipy.signal.windows as w
     po = oracle
