@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libsgz.so")
 SOURCES = ["plan.cpp", "spectrum_fft.hip", "spectrum_real.hip", "spectrum_real16.hip", "spectrum_generic.hip", "spectrum_post.hip", "resonator.hip", "scope_vector.hip", "scope_stream.hip", "vector_stream.hip", "sharded.hip", "tracker.hip", "api.hip", "realtime.hip"]
 DRIVER = os.path.join(HERE, "librtdriver.so")
 DRIVER_SRC = os.path.join(os.path.dirname(HERE), "tools", "rt_driver.cpp")
-HEADERS = ["plan.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "real_common.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
+HEADERS = ["plan.hpp", "rt_lockfree.hpp", "kernels.hpp", "fft_common.hpp", "fft_scalar.hpp", "chunk_map.hpp", "real_common.hpp", "late_fix.hpp", "stft_body.hpp", "complex_dc.hpp", "decay_body.hpp", "runtime.hpp", "rt_common.hpp", "trace.hpp", "fade_chain.hpp", os.path.join("..", "..", "include", "sgz.h")]
 
 
 def _hipcc() -> str:

@@ -129,7 +129,7 @@ struct sgz_spectrum {
     static constexpr int kLineSlots = 3;
     float *h_lines = nullptr;         // pinned [kLineSlots][C][graphs][P][2]
     hipEvent_t lineEvents[kLineSlots] = {};
-    std::atomic<uint64_t> lineBegun{0}, linePublished{0};   // copies the producer has started / enqueued (slot = (n - 1) % kLineSlots)
+    LineSeqlock<kLineSlots> lineSeq;  // copies the producer has announced / enqueued (rt_lockfree.hpp; slot = (n - 1) % kLineSlots)
     std::atomic<uint64_t> deferredStat{0}; std::atomic<uint32_t> waitingStat{0};   // the backlog's counters for sgz_spectrum_backlog
     uint32_t maxFrames = 1;
     uint8_t *d_mix = nullptr;
@@ -140,7 +140,7 @@ struct sgz_spectrum {
     uint8_t *h_cols = nullptr;        // pinned [kQueueDepth][P][4]
     hipEvent_t colEvents[kQueueDepth] = {};
     // SPSC column queue: the producer fills slot tail % depth and bumps tail, the consumer reads slot head % depth and bumps head
-    std::atomic<uint64_t> qHead{0}, qTail{0};
+    ColumnQueue<kQueueDepth> colQ;    // rt_lockfree.hpp
     std::atomic<uint64_t> dropped{0}, busy{0};
     // display hand-off (consumer thread): device copy of the queue slots, the bound image, framePixelPosition
     uint8_t *d_colsQ = nullptr;       // [kQueueDepth][P][4]
@@ -196,7 +196,7 @@ static sgz_status uploadMix(sgz_spectrum *s, uint32_t numSources, const uint8_t 
     SGZ_HIP(hipMemcpy(s->d_mix, m.data(), m.size(), hipMemcpyHostToDevice));
     s->numSources = numSources;
     // one second of audio may wait for the GPU (at least 32 staging pieces)
-    if (sgz_status st = s->backlog.init(backlogFloats(numSources, s->plan->cfg.sample_rate, 8 * kPiece)); st != SGZ_OK) return st;
+    if (!s->backlog.init(backlogFloats(numSources, s->plan->cfg.sample_rate, 8 * kPiece))) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
     return s->stage.init(numSources, kPiece);
 }
 
@@ -240,7 +240,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     SGZ_HIP(hipMemsetAsync(s->d_ring, 0, nch * 2 * s->cap * sizeof(float), s->stream));    // history starts as silence
     s->written.store(0); s->planned.store(0);
     s->sinceLast = 0;
-    s->lineBegun.store(0); s->linePublished.store(0);
+    s->lineSeq.reset();
     s->deferredStat.store(0); s->waitingStat.store(0);
     const size_t stateN = size_t(p.C) * SGZ_NUM_GRAPHS * p.P * 2;
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_mapped), size_t(s->maxFrames) * p.C * p.sides * p.P * sizeof(float)));
@@ -261,7 +261,7 @@ static sgz_status setup(sgz_spectrum *s, const sgz_spectrum_config *cfg)
     SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_colsQ), size_t(kQueueDepth) * p.P * 4));
     if (!s->outStream) SGZ_HIP(hipStreamCreateWithFlags(&s->outStream, hipStreamNonBlocking));
     for (auto &e : s->colEvents) if (!e) SGZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    s->qHead.store(0); s->qTail.store(0);
+    s->colQ.reset();
     if ((st = uploadMix(s, uint32_t(nch), nullptr)) != SGZ_OK) return st;
     // warm-up: the largest batch a push can produce, on the silent ring -- every lazy allocation and LDS grant of the kernels
     // happens here, not on the audio thread.  The state it leaves is cleared again.
@@ -358,24 +358,22 @@ static sgz_status emitFrames(sgz_spectrum *s, uint32_t frames)
     const float *last = s->d_linesBatch + size_t(frames - 1) * stateN;
     SGZ_HIP(hipMemcpyAsync(s->d_lines, last, stateN * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
     {
-        // sgz_spectrum_line_results reads the newest COMPLETED copy; `lineBegun` tells it that a slot is about to be rewritten
-        const uint64_t n = s->lineBegun.load(std::memory_order_relaxed) + 1;
-        const int slot = int((n - 1) % sgz_spectrum::kLineSlots);
-        s->lineBegun.store(n, std::memory_order_seq_cst);
+        // sgz_spectrum_line_results reads the newest COMPLETED copy; `lineSeq.begun` tells it that a slot is about to be rewritten
+        const uint64_t n = s->lineSeq.begin();
+        const int slot = s->lineSeq.slotOf(n);
         SGZ_HIP(hipMemcpyAsync(s->h_lines + size_t(slot) * stateN, last, stateN * sizeof(float), hipMemcpyDeviceToHost, s->stream));
         SGZ_HIP(hipEventRecord(s->lineEvents[slot], s->stream));
-        s->linePublished.store(n, std::memory_order_release);
+        s->lineSeq.publish(n);
     }
     for (uint32_t k = 0; k < frames; ++k) {
-        const uint64_t tail = s->qTail.load(std::memory_order_relaxed);
-        if (tail - s->qHead.load(std::memory_order_acquire) >= uint64_t(kQueueDepth)) { s->dropped++; continue; }   // SpectrumDSP.cpp:185-186
-        const int slot = int(tail % kQueueDepth);
+        int slot = 0;
+        if (!s->colQ.producerSlot(&slot)) { s->dropped++; continue; }   // SpectrumDSP.cpp:185-186
         SGZ_HIP(hipMemcpyAsync(s->h_cols + size_t(slot) * p.P * 4, s->d_colsBatch + size_t(k) * p.P * 4, size_t(p.P) * 4,
                                hipMemcpyDeviceToHost, s->stream));
         SGZ_HIP(hipMemcpyAsync(s->d_colsQ + size_t(slot) * p.P * 4, s->d_colsBatch + size_t(k) * p.P * 4, size_t(p.P) * 4,
                                hipMemcpyDeviceToDevice, s->stream));
         SGZ_HIP(hipEventRecord(s->colEvents[slot], s->stream));
-        s->qTail.store(tail + 1, std::memory_order_release);
+        s->colQ.producerPublish();
     }
     return SGZ_OK;
 }
@@ -508,8 +506,8 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba, uint32_t *axi
     // a LINE_GRAPH handle (display_mode 0: what a zero-initialised configuration asks for, as in the reference's enum) produces no columns:
     // say so instead of staying empty for ever
     if (s->plan->cfg.display_mode == SGZ_DISPLAY_LINE_GRAPH) return fail(SGZ_EINVAL, "a LINE_GRAPH handle has no colour columns (sgz_spectrum_config::display_mode)");
-    const uint64_t head = s->qHead.load(std::memory_order_relaxed);
-    if (head == s->qTail.load(std::memory_order_acquire)) return SGZ_EMPTY;
+    const uint64_t head = s->colQ.consumerHead();
+    if (!s->colQ.consumerHas(head)) return SGZ_EMPTY;
     const int slot = int(head % kQueueDepth);
     const hipError_t q = hipEventQuery(s->colEvents[slot]);
     if (q == hipErrorNotReady) return SGZ_EMPTY;
@@ -517,7 +515,7 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba, uint32_t *axi
     const Plan &p = *s->plan;
     std::memcpy(rgba, s->h_cols + size_t(slot) * p.P * 4, size_t(p.P) * 4);
     if (axis_points) *axis_points = p.P;
-    s->qHead.store(head + 1, std::memory_order_release);
+    s->colQ.consumerRelease(head + 1);
     return SGZ_OK;
 }
 
@@ -595,9 +593,9 @@ sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, u
     }
     uint32_t n = 0;
     const uint32_t first = s->imgX;
-    uint64_t head = s->qHead.load(std::memory_order_relaxed);
+    uint64_t head = s->colQ.consumerHead();
     // at most one lap of the image per call, so that `first` / `count` describe the dirty range unambiguously
-    while (n < s->imgColumns && head != s->qTail.load(std::memory_order_acquire)) {
+    while (n < s->imgColumns && s->colQ.consumerHas(head)) {
         const int slot = int(head % kQueueDepth);
         const hipError_t q = hipEventQuery(s->colEvents[slot]);
         if (q == hipErrorNotReady) break;
@@ -620,7 +618,7 @@ sgz_status sgz_spectrum_flush_columns(sgz_spectrum *s, uint32_t *first_column, u
             if (gl) (void)hipGraphicsUnmapResources(1, &gl, s->outStream);
             return hipFail(e, "hipStreamSynchronize");
         }
-        s->qHead.store(head, std::memory_order_release);
+        s->colQ.consumerRelease(head);
     }
     if (gl) SGZ_HIP(hipGraphicsUnmapResources(1, &gl, s->outStream));
     if (first_column) *first_column = first;
@@ -639,17 +637,17 @@ sgz_status sgz_spectrum_line_results(sgz_spectrum *s, uint32_t pair, uint32_t gr
         return SGZ_OK;
     }
     // the newest copy that has arrived: nothing is waited for and the producer's stream is not touched.  Seqlock: a slot is rewritten
-    // by copy number n + kLineSlots, which `lineBegun` announces first -- a read that may have overlapped it is repeated on a newer slot.
+    // by copy number n + kLineSlots, which `lineSeq.begun` announces first -- a read that may have overlapped it is repeated on a newer slot.
+    auto landed = [&](int slot) { return hipEventQuery(s->lineEvents[slot]) == hipSuccess; };
     for (int attempt = 0; attempt < 8; ++attempt) {
-        const uint64_t pub = s->linePublished.load(std::memory_order_acquire);
-        uint64_t n = pub;
-        while (n > 0 && pub - n < uint64_t(sgz_spectrum::kLineSlots - 1) && hipEventQuery(s->lineEvents[(n - 1) % sgz_spectrum::kLineSlots]) != hipSuccess) --n;
-        if (n == 0 || hipEventQuery(s->lineEvents[(n - 1) % sgz_spectrum::kLineSlots]) != hipSuccess) {
-            if (pub == 0 || n == 0) { std::memset(out, 0, bytes); return SGZ_OK; }     // no frame yet (lineGraphs start zeroed)
+        bool none = false;
+        const uint64_t n = s->lineSeq.newest(landed, &none);
+        if (n == 0) {
+            if (none) { std::memset(out, 0, bytes); return SGZ_OK; }                    // no frame yet (lineGraphs start zeroed)
             continue;                                               // (every candidate still in flight: look again)
         }
-        std::memcpy(out, s->h_lines + size_t((n - 1) % sgz_spectrum::kLineSlots) * stateN + at, bytes);
-        if (s->lineBegun.load(std::memory_order_seq_cst) < n + uint64_t(sgz_spectrum::kLineSlots)) return SGZ_OK;
+        std::memcpy(out, s->h_lines + size_t(s->lineSeq.slotOf(n)) * stateN + at, bytes);
+        if (s->lineSeq.stillValid(n)) return SGZ_OK;
     }
     // the producer lapped the reader eight times in a row: fall back to the device copy behind the producer's work (waits)
     SGZ_HIP(hipMemcpyAsync(out, s->d_lines + at, bytes, hipMemcpyDeviceToHost, s->stream));

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "rt_lockfree.hpp"     // Backlog, SpinFlag, BatchCore, the hand-over protocol, ColumnQueue, LineSeqlock: HIP-free (ThreadSanitizer harness)
 #include "runtime.hpp"
 
 namespace sgz {
@@ -160,27 +161,13 @@ struct StageRing {
 // costs ~20 us per block whether the blocks come in one launch or seven, and what the eager form overlaps with the audio thread's next
 // callbacks the deferred form runs while the render thread waits.)
 //
-// Two threads touch the open batch: the producer (append, submit when full) and the consumer (submit on read).  `busy` is a spin
-// flag around every such step; the producer only ever TRIES it (a block that finds it held waits its turn in the Backlog like one that
-// finds no slot free), the consumer may spin for the few microseconds an append or an enqueue takes.
-struct BatchRing {
-    static constexpr int kSlots = 8;
-    static constexpr uint32_t kMaxBlocks = 16;
-    float *h = nullptr;            // pinned  [kSlots][channels * slotSamples]
-    float *hd = nullptr;           // the same memory as the device sees it (null: not mapped -- the batch is copied by the DMA engine)
+// The open batch itself, the flag two threads take around it and the hand-over protocol are rt_lockfree.hpp's (BatchCore, batchPush /
+// batchSync / batchFlushAll); this struct adds the GPU side of a slot: its device twin, its event, the upload.
+struct BatchRing : BatchCore {
+    float *hd = nullptr;           // the pinned slots (BatchCore::h) as the device sees them (null: not mapped -- the batch is copied by the DMA engine)
     float *d = nullptr;            // device  [kSlots][channels * slotSamples]
     hipEvent_t ev[kSlots] = {};
     bool used[kSlots] = {};
-    uint32_t channels = 0, slotSamples = 0;
-    uint64_t seq = 0;
-    // the open batch lives in slot seq % kSlots: block b = [channels][len[b]] at float offset off[b]
-    uint32_t count = 0, samples = 0;
-    uint32_t off[kMaxBlocks] = {}, len[kMaxBlocks] = {};
-    std::atomic_flag busy = ATOMIC_FLAG_INIT;
-
-    bool tryLock() { return !busy.test_and_set(std::memory_order_acquire); }
-    void lock() { while (busy.test_and_set(std::memory_order_acquire)) { } }
-    void unlock() { busy.clear(std::memory_order_release); }
 
     sgz_status init(uint32_t nch, uint32_t samplesPerSlot)
     {
@@ -208,7 +195,6 @@ struct BatchRing {
         for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         count = samples = 0;
     }
-    bool fits(uint32_t n) const { return count < kMaxBlocks && samples + n <= slotSamples; }
     // has the GPU finished with everything submitted so far?  (then a new block may as well start now: batching is for a GPU that is
     // behind, not a reason to let an idle one wait for the render thread)
     bool idle()
@@ -227,14 +213,6 @@ struct BatchRing {
         if (q != hipSuccess) return hipFail(q, "hipEventQuery");
         used[slot] = false;
         return SGZ_OK;
-    }
-    void append(const float *const *planar, uint32_t n)
-    {
-        const int slot = int(seq % kSlots);
-        float *dst = h + size_t(slot) * channels * slotSamples + size_t(channels) * samples;
-        for (uint32_t c = 0; c < channels; ++c) std::memcpy(dst + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
-        off[count] = channels * samples; len[count] = n;
-        samples += n; ++count;
     }
     // the open batch -> device; returns the device address of its first block.  When the pinned slot is mapped into the device's address
     // space the ingest kernel fetches the batch itself (batchFetch below: *fetchFrom = the slot as the device sees it, `floats` values):
@@ -257,7 +235,7 @@ struct BatchRing {
         const int slot = int(seq % kSlots);
         SGZ_HIP(hipEventRecord(ev[slot], stream));
         used[slot] = true;
-        ++seq; count = samples = 0;
+        committed();
         return SGZ_OK;
     }
 };
@@ -276,91 +254,5 @@ __device__ __forceinline__ void batchFetch(const float *from, float *to, uint32_
     __syncthreads();
 }
 #endif
-
-// Blocks the GPU was not ready for, in arrival order.  One writer, one reader at a time: push() belongs to the producer thread (under the
-// handle's push lock); front() / pop() to whoever holds the right to hand blocks to the GPU -- the producer inside its push, or the
-// consumer thread in a flush-on-read (scope / vector handles: the batch flag; spectrum handle: the push lock itself) -- so a block parked
-// here while the consumer held that right reaches the GPU with the consumer's next read even if no further push ever comes (a stopped
-// transport).  Storage is allocated when the handle is configured, never on the audio thread.  Capacity: `seconds` of audio at the handle's
-// rate (and at least 32 blocks of the largest push) -- with the 8 staging slots that is how far the GPU may fall behind before audio is lost;
-// the reference's stream FIFO has the same kind of bound (its `bufferSize`).
-struct Backlog {
-    static constexpr int kEntries = 256;
-    struct Entry { uint32_t n, channels; size_t off; uint64_t end; };   // end: the write position behind this block (what pop() frees up to)
-    float *buf = nullptr;
-    size_t cap = 0;
-    Entry ent[kEntries];
-    // writer
-    uint64_t wpos = 0;                                  // floats ever written, the padding skipped at the wraps included
-    uint32_t ewr = 0;
-    uint64_t deferred = 0;                              // blocks that ever waited here
-    // reader
-    uint32_t erd = 0;
-    std::atomic<uint64_t> rpos{0};                      // everything below this position has been consumed
-    std::atomic<uint32_t> count{0};                     // entries waiting (written by both sides: the entry and its samples are published by the increment)
-
-    sgz_status init(size_t floats)
-    {
-        release();
-        buf = static_cast<float *>(std::malloc(floats * sizeof(float)));
-        if (!buf) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
-        cap = floats;
-        return SGZ_OK;
-    }
-    void release() { std::free(buf); buf = nullptr; cap = 0; clear(); }
-    void clear() { wpos = 0; ewr = erd = 0; rpos.store(0); count.store(0); }      // (no other thread in the handle: configure / destroy)
-    bool push(const float *const *planar, uint32_t channels, uint32_t n)
-    {
-        const size_t need = size_t(channels) * n;
-        if (count.load(std::memory_order_acquire) == uint32_t(kEntries) || need > cap) return false;
-        size_t at = size_t(wpos % cap), pad = 0;
-        if (at + need > cap) { pad = cap - at; at = 0; }                        // does not fit behind the tail: start over at the front
-        if (wpos - rpos.load(std::memory_order_acquire) + pad + need > cap) return false;
-        for (uint32_t c = 0; c < channels; ++c) std::memcpy(buf + at + size_t(c) * n, planar[c], size_t(n) * sizeof(float));
-        wpos += pad + need;
-        ent[ewr % kEntries] = Entry{n, channels, at, wpos};
-        ++ewr; ++deferred;
-        count.fetch_add(1, std::memory_order_release);
-        return true;
-    }
-    const Entry &front() const { return ent[erd % kEntries]; }                  // (count != 0, read with acquire by the caller's test)
-    void pop()
-    {
-        rpos.store(ent[erd % kEntries].end, std::memory_order_release);
-        ++erd;
-        count.fetch_sub(1, std::memory_order_release);
-    }
-};
-
-// The FIFO's size in floats: one second of audio, at least four of the longest blocks -- and never more than 64 MiB however long a block
-// the host announces (a 64-channel handle with max_block = 131072 asked for 1 GiB of host memory under the old "32 blocks" rule)
-inline size_t backlogFloats(uint32_t channels, double sampleRate, uint32_t maxBlock)
-{
-    const size_t perChannel = std::max<size_t>(size_t(sampleRate), size_t(4) * maxBlock);
-    const size_t cap = (size_t(64) << 20) / sizeof(float);
-    return std::max<size_t>(std::min<size_t>(size_t(channels) * perChannel, cap), size_t(channels) * maxBlock);
-}
-
-// push with the FIFO in front: drain what waited (in order) while the GPU takes it, then the new block -- directly if nothing is waiting
-// and a slot is free, behind the others otherwise.  pushNow(planar, channels, n) is the handle's own enqueue (SGZ_BUSY = no slot free,
-// nothing consumed).
-template <typename PushNow>
-sgz_status pushThroughBacklog(Backlog &bl, const float *const *planar, uint32_t channels, uint32_t n, PushNow pushNow)
-{
-    const float *ptrs[64];
-    while (bl.count.load(std::memory_order_acquire)) {
-        const Backlog::Entry e = bl.front();
-        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = bl.buf + e.off + size_t(c) * e.n;
-        const sgz_status st = pushNow(ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) break;
-        bl.pop();
-        if (st != SGZ_OK) return st;
-    }
-    if (!bl.count.load(std::memory_order_acquire)) {
-        const sgz_status st = pushNow(planar, channels, n);
-        if (st != SGZ_BUSY) return st;
-    }
-    return bl.push(planar, channels, n) ? SGZ_OK : SGZ_BUSY;
-}
 
 }  // namespace sgz

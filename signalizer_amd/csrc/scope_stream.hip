@@ -1355,8 +1355,8 @@ __global__ void __launch_bounds__(1024) scopeSpectralKernel(const SpectralParams
 
 struct sgz_scope {
     sgz_scope_config cfg{};
-    bool deferSubmit = false;                  // sgz_scope_set_option(SGZ_RT_OPT_DEFER_SUBMIT)
-    bool parkPushes = false;                   // ... (SGZ_RT_OPT_PARK_PUSHES): every push waits in the host FIFO for the next reader / flush
+    std::atomic<bool> deferSubmit{false};      // sgz_scope_set_option(SGZ_RT_OPT_DEFER_SUBMIT); read by whoever holds the batch flag
+    std::atomic<bool> parkPushes{false};                  // ... (SGZ_RT_OPT_PARK_PUSHES): every push waits in the host FIFO for the next reader / flush
     std::mutex mu;                    // configure (consumer thread) against push (producer: try_lock only, never waits)
     hipStream_t stream = nullptr;
     BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
@@ -1459,7 +1459,7 @@ static sgz_status scopeSetup(sgz_scope *s, const sgz_scope_config *cfg, bool fre
         if ((st = s->batch.init(C, std::max<uint32_t>(maxBlock, 8192u))) != SGZ_OK) return st;
         s->maxBlock = maxBlock;
         // one second of audio may wait for the GPU (at least 32 blocks)
-        if ((st = s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) != SGZ_OK) return st;
+        if (!s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(ScopeDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_peaks), size_t(kPeakCap) * sizeof(unsigned long long)));
@@ -1606,49 +1606,26 @@ static sgz_status scopeSubmit(sgz_scope *s, const PeakParams *peak = nullptr)
     return s->batch.commit(s->stream);
 }
 
-// one block behind the ones already staged (caller holds the batch flag); SGZ_BUSY (nothing consumed) when a new batch would need a
-// slot whose last upload is still in flight
-static sgz_status scopePushNow(sgz_scope *s, const float *const *blk, uint32_t nch, uint32_t n)
-{
-    (void)nch;
-    if (s->batch.count && !s->batch.fits(n))
-        if (sgz_status st = scopeSubmit(s); st != SGZ_OK) return st;
-    if (s->batch.count == 0)
-        if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
-    s->batch.append(blk, n);
-    // nothing in flight: start now (a busy GPU picks the block up with the next ones).  SGZ_RT_OPT_DEFER_SUBMIT: every block waits for a
-    // full batch or a reader -- multi-block launches on demand (tests)
-    if (!s->deferSubmit && s->batch.idle()) return scopeSubmit(s);
-    return SGZ_OK;
-}
-
-// The blocks a push had to park in the host FIFO (rt_common.hpp Backlog: the consumer held the batch flag, or no staging slot was free) go
-// behind the open batch's, in order.  Caller holds the batch flag and is NOT the audio thread (a staging slot that is still in flight is
-// waited for).  all = false: only the blocks that wait at the time of the call -- a producer that keeps pushing cannot keep a reader here.
-static sgz_status scopeTakeBacklog(sgz_scope *s, bool all)
-{
-    const float *ptrs[64];
-    uint32_t left = s->backlog.count.load(std::memory_order_acquire);
-    while (all ? s->backlog.count.load(std::memory_order_acquire) != 0 : left != 0) {
-        const Backlog::Entry e = s->backlog.front();
-        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
-        const sgz_status st = scopePushNow(s, ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }
-        s->backlog.pop();
-        if (left) --left;
-        if (st != SGZ_OK) return st;
-    }
-    return SGZ_OK;
-}
+// the handle's GPU side for rt_lockfree.hpp's hand-over protocol (batchPush / batchSync / batchFlushAll: one block behind the ones already
+// staged, parked blocks behind the open batch's in order, flush on read -- the same code the ThreadSanitizer harness runs on a mock GPU)
+namespace {
+struct ScopeIngestSide {
+    sgz_scope *s;
+    BatchCore &batch() { return s->batch; }
+    Backlog &backlog() { return s->backlog; }
+    sgz_status submit() { return scopeSubmit(s); }
+    sgz_status slotReady() { return s->batch.slotReady(); }
+    bool gpuIdle() { return s->batch.idle(); }
+    void waitGpu() { (void)hipStreamSynchronize(s->stream); }
+    bool deferSubmit() { return s->deferSubmit.load(std::memory_order_relaxed); }
+};
+}  // namespace
 
 // consumer side (flush on read): what waits in the host FIFO and in the open batch goes to the GPU in front of the caller's own work
 static sgz_status scopeSync(sgz_scope *s)
 {
-    s->batch.lock();
-    sgz_status st = scopeTakeBacklog(s, false);
-    if (st == SGZ_OK && s->batch.count) st = scopeSubmit(s);
-    s->batch.unlock();
-    return st;
+    ScopeIngestSide side{s};
+    return batchSync(side);
 }
 
 sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
@@ -1662,14 +1639,8 @@ sgz_status sgz_scope_push(sgz_scope *s, const float *const *planar, uint32_t num
     // never waits: the render thread is submitting the open batch right now -> the block waits its turn in the host FIFO, like one
     // the GPU is not ready for (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
     // (SGZ_RT_OPT_PARK_PUSHES: every block takes that way -- the tests' handle on a race that timing alone produces)
-    if (s->parkPushes || !s->batch.tryLock()) {
-        const bool queued = s->backlog.push(planar, num_channels, nsamples);
-        if (!queued) s->busy++;
-        return queued ? SGZ_OK : SGZ_BUSY;
-    }
-    auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return scopePushNow(s, blk, nch, n); };
-    const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
-    s->batch.unlock();
+    ScopeIngestSide side{s};
+    const sgz_status st = batchPush(side, planar, num_channels, nsamples, s->parkPushes.load(std::memory_order_relaxed));
     if (st == SGZ_BUSY) s->busy++;
     return st;
 }
@@ -1680,9 +1651,9 @@ sgz_status sgz_scope_set_option(sgz_scope *s, uint32_t option, uint64_t value)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
-    if (option == SGZ_RT_OPT_PARK_PUSHES) { s->parkPushes = value != 0; return SGZ_OK; }
+    if (option == SGZ_RT_OPT_PARK_PUSHES) { s->parkPushes.store(value != 0, std::memory_order_relaxed); return SGZ_OK; }
     if (option != SGZ_RT_OPT_DEFER_SUBMIT) return fail(SGZ_EINVAL, "unknown scope option");
-    s->deferSubmit = value != 0;
+    s->deferSubmit.store(value != 0, std::memory_order_relaxed);
     return SGZ_OK;
 }
 
@@ -1690,11 +1661,8 @@ sgz_status sgz_scope_flush(sgz_scope *s)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
-    s->batch.lock();
-    sgz_status out = scopeTakeBacklog(s, true);                       // (this call may wait: it is not the audio thread's)
-    if (out == SGZ_OK && s->batch.count) out = scopeSubmit(s);
-    s->batch.unlock();
-    return out;
+    ScopeIngestSide side{s};
+    return batchFlushAll(side);                                       // (this call may wait: it is not the audio thread's)
 }
 
 sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes, double *auto_gain)
@@ -1708,8 +1676,9 @@ sgz_status sgz_scope_peak_filter(sgz_scope *s, double delta_time, uint32_t lanes
     PeakParams prm{s->d_state, s->d_front, s->size, s->cfg.num_channels, s->cfg.channel_mode, lanes, coeff, spectral ? numSamples : 0u};
     // flush on read: the blocks that wait in the open batch come first -- and the filter rides on their launch (one workgroup either
     // way: a launch and the gap in front of it less per rendered frame)
+    ScopeIngestSide side{s};
     s->batch.lock();
-    const sgz_status tb = scopeTakeBacklog(s, false);
+    const sgz_status tb = batchTakeBacklog(side, false);
     const bool fused = tb == SGZ_OK && s->batch.count != 0;
     const sgz_status sy = tb != SGZ_OK ? tb : fused ? scopeSubmit(s, &prm) : SGZ_OK;
     s->batch.unlock();

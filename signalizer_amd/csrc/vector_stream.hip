@@ -319,8 +319,8 @@ __global__ void __launch_bounds__(256) vectorPolarViewKernel(const PolarParams p
 
 struct sgz_vector {
     sgz_vector_config cfg{};
-    bool deferSubmit = false;                  // sgz_vector_set_option(SGZ_RT_OPT_DEFER_SUBMIT)
-    bool parkPushes = false;                   // ... (SGZ_RT_OPT_PARK_PUSHES): every push waits in the host FIFO for the next reader / flush
+    std::atomic<bool> deferSubmit{false};      // sgz_vector_set_option(SGZ_RT_OPT_DEFER_SUBMIT); read by whoever holds the batch flag
+    std::atomic<bool> parkPushes{false};                  // ... (SGZ_RT_OPT_PARK_PUSHES): every push waits in the host FIFO for the next reader / flush
     std::mutex mu;
     hipStream_t stream = nullptr;
     BatchRing batch;                           // staged blocks waiting for their (one) ingest launch (rt_common.hpp)
@@ -385,7 +385,7 @@ static sgz_status vectorSetup(sgz_vector *s, const sgz_vector_config *cfg, bool 
         s->maxBlock = maxBlock;
         if (st != SGZ_OK) return st;
         // one second of audio may wait for the GPU (at least 32 blocks)
-        if ((st = s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) != SGZ_OK) return st;
+        if (!s->backlog.init(backlogFloats(C, cfg->sample_rate, maxBlock))) return fail(SGZ_ENOMEM, "out of memory (push backlog)");
         if (!s->d_state) {
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_state), sizeof(VecDev)));
             SGZ_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_tail), 2 * sizeof(float)));
@@ -454,48 +454,26 @@ static sgz_status vectorSubmit(sgz_vector *s)
     return s->batch.commit(s->stream);
 }
 
-// one block behind the ones already staged (caller holds the batch flag); SGZ_BUSY (nothing consumed) when a new batch would need a
-// slot whose last upload is still in flight
-static sgz_status vectorPushNow(sgz_vector *s, const float *const *blk, uint32_t nch, uint32_t n)
-{
-    (void)nch;
-    if (s->batch.count && !s->batch.fits(n))
-        if (sgz_status st = vectorSubmit(s); st != SGZ_OK) return st;
-    if (s->batch.count == 0)
-        if (sgz_status st = s->batch.slotReady(); st != SGZ_OK) return st;
-    s->batch.append(blk, n);
-    // nothing in flight: start now (a busy GPU picks the block up with the next ones); SGZ_RT_OPT_DEFER_SUBMIT: wait for a full batch or a reader
-    if (!s->deferSubmit && s->batch.idle()) return vectorSubmit(s);
-    return SGZ_OK;
-}
-
-// The blocks a push had to park in the host FIFO (rt_common.hpp Backlog: the consumer held the batch flag, or no staging slot was free) go
-// behind the open batch's, in order.  Caller holds the batch flag and is NOT the audio thread (a staging slot that is still in flight is
-// waited for).  all = false: only the blocks that wait at the time of the call -- a producer that keeps pushing cannot keep a reader here.
-static sgz_status vectorTakeBacklog(sgz_vector *s, bool all)
-{
-    const float *ptrs[64];
-    uint32_t left = s->backlog.count.load(std::memory_order_acquire);
-    while (all ? s->backlog.count.load(std::memory_order_acquire) != 0 : left != 0) {
-        const Backlog::Entry e = s->backlog.front();
-        for (uint32_t c = 0; c < e.channels && c < 64; ++c) ptrs[c] = s->backlog.buf + e.off + size_t(c) * e.n;
-        const sgz_status st = vectorPushNow(s, ptrs, e.channels, e.n);
-        if (st == SGZ_BUSY) { (void)hipStreamSynchronize(s->stream); continue; }
-        s->backlog.pop();
-        if (left) --left;
-        if (st != SGZ_OK) return st;
-    }
-    return SGZ_OK;
-}
+// the handle's GPU side for rt_lockfree.hpp's hand-over protocol (batchPush / batchSync / batchFlushAll; the ThreadSanitizer harness runs
+// the same protocol code on a mock GPU)
+namespace {
+struct VectorIngestSide {
+    sgz_vector *s;
+    BatchCore &batch() { return s->batch; }
+    Backlog &backlog() { return s->backlog; }
+    sgz_status submit() { return vectorSubmit(s); }
+    sgz_status slotReady() { return s->batch.slotReady(); }
+    bool gpuIdle() { return s->batch.idle(); }
+    void waitGpu() { (void)hipStreamSynchronize(s->stream); }
+    bool deferSubmit() { return s->deferSubmit.load(std::memory_order_relaxed); }
+};
+}  // namespace
 
 // consumer side (flush on read): what waits in the host FIFO and in the open batch goes to the GPU in front of the caller's own work
 static sgz_status vectorSync(sgz_vector *s)
 {
-    s->batch.lock();
-    sgz_status st = vectorTakeBacklog(s, false);
-    if (st == SGZ_OK && s->batch.count) st = vectorSubmit(s);
-    s->batch.unlock();
-    return st;
+    VectorIngestSide side{s};
+    return batchSync(side);
 }
 
 sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t num_channels, uint32_t nsamples)
@@ -509,14 +487,8 @@ sgz_status sgz_vector_push(sgz_vector *s, const float *const *planar, uint32_t n
     // never waits: the render thread is submitting the open batch right now -> the block waits its turn in the host FIFO, like one the
     // GPU is not ready for (rt_common.hpp Backlog); SGZ_BUSY = that FIFO is full
     // (SGZ_RT_OPT_PARK_PUSHES: every block takes that way -- the tests' handle on a race that timing alone produces)
-    if (s->parkPushes || !s->batch.tryLock()) {
-        const bool queued = s->backlog.push(planar, num_channels, nsamples);
-        if (!queued) s->busy++;
-        return queued ? SGZ_OK : SGZ_BUSY;
-    }
-    auto pushNow = [&](const float *const *blk, uint32_t nch, uint32_t n) -> sgz_status { return vectorPushNow(s, blk, nch, n); };
-    const sgz_status st = pushThroughBacklog(s->backlog, planar, num_channels, nsamples, pushNow);
-    s->batch.unlock();
+    VectorIngestSide side{s};
+    const sgz_status st = batchPush(side, planar, num_channels, nsamples, s->parkPushes.load(std::memory_order_relaxed));
     if (st == SGZ_BUSY) s->busy++;
     return st;
 }
@@ -527,9 +499,9 @@ sgz_status sgz_vector_set_option(sgz_vector *s, uint32_t option, uint64_t value)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
-    if (option == SGZ_RT_OPT_PARK_PUSHES) { s->parkPushes = value != 0; return SGZ_OK; }
+    if (option == SGZ_RT_OPT_PARK_PUSHES) { s->parkPushes.store(value != 0, std::memory_order_relaxed); return SGZ_OK; }
     if (option != SGZ_RT_OPT_DEFER_SUBMIT) return fail(SGZ_EINVAL, "unknown vector option");
-    s->deferSubmit = value != 0;
+    s->deferSubmit.store(value != 0, std::memory_order_relaxed);
     return SGZ_OK;
 }
 
@@ -537,11 +509,8 @@ sgz_status sgz_vector_flush(sgz_vector *s)
 {
     if (!s) return fail(SGZ_EINVAL, "null handle");
     std::lock_guard<std::mutex> lk(s->mu);
-    s->batch.lock();
-    sgz_status out = vectorTakeBacklog(s, true);                      // (this call may wait: it is not the audio thread's)
-    if (out == SGZ_OK && s->batch.count) out = vectorSubmit(s);
-    s->batch.unlock();
-    return out;
+    VectorIngestSide side{s};
+    return batchFlushAll(side);                                       // (this call may wait: it is not the audio thread's)
 }
 
 sgz_status sgz_vector_peak_filter(sgz_vector *s, double delta_time, double *envelope_gain)

@@ -1,0 +1,90 @@
+"""ThreadSanitizer on the host-side lock-free structures of the real-time handles (round-5 review item 5).
+
+signalizer_amd/csrc/rt_lockfree.hpp -- Backlog, SpinFlag / BatchCore, the batch-flag hand-over protocol (batchPush / batchSync /
+batchFlushAll), ColumnQueue, LineSeqlock -- is HIP-free; tests/tsan/rt_lockfree_tsan.cpp compiles THAT header (the one libsgz.so is built
+from) with g++ -fsanitize=thread and drives it with one producer, one consumer and one control / configure thread against a mock GPU:
+parked pushes, flush on read, reconfiguration, a full host FIFO, a full column queue, a lapped triple buffer.  Reference threading contract:
+SpectrumDSP.cpp:67 (audio thread holds the stream lock for a transform), SpectrumRendering.cpp:594 (the GL thread takes the same lock),
+SURVEY.md 8(b) "Threading".
+
+The second test mutates a copy of the header (the batch flag that always "succeeds"; a relaxed load where the column queue needs an
+acquire) and expects the harness to FAIL: a harness that cannot see a planted race proves nothing by passing."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "tsan", "rt_lockfree_tsan.cpp")
+HDR = os.path.join(ROOT, "signalizer_amd", "csrc", "rt_lockfree.hpp")
+# -fno-builtin-memcpy: gcc expands fixed-size memcpy inline WITHOUT instrumentation -- such copies would be invisible to the sanitizer
+FLAGS = ["-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-builtin-memcpy", "-fno-builtin-memset", "-pthread"]
+ENV = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1")
+
+
+def _compile(src: str, out: str):
+    cxx = os.environ.get("CXX", "g++")
+    r = subprocess.run([cxx, *FLAGS, src, "-o", out], capture_output=True, text=True)
+    if r.returncode != 0 and ("sanitize" in r.stderr or "tsan" in r.stderr.lower()):
+        pytest.skip(f"{cxx} cannot build with -fsanitize=thread here: {r.stderr.strip().splitlines()[-1]}")
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def _tsan_runs_here(tmp_path) -> None:
+    probe = tmp_path / "probe.cpp"
+    probe.write_text("#include <thread>\n#include <atomic>\nstd::atomic<int> a{0};\nint main() { std::thread t([] { a++; }); a++; t.join(); return a == 2 ? 0 : 1; }\n")
+    exe = _compile(str(probe), str(tmp_path / "probe"))
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV)
+    if r.returncode != 0:
+        pytest.skip(f"ThreadSanitizer binaries do not run in this environment: {(r.stderr or r.stdout).strip()[:200]}")
+
+
+def test_lockfree_structures_are_clean_under_threadsanitizer(tmp_path):
+    _tsan_runs_here(tmp_path)
+    exe = _compile(SRC, str(tmp_path / "rt_lockfree_tsan"))
+    r = subprocess.run([exe, "120000"], capture_output=True, text=True, env=ENV, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "ThreadSanitizer" not in out and "CHECK failed" not in out, out[-4000:]
+    m = re.search(r"tsan harness ok: (\d+) operations", out)
+    assert m and int(m.group(1)) >= 1_000_000, out[-2000:]
+    # the runs must have gone through the paths the harness is about: blocks parked in the host FIFO, refused pushes, dropped columns
+    b = re.search(r"batched handle: (\d+) blocks, (\d+) waited in the host FIFO, (\d+) pushes refused", out)
+    s = re.search(r"spectrum handle: (\d+) blocks, (\d+) waited in the host FIFO, (\d+) pushes refused, (\d+) columns dropped", out)
+    assert b and int(b.group(2)) > 0 and s and int(s.group(2)) > 0, out[-2000:]
+
+
+MUTATIONS = {
+    # the batch flag no longer excludes anybody: producer and consumer both touch the open batch
+    "flag": ("bool tryLock() { return !busy.test_and_set(std::memory_order_acquire); }", "bool tryLock() { return true; }"),
+    # the producer reuses a column slot without having acquired the consumer's release of it
+    "column_queue": ("if (t - head.load(std::memory_order_acquire) >= uint64_t(Depth)) return false;",
+                     "if (t - head.load(std::memory_order_relaxed) >= uint64_t(Depth)) return false;"),
+    # the reader of the line results never re-checks that its slot was not being rewritten
+    "seqlock": ("bool stillValid(uint64_t n) const { return begun.load(std::memory_order_seq_cst) < n + uint64_t(Slots); }",
+                "bool stillValid(uint64_t) const { return true; }"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MUTATIONS))
+def test_the_harness_sees_a_planted_race(tmp_path, name):
+    _tsan_runs_here(tmp_path)
+    old, new = MUTATIONS[name]
+    text = open(HDR).read()
+    assert text.count(old) == 1, f"mutation target not found in rt_lockfree.hpp: {old}"
+    tree = tmp_path / "tree"
+    (tree / "signalizer_amd" / "csrc").mkdir(parents=True)
+    (tree / "include").mkdir()
+    (tree / "tests" / "tsan").mkdir(parents=True)
+    (tree / "signalizer_amd" / "csrc" / "rt_lockfree.hpp").write_text(text.replace(old, new))
+    shutil.copy(os.path.join(ROOT, "include", "sgz.h"), tree / "include" / "sgz.h")
+    shutil.copy(SRC, tree / "tests" / "tsan" / "rt_lockfree_tsan.cpp")
+    exe = _compile(str(tree / "tests" / "tsan" / "rt_lockfree_tsan.cpp"), str(tmp_path / "mutant"))
+    try:
+        r = subprocess.run([exe, "60000"], capture_output=True, text=True, env=ENV, timeout=600)
+    except subprocess.TimeoutExpired:
+        return                                                    # (a broken protocol may also hang: not a pass of the mutant)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and ("ThreadSanitizer" in out or "CHECK failed" in out), f"the planted {name} bug went unnoticed:\n{out[-2000:]}"
