@@ -404,9 +404,10 @@ sgz_status sgz_spectrum_pop_column(sgz_spectrum *s, uint8_t *rgba /*4*P*/, uint3
  *                               rounded up to 2 MiB); dmabuf_fd may be NULL
  *   sgz_spectrum_bind_gl_buffer an OpenGL buffer object (e.g. a pixel-unpack buffer the texture is updated from) of a context that is
  *                               current on this thread and lives on the same device: hipGraphicsGLRegisterBuffer; flush_columns maps
- *                               and unmaps it around its writes.  UNTESTED beyond "fails with a status": the MI355X boxes this library
- *                               is developed on have no GL context to offer (no display engine; the image has libGL / GLX, which needs an X
- *                               server, but neither libEGL nor libgbm for a surfaceless context: probed, round 3)
+ *                               and unmaps it around its writes.  tests/test_gpu_realtime.py test_gl_buffer_round_trip executes it where an
+ *                               EGL surfaceless context can be made current; on the MI355X boxes this library is developed on it cannot (no
+ *                               display engine; the image has libGL / GLX, which needs an X server, but neither libEGL nor libgbm) and the
+ *                               test skips with the loader's error: there the call is only known to fail with a status
  * A configure drops the binding (the image height is the axis size). */
 sgz_status sgz_spectrum_bind_image(sgz_spectrum *s, void *d_image, uint32_t columns, size_t pitch_bytes);
 sgz_status sgz_spectrum_create_image(sgz_spectrum *s, uint32_t columns, void **d_image, size_t *pitch_bytes, int *dmabuf_fd);

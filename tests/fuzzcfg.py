@@ -31,3 +31,23 @@ def random_config(rng, wild=False):
                    num_pairs=int(rng.integers(1, 6)), low_db=float(rng.uniform(-150, -20)), high_db=float(rng.uniform(-10, 12)))
     return cfg
 
+
+
+def rsnt_case(seed: int, index: int):
+    """case `index` of tools/fuzz_rsnt.py's stream for `seed` (the same draws in the same order: the campaign records name cases this
+    way): (config dict, frames, planar input)."""
+    import numpy as np
+
+    from signalizer_amd import config as cf, synth
+    rng = np.random.default_rng(seed)
+    for _ in range(index + 1):
+        mode = int(rng.integers(0, 8))
+        d = cf.spectrum_config(algorithm=cf.ALGO_RSNT, channel_mode=mode, window_type=int(rng.integers(0, 13)),
+                               window_size=int(rng.choice([512, 4096, 32768])), hop=int(rng.choice([int(rng.integers(40, 3000)), 1024, 2048, 3072])),
+                               axis_points=int(rng.integers(2, 1500)), num_pairs=int(rng.integers(1, 4)), free_q=int(rng.integers(0, 2)),
+                               view_scaling=int(rng.integers(0, 2)), sample_rate=float(rng.choice([44100.0, 48000.0, 96000.0])),
+                               view_left=float(rng.uniform(0, 0.3)), view_right=float(rng.uniform(0.5, 1.0)),
+                               pole=(float(rng.uniform(0.5, 0.999)), float(rng.uniform(0.5, 0.999))))
+        F = int(rng.integers(1, 20))
+        x = synth.gen(int(rng.integers(1, 1000)), int(d["sample_rate"]), F * d["hop"] + int(rng.integers(0, d["hop"])), 2 * d["num_pairs"])
+    return d, F, x

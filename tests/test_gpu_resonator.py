@@ -292,3 +292,114 @@ def test_real_time_handle_mix_matrix_feeds_the_resonators(gpu, oracle):
         assert np.array_equal(got, want), int((got != want).sum())
     finally:
         api.lib().sgz_spectrum_destroy(h)
+
+
+# ---- device against the truth (round-5 review item 3) ------------------------------------------------------------------------------------
+# STATE_K above is 8 because the device and the oracle are BOTH fp32 evaluations and sit on opposite sides of the exact value; what that
+# loosened bar no longer says -- that the device itself is within the original 4 units -- is enforced here against an fp64 walk of the same
+# resonators (tests/rsnt_truth.py; the reference's recurrence: TransformDSP.inl:1213-1295, state -> frame :1103-1133).
+TRUTH_K = 4.0
+
+
+def _truth_ratio(oracle, d, F, x, got, pair, sig):
+    """largest |device - truth| / bar over the frames of (pair, signal); bar = CHAIN_TOL x the frame's largest value (of this signal: not
+    larger than check_planes' top) + TRUTH_K eps sqrt(1 / (1 - r)) x the size of the terms the window sums"""
+    import rsnt_truth
+    p = oracle.params_from_dict(d)
+    truth, scale = rsnt_truth.frame_magnitudes(oracle, p, x, pair, sig, F)
+    gain = oracle.resonator_map(p)[1].astype(np.float64)
+    state_tol = TRUTH_K * EPS * np.sqrt(1.0 / np.maximum(gain, 1e-12))
+    worst, where = 0.0, None
+    for f in range(F):
+        bar = CHAIN_TOL * max(float(truth[f].max()), 1e-30) + state_tol * scale[f]
+        e = np.abs(got[f, pair, sig].astype(np.float64) - truth[f]) / np.maximum(bar, 1e-37)
+        if float(e.max()) > worst:
+            worst, where = float(e.max()), (f, int(e.argmax()))
+    return worst, where
+
+
+@pytest.mark.parametrize("seed,index,pair,sig", [(2008, 52, 1, 0), (2021, 23, 1, 0)])
+def test_device_is_within_four_units_of_an_fp64_walk_on_the_recorded_worst_cases(gpu, oracle, seed, index, pair, sig):
+    """the two cases of 5 200 fuzz configurations where device and oracle differed by more than the 4-unit bar (profiles/r05e/
+    fuzz_campaign_2.txt: seed 2008 case 52, seed 2021 case 23; Blackman-Harris, seven detuned resonators per point, matrix-core path):
+    against the exact value the DEVICE is inside 4 units (recorded: <= 0.76)"""
+    import fuzzcfg
+    d, F, x = fuzzcfg.rsnt_case(seed, index)
+    assert d["hop"] % 1024 == 0 and d["window_type"] == cf.WIN_BLACKMAN_HARRIS
+    got = api.Plan(d).upload().stage_mapped(_cuda(x, gpu)).cpu().numpy()
+    worst, where = _truth_ratio(oracle, d, F, x, got, pair, sig)
+    assert worst <= 1.0, (worst, where)
+
+
+def test_device_is_within_four_units_of_an_fp64_walk_seeded_sweep(gpu, oracle):
+    """a seeded sweep of tools/fuzz_rsnt.py's configuration stream: ten launches on the matrix cores (hop a multiple of 1024, several
+    frames) and six on the vector-ALU forms, every pair's first signal, device against the fp64 walk at the 4-unit bar"""
+    import fuzzcfg
+    matrix = vector = 0
+    worst_all = 0.0
+    for index in range(400):
+        if matrix >= 10 and vector >= 6:
+            break
+        d, F, x = fuzzcfg.rsnt_case(6100, index)
+        on_matrix = d["hop"] % 1024 == 0 and F >= 2
+        if d["channel_mode"] == cf.CH_PHASE or F * d["hop"] * d["axis_points"] > 40_000_000 or (matrix >= 10 if on_matrix else vector >= 6):
+            continue
+        got = api.Plan(d).upload().stage_mapped(_cuda(x, gpu)).cpu().numpy()
+        for pair in range(d["num_pairs"]):
+            worst, where = _truth_ratio(oracle, d, F, x, got, pair, 0)
+            assert worst <= 1.0, (index, pair, worst, where, {k: d[k] for k in ("window_size", "hop", "axis_points", "channel_mode", "window_type", "free_q")})
+            worst_all = max(worst_all, worst)
+        matrix, vector = matrix + on_matrix, vector + (not on_matrix)
+    assert matrix == 10 and vector == 6, (matrix, vector)
+
+
+_DIGEST_SCRIPT = """
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np, torch, fuzzcfg
+from signalizer_amd import api
+h = hashlib.sha256()
+for seed, index in {cases!r}:
+    d, F, x = fuzzcfg.rsnt_case(seed, index)
+    xs = torch.from_numpy(x).to("cuda:0")
+    plan = api.Plan(d).upload()
+    h.update(plan.stage_mapped(xs).cpu().numpy().tobytes()); h.update(plan.render(xs).cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_rsnt_renders_are_deterministic(gpu):
+    """The one campaign failure nobody could reproduce (seed 1005, case 12: Hamming, hop 3072, P = 1033, two pairs, 16 frames -- a wrong
+    result on a path with hand-pipelined MFMA loops and sched_barriers is a possible race until shown otherwise) and the worst matrix-core
+    case, 200 repetitions each on reused and fresh plans: every output bit-identical to the first run's.  Control: the same renders in a
+    second process with AMD_SERIALIZE_KERNEL=3 (every kernel waited for before and after: no two kernels ever overlap) give the same bits."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    import fuzzcfg
+    cases = [(1005, 12), (2008, 52)]
+    h = hashlib.sha256()
+    for seed, index in cases:
+        d, F, x = fuzzcfg.rsnt_case(seed, index)
+        assert d["hop"] % 1024 == 0 and F >= 2                                        # the matrix-core path
+        xs = _cuda(x, gpu)
+        plan = api.Plan(d).upload()
+        m0 = plan.stage_mapped(xs).cpu().numpy()
+        r0 = plan.render(xs).cpu().numpy()
+        h.update(m0.tobytes()); h.update(r0.tobytes())
+        assert np.isfinite(m0).all()
+        for it in range(200):
+            p = plan if it % 4 else api.Plan(d).upload()                              # every fourth run on a fresh plan
+            m = p.stage_mapped(xs).cpu().numpy()
+            r = p.render(xs).cpu().numpy()
+            assert np.array_equal(m, m0), (seed, index, it, int((m != m0).sum()), "fresh plan" if it % 4 == 0 else "reused plan")
+            assert np.array_equal(r, r0), (seed, index, it, int((r != r0).sum()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _DIGEST_SCRIPT.format(root=root, tests=os.path.join(root, "tests"), cases=cases)
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3")
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    digest = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("DIGEST")]
+    assert digest == [h.hexdigest()], (digest, h.hexdigest())

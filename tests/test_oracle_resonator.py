@@ -110,3 +110,32 @@ def test_library_tables_equal_the_oracle(oracle, over):
     oc, og, ow = oracle.resonator_map(oracle.params_from_dict(d))
     assert np.array_equal(coeff.view(np.float32), oc.view(np.float32)) and np.array_equal(gain, og) and np.array_equal(w, ow)
     assert plan.num_frames(10 * d["hop"] + 5) == 10 and plan.num_frames(d["hop"] - 1) == 0
+
+
+def test_fp64_walk_helper_against_lfilter_and_the_oracle(oracle):
+    """tests/rsnt_truth.py (the "truth" the GPU tests hold the device to at the 4-unit bar): its block-sum evaluation equals a plain
+    complex128 recurrence (scipy.signal.lfilter), and the oracle's sequential fp32 evaluation of a recorded worst case
+    (profiles/r05e/fuzz_campaign_2.txt: seed 2021, case 23) stays within 8 units of it (recorded: 1.09 of the 4-unit bar)."""
+    import fuzzcfg
+    import rsnt_truth
+    from scipy.signal import lfilter
+    po = oracle
+    d, F, x = fuzzcfg.rsnt_case(2021, 23)
+    p = po.params_from_dict(d)
+    pair, sig, hop, P = 1, 0, d["hop"], d["axis_points"]
+    truth, scale = rsnt_truth.frame_magnitudes(po, p, x, pair, sig, F)
+    coeff, gain, weights = po.resonator_map(p)
+    xin = rsnt_truth.dispatch_signal(po, d["channel_mode"], x[2 * pair], x[2 * pair + 1], sig)[:F * hop].astype(np.complex128)
+    for i in (0, 11, P // 2, P - 1):
+        acc = np.zeros(F, np.complex128)
+        for v in range(coeff.shape[0]):
+            acc += float(weights[v]) * lfilter([1.0], [1.0, -complex(coeff[v, i])], xin)[hop - 1::hop][:F]
+        assert np.allclose(np.abs(acc) * float(gain[i]), truth[:, i], rtol=1e-7, atol=1e-9 * float(scale[:, i].max()))
+    r = po.resonator_spectrogram(p, x, want_mapped=True, want_scale=True)
+    assert np.allclose(r["scale"][:, pair, sig], scale, rtol=1e-4, atol=1e-12)                   # the same bar either way
+    mag = lambda z: np.sqrt(z.real * z.real + z.imag * z.imag)
+    ref = mag(r["mapped"][:, pair, :P])
+    state_tol = 8.0 * 2.0 ** -24 * np.sqrt(1.0 / np.maximum(gain.astype(np.float64), 1e-12))
+    for f in range(F):
+        bar = 2e-5 * max(float(truth[f].max()), 1e-30) + state_tol * scale[f]
+        assert float(np.max(np.abs(ref[f] - truth[f]) / bar)) <= 1.0
