@@ -168,7 +168,9 @@ sgz_status sgz_plan_get_resonator(const sgz_plan *plan, uint32_t *vectors, float
 sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 /* Per-plan switches (all default to what is fastest; the parity tests and measurements flip them):
  *   SGZ_OPT_CHANNEL_SPLIT  1 (default): eligible plans run the real-input channel-split kernels (SGZ_PATH_CHANNEL_SPLIT); 0: never
- *   SGZ_OPT_FUSED_COLOUR   1 (default): an image-only K_B of one pair runs as the single fused launch; 0: scan + emit launches
+ *   SGZ_OPT_FUSED_COLOUR   1 (default): an image-only K_B of one pair runs as the single fused launch, a workgroup per 4 pixels; 8 / 16:
+ *                          the same with 8 / 16 pixels per workgroup (fewer, longer workgroups: slower on an idle device, but less of
+ *                          the chip is taken from kernels that run beside it -- what sgz_render_queue lanes use); 0: scan + emit launches
  *   SGZ_OPT_FETCH_WINDOW   0 (default): Hann / Hamming periodic windows at W == N are evaluated inside K_A; 1: fetched from the table
  * Call between sgz_plan_create and the first compute call on the plan (same threading rule as every other plan call). */
 #define SGZ_OPT_CHANNEL_SPLIT 1u
@@ -220,6 +222,35 @@ long       sgz_num_frames(size_t nsamples, uint32_t window_size, uint32_t hop);
 sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, size_t channel_stride,
                                          size_t nsamples, uint8_t *d_rgba, float *d_lines,
                                          float *d_state, void *stream);
+/* ---- render queue: a job of MANY buffers, several renders in flight (round 6) ------------------------------------------------------
+ * One render of BASELINE configs[1] is 696 workgroups on 512 slots: two full generations and a third that leaves two thirds of the
+ * chip idle, then K_B's dependent chain.  A job of many buffers (a folder of files, the channel pairs of a session rendered to separate
+ * images, a long buffer cut into independent images) need not pay that per buffer: the queue owns `depth` lanes -- a plan (a plan owns
+ * its scratch) and a stream each -- and submits round-robin, so that one buffer's K_B and the partly filled last generation of its K_A
+ * run beside the next buffers' K_A.  Measured (tools/pipeline_depth.py, input rotated past the Infinity Cache): 33.3 us per render one
+ * after the other, 25.3-26.1 us at depth >= 3: +27 ... 31 % frames/s.  The reference has no counterpart (it transforms one frame per
+ * audio callback, TransformDSP.inl:1165-1211); results per buffer are those of sgz_spectrogram_render_device(plan, ..., d_lines = NULL,
+ * d_state = NULL, ...) byte for byte (every buffer is a job of its own: decay states start from zero).
+ *   submit   never waits for the GPU (a lane that is still busy simply queues the work behind its previous render).  The samples must be
+ *            complete when the render starts: `after_stream` (may be NULL) is the caller's stream that produced them -- the lane waits
+ *            for what that stream holds at the time of the call.  *ticket (optional) numbers the submission, from 1.
+ *   wait     host wait until submission `ticket` has finished (0: everything submitted so far)
+ *   join     makes `stream` (the caller's) wait for everything submitted so far, without a host wait
+ * One thread at a time per queue.  depth 1 .. 16 (3 or more reaches the plateau). */
+typedef struct sgz_render_queue sgz_render_queue;
+sgz_status sgz_render_queue_create(const sgz_spectrum_config *cfg, uint32_t depth, sgz_render_queue **out);
+void       sgz_render_queue_destroy(sgz_render_queue *q);
+sgz_status sgz_render_queue_submit(sgz_render_queue *q, const float *d_planar, size_t channel_stride, size_t nsamples,
+                                   uint8_t *d_rgba /*[frames][P][4]*/, void *after_stream, uint64_t *ticket);
+sgz_status sgz_render_queue_wait(sgz_render_queue *q, uint64_t ticket);
+sgz_status sgz_render_queue_join(sgz_render_queue *q, void *stream);
+/* Lanes whose streams run side by side.  The runtime maps streams onto a few hardware queues (4 by default; GPU_MAX_HW_QUEUES) and two
+ * lanes on one queue run one after the other, so sgz_render_queue_create picks its streams by measurement (a 100 us spin kernel per
+ * stream); with depth above the number of hardware queues the remaining lanes share.  Diagnostic. */
+uint32_t   sgz_render_queue_distinct_lanes(const sgz_render_queue *q);
+/* the lane plans' option (sgz_plan_set_option on every lane; before the first submit) */
+sgz_status sgz_render_queue_set_option(sgz_render_queue *q, uint32_t option, uint32_t value);
+
 /* Host buffers in, host buffers out (H2D, render, D2H on a stream of the plan's own); `planar` are the reference's planar channel
  * pointers (AudioStream::Listener::onStreamAudio's float** buffer, Spectrum.h:370).  The plan keeps the device copies between calls:
  * repeated renders of the same shape allocate nothing and rebuild no tables.  sgz_spectrogram_render is the one-shot form (plan

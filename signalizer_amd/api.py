@@ -123,6 +123,7 @@ EXPORTS = [
     "sgz_plan_window_scale", "sgz_plan_break_pixel", "sgz_plan_path", "sgz_plan_dc_pixels", "sgz_plan_get_window",
     "sgz_plan_get_mapped_frequencies", "sgz_plan_get_slope_map", "sgz_plan_get_colour_ratios",
     "sgz_plan_get_colour_table", "sgz_rotate_hue_rgb8", "sgz_num_frames", "sgz_plan_num_frames", "sgz_plan_get_resonator", "sgz_plan_reset_resonator",
+    "sgz_render_queue_create", "sgz_render_queue_destroy", "sgz_render_queue_submit", "sgz_render_queue_wait", "sgz_render_queue_join", "sgz_render_queue_set_option", "sgz_render_queue_distinct_lanes",
     "sgz_spectrogram_render_device", "sgz_spectrogram_render", "sgz_stage_bins", "sgz_stage_mapped", "sgz_stage_mapped_dominant", "sgz_plan_set_option",
     "sgz_stage_map_from_bins", "sgz_stage_track_peak", "sgz_spectrum_track_peak", "sgz_track_peak_lines", "sgz_spectrum_track_peak_lines", "sgz_stage_decay_colour", "sgz_stage_decay_scan", "sgz_stage_decay_emit", "sgz_stage_logf", "sgz_stage_finish_pixel", "sgz_decay_fold_carry", "sgz_comm_unique_id", "sgz_comm_create", "sgz_comm_destroy", "sgz_shard_layout", "sgz_spectrogram_render_sharded_on",
     "sgz_spectrogram_render_sharded", "sgz_peer_group_create", "sgz_peer_group_destroy", "sgz_peer_transport", "sgz_peer_transport_release",
@@ -161,6 +162,15 @@ def lib() -> C.CDLL:
     L.sgz_plan_destroy.argtypes = [vp]
     L.sgz_plan_destroy.restype = None
     L.sgz_plan_upload.argtypes = [vp]
+    L.sgz_render_queue_create.argtypes = [C.POINTER(SpectrumConfig), u32, C.POINTER(vp)]
+    L.sgz_render_queue_destroy.argtypes = [vp]
+    L.sgz_render_queue_destroy.restype = None
+    L.sgz_render_queue_submit.argtypes = [vp, vp, sz, sz, vp, vp, C.POINTER(C.c_uint64)]
+    L.sgz_render_queue_wait.argtypes = [vp, C.c_uint64]
+    L.sgz_render_queue_join.argtypes = [vp, vp]
+    L.sgz_render_queue_set_option.argtypes = [vp, u32, u32]
+    L.sgz_render_queue_distinct_lanes.argtypes = [vp]
+    L.sgz_render_queue_distinct_lanes.restype = u32
     L.sgz_plan_transform_size.argtypes = [vp]
     L.sgz_plan_transform_size.restype = u32
     L.sgz_plan_window_scale.argtypes = [vp]
@@ -467,6 +477,45 @@ class Plan:
         check(lib().sgz_decay_fold_carry(self.h, aggs.data_ptr(), fr, world, rank, carry.data_ptr(),
                                          torch.cuda.current_stream().cuda_stream))
         return carry
+
+
+class RenderQueue:
+    """sgz_render_queue: `depth` lanes of (plan, stream); renders of independent device buffers submitted round-robin (sgz.h)."""
+
+    def __init__(self, cfg: dict, depth: int = 3):
+        self.cfg = config_from_dict(cfg)
+        self.h = C.c_void_p()
+        check(lib().sgz_render_queue_create(C.byref(self.cfg), depth, C.byref(self.h)))
+        self.depth = depth
+        self.distinct_lanes = int(lib().sgz_render_queue_distinct_lanes(self.h))
+
+    def submit(self, planar, rgba, after_stream=None) -> int:
+        """planar: torch.float32 [2*C, S] (cuda), rgba: torch.uint8 [F, P, 4] (cuda); returns the ticket"""
+        t = C.c_uint64(0)
+        check(lib().sgz_render_queue_submit(self.h, C.c_void_p(planar.data_ptr()), C.c_size_t(planar.stride(0)), C.c_size_t(planar.shape[1]),
+                                            C.c_void_p(rgba.data_ptr()), C.c_void_p(after_stream) if after_stream else None, C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int = 0):
+        check(lib().sgz_render_queue_wait(self.h, C.c_uint64(ticket)))
+
+    def join(self, stream: int):
+        check(lib().sgz_render_queue_join(self.h, C.c_void_p(stream)))
+
+    def set_option(self, option: int, value: int):
+        check(lib().sgz_render_queue_set_option(self.h, option, value))
+        return self
+
+    def close(self):
+        if self.h:
+            lib().sgz_render_queue_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                           # noqa: BLE001
+            pass
 
 
 def render_spectrogram(cfg: dict, planar: np.ndarray, want_lines: bool = False):

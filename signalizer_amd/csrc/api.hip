@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -477,6 +478,7 @@ sgz_status runDecayColour(Plan &p, const float *d_mapped, long frames, uint8_t *
     sgz_status stp = fillDecayParams(p, d_mapped, frames, d_rgba, d_lines, d_state, stream, prm);
     if (stp != SGZ_OK) return stp;
     const bool noFused = !p.optFusedColour;                                  // (sgz_plan_set_option: A/B switch for measurements)
+    prm.fusedPixels = p.optFusedPixels;
     // the one-launch form of the step with line results / state (one pair, 2 .. 64 chunks; not the scan half of the two-step K_B,
     // whose aggregates the emit half needs in HBM)
     const bool fullFused = !noFused && !magnitudeOnly && p.cfg.channel_mode != SGZ_CH_PHASE && prm.numChunks > 1 && decayFullFusedApplies(prm);
@@ -617,7 +619,9 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     Plan &p = plan->impl;
     switch (option) {
     case SGZ_OPT_CHANNEL_SPLIT: p.optChannelSplit = value != 0; return SGZ_OK;
-    case SGZ_OPT_FUSED_COLOUR: p.optFusedColour = value != 0; return SGZ_OK;
+    case SGZ_OPT_FUSED_COLOUR:
+        if (value > 1 && value != 4 && value != 8 && value != 16) return fail(SGZ_EINVAL, "SGZ_OPT_FUSED_COLOUR: 0, 1 (= 4 pixels per workgroup), 4, 8 or 16");
+        p.optFusedColour = value != 0; p.optFusedPixels = value > 1 ? value : 4u; return SGZ_OK;
     case SGZ_OPT_FETCH_WINDOW: p.optFetchWindow = value != 0; return SGZ_OK;
     case SGZ_OPT_MATRIX_RESONATOR: if (value > 2) return fail(SGZ_EINVAL, "SGZ_OPT_MATRIX_RESONATOR: 0, 1 or 2"); p.optMatrixResonator = int(value); return SGZ_OK;
     case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
@@ -739,6 +743,151 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
     if (!d_state && (st = resetResonator(p, s)) != SGZ_OK) return st;
     if ((st = runStft(p, d_planar, channel_stride, frames, p.d_mapped, nullptr, nullptr, s, nullptr, /*deferLate=*/true)) != SGZ_OK) return st;
     return runDecayColour(p, p.d_mapped, frames, d_rgba, d_lines, d_state, s);
+}
+
+// ---- render queue (sgz.h): `depth` lanes of (plan, stream); submissions go round-robin, every lane is an in-order stream, so a lane's
+// scratch is never touched by two renders at once and nothing on the host waits.
+struct sgz_render_queue {
+    std::vector<sgz_plan *> plans;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;           // per lane: recorded by join() behind the lane's newest render
+    std::vector<uint64_t> newest;           // per lane: ticket of that render (0: none yet)
+    hipEvent_t inputReady = nullptr;
+    uint64_t submitted = 0;
+    uint32_t distinct = 0;                  // lanes whose streams were measured to run side by side (the others share a hardware queue)
+};
+
+void sgz_render_queue_destroy(sgz_render_queue *q)
+{
+    if (!q) return;
+    for (hipStream_t s : q->streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t e : q->done) if (e) (void)hipEventDestroy(e);
+    if (q->inputReady) (void)hipEventDestroy(q->inputReady);
+    for (sgz_plan *p : q->plans) sgz_plan_destroy(p);
+    delete q;
+}
+
+// The runtime maps streams onto a few hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise), in an order that depends on every
+// stream the process has made so far -- and two lanes that share a hardware queue run one after the other: the same queue measured
+// 25 us per render or 38 (= no overlap at all) depending on how many OTHER streams the process had created (tools/pipeline_depth.py,
+// SGZ_DUMMY_STREAMS).  So the lanes' streams are picked by measurement: two kernels that spin for 100 us on the shared 100 MHz clock,
+// one per stream -- together they take ~100 us on different hardware queues and ~200 us on the same one.
+__global__ void queueProbeSpinKernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static bool streamsRunSideBySide(hipStream_t a, hipStream_t b)
+{
+    constexpr unsigned long long kTicks = 10000;                // 100 us
+    double best = 1e9;
+    for (int rep = 0; rep < 2; ++rep) {                         // (the shorter of two tries: a host hiccup can only make a pair look serial)
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(queueProbeSpinKernel, dim3(1), dim3(64), 0, a, kTicks);
+        hipLaunchKernelGGL(queueProbeSpinKernel, dim3(1), dim3(64), 0, b, kTicks);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best < 170.0;
+}
+
+sgz_status sgz_render_queue_create(const sgz_spectrum_config *cfg, uint32_t depth, sgz_render_queue **out)
+{
+    if (!cfg || !out) return fail(SGZ_EINVAL, "null argument");
+    if (depth == 0 || depth > 16) return fail(SGZ_EINVAL, "sgz_render_queue_create: depth 1 .. 16");
+    sgz_render_queue *q = new (std::nothrow) sgz_render_queue();
+    if (!q) return fail(SGZ_ENOMEM, "out of memory");
+    std::vector<hipStream_t> spare;
+    auto bail = [&](sgz_status st) { for (hipStream_t s : spare) (void)hipStreamDestroy(s); sgz_render_queue_destroy(q); return st; };
+    // streams first: up to 16 candidates, a candidate becomes a lane if it runs side by side with every lane chosen so far
+    for (int tries = 0; tries < 16 && q->streams.size() < depth; ++tries) {
+        hipStream_t s = nullptr;
+        if (hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); e != hipSuccess) return bail(hipFail(e, "hipStreamCreateWithFlags"));
+        bool distinct = true;
+        for (hipStream_t chosen : q->streams) distinct = distinct && streamsRunSideBySide(chosen, s);
+        if (distinct) q->streams.push_back(s); else spare.push_back(s);
+    }
+    q->distinct = uint32_t(q->streams.size());
+    while (q->streams.size() < depth && !spare.empty()) { q->streams.push_back(spare.back()); spare.pop_back(); }   // more lanes than hardware queues: the rest share
+    for (hipStream_t s : spare) (void)hipStreamDestroy(s);
+    spare.clear();
+    while (q->streams.size() < depth) {
+        hipStream_t s = nullptr;
+        if (hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking); e != hipSuccess) return bail(hipFail(e, "hipStreamCreateWithFlags"));
+        q->streams.push_back(s);
+    }
+    (void)hipGetLastError();
+    for (uint32_t i = 0; i < depth; ++i) {
+        sgz_plan *pl = nullptr;
+        if (sgz_status st = sgz_plan_create(cfg, &pl); st != SGZ_OK) return bail(st);
+        q->plans.push_back(pl);
+        // several renders in flight: K_B as few, long workgroups -- it shares the chip with the other lanes' K_A, whose workgroups it
+        // displaces CU by CU (tools/pipeline_depth.py: 26.1 -> 25.3 us per render at depth 3; on an idle device the 4-pixel form is faster)
+        if (depth >= 2) pl->impl.optFusedPixels = 16;
+        if (sgz_status st = sgz_plan_upload(pl); st != SGZ_OK) return bail(st);
+        hipEvent_t ev = nullptr;
+        if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); e != hipSuccess) return bail(hipFail(e, "hipEventCreateWithFlags"));
+        q->done.push_back(ev);
+        q->newest.push_back(0);
+    }
+    if (hipError_t e = hipEventCreateWithFlags(&q->inputReady, hipEventDisableTiming); e != hipSuccess) return bail(hipFail(e, "hipEventCreateWithFlags"));
+    *out = q;
+    return SGZ_OK;
+}
+
+uint32_t sgz_render_queue_distinct_lanes(const sgz_render_queue *q) { return q ? q->distinct : 0; }
+
+sgz_status sgz_render_queue_set_option(sgz_render_queue *q, uint32_t option, uint32_t value)
+{
+    if (!q) return fail(SGZ_EINVAL, "null queue");
+    if (q->submitted) return fail(SGZ_EINVAL, "sgz_render_queue_set_option: before the first submit");
+    for (sgz_plan *p : q->plans)
+        if (sgz_status st = sgz_plan_set_option(p, option, value); st != SGZ_OK) return st;
+    return SGZ_OK;
+}
+
+sgz_status sgz_render_queue_submit(sgz_render_queue *q, const float *d_planar, size_t channel_stride, size_t nsamples, uint8_t *d_rgba,
+                                   void *after_stream, uint64_t *ticket)
+{
+    if (!q || !d_planar || !d_rgba) return fail(SGZ_EINVAL, "null argument");
+    const size_t lane = size_t(q->submitted % q->plans.size());
+    hipStream_t s = q->streams[lane];
+    if (after_stream) {
+        SGZ_HIP(hipEventRecord(q->inputReady, reinterpret_cast<hipStream_t>(after_stream)));
+        SGZ_HIP(hipStreamWaitEvent(s, q->inputReady, 0));
+    }
+    const sgz_status st = sgz_spectrogram_render_device(q->plans[lane], d_planar, channel_stride, nsamples, d_rgba, nullptr, nullptr, s);
+    if (st != SGZ_OK) return st;                               // (SGZ_SKIPPED_FRAME included: nothing was enqueued, no ticket)
+    // (no event per submission: a marker behind every render cost ~9 us per render at depth 2-3 -- tools/pipeline_depth.py -- because the
+    // lane's next kernel waits for the marker's own completion signal; wait / join look at the lane's stream instead)
+    q->newest[lane] = ++q->submitted;
+    if (ticket) *ticket = q->submitted;
+    return SGZ_OK;
+}
+
+sgz_status sgz_render_queue_wait(sgz_render_queue *q, uint64_t ticket)
+{
+    if (!q) return fail(SGZ_EINVAL, "null queue");
+    if (ticket > q->submitted) return fail(SGZ_EINVAL, "sgz_render_queue_wait: no such ticket");
+    // a lane's stream is in order: submission `ticket` has finished once its lane has drained (which may include later submissions
+    // of the same lane: the wait is for at least the ticket)
+    for (size_t lane = 0; lane < q->plans.size(); ++lane) {
+        if (q->newest[lane] == 0) continue;
+        if (ticket == 0 || size_t((ticket - 1) % q->plans.size()) == lane) SGZ_HIP(hipStreamSynchronize(q->streams[lane]));
+    }
+    return SGZ_OK;
+}
+
+sgz_status sgz_render_queue_join(sgz_render_queue *q, void *stream)
+{
+    if (!q) return fail(SGZ_EINVAL, "null queue");
+    for (size_t lane = 0; lane < q->plans.size(); ++lane)
+        if (q->newest[lane]) {
+            SGZ_HIP(hipEventRecord(q->done[lane], q->streams[lane]));
+            SGZ_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), q->done[lane], 0));
+        }
+    return SGZ_OK;
 }
 
 // Host buffers in, host buffers out, on a plan the caller keeps: the constant block is built and uploaded once, the device buffers and

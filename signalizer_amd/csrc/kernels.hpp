@@ -135,6 +135,7 @@ struct DecayParams {
     float *lines;             // [frames][C][G][P][2] or null
     float magScale;           // factor on the mapped magnitudes before the decay: 1, or 0.5 in Phase mode (mag *= consts::half, TransformDSP.inl:1407) -- fused kernel only
     uint32_t colourOnly;      // neither lines nor state are wanted: only (side 0, LineMain) of every pair feeds the colour column, the scans skip the rest
+    uint32_t fusedPixels;     // fused colour kernel: pixels per workgroup (4 -- the fastest launch on an idle device --, 8 or 16: fewer, longer workgroups, less of the chip taken from kernels that run beside it)
     LateFix late; uint32_t hasLate;   // fused colour kernel: `mapped` comes from channel workgroups whose late pixels (late_fix.hpp) are applied while it is read
 };
 hipError_t launchDecayLocalCarry(const DecayParams &prm, hipStream_t stream);   // local + carry, one launch when the chunks fit a workgroup

@@ -803,8 +803,9 @@ hipError_t launchDecayFullFused(const DecayParams &prm, hipStream_t stream)
 }
 hipError_t launchDecayColourFused(const DecayParams &prm, hipStream_t stream)
 {
-    constexpr int PX = 4;
-    hipLaunchKernelGGL(decayColourFusedKernel<PX>, dim3((prm.P + PX - 1) / PX), dim3(1024), 0, stream, prm);
+    if (prm.fusedPixels == 16) hipLaunchKernelGGL(decayColourFusedKernel<16>, dim3((prm.P + 15) / 16), dim3(1024), 0, stream, prm);
+    else if (prm.fusedPixels == 8) hipLaunchKernelGGL(decayColourFusedKernel<8>, dim3((prm.P + 7) / 8), dim3(1024), 0, stream, prm);
+    else hipLaunchKernelGGL(decayColourFusedKernel<4>, dim3((prm.P + 3) / 4), dim3(1024), 0, stream, prm);
     return hipGetLastError();
 }
 

@@ -76,6 +76,36 @@ __device__ __forceinline__ void pass1Columns(v2 (&c)[R])
     }
 }
 
+// ---- "fetch diet" (round 6): what a thread's SECOND column needs from the tables is one fixed rotation away from the first column's.
+// A workgroup fetches ~60 KB of tables beside its 128 KB of samples, the same bytes for every workgroup, through a per-CU fetch path that
+// is as busy as the vector ALUs (NOTES.md, round 5): columns 2 tid and 2 tid + 1 differ by ONE sample pair, so the second column's window
+// phase is the first's turned by a = 2 pi 2 / N, its pass-1 twiddle rows W_M^{c + 1} = W_M^c W_M^1 and W_M^{4 (c + 1)} = W_M^{4c} W_M^4.
+// Rotations by tiny angles in the form x + (x (cos a - 1) - y sin a): cos a - 1 is a full-precision float (cos a itself would round to
+// 1 - 2^-24), so the turned value is within an ulp of its magnitude.  32 bytes and three requests per thread less, eight packed
+// operations more.  N = 32768 (M = 16384): a = 2 pi / 16384 for the phase and for W_M^1, 2 pi / 4096 for W_M^4.
+// MEASURED (round 6, tools/ab.sh + tools/ab_rot.sh on one box, all 131 spectrum / golden / fuzz tests green with it): 16 KB of table
+// bytes (of ~60) and 3 of a thread's ~29 requests less move nothing -- cfg2 24.6 | 24.6 us with the input L2-resident, 26.8 | 27.1 us
+// from HBM, tail-free 155.9 | 156.2, cfg5 +-0.  The tables are not what the fetch path is busy with (they are the same lines for every
+// workgroup of a CU and hit its L1); kept behind -DSGZ_DIET as the record of the experiment.
+constexpr float kRotA1Cm1 = -0x1.3bd3ccp-24f, kRotA1Sin = 0x1.921fb4p-12f;      // cos(2 pi / 16384) - 1, sin(2 pi / 16384)
+constexpr float kRotA4Cm1 = -0x1.3bd3c8p-20f, kRotA4Sin = 0x1.921faap-10f;      // cos(2 pi / 4096) - 1,  sin(2 pi / 4096)
+// (cos t, cos t', sin t, sin t') -> the same of t + a, t' + a
+__device__ __forceinline__ float4 rotatePhaseForward(const float4 ph, const float cm1, const float sn)
+{
+    const v2 pc = v2{ph.x, ph.y}, ps = v2{ph.z, ph.w};
+    const v2 kc = v2{cm1, cm1}, ks = v2{sn, sn};
+    const v2 c2 = __builtin_elementwise_fma(pc, kc, __builtin_elementwise_fma(ps, -ks, pc));
+    const v2 s2 = __builtin_elementwise_fma(ps, kc, __builtin_elementwise_fma(pc, ks, ps));
+    return float4{c2.x, c2.y, s2.x, s2.y};
+}
+// w = (cos t, -sin t) -> (cos(t + a), -sin(t + a)):  w (cos a - i sin a)
+__device__ __forceinline__ float2 rotateTwiddle(const float2 w, const float cm1, const float sn)
+{
+    const v2 v = v2{w.x, w.y}, sw = v2{w.y, w.x};
+    const v2 r = __builtin_elementwise_fma(v, v2{cm1, cm1}, __builtin_elementwise_fma(sw, v2{sn, -sn}, v));   // (x + y sin a, y - x sin a) + (x, y)(cos a - 1)
+    return float2{r.x, r.y};
+}
+
 // Everything behind the barrier that completes a side's magnitudes in LDS: the test hook that writes them out, the pair exchange,
 // the pixel map (chunk_map.hpp) and the settlement of the pixels that need both channels.  Shared by the transform kernel and by
 // realMapFromBinsKernel (sgz_stage_map_from_bins: the same code maps injected bins, so "the mapping is bit-exact given the bins"
@@ -177,6 +207,11 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     constexpr bool PAIRED = U == 2;                          // thread -> columns 2 tid, 2 tid + 1 (otherwise tid + T u): see the sample loads
     constexpr int COLSTEP = PAIRED ? 1 : T, COLLANE = PAIRED ? 2 : 1;     // column of (tid, u) = COLLANE tid + COLSTEP u
     constexpr bool FRONT = LR1 >= 4 && !mixed && WCOS;       // (the mixed modes and a fetched window hold more values in flight: they would spill)
+#ifdef SGZ_DIET                                              // (measured +-0 with the input L2-resident, +0.2 ... 0.6 us from HBM: NOTES.md round 6 -- off by default)
+    constexpr bool DIET = PAIRED && FRONT && LR1 == 4;       // the second column's phase and twiddle rows by rotation of the first's (above)
+#else
+    constexpr bool DIET = false;
+#endif
     [[maybe_unused]] float4 phase[U];
     [[maybe_unused]] float2 twA[U], twB[U];
     [[maybe_unused]] float4 tw2piece, tw2tail;                  // (T = 512: threads 0 .. 31 carry a second piece of the 544)
@@ -221,7 +256,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         if constexpr (FRONT) {
             if constexpr (WALK) tw2piece = prm.tw2Full[tid < kTw2Floats / 4 ? tid : 0];     // (unconditional: a conditional one makes the registers loop-carried)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < (DIET ? 1 : U); ++u) {
                 if (WCOS) phase[u] = ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);
                 twA[u] = ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
                 twB[u] = ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
@@ -311,7 +346,8 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             const v2 p0 = v2{prm.winP0, prm.winP0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 ph = FRONT ? phase[u] : ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
+                const float4 ph = (DIET && u == 1) ? rotatePhaseForward(phase[0], kRotA1Cm1, kRotA1Sin)
+                                  : FRONT ? phase[u] : ldg(prm.winPhase + COLSTEP * u, uint32_t(tid) * 16u * COLLANE);     // p1 x (cos even, cos odd, sin even, sin odd) of the column's first pair
                 const v2 pc = v2{ph.x, ph.y}, ps = v2{ph.z, ph.w};
 #pragma unroll
                 for (int j = 0; j < R1 / 2; ++j) {
@@ -379,8 +415,13 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
         // row and workgroup, and what a workgroup fetches costs as much as what it computes)
         auto sq = [](float2 w) { return float2{w.x * w.x - w.y * w.y, 2.f * w.x * w.y}; };
         auto mul = [](float2 p, float2 q) { return float2{p.x * q.x - p.y * q.y, p.x * q.y + p.y * q.x}; };
-        a[0] = FRONT ? twA[u] : ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
-        if (NB > 0) b[0] = FRONT ? twB[u] : ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
+        if (DIET && u == 1) {
+            a[0] = rotateTwiddle(twA[0], kRotA1Cm1, kRotA1Sin);
+            if (NB > 0) b[0] = rotateTwiddle(twB[0], kRotA4Cm1, kRotA4Sin);
+        } else {
+            a[0] = FRONT ? twA[u] : ldg(prm.tw1 + (COLSTEP * u), uint32_t(tid) * 8u * COLLANE);
+            if (NB > 0) b[0] = FRONT ? twB[u] : ldg(prm.tw1 + (COLSTEP * u + 3 * RR), uint32_t(tid) * 8u * COLLANE);
+        }
         a[1] = sq(a[0]); a[2] = mul(a[1], a[0]);
 #pragma unroll
         for (int i = 1; i < NB; ++i) b[i] = (i & 1) ? sq(b[i / 2]) : mul(b[i - 1], b[0]);

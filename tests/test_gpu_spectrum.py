@@ -161,6 +161,11 @@ def test_decay_colour_every_kernel(gpu, oracle, pairs, frames, P):
     ref = np.stack([r["lines"].real, r["lines"].imag], axis=-1).astype(np.float32)
     img, _ = plan.stage_decay_colour(mag)                                         # image only
     assert np.array_equal(img.cpu().numpy(), r["rgba"])
+    for px in (8, 16):                                                            # the fused colour kernel with 8 / 16 pixels per workgroup (sgz_render_queue's lanes)
+        wide = api.Plan(cfg)
+        wide.set_option(api.OPT_FUSED_COLOUR, px)
+        img_w, _ = wide.upload().stage_decay_colour(mag)
+        assert np.array_equal(img_w.cpu().numpy(), r["rgba"]), px
     state = torch.zeros((pairs, 2, P, 2), dtype=torch.float32, device=gpu)
     img2, lines = plan.stage_decay_colour(mag, want_lines=True, state=state)      # with lines and state
     assert np.array_equal(img2.cpu().numpy(), r["rgba"])
@@ -598,3 +603,72 @@ def test_result_does_not_depend_on_the_row_layout(gpu, N, sr, mode):
     b = plan.stage_mapped(odd[:, 1:S + 1]).cpu().numpy()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.array_equal(plan.render(even[:, :S]).cpu().numpy(), plan.render(odd[:, 1:S + 1]).cpu().numpy())
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 5])
+def test_render_queue_equals_one_render_after_the_other(gpu, depth):
+    """sgz_render_queue (round 6): independent buffers submitted round-robin over `depth` lanes -- every image byte for byte the one
+    sgz_spectrogram_render_device gives for that buffer alone (decay states from zero), whatever overlaps on the device; tickets,
+    wait, join, the input-ready dependency on the caller's stream, and the refusals."""
+    import ctypes as C
+    import torch
+    cfg = config.spectrum_config(window_size=4096, hop=1024, axis_points=300)
+    S = 4096 + 1024 * 40
+    n = 11
+    plan = api.Plan(cfg).upload()
+    F = plan.num_frames(S)
+    xs = [torch.from_numpy(synth.gen(100 + k, 48000, S, 2)).to(gpu) for k in range(n)]
+    want = [plan.render(x).cpu().numpy() for x in xs]
+    q = api.RenderQueue(cfg, depth)
+    outs = [torch.zeros((F, 300, 4), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    tickets = [q.submit(xs[k], outs[k]) for k in range(n)]
+    assert tickets == list(range(1, n + 1))
+    q.wait(tickets[0])
+    assert np.array_equal(outs[0].cpu().numpy(), want[0])                         # the first one is done; the others may still run
+    q.wait()
+    for k in range(n):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k]), k
+    # the samples are produced on the caller's stream right before the submit: the lane must wait for them
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fresh = torch.zeros_like(xs[0])
+        big = torch.randn((4096, 4096), device=gpu)
+        for _ in range(8):
+            big = big @ big * 1e-3                                                 # keep the stream busy in front of the copy
+        fresh.copy_(xs[3])
+        out = torch.zeros((F, 300, 4), dtype=torch.uint8, device=gpu)
+        t = q.submit(fresh, out, after_stream=side.cuda_stream)
+        q.join(side.cuda_stream)                                                  # ... and the caller's stream can wait for the image without the host
+        got = out.clone()
+    side.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want[3]) and t == n + 1
+    # refusals: an unknown ticket, a buffer shorter than one window (nothing enqueued, no ticket), options once work is in
+    assert api.lib().sgz_render_queue_wait(q.h, C.c_uint64(t + 1)) == api.SGZ_EINVAL
+    short = torch.zeros((2, 100), dtype=torch.float32, device=gpu)
+    tk = C.c_uint64(0)
+    assert api.lib().sgz_render_queue_submit(q.h, C.c_void_p(short.data_ptr()), short.stride(0), 100, C.c_void_p(out.data_ptr()), None, C.byref(tk)) == api.SGZ_SKIPPED_FRAME
+    assert tk.value == 0
+    assert api.lib().sgz_render_queue_set_option(q.h, api.OPT_FUSED_COLOUR, 4) == api.SGZ_EINVAL
+    q.close()
+    h = C.c_void_p()
+    c = api.config_from_dict(cfg)
+    assert api.lib().sgz_render_queue_create(C.byref(c), 0, C.byref(h)) == api.SGZ_EINVAL
+    assert api.lib().sgz_render_queue_create(C.byref(c), 17, C.byref(h)) == api.SGZ_EINVAL
+
+
+def test_render_queue_at_the_bench_size(gpu):
+    """the queue at BASELINE configs[1] (348 frames, N = 32768: the channel-split K_A + the 16-pixel fused K_B), 9 buffers over 3 lanes"""
+    import torch
+    cfg = config.cfg2()
+    S = 32768 + 8192 * 347
+    plan = api.Plan(cfg).upload()
+    q = api.RenderQueue(cfg, 3)
+    xs = [torch.from_numpy(synth.gen(200 + k, 48000, S, 2)).to(gpu) for k in range(3)]
+    want = [plan.render(x).cpu().numpy() for x in xs]
+    outs = [torch.zeros((348, 1024, 4), dtype=torch.uint8, device=gpu) for _ in range(9)]
+    for k in range(9):
+        q.submit(xs[k % 3], outs[k])
+    q.wait()
+    for k in range(9):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k % 3]), k
+    q.close()
