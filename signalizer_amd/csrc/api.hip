@@ -361,6 +361,7 @@ sgz_status runStft(Plan &p, const float *d_planar, size_t chStride, long frames,
         // K_B's fused kernel while it loads the magnitudes (then the step stays at two launches)
         if (deferLate && !p.realMono && d_mapped && !d_binsOut && p.realLowCount[0] + p.realLowCount[1] == 0) { rp.lateInNext = 1u; p.lateDeferred = d_mapped; p.lateFrames = frames; }
         rp.roundSize = uint32_t(numCUs()) * (p.N == 16384 ? 4u : p.N == 32768 ? 2u : 1u);   // workgroups a CU holds at once
+        rp.pipelined = p.optPipelined ? 1u : 0u;
 #ifdef SGZ_DEBUG
         rp.phaseClock = d_phaseClock; rp.clkUnit = g_ablate >> 16;
 #endif
@@ -824,7 +825,7 @@ sgz_status sgz_render_queue_create(const sgz_spectrum_config *cfg, uint32_t dept
         q->plans.push_back(pl);
         // several renders in flight: K_B as few, long workgroups -- it shares the chip with the other lanes' K_A, whose workgroups it
         // displaces CU by CU (tools/pipeline_depth.py: 26.1 -> 25.3 us per render at depth 3; on an idle device the 4-pixel form is faster)
-        if (depth >= 2) pl->impl.optFusedPixels = 16;
+        if (depth >= 2) { pl->impl.optFusedPixels = 16; pl->impl.optPipelined = true; }
         if (sgz_status st = sgz_plan_upload(pl); st != SGZ_OK) return bail(st);
         hipEvent_t ev = nullptr;
         if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); e != hipSuccess) return bail(hipFail(e, "hipEventCreateWithFlags"));

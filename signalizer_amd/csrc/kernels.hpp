@@ -85,6 +85,8 @@ struct RealParams {
     uint32_t lowCount[2];
     unsigned long long *phaseClock; uint32_t clkUnit;   // -DSGZ_DEBUG builds: shader clocks of workgroup `clkUnit` at the phase boundaries
     uint32_t roundSize;       // workgroups that run concurrently, for the XCD-aware order
+    uint32_t pipelined;       // 1: other launches run beside this one (sgz_render_queue): the second generation's delayed start and the wave priorities --
+                              // tuned for a launch that has the chip to itself -- are left out (tools/pipeline_depth.py: 25.5 -> 22.0 us per render at depth 3)
 };
 constexpr int kLowBins = 24;
 hipError_t launchStftReal(const RealParams &prm, uint32_t N, hipStream_t stream);

@@ -123,6 +123,7 @@ struct Plan {
     DeviceScalars scalars{};
     // sgz_plan_set_option
     bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = false;
+    bool optPipelined = false;          // the plan is a lane of an sgz_render_queue of depth >= 2 (RealParams::pipelined)
     uint32_t optFusedPixels = 4;        // pixels per workgroup of the fused colour K_B (4, 8, 16): SGZ_OPT_FUSED_COLOUR = 1 / 8 / 16
     int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)

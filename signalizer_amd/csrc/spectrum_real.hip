@@ -195,11 +195,17 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
 #ifndef SGZ_STAGGER
 #define SGZ_STAGGER 5
 #endif
-        if (cus && gridDim.x >= 2u * cus && blockIdx.x >= cus && blockIdx.x < 2u * cus) {       // (a launch with a FULL second generation: a partial one -- 1.5 generations -- loses 1.3 us to the delay)
+        if (cus && !launchPrm.pipelined && gridDim.x >= 2u * cus && blockIdx.x >= cus && blockIdx.x < 2u * cus) {       // (a launch with a FULL second generation: a partial one -- 1.5 generations -- loses 1.3 us to the delay)
 #pragma unroll
             for (int k = 0; k < SGZ_STAGGER; ++k) __builtin_amdgcn_s_sleep(32);      // (32 x 64 clocks per step)
         }
-        if (cus && gridDim.x > 2u * cus && gridDim.x <= 3u * cus) {
+        // (both are for a launch that has the chip to itself: with other launches beside it -- sgz_render_queue -- the delay and the priorities
+        // cost 3.5 us per render, tools/pipeline_depth.py; RealParams::pipelined)
+#ifndef SGZ_NO_PRIO
+        if (cus && !launchPrm.pipelined && gridDim.x > 2u * cus && gridDim.x <= 3u * cus) {
+#else
+        if (false) {
+#endif
             const uint32_t generation = blockIdx.x / cus;
             if (generation == 0u) __builtin_amdgcn_s_setprio(2); else if (generation == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
         }
