@@ -692,17 +692,22 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = HipEvents(2)
+    # the timed region holds the K steps and nothing else (until round 5 two HIP event records sat inside it for the gpu_ms diagnostic:
+    # 0.3-0.6 us per step of a 20-step region, tools/steps20_probe.py -- that diagnostic is now taken from a second, untimed pass)
     t0 = time.perf_counter()
-    ev.record(0, stream)
     for _ in range(args.steps):
         step()
-    ev.record(1, stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ev = HipEvents(2)
+    ev.record(0, stream)
+    for _ in range(args.steps):
+        step()
+    ev.record(1, stream)
+    torch.cuda.synchronize()
     gpu_ms = ev.elapsed_ms(0, 1)
 
     # ---- outside the timed region ------------------------------------------------------------------------------------------------
