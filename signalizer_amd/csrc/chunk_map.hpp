@@ -159,9 +159,17 @@ struct ChunkMap {
         // per wave, ~2 k clocks of a workgroup's critical path)
         uint32_t slotAddr = (slotBase << 2) + uint32_t(uintptr_t((__attribute__((address_space(3))) const void *)re));   // LDS byte address of the chunk's first tile slot
         uint64_t prev = 0;
+        // (round 6: the mask of element j as the CARRY of a left shift -- v_add_co x, x of the bit-reversed word delivers the lane mask and
+        // the shifted word in one vector operation, where "and with 1 << j, compare with 0" took two)
+        uint32_t rev = __builtin_bitreverse32(endBits);
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
+#ifndef SGZ_SCAN_MASK_BY_COMPARE
+            uint64_t e;
+            asm volatile("v_add_co_u32_e64 %0, %1, %0, %0" : "+v"(rev), "=s"(e));
+#else
             const uint64_t e = __builtin_amdgcn_uicmp(endBits & (1u << j), 0u, 33 /* ICMP_NE */);
+#endif
             if (j > 0)
                 asm volatile("s_andn2_b64 exec, exec, %2\n\tv_max_f32 %0, %0, %1\n\ts_mov_b64 exec, -1"
                              : "+v"(v[j]) : "v"(v[j - 1]), "s"(prev) : "scc");      // (s_andn2 writes SCC)

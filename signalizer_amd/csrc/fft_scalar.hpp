@@ -115,6 +115,24 @@ __device__ __forceinline__ void bflyPackedRot(v2 &a, v2 &b)
     a = p; b = q;
 }
 
+// A first-level (twiddle-free) butterfly with the twiddles its two inputs still owe from the pass before -- p = ta a + tb b, q = ta a - tb b
+// -- as u = ta a (2 operations; none where ta = 1), p = u + tb b (2), q = 2 u - p (1): five packed operations where "multiply both,
+// then add and subtract" takes six.  ta, tb per lane (vector registers).
+template <bool UNIT_A>
+__device__ __forceinline__ void bflyPackedFusedTw(v2 &a, v2 &b, v2 ta, v2 tb)
+{
+    v2 u = a, t, p, q;
+    if constexpr (!UNIT_A) {
+        v2 m;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(ta));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(a), "v"(ta), "v"(m));
+    }
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "v"(tb), "v"(u));                                  // u + b tb.re
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(p) : "v"(b), "v"(tb), "v"(t));                     // + (-b.im, b.re) tb.im
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(q) : "v"(u), "v"(p));
+    a = p; b = q;
+}
+
 template <int LR, int S, int BASE, int NREG>
 __device__ __forceinline__ void ditStagePacked(v2 (&c)[NREG])
 {

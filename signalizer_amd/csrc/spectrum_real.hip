@@ -508,7 +508,12 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     }
     // -------------------------------------------------------------------------- pass 2 (c_lo = ix): radix R over c_hi
     ditPacked<LR, 0>(c);
-    if constexpr (LR1 >= 4) {
+#ifndef SGZ_NO_TW_FUSE
+    constexpr bool TWFUSE = LR1 >= 4;       // the pass-2 twiddles are applied BEHIND exchange 2, fused into pass 3's first butterfly level (below)
+#else
+    constexpr bool TWFUSE = false;
+#endif
+    if constexpr (LR1 >= 4 && !TWFUSE) {
         // times W_1024^{c_lo q2}: the whole table sits in LDS behind the exchange areas (copied at the start of the kernel) -- one
         // ds_read_b64 and one complex product per value, instead of 10 fetched rows and 21 products to build the other 21
         const float4 *tab = reinterpret_cast<const float4 *>(lds + TAB + ix * kTw2Row);      // this thread's 32 factors, contiguous: 16 ds_read_b128
@@ -518,7 +523,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             if (i > 0) c[brev(2 * i, LR)] = cmul(c[brev(2 * i, LR)], v2{w.x, w.y});
             c[brev(2 * i + 1, LR)] = cmul(c[brev(2 * i + 1, LR)], v2{w.z, w.w});
         }
-    } else {
+    } else if constexpr (!TWFUSE) {
         TwFactors<LR> tw;
         tw.load(prm.tw2, ix, R);
         tw.apply(c);
@@ -551,7 +556,24 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // -------------------------------------------------------------------------- pass 3 (q2 = ix): radix R over c_lo
     float2 wk;                                                           // W_N^{kc}, for the recombination (a bin's is W_N^{kc} W_{2R}^{m3})
     if constexpr (EARLYTAB) wk = wkEarly; else wk = ldg(prm.twPost, uint32_t(q1 + R1 * ix) * 8u);
-    ditPacked<LR, 0>(c);
+    if constexpr (TWFUSE) {
+        // The factor W_1024^{c_lo q2} every value still owes from pass 2 is the same number on either side of the transpose (the table is
+        // symmetric: this thread is q2 = ix now and register r is c_lo = r), so it is applied HERE, inside pass 3's first level -- whose
+        // butterflies (registers r, r + 16) carry no twiddle of their own: u = ta a, p = u + tb b, q = 2u - p is five packed operations
+        // where the product in front of the exchange plus a plain butterfly took six (16 of a pass's ~250 fewer).  Same table, same
+        // sixteen ds_read_b128 per thread.
+        const float4 *tab = reinterpret_cast<const float4 *>(lds + TAB + ix * kTw2Row);
+#pragma unroll
+        for (int i = 0; i < R / 4; ++i) {
+            const float4 wa = tab[i], wb = tab[i + R / 4];               // entries 2i, 2i + 1 and 2i + 16, 2i + 17
+            if (i == 0) bflyPackedFusedTw<true>(c[0], c[R / 2], v2{1.f, 0.f}, v2{wb.x, wb.y});
+            else bflyPackedFusedTw<false>(c[2 * i], c[2 * i + R / 2], v2{wa.x, wa.y}, v2{wb.x, wb.y});
+            bflyPackedFusedTw<false>(c[2 * i + 1], c[2 * i + 1 + R / 2], v2{wa.z, wa.w}, v2{wb.z, wb.w});
+        }
+        ditPacked<LR, 0, R, 2>(c);
+    } else {
+        ditPacked<LR, 0>(c);
+    }
     RCLK(5);
     // Z[kc + T m3] at register brev(m3), kc = q1 + R1 ix
     const int kc = q1 + R1 * ix;
