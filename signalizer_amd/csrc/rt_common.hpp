@@ -248,7 +248,28 @@ __device__ __forceinline__ void batchFetch(const float *from, float *to, uint32_
 {
     if (!from) return;                                       // (uniform: the host copied)
     const uint32_t quads = floats / 4u;
-    for (uint32_t q = uint32_t(tid); q < quads; q += uint32_t(threads)) reinterpret_cast<float4 *>(to)[q] = reinterpret_cast<const float4 *>(from)[q];
+    // Every read is a round trip over PCIe (~2 us): eight of a thread's reads are in flight before the first is stored, so that a batch of
+    // up to 8 x threads x 16 bytes costs ONE round trip (as a plain copy loop the compiler keeps one load in flight per thread: a
+    // 512-sample callback of 8 channels on 256 threads was four round trips in a row -- round 6)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *src = reinterpret_cast<const v4f *>(from);
+    v4f *dst = reinterpret_cast<v4f *>(to);
+    const uint32_t T = uint32_t(threads);
+    for (uint32_t q0 = uint32_t(tid); q0 < quads; q0 += 8u * T) {
+        // (unconditional loads from clamped indices, conditional stores; eight named values: an array here went to scratch)
+        const uint32_t last = quads - 1u;
+        const uint32_t i0 = q0, i1 = q0 + T, i2 = q0 + 2u * T, i3 = q0 + 3u * T, i4 = q0 + 4u * T, i5 = q0 + 5u * T, i6 = q0 + 6u * T, i7 = q0 + 7u * T;
+        const v4f a0 = src[i0 < last ? i0 : last], a1 = src[i1 < last ? i1 : last], a2 = src[i2 < last ? i2 : last], a3 = src[i3 < last ? i3 : last];
+        const v4f a4 = src[i4 < last ? i4 : last], a5 = src[i5 < last ? i5 : last], a6 = src[i6 < last ? i6 : last], a7 = src[i7 < last ? i7 : last];
+        if (i0 < quads) dst[i0] = a0;
+        if (i1 < quads) dst[i1] = a1;
+        if (i2 < quads) dst[i2] = a2;
+        if (i3 < quads) dst[i3] = a3;
+        if (i4 < quads) dst[i4] = a4;
+        if (i5 < quads) dst[i5] = a5;
+        if (i6 < quads) dst[i6] = a6;
+        if (i7 < quads) dst[i7] = a7;
+    }
     for (uint32_t e = quads * 4u + uint32_t(tid); e < floats; e += uint32_t(threads)) to[e] = from[e];
     __threadfence_block();
     __syncthreads();
