@@ -672,3 +672,26 @@ def test_render_queue_at_the_bench_size(gpu):
     for k in range(9):
         assert np.array_equal(outs[k].cpu().numpy(), want[k % 3]), k
     q.close()
+
+
+@pytest.mark.parametrize("over", [dict(num_pairs=3, channel_mode=config.CH_MIDSIDE), dict(channel_mode=config.CH_PHASE), dict(channel_mode=config.CH_LEFT, window_size=3000),
+                                  dict(algorithm=config.ALGO_RSNT, hop=1024, window_type=config.WIN_HANN), dict(window_size=32768, hop=8192, num_pairs=2)])
+def test_render_queue_on_other_plans(gpu, over):
+    """the queue is plan-agnostic: several pairs (the scan / emit K_B), Phase, a mono mode with a zero-padded window, the RSNT algorithm
+    (every buffer from rest: the resonators' state lives in the lane's plan and is reset per render), N = 32768 with two pairs -- each
+    image equals the single render's"""
+    import torch
+    cfg = config.spectrum_config(**{**dict(window_size=4096, hop=1024, axis_points=257), **over})
+    S = cfg["window_size"] + cfg["hop"] * 30
+    plan = api.Plan(cfg).upload()
+    F = plan.num_frames(S)
+    xs = [torch.from_numpy(synth.gen(300 + k, 48000, S, 2 * cfg["num_pairs"])).to(gpu) for k in range(4)]
+    want = [plan.render(x).cpu().numpy() for x in xs]
+    q = api.RenderQueue(cfg, 3)
+    outs = [torch.zeros((F, 257, 4), dtype=torch.uint8, device=gpu) for _ in range(8)]
+    for k in range(8):
+        q.submit(xs[k % 4], outs[k])
+    q.wait()
+    for k in range(8):
+        assert np.array_equal(outs[k].cpu().numpy(), want[k % 4]), k
+    q.close()
