@@ -192,6 +192,8 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
                                       chunk between its two halves (from rest ... carry + windows) and cannot cut it, so this is a bound, in frames
                                       (0, the default: 8 GiB worth): a rank's chunk above it is refused with SGZ_EUNSUPPORTED on every rank before
                                       anything is allocated or exchanged (round 6; rounds 4-5 read SGZ_OPT_RESONATOR_SLAB here) */
+#define SGZ_OPT_PIPELINED 8u          /* 1: other launches run beside this plan's (a lane of an sgz_render_queue sets it): K_A without the tunings of a launch
+                                      that has the chip to itself (the second generation's delayed start, the wave priorities).  Same results. */
 sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value);
 /* The pixels whose filter taps or arg-max run reach a csf entry the reference leaves complex -- Complex: csf[0] = Z[0]/2
  * (TransformDSP.inl:993); Left / Right / Merge / Side: csf[N/2 .. N-1] (:553-560), reached by windows that wrap below bin 0 or
@@ -232,8 +234,9 @@ sgz_status sgz_spectrogram_render_device(sgz_plan *plan, const float *d_planar, 
  * audio callback, TransformDSP.inl:1165-1211); results per buffer are those of sgz_spectrogram_render_device(plan, ..., d_lines = NULL,
  * d_state = NULL, ...) byte for byte (every buffer is a job of its own: decay states start from zero).
  *   submit   never waits for the GPU (a lane that is still busy simply queues the work behind its previous render).  The samples must be
- *            complete when the render starts: `after_stream` (may be NULL) is the caller's stream that produced them -- the lane waits
- *            for what that stream holds at the time of the call.  *ticket (optional) numbers the submission, from 1.
+ *            complete -- and d_rgba free of pending work of other streams (a fill, an earlier reader) -- when the render starts:
+ *            `after_stream` (may be NULL) is the caller's stream that produced / last touched them; the lane waits for what that stream
+ *            holds at the time of the call.  *ticket (optional) numbers the submission, from 1.
  *   wait     host wait until submission `ticket` has finished (0: everything submitted so far)
  *   join     makes `stream` (the caller's) wait for everything submitted so far, without a host wait
  * One thread at a time per queue.  depth 1 .. 16 (3 or more reaches the plateau). */

@@ -297,6 +297,7 @@ def _np_ptr(a: np.ndarray):
 RT_OPT_STRICT_REFERENCE_QUIRKS, RT_OPT_AUDIO_HISTORY, RT_OPT_DEFER_SUBMIT, RT_OPT_PARK_PUSHES = 1, 2, 3, 4
 OPT_CHANNEL_SPLIT, OPT_FUSED_COLOUR, OPT_FETCH_WINDOW, OPT_MATRIX_RESONATOR, OPT_RESONATOR_SLAB, OPT_WIDE_GROUPS = 1, 2, 3, 4, 5, 6
 OPT_RESONATOR_SHARD_BOUND = 7
+OPT_PIPELINED = 8
 
 
 class Plan:

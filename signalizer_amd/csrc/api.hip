@@ -627,6 +627,7 @@ sgz_status sgz_plan_set_option(sgz_plan *plan, uint32_t option, uint32_t value)
     case SGZ_OPT_MATRIX_RESONATOR: if (value > 2) return fail(SGZ_EINVAL, "SGZ_OPT_MATRIX_RESONATOR: 0, 1 or 2"); p.optMatrixResonator = int(value); return SGZ_OK;
     case SGZ_OPT_RESONATOR_SLAB: p.optResonatorSlab = value; return SGZ_OK;
     case SGZ_OPT_RESONATOR_SHARD_BOUND: p.optResonatorShardBound = value; return SGZ_OK;
+    case SGZ_OPT_PIPELINED: p.optPipelined = value != 0; return SGZ_OK;
     case SGZ_OPT_WIDE_GROUPS: p.optWideGroups = value != 0; return SGZ_OK;
     default: return fail(SGZ_EINVAL, "unknown plan option");
     }

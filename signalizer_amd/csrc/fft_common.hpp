@@ -144,8 +144,15 @@ __device__ __forceinline__ float2 bufLoad2(__amdgpu_buffer_rsrc_t r, int voff, i
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() is fence(all address spaces) + s_barrier: the fence makes
 // every wave wait for its outstanding GLOBAL loads too (s_waitcnt vmcnt(0)) -- the map tables and twiddles that are prefetched
 // across a barrier on purpose.  With the fence restricted to the local address space only LDS traffic is waited for.
+// The explicit s_waitcnt is NOT redundant: the fence makes the compiler wait for the LDS operations IT knows of, and the exchange-1
+// stores (ldsWrite64 / ldsWrite128 below) are inline assembly -- invisible to its counters.  Until round 6 the barrier behind exchange 1's
+// SECOND store round had no wait in front of it (the first one had, by the luck of a compiler-visible table store beside it): a wave
+// could pass the barrier with its ds_write_b128 still in flight and a reader of another wave could be served first.  With one launch
+// on the chip that practically never happened (0 of 20 000 fuzz cases); with several launches in flight it did, in 1-2 of 1 000 launches:
+// one workgroup's transform with a stale value in it -- a faint broadband error in one frame (tools/ka_overlap_stress.py).
 __device__ __forceinline__ void ldsBarrier()
 {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");

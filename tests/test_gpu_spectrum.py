@@ -621,6 +621,7 @@ def test_render_queue_equals_one_render_after_the_other(gpu, depth):
     want = [plan.render(x).cpu().numpy() for x in xs]
     q = api.RenderQueue(cfg, depth)
     outs = [torch.zeros((F, 300, 4), dtype=torch.uint8, device=gpu) for _ in range(n)]
+    torch.cuda.synchronize()                     # the zero fills run on torch's stream: a lane must not write an image before its fill has (sgz.h: after_stream)
     tickets = [q.submit(xs[k], outs[k]) for k in range(n)]
     assert tickets == list(range(1, n + 1))
     q.wait(tickets[0])
@@ -666,6 +667,7 @@ def test_render_queue_at_the_bench_size(gpu):
     xs = [torch.from_numpy(synth.gen(200 + k, 48000, S, 2)).to(gpu) for k in range(3)]
     want = [plan.render(x).cpu().numpy() for x in xs]
     outs = [torch.zeros((348, 1024, 4), dtype=torch.uint8, device=gpu) for _ in range(9)]
+    torch.cuda.synchronize()
     for k in range(9):
         q.submit(xs[k % 3], outs[k])
     q.wait()
@@ -689,9 +691,41 @@ def test_render_queue_on_other_plans(gpu, over):
     want = [plan.render(x).cpu().numpy() for x in xs]
     q = api.RenderQueue(cfg, 3)
     outs = [torch.zeros((F, 257, 4), dtype=torch.uint8, device=gpu) for _ in range(8)]
+    torch.cuda.synchronize()
     for k in range(8):
         q.submit(xs[k % 4], outs[k])
     q.wait()
     for k in range(8):
         assert np.array_equal(outs[k].cpu().numpy(), want[k % 4]), k
     q.close()
+
+
+@pytest.mark.parametrize("size", ["cfg2", "cfg5-like"])
+def test_launches_in_flight_on_several_streams_are_bit_identical(gpu, size):
+    """Round 6's find.  The barrier behind exchange 1's second store round had no s_waitcnt in front of it (the stores are inline
+    assembly: invisible to the compiler's wait counts) -- a wave could pass it with its ds_write_b128 in flight and a reader of another wave
+    be served first.  One launch at a time that practically never happened (no fuzz campaign ever saw it); with launches of several
+    streams sharing the CUs one workgroup in ~1 000 launches transformed a stale value: a faint broadband error in one frame.  Here:
+    K_A (sgz_stage_mapped) of three fixed buffers over four plans / streams, thousands of launches, every output bit for bit the quiet
+    run's (fft_common.hpp ldsBarrier; tools/ka_overlap_stress.py is the same loop with diagnostics)."""
+    import torch
+    if size == "cfg2":
+        cfg, S, rounds = config.cfg2(), 32768 + 8192 * 347, 500
+    else:                                                             # N = 65536 (the walking kernel, ldsWrite64 stores), two pairs
+        cfg, S, rounds = config.cfg5(2), 65536 + 16384 * 99, 150
+    xs = [torch.from_numpy(synth.gen(400 + k, int(cfg["sample_rate"]), S, 2 * cfg["num_pairs"])).to(gpu) for k in range(3)]
+    ref = api.Plan(cfg).upload()
+    want = [ref.stage_mapped(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+    plans = [api.Plan(cfg).upload() for _ in range(4)]
+    bad = 0
+    for r in range(rounds):
+        outs = []
+        torch.cuda.synchronize()
+        for k in range(9):
+            with torch.cuda.stream(streams[k % 4]):
+                outs.append(plans[k % 4].stage_mapped(xs[k % 3]))
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(outs[k].view(torch.int32), want[k % 3].view(torch.int32)) else 1 for k in range(9))
+    assert bad == 0, f"{bad} of {rounds * 9} launches differ from the quiet run"
