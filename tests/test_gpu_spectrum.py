@@ -729,3 +729,50 @@ def test_launches_in_flight_on_several_streams_are_bit_identical(gpu, size):
         torch.cuda.synchronize()
         bad += sum(0 if torch.equal(outs[k].view(torch.int32), want[k % 3].view(torch.int32)) else 1 for k in range(9))
     assert bad == 0, f"{bad} of {rounds * 9} launches differ from the quiet run"
+
+
+_OVERLAP_CASES = {
+    "real-16384-midside": dict(window_size=16384, hop=4096, channel_mode=config.CH_MIDSIDE),
+    "real-mono-merge": dict(channel_mode=config.CH_MERGE),
+    "wide-groups": dict(_wide=1),
+    "whole-frame-complex": dict(channel_mode=config.CH_COMPLEX),
+    "whole-frame-4096-padded": dict(window_size=3000, hop=750),
+    "halves-8192": dict(window_size=8192, hop=2048),
+    "generic-2048": dict(window_size=2048, hop=512),
+    "phase-32768": dict(channel_mode=config.CH_PHASE),
+    "rsnt-matrix": dict(algorithm=config.ALGO_RSNT, window_size=4096, hop=1024),
+    "three-pairs": dict(window_size=4096, hop=1024, num_pairs=3),
+    "fetched-window": dict(window_type=config.WIN_BLACKMAN),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_OVERLAP_CASES))
+def test_every_kernel_family_is_bit_identical_with_launches_in_flight(gpu, case):
+    """the concurrency axis for the other K_A / K_B forms (tools/overlap_stress_cfgs.py is the long version: 15 configurations x 1 800
+    renders, 0 differing): whole renders of three fixed buffers over four plans / streams against the quiet run"""
+    import torch
+    over = dict(_OVERLAP_CASES[case])
+    wide = over.pop("_wide", 0)
+    cfg = config.spectrum_config(**over)
+    frames = 100 if cfg["window_size"] >= 16384 else 160
+    S = cfg["window_size"] + cfg["hop"] * (frames - 1)
+    xs = [torch.from_numpy(synth.gen(500 + k, int(cfg["sample_rate"]), S, 2 * cfg["num_pairs"])).to(gpu) for k in range(3)]
+
+    def make():
+        p = api.Plan(cfg)
+        if wide:
+            p.set_option(api.OPT_WIDE_GROUPS, 1)
+        return p.upload()
+
+    ref = make()
+    want = [ref.render(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    plans = [make() for _ in range(4)]
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+    bad = 0
+    for r in range(25 if cfg["algorithm"] else 80):
+        torch.cuda.synchronize()
+        outs = [plans[k % 4].render(xs[k % 3], stream=streams[k % 4].cuda_stream) for k in range(9)]
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(outs[k], want[k % 3]) else 1 for k in range(9))
+    assert bad == 0, bad
