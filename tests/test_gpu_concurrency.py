@@ -1,0 +1,74 @@
+"""Bit-exactness with OTHER work on the GPU (round 6).  Every parity test of the earlier rounds ran with the device to itself; the
+race round 6 found in K_A (fft_common.hpp ldsBarrier) only showed when the workgroups of several launches shared the CUs.  In a plugin
+the three views run side by side, so the real-time handles' own parity tests are repeated here while two background threads keep the
+device busy with spectrogram renders on their own streams (different kernels on every CU, different timing for every hand-over)."""
+import threading
+
+import numpy as np
+import pytest
+
+from signalizer_amd import api, config, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class BackgroundLoad:
+    """two threads rendering cfg2-sized and small buffers on streams of their own until stopped; checks its own images as well"""
+
+    def __init__(self, gpu):
+        import torch
+        self.torch, self.gpu = torch, gpu
+        self.stop = threading.Event()
+        self.errors, self.renders = [], 0
+        self.threads = [threading.Thread(target=self._run, args=(k,)) for k in range(2)]
+
+    def _run(self, k):
+        torch = self.torch
+        try:
+            torch.cuda.set_device(self.gpu)
+            cfg = config.cfg2() if k == 0 else config.spectrum_config(window_size=4096, hop=1024, channel_mode=config.CH_COMPLEX)
+            S = cfg["window_size"] + cfg["hop"] * (139 if k == 0 else 300)
+            x = torch.from_numpy(synth.gen(700 + k, 48000, S, 2)).to(self.gpu)
+            plan = api.Plan(cfg).upload()
+            stream = torch.cuda.Stream(device=self.gpu)
+            with torch.cuda.stream(stream):
+                want = plan.render(x, stream=stream.cuda_stream).clone()
+                stream.synchronize()
+                while not self.stop.is_set():
+                    outs = [plan.render(x, stream=stream.cuda_stream).clone() for _ in range(8)]
+                    stream.synchronize()
+                    self.renders += 8
+                    if not all(torch.equal(o, want) for o in outs):
+                        self.errors.append(f"background render {k} differs from its first run")
+        except BaseException as e:                       # noqa: BLE001
+            self.errors.append(repr(e))
+
+    def __enter__(self):
+        for t in self.threads:
+            t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        for t in self.threads:
+            t.join(timeout=60)
+        assert not self.errors, self.errors
+        assert self.renders > 0
+
+
+def test_real_time_handles_are_bit_exact_beside_other_work(gpu, oracle):
+    import test_gpu_realtime as rt
+    import test_gpu_scope_stream as sc
+    import test_gpu_vector_stream as vs
+    with BackgroundLoad(gpu) as load:
+        # Oscilloscope: the audio-thread state machine (BASELINE cfg3, many triggers per block, six channels + RMS), frequency colouring
+        for over in (dict(), dict(window_size=480.3, trigger_threshold=0.0), dict(window_size=2048.0, channel_mode=4, num_channels=6, trigger_channel=5.0, envelope_mode=1)):
+            sc.test_stream_state_machine_is_bit_exact(gpu, oracle, over)
+        sc.test_frequency_colouring_is_bit_exact(gpu, oracle, dict(trigger_mode=4, window_size=1500.5, trigger_threshold=0.1))
+        # Vectorscope: ring, envelopes, balance, phase filters, vertices
+        vs.test_vector_stream_against_the_oracle(gpu, oracle, 8, 9600, 1, 1)
+        vs.test_vector_stream_against_the_oracle(gpu, oracle, 4, 777, 2, 0)
+        # Spectrum handle: pushed blocks == the offline render of the frames they complete
+        rt.test_push_pop_matches_offline(gpu, oracle, 480, config.CH_SEPARATE, 4096)
+        rt.test_push_pop_matches_offline(gpu, oracle, 1024, config.CH_SEPARATE, 4096)
+        assert load.renders > 0
