@@ -627,6 +627,12 @@ __global__ __launch_bounds__(kResBlock) void resonatorSegmentFoldKernel(ResParam
         cmulD(br, bi, br, bi);
     }
     const float2 s0 = prm.state[(size_t(pair) * 2 + sg) * V * prm.P + size_t(v) * prm.P + i];
+    // ... and a snapshot of the carried state for the FIRST segment, in the one slot no end state uses (index `ends`).  Until round 6 the
+    // chain kernel's first-segment workgroups read prm.state themselves while its last-segment workgroups write the new state there -- in
+    // the same launch.  On a device of its own every workgroup of that small launch starts at once and the read always came first; with
+    // other processes time-slicing the device (pytest -n 4) a first-segment workgroup could start after a last-segment one had finished and
+    // chain frames 0 .. from the wrong state: the "unreproduced wrong result" of round 5's fuzz campaign (seed 1005, case 12).
+    prm.segEnd[(size_t(ends) * gridDim.y + unit) * prm.P + i] = s0;
     double sr = double(s0.x), si = double(s0.y);
 #pragma unroll
     for (int q = 0; q < kResSegments - 1; ++q) {
@@ -659,7 +665,10 @@ __global__ __launch_bounds__(kResBlock) void resonatorChainWindowKernel(ResParam
             if (s >= S) break;
             const size_t unit = (size_t(pair) * size_t(S) + size_t(s)) * V + v;
             // the state entering this segment: the carried one, or what resonatorSegmentFoldKernel left in the slot of the segment in front
-            const float2 s0 = g == 0 ? prm.state[(size_t(pair) * 2 + s) * V * prm.P + size_t(v) * prm.P + i] : prm.segEnd[(size_t(g - 1) * units + unit) * prm.P + i];
+            // (one segment: this workgroup reads the carried state and is the only one that writes it, behind its last frame.  Several:
+            // the first segment takes the fold kernel's snapshot -- the last segment's workgroups overwrite prm.state in this same launch)
+            const float2 s0 = gridDim.z == 1 ? prm.state[(size_t(pair) * 2 + s) * V * prm.P + size_t(v) * prm.P + i]
+                                             : prm.segEnd[(size_t(g == 0 ? gridDim.z - 1 : g - 1) * units + unit) * prm.P + i];
             sre[s][v] = s0.x; sim[s][v] = s0.y;
         }
     }

@@ -72,3 +72,66 @@ def test_real_time_handles_are_bit_exact_beside_other_work(gpu, oracle):
         rt.test_push_pop_matches_offline(gpu, oracle, 480, config.CH_SEPARATE, 4096)
         rt.test_push_pop_matches_offline(gpu, oracle, 1024, config.CH_SEPARATE, 4096)
         assert load.renders > 0
+
+
+_LOAD_SCRIPT = """
+import sys, time
+sys.path.insert(0, {root!r})
+import torch
+from signalizer_amd import api, config, synth
+cfg = config.cfg2(); cfg["num_pairs"] = 4
+S = 32768 + 8192 * 347
+x = torch.from_numpy(synth.gen(9, 48000, S, 8)).cuda()
+plan = api.Plan(cfg).upload()
+out = plan.render(x)
+print("READY", flush=True)
+t0 = time.time()
+while time.time() - t0 < {seconds}:
+    for _ in range(32):
+        plan.render(x, rgba=out)
+    torch.cuda.synchronize()
+"""
+
+
+def test_rsnt_is_deterministic_while_other_processes_share_the_gpu(gpu):
+    """Round 5's one unreproduced fuzz failure (RSNT, seed 1005, case 12), reproduced and fixed in round 6: the segmented chain kernel's
+    first-segment workgroups read the carried state from the buffer its last-segment workgroups overwrite IN THE SAME LAUNCH.  With the
+    device to itself the read always came first; with other PROCESSES time-slicing the device (the suite under pytest -n 4) it lost in
+    half the renders.  Here: three other processes render flat out while case 1005 / 12 and a matrix-core case are rendered 120 times
+    each; every output equals the quiet run's (resonator.hip resonatorSegmentFoldKernel now snapshots the carried state)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    import fuzzcfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = []
+    for seed, index in ((1005, 12), (2008, 52)):
+        d, F, x = fuzzcfg.rsnt_case(seed, index)
+        xs = torch.from_numpy(x).to(gpu)
+        plan = api.Plan(d).upload()
+        m0 = plan.stage_mapped(xs).clone()
+        r0 = plan.render(xs).clone()
+        torch.cuda.synchronize()
+        cases.append((d, xs, plan, m0, r0))
+    procs = [subprocess.Popen([sys.executable, "-c", _LOAD_SCRIPT.format(root=root, seconds=14)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(3)]
+    try:
+        for p in procs:
+            assert p.stdout.readline().strip() == "READY"            # (the first import of torch in a fresh process can take a while)
+        bad = 0
+        for it in range(120):
+            for d, xs, plan, m0, r0 in cases:
+                p = plan if it % 4 else api.Plan(d).upload()              # every fourth run on a fresh plan
+                m = p.stage_mapped(xs)
+                r = p.render(xs)
+                torch.cuda.synchronize()
+                bad += (not torch.equal(m.view(torch.int32), m0.view(torch.int32))) + (not torch.equal(r, r0))
+        assert all(p.poll() is None for p in procs), "the load processes ended before the renders did: nothing was shared"
+        assert bad == 0, f"{bad} outputs differ from the quiet run"
+    finally:
+        for p in procs:
+            p.kill()
+            p.wait()
