@@ -28,3 +28,17 @@ def test_hot_kernels_do_not_spill():
     for r in hot:
         if "stftRealKernel<5" in r["demangled"] or "stftMapKernel<5" in r["demangled"]:
             assert r["vgpr_count"] <= 128, r
+
+
+def test_no_lds_store_in_flight_at_a_barrier():
+    """Round 6's K_A race as a listing check (tools/barrier_audit.py): inline-asm LDS stores are invisible to the compiler's wait-count
+    insertion, so a barrier behind them needs its own s_waitcnt lgkmcnt(0) -- fft_common.hpp ldsBarrier().  The library before that fix
+    has 37 such barriers, all in stftRealKernel; no test on an idle device saw them in 20 000 fuzz cases."""
+    import barrier_audit
+    import codeobj_report as cr
+    lib = os.path.join(ROOT, "signalizer_amd", "libsgz.so")
+    if not (os.path.exists(lib) and os.path.exists(f"{cr.LLVM}/llvm-objdump") and os.path.exists(f"{cr.LLVM}/llvm-objcopy")):
+        pytest.skip("library or llvm tools not present")
+    bad, totals = barrier_audit.audit(lib)
+    assert totals["kernels"] >= 80 and totals["barriers"] >= 500, totals             # (the walk found the kernels at all)
+    assert not bad, bad[:5]
