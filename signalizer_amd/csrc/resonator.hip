@@ -752,8 +752,8 @@ hipError_t launchV(const ResParams &prm0, hipStream_t stream)
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     if (matrix && prm.segEnd) {
-        // (the carried state is read by every segment's fold and written by the last segment: the kernel's own two phases are ordered
-        //  by the launch order of the two kernels -- the first never touches it)
+        // (the carried state is read by the fold kernel only -- which leaves the first segment a snapshot of it -- and written by the
+        //  chain kernel's last segment: the read and the write are in different launches of one stream)
         const long segs = std::max<long>(1, std::min<long>(kResSegments, prm.frames / 8));
         prm.segLen = (prm.frames + segs - 1) / segs;
         const unsigned G = unsigned((prm.frames + prm.segLen - 1) / prm.segLen);
