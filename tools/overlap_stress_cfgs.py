@@ -1,6 +1,8 @@
 """Bit-identity under concurrency for every kernel family: whole renders (K_A + K_B) of three fixed buffers over four plans / streams,
-against the quiet run, for a list of configurations that together reach every K_A / K_B form.   usage: overlap_stress_cfgs.py [rounds]"""
-import os, sys
+against the quiet run, for a list of configurations that together reach every K_A / K_B form.
+usage: [LOAD=n] overlap_stress_cfgs.py [rounds]        LOAD=n: n other PROCESSES render beside it as well (tools/gpu_load.py; the quiet
+references of every case are taken before they start) -- the regime in which the RSNT carried-state race of round 6 showed"""
+import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from signalizer_amd import api, config as cf, synth
@@ -22,33 +24,59 @@ CASES = {
     "rsnt hop 1000 (vector form)": dict(algorithm=cf.ALGO_RSNT, window_size=4096, hop=1000),
     "three pairs N=4096 (scan/emit K_B)": dict(window_size=4096, hop=1024, num_pairs=3),
     "fetch window blackman N=32768": dict(window_type=cf.WIN_BLACKMAN),
+    "rsnt segmented chain (fuzz 1005 / 12)": dict(_fuzz=(1005, 12)),
+    "rsnt matrix worst case (fuzz 2008 / 52)": dict(_fuzz=(2008, 52)),
 }
-total_bad = 0
+load = int(os.environ.get("LOAD", "0"))
+prepared = []
 for name, over in CASES.items():
     over = dict(over)
     wide = over.pop("_wide", 0)
-    cfg = cf.spectrum_config(**over)
-    frames = 120 if cfg["window_size"] >= 16384 else 200
-    S = cfg["window_size"] + cfg["hop"] * (frames - 1)
-    xs = [torch.from_numpy(synth.gen(500 + k, int(cfg["sample_rate"]), S, 2 * cfg["num_pairs"])).to(gpu) for k in range(3)]
-    def mk():
+    fuzz = over.pop("_fuzz", None)
+    if fuzz:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import fuzzcfg
+        cfg, _, x = fuzzcfg.rsnt_case(*fuzz)
+        xs = [torch.from_numpy(x).to(gpu)] * 3
+    else:
+        cfg = cf.spectrum_config(**over)
+        frames = 120 if cfg["window_size"] >= 16384 else 200
+        S = cfg["window_size"] + cfg["hop"] * (frames - 1)
+        xs = [torch.from_numpy(synth.gen(500 + k, int(cfg["sample_rate"]), S, 2 * cfg["num_pairs"])).to(gpu) for k in range(3)]
+    def mk(cfg=cfg, wide=wide):
         p = api.Plan(cfg)
         if wide: p.set_option(api.OPT_WIDE_GROUPS, 1)
         return p.upload()
     ref = mk()
     want = [ref.render(x).clone() for x in xs]
     torch.cuda.synchronize()
-    plans = [mk() for _ in range(4)]
-    streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
-    bad = 0
-    n = rounds if cfg["algorithm"] == 0 else max(20, rounds // 4)
-    for r in range(n):
-        outs = []
-        torch.cuda.synchronize()
-        for k in range(9):
-            outs.append(plans[k % 4].render(xs[k % 3], stream=streams[k % 4].cuda_stream))
-        torch.cuda.synchronize()
-        bad += sum(0 if torch.equal(outs[k], want[k % 3]) else 1 for k in range(9))
-    total_bad += bad
-    print(f"{name:40s}: {bad} of {n * 9} renders differ (path {ref.path})", flush=True)
+    prepared.append((name, cfg, xs, mk, ref.path, want))
+procs = []
+if load:
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "gpu_load.py"), "1200", "rsnt" if k % 2 else "spectrum"], stdout=subprocess.PIPE, text=True) for k in range(load)]
+    for p in procs:
+        assert p.stdout.readline().strip() == "READY"
+    print(f"{load} load processes render beside every case", flush=True)
+total_bad = 0
+try:
+    for name, cfg, xs, mk, path, want in prepared:
+        plans = [mk() for _ in range(4)]
+        streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+        bad = 0
+        n = rounds if cfg["algorithm"] == 0 else max(20, rounds // 4)
+        for r in range(n):
+            outs = []
+            torch.cuda.synchronize()
+            for k in range(9):
+                outs.append(plans[k % 4].render(xs[k % 3], stream=streams[k % 4].cuda_stream))
+            torch.cuda.synchronize()
+            bad += sum(0 if torch.equal(outs[k], want[k % 3]) else 1 for k in range(9))
+        total_bad += bad
+        print(f"{name:40s}: {bad} of {n * 9} renders differ (path {path})", flush=True)
+    assert all(p.poll() is None for p in procs), "a load process ended early"
+finally:
+    for p in procs:
+        p.kill()
+        p.wait()
 print("total differing:", total_bad)
