@@ -119,8 +119,10 @@ def test_rsnt_is_deterministic_while_other_processes_share_the_gpu(gpu):
     procs = [subprocess.Popen([sys.executable, "-c", _LOAD_SCRIPT.format(root=root, seconds=14)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for _ in range(3)]
     try:
-        for p in procs:
-            assert p.stdout.readline().strip() == "READY"            # (the first import of torch in a fresh process can take a while)
+        import select
+        for p in procs:                                               # (the first import of torch in a fresh process can take a while)
+            assert select.select([p.stdout], [], [], 300.0)[0], "a load process did not start rendering within 300 s"
+            assert p.stdout.readline().strip() == "READY"
         bad = 0
         for it in range(120):
             for d, xs, plan, m0, r0 in cases:
