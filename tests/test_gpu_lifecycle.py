@@ -89,7 +89,9 @@ def test_create_use_destroy_gives_the_memory_back(gpu, kind):
         cycle(x)
     gc.collect()
     free1, rss1 = _free_device_bytes(), _rss()
-    assert free0 - free1 < 64 << 20, f"device memory: {(free0 - free1) / 2**20:.1f} MiB fewer free after 60 cycles"
+    import os
+    if "PYTEST_XDIST_WORKER" not in os.environ:                   # (the figure is the DEVICE's: under pytest -n the other workers' allocations move it)
+        assert free0 - free1 < 64 << 20, f"device memory: {(free0 - free1) / 2**20:.1f} MiB fewer free after 60 cycles"
     assert rss1 - rss0 < 96 << 20, f"host memory: resident set grew by {(rss1 - rss0) / 2**20:.1f} MiB over 60 cycles"
 
 
