@@ -515,39 +515,52 @@ def cfg5_extra(dev) -> dict:
 
 def rsnt_extra(dev, x_host) -> dict:
     """the Spectrum view's other transform algorithm (RSNT, the resonator bank: resonator.hip) on the same 60 s buffer: one render =
-    351 frames (one per hop), 2 signals x 3 vectors x 1024 resonators advanced by every sample"""
+    351 frames (one per hop), 2 signals x 3 vectors x 1024 resonators advanced by every sample.  `value`: the default form (block sums on
+    the fp32 matrix cores); `bf16_form`: the opt-in three-part bf16 kernel (sgz.h SGZ_OPT_MATRIX_RESONATOR = 1: twice as fast, and on these
+    boxes its instruction stream disturbs FFT kernels that run beside it -- NOTES.md round 6)"""
     import torch
     from signalizer_amd import api, config
     cfg = config.spectrum_config(algorithm=config.ALGO_RSNT)
     xs = torch.from_numpy(x_host[:2]).to(dev)
-    plan = api.Plan(cfg).upload()
-    F = plan.num_frames(xs.shape[1])
-    rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
-    V = plan.resonator()[0].shape[0]
-    plan.render(xs, rgba=rgba)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(10):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); plan.render(xs, rgba=rgba); b.record(); torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    ms = float(np.median(ts))
-    flops = 8.0 * F * cfg["hop"] * 2 * V * plan.P
-    # what resonateMfmaBf16Kernel EXECUTES on the matrix cores: per frame (all from rest), (signal, vector, 32 resonators) wave and
-    # 1024-sample tile 24 v_mfma_f32_32x32x16_bf16 (six bf16 x bf16 part products x two K halves, for the real and for the imaginary
-    # weights) of 32 * 32 * 16 multiply-adds each
-    mfma = F * 2 * V * (plan.P // 32) * (cfg["hop"] // 1024) * 24
-    mfma_flops = mfma * 32 * 32 * 16 * 2
-    BF16_MFMA_PEAK = 2500.0
+
+    def timed(form):
+        plan = api.Plan(cfg)
+        if form is not None:
+            plan.set_option(api.OPT_MATRIX_RESONATOR, form)
+        plan.upload()
+        F = plan.num_frames(xs.shape[1])
+        rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)
+        V = plan.resonator()[0].shape[0]
+        plan.render(xs, rgba=rgba)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); plan.render(xs, rgba=rgba); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts)), F, V, plan.P
+    ms, F, V, P = timed(None)
+    ms_bf16 = timed(1)[0]
+    flops = 8.0 * F * cfg["hop"] * 2 * V * P
+    # what the matrix kernels EXECUTE: per frame (all from rest), (signal, vector, 32 resonators) wave and 1024-sample tile
+    #   fp32 form: 32 v_mfma_f32_32x32x2_f32 (sixteen for the real, sixteen for the imaginary weights) of 32 * 32 * 2 multiply-adds
+    #   bf16 form: 24 v_mfma_f32_32x32x16_bf16 (six bf16 x bf16 part products x two K halves, real and imaginary) of 32 * 32 * 16
+    tiles = F * 2 * V * (P // 32) * (cfg["hop"] // 1024)
+    f32_flops, bf16_flops = tiles * 32 * 32 * 32 * 2 * 2, tiles * 24 * 32 * 32 * 16 * 2
+    F32_MFMA_PEAK, BF16_MFMA_PEAK = 157.3, 2500.0
     return {"metric": "RSNT (resonator bank) spectrogram frames/sec, stereo 48 kHz, 1024 axis points, Hann (3 vectors), one frame per 8192 samples",
             "value": F / ms * 1e3, "unit": "frames/s", "ms_per_step": ms, "frames": F, "realtime_factor": 60.0 / (ms * 1e-3),
-            "kernel": "resonateMfmaBf16Kernel (block sums on the bf16 matrix cores, every fp32 value as three exact bf16 parts) + "
+            "kernel": "resonateMfmaKernel (block sums on the fp32 matrix cores: exact fp32 multiply-add chains) + "
                       "resonatorSegmentKernel / SegmentFoldKernel / ChainWindowKernel<3> + K_B",
-            "mfma_instructions": mfma, "mfma_tflops": mfma_flops / (ms * 1e-3) / 1e12, "mfma_frac_of_peak": mfma_flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK,
+            "mfma_instructions": tiles * 32, "mfma_tflops": f32_flops / (ms * 1e-3) / 1e12, "mfma_frac_of_peak": f32_flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK,
             "recurrence_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
-            "note": "compute-bound.  mfma_tflops = bf16 multiply-adds the matrix kernel executes (x 2) over the WHOLE render's time (chain, window "
-                    "and K_B kernels included) against the 2500 TFLOP/s dense bf16 MFMA peak -- six bf16 products stand for one fp32 product, so "
-                    "the fp32-equivalent rate is a sixth of it; profiles/r04c/rsnt_* hold the kernel's own duration and the MFMA counters.  "
+            "bf16_form": {"ms_per_step": ms_bf16, "value": F / ms_bf16 * 1e3, "mfma_instructions": tiles * 24,
+                          "mfma_tflops": bf16_flops / (ms_bf16 * 1e-3) / 1e12, "mfma_frac_of_peak": bf16_flops / (ms_bf16 * 1e-3) / 1e12 / BF16_MFMA_PEAK,
+                          "note": "SGZ_OPT_MATRIX_RESONATOR = 1 (resonateMfmaBf16Kernel: every fp32 value as three exact bf16 parts, six part products); "
+                                  "opt-in since round 6"},
+            "note": "compute-bound.  mfma_tflops = multiply-adds the matrix kernel executes (x 2) over the WHOLE render's time (chain, window and K_B "
+                    "kernels included) against the dense matrix peak of its type (fp32 157 TFLOP/s, bf16 2500 TFLOP/s; six bf16 products stand for one "
+                    "fp32 product); profiles/r04a / r04c rsnt_* hold the kernels' own durations and the MFMA counters.  "
                     "recurrence_equivalent_tflops prices the sample-by-sample recurrence the reference runs (8 flops per sample, resonator, "
                     "vector and signal) at the same time: a statement about the algorithm, not about the pipe"}
 

@@ -178,10 +178,15 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
 #define SGZ_OPT_FETCH_WINDOW  3u
 #define SGZ_OPT_MATRIX_RESONATOR 4u /* RSNT launches of several frames at a hop that is a multiple of 1024: every frame starts from rest as block
                                       sums on the matrix cores and the frames are chained afterwards (a one-frame launch -- the real-time case --
-                                      is always the reference's recurrence sample by sample).  1 (default): the bf16 matrix cores, every fp32
-                                      sample and weight as the exact sum of three bf16 parts, six part products (fp32-equivalent accuracy:
-                                      resonator.hip resonateMfmaBf16Kernel); 2: the fp32 matrix cores (resonateMfmaKernel); 0: the vector-ALU
-                                      block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
+                                      is always the reference's recurrence sample by sample).  2 (default): the fp32 matrix cores
+                                      (resonateMfmaKernel, exact fp32 multiply-add chains); 1: the bf16 matrix cores, every fp32 sample and
+                                      weight as the exact sum of three bf16 parts, six part products (fp32-equivalent accuracy, twice as fast:
+                                      resonator.hip resonateMfmaBf16Kernel) -- OPT-IN since round 6: on the MI355X boxes this was measured on, FFT
+                                      kernels that run on the device at the same time (another stream, another process; this library's and
+                                      rocFFT's alike) come back with a wrong cache line's worth of values in 2 of 100 000 launches while this
+                                      kernel runs, and in every second launch with other instruction orders of the same kernel: choose it when
+                                      nothing else shares the device (NOTES.md, "A matrix-core kernel that disturbs its neighbours"); 0: the
+                                      vector-ALU block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
                                       slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one
                                       before it left.  It plays no part in the sharded render (SGZ_OPT_RESONATOR_SHARD_BOUND) */

@@ -172,7 +172,7 @@ struct ResParams {
     const float2 *cpowBLo;            // [V][P][2]: low words of pole^4, pole^8
     const float2 *w1, *w2;            // [32][V][P]: the matrix kernels' weights (null: not available for this hop, or switched off)
     const uint4 *w1b;                 // [2 kh][2 h][3 parts][re, im][V][P]: w1 as bf16 parts, eight consecutive samples' weights per entry (B operands)
-    int matrixForm;                   // 1: bfloat16 matrix cores, every fp32 value as three exact bf16 parts (default); 2: fp32 matrix cores
+    int matrixForm;                   // 1: bfloat16 matrix cores, every fp32 value as three exact bf16 parts (opt-in); 2: fp32 matrix cores (default)
     const float4 *tilePow;            // [V][P]: pole^1024 (hi, lo)
     const float *gain;                // [P]
     float weights[9];                 // [V]

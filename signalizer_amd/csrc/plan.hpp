@@ -125,7 +125,8 @@ struct Plan {
     bool optChannelSplit = true, optFusedColour = true, optFetchWindow = false, optWideGroups = false;
     bool optPipelined = false;          // the plan is a lane of an sgz_render_queue of depth >= 2 (RealParams::pipelined)
     uint32_t optFusedPixels = 4;        // pixels per workgroup of the fused colour K_B (4, 8, 16): SGZ_OPT_FUSED_COLOUR = 1 / 8 / 16
-    int optMatrixResonator = 1;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split), 2: fp32 matrix cores
+    int optMatrixResonator = 2;        // 0: vector ALUs, 1: bf16 matrix cores (three-part split; opt-in: on MI355X its instruction stream disturbs FFT
+                                       //    kernels running beside it -- rocFFT's too --, NOTES.md round 6), 2: fp32 matrix cores (default since round 6)
     uint32_t optResonatorSlab = 0;      // RSNT: frames per slab of a long render (0: as many as fit 256 MiB of per-frame states)
     uint32_t optResonatorShardBound = 0; // RSNT, sharded render: most frames a rank's chunk may hold (0: 8 GiB worth of per-frame states)
 

@@ -188,6 +188,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SGZ_RES_UPW 4
 #endif
 constexpr unsigned kResUnitsPerWg = SGZ_RES_UPW;                     // units (frame, pair, signal) a workgroup of the bf16 form walks in a row
+#if defined(SGZ_RES_EXP_GAP)                                         // (platform experiment: idle issue slots behind every matrix instruction)
+#define SGZ_RES_SCHED_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" ::"n"(SGZ_RES_EXP_GAP)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif !defined(SGZ_RES_NO_SCHED)                                    // (timing / platform experiments: let the compiler order the tile loop)
+#define SGZ_RES_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SGZ_RES_SCHED_BARRIER() do { } while (0)
+#endif
 #ifndef SGZ_RES_BF16_OCC
 #define SGZ_RES_BF16_OCC 3                                          // waves per SIMD the bf16 form is compiled for (168 registers)
 #endif
@@ -305,7 +312,18 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
 {
     constexpr int TH = 64 * WAVES, PER = 1024 / TH;                  // threads, samples a thread stages per tile
     constexpr int ROW = 40;                                          // uint16 per padded row of 32 samples (80 bytes)
-    __shared__ __attribute__((aligned(16))) uint16_t xs[2][3][32 * ROW];
+#ifdef SGZ_RES_EXP_DWORD_STORES                                      // (platform experiment, results meaningless: the parts stored as whole dwords)
+    using XsWord = uint32_t;
+#else
+    using XsWord = uint16_t;
+#endif
+    __shared__ __attribute__((aligned(16))) XsWord xs[2][3][32 * ROW];
+#ifdef SGZ_RES_EXP_JITTER                                            // (platform experiment: the workgroups' tile loops out of phase with one another)
+    for (uint32_t d = (blockIdx.x * 5u + blockIdx.y * 11u) & 15u; d > 0; --d) asm volatile("s_nop 7");
+#endif
+#ifdef SGZ_RES_PAD_VGPR                                              // (platform experiments: a register count that allows two waves per SIMD only)
+    asm volatile("v_mov_b32 v191, 0" ::: "v191");
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const uint32_t groups = (prm.P + 31) / 32;
     const uint32_t g = blockIdx.x * WAVES + wave;
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
         const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
         const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
         const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
-        xs[0][0][o] = uint16_t(__float_as_uint(x) >> 16); xs[0][1][o] = uint16_t(__float_as_uint(r1) >> 16); xs[0][2][o] = uint16_t(__float_as_uint(r2) >> 16);
+        xs[0][0][o] = XsWord(__float_as_uint(x) >> 16); xs[0][1][o] = XsWord(__float_as_uint(r1) >> 16); xs[0][2][o] = XsWord(__float_as_uint(r2) >> 16);
     }
     advance();
     clHeld = clNext; crHeld = crNext;
@@ -416,9 +434,13 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
                 if (unitEnded) finish(uMul - 1);
             }
             asm volatile("" : "+v"(pr), "+v"(pi), "+v"(sre), "+v"(sim));          // (pins this step's vector work between its neighbours' ...
+#ifndef SGZ_RES_EXP_NO_MFMA
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TP[m >> 1]][m & 1], Wr[TQ[m >> 1] * 2 + (m & 1)], acc, 0, 0, 0);
+#else                                                                             // (platform experiment, results meaningless: no matrix instructions)
+            acc[m] += float(A[TP[m >> 1]][m & 1][0]) * float(Wr[TQ[m >> 1] * 2 + (m & 1)][0]);
+#endif
             asm volatile("" : "+v"(acc));                                         //  ... and the product behind it: both are pure values otherwise)
-            __builtin_amdgcn_sched_barrier(0);
+            SGZ_RES_SCHED_BARRIER();
         }
         dre = acc;
         // ---- phase B: the imaginary block sums of tile T  |  tile T + 1 parked, tile T + 2 requested, the real block sums folded
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
                 const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
                 const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
                 const uint32_t o = slot + uint32_t(k) * (TH / 32) * ROW;
-                xs[buf ^ 1][0][o] = uint16_t(__float_as_uint(x) >> 16); xs[buf ^ 1][1][o] = uint16_t(__float_as_uint(r1) >> 16); xs[buf ^ 1][2][o] = uint16_t(__float_as_uint(r2) >> 16);
+                xs[buf ^ 1][0][o] = XsWord(__float_as_uint(x) >> 16); xs[buf ^ 1][1][o] = XsWord(__float_as_uint(r1) >> 16); xs[buf ^ 1][2][o] = XsWord(__float_as_uint(r2) >> 16);
                 nl[k] = pl[tid + TH * k]; if constexpr (!SINGLE) nr[k] = pr2[tid + TH * k];
             } else {
 #pragma unroll
@@ -442,9 +464,13 @@ __global__ __launch_bounds__(64 * WAVES, SGZ_RES_BF16_OCC) void resonateMfmaBf16
                 }
             }
             asm volatile("" : "+v"(pr), "+v"(pi));
+#ifndef SGZ_RES_EXP_NO_MFMA
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[TP[m >> 1]][m & 1], Wi[TQ[m >> 1] * 2 + (m & 1)], acc2, 0, 0, 0);
+#else
+            acc2[m] += float(A[TP[m >> 1]][m & 1][1]) * float(Wi[TQ[m >> 1] * 2 + (m & 1)][1]);
+#endif
             asm volatile("" : "+v"(acc2));
-            __builtin_amdgcn_sched_barrier(0);
+            SGZ_RES_SCHED_BARRIER();
         }
         dim = acc2;
         clHeld = clNext; crHeld = crNext;

@@ -27,7 +27,9 @@ def main():
         if "--valu" in sys.argv:
             plan.set_option(api.OPT_MATRIX_RESONATOR, 0)
         if "--fp32-matrix" in sys.argv:
-            plan.set_option(api.OPT_MATRIX_RESONATOR, 2)
+            plan.set_option(api.OPT_MATRIX_RESONATOR, 2)           # (the default since round 6)
+        if "--bf16" in sys.argv:
+            plan.set_option(api.OPT_MATRIX_RESONATOR, 1)           # the opt-in three-part bf16 kernel
         plan.upload()
         F = plan.num_frames(x.shape[1])
         rgba = torch.empty((F, plan.P, 4), dtype=torch.uint8, device=dev)

@@ -28,6 +28,10 @@ CASES = {
     "rsnt matrix worst case (fuzz 2008 / 52)": dict(_fuzz=(2008, 52)),
 }
 load = int(os.environ.get("LOAD", "0"))
+NS = int(os.environ.get("STREAMS", "4"))                    # plans / streams the launches rotate over (1: one launch at a time)
+STAGE = os.environ.get("STAGE", "render")                  # STAGE=mapped: K_A alone (sgz_stage_mapped), compared as bit patterns
+if os.environ.get("CASES"):                                # CASES=substring,substring: only those
+    CASES = {k: v for k, v in CASES.items() if any(w in k for w in os.environ["CASES"].split(","))}
 prepared = []
 for name, over in CASES.items():
     over = dict(over)
@@ -48,7 +52,7 @@ for name, over in CASES.items():
         if wide: p.set_option(api.OPT_WIDE_GROUPS, 1)
         return p.upload()
     ref = mk()
-    want = [ref.render(x).clone() for x in xs]
+    want = [(ref.render(x) if STAGE == "render" else ref.stage_mapped(x).view(torch.int32)).clone() for x in xs]
     torch.cuda.synchronize()
     prepared.append((name, cfg, xs, mk, ref.path, want))
 procs = []
@@ -61,17 +65,36 @@ if load:
 total_bad = 0
 try:
     for name, cfg, xs, mk, path, want in prepared:
-        plans = [mk() for _ in range(4)]
-        streams = [torch.cuda.Stream(device=gpu) for _ in range(4)]
+        plans = [mk() for _ in range(NS)]
+        streams = [torch.cuda.Stream(device=gpu) for _ in range(NS)]
         bad = 0
         n = rounds if cfg["algorithm"] == 0 else max(20, rounds // 4)
         for r in range(n):
             outs = []
             torch.cuda.synchronize()
             for k in range(9):
-                outs.append(plans[k % 4].render(xs[k % 3], stream=streams[k % 4].cuda_stream))
+                if STAGE == "render":
+                    outs.append(plans[k % NS].render(xs[k % 3], stream=streams[k % NS].cuda_stream))
+                else:
+                    with torch.cuda.stream(streams[k % NS]):
+                        outs.append(plans[k % NS].stage_mapped(xs[k % 3]).view(torch.int32))
             torch.cuda.synchronize()
-            bad += sum(0 if torch.equal(outs[k], want[k % 3]) else 1 for k in range(9))
+            for k in range(9):
+                if not torch.equal(outs[k], want[k % 3]):
+                    bad += 1
+                    if STAGE != "render":
+                        g, w = outs[k].view(torch.float32), want[k % 3].view(torch.float32)
+                        idx = torch.nonzero(outs[k] != want[k % 3]).cpu().numpy()           # [n][frame, pair, side, pixel]
+                        rel = ((g - w).abs() / w.abs().clamp_min(1e-30))[outs[k] != want[k % 3]].cpu().numpy()
+                        units = sorted({(int(a), int(b), int(c)) for a, b, c, _ in idx})
+                        print(f"    round {r} launch {k} (plan {k % NS}, input {k % 3}): {len(idx)} magnitudes differ in (frame, pair, side) {units[:6]}{' ...' if len(units) > 6 else ''}, "
+                              f"pixels {idx[:, 3].min()}..{idx[:, 3].max()}, relative difference median {np.median(rel):.2e} max {rel.max():.2e}", flush=True)
+                        continue
+                    d = (outs[k].to(torch.int16) - want[k % 3].to(torch.int16)).abs().amax(dim=2).cpu().numpy()      # [frame][pixel]
+                    fr = np.nonzero(d.max(axis=1))[0]
+                    px = np.nonzero(d.max(axis=0))[0]
+                    print(f"    round {r} render {k} (plan {k % NS}, input {k % 3}): frames {fr.min()}..{fr.max()} ({len(fr)}), pixels {px.min()}..{px.max()} ({len(px)}), "
+                          f"largest byte difference {d.max()}; first frame's differing pixels {np.nonzero(d[fr.min()])[0][:12].tolist()}", flush=True)
         total_bad += bad
         print(f"{name:40s}: {bad} of {n * 9} renders differ (path {path})", flush=True)
     assert all(p.poll() is None for p in procs), "a load process ended early"
