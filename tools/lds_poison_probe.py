@@ -10,6 +10,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 from signalizer_amd import api, config as cf, synth
 here = os.path.dirname(os.path.abspath(__file__))
+for lib, src in (("liblds_poison.so", "lds_poison.hip"), ("libvgpr_poison.so", "vgpr_poison.hip")):      # (two tiny kernels: built on first use)
+    if not os.path.exists(os.path.join(here, "ab", lib)):
+        import subprocess
+        os.makedirs(os.path.join(here, "ab"), exist_ok=True)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(here, "ubench", src), "-o", os.path.join(here, "ab", lib)], check=True)
 P = C.CDLL(os.path.join(here, "ab", "liblds_poison.so"))
 P.lds_poison.argtypes = [C.c_uint32, C.c_void_p]
 gpu = torch.device("cuda", 0)
@@ -109,6 +114,6 @@ for name, over in CASES.items():
             for k in range(5):
                 bad[k] += 0 if torch.equal(got[k], want[k]) else 1
     total += sum(bad)
-    print(f"{name:38s}: differing after an LDS fill -- mapped {bad[0]}, image+lines+state render: image {bad[1]} lines {bad[2]} state {bad[3]}, image-only render {bad[4]}   (of {4 * rounds} each)", flush=True)
-print("dependences on the LDS's earlier contents:", total)
+    print(f"{name:38s}: differing after an LDS / register fill -- mapped {bad[0]}, image+lines+state render: image {bad[1]} lines {bad[2]} state {bad[3]}, image-only render {bad[4]}   (of {4 * rounds} each)", flush=True)
+print("dependences on the earlier contents of the LDS or the registers:", total)
 sys.exit(1 if total else 0)
