@@ -102,7 +102,30 @@ struct ChunkMap {
         else if (!(c.y & kChunkNoScan)) {
             best = re[c.x & 0xFFFFu];
             const int c0 = int(c.x >> 16), nC = int(c.y & 0xFFFFu);
+#ifndef SGZ_RESOLVE_CHAIN
+            // the run's tile maxima four at a time as independent requests (a pixel of the log view's top covers 4-8 tiles, and as a
+            // dependent chain -- read, wait, max, read -- this was the longest thing behind the map's barrier: the last wave of a
+            // workgroup left 1.5 k clocks after the first).  max is exact: any order gives the same value.  (Eight at a time spills a
+            // register of the N = 65536 kernel.)
+            // The first four go out together with the run's own partial maximum (re) -- an index past the run repeats its last tile, a run
+            // without whole tiles (nC = 0) takes re in their place.
+            {
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = ce[c0 + min(i, max(nC - 1, 0))];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = nC > 0 ? e[i] : best;
+                best = __builtin_fmaxf(__builtin_fmaxf(best, e[0]), __builtin_fmaxf(__builtin_fmaxf(e[1], e[2]), e[3]));
+            }
+            for (int i0 = 4; i0 < nC; i0 += 4) {
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = ce[c0 + min(i0 + i, nC - 1)];
+                best = __builtin_fmaxf(__builtin_fmaxf(best, e[0]), __builtin_fmaxf(__builtin_fmaxf(e[1], e[2]), e[3]));
+            }
+#else
             for (int i = 0; i < nC; ++i) best = __builtin_fmaxf(best, ce[c0 + i]);
+#endif
         }
         if (c.y & kChunkPlusM) best = __builtin_fmaxf(best, __builtin_fabsf(lds[at(tb.right ? at.size() : at.size() / 2)]));
         float val = best, bestSq = best * best + 0.f;                    // Math::square(csf[offset]) of the winner (imag == 0)
