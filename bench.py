@@ -571,6 +571,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="single device: replay ONE hipGraph of the K timed steps instead of enqueuing them one by one "
+                                                          "(immune to a descheduled host thread; ~0.7 us per step slower at K = 20, equal at K = 200)")
     ap.add_argument("--spinup-ms", type=float, default=150.0, help="untimed back-to-back steps before the warm-up steps, so that the device runs at "
                                                                    "its sustained clock when the timed region starts (0: none)")
     ap.add_argument("--rotate-mb", type=float, default=288.0, help="consecutive steps read distinct copies of the audio, this many MB of them in "
@@ -681,6 +683,32 @@ def main() -> None:
     # of the W warm-up steps), and the line says for how long.
     # (the number of steps is the same on every rank -- a step of a sharded render holds collectives: 32 steps are timed, the slowest
     # rank's time decides)
+    # --graph: the K timed steps as ONE hipGraph launch (single device) -- the same launches in the same order on the same rotating inputs,
+    # captured once from the library's own calls on the capturing stream and replayed: the timed region then holds one launch call and one
+    # wait, so a host thread that is descheduled for a few milliseconds between two enqueues (seen once in this round's ~15 runs of the
+    # default line: 74.8 us per step in the main region, 32-35 us in every other region of the same process) cannot sit inside it.
+    # Measured (profiles/r06g): equal at K = 200 (31.8 | 31.6 us per step), 0.6-0.9 us per step slower at K = 20 (the graph's own launch),
+    # which is why it is an option and not the default.  `ms_per_step_enqueued` is the one-by-one figure beside it.
+    graph, graph_note = None, "steps enqueued one by one"
+    if world == 1 and shard is timer and not strong and args.graph:
+        try:
+            warm = torch.cuda.Stream(device=dev)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            graph.replay()
+            torch.cuda.synchronize()
+            graph_note = f"one hipGraph of the {args.steps} steps (captured from the library's launches)"
+        except Exception as e:                                       # noqa: BLE001 -- any failure: time the enqueue loop
+            graph, graph_note = None, f"steps enqueued one by one (graph capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
     spun = 0
     if args.spinup_ms > 0:
         torch.cuda.synchronize()
@@ -708,13 +736,24 @@ def main() -> None:
     # the timed region holds the K steps and nothing else (until round 5 two HIP event records sat inside it for the gpu_ms diagnostic:
     # 0.3-0.6 us per step of a 20-step region, tools/steps20_probe.py -- that diagnostic is now taken from a second, untimed pass)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    enq_ms = None
+    if graph is not None:                                           # the same K steps enqueued one by one (diagnostic, untimed for `value`)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        enq_ms = (time.perf_counter() - t1) / args.steps * 1e3
     ev = HipEvents(2)
     ev.record(0, stream)
     for _ in range(args.steps):
@@ -843,7 +882,7 @@ def main() -> None:
                        "frames_per_gpu": frames_per_rank, "parallelism": f"time-chunk x{world}",
                        "step": "K_A + K_B -> RGBA8 columns; line results and the decay end state are not requested in the timed step "
                                "(the image does not depend on them; ms_per_step_with_state times the step that writes them)",
-                       "shard_impl": shard_note,
+                       "shard_impl": shard_note, "timed_region": graph_note,
                        "gpu_ms_per_step_rank0": gpu_ms / args.steps, "single_shot_ms": single_shot_ms,
                        "collectives_ms_per_step": coll_ms,
                        "input_rotation": {"buffers": len(timer._bufs), "mb": args.rotate_mb,
@@ -917,6 +956,9 @@ def main() -> None:
             out["pipelined"] = extra["pipelined"]
             if "value" in extra["pipelined"]:
                 out["value_pipelined"] = extra["pipelined"]["value"]
+        if enq_ms is not None:
+            out["ms_per_step_enqueued"] = enq_ms
+            out["value_enqueued"] = total_frames * pairs / (enq_ms * 1e-3)
         if "one_buffer" in extra:
             ob = extra["one_buffer"]
             out["value_one_buffer"] = total_frames * pairs / (ob["ms_per_step"] * 1e-3)
