@@ -183,9 +183,11 @@ sgz_status sgz_plan_reset_resonator(sgz_plan *plan, void *stream);
                                       weight as the exact sum of three bf16 parts, six part products (fp32-equivalent accuracy, twice as fast:
                                       resonator.hip resonateMfmaBf16Kernel) -- OPT-IN since round 6: on the MI355X boxes this was measured on, FFT
                                       kernels that run on the device at the same time (another stream, another process; this library's and
-                                      rocFFT's alike) come back with a wrong cache line's worth of values in 2 of 100 000 launches while this
-                                      kernel runs, and in every second launch with other instruction orders of the same kernel: choose it when
-                                      nothing else shares the device (NOTES.md, "A matrix-core kernel that disturbs its neighbours"); 0: the
+                                      rocFFT's alike) came back with a wrong cache line's worth of values in 2 of 100 000 launches while this
+                                      kernel ran in its round-4 form, and in every second launch with other instruction orders of the same
+                                      kernel; the form shipped now (four idle cycles behind every matrix instruction, the middle of a range
+                                      that was clean in 350 000 launches) showed none -- a measurement, not a guarantee: choose it when nothing
+                                      else shares the device (NOTES.md, "A matrix-core kernel that disturbs its neighbours"); 0: the
                                       vector-ALU block form everywhere (frame 0 of a launch then continues the carried state sample by sample) */
 #define SGZ_OPT_RESONATOR_SLAB 5u   /* RSNT: frames per slab of a long render (the per-frame resonator states between the kernels are held for one
                                       slab at a time; 0, the default: as many frames as fit 256 MiB).  A slab continues the state the one

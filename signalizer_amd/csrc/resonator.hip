@@ -188,12 +188,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SGZ_RES_UPW 4
 #endif
 constexpr unsigned kResUnitsPerWg = SGZ_RES_UPW;                     // units (frame, pair, signal) a workgroup of the bf16 form walks in a row
-#if defined(SGZ_RES_EXP_GAP)                                         // (platform experiment: idle issue slots behind every matrix instruction)
-#define SGZ_RES_SCHED_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" ::"n"(SGZ_RES_EXP_GAP)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif !defined(SGZ_RES_NO_SCHED)                                    // (timing / platform experiments: let the compiler order the tile loop)
-#define SGZ_RES_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
+// Behind every matrix instruction of the bf16 kernel: `s_nop SGZ_RES_EXP_GAP` (default 3 = 4 idle cycles) between two sched_barriers.
+// Round 6 (NOTES.md "A matrix-core kernel that disturbs its neighbours"): while this kernel runs, FFT kernels elsewhere on the device come
+// back with wrong cache lines -- rarely without the s_nop (1-4 of 24 000 launches), in 60 % of the launches with s_nop 9 ... 15 or in the
+// compiler's own order (-DSGZ_RES_NO_SCHED), and in NONE of 8 x 24 000 with s_nop 1 ... 7 (+3 ... +7 % of the render; profiles/r06g/
+// rsnt_gap_scan.txt).  The middle of the clean range is shipped; the kernel stays opt-in all the same (sgz.h SGZ_OPT_MATRIX_RESONATOR).
+#ifndef SGZ_RES_EXP_GAP
+#define SGZ_RES_EXP_GAP 3
+#endif
+#if defined(SGZ_RES_NO_SCHED)                                        // (platform experiment: let the compiler order the tile loop)
 #define SGZ_RES_SCHED_BARRIER() do { } while (0)
+#elif SGZ_RES_EXP_GAP >= 0
+#define SGZ_RES_SCHED_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" ::"n"(SGZ_RES_EXP_GAP)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else                                                               // (-DSGZ_RES_EXP_GAP=-1: rounds 4-5's stream, no idle cycles)
+#define SGZ_RES_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 #ifndef SGZ_RES_BF16_OCC
 #define SGZ_RES_BF16_OCC 3                                          // waves per SIMD the bf16 form is compiled for (168 registers)
