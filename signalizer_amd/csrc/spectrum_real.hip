@@ -513,6 +513,11 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
 #else
     constexpr bool TWFUSE = false;
 #endif
+#ifndef SGZ_LATE_DEAD_BARRIER
+    constexpr bool EARLYDEAD = TWFUSE && LR1 == 5;     // "the tiles are dead" barrier behind pass 3's table reads instead of behind the recombination (below)
+#else
+    constexpr bool EARLYDEAD = false;
+#endif
     if constexpr (LR1 >= 4 && !TWFUSE) {
         // times W_1024^{c_lo q2}: the whole table sits in LDS behind the exchange areas (copied at the start of the kernel) -- one
         // ds_read_b64 and one complex product per value, instead of 10 fetched rows and 21 products to build the other 21
@@ -570,6 +575,14 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
             else bflyPackedFusedTw<false>(c[2 * i], c[2 * i + R / 2], v2{wa.x, wa.y}, v2{wb.x, wb.y});
             bflyPackedFusedTw<false>(c[2 * i + 1], c[2 * i + 1 + R / 2], v2{wa.z, wa.w}, v2{wb.z, wb.w});
         }
+        // These were the workgroup's last reads of the exchange tiles and of the table: from here on |X| may overwrite them.  The barrier
+        // that says so stood behind the recombination until round 6, where every wave waited for the SLOWEST wave's recombination
+        // before its first store (phase clocks of the N = 65536 kernel: 3.6 k of a unit's 50 k clocks between the last wave's
+        // recombination and the magnitudes' barrier for 2 k clocks of stores).  Here the waves that arrive early wait while their SIMD
+        // is busy with the others' pass 2 anyway, and behind it every wave stores its magnitudes as soon as it has them: N = 65536
+        // (one workgroup per CU) -3.6 %; N = 32768, where a second workgroup fills such gaps, +0.3 ... +0.7 % -- so only there
+        // (tools/ab.sh, profiles/r06h/ab_early_barrier.txt).
+        if constexpr (EARLYDEAD) ldsBarrier();
         ditPacked<LR, 0, R, 2>(c);
     } else {
         ditPacked<LR, 0>(c);
@@ -688,7 +701,7 @@ __global__ void __launch_bounds__(1 << (LR1 + 5), 4) stftRealKernel(const RealPa
     // csf[N/2 - 1] *= 0.5 (quirk Q3, TransformDSP.inl:864): the left channel's bin M - 1 = the mirror of bin 1
     if (!MONO && side == 0 && q1 == 1 && ix == 0) magB[0] *= 0.5f;
     if constexpr (WALK) mapper.arrived(); else if constexpr (!EARLYTAB) mapper.prefetch(tb, tid);
-    ldsBarrier();                                                        // the tiles are dead: |X| may overwrite them
+    if constexpr (!EARLYDEAD) ldsBarrier();                              // the tiles are dead: |X| may overwrite them (EARLYDEAD: that barrier stands behind pass 3's table reads, above)
     {
         // left: bin k at position k; right: at position M - k (csf[N - k] = |X_R[k]|: csf order is ascending in LDS on both sides)
         // (two base addresses and compile-time offsets: a run-time stride costs a 64-bit multiply-add per store)
