@@ -24,6 +24,9 @@ CASES = {
     "rsnt hop 1000 (vector form)": dict(algorithm=cf.ALGO_RSNT, window_size=4096, hop=1000),
     "three pairs N=4096 (scan/emit K_B)": dict(window_size=4096, hop=1024, num_pairs=3),
     "fetch window blackman N=32768": dict(window_type=cf.WIN_BLACKMAN),
+    "real N=65536 mono merge": dict(window_size=65536, hop=16384, channel_mode=cf.CH_MERGE, sample_rate=96000.0),
+    "real N=65536 midside": dict(window_size=65536, hop=16384, channel_mode=cf.CH_MIDSIDE, sample_rate=96000.0),
+    "real N=65536 fetched window (blackman)": dict(window_size=65536, hop=16384, window_type=cf.WIN_BLACKMAN, sample_rate=96000.0),
     "rsnt segmented chain (fuzz 1005 / 12)": dict(_fuzz=(1005, 12)),
     "rsnt matrix worst case (fuzz 2008 / 52)": dict(_fuzz=(2008, 52)),
 }
